@@ -1,0 +1,322 @@
+/* pbdx.h -- C ABI of the MI355X-native PBD/XPBD constraint-projection engine.
+ *
+ * This is the drop-in boundary for ONE path of
+ * InteractiveComputerGraphics/PositionBasedDynamics: the inner solver loop of
+ * PBD::TimeStepController::step (reference Simulation/TimeStepController.cpp:75-241,
+ * positionConstraintProjection :251-295) plus the SimulationModel / ParticleData
+ * state it reads (Simulation/SimulationModel.h:138-263, Simulation/ParticleData.h:86-311).
+ *
+ * Plain pointers and sizes only; every function returns an int status
+ * (PBDX_OK == 0) unless documented otherwise; no exceptions cross the ABI; all
+ * host buffers are caller-owned; no global state except the thread-local
+ * last-error string.  All compute entry points run hand-written HIP kernels on
+ * gfx950 -- there is NO CPU fallback: without a GPU they return
+ * PBDX_ERR_NO_DEVICE.
+ *
+ * Three object kinds:
+ *   pbdx_solver   device engine: particle SoA + colour-batched constraint
+ *                 schedule + the substep loop.  This is what a reference-side
+ *                 TimeStep plug-in binds to.
+ *   pbdx_model    host-side mirror of PBD::SimulationModel for particle
+ *                 scenes (mesh builders, add*Constraint, greedy colouring) so
+ *                 that scenes can be built without the reference.
+ *   pbdx_timestep host-side mirror of PBD::TimeStepController (same parameter
+ *                 names and defaults) driving a pbdx_solver from a pbdx_model.
+ */
+#ifndef PBDX_H
+#define PBDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBDX_VERSION 100
+
+/* ---- status codes ------------------------------------------------------ */
+enum {
+	PBDX_OK = 0,
+	PBDX_ERR_INVALID = 1,      /* bad argument / bad state */
+	PBDX_ERR_NO_DEVICE = 2,    /* no HIP device (engine never falls back to CPU) */
+	PBDX_ERR_HIP = 3,          /* a HIP runtime call failed; see pbdx_last_error() */
+	PBDX_ERR_UNSUPPORTED = 4,  /* constraint type not handled by the engine */
+	PBDX_ERR_ALLOC = 5
+};
+
+/* ---- constraint types on the path --------------------------------------
+ * One enumerator per particle constraint class of the reference
+ * (Simulation/Constraints.h:255-491).  The reference's own TYPE_IDs are
+ * run-time counters (Simulation/Constraints.cpp:17-49), so a binding maps
+ * `X::TYPE_ID` -> these values; never hard-code the reference ids.
+ *
+ * Host parameter record (floats per constraint, `param_stride`), matrices in
+ * Eigen's default column-major order M(r,c) -> [c*rows + r]:
+ *   DISTANCE, DISTANCE_XPBD        [restLength, stiffness]                              2
+ *   DIHEDRAL                       [restAngle, stiffness]                               2
+ *   ISOMETRIC_BENDING(_XPBD)       [stiffness, Q(4x4)]                                  17
+ *   FEM_TRIANGLE                   [area, invRestMat(2x2), xx, yy, xy, xyPoisson, yxPoisson]  10
+ *   STRAIN_TRIANGLE                [invRestMat(2x2), xx, yy, xy, normStretch, normShear]      9
+ *   VOLUME, VOLUME_XPBD            [restVolume, stiffness]                              2
+ *   FEM_TET, FEM_TET_XPBD          [volume, invRestMat(3x3), stiffness, poissonRatio]   12
+ *   STRAIN_TET                     [invRestMat(3x3), stretch, shear, normStretch, normShear]  13
+ *   SHAPE_MATCHING (4 particles)   [stiffness, restCm(3), x0(4x3), w(4), numClusters(4)]      24
+ * XPBD multipliers (m_lambda) are engine-owned and reset at iteration 0 of
+ * every substep (Simulation/Constraints.cpp:1241,1448,1725,1877).
+ */
+typedef enum pbdx_constraint_type {
+	PBDX_DISTANCE = 0,               /* DistanceConstraint               Constraints.cpp:1166-1206 */
+	PBDX_DISTANCE_XPBD = 1,          /* DistanceConstraint_XPBD          Constraints.cpp:1211-1258 */
+	PBDX_DIHEDRAL = 2,               /* DihedralConstraint               Constraints.cpp:1264-1339 */
+	PBDX_ISOMETRIC_BENDING = 3,      /* IsometricBendingConstraint       Constraints.cpp:1345-1402 */
+	PBDX_ISOMETRIC_BENDING_XPBD = 4, /* IsometricBendingConstraint_XPBD  Constraints.cpp:1407-1471 */
+	PBDX_FEM_TRIANGLE = 5,           /* FEMTriangleConstraint            Constraints.cpp:1476-1538 */
+	PBDX_STRAIN_TRIANGLE = 6,        /* StrainTriangleConstraint         Constraints.cpp:1544-1610 */
+	PBDX_VOLUME = 7,                 /* VolumeConstraint                 Constraints.cpp:1617-1680 */
+	PBDX_VOLUME_XPBD = 8,            /* VolumeConstraint_XPBD            Constraints.cpp:1686-1750 */
+	PBDX_FEM_TET = 9,                /* FEMTetConstraint                 Constraints.cpp:1755-1825 */
+	PBDX_FEM_TET_XPBD = 10,          /* XPBD_FEMTetConstraint            Constraints.cpp:1830-1906 */
+	PBDX_STRAIN_TET = 11,            /* StrainTetConstraint              Constraints.cpp:1912-1980 */
+	PBDX_SHAPE_MATCHING = 12,        /* ShapeMatchingConstraint (4 pts)  Constraints.cpp:1985-2028 */
+	PBDX_NUM_CONSTRAINT_TYPES = 13
+} pbdx_constraint_type;
+
+/* number of particles / floats per host parameter record of a type (0 if invalid) */
+uint32_t pbdx_type_num_bodies(int type);
+uint32_t pbdx_type_param_stride(int type);
+const char *pbdx_type_name(int type);
+
+/* velocity update (TimeStepController::ENUM_VUPDATE_*, TimeStepController.cpp:67-72) */
+enum { PBDX_VUPDATE_FIRST_ORDER = 0, PBDX_VUPDATE_SECOND_ORDER = 1 };
+
+/* thread-local description of the last failure ("" if none) */
+const char *pbdx_last_error(void);
+int pbdx_version(void);
+/* number of visible HIP devices (0 without a GPU; never fails) */
+int pbdx_device_count(void);
+
+/* ======================================================================== */
+/* pbdx_solver -- the device engine                                         */
+/* ======================================================================== */
+typedef struct pbdx_solver pbdx_solver;
+
+/* Create an engine on HIP device `device` with its own stream.
+ * Replaces: construction of PBD::TimeStepController (TimeStepController.cpp:23-32). */
+int pbdx_solver_create(pbdx_solver **out, int device);
+void pbdx_solver_destroy(pbdx_solver *s);
+
+/* Upload particle state.  Arrays are packed xyz triples exactly as
+ * ParticleData's std::vector<Vector3r> (Simulation/ParticleData.h:91-100) in a
+ * float build; `mass`/`inv_mass` as m_masses/m_invMasses.  `v`, `old_x`,
+ * `last_x` may be NULL (=> 0, x, x).  Accelerations are not uploaded: the
+ * reference overwrites them with gravity for every dynamic particle at the
+ * start of each step (TimeStep::clearAccelerations, TimeStep.cpp:28-62).
+ * A particle is static iff mass == 0 (TimeIntegration.cpp:14). */
+int pbdx_solver_set_particles(pbdx_solver *s, uint32_t n,
+	const float *x, const float *v, const float *old_x, const float *last_x,
+	const float *mass, const float *inv_mass);
+/* Overwrite positions only (n must match); used for teacher-forced parity. */
+int pbdx_solver_set_positions(pbdx_solver *s, uint32_t n, const float *x);
+
+/* Download state; any pointer may be NULL.  Synchronises the engine stream. */
+int pbdx_solver_get_particles(pbdx_solver *s, uint32_t n,
+	float *x, float *v, float *old_x, float *last_x);
+
+/* Constraint schedule = the reference's colour groups
+ * (SimulationModel::getConstraintGroups(), SimulationModel.cpp:1033-1094).
+ * begin -> add_batch* -> end.  `group` is the colour index: groups execute in
+ * increasing order each iteration (Gauss-Seidel across colours,
+ * TimeStepController.cpp:270-286); batches of the same group touch disjoint
+ * particles and may run in any order.  `indices` holds count*num_bodies(type)
+ * particle indices (Constraint::m_bodies order), `params` count*param_stride
+ * floats laid out as documented above.  Order inside a batch is kept. */
+int pbdx_solver_begin_schedule(pbdx_solver *s);
+int pbdx_solver_add_batch(pbdx_solver *s, uint32_t group, int type, uint32_t count,
+	const uint32_t *indices, const float *params, uint32_t param_stride);
+int pbdx_solver_end_schedule(pbdx_solver *s);
+/* Debug validator: every group's batches touch pairwise-disjoint particles
+ * (the invariant data-race freedom rests on).  Returns PBDX_OK or PBDX_ERR_INVALID. */
+int pbdx_solver_validate_schedule(pbdx_solver *s);
+
+/* Advance `num_steps` full time steps of size h, device-resident (no host
+ * transfers).  One step == TimeStepController::step for a particle scene:
+ *   a_i = gravity (dynamic particles); hs = h/sub_steps;
+ *   repeat sub_steps: integrate -> max_iterations x (groups in order) -> velocity update.
+ * Replaces TimeStepController.cpp:75-176 + positionConstraintProjection :251-295. */
+int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_iterations,
+	int velocity_update_method, const float gravity[3], uint32_t num_steps);
+/* Run only the projection loop of ONE substep on the current positions (no
+ * integrate / velocity update): `iterations` Gauss-Seidel sweeps, lambda reset
+ * at sweep 0, XPBD dt = h_sub.  Used by known-answer tests. */
+int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations);
+int pbdx_solver_synchronize(pbdx_solver *s);
+
+/* XPBD multipliers of batch `batch_index` (order of add_batch calls). */
+int pbdx_solver_get_lambdas(pbdx_solver *s, uint32_t batch_index, uint32_t count, float *out);
+
+/* Launch options. */
+enum {
+	PBDX_OPT_USE_GRAPH = 1,        /* capture one substep into a hipGraph (default 1) */
+	PBDX_OPT_BLOCK_SIZE = 2,       /* threads per workgroup for projection kernels (default 256) */
+	PBDX_OPT_SORT_BATCHES = 3,     /* reorder constraints inside a batch for locality (default 0; results invariant) */
+	PBDX_OPT_FUSE_GROUPS = 4       /* one launch per colour group even if it mixes types (default 1) */
+};
+int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
+
+/* Timing of the last pbdx_solver_step call measured with HIP events on the
+ * engine's own stream: total milliseconds, and (if profile_kernels was set)
+ * accumulated milliseconds + launch count of the projection kernels only. */
+typedef struct pbdx_step_stats {
+	double total_ms;            /* whole pbdx_solver_step call on the stream */
+	double projection_ms;       /* sum over projection launches (profiled mode only, else 0) */
+	uint64_t projection_launches;
+	uint64_t projections;       /* constraint projections executed */
+	uint64_t kernel_launches;   /* all launches (integrate + projection + velocity) */
+	uint64_t algorithmic_bytes; /* SURVEY 8d bytes: sum_type count*bytes_per_projection*iters + particles*140 */
+} pbdx_step_stats;
+int pbdx_solver_get_stats(pbdx_solver *s, pbdx_step_stats *out);
+/* profile_kernels != 0: bracket every projection launch with HIP events (no graph). */
+int pbdx_solver_set_profiling(pbdx_solver *s, int profile_kernels);
+/* SURVEY 8d algorithmic bytes per projection of a type. */
+uint32_t pbdx_type_algorithmic_bytes(int type);
+/* Device / engine description for logs (device name, CU count, schedule size). */
+int pbdx_solver_describe(pbdx_solver *s, char *buf, size_t buf_size);
+
+/* ======================================================================== */
+/* pbdx_model -- host mirror of PBD::SimulationModel (particle scenes)      */
+/* ======================================================================== */
+typedef struct pbdx_model pbdx_model;
+
+int pbdx_model_create(pbdx_model **out);   /* SimulationModel::SimulationModel + init */
+void pbdx_model_destroy(pbdx_model *m);
+int pbdx_model_cleanup(pbdx_model *m);     /* SimulationModel::cleanup  SimulationModel.cpp:105-126 */
+int pbdx_model_reset(pbdx_model *m);       /* SimulationModel::reset    SimulationModel.cpp:270-304 */
+
+/* Mesh builders.  Return the model index (>=0) or -1.
+ * addRegularTriangleModel SimulationModel.cpp:831-901; rotation is a row-major 3x3. */
+int pbdx_model_add_regular_triangle_model(pbdx_model *m, int width, int height,
+	const float translation[3], const float rotation[9], const float scale[2]);
+/* addTriangleModel SimulationModel.cpp:806-829 (no UVs: rendering only). */
+int pbdx_model_add_triangle_model(pbdx_model *m, uint32_t n_points, uint32_t n_faces,
+	const float *points, const uint32_t *indices);
+/* addRegularTetModel SimulationModel.cpp:921-1005 */
+int pbdx_model_add_regular_tet_model(pbdx_model *m, int width, int height, int depth,
+	const float translation[3], const float rotation[9], const float scale[3]);
+/* addTetModel SimulationModel.cpp:903-919 */
+int pbdx_model_add_tet_model(pbdx_model *m, uint32_t n_points, uint32_t n_tets,
+	const float *points, const uint32_t *indices);
+
+/* Mesh topology queries (Utils/IndexedFaceMesh.cpp:118-226, IndexedTetMesh.cpp:55-182). */
+uint32_t pbdx_model_num_triangle_models(const pbdx_model *m);
+uint32_t pbdx_model_num_tet_models(const pbdx_model *m);
+uint32_t pbdx_model_triangle_model_index_offset(const pbdx_model *m, uint32_t tm);
+uint32_t pbdx_model_tet_model_index_offset(const pbdx_model *m, uint32_t tm);
+uint32_t pbdx_model_triangle_model_num_edges(const pbdx_model *m, uint32_t tm);
+/* out: num_edges * 4 values (vert0, vert1, face0, face1), 0xffffffff = no face */
+int pbdx_model_triangle_model_get_edges(const pbdx_model *m, uint32_t tm, uint32_t *out);
+uint32_t pbdx_model_tet_model_num_edges(const pbdx_model *m, uint32_t tm);
+int pbdx_model_tet_model_get_edges(const pbdx_model *m, uint32_t tm, uint32_t *out); /* num_edges*2 */
+
+/* ParticleData accessors (Simulation/ParticleData.h:139-260). */
+uint32_t pbdx_model_num_particles(const pbdx_model *m);
+int pbdx_model_add_vertex(pbdx_model *m, const float x[3]);            /* ParticleData::addVertex */
+int pbdx_model_set_mass(pbdx_model *m, uint32_t i, float mass);        /* setMass keeps invMass in sync :239-246 */
+/* which: 0=x 1=x0 2=v 3=a 4=oldX 5=lastX (xyz triples); 6=mass 7=invMass (scalars) */
+int pbdx_model_get_array(const pbdx_model *m, int which, float *out);
+int pbdx_model_set_array(pbdx_model *m, int which, const float *in);
+/* zero-copy pointer to the packed position array (pypbd getVertices analogue) */
+float *pbdx_model_positions_ptr(pbdx_model *m);
+
+/* Per-constraint builders (SimulationModel.cpp:565-806); return 1 on success, 0 if
+ * the reference's initConstraint would have returned false. */
+int pbdx_model_add_distance_constraint(pbdx_model *m, uint32_t p1, uint32_t p2, float stiffness);
+int pbdx_model_add_distance_constraint_xpbd(pbdx_model *m, uint32_t p1, uint32_t p2, float stiffness);
+int pbdx_model_add_dihedral_constraint(pbdx_model *m, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, float stiffness);
+int pbdx_model_add_isometric_bending_constraint(pbdx_model *m, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, float stiffness);
+int pbdx_model_add_isometric_bending_constraint_xpbd(pbdx_model *m, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, float stiffness);
+int pbdx_model_add_fem_triangle_constraint(pbdx_model *m, uint32_t p1, uint32_t p2, uint32_t p3,
+	float xx, float yy, float xy, float xy_poisson, float yx_poisson);
+int pbdx_model_add_strain_triangle_constraint(pbdx_model *m, uint32_t p1, uint32_t p2, uint32_t p3,
+	float xx, float yy, float xy, int normalize_stretch, int normalize_shear);
+int pbdx_model_add_volume_constraint(pbdx_model *m, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, float stiffness);
+int pbdx_model_add_volume_constraint_xpbd(pbdx_model *m, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, float stiffness);
+int pbdx_model_add_fem_tet_constraint(pbdx_model *m, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, float stiffness, float poisson);
+int pbdx_model_add_fem_tet_constraint_xpbd(pbdx_model *m, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, float stiffness, float poisson);
+int pbdx_model_add_strain_tet_constraint(pbdx_model *m, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4,
+	float stretch, float shear, int normalize_stretch, int normalize_shear);
+int pbdx_model_add_shape_matching_constraint(pbdx_model *m, uint32_t n, const uint32_t *particles,
+	const uint32_t *num_clusters, float stiffness);   /* n must be 4 */
+
+/* Bulk builders: addClothConstraints :1125-1184 (method 1 distance, 2 FEM tri,
+ * 3 strain tri, 4 XPBD distance), addBendingConstraints :1186-1240 (1 dihedral,
+ * 2 isometric, 3 isometric XPBD), addSolidConstraints :1242-1349 (1 distance+
+ * volume, 2 FEM tet, 3 XPBD FEM tet, 4 strain tet, 5 shape matching, 6 XPBD
+ * distance+volume). */
+int pbdx_model_add_cloth_constraints(pbdx_model *m, uint32_t tri_model, uint32_t method,
+	float distance_stiffness, float xx, float yy, float xy, float xy_poisson, float yx_poisson,
+	int normalize_stretch, int normalize_shear);
+int pbdx_model_add_bending_constraints(pbdx_model *m, uint32_t tri_model, uint32_t method, float stiffness);
+int pbdx_model_add_solid_constraints(pbdx_model *m, uint32_t tet_model, uint32_t method,
+	float stiffness, float poisson, float volume_stiffness, int normalize_stretch, int normalize_shear);
+
+/* Constraint inspection. */
+uint32_t pbdx_model_num_constraints(const pbdx_model *m);
+int pbdx_model_constraint_type(const pbdx_model *m, uint32_t c);            /* pbdx_constraint_type */
+int pbdx_model_constraint_bodies(const pbdx_model *m, uint32_t c, uint32_t *out); /* num_bodies values */
+int pbdx_model_constraint_params(const pbdx_model *m, uint32_t c, float *out);    /* param_stride values */
+int pbdx_model_set_constraint_params(pbdx_model *m, uint32_t c, const float *in); /* python-mutable fields */
+
+/* Greedy first-fit colouring in creation order; cached until the next add*
+ * (SimulationModel::initConstraintGroups, SimulationModel.cpp:1033-1094). */
+int pbdx_model_init_constraint_groups(pbdx_model *m);
+int pbdx_model_groups_initialized(const pbdx_model *m);   /* m_groupsInitialized */
+uint32_t pbdx_model_num_groups(const pbdx_model *m);
+uint32_t pbdx_model_group_size(const pbdx_model *m, uint32_t g);
+int pbdx_model_get_group(const pbdx_model *m, uint32_t g, uint32_t *out);
+
+/* ======================================================================== */
+/* pbdx_timestep -- host mirror of PBD::TimeStepController                  */
+/* ======================================================================== */
+typedef struct pbdx_timestep pbdx_timestep;
+
+/* Parameter ids; names mirror TimeStepController.cpp:47-72 so json scenes /
+ * python setValueUInt keep their meaning.  Defaults subSteps=5, maxIterations=1,
+ * maxIterationsV=5, velocityUpdateMethod=0 (TimeStepController.cpp:23-32). */
+enum {
+	PBDX_TS_NUM_SUB_STEPS = 0,          /* "subSteps" */
+	PBDX_TS_MAX_ITERATIONS = 1,         /* "maxIterations" */
+	PBDX_TS_MAX_ITERATIONS_V = 2,       /* "maxIterationsV" (no particle velocity constraints on this path) */
+	PBDX_TS_VELOCITY_UPDATE_METHOD = 3  /* "velocityUpdateMethod" */
+};
+
+int pbdx_timestep_create(pbdx_timestep **out, int device);
+void pbdx_timestep_destroy(pbdx_timestep *ts);
+int pbdx_timestep_set_param(pbdx_timestep *ts, int id, int64_t value);
+int64_t pbdx_timestep_get_param(const pbdx_timestep *ts, int id);
+const char *pbdx_timestep_param_name(int id);
+int pbdx_timestep_set_gravity(pbdx_timestep *ts, const float g[3]);     /* Simulation::GRAVITATION, Simulation.cpp:16 */
+int pbdx_timestep_set_time_step_size(pbdx_timestep *ts, float h);       /* TimeManager::setTimeStepSize, default 0.005 */
+float pbdx_timestep_get_time_step_size(const pbdx_timestep *ts);
+float pbdx_timestep_get_time(const pbdx_timestep *ts);                  /* TimeManager::getTime */
+int pbdx_timestep_reset(pbdx_timestep *ts);                             /* TimeStepController::reset + time=0 */
+
+/* TimeStep::step(model) semantics: host ParticleData in -> one full step on
+ * the device -> host ParticleData out (x, v, oldX, lastX, a).  The device image
+ * (particles + packed colour schedule) is rebuilt when the model's topology
+ * changed (groups re-initialised, particle/constraint count changed) or after
+ * pbdx_timestep_invalidate(). */
+int pbdx_timestep_step(pbdx_timestep *ts, pbdx_model *m);
+/* Device-resident variant: uploads only if the image is stale, runs
+ * `num_steps` steps without touching host memory; pbdx_timestep_sync_to_host
+ * writes the state back into the model. */
+int pbdx_timestep_step_resident(pbdx_timestep *ts, pbdx_model *m, uint32_t num_steps);
+int pbdx_timestep_sync_to_host(pbdx_timestep *ts, pbdx_model *m);
+int pbdx_timestep_invalidate(pbdx_timestep *ts);
+/* the engine underneath (owned by the timestep) */
+pbdx_solver *pbdx_timestep_solver(pbdx_timestep *ts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBDX_H */

@@ -1,0 +1,297 @@
+"""oracle/refdrv.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/_ref/libpbdref_{f32,f64,fast}.so: the *unmodified*
+reference (InteractiveComputerGraphics/PositionBasedDynamics) compiled from
+/root/reference by oracle/Makefile plus the headless driver oracle/ref_driver.cpp.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  Each variant is loaded with RTLD_LOCAL into its own namespace so
+f32 and f64 can coexist in one process (the reference uses singletons).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(_HERE, "_ref")
+
+_u = C.c_uint
+_d = C.c_double
+_i = C.c_int
+_pd = C.POINTER(C.c_double)
+_pu = C.POINTER(C.c_uint)
+
+
+def available(variant="f32"):
+    return os.path.exists(os.path.join(REF_DIR, "libpbdref_%s.so" % variant))
+
+
+def _dp(a):
+    return a.ctypes.data_as(_pd)
+
+
+def _up(a):
+    return a.ctypes.data_as(_pu)
+
+
+class Ref:
+    """One loaded build of the reference (variant in {'f32','f64','fast'})."""
+
+    _cache = {}
+
+    def __new__(cls, variant="f32"):
+        if variant in cls._cache:
+            return cls._cache[variant]
+        self = super().__new__(cls)
+        path = os.path.join(REF_DIR, "libpbdref_%s.so" % variant)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path + " (run `make -C oracle ref` where /root/reference exists)")
+        self.variant = variant
+        self.lib = lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+        lib.refdrv_get_time_step_size.restype = _d
+        lib.refdrv_get_time.restype = _d
+        lib.refdrv_time_steps.restype = _d
+        lib.refdrv_constraint_lambda.restype = _d
+        lib.refdrv_set_time_step_size.argtypes = [_d]
+        lib.refdrv_set_gravity.argtypes = [_d, _d, _d]
+        lib.refdrv_set_params.argtypes = [_u, _u, _i]
+        lib.refdrv_set_mass.argtypes = [_u, _d]
+        lib.refdrv_add_regular_triangle_model.argtypes = [_i, _i, _pd, _pd, _pd]
+        lib.refdrv_add_regular_tet_model.argtypes = [_i, _i, _i, _pd, _pd, _pd]
+        lib.refdrv_add_triangle_model.argtypes = [_u, _u, _pd, _pu]
+        lib.refdrv_add_tet_model.argtypes = [_u, _u, _pd, _pu]
+        lib.refdrv_add_vertex.argtypes = [_pd]
+        lib.refdrv_add_cloth_constraints.argtypes = [_u, _u, _d, _d, _d, _d, _d, _d, _i, _i]
+        lib.refdrv_add_bending_constraints.argtypes = [_u, _u, _d]
+        lib.refdrv_add_solid_constraints.argtypes = [_u, _u, _d, _d, _d, _i, _i]
+        lib.refdrv_add_distance_constraint.argtypes = [_u, _u, _d]
+        lib.refdrv_add_distance_constraint_xpbd.argtypes = [_u, _u, _d]
+        lib.refdrv_add_dihedral_constraint.argtypes = [_u, _u, _u, _u, _d]
+        lib.refdrv_add_isometric_bending_constraint.argtypes = [_u, _u, _u, _u, _d]
+        lib.refdrv_add_isometric_bending_constraint_xpbd.argtypes = [_u, _u, _u, _u, _d]
+        lib.refdrv_add_fem_triangle_constraint.argtypes = [_u, _u, _u, _d, _d, _d, _d, _d]
+        lib.refdrv_add_strain_triangle_constraint.argtypes = [_u, _u, _u, _d, _d, _d, _i, _i]
+        lib.refdrv_add_volume_constraint.argtypes = [_u, _u, _u, _u, _d]
+        lib.refdrv_add_volume_constraint_xpbd.argtypes = [_u, _u, _u, _u, _d]
+        lib.refdrv_add_fem_tet_constraint.argtypes = [_u, _u, _u, _u, _d, _d]
+        lib.refdrv_add_fem_tet_constraint_xpbd.argtypes = [_u, _u, _u, _u, _d, _d]
+        lib.refdrv_add_strain_tet_constraint.argtypes = [_u, _u, _u, _u, _d, _d, _i, _i]
+        lib.refdrv_add_shape_matching_constraint.argtypes = [_u, _pu, _pu, _d]
+        lib.refdrv_get_array.argtypes = [_i, _pd]
+        lib.refdrv_set_array.argtypes = [_i, _pd]
+        lib.refdrv_triangle_model_get_edges.argtypes = [_u, _pu]
+        lib.refdrv_tet_model_get_edges.argtypes = [_u, _pu]
+        lib.refdrv_constraint_bodies.argtypes = [_u, _pu]
+        lib.refdrv_constraint_params.argtypes = [_u, _pd]
+        lib.refdrv_get_group.argtypes = [_u, _pu]
+        lib.refdrv_install_timestep_plugin.argtypes = [C.c_char_p, C.c_char_p]
+        cls._cache[variant] = self
+        return self
+
+    # -- lifecycle -----------------------------------------------------------
+    def reset_all(self):
+        self.lib.refdrv_reset_all()
+
+    @property
+    def real_size(self):
+        return self.lib.refdrv_real_size()
+
+    def set_num_threads(self, n):
+        self.lib.refdrv_set_num_threads(int(n))
+
+    def max_threads(self):
+        return self.lib.refdrv_max_threads()
+
+    def set_time_step_size(self, h):
+        self.lib.refdrv_set_time_step_size(float(h))
+
+    def set_gravity(self, g):
+        self.lib.refdrv_set_gravity(float(g[0]), float(g[1]), float(g[2]))
+
+    def set_params(self, sub_steps, max_iter, vel_method=0):
+        self.lib.refdrv_set_params(int(sub_steps), int(max_iter), int(vel_method))
+
+    # -- meshes ---------------------------------------------------------------
+    def add_regular_triangle_model(self, w, h, T=(0, 0, 0), R=None, scale=(1, 1)):
+        T = np.asarray(T, dtype=np.float64)
+        R = np.eye(3) if R is None else np.ascontiguousarray(R, dtype=np.float64)
+        s = np.asarray(scale, dtype=np.float64)
+        return self.lib.refdrv_add_regular_triangle_model(int(w), int(h), _dp(T), _dp(R), _dp(s))
+
+    def add_regular_tet_model(self, w, h, d, T=(0, 0, 0), R=None, scale=(1, 1, 1)):
+        T = np.asarray(T, dtype=np.float64)
+        R = np.eye(3) if R is None else np.ascontiguousarray(R, dtype=np.float64)
+        s = np.asarray(scale, dtype=np.float64)
+        return self.lib.refdrv_add_regular_tet_model(int(w), int(h), int(d), _dp(T), _dp(R), _dp(s))
+
+    def add_triangle_model(self, points, faces):
+        p = np.ascontiguousarray(points, dtype=np.float64)
+        f = np.ascontiguousarray(faces, dtype=np.uint32)
+        return self.lib.refdrv_add_triangle_model(len(p), len(f), _dp(p), _up(f))
+
+    def add_tet_model(self, points, tets):
+        p = np.ascontiguousarray(points, dtype=np.float64)
+        t = np.ascontiguousarray(tets, dtype=np.uint32)
+        return self.lib.refdrv_add_tet_model(len(p), len(t), _dp(p), _up(t))
+
+    def add_vertex(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        return self.lib.refdrv_add_vertex(_dp(x))
+
+    def set_mass(self, i, m):
+        self.lib.refdrv_set_mass(int(i), float(m))
+
+    def add_cloth_constraints(self, tm, method, k=1.0, xx=1.0, yy=1.0, xy=1.0, xyP=0.3, yxP=0.3, ns=False, nsh=False):
+        self.lib.refdrv_add_cloth_constraints(tm, method, k, xx, yy, xy, xyP, yxP, int(ns), int(nsh))
+
+    def add_bending_constraints(self, tm, method, k):
+        self.lib.refdrv_add_bending_constraints(tm, method, k)
+
+    def add_solid_constraints(self, tm, method, k=1.0, poisson=0.3, kv=1.0, ns=False, nsh=False):
+        self.lib.refdrv_add_solid_constraints(tm, method, k, poisson, kv, int(ns), int(nsh))
+
+    def add_constraint(self, type_name, bodies, *args):
+        """type_name as in the reference's add*: 'distance', 'distance_xpbd', 'dihedral', ..."""
+        fn = getattr(self.lib, "refdrv_add_%s_constraint" % type_name if not type_name.endswith("_xpbd")
+                     else "refdrv_add_%s_constraint_xpbd" % type_name[:-5])
+        if type_name == "shape_matching":
+            b = np.asarray(bodies, dtype=np.uint32)
+            nc = np.asarray(args[0], dtype=np.uint32)
+            return fn(len(b), _up(b), _up(nc), float(args[1]))
+        return fn(*[int(b) for b in bodies], *args)
+
+    # -- state -----------------------------------------------------------------
+    def num_particles(self):
+        return self.lib.refdrv_num_particles()
+
+    def get_array(self, which):
+        n = self.num_particles()
+        out = np.empty((n, 3) if which < 6 else (n,), dtype=np.float64)
+        self.lib.refdrv_get_array(which, _dp(out))
+        return out
+
+    def set_array(self, which, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self.lib.refdrv_set_array(which, _dp(a))
+
+    def positions(self):
+        return self.get_array(0)
+
+    # -- topology ---------------------------------------------------------------
+    def triangle_model_edges(self, tm):
+        n = self.lib.refdrv_triangle_model_num_edges(tm)
+        out = np.empty((n, 4), dtype=np.uint32)
+        self.lib.refdrv_triangle_model_get_edges(tm, _up(out))
+        return out
+
+    def tet_model_edges(self, tm):
+        n = self.lib.refdrv_tet_model_num_edges(tm)
+        out = np.empty((n, 2), dtype=np.uint32)
+        self.lib.refdrv_tet_model_get_edges(tm, _up(out))
+        return out
+
+    # -- constraints --------------------------------------------------------------
+    def num_constraints(self):
+        return self.lib.refdrv_num_constraints()
+
+    def constraint_types(self):
+        n = self.num_constraints()
+        return np.array([self.lib.refdrv_constraint_type(i) for i in range(n)], dtype=np.int32)
+
+    def constraint_bodies(self, c):
+        nb = self.lib.refdrv_constraint_num_bodies(c)
+        out = np.empty(nb, dtype=np.uint32)
+        self.lib.refdrv_constraint_bodies(c, _up(out))
+        return out
+
+    def constraint_params(self, c):
+        out = np.empty(32, dtype=np.float64)
+        n = self.lib.refdrv_constraint_params(c, _dp(out))
+        return out[:n].copy()
+
+    def constraint_lambda(self, c):
+        return self.lib.refdrv_constraint_lambda(c)
+
+    def groups(self):
+        ng = self.lib.refdrv_num_groups()
+        res = []
+        for g in range(ng):
+            n = self.lib.refdrv_group_size(g)
+            out = np.empty(n, dtype=np.uint32)
+            self.lib.refdrv_get_group(g, _up(out))
+            res.append(out)
+        return res
+
+    # -- stepping -------------------------------------------------------------------
+    def step(self, n=1):
+        self.lib.refdrv_step(int(n))
+
+    def time_steps(self, n=1):
+        return self.lib.refdrv_time_steps(int(n))
+
+    def solve_position_constraints(self, it=0, grouped=False):
+        if grouped:
+            self.lib.refdrv_solve_position_constraints_grouped(int(it))
+        else:
+            self.lib.refdrv_solve_position_constraints(int(it))
+
+    def model_reset(self):
+        self.lib.refdrv_model_reset()
+
+    def install_timestep_plugin(self, path, symbol="pbdx_create_timestep_hip"):
+        return self.lib.refdrv_install_timestep_plugin(path.encode(), symbol.encode())
+
+
+# ---------------------------------------------------------------------------
+# Scene definitions restated from the reference demos (deterministic, no RNG).
+# ---------------------------------------------------------------------------
+def rot_x_half_pi(dtype=np.float64):
+    """AngleAxisr(M_PI*0.5, (1,0,0)).matrix() (Demos/ClothDemo/main.cpp:136).
+
+    Eigen evaluates sin/cos of the angle in Real, so the float build has
+    cos = float(cos(float(pi/2))) = -4.371139e-08, not 0."""
+    a = dtype(np.pi * 0.5)
+    c = np.cos(a).astype(dtype) if hasattr(np.cos(a), "astype") else dtype(np.cos(a))
+    s = dtype(np.sin(a))
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float64)
+
+
+def build_cloth(sim, n_cols, n_rows, cloth_method, bending_method, cloth_k=None, bending_k=None,
+                width=10.0, height=10.0, T=(0, 1, 0), pin=True, R=None):
+    """Demos/ClothDemo/main.cpp:132-162 with nCols x nRows particles.
+
+    `sim` is any object with the Ref-like builder API (Ref or the product's
+    SimulationModel adapter in tests)."""
+    if R is None:
+        R = rot_x_half_pi(np.float32 if getattr(sim, "real_size", 4) == 4 else np.float64)
+    off = sim.num_particles()
+    tm = sim.add_regular_triangle_model(n_cols, n_rows, T, R, (width, height))
+    if pin:
+        sim.set_mass(off, 0.0)
+        sim.set_mass(off + n_rows - 1, 0.0)
+    if cloth_k is None:
+        cloth_k = 100000.0 if cloth_method == 4 else 1.0
+    if bending_k is None:
+        bending_k = 100.0 if bending_method == 3 else 0.01
+    if cloth_method:
+        sim.add_cloth_constraints(tm, cloth_method, cloth_k)
+    if bending_method:
+        sim.add_bending_constraints(tm, bending_method, bending_k)
+    return tm
+
+
+def build_bar(sim, width, height, depth, solid_method, k=None, kv=None, poisson=0.3,
+              T=(5, 0, 0), scale=(10.0, 1.5, 1.5), ns=False, nsh=False):
+    """Demos/BarDemo/main.cpp:130-166 with width x height x depth particles."""
+    off = sim.num_particles()
+    tm = sim.add_regular_tet_model(width, height, depth, T, None, scale)
+    for j in range(height):
+        for k_ in range(depth):
+            sim.set_mass(off + j * depth + k_, 0.0)
+    if k is None:
+        k = {3: 1000000.0, 6: 100000.0}.get(solid_method, 1.0)
+    if kv is None:
+        kv = 100000.0 if solid_method == 6 else 1.0
+    sim.add_solid_constraints(tm, solid_method, k, poisson, kv, ns, nsh)
+    return tm
