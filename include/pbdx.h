@@ -158,9 +158,8 @@ int pbdx_solver_get_lambdas(pbdx_solver *s, uint32_t batch_index, uint32_t count
 /* Launch options. */
 enum {
 	PBDX_OPT_USE_GRAPH = 1,        /* capture one substep into a hipGraph (default 1) */
-	PBDX_OPT_BLOCK_SIZE = 2,       /* threads per workgroup for projection kernels (default 256) */
-	PBDX_OPT_SORT_BATCHES = 3,     /* reorder constraints inside a batch for locality (default 0; results invariant) */
-	PBDX_OPT_FUSE_GROUPS = 4       /* one launch per colour group even if it mixes types (default 1) */
+	PBDX_OPT_BLOCK_SIZE = 2,       /* threads per workgroup for projection kernels: 64/128/256 (default 256) */
+	PBDX_OPT_XCD_REMAP = 3         /* XCD-aware blockIdx -> constraint-range mapping (default 0; results invariant) */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
 
@@ -178,6 +177,10 @@ typedef struct pbdx_step_stats {
 int pbdx_solver_get_stats(pbdx_solver *s, pbdx_step_stats *out);
 /* profile_kernels != 0: bracket every projection launch with HIP events (no graph). */
 int pbdx_solver_set_profiling(pbdx_solver *s, int profile_kernels);
+/* Per-constraint-type totals of the last profiled pbdx_solver_step: milliseconds summed over
+ * that type's launches (event before the launch -> event before the next launch), number of
+ * launches, number of projections. */
+int pbdx_solver_get_type_stats(pbdx_solver *s, int type, double *ms, uint64_t *launches, uint64_t *projections);
 /* SURVEY 8d algorithmic bytes per projection of a type. */
 uint32_t pbdx_type_algorithmic_bytes(int type);
 /* Device / engine description for logs (device name, CU count, schedule size). */
@@ -313,6 +316,10 @@ int pbdx_timestep_step(pbdx_timestep *ts, pbdx_model *m);
 int pbdx_timestep_step_resident(pbdx_timestep *ts, pbdx_model *m, uint32_t num_steps);
 int pbdx_timestep_sync_to_host(pbdx_timestep *ts, pbdx_model *m);
 int pbdx_timestep_invalidate(pbdx_timestep *ts);
+/* Known-answer / teacher-forced entry: upload the model's host state, run only the projection
+ * loop of one substep (`iterations` Gauss-Seidel sweeps over the colour groups, lambda reset at
+ * sweep 0, XPBD dt = h/subSteps), download positions.  No integration, no velocity update. */
+int pbdx_timestep_project(pbdx_timestep *ts, pbdx_model *m, uint32_t iterations);
 /* the engine underneath (owned by the timestep) */
 pbdx_solver *pbdx_timestep_solver(pbdx_timestep *ts);
 

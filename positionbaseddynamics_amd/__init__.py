@@ -1,0 +1,619 @@
+"""positionbaseddynamics_amd -- MI355X-native PBD/XPBD constraint-projection engine.
+
+Host-side mirror of the `pypbd` surface that sits on the hot path of
+InteractiveComputerGraphics/PositionBasedDynamics (reference pyPBD/*Module.cpp):
+`Simulation`, `SimulationModel`, `ParticleData`, `TimeManager`, `TimeStepController`
+with the reference's method names, argument meaning and defaults, so a script
+written for `pypbd` cloth / solid scenes runs unchanged apart from the import:
+
+    import positionbaseddynamics_amd as pbd
+    sim = pbd.Simulation.getCurrent(); sim.initDefault()
+    model = sim.getModel()
+    model.addRegularTriangleModel(50, 50, (0, 1, 0), R, (10, 10))
+    model.getParticles().setMass(0, 0.0)
+    model.addClothConstraints(model.getTriangleModels()[0], 4, 1e5, ...)
+    ts = sim.getTimeStep(); ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 10)
+    ts.step(model)
+
+Everything below is a thin shim over the C ABI (include/pbdx.h, libpbdx.so);
+all simulation arithmetic runs in hand-written HIP kernels on gfx950.  There is
+no CPU path: stepping without a GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import lib, check, PbdxError, StepStats  # noqa: F401
+
+__all__ = ["Simulation", "SimulationModel", "ParticleData", "TimeManager", "TimeStepController",
+           "TriangleModel", "TetModel", "Solver", "ConstraintType", "PbdxError", "device_count"]
+
+
+def device_count():
+    return lib.pbdx_device_count()
+
+
+def _f(a):
+    return a.ctypes.data_as(_ffi.pf)
+
+
+def _u(a):
+    return a.ctypes.data_as(_ffi.pu)
+
+
+def _vec(v, n):
+    a = np.ascontiguousarray(v, dtype=np.float32).reshape(-1)
+    if a.size != n:
+        raise ValueError("expected %d values" % n)
+    return a
+
+
+class ConstraintType:
+    """pbdx_constraint_type (include/pbdx.h)."""
+    DISTANCE, DISTANCE_XPBD, DIHEDRAL, ISOMETRIC_BENDING, ISOMETRIC_BENDING_XPBD, FEM_TRIANGLE, STRAIN_TRIANGLE, \
+        VOLUME, VOLUME_XPBD, FEM_TET, FEM_TET_XPBD, STRAIN_TET, SHAPE_MATCHING = range(13)
+    COUNT = 13
+
+    @staticmethod
+    def name(t):
+        return lib.pbdx_type_name(t).decode()
+
+    @staticmethod
+    def num_bodies(t):
+        return lib.pbdx_type_num_bodies(t)
+
+    @staticmethod
+    def param_stride(t):
+        return lib.pbdx_type_param_stride(t)
+
+    @staticmethod
+    def algorithmic_bytes(t):
+        return lib.pbdx_type_algorithmic_bytes(t)
+
+
+# --------------------------------------------------------------------------
+class TimeManager:
+    """PBD::TimeManager (Simulation/TimeManager.cpp): current time and step size h (default 0.005)."""
+    _current = None
+
+    def __init__(self):
+        self._h = np.float32(0.005)
+        self._time = np.float32(0.0)
+
+    @staticmethod
+    def getCurrent():
+        if TimeManager._current is None:
+            TimeManager._current = TimeManager()
+        return TimeManager._current
+
+    @staticmethod
+    def setCurrent(tm):
+        TimeManager._current = tm
+
+    @staticmethod
+    def hasCurrent():
+        return TimeManager._current is not None
+
+    def getTime(self):
+        return float(self._time)
+
+    def setTime(self, t):
+        self._time = np.float32(t)
+
+    def getTimeStepSize(self):
+        return float(self._h)
+
+    def setTimeStepSize(self, h):
+        self._h = np.float32(h)
+
+
+class ParticleData:
+    """PBD::ParticleData accessors (Simulation/ParticleData.h:139-260) over the model's host arrays."""
+
+    def __init__(self, model):
+        self._m = model
+
+    def _arr(self, which):
+        n = self.size()
+        out = np.empty((n, 3) if which < 6 else (n,), dtype=np.float32)
+        check(lib.pbdx_model_get_array(self._m._h, which, _f(out)), "pbdx_model_get_array")
+        return out
+
+    def _set(self, which, i, v):
+        a = self._arr(which)
+        a[i] = v
+        check(lib.pbdx_model_set_array(self._m._h, which, _f(np.ascontiguousarray(a))), "pbdx_model_set_array")
+
+    def size(self):
+        return lib.pbdx_model_num_particles(self._m._h)
+
+    getNumberOfParticles = size
+
+    def addVertex(self, x):
+        return lib.pbdx_model_add_vertex(self._m._h, _f(_vec(x, 3)))
+
+    def getPosition(self, i):
+        return self._arr(0)[i]
+
+    def setPosition(self, i, x):
+        self._set(0, i, x)
+
+    def getPosition0(self, i):
+        return self._arr(1)[i]
+
+    def setPosition0(self, i, x):
+        self._set(1, i, x)
+
+    def getVelocity(self, i):
+        return self._arr(2)[i]
+
+    def setVelocity(self, i, v):
+        self._set(2, i, v)
+
+    def getAcceleration(self, i):
+        return self._arr(3)[i]
+
+    def setAcceleration(self, i, a):
+        self._set(3, i, a)
+
+    def getMass(self, i):
+        return float(self._arr(6)[i])
+
+    def getInvMass(self, i):
+        return float(self._arr(7)[i])
+
+    def setMass(self, i, m):
+        check(lib.pbdx_model_set_mass(self._m._h, int(i), float(m)), "pbdx_model_set_mass")
+
+    def getVertices(self):
+        """Zero-copy view of the packed position array (pyPBD/ParticleDataModule.cpp:54-58)."""
+        n = self.size()
+        if n == 0:
+            return np.empty((0, 3), dtype=np.float32)
+        ptr = lib.pbdx_model_positions_ptr(self._m._h)
+        return np.ctypeslib.as_array(ptr, shape=(n, 3))
+
+    # bulk helpers (not in pypbd; used by tests / bench)
+    def positions(self):
+        return self._arr(0)
+
+    def velocities(self):
+        return self._arr(2)
+
+    def array(self, which):
+        return self._arr(which)
+
+    def set_array(self, which, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        check(lib.pbdx_model_set_array(self._m._h, which, _f(a)), "pbdx_model_set_array")
+
+
+class _MeshModel:
+    def __init__(self, model, index):
+        self._m = model
+        self._i = index
+
+
+class TriangleModel(_MeshModel):
+    def getIndexOffset(self):
+        return lib.pbdx_model_triangle_model_index_offset(self._m._h, self._i)
+
+    def getEdges(self):
+        n = lib.pbdx_model_triangle_model_num_edges(self._m._h, self._i)
+        out = np.empty((n, 4), dtype=np.uint32)
+        check(lib.pbdx_model_triangle_model_get_edges(self._m._h, self._i, _u(out)), "get_edges")
+        return out
+
+
+class TetModel(_MeshModel):
+    def getIndexOffset(self):
+        return lib.pbdx_model_tet_model_index_offset(self._m._h, self._i)
+
+    def getEdges(self):
+        n = lib.pbdx_model_tet_model_num_edges(self._m._h, self._i)
+        out = np.empty((n, 2), dtype=np.uint32)
+        check(lib.pbdx_model_tet_model_get_edges(self._m._h, self._i, _u(out)), "get_edges")
+        return out
+
+
+def _idx(tm):
+    return tm._i if isinstance(tm, _MeshModel) else int(tm)
+
+
+class SimulationModel:
+    """PBD::SimulationModel for particle scenes (pyPBD/SimulationModelModule.cpp:90-383)."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(lib.pbdx_model_create(C.byref(h)), "pbdx_model_create")
+        self._h = h
+        self._pd = ParticleData(self)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib.pbdx_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def init(self):
+        pass
+
+    def reset(self):
+        check(lib.pbdx_model_reset(self._h), "pbdx_model_reset")
+
+    def cleanup(self):
+        check(lib.pbdx_model_cleanup(self._h), "pbdx_model_cleanup")
+
+    def getParticles(self):
+        return self._pd
+
+    def getTriangleModels(self):
+        return [TriangleModel(self, i) for i in range(lib.pbdx_model_num_triangle_models(self._h))]
+
+    def getTetModels(self):
+        return [TetModel(self, i) for i in range(lib.pbdx_model_num_tet_models(self._h))]
+
+    # -- meshes --
+    def addRegularTriangleModel(self, width, height, translation=(0, 0, 0), rotation=None, scale=(1, 1)):
+        R = np.eye(3, dtype=np.float32) if rotation is None else np.ascontiguousarray(rotation, dtype=np.float32)
+        r = lib.pbdx_model_add_regular_triangle_model(self._h, int(width), int(height), _f(_vec(translation, 3)), _f(_vec(R, 9)), _f(_vec(scale, 2)))
+        if r < 0:
+            raise PbdxError(r, "addRegularTriangleModel")
+        return r
+
+    def addTriangleModel(self, points, indices):
+        p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        f = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        r = lib.pbdx_model_add_triangle_model(self._h, len(p), len(f), _f(p), _u(f))
+        if r < 0:
+            raise PbdxError(r, "addTriangleModel")
+        return r
+
+    def addRegularTetModel(self, width, height, depth, translation=(0, 0, 0), rotation=None, scale=(1, 1, 1)):
+        R = np.eye(3, dtype=np.float32) if rotation is None else np.ascontiguousarray(rotation, dtype=np.float32)
+        r = lib.pbdx_model_add_regular_tet_model(self._h, int(width), int(height), int(depth), _f(_vec(translation, 3)), _f(_vec(R, 9)), _f(_vec(scale, 3)))
+        if r < 0:
+            raise PbdxError(r, "addRegularTetModel")
+        return r
+
+    def addTetModel(self, points, indices):
+        p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 4)
+        r = lib.pbdx_model_add_tet_model(self._h, len(p), len(t), _f(p), _u(t))
+        if r < 0:
+            raise PbdxError(r, "addTetModel")
+        return r
+
+    # -- per-constraint builders (return bool like the reference) --
+    def addDistanceConstraint(self, p1, p2, stiffness):
+        return bool(lib.pbdx_model_add_distance_constraint(self._h, p1, p2, stiffness))
+
+    def addDistanceConstraint_XPBD(self, p1, p2, stiffness):
+        return bool(lib.pbdx_model_add_distance_constraint_xpbd(self._h, p1, p2, stiffness))
+
+    def addDihedralConstraint(self, p1, p2, p3, p4, stiffness):
+        return bool(lib.pbdx_model_add_dihedral_constraint(self._h, p1, p2, p3, p4, stiffness))
+
+    def addIsometricBendingConstraint(self, p1, p2, p3, p4, stiffness):
+        return bool(lib.pbdx_model_add_isometric_bending_constraint(self._h, p1, p2, p3, p4, stiffness))
+
+    def addIsometricBendingConstraint_XPBD(self, p1, p2, p3, p4, stiffness):
+        return bool(lib.pbdx_model_add_isometric_bending_constraint_xpbd(self._h, p1, p2, p3, p4, stiffness))
+
+    def addFEMTriangleConstraint(self, p1, p2, p3, xx, yy, xy, xyPoisson, yxPoisson):
+        return bool(lib.pbdx_model_add_fem_triangle_constraint(self._h, p1, p2, p3, xx, yy, xy, xyPoisson, yxPoisson))
+
+    def addStrainTriangleConstraint(self, p1, p2, p3, xx, yy, xy, normalizeStretch, normalizeShear):
+        return bool(lib.pbdx_model_add_strain_triangle_constraint(self._h, p1, p2, p3, xx, yy, xy, int(normalizeStretch), int(normalizeShear)))
+
+    def addVolumeConstraint(self, p1, p2, p3, p4, stiffness):
+        return bool(lib.pbdx_model_add_volume_constraint(self._h, p1, p2, p3, p4, stiffness))
+
+    def addVolumeConstraint_XPBD(self, p1, p2, p3, p4, stiffness):
+        return bool(lib.pbdx_model_add_volume_constraint_xpbd(self._h, p1, p2, p3, p4, stiffness))
+
+    def addFEMTetConstraint(self, p1, p2, p3, p4, stiffness, poissonRatio):
+        return bool(lib.pbdx_model_add_fem_tet_constraint(self._h, p1, p2, p3, p4, stiffness, poissonRatio))
+
+    def addFEMTetConstraint_XPBD(self, p1, p2, p3, p4, stiffness, poissonRatio):
+        return bool(lib.pbdx_model_add_fem_tet_constraint_xpbd(self._h, p1, p2, p3, p4, stiffness, poissonRatio))
+
+    def addStrainTetConstraint(self, p1, p2, p3, p4, stretch, shear, normalizeStretch, normalizeShear):
+        return bool(lib.pbdx_model_add_strain_tet_constraint(self._h, p1, p2, p3, p4, stretch, shear, int(normalizeStretch), int(normalizeShear)))
+
+    def addShapeMatchingConstraint(self, numberOfParticles, particleIndices, numClusters, stiffness):
+        p = np.ascontiguousarray(particleIndices, dtype=np.uint32)
+        nc = np.ascontiguousarray(numClusters, dtype=np.uint32)
+        return bool(lib.pbdx_model_add_shape_matching_constraint(self._h, int(numberOfParticles), _u(p), _u(nc), stiffness))
+
+    # -- bulk builders --
+    def addClothConstraints(self, tm, clothMethod, distanceStiffness=1.0, xxStiffness=1.0, yyStiffness=1.0, xyStiffness=1.0,
+                            xyPoissonRatio=0.3, yxPoissonRatio=0.3, normalizeStretch=False, normalizeShear=False):
+        check(lib.pbdx_model_add_cloth_constraints(self._h, _idx(tm), clothMethod, distanceStiffness, xxStiffness, yyStiffness, xyStiffness,
+                                                   xyPoissonRatio, yxPoissonRatio, int(normalizeStretch), int(normalizeShear)), "addClothConstraints")
+
+    def addBendingConstraints(self, tm, bendingMethod, stiffness):
+        check(lib.pbdx_model_add_bending_constraints(self._h, _idx(tm), bendingMethod, stiffness), "addBendingConstraints")
+
+    def addSolidConstraints(self, tm, solidMethod, stiffness=1.0, poissonRatio=0.3, volumeStiffness=1.0,
+                            normalizeStretch=False, normalizeShear=False):
+        check(lib.pbdx_model_add_solid_constraints(self._h, _idx(tm), solidMethod, stiffness, poissonRatio, volumeStiffness,
+                                                   int(normalizeStretch), int(normalizeShear)), "addSolidConstraints")
+
+    # -- constraints / colouring --
+    def numConstraints(self):
+        return lib.pbdx_model_num_constraints(self._h)
+
+    def constraintTypes(self):
+        n = self.numConstraints()
+        return np.array([lib.pbdx_model_constraint_type(self._h, i) for i in range(n)], dtype=np.int32)
+
+    def constraintBodies(self, c):
+        nb = ConstraintType.num_bodies(lib.pbdx_model_constraint_type(self._h, c))
+        out = np.empty(nb, dtype=np.uint32)
+        check(lib.pbdx_model_constraint_bodies(self._h, c, _u(out)), "constraint_bodies")
+        return out
+
+    def constraintParams(self, c):
+        ns = ConstraintType.param_stride(lib.pbdx_model_constraint_type(self._h, c))
+        out = np.empty(ns, dtype=np.float32)
+        check(lib.pbdx_model_constraint_params(self._h, c, _f(out)), "constraint_params")
+        return out
+
+    def setConstraintParams(self, c, params):
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        check(lib.pbdx_model_set_constraint_params(self._h, c, _f(p)), "set_constraint_params")
+
+    def initConstraintGroups(self):
+        check(lib.pbdx_model_init_constraint_groups(self._h), "initConstraintGroups")
+
+    def getConstraintGroups(self):
+        self.initConstraintGroups()
+        res = []
+        for g in range(lib.pbdx_model_num_groups(self._h)):
+            out = np.empty(lib.pbdx_model_group_size(self._h, g), dtype=np.uint32)
+            check(lib.pbdx_model_get_group(self._h, g, _u(out)), "get_group")
+            res.append(out)
+        return res
+
+
+class TimeStepController:
+    """PBD::TimeStepController (Simulation/TimeStepController.cpp) running on the GPU engine.
+
+    Parameter ids are the class attributes below; `setValueUInt/Int`, `getValueUInt/Int`
+    follow GenParam::ParameterObject as exposed by pyPBD/ParameterObjectModule.cpp:17-30.
+    """
+    NUM_SUB_STEPS = 0
+    MAX_ITERATIONS = 1
+    MAX_ITERATIONS_V = 2
+    VELOCITY_UPDATE_METHOD = 3
+    ENUM_VUPDATE_FIRST_ORDER = 0
+    ENUM_VUPDATE_SECOND_ORDER = 1
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        check(lib.pbdx_timestep_create(C.byref(h), int(device)), "pbdx_timestep_create")
+        self._h = h
+        self._sim = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib.pbdx_timestep_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def init(self):
+        pass
+
+    def reset(self):
+        check(lib.pbdx_timestep_reset(self._h), "pbdx_timestep_reset")
+
+    def setValueUInt(self, pid, v):
+        check(lib.pbdx_timestep_set_param(self._h, pid, int(v)), "setValue")
+
+    setValueInt = setValueUInt
+
+    def getValueUInt(self, pid):
+        return int(lib.pbdx_timestep_get_param(self._h, pid))
+
+    getValueInt = getValueUInt
+
+    def _sync_globals(self):
+        tm = TimeManager.getCurrent()
+        check(lib.pbdx_timestep_set_time_step_size(self._h, float(tm._h)), "set_time_step_size")
+        g = Simulation.getCurrent()._gravity if Simulation.hasCurrent() else np.array([0, -9.81, 0], dtype=np.float32)
+        check(lib.pbdx_timestep_set_gravity(self._h, _f(_vec(g, 3))), "set_gravity")
+
+    def step(self, model):
+        """TimeStep::step(model): host state in, one full time step on the GPU, host state out."""
+        self._sync_globals()
+        check(lib.pbdx_timestep_step(self._h, model._h), "TimeStepController.step")
+        tm = TimeManager.getCurrent()
+        tm._time = np.float32(tm._time + tm._h)
+
+    def stepResident(self, model, numSteps=1):
+        """Device-resident stepping: no host transfers until syncToHost()."""
+        self._sync_globals()
+        check(lib.pbdx_timestep_step_resident(self._h, model._h, int(numSteps)), "TimeStepController.stepResident")
+        tm = TimeManager.getCurrent()
+        for _ in range(int(numSteps)):
+            tm._time = np.float32(tm._time + tm._h)
+
+    def syncToHost(self, model):
+        check(lib.pbdx_timestep_sync_to_host(self._h, model._h), "syncToHost")
+
+    def invalidate(self):
+        check(lib.pbdx_timestep_invalidate(self._h), "invalidate")
+
+    def project(self, model, iterations=1):
+        """Projection loop only (no integrate / velocity update): known-answer tests."""
+        self._sync_globals()
+        check(lib.pbdx_timestep_project(self._h, model._h, int(iterations)), "TimeStepController.project")
+
+    def solver(self):
+        return Solver(handle=lib.pbdx_timestep_solver(self._h), owner=self)
+
+
+class Solver:
+    """The raw device engine (pbdx_solver_*): what a reference-side TimeStep plug-in binds to."""
+
+    def __init__(self, device=0, handle=None, owner=None):
+        self._owner = owner
+        if handle is not None:
+            self._h = C.c_void_p(handle)
+            self._own = False
+        else:
+            h = C.c_void_p()
+            check(lib.pbdx_solver_create(C.byref(h), int(device)), "pbdx_solver_create")
+            self._h = h
+            self._own = True
+        self._n = 0
+
+    def __del__(self):
+        try:
+            if self._own and self._h:
+                lib.pbdx_solver_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_particles(self, x, mass, inv_mass=None, v=None, old_x=None, last_x=None):
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 3)
+        mass = np.ascontiguousarray(mass, dtype=np.float32)
+        if inv_mass is None:
+            inv_mass = np.where(mass != 0, np.float32(1.0) / np.where(mass != 0, mass, 1).astype(np.float32), np.float32(0)).astype(np.float32)
+        inv_mass = np.ascontiguousarray(inv_mass, dtype=np.float32)
+        opt = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in (v, old_x, last_x)]
+        self._n = len(x)
+        check(lib.pbdx_solver_set_particles(self._h, len(x), _f(x), *[None if a is None else _f(a) for a in opt], _f(mass), _f(inv_mass)),
+              "pbdx_solver_set_particles")
+
+    def set_positions(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 3)
+        check(lib.pbdx_solver_set_positions(self._h, len(x), _f(x)), "pbdx_solver_set_positions")
+
+    def get_particles(self, n=None):
+        n = self._n if n is None else n
+        out = [np.empty((n, 3), dtype=np.float32) for _ in range(4)]
+        check(lib.pbdx_solver_get_particles(self._h, n, *[_f(a) for a in out]), "pbdx_solver_get_particles")
+        return out
+
+    def begin_schedule(self):
+        check(lib.pbdx_solver_begin_schedule(self._h), "begin_schedule")
+
+    def add_batch(self, group, ctype, indices, params):
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        par = np.ascontiguousarray(params, dtype=np.float32)
+        nb = ConstraintType.num_bodies(ctype)
+        count = idx.size // nb if nb else 0
+        check(lib.pbdx_solver_add_batch(self._h, int(group), int(ctype), count, _u(idx), _f(par), par.size // max(count, 1)), "add_batch")
+
+    def end_schedule(self):
+        check(lib.pbdx_solver_end_schedule(self._h), "end_schedule")
+
+    def validate_schedule(self):
+        check(lib.pbdx_solver_validate_schedule(self._h), "validate_schedule")
+
+    def step(self, h, sub_steps, max_iterations, velocity_update_method=0, gravity=(0, -9.81, 0), num_steps=1):
+        check(lib.pbdx_solver_step(self._h, float(h), int(sub_steps), int(max_iterations), int(velocity_update_method),
+                                   _f(_vec(gravity, 3)), int(num_steps)), "pbdx_solver_step")
+
+    def project(self, h_sub, iterations):
+        check(lib.pbdx_solver_project(self._h, float(h_sub), int(iterations)), "pbdx_solver_project")
+
+    def get_lambdas(self, batch_index, count):
+        out = np.empty(count, dtype=np.float32)
+        check(lib.pbdx_solver_get_lambdas(self._h, batch_index, count, _f(out)), "get_lambdas")
+        return out
+
+    def set_option(self, option, value):
+        check(lib.pbdx_solver_set_option(self._h, int(option), int(value)), "set_option")
+
+    def set_profiling(self, on):
+        check(lib.pbdx_solver_set_profiling(self._h, int(bool(on))), "set_profiling")
+
+    def stats(self):
+        st = StepStats()
+        check(lib.pbdx_solver_get_stats(self._h, C.byref(st)), "get_stats")
+        return {k: getattr(st, k) for k, _ in StepStats._fields_}
+
+    def type_stats(self, ctype):
+        ms = C.c_double()
+        launches = C.c_uint64()
+        proj = C.c_uint64()
+        check(lib.pbdx_solver_get_type_stats(self._h, int(ctype), C.byref(ms), C.byref(launches), C.byref(proj)), "get_type_stats")
+        return ms.value, launches.value, proj.value
+
+    def describe(self):
+        buf = C.create_string_buffer(512)
+        check(lib.pbdx_solver_describe(self._h, buf, 512), "describe")
+        return buf.value.decode()
+
+    OPT_USE_GRAPH = 1
+    OPT_BLOCK_SIZE = 2
+    OPT_XCD_REMAP = 3
+
+
+class Simulation:
+    """PBD::Simulation singleton (Simulation/Simulation.cpp): model + time step + gravity."""
+    _current = None
+    GRAVITATION = 0
+
+    def __init__(self):
+        self._gravity = np.array([0.0, -9.81, 0.0], dtype=np.float32)   # Simulation.cpp:16
+        self._model = None
+        self._timeStep = None
+
+    @staticmethod
+    def getCurrent():
+        if Simulation._current is None:
+            Simulation._current = Simulation()
+        return Simulation._current
+
+    @staticmethod
+    def setCurrent(s):
+        Simulation._current = s
+
+    @staticmethod
+    def hasCurrent():
+        return Simulation._current is not None
+
+    def init(self):
+        """Simulation::init (Simulation.cpp:50-57): default TimeStepController, h = 0.005."""
+        self._timeStep = TimeStepController()
+        TimeManager.getCurrent().setTimeStepSize(0.005)
+
+    def initDefault(self):
+        """pyPBD/SimulationModule.cpp:26-32: a fresh SimulationModel + default time step."""
+        self._model = SimulationModel()
+        self.init()
+
+    def reset(self):
+        if self._model is not None:
+            self._model.reset()
+        if self._timeStep is not None:
+            self._timeStep.reset()
+        TimeManager.getCurrent().setTime(0.0)
+
+    def getModel(self):
+        return self._model
+
+    def setModel(self, m):
+        self._model = m
+
+    def getTimeStep(self):
+        return self._timeStep
+
+    def setTimeStep(self, ts):
+        self._timeStep = ts
+
+    def getVecValueFloat(self, pid):
+        return self._gravity.copy()
+
+    def setVecValueFloat(self, pid, v):
+        self._gravity = np.asarray(v, dtype=np.float32).copy()

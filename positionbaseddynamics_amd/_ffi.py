@@ -1,0 +1,119 @@
+"""ctypes binding of libpbdx.so (the C ABI declared in include/pbdx.h).
+
+The library is built in-tree by `__graft_entry__.build()` /
+`make -C positionbaseddynamics_amd/csrc`.  There is deliberately no Python or
+CPU fallback: if the shared library is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libpbdx.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libpbdx.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C positionbaseddynamics_amd/csrc` (hipcc --offload-arch=gfx950)" % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+u32 = C.c_uint32
+i64 = C.c_int64
+f32 = C.c_float
+vp = C.c_void_p
+pf = C.POINTER(C.c_float)
+pu = C.POINTER(C.c_uint32)
+
+
+class StepStats(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("projection_ms", C.c_double), ("projection_launches", C.c_uint64),
+                ("projections", C.c_uint64), ("kernel_launches", C.c_uint64), ("algorithmic_bytes", C.c_uint64)]
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+# every symbol include/pbdx.h declares: (name, restype, argtypes...)
+SIGNATURES = [
+    ("pbdx_type_num_bodies", u32, C.c_int), ("pbdx_type_param_stride", u32, C.c_int), ("pbdx_type_name", C.c_char_p, C.c_int),
+    ("pbdx_type_algorithmic_bytes", u32, C.c_int),
+    ("pbdx_last_error", C.c_char_p), ("pbdx_version", C.c_int), ("pbdx_device_count", C.c_int),
+    ("pbdx_solver_create", C.c_int, C.POINTER(vp), C.c_int), ("pbdx_solver_destroy", None, vp),
+    ("pbdx_solver_set_particles", C.c_int, vp, u32, pf, pf, pf, pf, pf, pf),
+    ("pbdx_solver_set_positions", C.c_int, vp, u32, pf),
+    ("pbdx_solver_get_particles", C.c_int, vp, u32, pf, pf, pf, pf),
+    ("pbdx_solver_begin_schedule", C.c_int, vp),
+    ("pbdx_solver_add_batch", C.c_int, vp, u32, C.c_int, u32, pu, pf, u32),
+    ("pbdx_solver_end_schedule", C.c_int, vp), ("pbdx_solver_validate_schedule", C.c_int, vp),
+    ("pbdx_solver_step", C.c_int, vp, f32, u32, u32, C.c_int, pf, u32),
+    ("pbdx_solver_project", C.c_int, vp, f32, u32), ("pbdx_solver_synchronize", C.c_int, vp),
+    ("pbdx_solver_get_lambdas", C.c_int, vp, u32, u32, pf),
+    ("pbdx_solver_set_option", C.c_int, vp, C.c_int, i64),
+    ("pbdx_solver_get_stats", C.c_int, vp, C.POINTER(StepStats)),
+    ("pbdx_solver_set_profiling", C.c_int, vp, C.c_int),
+    ("pbdx_solver_get_type_stats", C.c_int, vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)),
+    ("pbdx_solver_describe", C.c_int, vp, C.c_char_p, C.c_size_t),
+    ("pbdx_model_create", C.c_int, C.POINTER(vp)), ("pbdx_model_destroy", None, vp),
+    ("pbdx_model_cleanup", C.c_int, vp), ("pbdx_model_reset", C.c_int, vp),
+    ("pbdx_model_add_regular_triangle_model", C.c_int, vp, C.c_int, C.c_int, pf, pf, pf),
+    ("pbdx_model_add_triangle_model", C.c_int, vp, u32, u32, pf, pu),
+    ("pbdx_model_add_regular_tet_model", C.c_int, vp, C.c_int, C.c_int, C.c_int, pf, pf, pf),
+    ("pbdx_model_add_tet_model", C.c_int, vp, u32, u32, pf, pu),
+    ("pbdx_model_num_triangle_models", u32, vp), ("pbdx_model_num_tet_models", u32, vp),
+    ("pbdx_model_triangle_model_index_offset", u32, vp, u32), ("pbdx_model_tet_model_index_offset", u32, vp, u32),
+    ("pbdx_model_triangle_model_num_edges", u32, vp, u32), ("pbdx_model_triangle_model_get_edges", C.c_int, vp, u32, pu),
+    ("pbdx_model_tet_model_num_edges", u32, vp, u32), ("pbdx_model_tet_model_get_edges", C.c_int, vp, u32, pu),
+    ("pbdx_model_num_particles", u32, vp), ("pbdx_model_add_vertex", C.c_int, vp, pf),
+    ("pbdx_model_set_mass", C.c_int, vp, u32, f32),
+    ("pbdx_model_get_array", C.c_int, vp, C.c_int, pf), ("pbdx_model_set_array", C.c_int, vp, C.c_int, pf),
+    ("pbdx_model_positions_ptr", pf, vp),
+    ("pbdx_model_add_distance_constraint", C.c_int, vp, u32, u32, f32),
+    ("pbdx_model_add_distance_constraint_xpbd", C.c_int, vp, u32, u32, f32),
+    ("pbdx_model_add_dihedral_constraint", C.c_int, vp, u32, u32, u32, u32, f32),
+    ("pbdx_model_add_isometric_bending_constraint", C.c_int, vp, u32, u32, u32, u32, f32),
+    ("pbdx_model_add_isometric_bending_constraint_xpbd", C.c_int, vp, u32, u32, u32, u32, f32),
+    ("pbdx_model_add_fem_triangle_constraint", C.c_int, vp, u32, u32, u32, f32, f32, f32, f32, f32),
+    ("pbdx_model_add_strain_triangle_constraint", C.c_int, vp, u32, u32, u32, f32, f32, f32, C.c_int, C.c_int),
+    ("pbdx_model_add_volume_constraint", C.c_int, vp, u32, u32, u32, u32, f32),
+    ("pbdx_model_add_volume_constraint_xpbd", C.c_int, vp, u32, u32, u32, u32, f32),
+    ("pbdx_model_add_fem_tet_constraint", C.c_int, vp, u32, u32, u32, u32, f32, f32),
+    ("pbdx_model_add_fem_tet_constraint_xpbd", C.c_int, vp, u32, u32, u32, u32, f32, f32),
+    ("pbdx_model_add_strain_tet_constraint", C.c_int, vp, u32, u32, u32, u32, f32, f32, C.c_int, C.c_int),
+    ("pbdx_model_add_shape_matching_constraint", C.c_int, vp, u32, pu, pu, f32),
+    ("pbdx_model_add_cloth_constraints", C.c_int, vp, u32, u32, f32, f32, f32, f32, f32, f32, C.c_int, C.c_int),
+    ("pbdx_model_add_bending_constraints", C.c_int, vp, u32, u32, f32),
+    ("pbdx_model_add_solid_constraints", C.c_int, vp, u32, u32, f32, f32, f32, C.c_int, C.c_int),
+    ("pbdx_model_num_constraints", u32, vp), ("pbdx_model_constraint_type", C.c_int, vp, u32),
+    ("pbdx_model_constraint_bodies", C.c_int, vp, u32, pu), ("pbdx_model_constraint_params", C.c_int, vp, u32, pf),
+    ("pbdx_model_set_constraint_params", C.c_int, vp, u32, pf),
+    ("pbdx_model_init_constraint_groups", C.c_int, vp), ("pbdx_model_groups_initialized", C.c_int, vp),
+    ("pbdx_model_num_groups", u32, vp), ("pbdx_model_group_size", u32, vp, u32), ("pbdx_model_get_group", C.c_int, vp, u32, pu),
+    ("pbdx_timestep_create", C.c_int, C.POINTER(vp), C.c_int), ("pbdx_timestep_destroy", None, vp),
+    ("pbdx_timestep_set_param", C.c_int, vp, C.c_int, i64), ("pbdx_timestep_get_param", i64, vp, C.c_int),
+    ("pbdx_timestep_param_name", C.c_char_p, C.c_int),
+    ("pbdx_timestep_set_gravity", C.c_int, vp, pf), ("pbdx_timestep_set_time_step_size", C.c_int, vp, f32),
+    ("pbdx_timestep_get_time_step_size", f32, vp), ("pbdx_timestep_get_time", f32, vp),
+    ("pbdx_timestep_reset", C.c_int, vp), ("pbdx_timestep_step", C.c_int, vp, vp),
+    ("pbdx_timestep_step_resident", C.c_int, vp, vp, u32), ("pbdx_timestep_sync_to_host", C.c_int, vp, vp),
+    ("pbdx_timestep_invalidate", C.c_int, vp), ("pbdx_timestep_project", C.c_int, vp, vp, u32), ("pbdx_timestep_solver", vp, vp),
+]
+
+for _s in SIGNATURES:
+    _sig(*_s)
+
+
+class PbdxError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib.pbdx_last_error().decode(errors="replace")
+        super().__init__("%s failed with status %d: %s" % (where, code, msg))
+
+
+def check(code, where):
+    if code != 0:
+        raise PbdxError(code, where)
+    return code

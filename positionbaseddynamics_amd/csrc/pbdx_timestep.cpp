@@ -1,0 +1,210 @@
+// pbdx_timestep.cpp -- host mirror of PBD::TimeStepController for particle scenes.
+//
+// Same parameter names and defaults as the reference
+// (Simulation/TimeStepController.cpp:23-32, 47-72); `step` keeps TimeStep::step's
+// contract (host ParticleData in -> one step -> host ParticleData out) and packs
+// the model's colour groups into the engine's per-(group,type) batches the first
+// time and whenever the model's topology or parameters changed.
+#include "pbdx_internal.h"
+#include <string.h>
+
+using namespace pbdx;
+
+struct pbdx_timestep
+{
+	pbdx_solver *solver = nullptr;
+	uint32_t sub_steps = 5, max_iterations = 1, max_iterations_v = 5;
+	int velocity_update_method = 0;
+	float gravity[3] = { 0.0f, -9.81f, 0.0f };
+	float h = 0.005f;
+	float time = 0.0f;
+	// device image bookkeeping
+	const pbdx_model *image_of = nullptr;
+	uint64_t topo = ~0ull, params = ~0ull;
+	bool schedule_valid = false;
+	bool device_ahead = false;   // device state newer than the host model (resident stepping)
+};
+
+namespace {
+
+int upload_particles(pbdx_timestep *ts, pbdx_model *m)
+{
+	return pbdx_solver_set_particles(ts->solver, m->size(), m->x.data(), m->v.data(), m->old_x.data(), m->last_x.data(),
+		m->mass.data(), m->inv_mass.data());
+}
+
+int build_schedule(pbdx_timestep *ts, pbdx_model *m)
+{
+	int r = pbdx_model_init_constraint_groups(m);        // TimeStepController.cpp:256
+	if (r) return r;
+	r = pbdx_solver_begin_schedule(ts->solver);
+	if (r) return r;
+	std::vector<uint32_t> idx;
+	std::vector<float> par;
+	for (uint32_t g = 0; g < m->groups.size(); g++)
+	{
+		// bucket the group by constraint type, keeping creation order inside each bucket
+		for (int type = 0; type < PBDX_NUM_CONSTRAINT_TYPES; type++)
+		{
+			const TypeInfo *ti = type_info(type);
+			idx.clear(); par.clear();
+			for (uint32_t ci : m->groups[g])
+			{
+				const HostConstraint &c = m->constraints[ci];
+				if (c.type != type) continue;
+				idx.insert(idx.end(), c.bodies, c.bodies + ti->num_bodies);
+				par.insert(par.end(), c.params, c.params + ti->param_stride);
+			}
+			if (idx.empty()) continue;
+			r = pbdx_solver_add_batch(ts->solver, g, type, (uint32_t)(idx.size() / ti->num_bodies), idx.data(), par.data(), ti->param_stride);
+			if (r) return r;
+		}
+	}
+	return pbdx_solver_end_schedule(ts->solver);
+}
+
+int refresh_image(pbdx_timestep *ts, pbdx_model *m, bool force_particles)
+{
+	const bool stale_topology = !ts->schedule_valid || ts->image_of != m || ts->topo != m->topology_version || !m->groups_initialized;
+	const bool stale_params = ts->params != m->params_version;
+	if (stale_topology || stale_params || force_particles)
+	{
+		int r = upload_particles(ts, m);
+		if (r) return r;
+		ts->device_ahead = false;
+	}
+	if (stale_topology || stale_params)
+	{
+		int r = build_schedule(ts, m);
+		if (r) return r;
+		ts->image_of = m; ts->topo = m->topology_version; ts->params = m->params_version; ts->schedule_valid = true;
+	}
+	return PBDX_OK;
+}
+
+void clear_accelerations(pbdx_timestep *ts, pbdx_model *m)
+{
+	// TimeStep::clearAccelerations  TimeStep.cpp:28-62: static particles keep their (stale) value
+	for (uint32_t i = 0; i < m->size(); i++)
+		if (m->mass[i] != 0.0f) { m->a[3 * i] = ts->gravity[0]; m->a[3 * i + 1] = ts->gravity[1]; m->a[3 * i + 2] = ts->gravity[2]; }
+}
+
+} // namespace
+
+extern "C" {
+
+int pbdx_timestep_create(pbdx_timestep **out, int device)
+{
+	if (!out) { set_error("pbdx_timestep_create: null out"); return PBDX_ERR_INVALID; }
+	*out = nullptr;
+	pbdx_solver *s = nullptr;
+	int r = pbdx_solver_create(&s, device);
+	if (r) return r;
+	pbdx_timestep *ts = new (std::nothrow) pbdx_timestep();
+	if (!ts) { pbdx_solver_destroy(s); set_error("out of memory"); return PBDX_ERR_ALLOC; }
+	ts->solver = s;
+	*out = ts;
+	return PBDX_OK;
+}
+
+void pbdx_timestep_destroy(pbdx_timestep *ts)
+{
+	if (!ts) return;
+	pbdx_solver_destroy(ts->solver);
+	delete ts;
+}
+
+int pbdx_timestep_set_param(pbdx_timestep *ts, int id, int64_t value)
+{
+	if (!ts) return PBDX_ERR_INVALID;
+	switch (id)
+	{
+	case PBDX_TS_NUM_SUB_STEPS: ts->sub_steps = value < 1 ? 1u : (uint32_t)value; break;          // setMinValue(1)
+	case PBDX_TS_MAX_ITERATIONS: ts->max_iterations = value < 1 ? 1u : (uint32_t)value; break;    // setMinValue(1)
+	case PBDX_TS_MAX_ITERATIONS_V: ts->max_iterations_v = value < 0 ? 0u : (uint32_t)value; break;
+	case PBDX_TS_VELOCITY_UPDATE_METHOD:
+		if (value != 0 && value != 1) { set_error("velocityUpdateMethod must be 0 or 1"); return PBDX_ERR_INVALID; }
+		ts->velocity_update_method = (int)value; break;
+	default: set_error("unknown time step parameter %d", id); return PBDX_ERR_INVALID;
+	}
+	return PBDX_OK;
+}
+
+int64_t pbdx_timestep_get_param(const pbdx_timestep *ts, int id)
+{
+	if (!ts) return -1;
+	switch (id)
+	{
+	case PBDX_TS_NUM_SUB_STEPS: return ts->sub_steps;
+	case PBDX_TS_MAX_ITERATIONS: return ts->max_iterations;
+	case PBDX_TS_MAX_ITERATIONS_V: return ts->max_iterations_v;
+	case PBDX_TS_VELOCITY_UPDATE_METHOD: return ts->velocity_update_method;
+	default: return -1;
+	}
+}
+
+const char *pbdx_timestep_param_name(int id)
+{
+	static const char *names[] = { "subSteps", "maxIterations", "maxIterationsV", "velocityUpdateMethod" };
+	return (id >= 0 && id < 4) ? names[id] : "";
+}
+
+int pbdx_timestep_set_gravity(pbdx_timestep *ts, const float g[3])
+{
+	if (!ts || !g) return PBDX_ERR_INVALID;
+	memcpy(ts->gravity, g, sizeof(ts->gravity));
+	return PBDX_OK;
+}
+int pbdx_timestep_set_time_step_size(pbdx_timestep *ts, float h) { if (!ts) return PBDX_ERR_INVALID; ts->h = h; return PBDX_OK; }
+float pbdx_timestep_get_time_step_size(const pbdx_timestep *ts) { return ts ? ts->h : 0.0f; }
+float pbdx_timestep_get_time(const pbdx_timestep *ts) { return ts ? ts->time : 0.0f; }
+int pbdx_timestep_reset(pbdx_timestep *ts) { if (!ts) return PBDX_ERR_INVALID; ts->time = 0.0f; ts->schedule_valid = false; ts->device_ahead = false; return PBDX_OK; }
+int pbdx_timestep_invalidate(pbdx_timestep *ts) { if (!ts) return PBDX_ERR_INVALID; ts->schedule_valid = false; return PBDX_OK; }
+pbdx_solver *pbdx_timestep_solver(pbdx_timestep *ts) { return ts ? ts->solver : nullptr; }
+
+int pbdx_timestep_sync_to_host(pbdx_timestep *ts, pbdx_model *m)
+{
+	if (!ts || !m) return PBDX_ERR_INVALID;
+	int r = pbdx_solver_get_particles(ts->solver, m->size(), m->x.data(), m->v.data(), m->old_x.data(), m->last_x.data());
+	if (r) return r;
+	ts->device_ahead = false;
+	return PBDX_OK;
+}
+
+int pbdx_timestep_step(pbdx_timestep *ts, pbdx_model *m)
+{
+	if (!ts || !m) return PBDX_ERR_INVALID;
+	// host ParticleData is authoritative (its arrays are freely writable through the model API)
+	int r = refresh_image(ts, m, /*force_particles=*/true);
+	if (r) return r;
+	clear_accelerations(ts, m);
+	r = pbdx_solver_step(ts->solver, ts->h, ts->sub_steps, ts->max_iterations, ts->velocity_update_method, ts->gravity, 1);
+	if (r) return r;
+	ts->time = ts->time + ts->h;                            // TimeStepController.cpp:239
+	return pbdx_timestep_sync_to_host(ts, m);
+}
+
+int pbdx_timestep_project(pbdx_timestep *ts, pbdx_model *m, uint32_t iterations)
+{
+	if (!ts || !m) return PBDX_ERR_INVALID;
+	int r = refresh_image(ts, m, /*force_particles=*/true);
+	if (r) return r;
+	r = pbdx_solver_project(ts->solver, ts->h / (float)ts->sub_steps, iterations);
+	if (r) return r;
+	return pbdx_solver_get_particles(ts->solver, m->size(), m->x.data(), nullptr, nullptr, nullptr);
+}
+
+int pbdx_timestep_step_resident(pbdx_timestep *ts, pbdx_model *m, uint32_t num_steps)
+{
+	if (!ts || !m) return PBDX_ERR_INVALID;
+	int r = refresh_image(ts, m, /*force_particles=*/!ts->device_ahead && (ts->image_of != m));
+	if (r) return r;
+	clear_accelerations(ts, m);
+	r = pbdx_solver_step(ts->solver, ts->h, ts->sub_steps, ts->max_iterations, ts->velocity_update_method, ts->gravity, num_steps);
+	if (r) return r;
+	for (uint32_t i = 0; i < num_steps; i++) ts->time = ts->time + ts->h;
+	ts->device_ahead = true;
+	return PBDX_OK;
+}
+
+} // extern "C"

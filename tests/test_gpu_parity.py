@@ -1,0 +1,318 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the oracle
+on identical, seeded / deterministic inputs.
+
+Tolerances (fp32 positions, per-particle Euclidean distance, scene bounding box
+diagonal ~14 for the cloth and ~10 for the bar):
+  * known-answer projections and short horizons against the contraction-free float
+    build of the reference: <= 1e-6 absolute after one sweep/step (the arithmetic
+    is restated in the reference's operation order and compiled with
+    -ffp-contract=off, so most cases are bit-exact; libm acos and a few double
+    sub-expressions are the exceptions),
+  * long horizons against the f64 build: GPU error must stay within a small factor
+    of the f32 reference's own error against f64 (the envelope), since
+    fp32 trajectories decorrelate on ill-conditioned constraint sets.
+"""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pbd():
+    import positionbaseddynamics_amd as pbd
+    assert pbd.device_count() > 0, "GPU tests need a MI355X: the engine has no CPU fallback"
+    return pbd
+
+
+# ---------------------------------------------------------------------------
+# known-answer tests: random disjoint constraints, one and two sweeps
+# ---------------------------------------------------------------------------
+def _random_points(rng, n, spread=1.0):
+    return (rng.standard_normal((n, 3)) * spread).astype(np.float32)
+
+
+def _kat_ops(type_name, n_constraints, rng, static_fraction=0.2):
+    nb = {"distance": 2, "distance_xpbd": 2, "fem_triangle": 3, "strain_triangle": 3}.get(type_name, 4)
+    ops = []
+    pts = []
+    for c in range(n_constraints):
+        if type_name in ("dihedral", "isometric_bending", "isometric_bending_xpbd"):
+            # two triangles sharing the edge (p2,p3): keep them well shaped
+            e0 = _random_points(rng, 1)[0]
+            d = _random_points(rng, 1)[0]
+            d /= np.linalg.norm(d)
+            e1 = e0 + d * np.float32(0.5 + rng.random())
+            a = _random_points(rng, 1)[0]
+            a -= d * np.dot(a, d)
+            a /= np.linalg.norm(a)
+            th = np.float32(2.0 + rng.random())
+            b = a * np.cos(th) + np.cross(d, a) * np.sin(th)
+            p = [0.5 * (e0 + e1) + a * np.float32(0.4 + 0.3 * rng.random()), 0.5 * (e0 + e1) + b * np.float32(0.4 + 0.3 * rng.random()), e0, e1]
+        elif nb == 4:
+            base = _random_points(rng, 1, 3.0)[0]
+            p = [base, base + [1, 0, 0], base + [0, 1, 0], base + [0, 0, 1]]
+            p = [np.asarray(q, dtype=np.float32) + _random_points(rng, 1, 0.15)[0] for q in p]
+        elif nb == 3:
+            base = _random_points(rng, 1, 3.0)[0]
+            p = [base, base + [1, 0, 0.2], base + [0.1, 0, 1]]
+            p = [np.asarray(q, dtype=np.float32) + _random_points(rng, 1, 0.1)[0] for q in p]
+        else:
+            base = _random_points(rng, 1, 3.0)[0]
+            p = [base, base + _random_points(rng, 1, 0.5)[0]]
+        pts.extend(np.asarray(q, dtype=np.float32) for q in p)
+    for q in pts:
+        ops.append(("vertex", q))
+    n = len(pts)
+    masses = np.where(rng.random(n) < static_fraction, 0.0, 0.5 + rng.random(n)).astype(np.float32)
+    # shape matching stores w at init: masses must be set before the constraints are created
+    for i in range(n):
+        ops.append(("mass", i, float(masses[i])))
+    for c in range(n_constraints):
+        bodies = list(range(c * nb, (c + 1) * nb))
+        if type_name in ("distance", "dihedral", "isometric_bending", "volume"):
+            args = (float(np.float32(0.1 + 0.9 * rng.random())),)
+        elif type_name in ("distance_xpbd", "volume_xpbd"):
+            args = (float(np.float32(10 ** rng.uniform(2, 5))),)
+        elif type_name == "isometric_bending_xpbd":
+            args = (float(np.float32(10 ** rng.uniform(0, 3))),)
+        elif type_name == "fem_triangle":
+            args = (1.0, 1.0, 1.0, 0.3, 0.3)
+        elif type_name == "strain_triangle":
+            args = (1.0, 1.0, 1.0, bool(c % 2), bool((c // 2) % 2))
+        elif type_name == "fem_tet":
+            args = (float(np.float32(0.5 + rng.random())), 0.3)
+        elif type_name == "fem_tet_xpbd":
+            args = (float(np.float32(10 ** rng.uniform(3, 6))), 0.3)
+        elif type_name == "strain_tet":
+            args = (1.0, 1.0, bool(c % 2), bool((c // 2) % 2))
+        elif type_name == "shape_matching":
+            args = ([1 + (c + k) % 4 for k in range(4)], float(np.float32(0.2 + 0.8 * rng.random())))
+        ops.append(("constraint", type_name, bodies) + tuple(args))
+    return ops, np.array(pts, dtype=np.float32)
+
+
+def _perturb(x0, rng, scale):
+    return (x0 + rng.standard_normal(x0.shape).astype(np.float32) * np.float32(scale)).astype(np.float32)
+
+
+KAT_TYPES = ["distance", "distance_xpbd", "dihedral", "isometric_bending", "isometric_bending_xpbd", "fem_triangle",
+             "strain_triangle", "volume", "volume_xpbd", "fem_tet", "fem_tet_xpbd", "strain_tet", "shape_matching"]
+
+# absolute tolerance after two sweeps on O(1)-sized elements; exact types must be bit-identical
+KAT_EXACT = {"distance", "distance_xpbd", "isometric_bending", "isometric_bending_xpbd", "volume", "volume_xpbd",
+             "fem_triangle", "strain_triangle", "fem_tet", "strain_tet"}
+
+
+@pytest.mark.parametrize("type_name", KAT_TYPES)
+def test_known_answer_projection(pbd, type_name):
+    rng = np.random.default_rng(1234 + KAT_TYPES.index(type_name))
+    ops, x0 = _kat_ops(type_name, 257, rng)
+    x_start = _perturb(x0, rng, 0.08)
+
+    ref = util.get_oracle("f32")
+    util.apply_ref(ref, ops)
+    ref.set_array(0, x_start)
+    ref.set_time_step_size(0.005)
+
+    m = util.build_mine(ops)
+    m.getParticles().set_array(0, x_start)
+    ts = pbd.TimeStepController()
+    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+    pbd.TimeManager.setCurrent(pbd.TimeManager())
+
+    assert np.array_equal(ref.constraint_types(), m.constraintTypes())
+    worst = 0.0
+    for sweeps in (1, 2):
+        ref.set_array(0, x_start)
+        for it in range(sweeps):
+            ref.solve_position_constraints(it)
+        m.getParticles().set_array(0, x_start)
+        ts.project(m, sweeps)
+        xr = ref.positions()
+        xg = m.getParticles().positions()
+        assert np.all(np.isfinite(xg))
+        moved = util.max_err(xr, x_start)
+        assert moved > 1e-4, "degenerate test: the oracle did not move anything"
+        err = util.max_err(xg, xr)
+        worst = max(worst, err)
+        if type_name in KAT_EXACT:
+            assert util.bitwise_equal(xg, xr.astype(np.float32)), \
+                "%s: not bit-identical to the float reference after %d sweep(s): max err %.3e, %d ulp" % (
+                    type_name, sweeps, err, util.ulp_diff(xg, xr.astype(np.float32)))
+        else:
+            assert err <= 2e-6, "%s: max |dx| %.3e after %d sweep(s)" % (type_name, err, sweeps)
+    print("KAT %-26s max |dx| vs float reference = %.3e" % (type_name, worst))
+
+
+def test_fem_tet_inversion_branch(pbd):
+    """Crushed / inverted tets take the SVD branch (MathFunctions.cpp:261-388)."""
+    rng = np.random.default_rng(99)
+    for tname in ("fem_tet", "fem_tet_xpbd"):
+        ops, x0 = _kat_ops(tname, 128, rng, static_fraction=0.1)
+        x_start = x0.copy()
+        # push vertex 3 of every tet through the opposite face (volume ratio < 0.2 or negative)
+        for c in range(128):
+            p = x_start[4 * c:4 * c + 4]
+            n = np.cross(p[1] - p[0], p[2] - p[0])
+            n /= np.linalg.norm(n)
+            h = np.dot(p[3] - p[0], n)
+            p[3] -= n * np.float32(h * (1.0 + 0.6 * rng.random()) if c % 2 else h * 0.95)
+        ref = util.get_oracle("f32")
+        util.apply_ref(ref, ops)
+        ref.set_array(0, x_start)
+        ref.set_time_step_size(0.005)
+        ref.solve_position_constraints(0)
+        m = util.build_mine(ops)
+        m.getParticles().set_array(0, x_start)
+        ts = pbd.TimeStepController()
+        ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+        pbd.TimeManager.setCurrent(pbd.TimeManager())
+        ts.project(m, 1)
+        xr = ref.positions()
+        xg = m.getParticles().positions()
+        assert np.all(np.isfinite(xg))
+        assert util.max_err(xr, x_start) > 1e-3
+        err = util.max_err(xg, xr)
+        print("inversion branch %-14s max |dx| = %.3e" % (tname, err))
+        assert err <= 5e-5, "%s inversion branch: %.3e" % (tname, err)
+
+
+# ---------------------------------------------------------------------------
+# whole-step parity on the BASELINE scenes (reduced sizes)
+# ---------------------------------------------------------------------------
+SCENES = {
+    # name: (ops, sub_steps, iters, [(steps, tol_vs_f32_reference)], must_be_bit_exact_at_first_horizon)
+    "C2 cloth 50x50 XPBD dist+bend 10it": (util.cloth_spec(50, 50, 4, 3), 1, 10, [(1, 1e-6), (10, 1e-5), (100, 1e-3)]),
+    "C2 cloth 64x40 XPBD dist+bend 10it 3 substeps": (util.cloth_spec(64, 40, 4, 3), 3, 10, [(1, 1e-6), (10, 1e-5)]),
+    "cloth 50x50 XPBD dist only": (util.cloth_spec(50, 50, 4, 0), 1, 10, [(1, 1e-6), (10, 1e-5)]),
+    "cloth 50x50 FEM tri + dihedral": (util.cloth_spec(50, 50, 2, 1), 1, 5, [(1, 1e-5), (10, 1e-4)]),
+    "cloth 50x50 strain tri": (util.cloth_spec(50, 50, 3, 0), 1, 5, [(1, 1e-6), (10, 1e-5)]),
+    "C3 bar 30x5x5 FEM tet (2) 10it": (util.bar_spec(30, 5, 5, 2), 1, 10, [(1, 1e-6), (10, 1e-5)]),
+    "C3 bar 30x5x5 XPBD dist+vol (6) 10it": (util.bar_spec(30, 5, 5, 6), 1, 10, [(1, 1e-6), (10, 1e-5), (100, 1e-3)]),
+    "C3 bar 30x5x5 dist+vol (1) 10it": (util.bar_spec(30, 5, 5, 1), 1, 10, [(1, 1e-6), (10, 1e-5)]),
+    "C3 bar 30x5x5 strain tet (4) 10it": (util.bar_spec(30, 5, 5, 4), 1, 10, [(1, 1e-6), (10, 1e-5)]),
+    "C3 bar 30x5x5 shape matching (5) 10it": (util.bar_spec(30, 5, 5, 5), 1, 10, [(1, 1e-5), (10, 1e-4)]),
+    "C3 bar 30x5x5 XPBD FEM tet (3) 1it x 5 substeps": (util.bar_spec(30, 5, 5, 3), 5, 1, [(1, 1e-5), (10, 1e-4)]),
+}
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_scene_parity_vs_float_reference(pbd, name):
+    ops, sub, iters, horizons = SCENES[name]
+    for steps, tol in horizons:
+        xr = util.oracle_positions(ops, steps, sub, iters, "f32")
+        m, ts = util.mine_run(ops, steps, sub, iters)
+        xg = m.getParticles().positions()
+        assert np.all(np.isfinite(xg))
+        err = util.max_err(xg, xr)
+        exact = util.bitwise_equal(xg, xr.astype(np.float32))
+        print("%-50s steps=%-4d max |dx| vs f32 reference = %.3e%s" % (name, steps, err, "  (bit-exact)" if exact else ""))
+        assert err <= tol, "%s after %d steps: %.3e > %.1e" % (name, steps, err, tol)
+
+
+def test_c1_plumbing_scene_envelope(pbd):
+    """C1 (PBD distance + PBD isometric bending, 5 it) is ill-conditioned in float: two
+    float builds of the reference differ by 1e-2 after one step.  The GPU must sit inside the
+    envelope spanned by the reference's own float builds around the f64 result."""
+    ops = util.cloth_spec(50, 50, 1, 2)
+    x64 = util.oracle_positions(ops, 1, 1, 5, "f64")
+    x32 = util.oracle_positions(ops, 1, 1, 5, "f32")
+    m, _ = util.mine_run(ops, 1, 1, 5)
+    xg = m.getParticles().positions()
+    e_ref = util.max_err(x32, x64)
+    e_gpu = util.max_err(xg, x64)
+    print("C1: |f32 ref - f64| = %.3e   |gpu - f64| = %.3e   |gpu - f32 ref| = %.3e" % (e_ref, e_gpu, util.max_err(xg, x32)))
+    assert e_gpu <= 3.0 * e_ref + 1e-6
+
+
+def test_long_horizon_envelope_vs_f64(pbd):
+    """100 steps of the C2 physics: GPU error against the f64 reference stays within 4x the f32
+    reference's own error (trajectory-level statement)."""
+    ops = util.cloth_spec(50, 50, 4, 3)
+    x64 = util.oracle_positions(ops, 100, 1, 10, "f64")
+    x32 = util.oracle_positions(ops, 100, 1, 10, "f32")
+    m, _ = util.mine_run(ops, 100, 1, 10, resident=True)
+    xg = m.getParticles().positions()
+    e_ref = util.max_err(x32, x64)
+    e_gpu = util.max_err(xg, x64)
+    print("100 steps: |f32 ref - f64| = %.3e   |gpu - f64| = %.3e" % (e_ref, e_gpu))
+    assert e_gpu <= 4.0 * e_ref + 1e-5
+
+
+def test_full_state_and_second_order_velocity(pbd):
+    """x, v, oldX, lastX all match, with the second-order velocity update (TimeIntegration.cpp:69-79)."""
+    ops = util.cloth_spec(40, 40, 4, 3)
+    o = util.oracle_run(ops, 5, 2, 4, "f32", vel_method=1)
+    m, ts = util.mine_run(ops, 5, 2, 4, vel_method=1)
+    pd = m.getParticles()
+    for which, nm in ((0, "x"), (2, "v"), (4, "oldX"), (5, "lastX")):
+        err = util.max_err(pd.array(which), o.get_array(which))
+        print("second-order: %-5s max err %.3e" % (nm, err))
+        assert err <= (1e-5 if which != 2 else 2e-3), nm
+    # accelerations: gravity for dynamic particles, untouched (0) for the two pinned ones
+    a = pd.array(3)
+    assert np.allclose(a[1], [0, -9.81, 0]) and np.all(a[0] == 0)
+
+
+def test_resident_equals_roundtrip_and_options_are_invariant(pbd):
+    """Device-resident stepping == upload/download every step; graph vs eager, XCD remap and
+    workgroup size must not change a single bit (they only reorder independent work)."""
+    ops = util.cloth_spec(48, 48, 4, 3)
+    base, _ = util.mine_run(ops, 6, 2, 5)
+    xb = base.getParticles().positions()
+    S = pbd.Solver
+    for label, kw in (("resident", dict(resident=True)),
+                      ("eager", dict(options={S.OPT_USE_GRAPH: 0})),
+                      ("xcd remap", dict(options={S.OPT_XCD_REMAP: 1})),
+                      ("block 64", dict(options={S.OPT_BLOCK_SIZE: 64})),
+                      ("block 128 resident", dict(resident=True, options={S.OPT_BLOCK_SIZE: 128}))):
+        m, _ = util.mine_run(ops, 6, 2, 5, **kw)
+        assert util.bitwise_equal(m.getParticles().positions(), xb), label
+
+
+def test_ensemble_instances_equal_independent_runs(pbd):
+    """C4 in small: K instances stacked at the same coordinates inside one model evolve exactly
+    like K independent single-instance runs, and the colouring is K x the single colouring."""
+    K = 5
+    single = util.cloth_spec(30, 30, 4, 3)
+    multi = util.cloth_spec(30, 30, 4, 3, instances=K)
+    m1, _ = util.mine_run(single, 8, 1, 10)
+    mk, _ = util.mine_run(multi, 8, 1, 10)
+    x1 = m1.getParticles().positions()
+    xk = mk.getParticles().positions().reshape(K, -1, 3)
+    for k in range(K):
+        assert util.bitwise_equal(xk[k], x1), "instance %d diverged from the single run" % k
+    g1 = [len(g) for g in m1.getConstraintGroups()]
+    gk = [len(g) for g in mk.getConstraintGroups()]
+    assert gk == [K * n for n in g1]
+    # and against the reference on the multi-instance model
+    xr = util.oracle_positions(multi, 8, 1, 10, "f32")
+    assert util.max_err(mk.getParticles().positions(), xr) <= 1e-5
+
+
+def test_static_particles_and_zero_stiffness(pbd):
+    ops = util.cloth_spec(20, 20, 4, 3, cloth_k=0.0, bending_k=0.0)
+    xr = util.oracle_positions(ops, 3, 1, 4, "f32")
+    m, _ = util.mine_run(ops, 3, 1, 4)
+    xg = m.getParticles().positions()
+    assert util.max_err(xg, xr) <= 1e-6
+    x0 = m.getParticles().array(1)
+    assert np.array_equal(xg[0], x0[0]) and np.array_equal(xg[19], x0[19])
+
+
+def test_schedule_validator_and_lambdas(pbd):
+    ops = util.cloth_spec(16, 16, 4, 3)
+    m, ts = util.mine_run(ops, 1, 1, 3)
+    sol = ts.solver()
+    sol.validate_schedule()
+    o = util.oracle_run(ops, 1, 1, 3, "f32")
+    groups = m.getConstraintGroups()
+    types = m.constraintTypes()
+    # batch 0 = distance XPBD constraints of colour 0 in creation order
+    ids = [c for c in groups[0] if types[c] == pbd.ConstraintType.DISTANCE_XPBD]
+    lam = sol.get_lambdas(0, len(ids))
+    lam_ref = np.array([o.constraint_lambda(int(c)) for c in ids])
+    assert np.allclose(lam, lam_ref, rtol=1e-5, atol=1e-9)

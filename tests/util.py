@@ -1,0 +1,210 @@
+"""Shared test helpers: scene specifications applied identically to the oracle
+(the reference itself, oracle/_ref, or the plain-C port) and to the product
+(positionbaseddynamics_amd).  A scene is a list of operations so that the same
+list drives both sides; all scenes are deterministic."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GRAVITY = (0.0, -9.81, 0.0)
+
+
+def rot_x_half_pi():
+    """AngleAxisr(M_PI*0.5, (1,0,0)).matrix() in a float build (Demos/ClothDemo/main.cpp:136):
+    cos(float(pi/2)) = -4.371139e-08, sin = 1."""
+    a = np.float32(np.pi * 0.5)
+    c = np.float32(np.cos(a))
+    s = np.float32(np.sin(a))
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float32)
+
+
+def cloth_spec(n_cols, n_rows, cloth_method, bending_method, cloth_k=None, bending_k=None,
+               width=10.0, height=10.0, T=(0, 1, 0), pin=True, instances=1, instance_offset=(0, 0, 0)):
+    """Demos/ClothDemo/main.cpp:132-162 generalised to n_cols x n_rows and K instances."""
+    if cloth_k is None:
+        cloth_k = 100000.0 if cloth_method == 4 else 1.0
+    if bending_k is None:
+        bending_k = 100.0 if bending_method == 3 else 0.01
+    ops = []
+    R = rot_x_half_pi()
+    for k in range(instances):
+        off = k * n_cols * n_rows
+        Tk = tuple(np.float32(T[i]) + np.float32(k) * np.float32(instance_offset[i]) for i in range(3))
+        ops.append(("tri", n_cols, n_rows, Tk, R, (width, height)))
+        if pin:
+            ops.append(("mass", off, 0.0))
+            ops.append(("mass", off + n_rows - 1, 0.0))
+        if cloth_method:
+            ops.append(("cloth", k, cloth_method, cloth_k, 1.0, 1.0, 1.0, 0.3, 0.3, False, False))
+        if bending_method:
+            ops.append(("bending", k, bending_method, bending_k))
+    return ops
+
+
+def bar_spec(width, height, depth, solid_method, k=None, kv=None, poisson=0.3, T=(5, 0, 0),
+             scale=(10.0, 1.5, 1.5), ns=False, nsh=False):
+    """Demos/BarDemo/main.cpp:130-166 generalised."""
+    if k is None:
+        k = {3: 1000000.0, 6: 100000.0}.get(solid_method, 1.0)
+    if kv is None:
+        kv = 100000.0 if solid_method == 6 else 1.0
+    ops = [("tet", width, height, depth, T, None, scale)]
+    for j in range(height):
+        for q in range(depth):
+            ops.append(("mass", j * depth + q, 0.0))
+    ops.append(("solid", 0, solid_method, k, poisson, kv, ns, nsh))
+    return ops
+
+
+_CONSTRAINT_ADD = {
+    "distance": "addDistanceConstraint", "distance_xpbd": "addDistanceConstraint_XPBD",
+    "dihedral": "addDihedralConstraint", "isometric_bending": "addIsometricBendingConstraint",
+    "isometric_bending_xpbd": "addIsometricBendingConstraint_XPBD", "fem_triangle": "addFEMTriangleConstraint",
+    "strain_triangle": "addStrainTriangleConstraint", "volume": "addVolumeConstraint",
+    "volume_xpbd": "addVolumeConstraint_XPBD", "fem_tet": "addFEMTetConstraint", "fem_tet_xpbd": "addFEMTetConstraint_XPBD",
+    "strain_tet": "addStrainTetConstraint",
+}
+
+
+def apply_ref(ref, ops):
+    """Apply a scene to an oracle.refdrv.Ref / oracle port object (same builder API)."""
+    ref.reset_all()
+    for op in ops:
+        k = op[0]
+        if k == "tri":
+            ref.add_regular_triangle_model(op[1], op[2], op[3], op[4], op[5])
+        elif k == "tet":
+            ref.add_regular_tet_model(op[1], op[2], op[3], op[4], op[5], op[6])
+        elif k == "trimesh":
+            ref.add_triangle_model(op[1], op[2])
+        elif k == "tetmesh":
+            ref.add_tet_model(op[1], op[2])
+        elif k == "vertex":
+            ref.add_vertex(op[1])
+        elif k == "mass":
+            ref.set_mass(op[1], op[2])
+        elif k == "cloth":
+            ref.add_cloth_constraints(*op[1:])
+        elif k == "bending":
+            ref.add_bending_constraints(*op[1:])
+        elif k == "solid":
+            ref.add_solid_constraints(*op[1:])
+        elif k == "constraint":
+            ok = ref.add_constraint(op[1], op[2], *op[3:])
+            assert ok, "oracle rejected constraint %r" % (op,)
+        else:
+            raise ValueError(k)
+    return ref
+
+
+def build_mine(ops):
+    """Build the same scene with the product's SimulationModel mirror."""
+    import positionbaseddynamics_amd as pbd
+    m = pbd.SimulationModel()
+    for op in ops:
+        k = op[0]
+        if k == "tri":
+            m.addRegularTriangleModel(op[1], op[2], op[3], op[4], op[5])
+        elif k == "tet":
+            m.addRegularTetModel(op[1], op[2], op[3], op[4], op[5], op[6])
+        elif k == "trimesh":
+            m.addTriangleModel(op[1], op[2])
+        elif k == "tetmesh":
+            m.addTetModel(op[1], op[2])
+        elif k == "vertex":
+            m.getParticles().addVertex(op[1])
+        elif k == "mass":
+            m.getParticles().setMass(op[1], op[2])
+        elif k == "cloth":
+            m.addClothConstraints(*op[1:])
+        elif k == "bending":
+            m.addBendingConstraints(*op[1:])
+        elif k == "solid":
+            m.addSolidConstraints(*op[1:])
+        elif k == "constraint":
+            if op[1] == "shape_matching":
+                ok = m.addShapeMatchingConstraint(len(op[2]), op[2], op[3], op[4])
+            else:
+                ok = getattr(m, _CONSTRAINT_ADD[op[1]])(*[int(b) for b in op[2]], *op[3:])
+            assert ok, "model rejected constraint %r" % (op,)
+        else:
+            raise ValueError(k)
+    return m
+
+
+def get_oracle(variant="f32"):
+    """The strongest oracle available: the reference itself (oracle/_ref) if its library was
+    built (it travels to the GPU box), otherwise the plain-C port (f32 / f64 only)."""
+    from oracle import refdrv
+    if refdrv.available(variant):
+        return refdrv.Ref(variant)
+    from oracle import port
+    return port.Port(variant)
+
+
+def oracle_run(ops, steps, sub_steps, iters, variant="f32", vel_method=0, h=0.005, gravity=GRAVITY, threads=1):
+    o = get_oracle(variant)
+    apply_ref(o, ops)
+    o.set_num_threads(threads)
+    o.set_time_step_size(h)
+    o.set_gravity(gravity)
+    o.set_params(sub_steps, iters, vel_method)
+    o.step(steps)
+    return o
+
+
+def oracle_positions(ops, steps, sub_steps, iters, variant="f32", **kw):
+    return oracle_run(ops, steps, sub_steps, iters, variant, **kw).positions()
+
+
+def mine_run(ops, steps, sub_steps, iters, vel_method=0, h=0.005, gravity=GRAVITY, resident=False, options=None):
+    """Step the product (GPU).  Returns (model, timestep)."""
+    import positionbaseddynamics_amd as pbd
+    m = build_mine(ops)
+    sim = pbd.Simulation()
+    pbd.Simulation.setCurrent(sim)
+    sim.setVecValueFloat(pbd.Simulation.GRAVITATION, gravity)
+    pbd.TimeManager.setCurrent(pbd.TimeManager())
+    pbd.TimeManager.getCurrent().setTimeStepSize(h)
+    ts = pbd.TimeStepController()
+    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, sub_steps)
+    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, iters)
+    ts.setValueInt(pbd.TimeStepController.VELOCITY_UPDATE_METHOD, vel_method)
+    if options:
+        sol = ts.solver()
+        for k, v in options.items():
+            sol.set_option(k, v)
+    if resident:
+        ts.stepResident(m, steps)
+        ts.syncToHost(m)
+    else:
+        for _ in range(steps):
+            ts.step(m)
+    return m, ts
+
+
+def max_err(a, b):
+    """max per-particle Euclidean distance."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.linalg.norm(a - b, axis=1))) if len(a) else 0.0
+
+
+def bitwise_equal(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def ulp_diff(a, b):
+    """max ULP distance between two float32 arrays (same sign assumed for nonzero)."""
+    a = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7fffffff), a)
+    b = np.where(b < 0, -(b & 0x7fffffff), b)
+    return int(np.max(np.abs(a - b))) if a.size else 0
