@@ -93,7 +93,8 @@ PBDX_HD bool solve_dihedral(V3 p0, float w0, V3 p1, float w1, V3 p2, float w2, V
 	float dt = dot(n1, n2);
 	if (dt < -1.0f) dt = -1.0f;
 	if (dt > 1.0f) dt = 1.0f;
-	const float phi = acosf(dt);
+	// PositionBasedDynamics.cpp:73 calls ::acos(double) (no <math.h> C++ overloads in that TU) and narrows
+	const float phi = (float)acos((double)dt);
 
 	float lambda = w0 * sqn(d0) + w1 * sqn(d1) + w2 * sqn(d2) + w3 * sqn(d3);
 	if (lambda == 0.0f)
@@ -393,9 +394,11 @@ PBDX_HD void jacobi_rotate(M3 &A, M3 &R, int p, int q)
 	if (A.m[p][q] == 0.0f)
 		return;
 	const float d = (A.m[p][p] - A.m[q][q]) / (2.0f * A.m[p][q]);
-	float t = 1.0f / (fabsf(d) + sqrtf(d * d + 1.0f));
+	// ::fabs / ::sqrt are the double functions in MathFunctions.cpp (:18,:20): the sum and the quotient
+	// are double expressions narrowed to Real on assignment
+	float t = (float)(1.0 / (fabs((double)d) + sqrt((double)(d * d + 1.0f))));
 	if (d < 0.0f) t = -t;
-	const float c = 1.0f / sqrtf(t * t + 1.0f);
+	const float c = (float)(1.0 / sqrt((double)(t * t + 1.0f)));
 	const float s = t * c;
 	A.m[p][p] += t * A.m[p][q];
 	A.m[q][q] -= t * A.m[p][q];
@@ -755,9 +758,10 @@ PBDX_HD bool solve_strain_tet(V3 p0, float w0, V3 p1, float w1, V3 p2, float w2,
 // PositionBasedDynamics.cpp:501-558, MathFunctions.cpp:147-254
 PBDX_HD float one_norm(const M3 &A)
 {
-	const float s1 = fabsf(A.m[0][0]) + fabsf(A.m[1][0]) + fabsf(A.m[2][0]);
-	const float s2 = fabsf(A.m[0][1]) + fabsf(A.m[1][1]) + fabsf(A.m[2][1]);
-	const float s3 = fabsf(A.m[0][2]) + fabsf(A.m[1][2]) + fabsf(A.m[2][2]);
+	// ::fabs(double): every sum is accumulated in double and narrowed (MathFunctions.cpp:149-151)
+	const float s1 = (float)(fabs((double)A.m[0][0]) + fabs((double)A.m[1][0]) + fabs((double)A.m[2][0]));
+	const float s2 = (float)(fabs((double)A.m[0][1]) + fabs((double)A.m[1][1]) + fabs((double)A.m[2][1]));
+	const float s3 = (float)(fabs((double)A.m[0][2]) + fabs((double)A.m[1][2]) + fabs((double)A.m[2][2]));
 	float mx = s1;
 	if (s2 > mx) mx = s2;
 	if (s3 > mx) mx = s3;
@@ -765,9 +769,9 @@ PBDX_HD float one_norm(const M3 &A)
 }
 PBDX_HD float inf_norm(const M3 &A)
 {
-	const float s1 = fabsf(A.m[0][0]) + fabsf(A.m[0][1]) + fabsf(A.m[0][2]);
-	const float s2 = fabsf(A.m[1][0]) + fabsf(A.m[1][1]) + fabsf(A.m[1][2]);
-	const float s3 = fabsf(A.m[2][0]) + fabsf(A.m[2][1]) + fabsf(A.m[2][2]);
+	const float s1 = (float)(fabs((double)A.m[0][0]) + fabs((double)A.m[0][1]) + fabs((double)A.m[0][2]));
+	const float s2 = (float)(fabs((double)A.m[1][0]) + fabs((double)A.m[1][1]) + fabs((double)A.m[1][2]));
+	const float s3 = (float)(fabs((double)A.m[2][0]) + fabs((double)A.m[2][1]) + fabs((double)A.m[2][2]));
 	float mx = s1;
 	if (s2 > mx) mx = s2;
 	if (s3 > mx) mx = s3;
@@ -814,7 +818,7 @@ PBDX_HD void polar_decomposition_stable(const M3 &M, float tolerance, M3 &R)
 		}
 		const float MadjTone = one_norm(MadjTt);
 		const float MadjTinf = inf_norm(MadjTt);
-		const float gamma = sqrtf(sqrtf((MadjTone * MadjTinf) / (Mone * Minf)) / fabsf(dt));
+		const float gamma = (float)sqrt(sqrt((double)((MadjTone * MadjTinf) / (Mone * Minf))) / fabs((double)dt));   // double ::sqrt / ::fabs, MathFunctions.cpp:235
 		const float g1 = gamma * 0.5f;
 		const float g2 = 0.5f / (gamma * dt);
 		for (int i = 0; i < 3; i++)

@@ -1,0 +1,111 @@
+"""C-ABI surface: libpbdx.so loads, exports every symbol include/pbdx.h declares, and refuses to
+compute without a GPU (no CPU fallback exists)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from tests import util
+
+HEADER = os.path.join(util.ROOT, "include", "pbdx.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pbdx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = declared_symbols()
+    assert len(syms) >= 80
+    for must in ("pbdx_solver_create", "pbdx_solver_add_batch", "pbdx_solver_step", "pbdx_model_init_constraint_groups",
+                 "pbdx_timestep_step", "pbdx_last_error"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    import positionbaseddynamics_amd._ffi as ffi
+    lib = ctypes.CDLL(ffi.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, "declared in include/pbdx.h but not exported: %s" % missing
+    bound = {s[0] for s in ffi.SIGNATURES}
+    unbound = [s for s in declared_symbols() if s not in bound]
+    assert not unbound, "declared but not bound in _ffi.py: %s" % unbound
+
+
+def test_type_table():
+    import positionbaseddynamics_amd as pbd
+    T = pbd.ConstraintType
+    assert [T.num_bodies(t) for t in range(T.COUNT)] == [2, 2, 4, 4, 4, 3, 3, 4, 4, 4, 4, 4, 4]
+    assert [T.param_stride(t) for t in range(T.COUNT)] == [2, 2, 2, 17, 17, 10, 9, 2, 2, 12, 12, 13, 24]
+    # SURVEY.md 8d algorithmic bytes per projection
+    assert T.algorithmic_bytes(T.DISTANCE_XPBD) == 76 and T.algorithmic_bytes(T.ISOMETRIC_BENDING_XPBD) == 200
+    assert T.algorithmic_bytes(T.FEM_TET) == 168 and T.num_bodies(99) == 0
+    assert T.name(T.FEM_TET_XPBD) == "XPBD_FEMTetConstraint"
+
+
+def test_no_cpu_fallback(have_gpu):
+    import positionbaseddynamics_amd as pbd
+    if have_gpu:
+        pytest.skip("GPU present: the refusal path is only reachable without a device")
+    with pytest.raises(pbd.PbdxError) as e:
+        pbd.TimeStepController()
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+    with pytest.raises(pbd.PbdxError):
+        pbd.Solver()
+
+
+def test_error_reporting_and_argument_checks():
+    import positionbaseddynamics_amd as pbd
+    m = pbd.SimulationModel()
+    m.addRegularTriangleModel(4, 4)
+    assert not m.addDistanceConstraint(0, 99, 1.0)          # out-of-range particle -> false like a failed initConstraint
+    assert b"out of range" in pbd.lib.pbdx_last_error()
+    with pytest.raises(pbd.PbdxError):
+        m.addClothConstraints(7, 1, 1.0)                    # no such triangle model
+    with pytest.raises(pbd.PbdxError):
+        m.addRegularTriangleModel(1, 5)
+    assert not m.addShapeMatchingConstraint(3, [0, 1, 2], [1, 1, 1], 1.0)   # only 4-particle clusters are on the path
+    # degenerate elements are rejected exactly like the reference's init functions
+    m2 = pbd.SimulationModel()
+    for p in ((0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0)):
+        m2.getParticles().addVertex(p)
+    assert not m2.addFEMTetConstraint(0, 1, 2, 3, 1.0, 0.3)
+    assert not m2.addFEMTriangleConstraint(0, 1, 2, 1, 1, 1, 0.3, 0.3)
+    assert m2.numConstraints() == 0
+
+
+def test_pypbd_style_surface():
+    """The python mirror keeps pypbd's names (pyPBD/*Module.cpp) for the path's classes."""
+    import positionbaseddynamics_amd as pbd
+    for cls, names in ((pbd.SimulationModel, ["addRegularTriangleModel", "addRegularTetModel", "addTriangleModel", "addTetModel",
+                                              "addDistanceConstraint", "addDistanceConstraint_XPBD", "addDihedralConstraint",
+                                              "addIsometricBendingConstraint", "addIsometricBendingConstraint_XPBD",
+                                              "addFEMTriangleConstraint", "addStrainTriangleConstraint", "addVolumeConstraint",
+                                              "addVolumeConstraint_XPBD", "addFEMTetConstraint", "addStrainTetConstraint",
+                                              "addShapeMatchingConstraint", "addClothConstraints", "addBendingConstraints",
+                                              "addSolidConstraints", "getParticles", "getTriangleModels", "getTetModels",
+                                              "getConstraintGroups", "initConstraintGroups", "reset", "cleanup"]),
+                       (pbd.ParticleData, ["addVertex", "getPosition", "setPosition", "getPosition0", "getMass", "getInvMass",
+                                           "setMass", "getVelocity", "setVelocity", "getAcceleration", "getNumberOfParticles",
+                                           "size", "getVertices"]),
+                       (pbd.TimeStepController, ["step", "reset", "init", "setValueUInt", "getValueUInt", "NUM_SUB_STEPS",
+                                                 "MAX_ITERATIONS", "MAX_ITERATIONS_V", "VELOCITY_UPDATE_METHOD",
+                                                 "ENUM_VUPDATE_FIRST_ORDER", "ENUM_VUPDATE_SECOND_ORDER"]),
+                       (pbd.Simulation, ["getCurrent", "setCurrent", "hasCurrent", "init", "initDefault", "reset", "getModel",
+                                         "setModel", "getTimeStep", "setTimeStep"]),
+                       (pbd.TimeManager, ["getCurrent", "getTime", "setTime", "getTimeStepSize", "setTimeStepSize"])):
+        for n in names:
+            assert hasattr(cls, n), "%s.%s" % (cls.__name__, n)
+    pd_model = pbd.SimulationModel()
+    pd_model.addRegularTriangleModel(3, 3)
+    pd = pd_model.getParticles()
+    pd.setMass(2, 4.0)
+    assert pd.getMass(2) == 4.0 and pd.getInvMass(2) == 0.25
+    pd.setMass(2, 0.0)
+    assert pd.getInvMass(2) == 0.0
+    view = pd.getVertices()
+    view[1, 1] = 42.0                      # zero-copy: writes land in the model
+    assert pd.getPosition(1)[1] == 42.0

@@ -12,10 +12,12 @@ diagonal ~14 for the cloth and ~10 for the bar):
     of the f32 reference's own error against f64 (the envelope), since
     fp32 trajectories decorrelate on ill-conditioned constraint sets.
 """
+import os
+
 import numpy as np
 import pytest
 
-from tests import util
+from tests import kat, util
 
 pytestmark = pytest.mark.gpu
 
@@ -30,112 +32,39 @@ def pbd():
 # ---------------------------------------------------------------------------
 # known-answer tests: random disjoint constraints, one and two sweeps
 # ---------------------------------------------------------------------------
-def _random_points(rng, n, spread=1.0):
-    return (rng.standard_normal((n, 3)) * spread).astype(np.float32)
+KAT_TYPES = kat.KAT_TYPES
+
+# types whose projection involves no libm call: must be bit-identical to the float reference
+# (dihedral calls acos in double on both sides; device and glibc libm may differ in the last bit)
+KAT_EXACT = set(KAT_TYPES) - {"dihedral"}
 
 
-def _kat_ops(type_name, n_constraints, rng, static_fraction=0.2):
-    nb = {"distance": 2, "distance_xpbd": 2, "fem_triangle": 3, "strain_triangle": 3}.get(type_name, 4)
-    ops = []
-    pts = []
-    for c in range(n_constraints):
-        if type_name in ("dihedral", "isometric_bending", "isometric_bending_xpbd"):
-            # two triangles sharing the edge (p2,p3): keep them well shaped
-            e0 = _random_points(rng, 1)[0]
-            d = _random_points(rng, 1)[0]
-            d /= np.linalg.norm(d)
-            e1 = e0 + d * np.float32(0.5 + rng.random())
-            a = _random_points(rng, 1)[0]
-            a -= d * np.dot(a, d)
-            a /= np.linalg.norm(a)
-            th = np.float32(2.0 + rng.random())
-            b = a * np.cos(th) + np.cross(d, a) * np.sin(th)
-            p = [0.5 * (e0 + e1) + a * np.float32(0.4 + 0.3 * rng.random()), 0.5 * (e0 + e1) + b * np.float32(0.4 + 0.3 * rng.random()), e0, e1]
-        elif nb == 4:
-            base = _random_points(rng, 1, 3.0)[0]
-            p = [base, base + [1, 0, 0], base + [0, 1, 0], base + [0, 0, 1]]
-            p = [np.asarray(q, dtype=np.float32) + _random_points(rng, 1, 0.15)[0] for q in p]
-        elif nb == 3:
-            base = _random_points(rng, 1, 3.0)[0]
-            p = [base, base + [1, 0, 0.2], base + [0.1, 0, 1]]
-            p = [np.asarray(q, dtype=np.float32) + _random_points(rng, 1, 0.1)[0] for q in p]
-        else:
-            base = _random_points(rng, 1, 3.0)[0]
-            p = [base, base + _random_points(rng, 1, 0.5)[0]]
-        pts.extend(np.asarray(q, dtype=np.float32) for q in p)
-    for q in pts:
-        ops.append(("vertex", q))
-    n = len(pts)
-    masses = np.where(rng.random(n) < static_fraction, 0.0, 0.5 + rng.random(n)).astype(np.float32)
-    # shape matching stores w at init: masses must be set before the constraints are created
-    for i in range(n):
-        ops.append(("mass", i, float(masses[i])))
-    for c in range(n_constraints):
-        bodies = list(range(c * nb, (c + 1) * nb))
-        if type_name in ("distance", "dihedral", "isometric_bending", "volume"):
-            args = (float(np.float32(0.1 + 0.9 * rng.random())),)
-        elif type_name in ("distance_xpbd", "volume_xpbd"):
-            args = (float(np.float32(10 ** rng.uniform(2, 5))),)
-        elif type_name == "isometric_bending_xpbd":
-            args = (float(np.float32(10 ** rng.uniform(0, 3))),)
-        elif type_name == "fem_triangle":
-            args = (1.0, 1.0, 1.0, 0.3, 0.3)
-        elif type_name == "strain_triangle":
-            args = (1.0, 1.0, 1.0, bool(c % 2), bool((c // 2) % 2))
-        elif type_name == "fem_tet":
-            args = (float(np.float32(0.5 + rng.random())), 0.3)
-        elif type_name == "fem_tet_xpbd":
-            args = (float(np.float32(10 ** rng.uniform(3, 6))), 0.3)
-        elif type_name == "strain_tet":
-            args = (1.0, 1.0, bool(c % 2), bool((c // 2) % 2))
-        elif type_name == "shape_matching":
-            args = ([1 + (c + k) % 4 for k in range(4)], float(np.float32(0.2 + 0.8 * rng.random())))
-        ops.append(("constraint", type_name, bodies) + tuple(args))
-    return ops, np.array(pts, dtype=np.float32)
-
-
-def _perturb(x0, rng, scale):
-    return (x0 + rng.standard_normal(x0.shape).astype(np.float32) * np.float32(scale)).astype(np.float32)
-
-
-KAT_TYPES = ["distance", "distance_xpbd", "dihedral", "isometric_bending", "isometric_bending_xpbd", "fem_triangle",
-             "strain_triangle", "volume", "volume_xpbd", "fem_tet", "fem_tet_xpbd", "strain_tet", "shape_matching"]
-
-# absolute tolerance after two sweeps on O(1)-sized elements; exact types must be bit-identical
-KAT_EXACT = {"distance", "distance_xpbd", "isometric_bending", "isometric_bending_xpbd", "volume", "volume_xpbd",
-             "fem_triangle", "strain_triangle", "fem_tet", "strain_tet"}
+def _project_both(pbd, ops, x_start, sweeps):
+    ref = util.get_oracle("f32")
+    util.apply_ref(ref, ops)
+    ref.set_time_step_size(0.005)
+    ref.set_array(0, x_start)
+    for it in range(sweeps):
+        ref.solve_position_constraints(it)
+    m = util.build_mine(ops)
+    m.getParticles().set_array(0, x_start)
+    pbd.TimeManager.setCurrent(pbd.TimeManager())
+    ts = pbd.TimeStepController()
+    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+    assert np.array_equal(ref.constraint_types(), m.constraintTypes())
+    ts.project(m, sweeps)
+    return ref.positions(), m.getParticles().positions()
 
 
 @pytest.mark.parametrize("type_name", KAT_TYPES)
 def test_known_answer_projection(pbd, type_name):
-    rng = np.random.default_rng(1234 + KAT_TYPES.index(type_name))
-    ops, x0 = _kat_ops(type_name, 257, rng)
-    x_start = _perturb(x0, rng, 0.08)
-
-    ref = util.get_oracle("f32")
-    util.apply_ref(ref, ops)
-    ref.set_array(0, x_start)
-    ref.set_time_step_size(0.005)
-
-    m = util.build_mine(ops)
-    m.getParticles().set_array(0, x_start)
-    ts = pbd.TimeStepController()
-    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
-    pbd.TimeManager.setCurrent(pbd.TimeManager())
-
-    assert np.array_equal(ref.constraint_types(), m.constraintTypes())
+    arrs = kat.kat_arrays(type_name, 257, seed=1234 + KAT_TYPES.index(type_name))
+    ops = kat.kat_ops(type_name, arrs)
     worst = 0.0
     for sweeps in (1, 2):
-        ref.set_array(0, x_start)
-        for it in range(sweeps):
-            ref.solve_position_constraints(it)
-        m.getParticles().set_array(0, x_start)
-        ts.project(m, sweeps)
-        xr = ref.positions()
-        xg = m.getParticles().positions()
+        xr, xg = _project_both(pbd, ops, arrs["x_start"], sweeps)
         assert np.all(np.isfinite(xg))
-        moved = util.max_err(xr, x_start)
-        assert moved > 1e-4, "degenerate test: the oracle did not move anything"
+        assert util.max_err(xr, arrs["x_start"]) > 1e-4, "degenerate test: the oracle did not move anything"
         err = util.max_err(xg, xr)
         worst = max(worst, err)
         if type_name in KAT_EXACT:
@@ -147,37 +76,39 @@ def test_known_answer_projection(pbd, type_name):
     print("KAT %-26s max |dx| vs float reference = %.3e" % (type_name, worst))
 
 
-def test_fem_tet_inversion_branch(pbd):
-    """Crushed / inverted tets take the SVD branch (MathFunctions.cpp:261-388)."""
-    rng = np.random.default_rng(99)
-    for tname in ("fem_tet", "fem_tet_xpbd"):
-        ops, x0 = _kat_ops(tname, 128, rng, static_fraction=0.1)
-        x_start = x0.copy()
-        # push vertex 3 of every tet through the opposite face (volume ratio < 0.2 or negative)
-        for c in range(128):
-            p = x_start[4 * c:4 * c + 4]
-            n = np.cross(p[1] - p[0], p[2] - p[0])
-            n /= np.linalg.norm(n)
-            h = np.dot(p[3] - p[0], n)
-            p[3] -= n * np.float32(h * (1.0 + 0.6 * rng.random()) if c % 2 else h * 0.95)
-        ref = util.get_oracle("f32")
-        util.apply_ref(ref, ops)
-        ref.set_array(0, x_start)
-        ref.set_time_step_size(0.005)
-        ref.solve_position_constraints(0)
+@pytest.mark.parametrize("type_name", KAT_TYPES)
+def test_known_answer_projection_vs_golden(pbd, type_name):
+    """Same, against the committed outputs of the reference (tests/golden/, float and double builds)."""
+    g = np.load(os.path.join(util.ROOT, "tests", "golden", "kat_%s.npz" % type_name))
+    ops = kat.kat_ops(type_name, g)
+    for sweeps in (1, 2):
         m = util.build_mine(ops)
-        m.getParticles().set_array(0, x_start)
+        m.getParticles().set_array(0, g["x_start"])
+        pbd.TimeManager.setCurrent(pbd.TimeManager())
         ts = pbd.TimeStepController()
         ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
-        pbd.TimeManager.setCurrent(pbd.TimeManager())
-        ts.project(m, 1)
-        xr = ref.positions()
+        ts.project(m, sweeps)
         xg = m.getParticles().positions()
+        if type_name in KAT_EXACT:
+            assert util.bitwise_equal(xg, g["x%d_f32" % sweeps]), type_name
+        else:
+            assert util.max_err(xg, g["x%d_f32" % sweeps]) <= 2e-6
+        # against the double build: fp32 rounding of O(1..10)-sized data through one or two projections
+        assert util.max_err(xg, g["x%d_f64" % sweeps]) <= 1e-3 * max(1.0, util.max_err(g["x%d_f64" % sweeps], g["x_start"]))
+
+
+def test_fem_tet_inversion_branch(pbd):
+    """Crushed / inverted tets take the SVD branch (MathFunctions.cpp:261-388)."""
+    for tname in ("fem_tet", "fem_tet_xpbd"):
+        arrs = kat.kat_arrays(tname, 128, seed=99, static_fraction=0.1)
+        x_start = kat.invert_tets(arrs, 5)
+        ops = kat.kat_ops(tname, arrs)
+        xr, xg = _project_both(pbd, ops, x_start, 1)
         assert np.all(np.isfinite(xg))
         assert util.max_err(xr, x_start) > 1e-3
         err = util.max_err(xg, xr)
-        print("inversion branch %-14s max |dx| = %.3e" % (tname, err))
-        assert err <= 5e-5, "%s inversion branch: %.3e" % (tname, err)
+        print("inversion branch %-14s max |dx| = %.3e  bit-exact=%s" % (tname, err, util.bitwise_equal(xg, xr.astype(np.float32))))
+        assert err <= 1e-6, "%s inversion branch: %.3e" % (tname, err)
 
 
 # ---------------------------------------------------------------------------
@@ -211,6 +142,22 @@ def test_scene_parity_vs_float_reference(pbd, name):
         exact = util.bitwise_equal(xg, xr.astype(np.float32))
         print("%-50s steps=%-4d max |dx| vs f32 reference = %.3e%s" % (name, steps, err, "  (bit-exact)" if exact else ""))
         assert err <= tol, "%s after %d steps: %.3e > %.1e" % (name, steps, err, tol)
+
+
+@pytest.mark.parametrize("name", list(util.GOLDEN_SCENES))
+def test_scene_parity_vs_golden(pbd, name):
+    """Against the committed outputs of the reference's float and double builds (tests/golden/)."""
+    ops, sub, iters, horizons = util.GOLDEN_SCENES[name]
+    g = np.load(os.path.join(util.ROOT, "tests", "golden", "scene_%s.npz" % name))
+    for steps in horizons:
+        m, ts = util.mine_run(ops, steps, sub, iters, resident=(steps > 10))
+        xg = m.getParticles().positions()
+        e32 = util.max_err(xg, g["x_f32_%d" % steps])
+        e64 = util.max_err(xg, g["x_f64_%d" % steps])
+        eref = util.max_err(g["x_f32_%d" % steps], g["x_f64_%d" % steps])
+        print("%-44s steps=%-4d |gpu-f32ref|=%.3e |gpu-f64ref|=%.3e |f32ref-f64ref|=%.3e" % (name, steps, e32, e64, eref))
+        assert e32 <= 1e-5 * steps ** 0.5 + (2e-6 if "dihedral" in name else 0)
+        assert e64 <= 3.0 * eref + 1e-6
 
 
 def test_c1_plumbing_scene_envelope(pbd):

@@ -208,3 +208,22 @@ def ulp_diff(a, b):
     a = np.where(a < 0, -(a & 0x7fffffff), a)
     b = np.where(b < 0, -(b & 0x7fffffff), b)
     return int(np.max(np.abs(a - b))) if a.size else 0
+
+
+# scenes with golden outputs of the reference under tests/golden/ (tests/golden/make_golden.py):
+# name -> (ops, sub_steps, iterations, horizons in steps)
+GOLDEN_SCENES = {
+    "c1_cloth50_pbd_dist_isobend_5it": (cloth_spec(50, 50, 1, 2), 1, 5, [1]),
+    "c2_cloth50_xpbd_dist_isobend_10it": (cloth_spec(50, 50, 4, 3), 1, 10, [1, 10, 100]),
+    "cloth40_femtri_dihedral_5it": (cloth_spec(40, 40, 2, 1), 1, 5, [1, 10]),
+    "cloth40_straintri_5it": (cloth_spec(40, 40, 3, 0), 1, 5, [1, 10]),
+    "c3_bar30x5x5_femtet_10it": (bar_spec(30, 5, 5, 2), 1, 10, [1, 10]),
+    "c3_bar30x5x5_xpbd_distvol_10it": (bar_spec(30, 5, 5, 6), 1, 10, [1, 10]),
+    "c3_bar30x5x5_distvol_10it": (bar_spec(30, 5, 5, 1), 1, 10, [10]),
+    "c3_bar30x5x5_straintet_10it": (bar_spec(30, 5, 5, 4), 1, 10, [10]),
+    "c3_bar30x5x5_shapematching_10it": (bar_spec(30, 5, 5, 5), 1, 10, [10]),
+    "c3_bar30x5x5_xpbd_femtet_1it_5sub": (bar_spec(30, 5, 5, 3), 5, 1, [10]),
+    "c4_cloth24_x3_instances_xpbd_10it": (cloth_spec(24, 24, 4, 3, instances=3), 1, 10, [5]),
+}
+
+
