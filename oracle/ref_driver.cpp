@@ -378,6 +378,9 @@ void refdrv_solve_position_constraints_grouped(unsigned iter)
 
 void refdrv_model_reset() { Simulation::getCurrent()->reset(); }
 
+// The currently installed TimeStep object (opaque; for plug-in side counters).
+void *refdrv_get_timestep() { model(); return (void*)Simulation::getCurrent()->getTimeStep(); }
+
 // Install a TimeStep plug-in from a shared library: the library must export
 //   extern "C" PBD::TimeStep *<symbol>();
 // This is the pattern of Demos/PositionBasedElasticRodsDemo/PositionBasedElasticRodsDemo.cpp:51-54:

@@ -86,6 +86,7 @@ class Ref:
         lib.refdrv_constraint_params.argtypes = [_u, _pd]
         lib.refdrv_get_group.argtypes = [_u, _pu]
         lib.refdrv_install_timestep_plugin.argtypes = [C.c_char_p, C.c_char_p]
+        lib.refdrv_get_timestep.restype = C.c_void_p
         cls._cache[variant] = self
         return self
 

@@ -93,8 +93,12 @@ def test_known_answer_projection_vs_golden(pbd, type_name):
             assert util.bitwise_equal(xg, g["x%d_f32" % sweeps]), type_name
         else:
             assert util.max_err(xg, g["x%d_f32" % sweeps]) <= 2e-6
-        # against the double build: fp32 rounding of O(1..10)-sized data through one or two projections
-        assert util.max_err(xg, g["x%d_f64" % sweeps]) <= 1e-3 * max(1.0, util.max_err(g["x%d_f64" % sweeps], g["x_start"]))
+        # against the double build: fp32 rounding of O(1..10)-sized data through one or two projections,
+        # or -- where the float build of the reference ITSELF leaves that envelope (shape matching on
+        # random tets: the polar decomposition flips branch in float) -- no worse than the float reference
+        f32_vs_f64 = util.max_err(g["x%d_f32" % sweeps], g["x%d_f64" % sweeps])
+        tol = max(1e-3 * max(1.0, util.max_err(g["x%d_f64" % sweeps], g["x_start"])), 1.0001 * f32_vs_f64)
+        assert util.max_err(xg, g["x%d_f64" % sweeps]) <= tol
 
 
 def test_fem_tet_inversion_branch(pbd):
