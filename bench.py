@@ -102,6 +102,11 @@ def main():
     ap.add_argument("--xcd-remap", type=int, default=None)
     ap.add_argument("--block", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph")
+    ap.add_argument("--fuse", type=int, default=None, help="1 = colour-fused LDS tiles (default), 0 = one launch per colour")
+    ap.add_argument("--tile", type=int, default=None, help="particles owned by one tile (0 = auto)")
+    ap.add_argument("--fuse-block", type=int, default=None)
+    ap.add_argument("--max-seg", type=int, default=None, help="max colours fused into one launch")
+    ap.add_argument("--lds-particles", type=int, default=None)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,6 +143,10 @@ def main():
         sol.set_option(pbd.Solver.OPT_BLOCK_SIZE, args.block)
     if args.no_graph:
         sol.set_option(pbd.Solver.OPT_USE_GRAPH, 0)
+    for val, opt in ((args.fuse, pbd.Solver.OPT_FUSE), (args.tile, pbd.Solver.OPT_TILE_PARTICLES), (args.fuse_block, pbd.Solver.OPT_FUSE_BLOCK),
+                     (args.max_seg, pbd.Solver.OPT_MAX_SEGMENT_COLOURS), (args.lds_particles, pbd.Solver.OPT_LDS_PARTICLES)):
+        if val is not None:
+            sol.set_option(opt, val)
 
     def barrier():
         torch.cuda.synchronize()
@@ -153,6 +162,7 @@ def main():
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
     stats = sol.stats()
+    plan = sol.plan_info()
     barrier()
     if dist is not None:
         tt = torch.tensor([t_local], dtype=torch.float64, device="cuda")
@@ -183,32 +193,54 @@ def main():
                    "state_ok": ok, "device_event_ms_per_substep": stats["total_ms"] / max(args.steps, 1),
                    "algorithmic_GB_per_substep": stats["algorithmic_bytes"] / max(args.steps, 1) / 1e9,
                    "whole_substep_algorithmic_GBs": stats["algorithmic_bytes"] / max(stats["total_ms"], 1e-9) / 1e6,
-                   "host_scene_build_s": t_build, "engine": sol.describe()},
+                   "host_scene_build_s": t_build, "plan": plan, "engine": sol.describe()},
     }
 
     if rank == 0 and not args.no_roofline:
-        # per-kernel durations measured live with HIP events on the engine's stream (eager launches,
-        # one event in front of every projection launch); dominant kernel = XPBD isometric bending
+        # kernel durations measured live with HIP events on the engine's own stream (eager launches, one
+        # event in front of every projection launch of the timed configuration)
         sol.set_profiling(True)
         psteps = max(2, min(5, args.steps))
         ts.stepResident(model, psteps)
         sol.set_profiling(False)
         T = pbd.ConstraintType
-        per_type = {}
-        for t in range(T.COUNT):
-            ms, launches, proj = sol.type_stats(t)
+        if plan["active"]:
+            segs = [sol.segment_info(i) for i in range(plan["num_segments"])]
+            rows = []
+            for i, si in enumerate(segs):
+                if not si["profiled_launches"]:
+                    continue
+                dur_s = 1e-3 * si["profiled_ms"] / si["profiled_launches"]
+                rows.append({"segment": i, "colours": [si["colour_begin"], si["colour_end"]], "tiles": si["num_tiles"], "block": si["block"],
+                             "lds_bytes": si["lds_bytes"], "constraints": si["constraints"], "slots": si["slots"],
+                             "launches": si["profiled_launches"], "avg_us": dur_s * 1e6,
+                             "algorithmic_bytes_per_launch": si["algorithmic_bytes"], "streamed_bytes_per_launch": si["stream_bytes"],
+                             "algorithmic_GBs": si["algorithmic_bytes"] / dur_s / 1e9, "streamed_GBs": si["stream_bytes"] / dur_s / 1e9})
+            if rows:
+                dom = max(rows, key=lambda r: r["avg_us"] * r["launches"])
+                out["roofline"] = {"bound": "hbm", "kernel": "fused_kernel (colour-fused LDS tiles), segment %d = colours [%d,%d)" % (dom["segment"], dom["colours"][0], dom["colours"][1]),
+                                   "achieved": dom["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["algorithmic_GBs"] / HBM_PEAK_GBS,
+                                   "traffic": None, "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                                   "streamed_bytes_per_launch": dom["streamed_bytes_per_launch"], "avg_launch_us": dom["avg_us"],
+                                   "launches_measured": dom["launches"], "segments": rows,
+                                   "note": "achieved = SURVEY 8d algorithmic bytes of the segment's distinct constraints / event-measured launch time; "
+                                           "positions stay in LDS for the whole segment, so the bytes actually streamed from HBM (streamed_*) are lower"}
+        else:
+            per_type = {}
+            for t in range(T.COUNT):
+                ms, launches, proj = sol.type_stats(t)
+                if launches:
+                    per_type[T.name(t)] = {"launches": launches, "avg_us": 1e3 * ms / launches, "projections": proj,
+                                           "algorithmic_GBs": proj * T.algorithmic_bytes(t) / ms / 1e6}
+            ms, launches, proj = sol.type_stats(T.ISOMETRIC_BENDING_XPBD)
             if launches:
-                per_type[T.name(t)] = {"launches": launches, "avg_us": 1e3 * ms / launches, "projections": proj,
-                                       "algorithmic_GBs": proj * T.algorithmic_bytes(t) / ms / 1e6}
-        ms, launches, proj = sol.type_stats(T.ISOMETRIC_BENDING_XPBD)
-        if launches:
-            bytes_per_launch = proj * T.algorithmic_bytes(T.ISOMETRIC_BENDING_XPBD) / launches
-            dur_s = 1e-3 * ms / launches
-            achieved = bytes_per_launch / dur_s / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "project_kernel<ISOMETRIC_BENDING_XPBD>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": dur_s * 1e6,
-                               "launches_measured": launches, "per_type": per_type}
+                bytes_per_launch = proj * T.algorithmic_bytes(T.ISOMETRIC_BENDING_XPBD) / launches
+                dur_s = 1e-3 * ms / launches
+                achieved = bytes_per_launch / dur_s / 1e9
+                out["roofline"] = {"bound": "hbm", "kernel": "project_kernel<ISOMETRIC_BENDING_XPBD>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                   "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": dur_s * 1e6,
+                                   "launches_measured": launches, "per_type": per_type}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.iters)

@@ -155,13 +155,40 @@ int pbdx_solver_synchronize(pbdx_solver *s);
 /* XPBD multipliers of batch `batch_index` (order of add_batch calls). */
 int pbdx_solver_get_lambdas(pbdx_solver *s, uint32_t batch_index, uint32_t count, float *out);
 
-/* Launch options. */
+/* Launch options.  None of them changes a result bit: they select how the same colour-ordered
+ * Gauss-Seidel sweep (TimeStepController.cpp:270-286) is mapped onto launches. */
 enum {
 	PBDX_OPT_USE_GRAPH = 1,        /* capture one substep into a hipGraph (default 1) */
-	PBDX_OPT_BLOCK_SIZE = 2,       /* threads per workgroup for projection kernels: 64/128/256 (default 256) */
-	PBDX_OPT_XCD_REMAP = 3         /* XCD-aware blockIdx -> constraint-range mapping (default 0; results invariant) */
+	PBDX_OPT_BLOCK_SIZE = 2,       /* threads per workgroup of the per-colour kernels: 64/128/256 (default 256) */
+	PBDX_OPT_XCD_REMAP = 3,        /* XCD-aware blockIdx -> constraint-range / tile mapping (default 1) */
+	PBDX_OPT_FUSE = 4,             /* colour-fused LDS tile schedule (default 1); 0 = one launch per (colour, type) */
+	PBDX_OPT_TILE_PARTICLES = 5,   /* particles owned by one tile; 0 = auto (default) */
+	PBDX_OPT_FUSE_BLOCK = 6,       /* threads per workgroup of the fused kernel: 0 = auto, 256, 512, 1024 */
+	PBDX_OPT_MAX_SEGMENT_COLOURS = 7, /* upper bound on colours fused into one launch (default 16) */
+	PBDX_OPT_LDS_PARTICLES = 8     /* LDS capacity of a tile in particles (default 10240 = 160 KiB / 16 B) */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
+
+/* The colour-fused schedule the engine planned for the current constraint schedule (built lazily by
+ * the first pbdx_solver_step / pbdx_solver_project).  active == 0: the per-colour schedule runs. */
+typedef struct pbdx_plan_info {
+	int built, active;
+	uint32_t num_segments;         /* launches per Gauss-Seidel sweep */
+	uint32_t num_tiles, num_colours, max_local;
+	uint64_t slots_per_sweep;      /* constraint executions incl. redundant halo copies */
+	uint64_t stream_bytes_per_sweep; /* index + parameter + multiplier bytes streamed from HBM per sweep */
+	double redundancy;             /* slots / distinct constraints */
+	double build_seconds;
+} pbdx_plan_info;
+int pbdx_solver_get_plan_info(pbdx_solver *s, pbdx_plan_info *out);
+typedef struct pbdx_segment_info {
+	uint32_t colour_begin, colour_end, num_tiles, block, lds_bytes, type_mask;
+	uint64_t constraints, slots, stream_bytes;
+	uint64_t algorithmic_bytes;    /* SURVEY 8d bytes of the distinct constraints of the segment (one launch) */
+	double profiled_ms;            /* last profiled pbdx_solver_step: summed launch time, launches */
+	uint64_t profiled_launches;
+} pbdx_segment_info;
+int pbdx_solver_get_segment_info(pbdx_solver *s, uint32_t segment, pbdx_segment_info *out);
 
 /* Timing of the last pbdx_solver_step call measured with HIP events on the
  * engine's own stream: total milliseconds, and (if profile_kernels was set)
@@ -277,6 +304,14 @@ int pbdx_model_groups_initialized(const pbdx_model *m);   /* m_groupsInitialized
 uint32_t pbdx_model_num_groups(const pbdx_model *m);
 uint32_t pbdx_model_group_size(const pbdx_model *m, uint32_t g);
 int pbdx_model_get_group(const pbdx_model *m, uint32_t g, uint32_t *out);
+
+/* Planner self-test (host only, no GPU needed): packs the model's colour groups exactly as
+ * pbdx_timestep does, plans the colour-fused tile schedule and proves by symbolic execution that
+ * every particle receives the update history of the colour-sequential sweep.  Returns PBDX_OK or
+ * PBDX_ERR_INVALID (pbdx_last_error() says why).  tile_particles / lds_particles / max_segment_colours
+ * as in PBDX_OPT_*; 0 = defaults. */
+int pbdx_model_plan_check(pbdx_model *m, uint32_t tile_particles, uint32_t lds_particles,
+	uint32_t max_segment_colours, pbdx_plan_info *out);
 
 /* ======================================================================== */
 /* pbdx_timestep -- host mirror of PBD::TimeStepController                  */

@@ -388,7 +388,7 @@ void *refdrv_get_timestep() { model(); return (void*)Simulation::getCurrent()->g
 int refdrv_install_timestep_plugin(const char *path, const char *symbol)
 {
 	model();
-	void *h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+	void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);   // LOCAL: float and double hosts may coexist in one test process
 	if (!h) { fprintf(stderr, "refdrv: dlopen failed: %s\n", dlerror()); return 1; }
 	typedef TimeStep *(*factory_t)();
 	factory_t f = (factory_t)dlsym(h, symbol);

@@ -367,6 +367,14 @@ class SimulationModel:
         p = np.ascontiguousarray(params, dtype=np.float32)
         check(lib.pbdx_model_set_constraint_params(self._h, c, _f(p)), "set_constraint_params")
 
+    def planCheck(self, tile_particles=0, lds_particles=0, max_segment_colours=0):
+        """Plan the colour-fused tile schedule on the host and prove it equivalent to the
+        colour-sequential sweep by symbolic execution (no GPU needed).  Returns the plan summary."""
+        pi = _ffi.PlanInfo()
+        check(lib.pbdx_model_plan_check(self._h, int(tile_particles), int(lds_particles), int(max_segment_colours), C.byref(pi)),
+              "pbdx_model_plan_check")
+        return {k: getattr(pi, k) for k, _ in _ffi.PlanInfo._fields_}
+
     def initConstraintGroups(self):
         check(lib.pbdx_model_init_constraint_groups(self._h), "initConstraintGroups")
 
@@ -554,9 +562,25 @@ class Solver:
         check(lib.pbdx_solver_describe(self._h, buf, 512), "describe")
         return buf.value.decode()
 
+    def plan_info(self):
+        """The colour-fused tile schedule planned for the current constraint schedule."""
+        pi = _ffi.PlanInfo()
+        check(lib.pbdx_solver_get_plan_info(self._h, C.byref(pi)), "get_plan_info")
+        return {k: getattr(pi, k) for k, _ in _ffi.PlanInfo._fields_}
+
+    def segment_info(self, segment):
+        si = _ffi.SegmentInfo()
+        check(lib.pbdx_solver_get_segment_info(self._h, int(segment), C.byref(si)), "get_segment_info")
+        return {k: getattr(si, k) for k, _ in _ffi.SegmentInfo._fields_}
+
     OPT_USE_GRAPH = 1
     OPT_BLOCK_SIZE = 2
     OPT_XCD_REMAP = 3
+    OPT_FUSE = 4
+    OPT_TILE_PARTICLES = 5
+    OPT_FUSE_BLOCK = 6
+    OPT_MAX_SEGMENT_COLOURS = 7
+    OPT_LDS_PARTICLES = 8
 
 
 class Simulation:

@@ -30,6 +30,19 @@ class StepStats(C.Structure):
                 ("projections", C.c_uint64), ("kernel_launches", C.c_uint64), ("algorithmic_bytes", C.c_uint64)]
 
 
+class PlanInfo(C.Structure):
+    _fields_ = [("built", C.c_int), ("active", C.c_int), ("num_segments", C.c_uint32), ("num_tiles", C.c_uint32),
+                ("num_colours", C.c_uint32), ("max_local", C.c_uint32), ("slots_per_sweep", C.c_uint64),
+                ("stream_bytes_per_sweep", C.c_uint64), ("redundancy", C.c_double), ("build_seconds", C.c_double)]
+
+
+class SegmentInfo(C.Structure):
+    _fields_ = [("colour_begin", C.c_uint32), ("colour_end", C.c_uint32), ("num_tiles", C.c_uint32), ("block", C.c_uint32),
+                ("lds_bytes", C.c_uint32), ("type_mask", C.c_uint32), ("constraints", C.c_uint64), ("slots", C.c_uint64),
+                ("stream_bytes", C.c_uint64), ("algorithmic_bytes", C.c_uint64), ("profiled_ms", C.c_double),
+                ("profiled_launches", C.c_uint64)]
+
+
 def _sig(name, restype, *argtypes):
     fn = getattr(lib, name)
     fn.restype = restype
@@ -57,6 +70,9 @@ SIGNATURES = [
     ("pbdx_solver_set_profiling", C.c_int, vp, C.c_int),
     ("pbdx_solver_get_type_stats", C.c_int, vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)),
     ("pbdx_solver_describe", C.c_int, vp, C.c_char_p, C.c_size_t),
+    ("pbdx_solver_get_plan_info", C.c_int, vp, C.POINTER(PlanInfo)),
+    ("pbdx_solver_get_segment_info", C.c_int, vp, u32, C.POINTER(SegmentInfo)),
+    ("pbdx_model_plan_check", C.c_int, vp, u32, u32, u32, C.POINTER(PlanInfo)),
     ("pbdx_model_create", C.c_int, C.POINTER(vp)), ("pbdx_model_destroy", None, vp),
     ("pbdx_model_cleanup", C.c_int, vp), ("pbdx_model_reset", C.c_int, vp),
     ("pbdx_model_add_regular_triangle_model", C.c_int, vp, C.c_int, C.c_int, pf, pf, pf),

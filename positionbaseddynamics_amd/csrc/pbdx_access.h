@@ -1,0 +1,316 @@
+// pbdx_access.h -- one constraint per lane: load indices / parameters / positions through an
+// accessor, run the projection arithmetic of pbdx_project.h, write the corrections back.
+//
+// The same wrappers serve both device schedules of the engine:
+//   GlobalAccess  per-colour launches; positions are float4 (x,y,z,invMass) in HBM/L2,
+//                 32-bit particle indices
+//   TileAccess    colour-fused tile launches; positions staged in LDS, 16-bit tile-local indices
+// so the two schedules execute literally the same floating-point code.
+#ifndef PBDX_ACCESS_H
+#define PBDX_ACCESS_H
+
+#include <hip/hip_runtime.h>
+#include "pbdx_plan.h"
+#include "pbdx_project.h"
+
+namespace pbdx {
+
+__device__ __forceinline__ float view_get(const TypeView &v, const float *par, uint32_t stride, int k, uint32_t i)
+{
+	return ((v.umask >> k) & 1u) ? v.u[k] : par[(size_t)v.slot[k] * stride + i];
+}
+
+struct GlobalAccess
+{
+	float4 *pos;
+	const uint32_t *idx;
+	const float *par;
+	uint32_t par_stride;
+	float *lambda;
+	const TypeView &view;
+
+	__device__ __forceinline__ uint2 idx2(uint32_t i) const { return reinterpret_cast<const uint2 *>(idx)[i]; }
+	__device__ __forceinline__ uint4 idx4(uint32_t i) const { return reinterpret_cast<const uint4 *>(idx)[i]; }
+	__device__ __forceinline__ float4 ld(uint32_t h) const { return pos[h]; }
+	__device__ __forceinline__ void st(uint32_t h, float4 v) const { pos[h] = v; }
+	__device__ __forceinline__ float p(int k, uint32_t i) const { return view_get(view, par, par_stride, k, i); }
+};
+
+struct TileAccess
+{
+	float4 *pos;               // LDS
+	const uint16_t *idx;
+	const float *par;
+	uint32_t par_stride;
+	float *lambda;
+	const TypeView &view;
+
+	__device__ __forceinline__ uint2 idx2(uint32_t i) const
+	{
+		const uint32_t v = reinterpret_cast<const uint32_t *>(idx)[i];
+		return make_uint2(v & 0xffffu, v >> 16);
+	}
+	__device__ __forceinline__ uint4 idx4(uint32_t i) const
+	{
+		const uint2 v = reinterpret_cast<const uint2 *>(idx)[i];
+		return make_uint4(v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16);
+	}
+	__device__ __forceinline__ float4 ld(uint32_t h) const { return pos[h]; }
+	__device__ __forceinline__ void st(uint32_t h, float4 v) const { pos[h] = v; }
+	__device__ __forceinline__ float p(int k, uint32_t i) const { return view_get(view, par, par_stride, k, i); }
+};
+
+template <class A> __device__ __forceinline__ void ldp(const A &a, uint32_t h, V3 &p, float &w)
+{
+	const float4 v = a.ld(h);
+	p = mk(v.x, v.y, v.z); w = v.w;
+}
+// Constraints.cpp:1198-1204: corrections are added only to dynamic particles
+template <class A> __device__ __forceinline__ void apply(const A &a, uint32_t h, V3 p, V3 c, float w)
+{
+	if (w != 0.0f)
+		a.st(h, make_float4(p.x + c.x, p.y + c.y, p.z + c.z, w));
+}
+
+struct QFull
+{
+	float q[16];   // column-major Q(j,k) = q[k*4+j]
+	__device__ __forceinline__ float operator()(int j, int k) const { return q[k * 4 + j]; }
+};
+
+template <class A> __device__ __forceinline__ M3 load_m3(const A &a, int first, uint32_t i)
+{
+	M3 R;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int r = 0; r < 3; r++) R.m[r][c] = a.p(first + c * 3 + r, i);
+	return R;
+}
+
+#define PBDX_LOAD4 \
+	const uint4 id = a.idx4(i); \
+	V3 p0, p1, p2, p3; float w0, w1, w2, w3; \
+	ldp(a, id.x, p0, w0); ldp(a, id.y, p1, w1); ldp(a, id.z, p2, w2); ldp(a, id.w, p3, w3); \
+	V3 c0, c1, c2, c3
+#define PBDX_APPLY4 \
+	apply(a, id.x, p0, c0, w0); apply(a, id.y, p1, c1, w1); apply(a, id.z, p2, c2, w2); apply(a, id.w, p3, c3, w3)
+#define PBDX_LOAD3 \
+	const uint4 id = a.idx4(i); \
+	V3 p0, p1, p2; float w0, w1, w2; \
+	ldp(a, id.x, p0, w0); ldp(a, id.y, p1, w1); ldp(a, id.z, p2, w2); \
+	V3 c0, c1, c2
+#define PBDX_APPLY3 \
+	apply(a, id.x, p0, c0, w0); apply(a, id.y, p1, c1, w1); apply(a, id.z, p2, c2, w2)
+
+// `dt` = substep size (XPBD compliance); `first_iter`: iteration 0 of a substep, lambda := 0
+// without reading it (Constraints.cpp:1241,1448,1725,1877).
+template <int TYPE, class A> struct Project;
+
+template <class A> struct Project<PBDX_DISTANCE, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float, int)
+	{
+		const uint2 id = a.idx2(i);
+		V3 p0, p1; float w0, w1;
+		ldp(a, id.x, p0, w0); ldp(a, id.y, p1, w1);
+		V3 c0, c1;
+		if (solve_distance(p0, w0, p1, w1, a.p(0, i), a.p(1, i), c0, c1))
+		{
+			apply(a, id.x, p0, c0, w0); apply(a, id.y, p1, c1, w1);
+		}
+	}
+};
+
+template <class A> struct Project<PBDX_DISTANCE_XPBD, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float dt, int first_iter)
+	{
+		const uint2 id = a.idx2(i);
+		V3 p0, p1; float w0, w1;
+		ldp(a, id.x, p0, w0); ldp(a, id.y, p1, w1);
+		float lambda = first_iter ? 0.0f : a.lambda[i];
+		V3 c0, c1;
+		if (solve_distance_xpbd(p0, w0, p1, w1, a.p(0, i), a.p(1, i), dt, lambda, c0, c1))
+		{
+			apply(a, id.x, p0, c0, w0); apply(a, id.y, p1, c1, w1);
+		}
+		a.lambda[i] = lambda;
+	}
+};
+
+template <class A> struct Project<PBDX_DIHEDRAL, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float, int)
+	{
+		PBDX_LOAD4;
+		if (solve_dihedral(p0, w0, p1, w1, p2, w2, p3, w3, a.p(0, i), a.p(1, i), c0, c1, c2, c3))
+		{
+			PBDX_APPLY4;
+		}
+	}
+};
+
+template <class A> struct Project<PBDX_ISOMETRIC_BENDING, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float, int)
+	{
+		PBDX_LOAD4;
+		QFull q;
+#pragma unroll
+		for (int k = 0; k < 16; k++) q.q[k] = a.p(1 + k, i);
+		if (solve_isometric_bending(p0, w0, p1, w1, p2, w2, p3, w3, q, a.p(0, i), c0, c1, c2, c3))
+		{
+			PBDX_APPLY4;
+		}
+	}
+};
+
+template <class A> struct Project<PBDX_ISOMETRIC_BENDING_XPBD, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float dt, int first_iter)
+	{
+		PBDX_LOAD4;
+		QFull q;
+#pragma unroll
+		for (int k = 0; k < 16; k++) q.q[k] = a.p(1 + k, i);
+		float lambda = first_iter ? 0.0f : a.lambda[i];
+		if (solve_isometric_bending_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, q, a.p(0, i), dt, lambda, c0, c1, c2, c3))
+		{
+			PBDX_APPLY4;
+		}
+		a.lambda[i] = lambda;
+	}
+};
+
+template <class A> struct Project<PBDX_FEM_TRIANGLE, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float, int)
+	{
+		PBDX_LOAD3;
+		float im[2][2];
+		im[0][0] = a.p(1, i); im[1][0] = a.p(2, i); im[0][1] = a.p(3, i); im[1][1] = a.p(4, i);
+		if (solve_fem_triangle(p0, w0, p1, w1, p2, w2, a.p(0, i), im, a.p(5, i), a.p(6, i), a.p(7, i), a.p(8, i), a.p(9, i), c0, c1, c2))
+		{
+			PBDX_APPLY3;
+		}
+	}
+};
+
+template <class A> struct Project<PBDX_STRAIN_TRIANGLE, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float, int)
+	{
+		PBDX_LOAD3;
+		float im[2][2];
+		im[0][0] = a.p(0, i); im[1][0] = a.p(1, i); im[0][1] = a.p(2, i); im[1][1] = a.p(3, i);
+		if (solve_strain_triangle(p0, w0, p1, w1, p2, w2, im, a.p(4, i), a.p(5, i), a.p(6, i), a.p(7, i) != 0.0f, a.p(8, i) != 0.0f, c0, c1, c2))
+		{
+			PBDX_APPLY3;
+		}
+	}
+};
+
+template <class A> struct Project<PBDX_VOLUME, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float, int)
+	{
+		PBDX_LOAD4;
+		if (solve_volume(p0, w0, p1, w1, p2, w2, p3, w3, a.p(0, i), a.p(1, i), c0, c1, c2, c3))
+		{
+			PBDX_APPLY4;
+		}
+	}
+};
+
+template <class A> struct Project<PBDX_VOLUME_XPBD, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float dt, int first_iter)
+	{
+		PBDX_LOAD4;
+		float lambda = first_iter ? 0.0f : a.lambda[i];
+		if (solve_volume_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, a.p(0, i), a.p(1, i), dt, lambda, c0, c1, c2, c3))
+		{
+			PBDX_APPLY4;
+		}
+		a.lambda[i] = lambda;
+	}
+};
+
+template <class A> struct Project<PBDX_FEM_TET, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float, int)
+	{
+		PBDX_LOAD4;
+		const float vol = a.p(0, i);
+		const M3 im = load_m3(a, 1, i);
+		const bool hi = fem_tet_handle_inversion(p0, p1, p2, p3, vol);
+		if (solve_fem_tet(p0, w0, p1, w1, p2, w2, p3, w3, vol, im, a.p(10, i), a.p(11, i), hi, c0, c1, c2, c3))
+		{
+			PBDX_APPLY4;
+		}
+	}
+};
+
+template <class A> struct Project<PBDX_FEM_TET_XPBD, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float dt, int first_iter)
+	{
+		PBDX_LOAD4;
+		const float vol = a.p(0, i);
+		const M3 im = load_m3(a, 1, i);
+		const bool hi = fem_tet_handle_inversion(p0, p1, p2, p3, vol);
+		float lambda = first_iter ? 0.0f : a.lambda[i];
+		if (solve_fem_tet_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, vol, im, a.p(10, i), a.p(11, i), hi, dt, lambda, c0, c1, c2, c3))
+		{
+			PBDX_APPLY4;
+		}
+		a.lambda[i] = lambda;
+	}
+};
+
+template <class A> struct Project<PBDX_STRAIN_TET, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float, int)
+	{
+		PBDX_LOAD4;
+		const M3 im = load_m3(a, 0, i);
+		if (solve_strain_tet(p0, w0, p1, w1, p2, w2, p3, w3, im, a.p(9, i), a.p(10, i), a.p(11, i) != 0.0f, a.p(12, i) != 0.0f, c0, c1, c2, c3))
+		{
+			PBDX_APPLY4;
+		}
+	}
+};
+
+template <class A> struct Project<PBDX_SHAPE_MATCHING, A>
+{
+	static __device__ __forceinline__ void run(const A &a, uint32_t i, float, int)
+	{
+		const uint4 id = a.idx4(i);
+		const uint32_t ids[4] = { id.x, id.y, id.z, id.w };
+		V3 x[4], x0[4], corr[4]; float wl[4], w[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+		{
+			ldp(a, ids[k], x[k], wl[k]);
+			x0[k] = mk(a.p(4 + 3 * k, i), a.p(5 + 3 * k, i), a.p(6 + 3 * k, i));
+			w[k] = a.p(16 + k, i);
+		}
+		const V3 restCm = mk(a.p(1, i), a.p(2, i), a.p(3, i));
+		if (solve_shape_matching4(x0, x, w, restCm, a.p(0, i), corr))
+		{
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+			{
+				// (1.0 / m_numClusters[i]) * m_corr[i]   Constraints.cpp:2024 (double quotient narrowed to Real)
+				const float f = (float)(1.0 / (double)(unsigned int)a.p(20 + k, i));
+				if (w[k] != 0.0f)
+					a.st(ids[k], make_float4(x[k].x + f * corr[k].x, x[k].y + f * corr[k].y, x[k].z + f * corr[k].z, wl[k]));
+			}
+		}
+	}
+};
+
+} // namespace pbdx
+
+#endif

@@ -1,0 +1,562 @@
+// pbdx_plan.cpp -- planner of the colour-fused tile schedule (see pbdx_plan.h).  Host only.
+#include "pbdx_plan.h"
+#include "pbdx_internal.h"
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <string.h>
+#include <thread>
+
+namespace pbdx {
+namespace {
+
+struct Graph
+{
+	uint32_t n = 0;
+	uint32_t nc = 0;
+	uint32_t ncolours = 0;
+	const std::vector<PlanBatch> *batches = nullptr;
+	std::vector<uint32_t> batch_base;     // nb + 1
+	std::vector<uint16_t> cbatch;         // constraint id -> batch
+	std::vector<uint32_t> adj_off, adj;   // particle -> constraint ids, ascending (= colour order)
+
+	inline const PlanBatch &batch_of(uint32_t cid) const { return (*batches)[cbatch[cid]]; }
+	inline uint32_t colour(uint32_t cid) const { return batch_of(cid).colour; }
+	inline uint32_t bodies(uint32_t cid, const uint32_t *&out) const
+	{
+		const uint32_t b = cbatch[cid];
+		const PlanBatch &pb = (*batches)[b];
+		const uint32_t nbod = type_info(pb.type)->num_bodies;
+		out = pb.idx + (size_t)(cid - batch_base[b]) * nbod;
+		return nbod;
+	}
+};
+
+struct Scratch
+{
+	std::vector<uint32_t> stamp_p, stamp_c, local_of;
+	uint32_t serial = 0;
+	std::vector<std::vector<uint32_t>> bucket;
+	std::vector<uint32_t> halo;
+
+	void init(const Graph &g)
+	{
+		stamp_p.assign(g.n, 0);
+		stamp_c.assign(g.nc, 0);
+		local_of.assign(g.n, 0);
+		serial = 0;
+	}
+};
+
+// Backward dependency closure of the owned particles over colours [c_lo, c1).  `after(c)` is called
+// when colour c is final: bucket[c - c_lo .. c1 - c_lo) hold the constraints (sorted by id) and
+// `halo` the non-owned particles of the closure of [c, c1).
+template <class F>
+void closure(const Graph &g, Scratch &s, const uint32_t *owned, uint32_t n_owned, uint32_t c_lo, uint32_t c1, F &&after)
+{
+	if (++s.serial == 0)
+	{
+		std::fill(s.stamp_p.begin(), s.stamp_p.end(), 0u);
+		std::fill(s.stamp_c.begin(), s.stamp_c.end(), 0u);
+		s.serial = 1;
+	}
+	const uint32_t serial = s.serial;
+	if (s.bucket.size() < c1 - c_lo) s.bucket.resize(c1 - c_lo);
+	for (uint32_t c = 0; c < c1 - c_lo; c++) s.bucket[c].clear();
+	s.halo.clear();
+	auto add = [&](uint32_t p, uint32_t c_limit)
+	{
+		s.stamp_p[p] = serial;
+		for (uint32_t a = g.adj_off[p]; a < g.adj_off[p + 1]; a++)
+		{
+			const uint32_t cid = g.adj[a];
+			const uint32_t col = g.colour(cid);
+			if (col >= c_limit) break;
+			if (col < c_lo) continue;
+			if (s.stamp_c[cid] != serial)
+			{
+				s.stamp_c[cid] = serial;
+				s.bucket[col - c_lo].push_back(cid);
+			}
+		}
+	};
+	for (uint32_t i = 0; i < n_owned; i++) add(owned[i], c1);
+	for (uint32_t c = c1; c-- > c_lo;)
+	{
+		std::vector<uint32_t> &bk = s.bucket[c - c_lo];
+		std::sort(bk.begin(), bk.end());
+		for (size_t k = 0; k < bk.size(); k++)
+		{
+			const uint32_t *b;
+			const uint32_t nbod = g.bodies(bk[k], b);
+			for (uint32_t j = 0; j < nbod; j++)
+				if (s.stamp_p[b[j]] != serial)
+				{
+					s.halo.push_back(b[j]);
+					add(b[j], c);
+				}
+		}
+		after(c);
+	}
+}
+
+uint32_t slot_bytes(const TypeView &v, int type)
+{
+	const TypeInfo *ti = type_info(type);
+	return (ti->num_bodies == 2 ? 4u : 8u) + v.nplanes * 4u + (ti->xpbd ? 8u : 0u);
+}
+
+template <class F>
+void parallel_for(uint32_t count, uint32_t threads, F &&fn)
+{
+	if (threads <= 1 || count <= 1)
+	{
+		for (uint32_t i = 0; i < count; i++) fn(i, 0u);
+		return;
+	}
+	std::atomic<uint32_t> next(0);
+	std::vector<std::thread> pool;
+	for (uint32_t t = 0; t < threads; t++)
+		pool.emplace_back([&, t]() {
+			for (;;)
+			{
+				const uint32_t i = next.fetch_add(1);
+				if (i >= count) break;
+				fn(i, t);
+			}
+		});
+	for (auto &th : pool) th.join();
+}
+
+// recursive coordinate bisection into k tiles of (nearly) equal particle count
+void rcb(const float *x, uint32_t *perm, uint32_t count, uint32_t k, uint32_t first_tile, std::vector<uint32_t> &tile_begin)
+{
+	if (k <= 1 || count <= 1)
+	{
+		tile_begin[first_tile] = 0;   // filled by caller through offsets; placeholder
+		return;
+	}
+	float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+	for (uint32_t i = 0; i < count; i++)
+		for (int d = 0; d < 3; d++)
+		{
+			const float v = x[3 * (size_t)perm[i] + d];
+			if (v < lo[d]) lo[d] = v;
+			if (v > hi[d]) hi[d] = v;
+		}
+	int axis = 0;
+	for (int d = 1; d < 3; d++) if (hi[d] - lo[d] > hi[axis] - lo[axis]) axis = d;
+	const uint32_t k_left = k / 2;
+	const uint32_t n_left = (uint32_t)((uint64_t)count * k_left / k);
+	std::nth_element(perm, perm + n_left, perm + count, [x, axis](uint32_t a, uint32_t b) {
+		const float va = x[3 * (size_t)a + axis], vb = x[3 * (size_t)b + axis];
+		return va < vb || (va == vb && a < b);
+	});
+	rcb(x, perm, n_left, k_left, first_tile, tile_begin);
+	rcb(x, perm + n_left, count - n_left, k - k_left, first_tile + k_left, tile_begin);
+}
+
+// sizes of the tiles produced by rcb() in tile order (same split arithmetic)
+void rcb_sizes(uint32_t count, uint32_t k, std::vector<uint32_t> &sizes)
+{
+	if (k <= 1 || count <= 1) { sizes.push_back(count); for (uint32_t i = 1; i < k; i++) sizes.push_back(0); return; }
+	const uint32_t k_left = k / 2;
+	const uint32_t n_left = (uint32_t)((uint64_t)count * k_left / k);
+	rcb_sizes(n_left, k_left, sizes);
+	rcb_sizes(count - n_left, k - k_left, sizes);
+}
+
+struct TileOut
+{
+	std::vector<uint32_t> gid;
+	std::vector<FusedStep> steps;
+	std::vector<uint16_t> idx;
+	std::vector<float> params;
+	std::vector<uint32_t> slot_cid;
+	uint32_t lam_count = 0;
+	uint32_t n_owned = 0;
+	uint32_t slots = 0;
+	uint64_t stream_bytes = 0;
+};
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+} // namespace
+
+bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &batches,
+	const PlanOptions &opt, FusedPlan &plan, std::string &why)
+{
+	const auto t_start = std::chrono::steady_clock::now();
+	plan = FusedPlan();
+	if (n == 0 || batches.empty()) { why = "empty schedule"; return false; }
+	if (batches.size() >= 65535) { why = "too many batches"; return false; }
+
+	Graph g;
+	g.n = n;
+	g.batches = &batches;
+	g.batch_base.resize(batches.size() + 1);
+	uint64_t total = 0;
+	uint32_t ncol = 0;
+	for (size_t b = 0; b < batches.size(); b++)
+	{
+		g.batch_base[b] = (uint32_t)total;
+		total += batches[b].count;
+		if (b && batches[b].colour < batches[b - 1].colour) { why = "batches not in colour order"; return false; }
+		ncol = std::max(ncol, batches[b].colour + 1);
+		if (!type_info(batches[b].type)) { why = "unknown constraint type"; return false; }
+	}
+	if (total >= 0xffffffffull) { why = "too many constraints"; return false; }
+	g.batch_base[batches.size()] = (uint32_t)total;
+	g.nc = (uint32_t)total;
+	g.ncolours = ncol;
+	g.cbatch.resize(g.nc);
+	g.adj_off.assign((size_t)n + 2, 0);
+	for (size_t b = 0; b < batches.size(); b++)
+	{
+		const uint32_t nbod = type_info(batches[b].type)->num_bodies;
+		for (uint32_t i = 0; i < batches[b].count; i++)
+		{
+			g.cbatch[g.batch_base[b] + i] = (uint16_t)b;
+			for (uint32_t j = 0; j < nbod; j++)
+			{
+				const uint32_t p = batches[b].idx[(size_t)i * nbod + j];
+				if (p >= n) { why = "particle index out of range"; return false; }
+				g.adj_off[p + 2]++;
+			}
+		}
+	}
+	for (size_t p = 2; p < g.adj_off.size(); p++) g.adj_off[p] += g.adj_off[p - 1];
+	g.adj.resize(g.adj_off[n + 1]);
+	for (size_t b = 0; b < batches.size(); b++)
+	{
+		const uint32_t nbod = type_info(batches[b].type)->num_bodies;
+		for (uint32_t i = 0; i < batches[b].count; i++)
+			for (uint32_t j = 0; j < nbod; j++)
+				g.adj[g.adj_off[batches[b].idx[(size_t)i * nbod + j] + 1]++] = g.batch_base[b] + i;
+	}
+	g.adj_off.pop_back();     // adj_off[p] .. adj_off[p+1]
+
+	// ---- parameter views: uniform over the whole schedule -> scalar ------------------------------
+	for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++)
+	{
+		TypeView &v = plan.views[t];
+		memset(&v, 0, sizeof(v));
+		const TypeInfo *ti = type_info(t);
+		bool seen = false;
+		uint32_t first[PBDX_MAX_PARAMS] = {};
+		uint32_t varying = 0;
+		for (const PlanBatch &pb : batches)
+		{
+			if (pb.type != t || !pb.count) continue;
+			const uint32_t np = ti->param_stride;
+			if (!seen) { memcpy(first, pb.params, np * 4); seen = true; }
+			for (uint32_t i = 0; i < pb.count; i++)
+			{
+				const uint32_t *row = reinterpret_cast<const uint32_t *>(pb.params) + (size_t)i * np;
+				for (uint32_t k = 0; k < np; k++) if (row[k] != first[k]) varying |= 1u << k;
+			}
+		}
+		for (uint32_t k = 0; k < ti->param_stride; k++)
+		{
+			if (!((varying >> k) & 1u)) { v.umask |= 1u << k; memcpy(&v.u[k], &first[k], 4); }
+			else v.slot[k] = (uint8_t)v.nplanes++;
+		}
+	}
+
+	// ---- tiles ---------------------------------------------------------------------------------
+	uint32_t T = opt.tile_particles;
+	if (T == 0)
+	{
+		T = (n + opt.num_cus - 1) / std::max(1u, opt.num_cus);
+		T = std::min(std::max(T, 512u), 4096u);
+	}
+	T = std::min(T, opt.max_local);
+	uint32_t k = (n + T - 1) / T;
+	if (opt.tile_particles == 0 && k > opt.num_cus) k = round_up(k, opt.num_cus);
+	std::vector<uint32_t> perm(n);
+	for (uint32_t i = 0; i < n; i++) perm[i] = i;
+	std::vector<uint32_t> dummy(k + 1, 0);
+	rcb(x, perm.data(), n, k, 0, dummy);
+	std::vector<uint32_t> sizes;
+	rcb_sizes(n, k, sizes);
+	std::vector<uint32_t> tile_begin(k + 1, 0);
+	for (uint32_t t = 0; t < k; t++) tile_begin[t + 1] = tile_begin[t] + sizes[t];
+	plan.tile_of.resize(n);
+	for (uint32_t t = 0; t < k; t++)
+	{
+		std::sort(perm.begin() + tile_begin[t], perm.begin() + tile_begin[t + 1]);
+		for (uint32_t i = tile_begin[t]; i < tile_begin[t + 1]; i++) plan.tile_of[perm[i]] = t;
+	}
+	plan.num_tiles = k;
+	plan.num_colours = ncol;
+	plan.num_particles = n;
+	plan.num_constraints = g.nc;
+	plan.batch_base = g.batch_base;
+
+	uint32_t threads = opt.threads ? opt.threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	std::vector<Scratch> scratch(threads);
+	for (Scratch &s : scratch) s.init(g);
+
+	// ---- segment boundaries: dynamic programme over a sample of tiles ---------------------------
+	const uint32_t maxlen = std::max(1u, std::min(opt.max_segment_colours, ncol));
+	const uint32_t nsample = std::min(k, 8u);
+	std::vector<uint32_t> sample(nsample);
+	for (uint32_t i = 0; i < nsample; i++) sample[i] = (uint32_t)(((uint64_t)(2 * i + 1) * k) / (2 * nsample));
+	// cost[c1][len-1] for segment [c1-len, c1)
+	std::vector<double> seg_bytes((size_t)(ncol + 1) * maxlen, 0.0);
+	std::vector<uint32_t> seg_maxlocal((size_t)(ncol + 1) * maxlen, 0u);
+	{
+		std::vector<std::vector<double>> tb(threads, std::vector<double>(seg_bytes.size(), 0.0));
+		std::vector<std::vector<uint32_t>> tm(threads, std::vector<uint32_t>(seg_bytes.size(), 0u));
+		parallel_for(ncol * nsample, threads, [&](uint32_t job, uint32_t th) {
+			const uint32_t c1 = job / nsample + 1;
+			const uint32_t t = sample[job % nsample];
+			const uint32_t c_lo = c1 > maxlen ? c1 - maxlen : 0;
+			Scratch &s = scratch[th];
+			const uint32_t n_owned = tile_begin[t + 1] - tile_begin[t];
+			double bytes = 0.0;
+			closure(g, s, perm.data() + tile_begin[t], n_owned, c_lo, c1, [&](uint32_t c) {
+				for (uint32_t cid : s.bucket[c - c_lo]) bytes += slot_bytes(plan.views[g.batch_of(cid).type], g.batch_of(cid).type);
+				const uint32_t n_local = n_owned + (uint32_t)s.halo.size();
+				const size_t e = (size_t)c1 * maxlen + (c1 - c - 1);
+				tb[th][e] += bytes + 16.0 * (n_local + n_owned);
+				tm[th][e] = std::max(tm[th][e], n_local);
+			});
+		});
+		for (uint32_t th = 0; th < threads; th++)
+			for (size_t e = 0; e < seg_bytes.size(); e++)
+			{
+				seg_bytes[e] += tb[th][e];
+				seg_maxlocal[e] = std::max(seg_maxlocal[e], tm[th][e]);
+			}
+	}
+	const double scale = (double)k / nsample;
+	const uint32_t cap_dp = (uint32_t)(opt.max_local * (nsample < k ? 0.95 : 1.0));
+	std::vector<double> best(ncol + 1, 1e300);
+	std::vector<uint32_t> prev(ncol + 1, 0);
+	best[0] = 0.0;
+	for (uint32_t c1 = 1; c1 <= ncol; c1++)
+		for (uint32_t len = 1; len <= maxlen && len <= c1; len++)
+		{
+			const size_t e = (size_t)c1 * maxlen + (len - 1);
+			if (len > 1 && seg_maxlocal[e] > cap_dp) break;       // closures only grow with the length
+			const double cst = best[c1 - len] + seg_bytes[e] * scale + opt.launch_cost_bytes;
+			if (cst < best[c1]) { best[c1] = cst; prev[c1] = c1 - len; }
+		}
+	std::vector<std::pair<uint32_t, uint32_t>> todo;
+	for (uint32_t c = ncol; c > 0; c = prev[c]) todo.push_back({ prev[c], c });
+	std::reverse(todo.begin(), todo.end());
+
+	// ---- full build ----------------------------------------------------------------------------
+	uint64_t slots_total = 0;
+	for (size_t si = 0; si < todo.size(); si++)
+	{
+		const uint32_t c0 = todo[si].first, c1 = todo[si].second;
+		std::vector<TileOut> outs(k);
+		std::atomic<uint32_t> worst(0);
+		parallel_for(k, threads, [&](uint32_t t, uint32_t th) {
+			Scratch &s = scratch[th];
+			TileOut &o = outs[t];
+			const uint32_t *owned = perm.data() + tile_begin[t];
+			o.n_owned = tile_begin[t + 1] - tile_begin[t];
+			closure(g, s, owned, o.n_owned, c0, c1, [](uint32_t) {});
+			std::sort(s.halo.begin(), s.halo.end());
+			const uint32_t n_local = o.n_owned + (uint32_t)s.halo.size();
+			uint32_t w = worst.load();
+			while (n_local > w && !worst.compare_exchange_weak(w, n_local)) {}
+			if (n_local > opt.max_local) return;
+			o.gid.reserve(n_local);
+			for (uint32_t i = 0; i < o.n_owned; i++) { s.local_of[owned[i]] = i; o.gid.push_back(owned[i]); }
+			for (uint32_t i = 0; i < s.halo.size(); i++) { s.local_of[s.halo[i]] = o.n_owned + i; o.gid.push_back(s.halo[i]); }
+			for (uint32_t c = c0; c < c1; c++)
+			{
+				const std::vector<uint32_t> &bk = s.bucket[c - c0];
+				size_t a = 0;
+				while (a < bk.size())
+				{
+					const uint32_t b = g.cbatch[bk[a]];
+					size_t e = a;
+					while (e < bk.size() && g.cbatch[bk[e]] == b) e++;
+					const PlanBatch &pb = batches[b];
+					const TypeInfo *ti = type_info(pb.type);
+					const TypeView &v = plan.views[pb.type];
+					FusedStep st;
+					st.type = (uint32_t)pb.type;
+					st.count = (uint32_t)(e - a);
+					st.idx_off = (uint32_t)o.idx.size();
+					st.par_off = (uint32_t)o.params.size();
+					st.par_stride = round_up(st.count, 4);
+					st.lam_off = o.lam_count;
+					st.barrier = (e == bk.size()) ? 1u : 0u;
+					st.cid_off = (uint32_t)o.slot_cid.size();
+					const uint32_t iw = ti->num_bodies == 2 ? 2 : 4;
+					o.idx.resize(o.idx.size() + round_up(st.count * iw, 8), 0);
+					o.params.resize(o.params.size() + (size_t)v.nplanes * st.par_stride, 0.0f);
+					for (size_t q = a; q < e; q++)
+					{
+						const uint32_t cid = bk[q];
+						const uint32_t i = cid - g.batch_base[b];
+						const uint32_t slot = (uint32_t)(q - a);
+						for (uint32_t j = 0; j < ti->num_bodies; j++)
+							o.idx[st.idx_off + slot * iw + j] = (uint16_t)s.local_of[pb.idx[(size_t)i * ti->num_bodies + j]];
+						for (uint32_t p = 0; p < ti->param_stride; p++)
+							if (!((v.umask >> p) & 1u))
+								o.params[st.par_off + (size_t)v.slot[p] * st.par_stride + slot] = pb.params[(size_t)i * ti->param_stride + p];
+						o.slot_cid.push_back(cid);
+					}
+					if (ti->xpbd) o.lam_count += round_up(st.count, 4);
+					o.slots += st.count;
+					o.stream_bytes += (uint64_t)st.count * slot_bytes(v, pb.type);
+					o.steps.push_back(st);
+					a = e;
+				}
+			}
+		});
+		if (worst.load() > opt.max_local)
+		{
+			if (c1 - c0 <= 1) { why = "a single colour does not fit the LDS tile: reduce tile_particles"; return false; }
+			// the sampled estimate missed a larger tile: split this segment and retry both halves
+			const uint32_t mid = (c0 + c1) / 2;
+			todo[si] = { c0, mid };
+			todo.insert(todo.begin() + si + 1, { mid, c1 });
+			si--;
+			continue;
+		}
+		plan.segs.emplace_back();
+		FusedSegment &seg = plan.segs.back();
+		seg.colour_begin = c0;
+		seg.colour_end = c1;
+		for (size_t b = 0; b < batches.size(); b++)
+			if (batches[b].colour >= c0 && batches[b].colour < c1) { seg.constraints += batches[b].count; seg.type_mask |= 1u << batches[b].type; }
+		seg.tiles.resize(k);
+		for (uint32_t t = 0; t < k; t++)
+		{
+			TileOut &o = outs[t];
+			FusedTile &ft = seg.tiles[t];
+			memset(&ft, 0, sizeof(ft));
+			ft.step_begin = (uint32_t)seg.steps.size();
+			ft.n_local = (uint32_t)o.gid.size();
+			ft.n_owned = o.n_owned;
+			ft.gid_off = (uint32_t)seg.gid.size();
+			ft.slots = o.slots;
+			const uint32_t idx_base = (uint32_t)seg.idx.size(), par_base = (uint32_t)seg.params.size();
+			const uint32_t lam_base = seg.lam_count, cid_base = (uint32_t)seg.slot_cid.size();
+			if ((uint64_t)idx_base + o.idx.size() >= 0xffffffffull || (uint64_t)par_base + o.params.size() >= 0xffffffffull)
+			{ why = "segment stream exceeds 32-bit offsets"; return false; }
+			for (FusedStep st : o.steps)
+			{
+				st.idx_off += idx_base; st.par_off += par_base; st.lam_off += lam_base; st.cid_off += cid_base;
+				seg.steps.push_back(st);
+			}
+			ft.step_end = (uint32_t)seg.steps.size();
+			seg.idx.insert(seg.idx.end(), o.idx.begin(), o.idx.end());
+			seg.params.insert(seg.params.end(), o.params.begin(), o.params.end());
+			seg.gid.insert(seg.gid.end(), o.gid.begin(), o.gid.end());
+			seg.gid.resize(round_up((uint32_t)seg.gid.size(), 4), 0);
+			seg.slot_cid.insert(seg.slot_cid.end(), o.slot_cid.begin(), o.slot_cid.end());
+			seg.lam_count += o.lam_count;
+			seg.max_local = std::max(seg.max_local, ft.n_local);
+			seg.slots += o.slots;
+			seg.stream_bytes += o.stream_bytes;
+		}
+		slots_total += seg.slots;
+	}
+	plan.redundancy = g.nc ? (double)slots_total / (double)g.nc : 1.0;
+	plan.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+	return true;
+}
+
+namespace {
+inline uint64_t mix(uint64_t a, uint64_t b)
+{
+	a ^= b + 0x9e3779b97f4a7c15ull + (a << 6) + (a >> 2);
+	a *= 0xff51afd7ed558ccdull;
+	a ^= a >> 33;
+	return a;
+}
+}
+
+bool check_fused_plan(uint32_t n, const std::vector<PlanBatch> &batches, const FusedPlan &plan, std::string &why)
+{
+	char msg[256];
+	if (plan.num_particles != n) { why = "particle count mismatch"; return false; }
+	// colour-sequential sweep
+	std::vector<uint64_t> want(n);
+	for (uint32_t p = 0; p < n; p++) want[p] = mix(0x1234, p);
+	std::vector<uint32_t> base(batches.size() + 1, 0);
+	for (size_t b = 0; b < batches.size(); b++) base[b + 1] = base[b] + batches[b].count;
+	auto apply = [&](uint32_t cid, size_t b, std::vector<uint64_t> &val, const uint32_t *bod, uint32_t nbod) {
+		(void)b;
+		uint64_t h = mix(0xabcdef, cid);
+		for (uint32_t j = 0; j < nbod; j++) h = mix(h, val[bod[j]]);
+		for (uint32_t j = 0; j < nbod; j++) val[bod[j]] = mix(mix(h, j), val[bod[j]]);
+	};
+	for (size_t b = 0; b < batches.size(); b++)
+	{
+		const uint32_t nbod = type_info(batches[b].type)->num_bodies;
+		for (uint32_t i = 0; i < batches[b].count; i++)
+			apply(base[b] + i, b, want, batches[b].idx + (size_t)i * nbod, nbod);
+	}
+	// fused schedule
+	std::vector<uint64_t> cur(n), nxt(n);
+	for (uint32_t p = 0; p < n; p++) cur[p] = mix(0x1234, p);
+	std::vector<uint64_t> local;
+	std::vector<uint32_t> owner_count(n);
+	uint32_t expect_colour = 0;
+	for (const FusedSegment &seg : plan.segs)
+	{
+		if (seg.colour_begin != expect_colour) { why = "segments do not tile the colour range"; return false; }
+		expect_colour = seg.colour_end;
+		std::fill(owner_count.begin(), owner_count.end(), 0u);
+		for (const FusedTile &t : seg.tiles)
+		{
+			if (t.n_local > 65535 || t.n_owned > t.n_local) { why = "bad tile sizes"; return false; }
+			local.resize(t.n_local);
+			for (uint32_t i = 0; i < t.n_local; i++)
+			{
+				const uint32_t p = seg.gid[t.gid_off + i];
+				if (p >= n) { why = "gid out of range"; return false; }
+				local[i] = cur[p];
+			}
+			for (uint32_t s = t.step_begin; s < t.step_end; s++)
+			{
+				const FusedStep &st = seg.steps[s];
+				const TypeInfo *ti = type_info((int)st.type);
+				if (!ti) { why = "bad step type"; return false; }
+				const uint32_t iw = ti->num_bodies == 2 ? 2 : 4;
+				for (uint32_t q = 0; q < st.count; q++)
+				{
+					const uint32_t cid = seg.slot_cid[st.cid_off + q];
+					const size_t b = std::upper_bound(base.begin(), base.end(), cid) - base.begin() - 1;
+					if (batches[b].type != (int)st.type) { why = "slot type mismatch"; return false; }
+					if (batches[b].colour < seg.colour_begin || batches[b].colour >= seg.colour_end) { why = "slot colour outside its segment"; return false; }
+					uint32_t lb[4];
+					for (uint32_t j = 0; j < ti->num_bodies; j++)
+					{
+						lb[j] = seg.idx[st.idx_off + q * iw + j];
+						if (lb[j] >= t.n_local) { why = "local index out of range"; return false; }
+						if (seg.gid[t.gid_off + lb[j]] != batches[b].idx[(size_t)(cid - base[b]) * ti->num_bodies + j]) { why = "local index maps to the wrong particle"; return false; }
+					}
+					uint64_t h = mix(0xabcdef, cid);
+					for (uint32_t j = 0; j < ti->num_bodies; j++) h = mix(h, local[lb[j]]);
+					for (uint32_t j = 0; j < ti->num_bodies; j++) local[lb[j]] = mix(mix(h, j), local[lb[j]]);
+				}
+			}
+			for (uint32_t i = 0; i < t.n_owned; i++)
+			{
+				const uint32_t p = seg.gid[t.gid_off + i];
+				nxt[p] = local[i];
+				owner_count[p]++;
+			}
+		}
+		for (uint32_t p = 0; p < n; p++)
+			if (owner_count[p] != 1) { snprintf(msg, sizeof(msg), "particle %u owned by %u tiles", p, owner_count[p]); why = msg; return false; }
+		cur.swap(nxt);
+	}
+	if (expect_colour != plan.num_colours) { why = "segments do not cover all colours"; return false; }
+	for (uint32_t p = 0; p < n; p++)
+		if (cur[p] != want[p]) { snprintf(msg, sizeof(msg), "particle %u: fused schedule differs from the colour-sequential sweep", p); why = msg; return false; }
+	return true;
+}
+
+} // namespace pbdx

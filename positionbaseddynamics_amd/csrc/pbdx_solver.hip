@@ -1,301 +1,69 @@
-// pbdx_solver.hip -- the device engine: particle state in HBM, colour-batched
-// constraint schedule, HIP kernels for gfx950 and the substep loop.
+// pbdx_solver.hip -- the device engine: particle state in HBM, the colour-ordered constraint
+// schedule, HIP kernels for gfx950 and the substep loop.
 //
 // Replaces the inner loop of PBD::TimeStepController::step
 // (Simulation/TimeStepController.cpp:75-176) and positionConstraintProjection
 // (:251-295) of the reference for particle scenes.
 //
 // HBM layout
-//   pos [n] float4  (x, y, z, invMass)   gathered/scattered by every projection: ONE 16-byte
-//                                        access per endpoint instead of 3+1 scattered dwords
-//   vel [n] float4  (vx, vy, vz, mass)   streamed by integrate / velocity update only
-//   old [n] float4, last [n] float4      oldX / lastX (w unused)
-//   per (colour group, constraint type) batch:
-//     idx    [count] uint2 / uint4       particle indices of one constraint, one vector load per lane
-//     params [planes][count] float       planar (SoA) parameter streams -> lane-contiguous loads;
-//                                        parameters that are uniform over the batch (stiffness,
-//                                        material constants) are folded into kernel arguments
-//     lambda [count] float               XPBD multipliers (own stream; not read at iteration 0)
-// One launch = one (group, type) batch, one constraint per lane (wave64, 256-thread workgroups);
-// groups are launched in colour order on one stream (stream order = Gauss-Seidel order); one
-// substep (integrate, iterations x batches, velocity update) is captured into a hipGraph.
-// All kernels are HBM/L2-bound gather-scatter streams: no LDS reuse exists inside one colour
-// (every particle is touched by at most one constraint per colour), no MFMA.
+//   pos[2] [n] float4  (x, y, z, invMass)  double buffered; gathered/scattered by the projections:
+//                                          ONE 16-byte access per endpoint
+//   vel    [n] float4  (vx, vy, vz, mass)  streamed by integrate / velocity update only
+//   old [n] float4, last [n] float4        oldX / lastX (w unused)
+//
+// Two device schedules execute the same per-constraint code (pbdx_access.h / pbdx_project.h):
+//
+//  (A) colour-fused tiles (default; planner in pbdx_plan.cpp).  A run of consecutive colours is
+//      ONE launch: a workgroup stages the dependency closure of its tile of particles in LDS
+//      (float4 per particle, up to 160 KiB), sweeps its constraints colour by colour with a
+//      workgroup barrier between colours and writes back the particles it owns.  Per slot it
+//      streams 16-bit tile-local indices, the planar parameter records and the XPBD multiplier
+//      once from HBM; positions never leave the CU during the segment.  A 27-colour cloth sweep
+//      becomes 2-4 launches instead of 29.
+//  (B) one launch per (colour, type) batch straight on the HBM/L2-resident position array
+//      (32-bit indices).  Used when a plan cannot be built, for per-type profiling, and as the
+//      cross-check of (A) in the tests (the two are bit-identical by construction).
+//
+// One substep (integrate, iterations x schedule, velocity update) is captured into a hipGraph.
+// No MFMA: there is no dense contraction on this path; everything is gather/scatter streaming.
 #include <hip/hip_runtime.h>
 #include "pbdx_internal.h"
-#include "pbdx_project.h"
+#include "pbdx_access.h"
+#include "pbdx_plan.h"
 #include <algorithm>
 #include <string.h>
 
 using namespace pbdx;
 
-#define PBDX_MAX_PARAMS 24
-
 namespace {
 
-struct ParamView
-{
-	const float *base;        // planar parameter streams
-	uint32_t stride;          // floats per plane (= count rounded up to 4)
-	uint32_t umask;           // bit k set: parameter k is uniform over the batch -> u[k]
-	float u[PBDX_MAX_PARAMS];
-	uint8_t slot[PBDX_MAX_PARAMS];   // plane index of a non-uniform parameter
-};
-
+// ------------------------------------------------------------------------------------------------
+// (B) per-colour kernels
+// ------------------------------------------------------------------------------------------------
 struct BatchArgs
 {
 	float4 *pos;
 	const uint32_t *idx;
 	float *lambda;
-	ParamView pv;
+	const float *par;
+	uint32_t par_stride;
 	uint32_t count;
 	float dt;                 // substep size (XPBD compliance)
 	int first_iter;           // iteration 0 of a substep: lambda := 0 without reading it
 	uint32_t num_blocks;      // grid size (for the XCD-aware remap)
 	int xcd_remap;
+	TypeView view;
 };
-
-__device__ __forceinline__ float pget(const ParamView &pv, int k, uint32_t i)
-{
-	return ((pv.umask >> k) & 1u) ? pv.u[k] : pv.base[(size_t)pv.slot[k] * pv.stride + i];
-}
-
-__device__ __forceinline__ void ldp(const float4 *pos, uint32_t i, V3 &p, float &w)
-{
-	const float4 v = pos[i];
-	p = mk(v.x, v.y, v.z); w = v.w;
-}
-__device__ __forceinline__ void apply(float4 *pos, uint32_t i, V3 p, V3 c, float w)
-{
-	if (w != 0.0f)
-		pos[i] = make_float4(p.x + c.x, p.y + c.y, p.z + c.z, w);
-}
-
-struct QFull
-{
-	float q[16];   // column-major Q(j,k) = q[k*4+j]
-	__device__ __forceinline__ float operator()(int j, int k) const { return q[k * 4 + j]; }
-};
-
-template <int TYPE> __device__ __forceinline__ void project_one(const BatchArgs &a, uint32_t i);
-
-template <> __device__ __forceinline__ void project_one<PBDX_DISTANCE>(const BatchArgs &a, uint32_t i)
-{
-	const uint2 id = reinterpret_cast<const uint2 *>(a.idx)[i];
-	V3 p0, p1; float w0, w1;
-	ldp(a.pos, id.x, p0, w0); ldp(a.pos, id.y, p1, w1);
-	V3 c0, c1;
-	if (solve_distance(p0, w0, p1, w1, pget(a.pv, 0, i), pget(a.pv, 1, i), c0, c1))
-	{
-		apply(a.pos, id.x, p0, c0, w0); apply(a.pos, id.y, p1, c1, w1);
-	}
-}
-
-template <> __device__ __forceinline__ void project_one<PBDX_DISTANCE_XPBD>(const BatchArgs &a, uint32_t i)
-{
-	const uint2 id = reinterpret_cast<const uint2 *>(a.idx)[i];
-	V3 p0, p1; float w0, w1;
-	ldp(a.pos, id.x, p0, w0); ldp(a.pos, id.y, p1, w1);
-	float lambda = a.first_iter ? 0.0f : a.lambda[i];
-	V3 c0, c1;
-	if (solve_distance_xpbd(p0, w0, p1, w1, pget(a.pv, 0, i), pget(a.pv, 1, i), a.dt, lambda, c0, c1))
-	{
-		apply(a.pos, id.x, p0, c0, w0); apply(a.pos, id.y, p1, c1, w1);
-	}
-	a.lambda[i] = lambda;
-}
-
-template <> __device__ __forceinline__ void project_one<PBDX_DIHEDRAL>(const BatchArgs &a, uint32_t i)
-{
-	const uint4 id = reinterpret_cast<const uint4 *>(a.idx)[i];
-	V3 p0, p1, p2, p3; float w0, w1, w2, w3;
-	ldp(a.pos, id.x, p0, w0); ldp(a.pos, id.y, p1, w1); ldp(a.pos, id.z, p2, w2); ldp(a.pos, id.w, p3, w3);
-	V3 c0, c1, c2, c3;
-	if (solve_dihedral(p0, w0, p1, w1, p2, w2, p3, w3, pget(a.pv, 0, i), pget(a.pv, 1, i), c0, c1, c2, c3))
-	{
-		apply(a.pos, id.x, p0, c0, w0); apply(a.pos, id.y, p1, c1, w1); apply(a.pos, id.z, p2, c2, w2); apply(a.pos, id.w, p3, c3, w3);
-	}
-}
-
-template <> __device__ __forceinline__ void project_one<PBDX_ISOMETRIC_BENDING>(const BatchArgs &a, uint32_t i)
-{
-	const uint4 id = reinterpret_cast<const uint4 *>(a.idx)[i];
-	V3 p0, p1, p2, p3; float w0, w1, w2, w3;
-	ldp(a.pos, id.x, p0, w0); ldp(a.pos, id.y, p1, w1); ldp(a.pos, id.z, p2, w2); ldp(a.pos, id.w, p3, w3);
-	QFull q;
-#pragma unroll
-	for (int k = 0; k < 16; k++) q.q[k] = pget(a.pv, 1 + k, i);
-	V3 c0, c1, c2, c3;
-	if (solve_isometric_bending(p0, w0, p1, w1, p2, w2, p3, w3, q, pget(a.pv, 0, i), c0, c1, c2, c3))
-	{
-		apply(a.pos, id.x, p0, c0, w0); apply(a.pos, id.y, p1, c1, w1); apply(a.pos, id.z, p2, c2, w2); apply(a.pos, id.w, p3, c3, w3);
-	}
-}
-
-template <> __device__ __forceinline__ void project_one<PBDX_ISOMETRIC_BENDING_XPBD>(const BatchArgs &a, uint32_t i)
-{
-	const uint4 id = reinterpret_cast<const uint4 *>(a.idx)[i];
-	V3 p0, p1, p2, p3; float w0, w1, w2, w3;
-	ldp(a.pos, id.x, p0, w0); ldp(a.pos, id.y, p1, w1); ldp(a.pos, id.z, p2, w2); ldp(a.pos, id.w, p3, w3);
-	QFull q;
-#pragma unroll
-	for (int k = 0; k < 16; k++) q.q[k] = pget(a.pv, 1 + k, i);
-	float lambda = a.first_iter ? 0.0f : a.lambda[i];
-	V3 c0, c1, c2, c3;
-	if (solve_isometric_bending_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, q, pget(a.pv, 0, i), a.dt, lambda, c0, c1, c2, c3))
-	{
-		apply(a.pos, id.x, p0, c0, w0); apply(a.pos, id.y, p1, c1, w1); apply(a.pos, id.z, p2, c2, w2); apply(a.pos, id.w, p3, c3, w3);
-	}
-	a.lambda[i] = lambda;
-}
-
-template <> __device__ __forceinline__ void project_one<PBDX_FEM_TRIANGLE>(const BatchArgs &a, uint32_t i)
-{
-	const uint4 id = reinterpret_cast<const uint4 *>(a.idx)[i];
-	V3 p0, p1, p2; float w0, w1, w2;
-	ldp(a.pos, id.x, p0, w0); ldp(a.pos, id.y, p1, w1); ldp(a.pos, id.z, p2, w2);
-	float im[2][2];
-	im[0][0] = pget(a.pv, 1, i); im[1][0] = pget(a.pv, 2, i); im[0][1] = pget(a.pv, 3, i); im[1][1] = pget(a.pv, 4, i);
-	V3 c0, c1, c2;
-	if (solve_fem_triangle(p0, w0, p1, w1, p2, w2, pget(a.pv, 0, i), im, pget(a.pv, 5, i), pget(a.pv, 6, i), pget(a.pv, 7, i),
-		pget(a.pv, 8, i), pget(a.pv, 9, i), c0, c1, c2))
-	{
-		apply(a.pos, id.x, p0, c0, w0); apply(a.pos, id.y, p1, c1, w1); apply(a.pos, id.z, p2, c2, w2);
-	}
-}
-
-template <> __device__ __forceinline__ void project_one<PBDX_STRAIN_TRIANGLE>(const BatchArgs &a, uint32_t i)
-{
-	const uint4 id = reinterpret_cast<const uint4 *>(a.idx)[i];
-	V3 p0, p1, p2; float w0, w1, w2;
-	ldp(a.pos, id.x, p0, w0); ldp(a.pos, id.y, p1, w1); ldp(a.pos, id.z, p2, w2);
-	float im[2][2];
-	im[0][0] = pget(a.pv, 0, i); im[1][0] = pget(a.pv, 1, i); im[0][1] = pget(a.pv, 2, i); im[1][1] = pget(a.pv, 3, i);
-	V3 c0, c1, c2;
-	if (solve_strain_triangle(p0, w0, p1, w1, p2, w2, im, pget(a.pv, 4, i), pget(a.pv, 5, i), pget(a.pv, 6, i),
-		pget(a.pv, 7, i) != 0.0f, pget(a.pv, 8, i) != 0.0f, c0, c1, c2))
-	{
-		apply(a.pos, id.x, p0, c0, w0); apply(a.pos, id.y, p1, c1, w1); apply(a.pos, id.z, p2, c2, w2);
-	}
-}
-
-template <> __device__ __forceinline__ void project_one<PBDX_VOLUME>(const BatchArgs &a, uint32_t i)
-{
-	const uint4 id = reinterpret_cast<const uint4 *>(a.idx)[i];
-	V3 p0, p1, p2, p3; float w0, w1, w2, w3;
-	ldp(a.pos, id.x, p0, w0); ldp(a.pos, id.y, p1, w1); ldp(a.pos, id.z, p2, w2); ldp(a.pos, id.w, p3, w3);
-	V3 c0, c1, c2, c3;
-	if (solve_volume(p0, w0, p1, w1, p2, w2, p3, w3, pget(a.pv, 0, i), pget(a.pv, 1, i), c0, c1, c2, c3))
-	{
-		apply(a.pos, id.x, p0, c0, w0); apply(a.pos, id.y, p1, c1, w1); apply(a.pos, id.z, p2, c2, w2); apply(a.pos, id.w, p3, c3, w3);
-	}
-}
-
-template <> __device__ __forceinline__ void project_one<PBDX_VOLUME_XPBD>(const BatchArgs &a, uint32_t i)
-{
-	const uint4 id = reinterpret_cast<const uint4 *>(a.idx)[i];
-	V3 p0, p1, p2, p3; float w0, w1, w2, w3;
-	ldp(a.pos, id.x, p0, w0); ldp(a.pos, id.y, p1, w1); ldp(a.pos, id.z, p2, w2); ldp(a.pos, id.w, p3, w3);
-	float lambda = a.first_iter ? 0.0f : a.lambda[i];
-	V3 c0, c1, c2, c3;
-	if (solve_volume_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, pget(a.pv, 0, i), pget(a.pv, 1, i), a.dt, lambda, c0, c1, c2, c3))
-	{
-		apply(a.pos, id.x, p0, c0, w0); apply(a.pos, id.y, p1, c1, w1); apply(a.pos, id.z, p2, c2, w2); apply(a.pos, id.w, p3, c3, w3);
-	}
-	a.lambda[i] = lambda;
-}
-
-__device__ __forceinline__ M3 load_m3(const ParamView &pv, int first, uint32_t i)
-{
-	M3 A;
-#pragma unroll
-	for (int c = 0; c < 3; c++)
-#pragma unroll
-		for (int r = 0; r < 3; r++) A.m[r][c] = pget(pv, first + c * 3 + r, i);
-	return A;
-}
-
-template <> __device__ __forceinline__ void project_one<PBDX_FEM_TET>(const BatchArgs &a, uint32_t i)
-{
-	const uint4 id = reinterpret_cast<const uint4 *>(a.idx)[i];
-	V3 p0, p1, p2, p3; float w0, w1, w2, w3;
-	ldp(a.pos, id.x, p0, w0); ldp(a.pos, id.y, p1, w1); ldp(a.pos, id.z, p2, w2); ldp(a.pos, id.w, p3, w3);
-	const float vol = pget(a.pv, 0, i);
-	const M3 im = load_m3(a.pv, 1, i);
-	const bool hi = fem_tet_handle_inversion(p0, p1, p2, p3, vol);
-	V3 c0, c1, c2, c3;
-	if (solve_fem_tet(p0, w0, p1, w1, p2, w2, p3, w3, vol, im, pget(a.pv, 10, i), pget(a.pv, 11, i), hi, c0, c1, c2, c3))
-	{
-		apply(a.pos, id.x, p0, c0, w0); apply(a.pos, id.y, p1, c1, w1); apply(a.pos, id.z, p2, c2, w2); apply(a.pos, id.w, p3, c3, w3);
-	}
-}
-
-template <> __device__ __forceinline__ void project_one<PBDX_FEM_TET_XPBD>(const BatchArgs &a, uint32_t i)
-{
-	const uint4 id = reinterpret_cast<const uint4 *>(a.idx)[i];
-	V3 p0, p1, p2, p3; float w0, w1, w2, w3;
-	ldp(a.pos, id.x, p0, w0); ldp(a.pos, id.y, p1, w1); ldp(a.pos, id.z, p2, w2); ldp(a.pos, id.w, p3, w3);
-	const float vol = pget(a.pv, 0, i);
-	const M3 im = load_m3(a.pv, 1, i);
-	const bool hi = fem_tet_handle_inversion(p0, p1, p2, p3, vol);
-	float lambda = a.first_iter ? 0.0f : a.lambda[i];
-	V3 c0, c1, c2, c3;
-	if (solve_fem_tet_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, vol, im, pget(a.pv, 10, i), pget(a.pv, 11, i), hi, a.dt, lambda, c0, c1, c2, c3))
-	{
-		apply(a.pos, id.x, p0, c0, w0); apply(a.pos, id.y, p1, c1, w1); apply(a.pos, id.z, p2, c2, w2); apply(a.pos, id.w, p3, c3, w3);
-	}
-	a.lambda[i] = lambda;
-}
-
-template <> __device__ __forceinline__ void project_one<PBDX_STRAIN_TET>(const BatchArgs &a, uint32_t i)
-{
-	const uint4 id = reinterpret_cast<const uint4 *>(a.idx)[i];
-	V3 p0, p1, p2, p3; float w0, w1, w2, w3;
-	ldp(a.pos, id.x, p0, w0); ldp(a.pos, id.y, p1, w1); ldp(a.pos, id.z, p2, w2); ldp(a.pos, id.w, p3, w3);
-	const M3 im = load_m3(a.pv, 0, i);
-	V3 c0, c1, c2, c3;
-	if (solve_strain_tet(p0, w0, p1, w1, p2, w2, p3, w3, im, pget(a.pv, 9, i), pget(a.pv, 10, i),
-		pget(a.pv, 11, i) != 0.0f, pget(a.pv, 12, i) != 0.0f, c0, c1, c2, c3))
-	{
-		apply(a.pos, id.x, p0, c0, w0); apply(a.pos, id.y, p1, c1, w1); apply(a.pos, id.z, p2, c2, w2); apply(a.pos, id.w, p3, c3, w3);
-	}
-}
-
-template <> __device__ __forceinline__ void project_one<PBDX_SHAPE_MATCHING>(const BatchArgs &a, uint32_t i)
-{
-	const uint4 id = reinterpret_cast<const uint4 *>(a.idx)[i];
-	const uint32_t ids[4] = { id.x, id.y, id.z, id.w };
-	V3 x[4], x0[4], corr[4]; float wl[4], w[4];
-#pragma unroll
-	for (int k = 0; k < 4; k++)
-	{
-		ldp(a.pos, ids[k], x[k], wl[k]);
-		x0[k] = mk(pget(a.pv, 4 + 3 * k, i), pget(a.pv, 5 + 3 * k, i), pget(a.pv, 6 + 3 * k, i));
-		w[k] = pget(a.pv, 16 + k, i);
-	}
-	const V3 restCm = mk(pget(a.pv, 1, i), pget(a.pv, 2, i), pget(a.pv, 3, i));
-	if (solve_shape_matching4(x0, x, w, restCm, pget(a.pv, 0, i), corr))
-	{
-#pragma unroll
-		for (int k = 0; k < 4; k++)
-		{
-			// (1.0 / m_numClusters[i]) * m_corr[i]   Constraints.cpp:2024 (double quotient narrowed to Real)
-			const float f = (float)(1.0 / (double)(unsigned int)pget(a.pv, 20 + k, i));
-			if (w[k] != 0.0f)
-				a.pos[ids[k]] = make_float4(x[k].x + f * corr[k].x, x[k].y + f * corr[k].y, x[k].z + f * corr[k].z, wl[k]);
-		}
-	}
-}
 
 // blockIdx -> logical block: with xcd_remap the 8 XCDs (hardware places block b on XCD b%8) each
-// walk one contiguous eighth of the batch, so the particles a chiplet touches stay the same
-// from colour to colour (per-XCD L2 locality); speed only, never correctness.
-__device__ __forceinline__ uint32_t logical_block(const BatchArgs &a)
+// walk one contiguous eighth of the batch / of the tile list, so the particles a chiplet touches
+// stay the same from launch to launch (per-XCD L2 locality); speed only, never correctness.
+__device__ __forceinline__ uint32_t logical_block(uint32_t num_blocks, int xcd_remap)
 {
 	const uint32_t b = blockIdx.x;
-	if (!a.xcd_remap || a.num_blocks < 16)
+	if (!xcd_remap || num_blocks < 16)
 		return b;
-	const uint32_t per = a.num_blocks >> 3;          // full blocks per XCD
+	const uint32_t per = num_blocks >> 3;          // full blocks per XCD
 	const uint32_t body = per << 3;
 	if (b >= body)
 		return b;                                    // remainder blocks keep their place at the end
@@ -305,21 +73,113 @@ __device__ __forceinline__ uint32_t logical_block(const BatchArgs &a)
 template <int TYPE>
 __global__ __launch_bounds__(256) void project_kernel(BatchArgs a)
 {
-	const uint32_t i = logical_block(a) * blockDim.x + threadIdx.x;
+	const uint32_t i = logical_block(a.num_blocks, a.xcd_remap) * blockDim.x + threadIdx.x;
 	if (i < a.count)
-		project_one<TYPE>(a, i);
+	{
+		const GlobalAccess acc = { a.pos, a.idx, a.par, a.par_stride, a.lambda, a.view };
+		Project<TYPE, GlobalAccess>::run(acc, i, a.dt, a.first_iter);
+	}
 }
 
+typedef void (*project_fn)(BatchArgs);
+project_fn kProjectKernels[PBDX_NUM_CONSTRAINT_TYPES] = {
+	project_kernel<PBDX_DISTANCE>, project_kernel<PBDX_DISTANCE_XPBD>, project_kernel<PBDX_DIHEDRAL>,
+	project_kernel<PBDX_ISOMETRIC_BENDING>, project_kernel<PBDX_ISOMETRIC_BENDING_XPBD>,
+	project_kernel<PBDX_FEM_TRIANGLE>, project_kernel<PBDX_STRAIN_TRIANGLE>,
+	project_kernel<PBDX_VOLUME>, project_kernel<PBDX_VOLUME_XPBD>,
+	project_kernel<PBDX_FEM_TET>, project_kernel<PBDX_FEM_TET_XPBD>, project_kernel<PBDX_STRAIN_TET>,
+	project_kernel<PBDX_SHAPE_MATCHING>,
+};
+
+// ------------------------------------------------------------------------------------------------
+// (A) colour-fused tile kernel
+// ------------------------------------------------------------------------------------------------
+struct FusedArgs
+{
+	const float4 *pos_in;
+	float4 *pos_out;
+	const FusedTile *tiles;
+	const FusedStep *steps;
+	const uint16_t *idx;
+	const float *params;
+	float *lambda;
+	const uint32_t *gid;
+	float dt;
+	int first_iter;
+	uint32_t num_tiles;
+	int xcd_remap;
+	TypeView views[PBDX_NUM_CONSTRAINT_TYPES];
+};
+
+template <int TYPE, int BLOCK>
+__device__ __forceinline__ void run_step(const FusedArgs &a, const FusedStep &st, float4 *lpos)
+{
+	const TileAccess acc = { lpos, a.idx + st.idx_off, a.params + st.par_off, st.par_stride, a.lambda + st.lam_off, a.views[TYPE] };
+	for (uint32_t q = threadIdx.x; q < st.count; q += BLOCK)
+		Project<TYPE, TileAccess>::run(acc, q, a.dt, a.first_iter);
+}
+
+#define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) run_step<T, BLOCK>(a, st, lpos); break;
+
+template <uint32_t MASK, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
+{
+	extern __shared__ float4 lpos[];
+	const FusedTile t = a.tiles[logical_block(a.num_tiles, a.xcd_remap)];
+	const uint32_t *gid = a.gid + t.gid_off;
+	for (uint32_t i = threadIdx.x; i < t.n_local; i += BLOCK)
+		lpos[i] = a.pos_in[gid[i]];
+	__syncthreads();
+	for (uint32_t s = t.step_begin; s < t.step_end; s++)
+	{
+		const FusedStep st = a.steps[s];
+		switch (st.type)
+		{
+			PBDX_CASE(PBDX_DISTANCE) PBDX_CASE(PBDX_DISTANCE_XPBD) PBDX_CASE(PBDX_DIHEDRAL)
+			PBDX_CASE(PBDX_ISOMETRIC_BENDING) PBDX_CASE(PBDX_ISOMETRIC_BENDING_XPBD)
+			PBDX_CASE(PBDX_FEM_TRIANGLE) PBDX_CASE(PBDX_STRAIN_TRIANGLE)
+			PBDX_CASE(PBDX_VOLUME) PBDX_CASE(PBDX_VOLUME_XPBD)
+			PBDX_CASE(PBDX_FEM_TET) PBDX_CASE(PBDX_FEM_TET_XPBD) PBDX_CASE(PBDX_STRAIN_TET)
+			PBDX_CASE(PBDX_SHAPE_MATCHING)
+		default: break;
+		}
+		if (st.barrier)
+			__syncthreads();
+	}
+	for (uint32_t i = threadIdx.x; i < t.n_owned; i += BLOCK)
+		a.pos_out[gid[i]] = lpos[i];
+}
+
+typedef void (*fused_fn)(FusedArgs);
+constexpr uint32_t kMaskClothXpbd = (1u << PBDX_DISTANCE_XPBD) | (1u << PBDX_ISOMETRIC_BENDING_XPBD);
+constexpr uint32_t kMaskLight = (1u << PBDX_DISTANCE) | (1u << PBDX_DISTANCE_XPBD) | (1u << PBDX_ISOMETRIC_BENDING) |
+	(1u << PBDX_ISOMETRIC_BENDING_XPBD) | (1u << PBDX_VOLUME) | (1u << PBDX_VOLUME_XPBD) | (1u << PBDX_DIHEDRAL);
+constexpr uint32_t kMaskAll = (1u << PBDX_NUM_CONSTRAINT_TYPES) - 1u;
+
+fused_fn pick_fused_kernel(uint32_t mask, int block)
+{
+	if ((mask & ~kMaskClothXpbd) == 0)
+		return block == 1024 ? fused_kernel<kMaskClothXpbd, 1024> : block == 512 ? fused_kernel<kMaskClothXpbd, 512> : fused_kernel<kMaskClothXpbd, 256>;
+	if ((mask & ~kMaskLight) == 0)
+		return block == 1024 ? fused_kernel<kMaskLight, 1024> : block == 512 ? fused_kernel<kMaskLight, 512> : fused_kernel<kMaskLight, 256>;
+	// heavy types (FEM / strain / shape matching) need > 128 VGPRs: at most 512 threads per workgroup
+	return block >= 512 ? fused_kernel<kMaskAll, 512> : fused_kernel<kMaskAll, 256>;
+}
+
+// ------------------------------------------------------------------------------------------------
+// particle kernels
+// ------------------------------------------------------------------------------------------------
 // lastX <- oldX; oldX <- x; semi-implicit Euler for dynamic particles
 // TimeStepController.cpp:112-118 + TimeIntegration.cpp:7-19 (acceleration == gravity for every
-// dynamic particle, TimeStep.cpp:28-62)
-__global__ __launch_bounds__(256) void integrate_kernel(float4 *__restrict__ pos, float4 *__restrict__ vel,
+// dynamic particle, TimeStep.cpp:28-62).  Reads pos_in, writes pos_out (the same buffer, or the
+// buffer the first fused segment of the substep reads).
+__global__ __launch_bounds__(256) void integrate_kernel(const float4 *pos_in, float4 *pos_out, float4 *__restrict__ vel,
 	float4 *__restrict__ old, float4 *__restrict__ last, uint32_t n, float h, float gx, float gy, float gz)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const float4 o = old[i];
-	float4 p = pos[i];
+	float4 p = pos_in[i];
 	last[i] = o;
 	old[i] = p;
 	float4 v = vel[i];
@@ -328,8 +188,8 @@ __global__ __launch_bounds__(256) void integrate_kernel(float4 *__restrict__ pos
 		v.x = v.x + gx * h; v.y = v.y + gy * h; v.z = v.z + gz * h;
 		p.x = p.x + v.x * h; p.y = p.y + v.y * h; p.z = p.z + v.z * h;
 		vel[i] = v;
-		pos[i] = p;
 	}
+	pos_out[i] = p;
 }
 
 // TimeIntegration::velocityUpdateFirstOrder / SecondOrder  TimeIntegration.cpp:42-51, 69-79
@@ -356,16 +216,6 @@ __global__ __launch_bounds__(256) void velocity_kernel(const float4 *__restrict_
 	vel[i] = v;
 }
 
-typedef void (*project_fn)(BatchArgs);
-project_fn kProjectKernels[PBDX_NUM_CONSTRAINT_TYPES] = {
-	project_kernel<PBDX_DISTANCE>, project_kernel<PBDX_DISTANCE_XPBD>, project_kernel<PBDX_DIHEDRAL>,
-	project_kernel<PBDX_ISOMETRIC_BENDING>, project_kernel<PBDX_ISOMETRIC_BENDING_XPBD>,
-	project_kernel<PBDX_FEM_TRIANGLE>, project_kernel<PBDX_STRAIN_TRIANGLE>,
-	project_kernel<PBDX_VOLUME>, project_kernel<PBDX_VOLUME_XPBD>,
-	project_kernel<PBDX_FEM_TET>, project_kernel<PBDX_FEM_TET_XPBD>, project_kernel<PBDX_STRAIN_TET>,
-	project_kernel<PBDX_SHAPE_MATCHING>,
-};
-
 struct Batch
 {
 	int type = 0;
@@ -375,8 +225,30 @@ struct Batch
 	uint32_t *d_idx = nullptr;
 	float *d_params = nullptr;
 	float *d_lambda = nullptr;
-	ParamView pv;                   // base filled in after upload
-	std::vector<uint32_t> h_idx;    // kept for validate_schedule
+	uint32_t par_stride = 0;
+	TypeView view;
+	std::vector<uint32_t> h_idx;    // kept for validate_schedule and the planner
+	std::vector<float> h_params;    // kept until the fused plan is built
+};
+
+struct DeviceSegment
+{
+	FusedTile *d_tiles = nullptr;
+	FusedStep *d_steps = nullptr;
+	uint16_t *d_idx = nullptr;
+	float *d_params = nullptr;
+	float *d_lambda = nullptr;
+	uint32_t *d_gid = nullptr;
+	uint32_t num_tiles = 0;
+	uint32_t lds_bytes = 0;
+	uint32_t type_mask = 0;
+	uint64_t algorithmic_bytes = 0;  // SURVEY 8d bytes of the DISTINCT constraints of the segment
+	uint64_t constraints = 0;
+	fused_fn kernel = nullptr;
+	int block = 0;
+	// profiling
+	double ms = 0.0;
+	uint64_t launches = 0;
 };
 
 #define HIPCHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -390,7 +262,9 @@ struct pbdx_solver
 	hipStream_t stream = nullptr;
 	hipDeviceProp_t prop;
 	uint32_t n = 0;
-	float4 *d_pos = nullptr, *d_vel = nullptr, *d_old = nullptr, *d_last = nullptr;
+	float4 *d_pos[2] = { nullptr, nullptr };
+	float4 *d_vel = nullptr, *d_old = nullptr, *d_last = nullptr;
+	std::vector<float> h_x;              // positions at upload time (tile partition only)
 	std::vector<Batch> batches;          // in add order
 	std::vector<uint32_t> order;         // batch indices sorted by (group, seq)
 	bool schedule_open = false;
@@ -399,13 +273,25 @@ struct pbdx_solver
 	// options
 	int use_graph = 1;
 	int block_size = 256;
-	int xcd_remap = 0;
+	int xcd_remap = 1;
 	int profile = 0;
+	int fuse = 1;
+	uint32_t tile_particles = 0;
+	int fuse_block = 0;                  // 0 = auto
+	uint32_t max_segment_colours = 16;
+	uint32_t lds_particles = 10240;
+
+	// fused plan
+	FusedPlan plan;
+	std::vector<DeviceSegment> dsegs;
+	bool plan_built = false;             // an attempt was made for the current schedule
+	bool plan_ok = false;
+	std::string plan_why;
 
 	// cached graph of one substep
 	hipGraph_t graph = nullptr;
 	hipGraphExec_t graph_exec = nullptr;
-	struct GraphKey { float h; uint32_t iters; int vel; float g[3]; uint64_t sched; int block; int remap; uint32_t n; } key = {};
+	struct GraphKey { float h; uint32_t iters; int vel; float g[3]; uint64_t sched; int block; int remap; uint32_t n; int fused; } key = {};
 	bool graph_valid = false;
 
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -415,6 +301,23 @@ struct pbdx_solver
 	uint64_t type_launches[PBDX_NUM_CONSTRAINT_TYPES] = {};
 	uint64_t type_projections[PBDX_NUM_CONSTRAINT_TYPES] = {};
 
+	void free_plan()
+	{
+		for (DeviceSegment &d : dsegs)
+		{
+			if (d.d_tiles) (void)hipFree(d.d_tiles);
+			if (d.d_steps) (void)hipFree(d.d_steps);
+			if (d.d_idx) (void)hipFree(d.d_idx);
+			if (d.d_params) (void)hipFree(d.d_params);
+			if (d.d_lambda) (void)hipFree(d.d_lambda);
+			if (d.d_gid) (void)hipFree(d.d_gid);
+		}
+		dsegs.clear();
+		plan = FusedPlan();
+		plan_built = false;
+		plan_ok = false;
+		plan_why.clear();
+	}
 	void free_batches()
 	{
 		for (Batch &b : batches)
@@ -425,6 +328,7 @@ struct pbdx_solver
 		}
 		batches.clear();
 		order.clear();
+		free_plan();
 	}
 	void drop_graph()
 	{
@@ -434,21 +338,108 @@ struct pbdx_solver
 	}
 	void free_particles()
 	{
-		for (float4 **p : { &d_pos, &d_vel, &d_old, &d_last })
+		for (float4 **p : { &d_pos[0], &d_pos[1], &d_vel, &d_old, &d_last })
 			if (*p) { (void)hipFree(*p); *p = nullptr; }
 		n = 0;
 	}
+	bool fused_active() const { return fuse && plan_ok && !dsegs.empty(); }
 };
 
 namespace {
 
+template <class T> int upload(T **dst, const std::vector<T> &src)
+{
+	*dst = nullptr;
+	if (src.empty()) return PBDX_OK;
+	HIPCHECK(hipMalloc(dst, src.size() * sizeof(T)));
+	HIPCHECK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+	return PBDX_OK;
+}
+
+// Build the colour-fused plan for the current schedule + particle positions and upload it.
+// A failure is not an error: the engine keeps schedule (B).
+int ensure_plan(pbdx_solver *s)
+{
+	if (!s->fuse || s->plan_built) return PBDX_OK;
+	s->plan_built = true;
+	s->plan_ok = false;
+	if (s->order.empty() || s->n == 0 || s->h_x.size() != (size_t)3 * s->n) { s->plan_why = "no schedule / particles"; return PBDX_OK; }
+	std::vector<PlanBatch> pbs;
+	uint32_t colour = 0;
+	for (size_t oi = 0; oi < s->order.size(); oi++)
+	{
+		const Batch &b = s->batches[s->order[oi]];
+		if (oi && b.group != s->batches[s->order[oi - 1]].group) colour++;
+		if (b.h_params.empty() && type_info(b.type)->param_stride) { s->plan_why = "host parameters released"; return PBDX_OK; }
+		pbs.push_back({ b.type, colour, b.count, b.h_idx.data(), b.h_params.data() });
+	}
+	PlanOptions opt;
+	opt.tile_particles = s->tile_particles;
+	{
+		const size_t lds = s->prop.maxSharedMemoryPerMultiProcessor ? s->prop.maxSharedMemoryPerMultiProcessor : s->prop.sharedMemPerBlock;
+		opt.max_local = std::min<uint32_t>(s->lds_particles, (uint32_t)(lds / 16));
+	}
+	opt.num_cus = (uint32_t)std::max(1, s->prop.multiProcessorCount);
+	opt.max_segment_colours = s->max_segment_colours;
+	if (!build_fused_plan(s->n, s->h_x.data(), pbs, opt, s->plan, s->plan_why))
+		return PBDX_OK;
+	// per-segment device image
+	for (const FusedSegment &seg : s->plan.segs)
+	{
+		DeviceSegment d;
+		int r = upload(&d.d_tiles, seg.tiles);
+		if (!r) r = upload(&d.d_steps, seg.steps);
+		if (!r) r = upload(&d.d_idx, seg.idx);
+		if (!r) r = upload(&d.d_params, seg.params);
+		if (!r) r = upload(&d.d_gid, seg.gid);
+		if (r)
+		{
+			s->dsegs.push_back(d);
+			s->free_plan();
+			s->plan_built = true;
+			return r;
+		}
+		if (seg.lam_count)
+		{
+			HIPCHECK(hipMalloc(&d.d_lambda, (size_t)seg.lam_count * sizeof(float)));
+			HIPCHECK(hipMemset(d.d_lambda, 0, (size_t)seg.lam_count * sizeof(float)));
+		}
+		d.num_tiles = (uint32_t)seg.tiles.size();
+		d.lds_bytes = std::max(seg.max_local, 1u) * 16u;
+		d.type_mask = seg.type_mask;
+		d.constraints = seg.constraints;
+		for (const PlanBatch &pb : pbs)
+			if (pb.colour >= seg.colour_begin && pb.colour < seg.colour_end)
+				d.algorithmic_bytes += (uint64_t)pb.count * type_info(pb.type)->algorithmic_bytes;
+		int block = s->fuse_block;
+		if (block != 256 && block != 512 && block != 1024)
+		{
+			// auto: enough threads to cover the largest colour step of a tile once, at most 1024
+			uint32_t widest = 0;
+			for (const FusedStep &st : seg.steps) widest = std::max(widest, st.count);
+			block = widest > 512 ? 1024 : widest > 256 ? 512 : 256;
+		}
+		if ((seg.type_mask & ~kMaskLight) && block > 512) block = 512;
+		d.block = block;
+		d.kernel = pick_fused_kernel(seg.type_mask, block);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(d.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
+		s->dsegs.push_back(d);
+	}
+	// the planner's copies of the parameter records are no longer needed
+	for (Batch &b : s->batches) { std::vector<float>().swap(b.h_params); }
+	s->plan_ok = true;
+	return PBDX_OK;
+}
+
 int launch_batch(pbdx_solver *s, const Batch &b, float dt, int first_iter)
 {
 	BatchArgs a;
-	a.pos = s->d_pos;
+	a.pos = s->d_pos[0];
 	a.idx = b.d_idx;
 	a.lambda = b.d_lambda;
-	a.pv = b.pv;
+	a.par = b.d_params;
+	a.par_stride = b.par_stride;
+	a.view = b.view;
 	a.count = b.count;
 	a.dt = dt;
 	a.first_iter = first_iter;
@@ -460,11 +451,29 @@ int launch_batch(pbdx_solver *s, const Batch &b, float dt, int first_iter)
 	return PBDX_OK;
 }
 
+int launch_segment(pbdx_solver *s, size_t si, int src, float dt, int first_iter)
+{
+	const DeviceSegment &d = s->dsegs[si];
+	FusedArgs a;
+	a.pos_in = s->d_pos[src];
+	a.pos_out = s->d_pos[src ^ 1];
+	a.tiles = d.d_tiles; a.steps = d.d_steps; a.idx = d.d_idx; a.params = d.d_params; a.lambda = d.d_lambda; a.gid = d.d_gid;
+	a.dt = dt;
+	a.first_iter = first_iter;
+	a.num_tiles = d.num_tiles;
+	a.xcd_remap = s->xcd_remap;
+	memcpy(a.views, s->plan.views, sizeof(a.views));
+	hipLaunchKernelGGL(d.kernel, dim3(d.num_tiles), dim3(d.block), d.lds_bytes, s->stream, a);
+	HIPCHECK(hipGetLastError());
+	return PBDX_OK;
+}
+
 // event bookkeeping for the profiled (eager) mode: one event before every projection launch and
 // one after the last launch of a sweep; elapsed(e[i], e[i+1]) is charged to launch i.
-struct ProfCursor { pbdx_solver *s; size_t next = 0; std::vector<int> types; std::vector<uint32_t> counts; };
+// kind >= 0: constraint type of a per-colour launch; kind <= -2: fused segment (-2 - kind); -1: end marker
+struct ProfCursor { pbdx_solver *s; size_t next = 0; std::vector<int> kinds; std::vector<uint32_t> counts; };
 
-int prof_mark(ProfCursor *pc)
+int prof_mark(ProfCursor *pc, int kind, uint32_t count)
 {
 	pbdx_solver *s = pc->s;
 	if (pc->next >= s->prof_events.size())
@@ -474,20 +483,44 @@ int prof_mark(ProfCursor *pc)
 		s->prof_events.push_back(e);
 	}
 	HIPCHECK(hipEventRecord(s->prof_events[pc->next++], s->stream));
+	pc->kinds.push_back(kind);
+	pc->counts.push_back(count);
 	return PBDX_OK;
 }
 
-int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, ProfCursor *pc)
+// number of position-buffer flips of `iterations` sweeps
+inline uint32_t sweep_flips(const pbdx_solver *s, uint32_t iterations)
 {
-	for (uint32_t it = 0; it < iterations; it++)
-		for (uint32_t bi : s->order)
-		{
-			const Batch &b = s->batches[bi];
-			if (pc) { int r = prof_mark(pc); if (r) return r; pc->types.push_back(b.type); pc->counts.push_back(b.count); }
-			int r = launch_batch(s, b, dt, it == 0);
-			if (r) return r;
-		}
-	if (pc) { int r = prof_mark(pc); if (r) return r; pc->types.push_back(-1); pc->counts.push_back(0); }
+	return s->fused_active() ? (uint32_t)(((uint64_t)iterations * s->dsegs.size()) & 1u) : 0u;
+}
+
+// `iterations` Gauss-Seidel sweeps over the schedule.  Fused: reads buffer `src`, ends in buffer
+// src ^ sweep_flips().  Per-colour: in place on buffer 0 (src must be 0).
+int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, ProfCursor *pc)
+{
+	if (s->fused_active())
+	{
+		for (uint32_t it = 0; it < iterations; it++)
+			for (size_t si = 0; si < s->dsegs.size(); si++)
+			{
+				if (pc) { int r = prof_mark(pc, -2 - (int)si, (uint32_t)s->dsegs[si].constraints); if (r) return r; }
+				int r = launch_segment(s, si, src, dt, it == 0);
+				if (r) return r;
+				src ^= 1;
+			}
+	}
+	else
+	{
+		for (uint32_t it = 0; it < iterations; it++)
+			for (uint32_t bi : s->order)
+			{
+				const Batch &b = s->batches[bi];
+				if (pc) { int r = prof_mark(pc, b.type, b.count); if (r) return r; }
+				int r = launch_batch(s, b, dt, it == 0);
+				if (r) return r;
+			}
+	}
+	if (pc) { int r = prof_mark(pc, -1, 0); if (r) return r; }
 	return PBDX_OK;
 }
 
@@ -495,16 +528,19 @@ int enqueue_substep(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int v
 {
 	const uint32_t bs = 256;
 	const uint32_t nb = (s->n + bs - 1) / bs;
+	// the state lives in buffer 0 between substeps; integrate writes the buffer from which an odd
+	// number of fused launches ends in buffer 0 again
+	const int start = (int)sweep_flips(s, iters);
 	if (s->n)
 	{
-		hipLaunchKernelGGL(integrate_kernel, dim3(nb), dim3(bs), 0, s->stream, s->d_pos, s->d_vel, s->d_old, s->d_last, s->n, hs, g[0], g[1], g[2]);
+		hipLaunchKernelGGL(integrate_kernel, dim3(nb), dim3(bs), 0, s->stream, s->d_pos[0], s->d_pos[start], s->d_vel, s->d_old, s->d_last, s->n, hs, g[0], g[1], g[2]);
 		HIPCHECK(hipGetLastError());
 	}
-	int r = projection_sweeps(s, hs, iters, pc);
+	int r = projection_sweeps(s, hs, iters, start, pc);
 	if (r) return r;
 	if (s->n)
 	{
-		hipLaunchKernelGGL(velocity_kernel, dim3(nb), dim3(bs), 0, s->stream, s->d_pos, s->d_vel, s->d_old, s->d_last, s->n, inv_h, vel != 0);
+		hipLaunchKernelGGL(velocity_kernel, dim3(nb), dim3(bs), 0, s->stream, s->d_pos[0], s->d_vel, s->d_old, s->d_last, s->n, inv_h, vel != 0);
 		HIPCHECK(hipGetLastError());
 	}
 	return PBDX_OK;
@@ -515,13 +551,22 @@ int collect_profile(pbdx_solver *s, ProfCursor *pc)
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	for (size_t i = 0; i + 1 < pc->next; i++)
 	{
-		const int t = pc->types[i];
-		if (t < 0) continue;
+		const int t = pc->kinds[i];
+		if (t == -1) continue;
 		float ms = 0.0f;
 		HIPCHECK(hipEventElapsedTime(&ms, s->prof_events[i], s->prof_events[i + 1]));
-		s->type_ms[t] += ms;
-		s->type_launches[t]++;
-		s->type_projections[t] += pc->counts[i];
+		if (t >= 0)
+		{
+			s->type_ms[t] += ms;
+			s->type_launches[t]++;
+			s->type_projections[t] += pc->counts[i];
+		}
+		else
+		{
+			DeviceSegment &d = s->dsegs[(size_t)(-2 - t)];
+			d.ms += ms;
+			d.launches++;
+		}
 		s->stats.projection_ms += ms;
 		s->stats.projection_launches++;
 	}
@@ -593,9 +638,11 @@ int pbdx_solver_set_particles(pbdx_solver *s, uint32_t n, const float *x, const 
 		HIPCHECK(hipStreamSynchronize(s->stream));
 		s->free_particles();
 		s->drop_graph();
+		s->free_plan();
 		if (n)
 		{
-			HIPCHECK(hipMalloc(&s->d_pos, (size_t)n * sizeof(float4)));
+			HIPCHECK(hipMalloc(&s->d_pos[0], (size_t)n * sizeof(float4)));
+			HIPCHECK(hipMalloc(&s->d_pos[1], (size_t)n * sizeof(float4)));
 			HIPCHECK(hipMalloc(&s->d_vel, (size_t)n * sizeof(float4)));
 			HIPCHECK(hipMalloc(&s->d_old, (size_t)n * sizeof(float4)));
 			HIPCHECK(hipMalloc(&s->d_last, (size_t)n * sizeof(float4)));
@@ -603,9 +650,10 @@ int pbdx_solver_set_particles(pbdx_solver *s, uint32_t n, const float *x, const 
 		s->n = n;
 	}
 	if (!n) return PBDX_OK;
+	if (!s->plan_ok) s->h_x.assign(x, x + (size_t)3 * n);     // tile partition input (first upload wins)
 	std::vector<float4> tmp(n);
 	for (uint32_t i = 0; i < n; i++) tmp[i] = make_float4(x[3 * i], x[3 * i + 1], x[3 * i + 2], inv_mass[i]);
-	HIPCHECK(hipMemcpyAsync(s->d_pos, tmp.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+	HIPCHECK(hipMemcpyAsync(s->d_pos[0], tmp.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	for (uint32_t i = 0; i < n; i++)
 		tmp[i] = v ? make_float4(v[3 * i], v[3 * i + 1], v[3 * i + 2], mass[i]) : make_float4(0.0f, 0.0f, 0.0f, mass[i]);
@@ -628,10 +676,10 @@ int pbdx_solver_set_positions(pbdx_solver *s, uint32_t n, const float *x)
 	if (!n) return PBDX_OK;
 	HIPCHECK(hipSetDevice(s->device));
 	std::vector<float4> tmp(n);
-	HIPCHECK(hipMemcpyAsync(tmp.data(), s->d_pos, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+	HIPCHECK(hipMemcpyAsync(tmp.data(), s->d_pos[0], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	for (uint32_t i = 0; i < n; i++) { tmp[i].x = x[3 * i]; tmp[i].y = x[3 * i + 1]; tmp[i].z = x[3 * i + 2]; }
-	HIPCHECK(hipMemcpyAsync(s->d_pos, tmp.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+	HIPCHECK(hipMemcpyAsync(s->d_pos[0], tmp.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	return PBDX_OK;
 }
@@ -642,7 +690,7 @@ int pbdx_solver_get_particles(pbdx_solver *s, uint32_t n, float *x, float *v, fl
 	if (!n) return PBDX_OK;
 	HIPCHECK(hipSetDevice(s->device));
 	std::vector<float4> tmp(n);
-	struct { float *dst; const float4 *src; } jobs[4] = { { x, s->d_pos }, { v, s->d_vel }, { old_x, s->d_old }, { last_x, s->d_last } };
+	struct { float *dst; const float4 *src; } jobs[4] = { { x, s->d_pos[0] }, { v, s->d_vel }, { old_x, s->d_old }, { last_x, s->d_last } };
 	for (auto &j : jobs)
 	{
 		if (!j.dst) continue;
@@ -682,6 +730,7 @@ int pbdx_solver_add_batch(pbdx_solver *s, uint32_t group, int type, uint32_t cou
 	Batch b;
 	b.type = type; b.group = group; b.count = count; b.seq = (uint32_t)s->batches.size();
 	b.h_idx.assign(indices, indices + (size_t)count * nb);
+	b.h_params.assign(params, params + (size_t)count * ti->param_stride);
 
 	// indices: uint2 for 2-body, uint4 (padded) for 3- and 4-body constraints
 	const uint32_t iw = (nb == 2) ? 2 : 4;
@@ -692,10 +741,9 @@ int pbdx_solver_add_batch(pbdx_solver *s, uint32_t group, int type, uint32_t cou
 	HIPCHECK(hipMemcpy(b.d_idx, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 
 	// parameters: detect batch-uniform ones, lay the rest out planar
-	memset(&b.pv, 0, sizeof(b.pv));
+	memset(&b.view, 0, sizeof(b.view));
 	const uint32_t np = ti->param_stride;
 	const uint32_t stride = (count + 3u) & ~3u;
-	uint32_t planes = 0;
 	for (uint32_t k = 0; k < np; k++)
 	{
 		bool uniform = true;
@@ -705,23 +753,22 @@ int pbdx_solver_add_batch(pbdx_solver *s, uint32_t group, int type, uint32_t cou
 			uint32_t cur; memcpy(&cur, &params[(size_t)i * np + k], 4);
 			uniform = (cur == first);
 		}
-		if (uniform) { b.pv.umask |= 1u << k; b.pv.u[k] = params[k]; }
-		else b.pv.slot[k] = (uint8_t)planes++;
+		if (uniform) { b.view.umask |= 1u << k; b.view.u[k] = params[k]; }
+		else b.view.slot[k] = (uint8_t)b.view.nplanes++;
 	}
-	b.pv.stride = stride;
-	if (planes)
+	b.par_stride = stride;
+	if (b.view.nplanes)
 	{
-		std::vector<float> planar((size_t)planes * stride, 0.0f);
+		std::vector<float> planar((size_t)b.view.nplanes * stride, 0.0f);
 		for (uint32_t k = 0; k < np; k++)
 		{
-			if ((b.pv.umask >> k) & 1u) continue;
-			float *dst = &planar[(size_t)b.pv.slot[k] * stride];
+			if ((b.view.umask >> k) & 1u) continue;
+			float *dst = &planar[(size_t)b.view.slot[k] * stride];
 			for (uint32_t i = 0; i < count; i++) dst[i] = params[(size_t)i * np + k];
 		}
 		HIPCHECK(hipMalloc(&b.d_params, planar.size() * sizeof(float)));
 		HIPCHECK(hipMemcpy(b.d_params, planar.data(), planar.size() * sizeof(float), hipMemcpyHostToDevice));
 	}
-	b.pv.base = b.d_params;
 	if (ti->xpbd)
 	{
 		HIPCHECK(hipMalloc(&b.d_lambda, (size_t)count * sizeof(float)));
@@ -763,6 +810,7 @@ int pbdx_solver_validate_schedule(pbdx_solver *s)
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 {
 	if (!s) return PBDX_ERR_INVALID;
+	bool replan = false;
 	switch (option)
 	{
 	case PBDX_OPT_USE_GRAPH: s->use_graph = value != 0; break;
@@ -770,9 +818,32 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 		if (value != 64 && value != 128 && value != 256) { set_error("block size must be 64, 128 or 256"); return PBDX_ERR_INVALID; }
 		s->block_size = (int)value; break;
 	case PBDX_OPT_XCD_REMAP: s->xcd_remap = value != 0; break;
+	case PBDX_OPT_FUSE: s->fuse = value != 0; break;
+	case PBDX_OPT_TILE_PARTICLES:
+		if (value < 0 || value > 10240) { set_error("tile_particles must be 0 (auto) .. 10240"); return PBDX_ERR_INVALID; }
+		s->tile_particles = (uint32_t)value; replan = true; break;
+	case PBDX_OPT_FUSE_BLOCK:
+		if (value != 0 && value != 256 && value != 512 && value != 1024) { set_error("fused block size must be 0 (auto), 256, 512 or 1024"); return PBDX_ERR_INVALID; }
+		s->fuse_block = (int)value; replan = true; break;
+	case PBDX_OPT_MAX_SEGMENT_COLOURS:
+		if (value < 1) { set_error("max_segment_colours must be >= 1"); return PBDX_ERR_INVALID; }
+		s->max_segment_colours = (uint32_t)value; replan = true; break;
+	case PBDX_OPT_LDS_PARTICLES:
+		if (value < 64 || value > 10240) { set_error("lds_particles must be 64 .. 10240"); return PBDX_ERR_INVALID; }
+		s->lds_particles = (uint32_t)value; replan = true; break;
 	default: set_error("unknown option %d", option); return PBDX_ERR_INVALID;
 	}
 	s->drop_graph();
+	if (replan && s->plan_built)
+	{
+		// the planner needs the host parameter records, which are released after a successful plan
+		bool have = true;
+		for (const Batch &b : s->batches) if (b.h_params.empty() && type_info(b.type)->param_stride) have = false;
+		if (!have) { set_error("option %d must be set before the first step of a schedule", option); return PBDX_ERR_INVALID; }
+		HIPCHECK(hipSetDevice(s->device));
+		HIPCHECK(hipStreamSynchronize(s->stream));
+		s->free_plan();
+	}
 	return PBDX_OK;
 }
 
@@ -789,19 +860,23 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	if (!s || !gravity || sub_steps == 0) { set_error("step: bad arguments"); return PBDX_ERR_INVALID; }
 	if (s->schedule_open) { set_error("step: schedule still open"); return PBDX_ERR_INVALID; }
 	HIPCHECK(hipSetDevice(s->device));
+	int rp = ensure_plan(s);
+	if (rp) return rp;
 	const float hs = h / (float)sub_steps;                  // TimeStepController.cpp:91
 	const float inv_h = (float)(1.0 / (double)hs);          // TimeIntegration.cpp:50 evaluates 1.0/h in double
 
 	uint64_t proj_per_sweep = 0, bytes_per_sweep = 0;
 	for (const Batch &b : s->batches) { proj_per_sweep += b.count; bytes_per_sweep += (uint64_t)b.count * type_info(b.type)->algorithmic_bytes; }
 	const uint64_t substeps_total = (uint64_t)sub_steps * num_steps;
+	const uint64_t launches_per_sweep = s->fused_active() ? s->dsegs.size() : s->order.size();
 	s->stats = pbdx_step_stats();
 	s->stats.projections = proj_per_sweep * max_iterations * substeps_total;
-	s->stats.kernel_launches = ((uint64_t)s->order.size() * max_iterations + 2) * substeps_total;
+	s->stats.kernel_launches = (launches_per_sweep * max_iterations + 2) * substeps_total;
 	s->stats.algorithmic_bytes = (bytes_per_sweep * max_iterations + (uint64_t)s->n * 140) * substeps_total;
 	memset(s->type_ms, 0, sizeof(s->type_ms));
 	memset(s->type_launches, 0, sizeof(s->type_launches));
 	memset(s->type_projections, 0, sizeof(s->type_projections));
+	for (DeviceSegment &d : s->dsegs) { d.ms = 0.0; d.launches = 0; }
 
 	if (s->profile)
 	{
@@ -818,7 +893,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	}
 	else if (s->use_graph)
 	{
-		pbdx_solver::GraphKey k = { hs, max_iterations, vel, { gravity[0], gravity[1], gravity[2] }, s->schedule_version, s->block_size, s->xcd_remap, s->n };
+		pbdx_solver::GraphKey k = { hs, max_iterations, vel, { gravity[0], gravity[1], gravity[2] }, s->schedule_version, s->block_size, s->xcd_remap, s->n, s->fused_active() ? 1 : 0 };
 		if (!s->graph_valid || memcmp(&k, &s->key, sizeof(k)) != 0)
 		{
 			s->drop_graph();
@@ -859,7 +934,12 @@ int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
 {
 	if (!s || s->schedule_open) { set_error("project: bad state"); return PBDX_ERR_INVALID; }
 	HIPCHECK(hipSetDevice(s->device));
-	int r = projection_sweeps(s, h_sub, iterations, nullptr);
+	int r = ensure_plan(s);
+	if (r) return r;
+	const int start = (int)sweep_flips(s, iterations);
+	if (start)
+		HIPCHECK(hipMemcpyAsync(s->d_pos[1], s->d_pos[0], (size_t)s->n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+	r = projection_sweeps(s, h_sub, iterations, start, nullptr);
 	if (r) return r;
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	return PBDX_OK;
@@ -880,7 +960,40 @@ int pbdx_solver_get_lambdas(pbdx_solver *s, uint32_t batch_index, uint32_t count
 	if (!b.d_lambda || count != b.count) { set_error("get_lambdas: batch has no multipliers or count mismatch"); return PBDX_ERR_INVALID; }
 	HIPCHECK(hipSetDevice(s->device));
 	HIPCHECK(hipStreamSynchronize(s->stream));
-	HIPCHECK(hipMemcpy(out, b.d_lambda, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+	if (!s->fused_active())
+	{
+		HIPCHECK(hipMemcpy(out, b.d_lambda, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+		return PBDX_OK;
+	}
+	// fused schedule: the multiplier of a constraint lives in the lambda stream of every tile that
+	// executes it (identical values); fetch the first copy
+	uint32_t pos = 0;
+	for (size_t oi = 0; oi < s->order.size(); oi++) if (s->order[oi] == batch_index) pos = (uint32_t)oi;
+	const uint32_t cid0 = s->plan.batch_base[pos];
+	std::vector<uint8_t> have(count, 0);
+	for (size_t si = 0; si < s->plan.segs.size(); si++)
+	{
+		const FusedSegment &seg = s->plan.segs[si];
+		if (!seg.lam_count) continue;
+		std::vector<float> lam(seg.lam_count);
+		bool fetched = false;
+		for (const FusedStep &st : seg.steps)
+		{
+			if (!type_info((int)st.type)->xpbd) continue;
+			for (uint32_t q = 0; q < st.count; q++)
+			{
+				const uint32_t cid = seg.slot_cid[st.cid_off + q];
+				if (cid < cid0 || cid >= cid0 + count || have[cid - cid0]) continue;
+				if (!fetched)
+				{
+					HIPCHECK(hipMemcpy(lam.data(), s->dsegs[si].d_lambda, (size_t)seg.lam_count * sizeof(float), hipMemcpyDeviceToHost));
+					fetched = true;
+				}
+				out[cid - cid0] = lam[st.lam_off + q];
+				have[cid - cid0] = 1;
+			}
+		}
+	}
 	return PBDX_OK;
 }
 
@@ -900,14 +1013,61 @@ int pbdx_solver_get_type_stats(pbdx_solver *s, int type, double *ms, uint64_t *l
 	return PBDX_OK;
 }
 
+int pbdx_solver_get_plan_info(pbdx_solver *s, pbdx_plan_info *out)
+{
+	if (!s || !out) return PBDX_ERR_INVALID;
+	memset(out, 0, sizeof(*out));
+	out->active = s->fused_active() ? 1 : 0;
+	out->built = s->plan_built ? 1 : 0;
+	if (!s->plan_ok) return PBDX_OK;
+	out->num_segments = (uint32_t)s->plan.segs.size();
+	out->num_tiles = s->plan.num_tiles;
+	out->num_colours = s->plan.num_colours;
+	out->redundancy = s->plan.redundancy;
+	out->build_seconds = s->plan.build_seconds;
+	for (const FusedSegment &seg : s->plan.segs)
+	{
+		out->max_local = std::max(out->max_local, seg.max_local);
+		out->stream_bytes_per_sweep += seg.stream_bytes;
+		out->slots_per_sweep += seg.slots;
+	}
+	return PBDX_OK;
+}
+
+int pbdx_solver_get_segment_info(pbdx_solver *s, uint32_t segment, pbdx_segment_info *out)
+{
+	if (!s || !out || !s->plan_ok || segment >= s->plan.segs.size()) { set_error("get_segment_info: no such segment"); return PBDX_ERR_INVALID; }
+	const FusedSegment &seg = s->plan.segs[segment];
+	const DeviceSegment &d = s->dsegs[segment];
+	memset(out, 0, sizeof(*out));
+	out->colour_begin = seg.colour_begin; out->colour_end = seg.colour_end;
+	out->num_tiles = d.num_tiles; out->block = (uint32_t)d.block; out->lds_bytes = d.lds_bytes; out->type_mask = seg.type_mask;
+	out->constraints = seg.constraints; out->slots = seg.slots; out->stream_bytes = seg.stream_bytes;
+	out->algorithmic_bytes = d.algorithmic_bytes;
+	out->profiled_ms = d.ms; out->profiled_launches = d.launches;
+	return PBDX_OK;
+}
+
 int pbdx_solver_describe(pbdx_solver *s, char *buf, size_t n)
 {
 	if (!s || !buf || !n) return PBDX_ERR_INVALID;
 	uint64_t nc = 0; uint32_t ng = 0, last = 0xffffffffu;
 	for (uint32_t bi : s->order) { nc += s->batches[bi].count; if (s->batches[bi].group != last) { ng++; last = s->batches[bi].group; } }
-	snprintf(buf, n, "device=%d name=%s arch=%s CUs=%d particles=%u constraints=%llu groups=%u batches=%zu graph=%d block=%d xcd_remap=%d",
+	int w = snprintf(buf, n, "device=%d name=%s arch=%s CUs=%d particles=%u constraints=%llu groups=%u batches=%zu graph=%d block=%d xcd_remap=%d",
 		s->device, s->prop.name, s->prop.gcnArchName, s->prop.multiProcessorCount, s->n, (unsigned long long)nc, ng, s->batches.size(),
 		s->use_graph, s->block_size, s->xcd_remap);
+	if (w > 0 && (size_t)w < n)
+	{
+		if (s->fused_active())
+		{
+			uint32_t ml = 0;
+			for (const FusedSegment &seg : s->plan.segs) ml = std::max(ml, seg.max_local);
+			snprintf(buf + w, n - w, " schedule=fused segments=%zu tiles=%u redundancy=%.3f max_tile_particles=%u plan_s=%.2f",
+				s->plan.segs.size(), s->plan.num_tiles, s->plan.redundancy, ml, s->plan.build_seconds);
+		}
+		else
+			snprintf(buf + w, n - w, " schedule=per-colour%s%s", s->plan_built && !s->plan_ok ? " plan_failed=" : "", s->plan_built && !s->plan_ok ? s->plan_why.c_str() : "");
+	}
 	return PBDX_OK;
 }
 

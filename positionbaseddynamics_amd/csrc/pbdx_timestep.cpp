@@ -6,7 +6,9 @@
 // the model's colour groups into the engine's per-(group,type) batches the first
 // time and whenever the model's topology or parameters changed.
 #include "pbdx_internal.h"
+#include "pbdx_plan.h"
 #include <string.h>
+#include <memory>
 
 using namespace pbdx;
 
@@ -33,17 +35,15 @@ int upload_particles(pbdx_timestep *ts, pbdx_model *m)
 		m->mass.data(), m->inv_mass.data());
 }
 
-int build_schedule(pbdx_timestep *ts, pbdx_model *m)
+// Walk the model's colour groups, bucket each group by constraint type (creation order kept inside
+// a bucket) and hand every non-empty (group, type) batch to `emit`.
+template <class F> int for_each_batch(pbdx_model *m, F &&emit)
 {
 	int r = pbdx_model_init_constraint_groups(m);        // TimeStepController.cpp:256
-	if (r) return r;
-	r = pbdx_solver_begin_schedule(ts->solver);
 	if (r) return r;
 	std::vector<uint32_t> idx;
 	std::vector<float> par;
 	for (uint32_t g = 0; g < m->groups.size(); g++)
-	{
-		// bucket the group by constraint type, keeping creation order inside each bucket
 		for (int type = 0; type < PBDX_NUM_CONSTRAINT_TYPES; type++)
 		{
 			const TypeInfo *ti = type_info(type);
@@ -56,10 +56,20 @@ int build_schedule(pbdx_timestep *ts, pbdx_model *m)
 				par.insert(par.end(), c.params, c.params + ti->param_stride);
 			}
 			if (idx.empty()) continue;
-			r = pbdx_solver_add_batch(ts->solver, g, type, (uint32_t)(idx.size() / ti->num_bodies), idx.data(), par.data(), ti->param_stride);
+			r = emit(g, type, (uint32_t)(idx.size() / ti->num_bodies), idx, par);
 			if (r) return r;
 		}
-	}
+	return PBDX_OK;
+}
+
+int build_schedule(pbdx_timestep *ts, pbdx_model *m)
+{
+	int r = pbdx_solver_begin_schedule(ts->solver);
+	if (r) return r;
+	r = for_each_batch(m, [&](uint32_t g, int type, uint32_t count, const std::vector<uint32_t> &idx, const std::vector<float> &par) {
+		return pbdx_solver_add_batch(ts->solver, g, type, count, idx.data(), par.data(), type_info(type)->param_stride);
+	});
+	if (r) return r;
 	return pbdx_solver_end_schedule(ts->solver);
 }
 
@@ -92,6 +102,48 @@ void clear_accelerations(pbdx_timestep *ts, pbdx_model *m)
 } // namespace
 
 extern "C" {
+
+int pbdx_model_plan_check(pbdx_model *m, uint32_t tile_particles, uint32_t lds_particles, uint32_t max_segment_colours, pbdx_plan_info *out)
+{
+	if (!m) return PBDX_ERR_INVALID;
+	struct Held { std::vector<uint32_t> idx; std::vector<float> par; };
+	std::vector<std::unique_ptr<Held>> held;
+	std::vector<PlanBatch> pbs;
+	uint32_t colour = 0, last_group = 0xffffffffu;
+	int r = for_each_batch(m, [&](uint32_t g, int type, uint32_t count, const std::vector<uint32_t> &idx, const std::vector<float> &par) {
+		if (last_group != 0xffffffffu && g != last_group) colour++;
+		last_group = g;
+		held.emplace_back(new Held{ idx, par });
+		pbs.push_back({ type, colour, count, held.back()->idx.data(), held.back()->par.data() });
+		return (int)PBDX_OK;
+	});
+	if (r) return r;
+	PlanOptions opt;
+	opt.tile_particles = tile_particles;
+	if (lds_particles) opt.max_local = lds_particles;
+	if (max_segment_colours) opt.max_segment_colours = max_segment_colours;
+	FusedPlan plan;
+	std::string why;
+	if (!build_fused_plan(m->size(), m->x.data(), pbs, opt, plan, why)) { set_error("plan: %s", why.c_str()); return PBDX_ERR_INVALID; }
+	if (!check_fused_plan(m->size(), pbs, plan, why)) { set_error("plan check: %s", why.c_str()); return PBDX_ERR_INVALID; }
+	if (out)
+	{
+		memset(out, 0, sizeof(*out));
+		out->built = 1;
+		out->num_segments = (uint32_t)plan.segs.size();
+		out->num_tiles = plan.num_tiles;
+		out->num_colours = plan.num_colours;
+		out->redundancy = plan.redundancy;
+		out->build_seconds = plan.build_seconds;
+		for (const FusedSegment &seg : plan.segs)
+		{
+			out->max_local = out->max_local > seg.max_local ? out->max_local : seg.max_local;
+			out->stream_bytes_per_sweep += seg.stream_bytes;
+			out->slots_per_sweep += seg.slots;
+		}
+	}
+	return PBDX_OK;
+}
 
 int pbdx_timestep_create(pbdx_timestep **out, int device)
 {

@@ -219,9 +219,59 @@ def test_resident_equals_roundtrip_and_options_are_invariant(pbd):
                       ("eager", dict(options={S.OPT_USE_GRAPH: 0})),
                       ("xcd remap", dict(options={S.OPT_XCD_REMAP: 1})),
                       ("block 64", dict(options={S.OPT_BLOCK_SIZE: 64})),
-                      ("block 128 resident", dict(resident=True, options={S.OPT_BLOCK_SIZE: 128}))):
-        m, _ = util.mine_run(ops, 6, 2, 5, **kw)
+                      ("block 128 resident", dict(resident=True, options={S.OPT_BLOCK_SIZE: 128})),
+                      ("per-colour schedule", dict(options={S.OPT_FUSE: 0})),
+                      ("per-colour, no remap, eager", dict(options={S.OPT_FUSE: 0, S.OPT_XCD_REMAP: 0, S.OPT_USE_GRAPH: 0})),
+                      ("fused, 100-particle tiles", dict(options={S.OPT_TILE_PARTICLES: 100})),
+                      ("fused, 700-particle tiles, 256 threads", dict(options={S.OPT_TILE_PARTICLES: 700, S.OPT_FUSE_BLOCK: 256})),
+                      ("fused, at most 3 colours per launch", dict(options={S.OPT_MAX_SEGMENT_COLOURS: 3})),
+                      ("fused, one colour per launch, resident", dict(resident=True, options={S.OPT_MAX_SEGMENT_COLOURS: 1})),
+                      ("fused, small LDS", dict(options={S.OPT_TILE_PARTICLES: 200, S.OPT_LDS_PARTICLES: 500})),
+                      ("fused, 1024 threads, no remap", dict(options={S.OPT_FUSE_BLOCK: 1024, S.OPT_XCD_REMAP: 0}))):
+        m, ts = util.mine_run(ops, 6, 2, 5, **kw)
         assert util.bitwise_equal(m.getParticles().positions(), xb), label
+        assert ts.solver().plan_info()["active"] == (0 if "per-colour" in label else 1), label
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_fused_tiles_equal_per_colour_schedule(pbd, name):
+    """Every constraint type through both device schedules: the colour-fused LDS tiles (forced to
+    many small tiles so that halos, redundant execution and multi-segment plans are exercised) must
+    reproduce the per-colour launches bit for bit -- positions, velocities and XPBD multipliers."""
+    ops, sub, iters, _ = SCENES[name]
+    S = pbd.Solver
+    ma, tsa = util.mine_run(ops, 4, sub, iters, options={S.OPT_FUSE: 0})
+    for tile in (48, 160, 0):
+        mb, tsb = util.mine_run(ops, 4, sub, iters, options={S.OPT_TILE_PARTICLES: tile})
+        info = tsb.solver().plan_info()
+        assert info["active"] == 1 and info["num_tiles"] >= 1
+        for which in (0, 2, 4, 5):
+            assert util.bitwise_equal(ma.getParticles().array(which), mb.getParticles().array(which)), (name, tile, which)
+    print("%-50s fused == per-colour (last plan: %d segments, %d tiles, redundancy %.2f)" % (
+        name, info["num_segments"], info["num_tiles"], info["redundancy"]))
+
+
+def test_fused_large_cloth_and_lambdas(pbd):
+    """300x300 cloth (90 000 particles, 537 606 constraints): fused auto plan vs per-colour launches,
+    bit-identical state and multipliers after 3 steps of 10 iterations."""
+    ops = util.cloth_spec(300, 300, 4, 3)
+    S = pbd.Solver
+    ma, tsa = util.mine_run(ops, 3, 1, 10, resident=True, options={S.OPT_FUSE: 0})
+    mb, tsb = util.mine_run(ops, 3, 1, 10, resident=True)
+    info = tsb.solver().plan_info()
+    print("300x300 plan:", info)
+    assert info["active"] == 1 and tsa.solver().plan_info()["active"] == 0
+    for which in (0, 2, 4, 5):
+        assert util.bitwise_equal(ma.getParticles().array(which), mb.getParticles().array(which)), which
+    groups = ma.getConstraintGroups()
+    types = ma.constraintTypes()
+    for batch in (0, 3, len(groups) - 1):
+        # batches are added per (group, type); with one type per leading group batch k == group k
+        n = sum(1 for c in groups[batch] if types[c] == types[groups[batch][0]])
+        if batch < 8:
+            la = tsa.solver().get_lambdas(batch, n)
+            lb = tsb.solver().get_lambdas(batch, n)
+            assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), batch
 
 
 def test_ensemble_instances_equal_independent_runs(pbd):

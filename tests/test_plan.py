@@ -1,0 +1,64 @@
+"""Planner of the colour-fused tile schedule (positionbaseddynamics_amd/csrc/pbdx_plan.cpp), host only.
+
+pbdx_model_plan_check packs the model's colour groups exactly as the time step does, plans tiles +
+segments and then EXECUTES the plan symbolically (every particle carries a hash of its update
+history): the fused schedule must hand every particle the history of the reference's
+colour-sequential sweep (TimeStepController.cpp:270-286), every particle must be owned by exactly
+one tile per segment and every tile-local index must map to the right particle."""
+import pytest
+
+from tests import util
+
+CASES = {
+    "cloth 50x50 XPBD dist+bend": util.cloth_spec(50, 50, 4, 3),
+    "cloth 37x91 PBD dist + isometric": util.cloth_spec(37, 91, 1, 2),
+    "cloth 40x40 FEM tri + dihedral": util.cloth_spec(40, 40, 2, 1),
+    "3 cloth instances": util.cloth_spec(24, 24, 4, 3, instances=3, instance_offset=(12, 0, 0)),
+    "bar 30x5x5 FEM tet": util.bar_spec(30, 5, 5, 2),
+    "bar 20x6x6 XPBD dist+vol": util.bar_spec(20, 6, 6, 6),
+    "bar 12x5x5 shape matching": util.bar_spec(12, 5, 5, 5),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("tile", [0, 33, 250])
+def test_plan_is_equivalent_to_colour_sequential_sweep(name, tile):
+    m = util.build_mine(CASES[name])
+    info = m.planCheck(tile_particles=tile)
+    n = m.getParticles().size()
+    assert info["built"] == 1 and info["num_segments"] >= 1
+    assert info["num_colours"] == len(m.getConstraintGroups())
+    assert info["slots_per_sweep"] >= m.numConstraints()
+    assert info["redundancy"] >= 1.0
+    if tile:
+        assert info["num_tiles"] == (n + tile - 1) // tile
+
+
+def test_plan_respects_lds_capacity_and_segment_cap():
+    m = util.build_mine(util.cloth_spec(60, 60, 4, 3))
+    a = m.planCheck(tile_particles=200, lds_particles=400)
+    assert a["max_local"] <= 400
+    b = m.planCheck(tile_particles=200, lds_particles=10240)
+    assert b["num_segments"] <= a["num_segments"]          # more LDS -> longer segments
+    c = m.planCheck(tile_particles=200, max_segment_colours=1)
+    assert c["num_segments"] == c["num_colours"]
+    one = m.planCheck(tile_particles=3600)                  # one tile owns everything: no halo, no redundancy
+    assert one["num_tiles"] == 1 and one["redundancy"] == 1.0 and one["max_local"] == 3600
+
+
+def test_plan_fails_loudly_when_a_colour_cannot_fit():
+    import positionbaseddynamics_amd as pbd
+    m = util.build_mine(util.cloth_spec(30, 30, 4, 3))
+    with pytest.raises(pbd.PbdxError):
+        m.planCheck(tile_particles=200, lds_particles=201)
+
+
+def test_plan_1m_particle_cloth_headline_numbers():
+    """The BASELINE config (1000x1000 cloth): the planner must fit 160 KiB of LDS per tile and keep the
+    redundant halo work moderate."""
+    m = util.build_mine(util.cloth_spec(400, 400, 4, 3))
+    info = m.planCheck()
+    print(info)
+    assert info["max_local"] <= 10240
+    assert info["num_segments"] <= 6
+    assert info["redundancy"] <= 3.0
