@@ -165,7 +165,8 @@ enum {
 	PBDX_OPT_TILE_PARTICLES = 5,   /* particles owned by one tile; 0 = auto (default) */
 	PBDX_OPT_FUSE_BLOCK = 6,       /* threads per workgroup of the fused kernel: 0 = auto, 256, 512, 1024 */
 	PBDX_OPT_MAX_SEGMENT_COLOURS = 7, /* upper bound on colours fused into one launch (default 16) */
-	PBDX_OPT_LDS_PARTICLES = 8     /* LDS capacity of a tile in particles (default 10240 = 160 KiB / 16 B) */
+	PBDX_OPT_LDS_PARTICLES = 8,    /* LDS capacity of a tile in particles (default 10240 = 160 KiB / 16 B) */
+	PBDX_OPT_TRACE = 9             /* developer aid: fused kernels stamp wall_clock64() per tile and colour step */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
 
@@ -189,6 +190,10 @@ typedef struct pbdx_segment_info {
 	uint64_t profiled_launches;
 } pbdx_segment_info;
 int pbdx_solver_get_segment_info(pbdx_solver *s, uint32_t segment, pbdx_segment_info *out);
+/* Developer trace of the LAST launch of `segment` (PBDX_OPT_TRACE): num_tiles * stride stamps of the
+ * 100 MHz wall clock; per tile [0] kernel entry, [1] LDS filled, [2+i] colour step i finished,
+ * [stride-1] tile written back. */
+int pbdx_solver_get_trace(pbdx_solver *s, uint32_t segment, uint64_t *out, uint32_t capacity, uint32_t *stride);
 
 /* Timing of the last pbdx_solver_step call measured with HIP events on the
  * engine's own stream: total milliseconds, and (if profile_kernels was set)

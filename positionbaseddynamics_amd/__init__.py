@@ -573,6 +573,16 @@ class Solver:
         check(lib.pbdx_solver_get_segment_info(self._h, int(segment), C.byref(si)), "get_segment_info")
         return {k: getattr(si, k) for k, _ in _ffi.SegmentInfo._fields_}
 
+    def trace(self, segment):
+        """(num_tiles, stride) array of 100 MHz wall-clock stamps of the last launch of `segment`."""
+        si = self.segment_info(segment)
+        cap = si["num_tiles"] * 128
+        buf = np.zeros(cap, dtype=np.uint64)
+        stride = C.c_uint32()
+        check(lib.pbdx_solver_get_trace(self._h, int(segment), buf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(stride)), "get_trace")
+        return buf[: si["num_tiles"] * stride.value].reshape(si["num_tiles"], stride.value)
+
+    OPT_TRACE = 9
     OPT_USE_GRAPH = 1
     OPT_BLOCK_SIZE = 2
     OPT_XCD_REMAP = 3

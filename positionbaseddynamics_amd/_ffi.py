@@ -72,6 +72,7 @@ SIGNATURES = [
     ("pbdx_solver_describe", C.c_int, vp, C.c_char_p, C.c_size_t),
     ("pbdx_solver_get_plan_info", C.c_int, vp, C.POINTER(PlanInfo)),
     ("pbdx_solver_get_segment_info", C.c_int, vp, u32, C.POINTER(SegmentInfo)),
+    ("pbdx_solver_get_trace", C.c_int, vp, u32, C.POINTER(C.c_uint64), u32, C.POINTER(u32)),
     ("pbdx_model_plan_check", C.c_int, vp, u32, u32, u32, C.POINTER(PlanInfo)),
     ("pbdx_model_create", C.c_int, C.POINTER(vp)), ("pbdx_model_destroy", None, vp),
     ("pbdx_model_cleanup", C.c_int, vp), ("pbdx_model_reset", C.c_int, vp),

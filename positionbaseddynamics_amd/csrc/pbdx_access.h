@@ -15,12 +15,19 @@
 
 namespace pbdx {
 
-__device__ __forceinline__ float view_get(const TypeView &v, const float *par, uint32_t stride, int k, uint32_t i)
+__device__ constexpr PlaneTable kPlanes = PlaneTable();
+
+// parameter k of slot i: a scalar of the view, or one coalesced dword of plane kPlanes[..][k].
+// `k` is a literal (or an unrolled loop index) at every call site, so the table lookups and the
+// scalar/streamed decision fold away at compile time: no branch, every load unconditional.
+template <int TYPE, bool COMPACT>
+__device__ __forceinline__ float param_get(const TypeView &v, const float *par, uint32_t stride, int k, uint32_t i)
 {
-	return ((v.umask >> k) & 1u) ? v.u[k] : par[(size_t)v.slot[k] * stride + i];
+	if (is_scalar_param(TYPE, COMPACT, k)) return v.u[k];
+	return par[(uint32_t)kPlanes.plane[COMPACT ? 1 : 0][TYPE][k] * stride + i];
 }
 
-struct GlobalAccess
+template <int TYPE, bool COMPACT> struct GlobalAccess
 {
 	float4 *pos;
 	const uint32_t *idx;
@@ -33,10 +40,13 @@ struct GlobalAccess
 	__device__ __forceinline__ uint4 idx4(uint32_t i) const { return reinterpret_cast<const uint4 *>(idx)[i]; }
 	__device__ __forceinline__ float4 ld(uint32_t h) const { return pos[h]; }
 	__device__ __forceinline__ void st(uint32_t h, float4 v) const { pos[h] = v; }
-	__device__ __forceinline__ float p(int k, uint32_t i) const { return view_get(view, par, par_stride, k, i); }
+	__device__ __forceinline__ float p(int k, uint32_t i) const { return param_get<TYPE, COMPACT>(view, par, par_stride, k, i); }
+	__device__ __forceinline__ bool sym() const { return COMPACT; }
+	__device__ __forceinline__ float lam_load(uint32_t i) const { return lambda[i]; }
+	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { lambda[i] = v; }
 };
 
-struct TileAccess
+template <int TYPE, bool COMPACT> struct TileAccess
 {
 	float4 *pos;               // LDS
 	const uint16_t *idx;
@@ -57,7 +67,10 @@ struct TileAccess
 	}
 	__device__ __forceinline__ float4 ld(uint32_t h) const { return pos[h]; }
 	__device__ __forceinline__ void st(uint32_t h, float4 v) const { pos[h] = v; }
-	__device__ __forceinline__ float p(int k, uint32_t i) const { return view_get(view, par, par_stride, k, i); }
+	__device__ __forceinline__ float p(int k, uint32_t i) const { return param_get<TYPE, COMPACT>(view, par, par_stride, k, i); }
+	__device__ __forceinline__ bool sym() const { return COMPACT; }
+	__device__ __forceinline__ float lam_load(uint32_t i) const { return lambda[i]; }
+	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { lambda[i] = v; }
 };
 
 template <class A> __device__ __forceinline__ void ldp(const A &a, uint32_t h, V3 &p, float &w)
@@ -77,6 +90,24 @@ struct QFull
 	float q[16];   // column-major Q(j,k) = q[k*4+j]
 	__device__ __forceinline__ float operator()(int j, int k) const { return q[k * 4 + j]; }
 };
+
+// Q of the isometric bending constraints, column-major; in the compact layout only the upper
+// triangle is streamed and the lower one mirrored (see pbdx_plan.h).
+template <class A> __device__ __forceinline__ void load_q(const A &a, uint32_t i, QFull &q)
+{
+#pragma unroll
+	for (int c = 0; c < 4; c++)
+#pragma unroll
+		for (int r = 0; r <= c; r++) q.q[c * 4 + r] = a.p(1 + c * 4 + r, i);
+#pragma unroll
+	for (int c = 0; c < 4; c++)
+#pragma unroll
+		for (int r = c + 1; r < 4; r++)
+		{
+			if (a.sym()) q.q[c * 4 + r] = q.q[r * 4 + c];
+			else q.q[c * 4 + r] = a.p(1 + c * 4 + r, i);
+		}
+}
 
 template <class A> __device__ __forceinline__ M3 load_m3(const A &a, int first, uint32_t i)
 {
@@ -129,13 +160,13 @@ template <class A> struct Project<PBDX_DISTANCE_XPBD, A>
 		const uint2 id = a.idx2(i);
 		V3 p0, p1; float w0, w1;
 		ldp(a, id.x, p0, w0); ldp(a, id.y, p1, w1);
-		float lambda = first_iter ? 0.0f : a.lambda[i];
+		float lambda = first_iter ? 0.0f : a.lam_load(i);
 		V3 c0, c1;
 		if (solve_distance_xpbd(p0, w0, p1, w1, a.p(0, i), a.p(1, i), dt, lambda, c0, c1))
 		{
 			apply(a, id.x, p0, c0, w0); apply(a, id.y, p1, c1, w1);
 		}
-		a.lambda[i] = lambda;
+		a.lam_store(i, lambda);
 	}
 };
 
@@ -157,8 +188,7 @@ template <class A> struct Project<PBDX_ISOMETRIC_BENDING, A>
 	{
 		PBDX_LOAD4;
 		QFull q;
-#pragma unroll
-		for (int k = 0; k < 16; k++) q.q[k] = a.p(1 + k, i);
+		load_q(a, i, q);
 		if (solve_isometric_bending(p0, w0, p1, w1, p2, w2, p3, w3, q, a.p(0, i), c0, c1, c2, c3))
 		{
 			PBDX_APPLY4;
@@ -172,14 +202,13 @@ template <class A> struct Project<PBDX_ISOMETRIC_BENDING_XPBD, A>
 	{
 		PBDX_LOAD4;
 		QFull q;
-#pragma unroll
-		for (int k = 0; k < 16; k++) q.q[k] = a.p(1 + k, i);
-		float lambda = first_iter ? 0.0f : a.lambda[i];
+		load_q(a, i, q);
+		float lambda = first_iter ? 0.0f : a.lam_load(i);
 		if (solve_isometric_bending_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, q, a.p(0, i), dt, lambda, c0, c1, c2, c3))
 		{
 			PBDX_APPLY4;
 		}
-		a.lambda[i] = lambda;
+		a.lam_store(i, lambda);
 	}
 };
 
@@ -228,12 +257,12 @@ template <class A> struct Project<PBDX_VOLUME_XPBD, A>
 	static __device__ __forceinline__ void run(const A &a, uint32_t i, float dt, int first_iter)
 	{
 		PBDX_LOAD4;
-		float lambda = first_iter ? 0.0f : a.lambda[i];
+		float lambda = first_iter ? 0.0f : a.lam_load(i);
 		if (solve_volume_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, a.p(0, i), a.p(1, i), dt, lambda, c0, c1, c2, c3))
 		{
 			PBDX_APPLY4;
 		}
-		a.lambda[i] = lambda;
+		a.lam_store(i, lambda);
 	}
 };
 
@@ -260,12 +289,12 @@ template <class A> struct Project<PBDX_FEM_TET_XPBD, A>
 		const float vol = a.p(0, i);
 		const M3 im = load_m3(a, 1, i);
 		const bool hi = fem_tet_handle_inversion(p0, p1, p2, p3, vol);
-		float lambda = first_iter ? 0.0f : a.lambda[i];
+		float lambda = first_iter ? 0.0f : a.lam_load(i);
 		if (solve_fem_tet_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, vol, im, a.p(10, i), a.p(11, i), hi, dt, lambda, c0, c1, c2, c3))
 		{
 			PBDX_APPLY4;
 		}
-		a.lambda[i] = lambda;
+		a.lam_store(i, lambda);
 	}
 };
 
@@ -310,6 +339,67 @@ template <class A> struct Project<PBDX_SHAPE_MATCHING, A>
 		}
 	}
 };
+
+// ---- prefetched records ------------------------------------------------------------------------
+// The fused kernel separates "fetch everything a constraint streams from HBM" (indices, parameter
+// record, multiplier) from "project it on the LDS-resident positions", so that the fetches of
+// several slots are in flight before the first projection starts.
+__device__ constexpr bool kTwoBodies[PBDX_NUM_CONSTRAINT_TYPES] = { true, true, false, false, false, false, false, false, false, false, false, false, false };
+__device__ constexpr bool kHasLambda[PBDX_NUM_CONSTRAINT_TYPES] = { false, true, false, false, true, false, false, false, true, false, true, false, false };
+
+// A record keeps exactly what came back from memory (packed 16-bit indices, raw multiplier): no
+// instruction may touch a prefetched value before its slot is projected, otherwise the compiler
+// has to drain the whole prefetch queue (s_waitcnt vmcnt(0)) at that instruction.
+template <int TYPE> struct Rec
+{
+	uint2 id_raw;
+	float lambda_raw;
+	float par[kParamCount[TYPE]];
+};
+
+template <int TYPE, class A> struct RecAccess
+{
+	const A &base;
+	const Rec<TYPE> &r;
+	int first_iter;
+	__device__ __forceinline__ uint2 idx2(uint32_t) const { return make_uint2(r.id_raw.x & 0xffffu, r.id_raw.x >> 16); }
+	__device__ __forceinline__ uint4 idx4(uint32_t) const { return make_uint4(r.id_raw.x & 0xffffu, r.id_raw.x >> 16, r.id_raw.y & 0xffffu, r.id_raw.y >> 16); }
+	__device__ __forceinline__ float4 ld(uint32_t h) const { return base.ld(h); }
+	__device__ __forceinline__ void st(uint32_t h, float4 v) const { base.st(h, v); }
+	__device__ __forceinline__ float p(int k, uint32_t) const { return r.par[k]; }
+	__device__ __forceinline__ bool sym() const { return false; }      // the record holds the full matrix
+	__device__ __forceinline__ float lam_load(uint32_t) const { return r.lambda_raw; }
+	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { base.lam_store(i, v); }
+};
+
+// only for TileAccess (packed 16-bit indices)
+template <int TYPE, class A> __device__ __forceinline__ void load_rec(const A &a, uint32_t i, Rec<TYPE> &r)
+{
+	if constexpr (kTwoBodies[TYPE]) r.id_raw = make_uint2(reinterpret_cast<const uint32_t *>(a.idx)[i], 0u);
+	else r.id_raw = reinterpret_cast<const uint2 *>(a.idx)[i];
+	if constexpr (TYPE == PBDX_ISOMETRIC_BENDING || TYPE == PBDX_ISOMETRIC_BENDING_XPBD)
+	{
+		r.par[0] = a.p(0, i);
+		QFull q;
+		load_q(a, i, q);
+#pragma unroll
+		for (int k = 0; k < 16; k++) r.par[1 + k] = q.q[k];
+	}
+	else
+	{
+#pragma unroll
+		for (int k = 0; k < kParamCount[TYPE]; k++) r.par[k] = a.p(k, i);
+	}
+	r.lambda_raw = 0.0f;
+	// unconditional load (the stream always exists; iteration 0 ignores the value): branch-free prefetch
+	if constexpr (kHasLambda[TYPE]) r.lambda_raw = a.lam_load(i);
+}
+
+template <int TYPE, class A> __device__ __forceinline__ void exec_rec(const A &a, const Rec<TYPE> &r, uint32_t i, float dt, int first_iter)
+{
+	const RecAccess<TYPE, A> ra = { a, r, first_iter };
+	Project<TYPE, RecAccess<TYPE, A>>::run(ra, i, dt, first_iter);
+}
 
 } // namespace pbdx
 

@@ -103,7 +103,7 @@ void closure(const Graph &g, Scratch &s, const uint32_t *owned, uint32_t n_owned
 uint32_t slot_bytes(const TypeView &v, int type)
 {
 	const TypeInfo *ti = type_info(type);
-	return (ti->num_bodies == 2 ? 4u : 8u) + v.nplanes * 4u + (ti->xpbd ? 8u : 0u);
+	return (ti->num_bodies == 2 ? 4u : 8u) + (uint32_t)num_planes(type, v.compact != 0) * 4u + (ti->xpbd ? 8u : 0u);
 }
 
 template <class F>
@@ -183,6 +183,35 @@ inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 } // namespace
 
+void compute_type_view(int type, const std::vector<ParamSpan> &spans, TypeView &v)
+{
+	memset(&v, 0, sizeof(v));
+	const TypeInfo *ti = type_info(type);
+	if (!ti) return;
+	const uint32_t np = ti->param_stride;
+	bool seen = false, compact = true;
+	uint32_t first[PBDX_MAX_PARAMS] = {};
+	for (const ParamSpan &sp : spans)
+	{
+		if (!sp.count) continue;
+		if (!seen) { memcpy(first, sp.params, np * 4); seen = true; }
+		for (uint32_t i = 0; i < sp.count && compact; i++)
+		{
+			const uint32_t *row = reinterpret_cast<const uint32_t *>(sp.params) + (size_t)i * np;
+			for (uint32_t k = 0; k < np; k++)
+				if (((kCompactScalars[type] >> k) & 1u) && row[k] != first[k]) compact = false;
+			if (is_bending_type(type))
+				for (int c = 0; c < 4; c++)
+					for (int r = c + 1; r < 4; r++)
+						if (row[1 + c * 4 + r] != row[1 + r * 4 + c]) compact = false;
+		}
+	}
+	v.compact = (seen && compact) ? 1u : 0u;
+	if (v.compact)
+		for (uint32_t k = 0; k < np; k++)
+			if ((kCompactScalars[type] >> k) & 1u) memcpy(&v.u[k], &first[k], 4);
+}
+
 bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &batches,
 	const PlanOptions &opt, FusedPlan &plan, std::string &why)
 {
@@ -239,28 +268,9 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	// ---- parameter views: uniform over the whole schedule -> scalar ------------------------------
 	for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++)
 	{
-		TypeView &v = plan.views[t];
-		memset(&v, 0, sizeof(v));
-		const TypeInfo *ti = type_info(t);
-		bool seen = false;
-		uint32_t first[PBDX_MAX_PARAMS] = {};
-		uint32_t varying = 0;
-		for (const PlanBatch &pb : batches)
-		{
-			if (pb.type != t || !pb.count) continue;
-			const uint32_t np = ti->param_stride;
-			if (!seen) { memcpy(first, pb.params, np * 4); seen = true; }
-			for (uint32_t i = 0; i < pb.count; i++)
-			{
-				const uint32_t *row = reinterpret_cast<const uint32_t *>(pb.params) + (size_t)i * np;
-				for (uint32_t k = 0; k < np; k++) if (row[k] != first[k]) varying |= 1u << k;
-			}
-		}
-		for (uint32_t k = 0; k < ti->param_stride; k++)
-		{
-			if (!((varying >> k) & 1u)) { v.umask |= 1u << k; memcpy(&v.u[k], &first[k], 4); }
-			else v.slot[k] = (uint8_t)v.nplanes++;
-		}
+		std::vector<ParamSpan> spans;
+		for (const PlanBatch &pb : batches) if (pb.type == t && pb.count) spans.push_back({ pb.params, pb.count });
+		compute_type_view(t, spans, plan.views[t]);
 	}
 
 	// ---- tiles ---------------------------------------------------------------------------------
@@ -365,6 +375,21 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 			uint32_t w = worst.load();
 			while (n_local > w && !worst.compare_exchange_weak(w, n_local)) {}
 			if (n_local > opt.max_local) return;
+			{
+				uint32_t nsteps = 0;
+				for (uint32_t c = c0; c < c1; c++)
+				{
+					const std::vector<uint32_t> &bk = s.bucket[c - c0];
+					for (size_t q = 0; q < bk.size(); q++) if (q == 0 || g.cbatch[bk[q]] != g.cbatch[bk[q - 1]]) nsteps++;
+				}
+				if (nsteps > opt.max_tile_steps)
+				{
+					uint32_t big = opt.max_local + 1;     // reported through the same channel: forces a split
+					uint32_t w2 = worst.load();
+					while (big > w2 && !worst.compare_exchange_weak(w2, big)) {}
+					return;
+				}
+			}
 			o.gid.reserve(n_local);
 			for (uint32_t i = 0; i < o.n_owned; i++) { s.local_of[owned[i]] = i; o.gid.push_back(owned[i]); }
 			for (uint32_t i = 0; i < s.halo.size(); i++) { s.local_of[s.halo[i]] = o.n_owned + i; o.gid.push_back(s.halo[i]); }
@@ -391,7 +416,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 					st.cid_off = (uint32_t)o.slot_cid.size();
 					const uint32_t iw = ti->num_bodies == 2 ? 2 : 4;
 					o.idx.resize(o.idx.size() + round_up(st.count * iw, 8), 0);
-					o.params.resize(o.params.size() + (size_t)v.nplanes * st.par_stride, 0.0f);
+					o.params.resize(o.params.size() + (size_t)num_planes(pb.type, v.compact != 0) * st.par_stride, 0.0f);
 					for (size_t q = a; q < e; q++)
 					{
 						const uint32_t cid = bk[q];
@@ -400,8 +425,8 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 						for (uint32_t j = 0; j < ti->num_bodies; j++)
 							o.idx[st.idx_off + slot * iw + j] = (uint16_t)s.local_of[pb.idx[(size_t)i * ti->num_bodies + j]];
 						for (uint32_t p = 0; p < ti->param_stride; p++)
-							if (!((v.umask >> p) & 1u))
-								o.params[st.par_off + (size_t)v.slot[p] * st.par_stride + slot] = pb.params[(size_t)i * ti->param_stride + p];
+							if (param_streams(pb.type, v.compact != 0, (int)p))
+								o.params[st.par_off + (size_t)param_plane(pb.type, v.compact != 0, (int)p) * st.par_stride + slot] = pb.params[(size_t)i * ti->param_stride + p];
 						o.slot_cid.push_back(cid);
 					}
 					if (ti->xpbd) o.lam_count += round_up(st.count, 4);
@@ -414,7 +439,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 		});
 		if (worst.load() > opt.max_local)
 		{
-			if (c1 - c0 <= 1) { why = "a single colour does not fit the LDS tile: reduce tile_particles"; return false; }
+			if (c1 - c0 <= 1) { why = "a single colour does not fit the LDS tile (particles or step descriptors): reduce tile_particles"; return false; }
 			// the sampled estimate missed a larger tile: split this segment and retry both halves
 			const uint32_t mid = (c0 + c1) / 2;
 			todo[si] = { c0, mid };

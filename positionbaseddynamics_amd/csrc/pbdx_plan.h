@@ -40,14 +40,71 @@ struct PlanBatch
 	const float *params;    // count * param_stride(type)
 };
 
-// which parameters of a type are uniform over the whole schedule (-> scalar), which are streamed
+// Parameter layout of a constraint type.  Two layouts, both fixed at compile time so that every
+// load in the kernels is unconditional (no data-dependent branch between a prefetch and its use):
+//   compact  the parameters that are normally shared by all constraints of a scene (stiffness,
+//            material constants, flags) are scalars (`u`), and of the isometric-bending matrix Q
+//            only the upper triangle is streamed (init_IsometricBendingConstraint builds Q
+//            bitwise symmetric, PositionBasedDynamics.cpp:169-180).  Chosen when the schedule's
+//            records really are like that (bitwise checks, compute_type_view).
+//   full     every parameter of the record is streamed.
 struct TypeView
 {
-	uint32_t umask;
-	uint32_t nplanes;
+	uint32_t compact;
+	uint32_t pad[3];
 	float u[PBDX_MAX_PARAMS];
-	uint8_t slot[PBDX_MAX_PARAMS];
 };
+
+// bit k set: parameter k of the host record (include/pbdx.h) is a scalar in the compact layout
+constexpr uint32_t kCompactScalars[13] = {
+	1u << 1,                                                    // DISTANCE            stiffness
+	1u << 1,                                                    // DISTANCE_XPBD
+	1u << 1,                                                    // DIHEDRAL
+	1u << 0,                                                    // ISOMETRIC_BENDING   stiffness (+ symmetric Q)
+	1u << 0,                                                    // ISOMETRIC_BENDING_XPBD
+	(1u << 5) | (1u << 6) | (1u << 7) | (1u << 8) | (1u << 9),  // FEM_TRIANGLE        xx, yy, xy, poisson ratios
+	(1u << 4) | (1u << 5) | (1u << 6) | (1u << 7) | (1u << 8),  // STRAIN_TRIANGLE     stiffnesses, normalise flags
+	1u << 1,                                                    // VOLUME
+	1u << 1,                                                    // VOLUME_XPBD
+	(1u << 10) | (1u << 11),                                    // FEM_TET             stiffness, poisson ratio
+	(1u << 10) | (1u << 11),                                    // FEM_TET_XPBD
+	(1u << 9) | (1u << 10) | (1u << 11) | (1u << 12),           // STRAIN_TET
+	1u << 0,                                                    // SHAPE_MATCHING      stiffness
+};
+constexpr int kParamCount[13] = { 2, 2, 2, 17, 17, 10, 9, 2, 2, 12, 12, 13, 24 };
+
+constexpr bool is_bending_type(int type) { return type == 3 || type == 4; }
+// Q(r,c) is parameter 1 + c*4 + r; the strictly lower triangle (r > c) is mirrored, not streamed
+constexpr bool is_mirrored_q(int type, bool compact, int k)
+{
+	return compact && is_bending_type(type) && k >= 1 && ((k - 1) % 4) > ((k - 1) / 4);
+}
+constexpr bool is_scalar_param(int type, bool compact, int k) { return compact && ((kCompactScalars[type] >> k) & 1u); }
+constexpr bool param_streams(int type, bool compact, int k) { return !is_scalar_param(type, compact, k) && !is_mirrored_q(type, compact, k); }
+constexpr int param_plane(int type, bool compact, int k)
+{
+	int n = 0;
+	for (int j = 0; j < k; j++) n += param_streams(type, compact, j) ? 1 : 0;
+	return n;
+}
+constexpr int num_planes(int type, bool compact) { return param_plane(type, compact, kParamCount[type]); }
+
+// plane index tables (constant-folded in the kernels once the parameter index is a constant)
+struct PlaneTable
+{
+	signed char plane[2][13][PBDX_MAX_PARAMS];
+	constexpr PlaneTable() : plane()
+	{
+		for (int c = 0; c < 2; c++)
+			for (int t = 0; t < 13; t++)
+				for (int k = 0; k < PBDX_MAX_PARAMS; k++)
+					plane[c][t][k] = (k < kParamCount[t] && param_streams(t, c != 0, k)) ? (signed char)param_plane(t, c != 0, k) : (signed char)-1;
+	}
+};
+
+// One view for a set of parameter-record arrays of the same type (bitwise comparisons).
+struct ParamSpan { const float *params; uint32_t count; };
+void compute_type_view(int type, const std::vector<ParamSpan> &spans, TypeView &out);
 
 struct FusedStep      // one (colour, type) run of a tile; 32 bytes, read with scalar loads
 {
@@ -94,6 +151,7 @@ struct PlanOptions
 	uint32_t max_local = 10240;         // LDS capacity in particles (160 KiB / 16 B)
 	uint32_t num_cus = 256;
 	uint32_t max_segment_colours = 16;
+	uint32_t max_tile_steps = 64;       // (colour, type) runs one tile may have in one segment
 	double launch_cost_bytes = 12.0e6;  // cost of one more launch expressed in streamed bytes
 	uint32_t threads = 0;               // 0 = auto
 };

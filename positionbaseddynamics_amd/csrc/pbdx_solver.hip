@@ -70,25 +70,26 @@ __device__ __forceinline__ uint32_t logical_block(uint32_t num_blocks, int xcd_r
 	return (b & 7u) * per + (b >> 3);
 }
 
-template <int TYPE>
+template <int TYPE, bool COMPACT>
 __global__ __launch_bounds__(256) void project_kernel(BatchArgs a)
 {
 	const uint32_t i = logical_block(a.num_blocks, a.xcd_remap) * blockDim.x + threadIdx.x;
 	if (i < a.count)
 	{
-		const GlobalAccess acc = { a.pos, a.idx, a.par, a.par_stride, a.lambda, a.view };
-		Project<TYPE, GlobalAccess>::run(acc, i, a.dt, a.first_iter);
+		const GlobalAccess<TYPE, COMPACT> acc = { a.pos, a.idx, a.par, a.par_stride, a.lambda, a.view };
+		Project<TYPE, GlobalAccess<TYPE, COMPACT>>::run(acc, i, a.dt, a.first_iter);
 	}
 }
 
 typedef void (*project_fn)(BatchArgs);
-project_fn kProjectKernels[PBDX_NUM_CONSTRAINT_TYPES] = {
-	project_kernel<PBDX_DISTANCE>, project_kernel<PBDX_DISTANCE_XPBD>, project_kernel<PBDX_DIHEDRAL>,
-	project_kernel<PBDX_ISOMETRIC_BENDING>, project_kernel<PBDX_ISOMETRIC_BENDING_XPBD>,
-	project_kernel<PBDX_FEM_TRIANGLE>, project_kernel<PBDX_STRAIN_TRIANGLE>,
-	project_kernel<PBDX_VOLUME>, project_kernel<PBDX_VOLUME_XPBD>,
-	project_kernel<PBDX_FEM_TET>, project_kernel<PBDX_FEM_TET_XPBD>, project_kernel<PBDX_STRAIN_TET>,
-	project_kernel<PBDX_SHAPE_MATCHING>,
+#define PBDX_PK(T) { project_kernel<T, false>, project_kernel<T, true> }
+project_fn kProjectKernels[PBDX_NUM_CONSTRAINT_TYPES][2] = {
+	PBDX_PK(PBDX_DISTANCE), PBDX_PK(PBDX_DISTANCE_XPBD), PBDX_PK(PBDX_DIHEDRAL),
+	PBDX_PK(PBDX_ISOMETRIC_BENDING), PBDX_PK(PBDX_ISOMETRIC_BENDING_XPBD),
+	PBDX_PK(PBDX_FEM_TRIANGLE), PBDX_PK(PBDX_STRAIN_TRIANGLE),
+	PBDX_PK(PBDX_VOLUME), PBDX_PK(PBDX_VOLUME_XPBD),
+	PBDX_PK(PBDX_FEM_TET), PBDX_PK(PBDX_FEM_TET_XPBD), PBDX_PK(PBDX_STRAIN_TET),
+	PBDX_PK(PBDX_SHAPE_MATCHING),
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -108,46 +109,170 @@ struct FusedArgs
 	int first_iter;
 	uint32_t num_tiles;
 	int xcd_remap;
+	// developer trace (PBDX_OPT_TRACE): per tile kTraceStride wall-clock stamps (100 MHz):
+	// [0] kernel entry, [1] LDS filled, [2+i] step i done (after its barrier), [last] tile written back
+	unsigned long long *trace;
 	TypeView views[PBDX_NUM_CONSTRAINT_TYPES];
 };
+constexpr uint32_t kTraceStride = 80;
 
-template <int TYPE, int BLOCK>
-__device__ __forceinline__ void run_step(const FusedArgs &a, const FusedStep &st, float4 *lpos)
+// ---- software pipeline over the steps of a tile ---------------------------------------------------
+// A tile's steps are walked in "chunks" of BLOCK slots (slot = threadIdx.x + k * BLOCK).  The record
+// of a slot (indices, parameters, multiplier) only depends on read-only streams, so it may be
+// fetched long before the positions it will be applied to are final: every thread keeps a ring of
+// D records and fetches the chunk D positions ahead -- across colour barriers -- while it projects
+// the current one.  This decouples the HBM latency of the streams from the barrier-synchronised
+// colour sweep.  The pipeline runs over maximal runs of steps of one constraint type.
+template <int TYPE> struct Depth { static constexpr int value = kParamCount[TYPE] <= 2 ? 4 : 2; };
+
+struct StepS { uint32_t type, count, idx_off, par_off, par_stride, lam_off, barrier; };
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// step descriptors are staged in LDS (uniform address -> broadcast read -> SGPRs)
+__device__ __forceinline__ StepS load_step(const uint4 *lsteps, uint32_t s)
 {
-	const TileAccess acc = { lpos, a.idx + st.idx_off, a.params + st.par_off, st.par_stride, a.lambda + st.lam_off, a.views[TYPE] };
-	for (uint32_t q = threadIdx.x; q < st.count; q += BLOCK)
-		Project<TYPE, TileAccess>::run(acc, q, a.dt, a.first_iter);
+	const uint4 a = lsteps[2 * s], b = lsteps[2 * s + 1];
+	StepS r;
+	r.type = rfl(a.x); r.count = rfl(a.y); r.idx_off = rfl(a.z); r.par_off = rfl(a.w);
+	r.par_stride = rfl(b.x); r.lam_off = rfl(b.y); r.barrier = rfl(b.z);
+	return r;
 }
 
-#define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) run_step<T, BLOCK>(a, st, lpos); break;
+// walks the chunks (step s, k-th group of BLOCK slots) of a run of steps of one type; once it has
+// run off the end it stays on the last chunk (valid == false), so that a prefetch issued from it is
+// a harmless re-load: the loads of the pipeline are unconditional, which lets the compiler wait
+// with an exact vmcnt(N) instead of draining every outstanding prefetch.
+template <int TYPE, int BLOCK> struct ChunkIt
+{
+	uint32_t s, k, s_end;
+	bool valid;
+	StepS st;
+	__device__ __forceinline__ void start(const uint4 *lsteps, uint32_t s0, uint32_t s_end_)
+	{
+		s = s0; k = 0; s_end = s_end_;
+		st = load_step(lsteps, s);
+		valid = true;
+	}
+	__device__ __forceinline__ bool last_of_step() const { return (k + 1) * BLOCK >= st.count; }
+	__device__ __forceinline__ void next(const uint4 *lsteps)
+	{
+		if (!valid) return;
+		if (!last_of_step()) { k++; return; }
+		if (s + 1 < s_end && rfl(lsteps[2 * (s + 1)].x) == (uint32_t)TYPE)
+		{
+			s++; k = 0;
+			st = load_step(lsteps, s);
+		}
+		else
+			valid = false;
+	}
+	// slot of this thread in the chunk, clamped into the step (clamped slots are fetched, never projected)
+	__device__ __forceinline__ uint32_t slot() const { return threadIdx.x + k * BLOCK; }
+	__device__ __forceinline__ uint32_t slot_clamped() const { const uint32_t q = slot(); return q < st.count ? q : st.count - 1; }
+};
+
+template <int TYPE, bool COMPACT, int BLOCK>
+__device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const uint4 *lsteps, uint32_t s0, uint32_t s_end, float4 *lpos, unsigned long long *trace)
+{
+	constexpr int D = Depth<TYPE>::value;
+	typedef TileAccess<TYPE, COMPACT> Acc;
+	ChunkIt<TYPE, BLOCK> ld, ex;
+	ld.start(lsteps, s0, s_end);
+	ex = ld;
+	Rec<TYPE> ring[D];
+#pragma unroll
+	for (int d = 0; d < D; d++)
+	{
+		const Acc acc = { lpos, a.idx + ld.st.idx_off, a.params + ld.st.par_off, ld.st.par_stride, a.lambda + ld.st.lam_off, a.views[TYPE] };
+		load_rec<TYPE>(acc, ld.slot_clamped(), ring[d]);
+		ld.next(lsteps);
+	}
+	while (ex.valid)
+	{
+#pragma unroll
+		for (int d = 0; d < D; d++)
+		{
+			if (ex.valid)
+			{
+				{
+					const Acc acc = { lpos, a.idx + ex.st.idx_off, a.params + ex.st.par_off, ex.st.par_stride, a.lambda + ex.st.lam_off, a.views[TYPE] };
+					const uint32_t q = ex.slot();
+					if (q < ex.st.count) exec_rec<TYPE>(acc, ring[d], q, a.dt, a.first_iter);
+				}
+				if (ex.last_of_step())
+				{
+					if (ex.st.barrier) __syncthreads();
+					if (trace && threadIdx.x == 0 && ex.s + 2 < kTraceStride - 1) trace[2 + ex.s] = wall_clock64();
+				}
+				ex.next(lsteps);
+				{
+					const Acc acc = { lpos, a.idx + ld.st.idx_off, a.params + ld.st.par_off, ld.st.par_stride, a.lambda + ld.st.lam_off, a.views[TYPE] };
+					load_rec<TYPE>(acc, ld.slot_clamped(), ring[d]);
+					ld.next(lsteps);
+				}
+			}
+		}
+	}
+	return ex.s + 1;
+}
+
+#define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) { \
+		s = a.views[T].compact ? run_typed<T, true, BLOCK>(a, lsteps, s, t.step_end, lpos, trace) \
+		                       : run_typed<T, false, BLOCK>(a, lsteps, s, t.step_end, lpos, trace); } \
+	else { s = t.step_end; } break;
+
+// LDS: [ step descriptors of the tile: kMaxTileSteps x 32 B ][ positions: n_local x float4 ]
+constexpr uint32_t kMaxTileSteps = 64;
 
 template <uint32_t MASK, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 {
-	extern __shared__ float4 lpos[];
-	const FusedTile t = a.tiles[logical_block(a.num_tiles, a.xcd_remap)];
+	extern __shared__ uint4 lds_raw[];
+	uint4 *lsteps = lds_raw;
+	float4 *lpos = reinterpret_cast<float4 *>(lds_raw + 2 * kMaxTileSteps);
+	const uint32_t tile_index = logical_block(a.num_tiles, a.xcd_remap);
+	const FusedTile t = a.tiles[tile_index];
+	unsigned long long *trace = a.trace ? a.trace + (size_t)tile_index * kTraceStride : nullptr;
+	if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
 	const uint32_t *gid = a.gid + t.gid_off;
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(a.steps + t.step_begin);
+		for (uint32_t i = threadIdx.x; i < 2 * (t.step_end - t.step_begin); i += BLOCK)
+			lsteps[i] = src[i];
+	}
 	for (uint32_t i = threadIdx.x; i < t.n_local; i += BLOCK)
 		lpos[i] = a.pos_in[gid[i]];
 	__syncthreads();
-	for (uint32_t s = t.step_begin; s < t.step_end; s++)
+	if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
+	// steps are addressed relative to the tile from here on
+	FusedTile tl = t;
+	(void)tl;
 	{
-		const FusedStep st = a.steps[s];
-		switch (st.type)
+		const struct { uint32_t step_end; } t = { tl.step_end - tl.step_begin };
+		uint32_t s = 0;
+		while (s < t.step_end)
 		{
-			PBDX_CASE(PBDX_DISTANCE) PBDX_CASE(PBDX_DISTANCE_XPBD) PBDX_CASE(PBDX_DIHEDRAL)
-			PBDX_CASE(PBDX_ISOMETRIC_BENDING) PBDX_CASE(PBDX_ISOMETRIC_BENDING_XPBD)
-			PBDX_CASE(PBDX_FEM_TRIANGLE) PBDX_CASE(PBDX_STRAIN_TRIANGLE)
-			PBDX_CASE(PBDX_VOLUME) PBDX_CASE(PBDX_VOLUME_XPBD)
-			PBDX_CASE(PBDX_FEM_TET) PBDX_CASE(PBDX_FEM_TET_XPBD) PBDX_CASE(PBDX_STRAIN_TET)
-			PBDX_CASE(PBDX_SHAPE_MATCHING)
-		default: break;
+			const uint32_t type = rfl(lsteps[2 * s].x);
+			switch (type)
+			{
+				PBDX_CASE(PBDX_DISTANCE) PBDX_CASE(PBDX_DISTANCE_XPBD) PBDX_CASE(PBDX_DIHEDRAL)
+				PBDX_CASE(PBDX_ISOMETRIC_BENDING) PBDX_CASE(PBDX_ISOMETRIC_BENDING_XPBD)
+				PBDX_CASE(PBDX_FEM_TRIANGLE) PBDX_CASE(PBDX_STRAIN_TRIANGLE)
+				PBDX_CASE(PBDX_VOLUME) PBDX_CASE(PBDX_VOLUME_XPBD)
+				PBDX_CASE(PBDX_FEM_TET) PBDX_CASE(PBDX_FEM_TET_XPBD) PBDX_CASE(PBDX_STRAIN_TET)
+				PBDX_CASE(PBDX_SHAPE_MATCHING)
+			default: s = t.step_end; break;
+			}
 		}
-		if (st.barrier)
-			__syncthreads();
 	}
 	for (uint32_t i = threadIdx.x; i < t.n_owned; i += BLOCK)
 		a.pos_out[gid[i]] = lpos[i];
+	if (trace && threadIdx.x == 0)
+	{
+		__builtin_amdgcn_s_waitcnt(0);
+		trace[kTraceStride - 1] = wall_clock64();
+	}
 }
 
 typedef void (*fused_fn)(FusedArgs);
@@ -239,6 +364,7 @@ struct DeviceSegment
 	float *d_params = nullptr;
 	float *d_lambda = nullptr;
 	uint32_t *d_gid = nullptr;
+	unsigned long long *d_trace = nullptr;
 	uint32_t num_tiles = 0;
 	uint32_t lds_bytes = 0;
 	uint32_t type_mask = 0;
@@ -280,6 +406,7 @@ struct pbdx_solver
 	int fuse_block = 0;                  // 0 = auto
 	uint32_t max_segment_colours = 16;
 	uint32_t lds_particles = 10240;
+	int trace = 0;
 
 	// fused plan
 	FusedPlan plan;
@@ -311,6 +438,7 @@ struct pbdx_solver
 			if (d.d_params) (void)hipFree(d.d_params);
 			if (d.d_lambda) (void)hipFree(d.d_lambda);
 			if (d.d_gid) (void)hipFree(d.d_gid);
+			if (d.d_trace) (void)hipFree(d.d_trace);
 		}
 		dsegs.clear();
 		plan = FusedPlan();
@@ -377,7 +505,8 @@ int ensure_plan(pbdx_solver *s)
 	opt.tile_particles = s->tile_particles;
 	{
 		const size_t lds = s->prop.maxSharedMemoryPerMultiProcessor ? s->prop.maxSharedMemoryPerMultiProcessor : s->prop.sharedMemPerBlock;
-		opt.max_local = std::min<uint32_t>(s->lds_particles, (uint32_t)(lds / 16));
+		opt.max_local = std::min<uint32_t>(s->lds_particles, (uint32_t)(lds / 16) - kMaxTileSteps * 2);
+		opt.max_tile_steps = kMaxTileSteps;
 	}
 	opt.num_cus = (uint32_t)std::max(1, s->prop.multiProcessorCount);
 	opt.max_segment_colours = s->max_segment_colours;
@@ -405,7 +534,7 @@ int ensure_plan(pbdx_solver *s)
 			HIPCHECK(hipMemset(d.d_lambda, 0, (size_t)seg.lam_count * sizeof(float)));
 		}
 		d.num_tiles = (uint32_t)seg.tiles.size();
-		d.lds_bytes = std::max(seg.max_local, 1u) * 16u;
+		d.lds_bytes = std::max(seg.max_local, 1u) * 16u + kMaxTileSteps * 32u;
 		d.type_mask = seg.type_mask;
 		d.constraints = seg.constraints;
 		for (const PlanBatch &pb : pbs)
@@ -446,14 +575,19 @@ int launch_batch(pbdx_solver *s, const Batch &b, float dt, int first_iter)
 	const uint32_t bs = (uint32_t)s->block_size;
 	a.num_blocks = (b.count + bs - 1) / bs;
 	a.xcd_remap = s->xcd_remap;
-	hipLaunchKernelGGL(kProjectKernels[b.type], dim3(a.num_blocks), dim3(bs), 0, s->stream, a);
+	hipLaunchKernelGGL(kProjectKernels[b.type][b.view.compact ? 1 : 0], dim3(a.num_blocks), dim3(bs), 0, s->stream, a);
 	HIPCHECK(hipGetLastError());
 	return PBDX_OK;
 }
 
 int launch_segment(pbdx_solver *s, size_t si, int src, float dt, int first_iter)
 {
-	const DeviceSegment &d = s->dsegs[si];
+	DeviceSegment &d = s->dsegs[si];
+	if (s->trace && !d.d_trace)
+	{
+		HIPCHECK(hipMalloc(&d.d_trace, (size_t)d.num_tiles * kTraceStride * sizeof(unsigned long long)));
+		HIPCHECK(hipMemset(d.d_trace, 0, (size_t)d.num_tiles * kTraceStride * sizeof(unsigned long long)));
+	}
 	FusedArgs a;
 	a.pos_in = s->d_pos[src];
 	a.pos_out = s->d_pos[src ^ 1];
@@ -462,6 +596,7 @@ int launch_segment(pbdx_solver *s, size_t si, int src, float dt, int first_iter)
 	a.first_iter = first_iter;
 	a.num_tiles = d.num_tiles;
 	a.xcd_remap = s->xcd_remap;
+	a.trace = s->trace ? d.d_trace : nullptr;
 	memcpy(a.views, s->plan.views, sizeof(a.views));
 	hipLaunchKernelGGL(d.kernel, dim3(d.num_tiles), dim3(d.block), d.lds_bytes, s->stream, a);
 	HIPCHECK(hipGetLastError());
@@ -740,30 +875,19 @@ int pbdx_solver_add_batch(pbdx_solver *s, uint32_t group, int type, uint32_t cou
 	HIPCHECK(hipMalloc(&b.d_idx, idx.size() * sizeof(uint32_t)));
 	HIPCHECK(hipMemcpy(b.d_idx, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 
-	// parameters: detect batch-uniform ones, lay the rest out planar
-	memset(&b.view, 0, sizeof(b.view));
+	// parameters: detect batch-uniform ones (and symmetric Q), lay the rest out planar
 	const uint32_t np = ti->param_stride;
 	const uint32_t stride = (count + 3u) & ~3u;
-	for (uint32_t k = 0; k < np; k++)
-	{
-		bool uniform = true;
-		uint32_t first; memcpy(&first, &params[k], 4);
-		for (uint32_t i = 1; i < count && uniform; i++)
-		{
-			uint32_t cur; memcpy(&cur, &params[(size_t)i * np + k], 4);
-			uniform = (cur == first);
-		}
-		if (uniform) { b.view.umask |= 1u << k; b.view.u[k] = params[k]; }
-		else b.view.slot[k] = (uint8_t)b.view.nplanes++;
-	}
+	compute_type_view(type, { { params, count } }, b.view);
 	b.par_stride = stride;
-	if (b.view.nplanes)
+	const bool compact = b.view.compact != 0;
+	if (num_planes(type, compact))
 	{
-		std::vector<float> planar((size_t)b.view.nplanes * stride, 0.0f);
+		std::vector<float> planar((size_t)num_planes(type, compact) * stride, 0.0f);
 		for (uint32_t k = 0; k < np; k++)
 		{
-			if ((b.view.umask >> k) & 1u) continue;
-			float *dst = &planar[(size_t)b.view.slot[k] * stride];
+			if (!param_streams(type, compact, (int)k)) continue;
+			float *dst = &planar[(size_t)param_plane(type, compact, (int)k) * stride];
 			for (uint32_t i = 0; i < count; i++) dst[i] = params[(size_t)i * np + k];
 		}
 		HIPCHECK(hipMalloc(&b.d_params, planar.size() * sizeof(float)));
@@ -831,6 +955,7 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 	case PBDX_OPT_LDS_PARTICLES:
 		if (value < 64 || value > 10240) { set_error("lds_particles must be 64 .. 10240"); return PBDX_ERR_INVALID; }
 		s->lds_particles = (uint32_t)value; replan = true; break;
+	case PBDX_OPT_TRACE: s->trace = value != 0; break;
 	default: set_error("unknown option %d", option); return PBDX_ERR_INVALID;
 	}
 	s->drop_graph();
@@ -1045,6 +1170,19 @@ int pbdx_solver_get_segment_info(pbdx_solver *s, uint32_t segment, pbdx_segment_
 	out->constraints = seg.constraints; out->slots = seg.slots; out->stream_bytes = seg.stream_bytes;
 	out->algorithmic_bytes = d.algorithmic_bytes;
 	out->profiled_ms = d.ms; out->profiled_launches = d.launches;
+	return PBDX_OK;
+}
+
+int pbdx_solver_get_trace(pbdx_solver *s, uint32_t segment, uint64_t *out, uint32_t capacity, uint32_t *stride)
+{
+	if (!s || !out || !s->plan_ok || segment >= s->dsegs.size() || !s->dsegs[segment].d_trace) { set_error("get_trace: no trace for this segment (set PBDX_OPT_TRACE and step once)"); return PBDX_ERR_INVALID; }
+	const DeviceSegment &d = s->dsegs[segment];
+	const size_t need = (size_t)d.num_tiles * kTraceStride;
+	if (capacity < need) { set_error("get_trace: need room for %zu stamps", need); return PBDX_ERR_INVALID; }
+	HIPCHECK(hipSetDevice(s->device));
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	HIPCHECK(hipMemcpy(out, d.d_trace, need * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	if (stride) *stride = kTraceStride;
 	return PBDX_OK;
 }
 

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Developer aid: per-colour-step timeline of the fused tile kernel on the headline cloth
+(PBDX_OPT_TRACE).  Prints, per segment, the median/max over tiles of: LDS fill, every colour
+step, write-back, and the spread of tile start/end times."""
+import argparse, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import positionbaseddynamics_amd as pbd
+from tests import util
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=1000)
+ap.add_argument("--max-seg", type=int, default=None)
+ap.add_argument("--tile", type=int, default=None)
+ap.add_argument("--fuse-block", type=int, default=None)
+args = ap.parse_args()
+model = util.build_mine(util.cloth_spec(args.size, args.size, 4, 3))
+ts = pbd.TimeStepController()
+ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 10)
+sol = ts.solver()
+for v, o in ((args.max_seg, sol.OPT_MAX_SEGMENT_COLOURS), (args.tile, sol.OPT_TILE_PARTICLES), (args.fuse_block, sol.OPT_FUSE_BLOCK)):
+    if v is not None:
+        sol.set_option(o, v)
+ts.stepResident(model, 10)
+sol.set_option(sol.OPT_TRACE, 1)
+sol.set_option(sol.OPT_USE_GRAPH, 0)
+ts.stepResident(model, 1)
+plan = sol.plan_info()
+print(plan)
+for seg in range(plan["num_segments"]):
+    si = sol.segment_info(seg)
+    tr = sol.trace(seg).astype(np.int64)
+    t0 = tr[:, 0].min()
+    start = (tr[:, 0] - t0) * 0.01
+    end = (tr[:, -1] - t0) * 0.01
+    fill = (tr[:, 1] - tr[:, 0]) * 0.01
+    print("segment %d colours [%d,%d): tiles %d block %d; tile start spread %.2f us, end median %.2f max %.2f us; fill median %.2f max %.2f us" % (
+        seg, si["colour_begin"], si["colour_end"], si["num_tiles"], si["block"], start.max(), np.median(end), end.max(), np.median(fill), fill.max()))
+    nsteps = int((tr[:, 2:-1] > 0).sum(axis=1).max())
+    prev = tr[:, 1]
+    rows = []
+    for i in range(nsteps):
+        cur = tr[:, 2 + i]
+        ok = cur > 0
+        d = (cur[ok] - prev[ok]) * 0.01
+        rows.append("%2d: med %.2f max %.2f" % (i, np.median(d), d.max()))
+        prev = np.where(ok, cur, prev)
+    print("   step durations (us): " + " | ".join(rows))
+    wb = (tr[:, -1] - prev) * 0.01
+    print("   write-back median %.2f max %.2f us" % (np.median(wb), wb.max()))
