@@ -26,12 +26,34 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 
 
-def build_cloth(pbd, n, cloth_method=4, bending_method=3):
+def build_workload(args, ens):
+    """Returns (model, build seconds, workload description, check function).  Workloads:
+       c2  (default, the headline config) one size x size cloth per GPU
+       c4  BASELINE configs[3]: `--instances` independent size x size cloths (512 x 200x200 over 8 GPUs
+           = 64 per GPU); the global instance list is sharded contiguously over the ranks
+       c3  BASELINE configs[2]: 101x21x11 FEM-tet bar (100 000 tets), one per GPU -- latency-bound by
+           construction (40 colours x 10 iterations over 23 331 particles), reported, not the headline"""
     from tests import util
     t0 = time.perf_counter()
-    model = util.build_mine(util.cloth_spec(n, n, cloth_method, bending_method))
+    if args.workload == "c3":
+        spec = util.bar_spec(101, 21, 11, args.solid_method)
+        desc = "configs[2]: 101x21x11 regular tet bar (100000 tets), solid method %d, %d iterations, 1 substep, h=0.005" % (args.solid_method, args.iters)
+        pins = [0]
+    elif args.workload == "c4":
+        begin, end = ens.shard(args.instances * ens.world)     # weak scaling: `instances` per GPU
+        k = end - begin
+        spec = util.cloth_spec(args.size, args.size, 4, 3, instances=k, instance_offset=(0.0, 0.0, 12.0))
+        desc = "configs[3]: %d independent %dx%d cloth instances per GPU (XPBD distance + XPBD isometric bending), %d iterations, 1 substep, h=0.005" % (
+            k, args.size, args.size, args.iters)
+        pins = [0, args.size - 1]
+    else:
+        spec = util.cloth_spec(args.size, args.size, 4, 3)
+        desc = "configs[1]: single %dx%d cloth sheet per GPU (XPBD distance k=1e5 + XPBD isometric bending k=100), %d iterations, 1 substep, h=0.005" % (
+            args.size, args.size, args.iters)
+        pins = [0, args.size - 1]
+    model = util.build_mine(spec)
     model.initConstraintGroups()
-    return model, time.perf_counter() - t0
+    return model, time.perf_counter() - t0, desc, pins
 
 
 def cpu_baseline(n, iters, budget_s=30.0):
@@ -90,12 +112,84 @@ def cpu_baseline(n, iters, budget_s=30.0):
                 " (-O3 -march=x86-64-v3 -fopenmp, float)" if variant == "fast" else "", sorted(results), os.cpu_count() or 1, t_setup)}
 
 
+CALIB_BYTES = 1 << 28
+
+
+def _pmc_pass(counter, child_args, timeout_s=240):
+    """One `rocprofv3 --pmc <counter>` pass over a short child run of this script (its own process:
+    counters and traces are never combined, and the profiled run is never the timed one).
+    Returns {kernel_name: [counter values per dispatch]} or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    outdir = tempfile.mkdtemp(prefix="pbdx_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "-o", "pmc", "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+    except Exception:
+        return None
+    vals = {}
+    for f in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") == counter:
+                    vals.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+    shutil.rmtree(outdir, ignore_errors=True)
+    return vals or None
+
+
+def collect_traffic(child_args, kernel_substring):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, as MI355X_MICROARCH.md (HBM)
+    prescribes: FETCH_SIZE and WRITE_SIZE in separate passes; the counters are turned into bytes with
+    factors calibrated IN THE SAME PASS on streaming kernels of known size in this engine's own access
+    widths (the guide: gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read; other widths
+    and WRITE_SIZE must be calibrated).  Infinity-Cache hits are counted as traffic."""
+    res = {}
+    for counter, calib in (("FETCH_SIZE", ("calib_read_b32", "calib_read_b128")), ("WRITE_SIZE", ("calib_write_b32", "calib_write_b128"))):
+        vals = _pmc_pass(counter, child_args)
+        if not vals:
+            return None
+        factors = {}
+        for name in calib:
+            v = [x for k, xs in vals.items() if name in k for x in xs]
+            if v:
+                factors[name] = CALIB_BYTES / (sum(v) / len(v))      # bytes per counter unit
+        dom = [x for k, xs in vals.items() if kernel_substring in k for x in xs]
+        if not dom or not factors:
+            return None
+        res[counter] = {"mean_counter_per_launch": sum(dom) / len(dom), "launches": len(dom), "bytes_per_unit": factors}
+    # the dominant kernel reads 4-byte streams (parameters, multipliers, packed indices) and 16-byte
+    # positions, writes 4-byte multipliers and 16-byte positions: bracket with both calibrations
+    out = {"fetch_bytes": {}, "write_bytes": {}}
+    for name, f in res["FETCH_SIZE"]["bytes_per_unit"].items():
+        out["fetch_bytes"][name] = res["FETCH_SIZE"]["mean_counter_per_launch"] * f
+    for name, f in res["WRITE_SIZE"]["bytes_per_unit"].items():
+        out["write_bytes"][name] = res["WRITE_SIZE"]["mean_counter_per_launch"] * f
+    fb = out["fetch_bytes"].get("calib_read_b32", next(iter(out["fetch_bytes"].values())))
+    wb = out["write_bytes"].get("calib_write_b32", next(iter(out["write_bytes"].values())))
+    out["bytes_per_launch"] = fb + wb
+    out["raw"] = res
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--size", type=int, default=1000, help="cloth is size x size particles")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2")
+    ap.add_argument("--size", type=int, default=None, help="cloth is size x size particles (default 1000; 200 for c4)")
+    ap.add_argument("--instances", type=int, default=64, help="c4: cloth instances per GPU")
+    ap.add_argument("--solid-method", type=int, default=2, help="c3: addSolidConstraints method (2 FEM tet, 4 strain tet, 6 XPBD distance+volume)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -107,19 +201,17 @@ def main():
     ap.add_argument("--fuse-block", type=int, default=None)
     ap.add_argument("--max-seg", type=int, default=None, help="max colours fused into one launch")
     ap.add_argument("--lds-particles", type=int, default=None)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.size is None:
+        args.size = 200 if args.workload == "c4" else 1000
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
+    from positionbaseddynamics_amd.ensemble import Ensemble
+    ens = Ensemble()
+    rank, local_rank, world, dist = ens.rank, ens.local_rank, ens.world, ens.dist
+    if world == 1:
         torch.cuda.set_device(0)
         local_rank = 0
 
@@ -127,7 +219,14 @@ def main():
     if pbd.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
 
-    model, t_build = build_cloth(pbd, args.size)
+    if args.pmc_child:
+        from positionbaseddynamics_amd import _ffi
+        for mode in range(4):
+            _ffi.check(_ffi.lib.pbdx_debug_stream(local_rank, CALIB_BYTES, mode), "pbdx_debug_stream")
+        args.no_roofline = args.no_cpu_baseline = True
+        args.steps, args.warmup = 2, 1
+
+    model, t_build, workload_desc, pins = build_workload(args, ens)
     n_particles = model.getParticles().size()
     n_constraints = model.numConstraints()
     n_groups = len(model.getConstraintGroups())
@@ -150,9 +249,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        ens.barrier()
 
     # warm-up (untimed): uploads the device image, instantiates the hipGraph, activates the constraints
     ts.stepResident(model, max(args.warmup, 1))
@@ -164,22 +261,18 @@ def main():
     stats = sol.stats()
     plan = sol.plan_info()
     barrier()
-    if dist is not None:
-        tt = torch.tensor([t_local], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_max = float(tt.item())
-    else:
-        t_max = t_local
+    t_max = ens.max_time(t_local)                       # max over ranks
+    total_constraints = ens.sum_count(n_constraints)    # all ranks (weak scaling: every rank owns its own instances)
 
     projections_per_step = n_constraints * args.iters
-    value = projections_per_step * args.steps * world / t_max
+    value = total_constraints * args.iters * args.steps / t_max
     ms_per_step = 1e3 * t_max / args.steps
 
     # sanity: the state must be finite and the pinned corners must not have moved
     ts.syncToHost(model)
     x = model.getParticles().positions()
     x0 = model.getParticles().array(1)
-    ok = bool(np.all(np.isfinite(x)) and np.array_equal(x[0], x0[0]) and np.array_equal(x[args.size - 1], x0[args.size - 1]))
+    ok = bool(np.all(np.isfinite(x)) and all(np.array_equal(x[p], x0[p]) for p in pins))
 
     out = {
         "metric": "constraint-projections/s", "value": value, "unit": "projections/s",
@@ -187,9 +280,9 @@ def main():
         "ms_per_step": ms_per_step, "ms_per_substep": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: single %dx%d cloth sheet per GPU (XPBD distance k=1e5 + XPBD isometric bending k=100), %d iterations, 1 substep, h=0.005" % (args.size, args.size, args.iters),
+        "config": {"workload": workload_desc,
                    "particles": n_particles, "constraints": n_constraints, "colour_groups": n_groups,
-                   "projections_per_substep": projections_per_step, "parallelism": "ensemble x%d (one sheet per GPU, no cross-GPU constraints)" % world,
+                   "projections_per_substep": projections_per_step, "parallelism": "ensemble x%d (independent instances per GPU, no cross-GPU constraints, no data-path collective)" % world,
                    "state_ok": ok, "device_event_ms_per_substep": stats["total_ms"] / max(args.steps, 1),
                    "algorithmic_GB_per_substep": stats["algorithmic_bytes"] / max(args.steps, 1) / 1e9,
                    "whole_substep_algorithmic_GBs": stats["algorithmic_bytes"] / max(stats["total_ms"], 1e-9) / 1e6,
@@ -242,14 +335,32 @@ def main():
                                    "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": dur_s * 1e6,
                                    "launches_measured": launches, "per_type": per_type}
 
+    if rank == 0 and world == 1 and "roofline" in out and not args.no_traffic and not args.pmc_child:
+        child = ["--workload", args.workload, "--size", str(args.size), "--iters", str(args.iters), "--instances", str(args.instances),
+                 "--solid-method", str(args.solid_method)]
+        for flag, val in (("--fuse", args.fuse), ("--tile", args.tile), ("--fuse-block", args.fuse_block), ("--max-seg", args.max_seg),
+                          ("--lds-particles", args.lds_particles), ("--xcd-remap", args.xcd_remap), ("--block", args.block)):
+            if val is not None:
+                child += [flag, str(val)]
+        tr = collect_traffic(child, "fused_kernel" if plan["active"] else "project_kernel")
+        if tr is not None:
+            r = out["roofline"]
+            if plan["active"]:
+                # the PMC mean runs over the launches of ALL segments: compare with the mean over segments
+                rows = r["segments"]
+                nl = sum(x["launches"] for x in rows)
+                r["traffic_scope"] = "mean over the launches of all %d segments of a sweep" % len(rows)
+                r["algorithmic_bytes_per_launch_mean"] = sum(x["algorithmic_bytes_per_launch"] * x["launches"] for x in rows) / nl
+                r["streamed_bytes_per_launch_mean"] = sum(x["streamed_bytes_per_launch"] * x["launches"] for x in rows) / nl
+            r["traffic"] = tr["bytes_per_launch"]
+            r["traffic_detail"] = {k: tr[k] for k in ("fetch_bytes", "write_bytes", "raw")}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.size, args.iters)
+        out["cpu_baseline"] = cpu_baseline(args.size if args.workload != "c3" else 400, args.iters)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ens.close()
 
 
 if __name__ == "__main__":

@@ -73,6 +73,7 @@ SIGNATURES = [
     ("pbdx_solver_get_plan_info", C.c_int, vp, C.POINTER(PlanInfo)),
     ("pbdx_solver_get_segment_info", C.c_int, vp, u32, C.POINTER(SegmentInfo)),
     ("pbdx_solver_get_trace", C.c_int, vp, u32, C.POINTER(C.c_uint64), u32, C.POINTER(u32)),
+    ("pbdx_debug_stream", C.c_int, C.c_int, C.c_uint64, C.c_int),
     ("pbdx_model_plan_check", C.c_int, vp, u32, u32, u32, C.POINTER(PlanInfo)),
     ("pbdx_model_create", C.c_int, C.POINTER(vp)), ("pbdx_model_destroy", None, vp),
     ("pbdx_model_cleanup", C.c_int, vp), ("pbdx_model_reset", C.c_int, vp),

@@ -341,6 +341,29 @@ __global__ __launch_bounds__(256) void velocity_kernel(const float4 *__restrict_
 	vel[i] = v;
 }
 
+// ---- counter calibration kernels (pbdx_debug_stream): known byte counts in this engine's own access
+// widths, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be turned into bytes (MI355X_MICROARCH.md, HBM)
+__global__ __launch_bounds__(256) void calib_read_b32(const float *__restrict__ src, float *__restrict__ sink, size_t n)
+{
+	float acc = 0.0f;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += src[i];
+	if (acc == 123.456f) sink[0] = acc;
+}
+__global__ __launch_bounds__(256) void calib_read_b128(const float4 *__restrict__ src, float *__restrict__ sink, size_t n)
+{
+	float acc = 0.0f;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { const float4 v = src[i]; acc += v.x + v.w; }
+	if (acc == 123.456f) sink[0] = acc;
+}
+__global__ __launch_bounds__(256) void calib_write_b32(float *__restrict__ dst, size_t n)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = 1.0f;
+}
+__global__ __launch_bounds__(256) void calib_write_b128(float4 *__restrict__ dst, size_t n)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = make_float4(1.0f, 2.0f, 3.0f, 4.0f);
+}
+
 struct Batch
 {
 	int type = 0;
@@ -603,12 +626,13 @@ int launch_segment(pbdx_solver *s, size_t si, int src, float dt, int first_iter)
 	return PBDX_OK;
 }
 
-// event bookkeeping for the profiled (eager) mode: one event before every projection launch and
-// one after the last launch of a sweep; elapsed(e[i], e[i+1]) is charged to launch i.
-// kind >= 0: constraint type of a per-colour launch; kind <= -2: fused segment (-2 - kind); -1: end marker
+// event bookkeeping for the profiled (eager) mode: one event right before and one right after every
+// projection launch; elapsed(before, after) is charged to the launch (kernel duration on the
+// engine's stream, without the host-side gap to the next launch).
+// kind >= 0: constraint type of a per-colour launch; kind <= -2: fused segment (-2 - kind)
 struct ProfCursor { pbdx_solver *s; size_t next = 0; std::vector<int> kinds; std::vector<uint32_t> counts; };
 
-int prof_mark(ProfCursor *pc, int kind, uint32_t count)
+int prof_event(ProfCursor *pc)
 {
 	pbdx_solver *s = pc->s;
 	if (pc->next >= s->prof_events.size())
@@ -618,10 +642,15 @@ int prof_mark(ProfCursor *pc, int kind, uint32_t count)
 		s->prof_events.push_back(e);
 	}
 	HIPCHECK(hipEventRecord(s->prof_events[pc->next++], s->stream));
-	pc->kinds.push_back(kind);
-	pc->counts.push_back(count);
 	return PBDX_OK;
 }
+int prof_begin(ProfCursor *pc, int kind, uint32_t count)
+{
+	pc->kinds.push_back(kind);
+	pc->counts.push_back(count);
+	return prof_event(pc);
+}
+int prof_end(ProfCursor *pc) { return prof_event(pc); }
 
 // number of position-buffer flips of `iterations` sweeps
 inline uint32_t sweep_flips(const pbdx_solver *s, uint32_t iterations)
@@ -638,9 +667,10 @@ int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, Pr
 		for (uint32_t it = 0; it < iterations; it++)
 			for (size_t si = 0; si < s->dsegs.size(); si++)
 			{
-				if (pc) { int r = prof_mark(pc, -2 - (int)si, (uint32_t)s->dsegs[si].constraints); if (r) return r; }
+				if (pc) { int r = prof_begin(pc, -2 - (int)si, (uint32_t)s->dsegs[si].constraints); if (r) return r; }
 				int r = launch_segment(s, si, src, dt, it == 0);
 				if (r) return r;
+				if (pc) { r = prof_end(pc); if (r) return r; }
 				src ^= 1;
 			}
 	}
@@ -650,12 +680,12 @@ int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, Pr
 			for (uint32_t bi : s->order)
 			{
 				const Batch &b = s->batches[bi];
-				if (pc) { int r = prof_mark(pc, b.type, b.count); if (r) return r; }
+				if (pc) { int r = prof_begin(pc, b.type, b.count); if (r) return r; }
 				int r = launch_batch(s, b, dt, it == 0);
 				if (r) return r;
+				if (pc) { r = prof_end(pc); if (r) return r; }
 			}
 	}
-	if (pc) { int r = prof_mark(pc, -1, 0); if (r) return r; }
 	return PBDX_OK;
 }
 
@@ -684,12 +714,11 @@ int enqueue_substep(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int v
 int collect_profile(pbdx_solver *s, ProfCursor *pc)
 {
 	HIPCHECK(hipStreamSynchronize(s->stream));
-	for (size_t i = 0; i + 1 < pc->next; i++)
+	for (size_t i = 0; i < pc->kinds.size(); i++)
 	{
 		const int t = pc->kinds[i];
-		if (t == -1) continue;
 		float ms = 0.0f;
-		HIPCHECK(hipEventElapsedTime(&ms, s->prof_events[i], s->prof_events[i + 1]));
+		HIPCHECK(hipEventElapsedTime(&ms, s->prof_events[2 * i], s->prof_events[2 * i + 1]));
 		if (t >= 0)
 		{
 			s->type_ms[t] += ms;
@@ -1183,6 +1212,30 @@ int pbdx_solver_get_trace(pbdx_solver *s, uint32_t segment, uint64_t *out, uint3
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	HIPCHECK(hipMemcpy(out, d.d_trace, need * sizeof(uint64_t), hipMemcpyDeviceToHost));
 	if (stride) *stride = kTraceStride;
+	return PBDX_OK;
+}
+
+int pbdx_debug_stream(int device, uint64_t nbytes, int mode)
+{
+	HIPCHECK(hipSetDevice(device));
+	if (nbytes < 4096) { set_error("debug_stream: nbytes too small"); return PBDX_ERR_INVALID; }
+	float *buf = nullptr, *sink = nullptr;
+	HIPCHECK(hipMalloc(&buf, nbytes));
+	HIPCHECK(hipMalloc(&sink, 64));
+	HIPCHECK(hipMemset(buf, 0, nbytes));
+	HIPCHECK(hipDeviceSynchronize());
+	const dim3 grid(256 * 32), block(256);
+	switch (mode)
+	{
+	case 0: hipLaunchKernelGGL(calib_read_b32, grid, block, 0, 0, buf, sink, (size_t)(nbytes / 4)); break;
+	case 1: hipLaunchKernelGGL(calib_read_b128, grid, block, 0, 0, reinterpret_cast<const float4 *>(buf), sink, (size_t)(nbytes / 16)); break;
+	case 2: hipLaunchKernelGGL(calib_write_b32, grid, block, 0, 0, buf, (size_t)(nbytes / 4)); break;
+	case 3: hipLaunchKernelGGL(calib_write_b128, grid, block, 0, 0, reinterpret_cast<float4 *>(buf), (size_t)(nbytes / 16)); break;
+	default: (void)hipFree(buf); (void)hipFree(sink); set_error("debug_stream: mode 0..3"); return PBDX_ERR_INVALID;
+	}
+	HIPCHECK(hipGetLastError());
+	HIPCHECK(hipDeviceSynchronize());
+	(void)hipFree(buf); (void)hipFree(sink);
 	return PBDX_OK;
 }
 

@@ -1,0 +1,103 @@
+"""Ensemble sharding of independent scene instances over GPUs.
+
+A single sheet / bar is one connected colour-sequential Gauss-Seidel problem and does not shard;
+what shards is a set of independent instances.  One process per GPU (`torch.distributed`; backend
+"nccl" is RCCL on ROCm, "gloo" on CPU for the tests), contiguous blocks of instances per rank, NO
+collective on the data path: RCCL/gloo carry only the barrier, the max-over-ranks time, a few
+counters and (for parity checks) per-instance checksums."""
+import os
+
+import numpy as np
+
+
+def shard_range(total, world, rank):
+    """Contiguous block [begin, end) of `total` instances owned by `rank` (sizes differ by at most 1)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    base, extra = divmod(int(total), int(world))
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def checksum(positions):
+    """Order-sensitive 64-bit checksum of a float32 position array (bit-exact comparisons across ranks)."""
+    a = np.ascontiguousarray(positions, dtype=np.float32).view(np.uint32).astype(np.uint64).reshape(-1)
+    w = (np.arange(a.size, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0xD1B54A32D192ED03))
+    with np.errstate(over="ignore"):
+        return int(np.bitwise_xor.reduce(a * w + (a << np.uint64(17)))) & 0x7FFFFFFFFFFFFFFF
+
+
+class Ensemble:
+    """Process-group plumbing shared by bench.py and the tests."""
+
+    def __init__(self, backend=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        self.device = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                self.device = torch.device("cuda", self.local_rank)
+                dist.init_process_group(backend="nccl", device_id=self.device)
+            else:
+                self.device = torch.device("cpu")
+                dist.init_process_group(backend=backend)
+            self.dist = dist
+        self.backend = backend
+
+    def shard(self, total):
+        return shard_range(total, self.world, self.rank)
+
+    def _sync_device(self):
+        if self.device is not None and self.device.type == "cuda":
+            import torch
+            torch.cuda.synchronize()
+
+    def barrier(self):
+        self._sync_device()
+        if self.dist is not None:
+            self.dist.barrier()
+        self._sync_device()
+
+    def _reduce(self, value, op_name, dtype):
+        if self.dist is None:
+            return value
+        import torch
+        t = torch.tensor([value], dtype=dtype, device=self.device)
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op_name))
+        return t.item()
+
+    def max_time(self, seconds):
+        import torch
+        return float(self._reduce(float(seconds), "MAX", torch.float64))
+
+    def sum_count(self, n):
+        import torch
+        return int(self._reduce(int(n), "SUM", torch.int64))
+
+    def gather_checksums(self, local, total):
+        """All ranks contribute the checksums of their instances; returns the full list (length `total`)
+        on every rank.  Implemented as a SUM all-reduce of a zero-padded vector (instances are disjoint)."""
+        begin, end = self.shard(total)
+        if len(local) != end - begin:
+            raise ValueError("rank %d owns %d instances, got %d checksums" % (self.rank, end - begin, len(local)))
+        if self.dist is None:
+            return list(local)
+        import torch
+        v = torch.zeros(total, dtype=torch.int64, device=self.device)
+        v[begin:end] = torch.tensor([int(c) for c in local], dtype=torch.int64)
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM)
+        return [int(x) for x in v.cpu().tolist()]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.dist = None

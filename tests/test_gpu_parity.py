@@ -317,3 +317,49 @@ def test_schedule_validator_and_lambdas(pbd):
     lam = sol.get_lambdas(0, len(ids))
     lam_ref = np.array([o.constraint_lambda(int(c)) for c in ids])
     assert np.allclose(lam, lam_ref, rtol=1e-5, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json full sizes
+# ---------------------------------------------------------------------------
+def test_full_size_c2_million_particle_cloth_vs_reference(pbd):
+    """configs[1] at full size: 1000x1000 cloth, 5 988 006 constraints, 27 colours, 10 iterations.
+    Two steps through the default (colour-fused) schedule against the reference's own float build
+    run on the host cores: every one of the 3 000 000 coordinates bit-identical; then the
+    per-colour schedule against the fused one (size-independent cross-check of the two device paths)."""
+    ops = util.cloth_spec(1000, 1000, 4, 3)
+    ref = util.oracle_run(ops, 2, 1, 10, "f32", threads=16)
+    xr, vr = ref.positions().astype(np.float32), ref.get_array(2).astype(np.float32)
+    m, ts = util.mine_run(ops, 2, 1, 10, resident=True)
+    info = ts.solver().plan_info()
+    print("C2 full size plan:", info)
+    assert info["active"] == 1 and info["max_local"] <= 10240
+    xg, vg = m.getParticles().positions(), m.getParticles().array(2)
+    assert util.bitwise_equal(xg, xr), "max err %.3e" % util.max_err(xg, xr)
+    assert util.bitwise_equal(vg, vr)
+    m2, ts2 = util.mine_run(ops, 2, 1, 10, resident=True, options={pbd.Solver.OPT_FUSE: 0})
+    assert ts2.solver().plan_info()["active"] == 0
+    assert util.bitwise_equal(m2.getParticles().positions(), xg)
+    # pinned corners never move, state finite
+    x0 = m.getParticles().array(1)
+    assert np.array_equal(xg[0], x0[0]) and np.array_equal(xg[999], x0[999]) and np.all(np.isfinite(xg))
+
+
+@pytest.mark.parametrize("method,iters,sub", [(2, 10, 1), (6, 10, 1), (4, 10, 1)])
+def test_full_size_c3_100k_tet_bar_vs_reference(pbd, method, iters, sub):
+    """configs[2] at full size: 101x21x11 bar, 100 000 tets (FEM tet / XPBD distance+volume / strain tet)."""
+    ops = util.bar_spec(101, 21, 11, method)
+    xr = util.oracle_positions(ops, 3, sub, iters, "f32", threads=8).astype(np.float32)
+    m, ts = util.mine_run(ops, 3, sub, iters, resident=True)
+    xg = m.getParticles().positions()
+    print("C3 full size method %d plan: %s" % (method, ts.solver().plan_info()))
+    assert util.bitwise_equal(xg, xr), "max err %.3e" % util.max_err(xg, xr)
+
+
+def test_c4_ensemble_block_of_instances_vs_reference(pbd):
+    """configs[3] in one GPU's share, reduced: 8 independent 200x200 sheets in one model (the per-GPU
+    block of the 512-instance ensemble is 64 of them) against the reference on the same model."""
+    ops = util.cloth_spec(200, 200, 4, 3, instances=8, instance_offset=(0.0, 0.0, 12.0))
+    xr = util.oracle_positions(ops, 2, 1, 10, "f32", threads=8).astype(np.float32)
+    m, ts = util.mine_run(ops, 2, 1, 10, resident=True)
+    assert util.bitwise_equal(m.getParticles().positions(), xr)
