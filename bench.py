@@ -274,6 +274,16 @@ def main():
     x0 = model.getParticles().array(1)
     ok = bool(np.all(np.isfinite(x)) and all(np.array_equal(x[p], x0[p]) for p in pins))
 
+    # PCIe-inclusive rate of the TimeStep::step contract (host ParticleData in -> step -> host ParticleData
+    # out every step); reported for information only, never `value`
+    t_pcie = None
+    if rank == 0:
+        ts.step(model)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ts.step(model)
+        t_pcie = (time.perf_counter() - t1) / 3
+
     out = {
         "metric": "constraint-projections/s", "value": value, "unit": "projections/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -286,7 +296,7 @@ def main():
                    "state_ok": ok, "device_event_ms_per_substep": stats["total_ms"] / max(args.steps, 1),
                    "algorithmic_GB_per_substep": stats["algorithmic_bytes"] / max(args.steps, 1) / 1e9,
                    "whole_substep_algorithmic_GBs": stats["algorithmic_bytes"] / max(stats["total_ms"], 1e-9) / 1e6,
-                   "host_scene_build_s": t_build, "plan": plan, "engine": sol.describe()},
+                   "host_scene_build_s": t_build, "pcie_inclusive_ms_per_step": None if t_pcie is None else 1e3 * t_pcie, "plan": plan, "engine": sol.describe()},
     }
 
     if rank == 0 and not args.no_roofline:

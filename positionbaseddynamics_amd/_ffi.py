@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libpbdx.so")
+# PBDX_LIB: developer override to A/B a differently tuned build of the SAME library (never a fallback)
+LIB_PATH = os.environ.get("PBDX_LIB") or os.path.join(_HERE, "_lib", "libpbdx.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

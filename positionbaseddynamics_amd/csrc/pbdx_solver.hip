@@ -123,7 +123,13 @@ constexpr uint32_t kTraceStride = 80;
 // D records and fetches the chunk D positions ahead -- across colour barriers -- while it projects
 // the current one.  This decouples the HBM latency of the streams from the barrier-synchronised
 // colour sweep.  The pipeline runs over maximal runs of steps of one constraint type.
-template <int TYPE> struct Depth { static constexpr int value = kParamCount[TYPE] <= 2 ? 4 : 2; };
+#ifndef PBDX_DEPTH_SMALL
+#define PBDX_DEPTH_SMALL 4     // ring depth for 2-parameter records (distance, volume, dihedral)
+#endif
+#ifndef PBDX_DEPTH_BIG
+#define PBDX_DEPTH_BIG 2       // ring depth for the wide records (bending 11-17, FEM 10-13, shape matching 24 floats)
+#endif
+template <int TYPE> struct Depth { static constexpr int value = kParamCount[TYPE] <= 2 ? PBDX_DEPTH_SMALL : PBDX_DEPTH_BIG; };
 
 struct StepS { uint32_t type, count, idx_off, par_off, par_stride, lam_off, barrier; };
 
@@ -341,6 +347,36 @@ __global__ __launch_bounds__(256) void velocity_kernel(const float4 *__restrict_
 	vel[i] = v;
 }
 
+// ---- host boundary: packed xyz (std::vector<Vector3r> of a float build, ParticleData.h:91-100) <-> float4
+// `src`/`dst` are device staging copies of the caller's arrays; w = inv_mass / mass / 0
+__global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ xyz, const float *__restrict__ w, float4 *__restrict__ dst, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	dst[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], w ? w[i] : 0.0f);
+}
+__global__ __launch_bounds__(256) void pack_zero_kernel(const float *__restrict__ w, float4 *__restrict__ dst, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	dst[i] = make_float4(0.0f, 0.0f, 0.0f, w[i]);
+}
+__global__ __launch_bounds__(256) void unpack_kernel(const float4 *__restrict__ src, float *__restrict__ xyz, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float4 v = src[i];
+	xyz[3 * (size_t)i] = v.x; xyz[3 * (size_t)i + 1] = v.y; xyz[3 * (size_t)i + 2] = v.z;
+}
+__global__ __launch_bounds__(256) void set_xyz_kernel(const float *__restrict__ xyz, float4 *__restrict__ dst, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	float4 v = dst[i];
+	v.x = xyz[3 * (size_t)i]; v.y = xyz[3 * (size_t)i + 1]; v.z = xyz[3 * (size_t)i + 2];
+	dst[i] = v;
+}
+
 // ---- counter calibration kernels (pbdx_debug_stream): known byte counts in this engine's own access
 // widths, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be turned into bytes (MI355X_MICROARCH.md, HBM)
 __global__ __launch_bounds__(256) void calib_read_b32(const float *__restrict__ src, float *__restrict__ sink, size_t n)
@@ -413,6 +449,7 @@ struct pbdx_solver
 	uint32_t n = 0;
 	float4 *d_pos[2] = { nullptr, nullptr };
 	float4 *d_vel = nullptr, *d_old = nullptr, *d_last = nullptr;
+	float *d_stage = nullptr;            // 4 x 3n + 2n floats: device staging of the caller's packed arrays
 	std::vector<float> h_x;              // positions at upload time (tile partition only)
 	std::vector<Batch> batches;          // in add order
 	std::vector<uint32_t> order;         // batch indices sorted by (group, seq)
@@ -491,6 +528,7 @@ struct pbdx_solver
 	{
 		for (float4 **p : { &d_pos[0], &d_pos[1], &d_vel, &d_old, &d_last })
 			if (*p) { (void)hipFree(*p); *p = nullptr; }
+		if (d_stage) { (void)hipFree(d_stage); d_stage = nullptr; }
 		n = 0;
 	}
 	bool fused_active() const { return fuse && plan_ok && !dsegs.empty(); }
@@ -810,26 +848,29 @@ int pbdx_solver_set_particles(pbdx_solver *s, uint32_t n, const float *x, const 
 			HIPCHECK(hipMalloc(&s->d_vel, (size_t)n * sizeof(float4)));
 			HIPCHECK(hipMalloc(&s->d_old, (size_t)n * sizeof(float4)));
 			HIPCHECK(hipMalloc(&s->d_last, (size_t)n * sizeof(float4)));
+			HIPCHECK(hipMalloc(&s->d_stage, (size_t)n * 14 * sizeof(float)));
 		}
 		s->n = n;
 	}
 	if (!n) return PBDX_OK;
 	if (!s->plan_ok) s->h_x.assign(x, x + (size_t)3 * n);     // tile partition input (first upload wins)
-	std::vector<float4> tmp(n);
-	for (uint32_t i = 0; i < n; i++) tmp[i] = make_float4(x[3 * i], x[3 * i + 1], x[3 * i + 2], inv_mass[i]);
-	HIPCHECK(hipMemcpyAsync(s->d_pos[0], tmp.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
-	HIPCHECK(hipStreamSynchronize(s->stream));
-	for (uint32_t i = 0; i < n; i++)
-		tmp[i] = v ? make_float4(v[3 * i], v[3 * i + 1], v[3 * i + 2], mass[i]) : make_float4(0.0f, 0.0f, 0.0f, mass[i]);
-	HIPCHECK(hipMemcpyAsync(s->d_vel, tmp.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
-	HIPCHECK(hipStreamSynchronize(s->stream));
-	const float *src = old_x ? old_x : x;
-	for (uint32_t i = 0; i < n; i++) tmp[i] = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], 0.0f);
-	HIPCHECK(hipMemcpyAsync(s->d_old, tmp.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
-	HIPCHECK(hipStreamSynchronize(s->stream));
-	src = last_x ? last_x : x;
-	for (uint32_t i = 0; i < n; i++) tmp[i] = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], 0.0f);
-	HIPCHECK(hipMemcpyAsync(s->d_last, tmp.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+	// raw packed arrays -> device staging (stream ordered), repacked into float4 on the device
+	float *st_x = s->d_stage, *st_v = st_x + (size_t)3 * n, *st_o = st_v + (size_t)3 * n, *st_l = st_o + (size_t)3 * n;
+	float *st_m = st_l + (size_t)3 * n, *st_w = st_m + n;
+	const size_t b3 = (size_t)3 * n * sizeof(float), b1 = (size_t)n * sizeof(float);
+	HIPCHECK(hipMemcpyAsync(st_x, x, b3, hipMemcpyHostToDevice, s->stream));
+	if (v) HIPCHECK(hipMemcpyAsync(st_v, v, b3, hipMemcpyHostToDevice, s->stream));
+	if (old_x) HIPCHECK(hipMemcpyAsync(st_o, old_x, b3, hipMemcpyHostToDevice, s->stream));
+	if (last_x) HIPCHECK(hipMemcpyAsync(st_l, last_x, b3, hipMemcpyHostToDevice, s->stream));
+	HIPCHECK(hipMemcpyAsync(st_m, mass, b1, hipMemcpyHostToDevice, s->stream));
+	HIPCHECK(hipMemcpyAsync(st_w, inv_mass, b1, hipMemcpyHostToDevice, s->stream));
+	const dim3 grid((n + 255) / 256), block(256);
+	hipLaunchKernelGGL(pack_kernel, grid, block, 0, s->stream, st_x, st_w, s->d_pos[0], n);
+	if (v) hipLaunchKernelGGL(pack_kernel, grid, block, 0, s->stream, st_v, st_m, s->d_vel, n);
+	else hipLaunchKernelGGL(pack_zero_kernel, grid, block, 0, s->stream, st_m, s->d_vel, n);
+	hipLaunchKernelGGL(pack_kernel, grid, block, 0, s->stream, old_x ? st_o : st_x, (const float *)nullptr, s->d_old, n);
+	hipLaunchKernelGGL(pack_kernel, grid, block, 0, s->stream, last_x ? st_l : st_x, (const float *)nullptr, s->d_last, n);
+	HIPCHECK(hipGetLastError());
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	return PBDX_OK;
 }
@@ -839,11 +880,9 @@ int pbdx_solver_set_positions(pbdx_solver *s, uint32_t n, const float *x)
 	if (!s || !x || n != s->n) { set_error("set_positions: particle count mismatch"); return PBDX_ERR_INVALID; }
 	if (!n) return PBDX_OK;
 	HIPCHECK(hipSetDevice(s->device));
-	std::vector<float4> tmp(n);
-	HIPCHECK(hipMemcpyAsync(tmp.data(), s->d_pos[0], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
-	HIPCHECK(hipStreamSynchronize(s->stream));
-	for (uint32_t i = 0; i < n; i++) { tmp[i].x = x[3 * i]; tmp[i].y = x[3 * i + 1]; tmp[i].z = x[3 * i + 2]; }
-	HIPCHECK(hipMemcpyAsync(s->d_pos[0], tmp.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+	HIPCHECK(hipMemcpyAsync(s->d_stage, x, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+	hipLaunchKernelGGL(set_xyz_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_stage, s->d_pos[0], n);
+	HIPCHECK(hipGetLastError());
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	return PBDX_OK;
 }
@@ -853,15 +892,18 @@ int pbdx_solver_get_particles(pbdx_solver *s, uint32_t n, float *x, float *v, fl
 	if (!s || n != s->n) { set_error("get_particles: particle count mismatch (%u vs %u)", n, s ? s->n : 0); return PBDX_ERR_INVALID; }
 	if (!n) return PBDX_OK;
 	HIPCHECK(hipSetDevice(s->device));
-	std::vector<float4> tmp(n);
 	struct { float *dst; const float4 *src; } jobs[4] = { { x, s->d_pos[0] }, { v, s->d_vel }, { old_x, s->d_old }, { last_x, s->d_last } };
+	const size_t b3 = (size_t)3 * n * sizeof(float);
+	int k = 0;
 	for (auto &j : jobs)
 	{
+		float *st = s->d_stage + (size_t)3 * n * k++;
 		if (!j.dst) continue;
-		HIPCHECK(hipMemcpyAsync(tmp.data(), j.src, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
-		HIPCHECK(hipStreamSynchronize(s->stream));
-		for (uint32_t i = 0; i < n; i++) { j.dst[3 * i] = tmp[i].x; j.dst[3 * i + 1] = tmp[i].y; j.dst[3 * i + 2] = tmp[i].z; }
+		hipLaunchKernelGGL(unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, j.src, st, n);
+		HIPCHECK(hipGetLastError());
+		HIPCHECK(hipMemcpyAsync(j.dst, st, b3, hipMemcpyDeviceToHost, s->stream));
 	}
+	HIPCHECK(hipStreamSynchronize(s->stream));
 	return PBDX_OK;
 }
 

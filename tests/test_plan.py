@@ -17,6 +17,9 @@ CASES = {
     "bar 30x5x5 FEM tet": util.bar_spec(30, 5, 5, 2),
     "bar 20x6x6 XPBD dist+vol": util.bar_spec(20, 6, 6, 6),
     "bar 12x5x5 shape matching": util.bar_spec(12, 5, 5, 5),
+    "irregular Delaunay cloth": util.delaunay_cloth_spec(600),
+    "irregular Delaunay tets, FEM": util.delaunay_solid_spec(250, solid_method=2),
+    "irregular Delaunay tets, distance+volume": util.delaunay_solid_spec(250, solid_method=1),
 }
 
 
@@ -62,3 +65,16 @@ def test_plan_1m_particle_cloth_headline_numbers():
     assert info["max_local"] <= 10240
     assert info["num_segments"] <= 6
     assert info["redundancy"] <= 3.0
+
+
+def test_plan_star_graph_more_than_64_colours_and_huge_valence():
+    """A star: 200 distance constraints share particle 0 -> 200 colours of one constraint each; the hub
+    has valence 200.  Long colour sequences must be split into segments and stay exact."""
+    n = 200
+    ops = [("vertex", (float(i), 0.0, 0.0)) for i in range(n + 1)]
+    ops += [("constraint", "distance", [0, i + 1], 1.0) for i in range(n)]
+    m = util.build_mine(ops)
+    for tile in (0, 16, 201):
+        info = m.planCheck(tile_particles=tile)
+        assert info["num_colours"] == n
+        assert info["num_segments"] >= n // 16      # default cap: 16 colours per launch

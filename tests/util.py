@@ -61,6 +61,39 @@ def bar_spec(width, height, depth, solid_method, k=None, kv=None, poisson=0.3, T
     return ops
 
 
+def delaunay_cloth_spec(n_points=900, seed=3, cloth_method=4, bending_method=3):
+    """An IRREGULAR triangle mesh (2-D Delaunay triangulation of random points, lifted to a wavy sheet):
+    vertex valences 3..12, no grid structure, boundary edges.  Deterministic."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    uv = rng.random((n_points, 2)) * 8.0
+    tri = Delaunay(uv)
+    pts = np.stack([uv[:, 0], 0.3 * np.sin(uv[:, 0]) * np.cos(uv[:, 1]) + 1.0, uv[:, 1]], axis=1).astype(np.float32)
+    faces = tri.simplices.astype(np.uint32)
+    ops = [("trimesh", pts, faces), ("mass", 0, 0.0), ("mass", 1, 0.0)]
+    ops.append(("cloth", 0, cloth_method, 100000.0 if cloth_method == 4 else 1.0, 1.0, 1.0, 1.0, 0.3, 0.3, False, False))
+    if bending_method:
+        ops.append(("bending", 0, bending_method, 100.0 if bending_method == 3 else 0.01))
+    return ops
+
+
+def delaunay_solid_spec(n_points=400, seed=5, solid_method=2):
+    """An irregular tetrahedral mesh (3-D Delaunay of random points in a box), slivers removed."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    pts = (rng.random((n_points, 3)) * np.array([4.0, 1.5, 1.5])).astype(np.float32)
+    tets = Delaunay(pts.astype(np.float64)).simplices
+    p = pts.astype(np.float64)
+    vol = np.abs(np.einsum("ij,ij->i", p[tets[:, 3]] - p[tets[:, 0]], np.cross(p[tets[:, 2]] - p[tets[:, 0]], p[tets[:, 1]] - p[tets[:, 0]]))) / 6.0
+    tets = tets[vol > 1e-3].astype(np.uint32)
+    k = {3: 1000000.0, 6: 100000.0}.get(solid_method, 1.0)
+    ops = [("tetmesh", pts, tets)]
+    for i in np.nonzero(pts[:, 0] < 0.3)[0]:
+        ops.append(("mass", int(i), 0.0))
+    ops.append(("solid", 0, solid_method, k, 0.3, 100000.0 if solid_method == 6 else 1.0, False, False))
+    return ops
+
+
 _CONSTRAINT_ADD = {
     "distance": "addDistanceConstraint", "distance_xpbd": "addDistanceConstraint_XPBD",
     "dihedral": "addDihedralConstraint", "isometric_bending": "addIsometricBendingConstraint",
