@@ -147,6 +147,39 @@ def _pmc_pass(counter, child_args, timeout_s=240):
     return vals or None
 
 
+def rocprof_kernel_durations(child_args, kernel_substring, timeout_s=240):
+    """Cross-check of the event-measured launch durations: a `rocprofv3 --kernel-trace` child pass (no
+    counters) of a short run of the same configuration; returns (mean ns, dispatches) of the dominant kernel."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    outdir = tempfile.mkdtemp(prefix="pbdx_trace_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", outdir, "-o", "trace", "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+    except Exception:
+        return None
+    durs = []
+    for f in glob.glob(os.path.join(outdir, "**", "*kernel_trace.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if kernel_substring in row.get("Kernel_Name", ""):
+                    durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    shutil.rmtree(outdir, ignore_errors=True)
+    if not durs:
+        return None
+    return sum(durs) / len(durs), len(durs)
+
+
 def collect_traffic(child_args, kernel_substring):
     """HBM bytes per launch of the dominant kernel from the PMC counters, as MI355X_MICROARCH.md (HBM)
     prescribes: FETCH_SIZE and WRITE_SIZE in separate passes; the counters are turned into bytes with
@@ -364,6 +397,15 @@ def main():
                 r["streamed_bytes_per_launch_mean"] = sum(x["streamed_bytes_per_launch"] * x["launches"] for x in rows) / nl
             r["traffic"] = tr["bytes_per_launch"]
             r["traffic_detail"] = {k: tr[k] for k in ("fetch_bytes", "write_bytes", "raw")}
+        kd = rocprof_kernel_durations(child, "fused_kernel" if plan["active"] else "project_kernel")
+        if kd is not None:
+            r = out["roofline"]
+            r["rocprofv3_mean_kernel_us"] = kd[0] / 1e3
+            r["rocprofv3_dispatches"] = kd[1]
+            if plan["active"]:
+                rows = r["segments"]
+                nl = sum(x["launches"] for x in rows)
+                r["event_mean_launch_us_all_segments"] = sum(x["avg_us"] * x["launches"] for x in rows) / nl
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size if args.workload != "c3" else 400, args.iters)

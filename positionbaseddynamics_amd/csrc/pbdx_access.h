@@ -20,11 +20,23 @@ __device__ constexpr PlaneTable kPlanes = PlaneTable();
 // parameter k of slot i: a scalar of the view, or one coalesced dword of plane kPlanes[..][k].
 // `k` is a literal (or an unrolled loop index) at every call site, so the table lookups and the
 // scalar/streamed decision fold away at compile time: no branch, every load unconditional.
+// Stream access as  uniform 64-bit base (SGPR pair) + 32-bit byte offset (one VGPR shared by all planes
+// of a slot): selects the `global_load v, v_off, s[base:base+1]` addressing form, so a slot costs one
+// VALU shift instead of a 64-bit address computation per plane.
+template <class T> __device__ __forceinline__ T ld_off(const void *base, uint32_t byte_off)
+{
+	return *reinterpret_cast<const T *>(static_cast<const char *>(base) + byte_off);
+}
+template <class T> __device__ __forceinline__ void st_off(void *base, uint32_t byte_off, T v)
+{
+	*reinterpret_cast<T *>(static_cast<char *>(base) + byte_off) = v;
+}
+
 template <int TYPE, bool COMPACT>
 __device__ __forceinline__ float param_get(const TypeView &v, const float *par, uint32_t stride, int k, uint32_t i)
 {
 	if (is_scalar_param(TYPE, COMPACT, k)) return v.u[k];
-	return par[(uint32_t)kPlanes.plane[COMPACT ? 1 : 0][TYPE][k] * stride + i];
+	return ld_off<float>(par + (size_t)((uint32_t)kPlanes.plane[COMPACT ? 1 : 0][TYPE][k] * stride), i * 4u);
 }
 
 template <int TYPE, bool COMPACT> struct GlobalAccess
@@ -42,35 +54,57 @@ template <int TYPE, bool COMPACT> struct GlobalAccess
 	__device__ __forceinline__ void st(uint32_t h, float4 v) const { pos[h] = v; }
 	__device__ __forceinline__ float p(int k, uint32_t i) const { return param_get<TYPE, COMPACT>(view, par, par_stride, k, i); }
 	__device__ __forceinline__ bool sym() const { return COMPACT; }
-	__device__ __forceinline__ float lam_load(uint32_t i) const { return lambda[i]; }
-	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { lambda[i] = v; }
+	__device__ __forceinline__ float lam_load(uint32_t i) const { return ld_off<float>(lambda, i * 4u); }
+	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { st_off<float>(lambda, i * 4u, v); }
+};
+
+// The three streams of a fused segment (packed indices, parameter planes, multipliers) are read through
+// buffer descriptors: address = descriptor base + SGPR offset (start of the run / of the plane) + one
+// 32-bit VGPR byte offset per slot.  No per-plane VALU address arithmetic, no 64-bit address VGPRs,
+// hardware bounds check against the stream size.
+struct TileStreams
+{
+	__amdgpu_buffer_rsrc_t idx, par, lam;
 };
 
 template <int TYPE, bool COMPACT> struct TileAccess
 {
 	float4 *pos;               // LDS
-	const uint16_t *idx;
-	const float *par;
-	uint32_t par_stride;
-	float *lambda;
+	const TileStreams &str;
+	uint32_t idx_soff;         // byte offsets of this (tile, colour, type) run inside the streams
+	uint32_t par_soff;
+	uint32_t par_stride_b;     // bytes between parameter planes
+	uint32_t lam_soff;
 	const TypeView &view;
 
+	__device__ __forceinline__ uint32_t idx_raw1(uint32_t i) const { return __builtin_amdgcn_raw_buffer_load_b32(str.idx, (int)(i * 4u), (int)idx_soff, 0); }
+	__device__ __forceinline__ uint2 idx_raw2(uint32_t i) const
+	{
+		typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+		const v2u v = __builtin_amdgcn_raw_buffer_load_b64(str.idx, (int)(i * 8u), (int)idx_soff, 0);
+		return make_uint2(v.x, v.y);
+	}
 	__device__ __forceinline__ uint2 idx2(uint32_t i) const
 	{
-		const uint32_t v = reinterpret_cast<const uint32_t *>(idx)[i];
+		const uint32_t v = idx_raw1(i);
 		return make_uint2(v & 0xffffu, v >> 16);
 	}
 	__device__ __forceinline__ uint4 idx4(uint32_t i) const
 	{
-		const uint2 v = reinterpret_cast<const uint2 *>(idx)[i];
+		const uint2 v = idx_raw2(i);
 		return make_uint4(v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16);
 	}
 	__device__ __forceinline__ float4 ld(uint32_t h) const { return pos[h]; }
 	__device__ __forceinline__ void st(uint32_t h, float4 v) const { pos[h] = v; }
-	__device__ __forceinline__ float p(int k, uint32_t i) const { return param_get<TYPE, COMPACT>(view, par, par_stride, k, i); }
+	__device__ __forceinline__ float p(int k, uint32_t i) const
+	{
+		if (is_scalar_param(TYPE, COMPACT, k)) return view.u[k];
+		const uint32_t plane = (uint32_t)kPlanes.plane[COMPACT ? 1 : 0][TYPE][k];
+		return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.par, (int)(i * 4u), (int)(par_soff + plane * par_stride_b), 0));
+	}
 	__device__ __forceinline__ bool sym() const { return COMPACT; }
-	__device__ __forceinline__ float lam_load(uint32_t i) const { return lambda[i]; }
-	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { lambda[i] = v; }
+	__device__ __forceinline__ float lam_load(uint32_t i) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.lam, (int)(i * 4u), (int)lam_soff, 0)); }
+	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), str.lam, (int)(i * 4u), (int)lam_soff, 0); }
 };
 
 template <class A> __device__ __forceinline__ void ldp(const A &a, uint32_t h, V3 &p, float &w)
@@ -375,8 +409,8 @@ template <int TYPE, class A> struct RecAccess
 // only for TileAccess (packed 16-bit indices)
 template <int TYPE, class A> __device__ __forceinline__ void load_rec(const A &a, uint32_t i, Rec<TYPE> &r)
 {
-	if constexpr (kTwoBodies[TYPE]) r.id_raw = make_uint2(reinterpret_cast<const uint32_t *>(a.idx)[i], 0u);
-	else r.id_raw = reinterpret_cast<const uint2 *>(a.idx)[i];
+	if constexpr (kTwoBodies[TYPE]) r.id_raw = make_uint2(a.idx_raw1(i), 0u);
+	else r.id_raw = a.idx_raw2(i);
 	if constexpr (TYPE == PBDX_ISOMETRIC_BENDING || TYPE == PBDX_ISOMETRIC_BENDING_XPBD)
 	{
 		r.par[0] = a.p(0, i);

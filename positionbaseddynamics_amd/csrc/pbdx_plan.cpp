@@ -129,13 +129,10 @@ void parallel_for(uint32_t count, uint32_t threads, F &&fn)
 }
 
 // recursive coordinate bisection into k tiles of (nearly) equal particle count
-void rcb(const float *x, uint32_t *perm, uint32_t count, uint32_t k, uint32_t first_tile, std::vector<uint32_t> &tile_begin)
+void rcb(const float *x, uint32_t *perm, uint32_t count, uint32_t k)
 {
 	if (k <= 1 || count <= 1)
-	{
-		tile_begin[first_tile] = 0;   // filled by caller through offsets; placeholder
 		return;
-	}
 	float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
 	for (uint32_t i = 0; i < count; i++)
 		for (int d = 0; d < 3; d++)
@@ -152,8 +149,8 @@ void rcb(const float *x, uint32_t *perm, uint32_t count, uint32_t k, uint32_t fi
 		const float va = x[3 * (size_t)a + axis], vb = x[3 * (size_t)b + axis];
 		return va < vb || (va == vb && a < b);
 	});
-	rcb(x, perm, n_left, k_left, first_tile, tile_begin);
-	rcb(x, perm + n_left, count - n_left, k - k_left, first_tile + k_left, tile_begin);
+	rcb(x, perm, n_left, k_left);
+	rcb(x, perm + n_left, count - n_left, k - k_left);
 }
 
 // sizes of the tiles produced by rcb() in tile order (same split arithmetic)
@@ -285,8 +282,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	if (opt.tile_particles == 0 && k > opt.num_cus) k = round_up(k, opt.num_cus);
 	std::vector<uint32_t> perm(n);
 	for (uint32_t i = 0; i < n; i++) perm[i] = i;
-	std::vector<uint32_t> dummy(k + 1, 0);
-	rcb(x, perm.data(), n, k, 0, dummy);
+	rcb(x, perm.data(), n, k);
 	std::vector<uint32_t> sizes;
 	rcb_sizes(n, k, sizes);
 	std::vector<uint32_t> tile_begin(k + 1, 0);
@@ -466,8 +462,10 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 			ft.slots = o.slots;
 			const uint32_t idx_base = (uint32_t)seg.idx.size(), par_base = (uint32_t)seg.params.size();
 			const uint32_t lam_base = seg.lam_count, cid_base = (uint32_t)seg.slot_cid.size();
-			if ((uint64_t)idx_base + o.idx.size() >= 0xffffffffull || (uint64_t)par_base + o.params.size() >= 0xffffffffull)
-			{ why = "segment stream exceeds 32-bit offsets"; return false; }
+			// streams are addressed with 32-bit BYTE offsets (buffer descriptors)
+			if (((uint64_t)idx_base + o.idx.size()) * 2 >= 0xfffffff0ull || ((uint64_t)par_base + o.params.size()) * 4 >= 0xfffffff0ull ||
+				((uint64_t)lam_base + o.lam_count) * 4 >= 0xfffffff0ull)
+			{ why = "a segment stream exceeds 4 GiB"; return false; }
 			for (FusedStep st : o.steps)
 			{
 				st.idx_off += idx_base; st.par_off += par_base; st.lam_off += lam_base; st.cid_off += cid_base;

@@ -105,6 +105,7 @@ struct FusedArgs
 	const float *params;
 	float *lambda;
 	const uint32_t *gid;
+	uint32_t idx_bytes, params_bytes, lambda_bytes;   // stream sizes (buffer descriptors)
 	float dt;
 	int first_iter;
 	uint32_t num_tiles;
@@ -179,7 +180,7 @@ template <int TYPE, int BLOCK> struct ChunkIt
 };
 
 template <int TYPE, bool COMPACT, int BLOCK>
-__device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const uint4 *lsteps, uint32_t s0, uint32_t s_end, float4 *lpos, unsigned long long *trace)
+__device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStreams &str, const uint4 *lsteps, uint32_t s0, uint32_t s_end, float4 *lpos, unsigned long long *trace)
 {
 	constexpr int D = Depth<TYPE>::value;
 	typedef TileAccess<TYPE, COMPACT> Acc;
@@ -190,43 +191,45 @@ __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const uint4 *l
 #pragma unroll
 	for (int d = 0; d < D; d++)
 	{
-		const Acc acc = { lpos, a.idx + ld.st.idx_off, a.params + ld.st.par_off, ld.st.par_stride, a.lambda + ld.st.lam_off, a.views[TYPE] };
+		const Acc acc = { lpos, str, ld.st.idx_off * 2u, ld.st.par_off * 4u, ld.st.par_stride * 4u, ld.st.lam_off * 4u, a.views[TYPE] };
 		load_rec<TYPE>(acc, ld.slot_clamped(), ring[d]);
 		ld.next(lsteps);
 	}
-	while (ex.valid)
+	// Every sub-iteration issues exactly one record fetch, whether or not a projection still happens
+	// in it (single loop exit at the bottom): the number of memory operations between a fetch and its
+	// use is then the same on every path, which is what lets the compiler wait with s_waitcnt vmcnt(N>0).
+	for (;;)
 	{
 #pragma unroll
 		for (int d = 0; d < D; d++)
 		{
 			if (ex.valid)
 			{
-				{
-					const Acc acc = { lpos, a.idx + ex.st.idx_off, a.params + ex.st.par_off, ex.st.par_stride, a.lambda + ex.st.lam_off, a.views[TYPE] };
-					const uint32_t q = ex.slot();
-					if (q < ex.st.count) exec_rec<TYPE>(acc, ring[d], q, a.dt, a.first_iter);
-				}
+				const Acc acc = { lpos, str, ex.st.idx_off * 2u, ex.st.par_off * 4u, ex.st.par_stride * 4u, ex.st.lam_off * 4u, a.views[TYPE] };
+				const uint32_t q = ex.slot();
+				if (q < ex.st.count) exec_rec<TYPE>(acc, ring[d], q, a.dt, a.first_iter);
 				if (ex.last_of_step())
 				{
 					if (ex.st.barrier) __syncthreads();
 					if (trace && threadIdx.x == 0 && ex.s + 2 < kTraceStride - 1) trace[2 + ex.s] = wall_clock64();
 				}
 				ex.next(lsteps);
-				{
-					const Acc acc = { lpos, a.idx + ld.st.idx_off, a.params + ld.st.par_off, ld.st.par_stride, a.lambda + ld.st.lam_off, a.views[TYPE] };
-					load_rec<TYPE>(acc, ld.slot_clamped(), ring[d]);
-					ld.next(lsteps);
-				}
+			}
+			{
+				const Acc acc = { lpos, str, ld.st.idx_off * 2u, ld.st.par_off * 4u, ld.st.par_stride * 4u, ld.st.lam_off * 4u, a.views[TYPE] };
+				load_rec<TYPE>(acc, ld.slot_clamped(), ring[d]);
+				ld.next(lsteps);
 			}
 		}
+		if (!ex.valid) break;
 	}
 	return ex.s + 1;
 }
 
 #define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) { \
-		s = a.views[T].compact ? run_typed<T, true, BLOCK>(a, lsteps, s, t.step_end, lpos, trace) \
-		                       : run_typed<T, false, BLOCK>(a, lsteps, s, t.step_end, lpos, trace); } \
-	else { s = t.step_end; } break;
+		s = a.views[T].compact ? run_typed<T, true, BLOCK>(a, str, lsteps, s, num_steps, lpos, trace) \
+		                       : run_typed<T, false, BLOCK>(a, str, lsteps, s, num_steps, lpos, trace); } \
+	else { s = num_steps; } break;
 
 // LDS: [ step descriptors of the tile: kMaxTileSteps x 32 B ][ positions: n_local x float4 ]
 constexpr uint32_t kMaxTileSteps = 64;
@@ -251,25 +254,26 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 		lpos[i] = a.pos_in[gid[i]];
 	__syncthreads();
 	if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
-	// steps are addressed relative to the tile from here on
-	FusedTile tl = t;
-	(void)tl;
+	// stream descriptors, from kernel arguments only (wave-uniform by construction)
+	TileStreams str;
+	str.idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.idx), 0, a.idx_bytes, 0x00020000);
+	str.par = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.params), 0, a.params_bytes, 0x00020000);
+	str.lam = __builtin_amdgcn_make_buffer_rsrc(a.lambda, 0, a.lambda_bytes, 0x00020000);
+	// steps are addressed relative to the tile from here on (they sit at lsteps[0 .. num_steps))
+	const uint32_t num_steps = t.step_end - t.step_begin;
+	uint32_t s = 0;
+	while (s < num_steps)
 	{
-		const struct { uint32_t step_end; } t = { tl.step_end - tl.step_begin };
-		uint32_t s = 0;
-		while (s < t.step_end)
+		const uint32_t type = rfl(lsteps[2 * s].x);
+		switch (type)
 		{
-			const uint32_t type = rfl(lsteps[2 * s].x);
-			switch (type)
-			{
-				PBDX_CASE(PBDX_DISTANCE) PBDX_CASE(PBDX_DISTANCE_XPBD) PBDX_CASE(PBDX_DIHEDRAL)
-				PBDX_CASE(PBDX_ISOMETRIC_BENDING) PBDX_CASE(PBDX_ISOMETRIC_BENDING_XPBD)
-				PBDX_CASE(PBDX_FEM_TRIANGLE) PBDX_CASE(PBDX_STRAIN_TRIANGLE)
-				PBDX_CASE(PBDX_VOLUME) PBDX_CASE(PBDX_VOLUME_XPBD)
-				PBDX_CASE(PBDX_FEM_TET) PBDX_CASE(PBDX_FEM_TET_XPBD) PBDX_CASE(PBDX_STRAIN_TET)
-				PBDX_CASE(PBDX_SHAPE_MATCHING)
-			default: s = t.step_end; break;
-			}
+			PBDX_CASE(PBDX_DISTANCE) PBDX_CASE(PBDX_DISTANCE_XPBD) PBDX_CASE(PBDX_DIHEDRAL)
+			PBDX_CASE(PBDX_ISOMETRIC_BENDING) PBDX_CASE(PBDX_ISOMETRIC_BENDING_XPBD)
+			PBDX_CASE(PBDX_FEM_TRIANGLE) PBDX_CASE(PBDX_STRAIN_TRIANGLE)
+			PBDX_CASE(PBDX_VOLUME) PBDX_CASE(PBDX_VOLUME_XPBD)
+			PBDX_CASE(PBDX_FEM_TET) PBDX_CASE(PBDX_FEM_TET_XPBD) PBDX_CASE(PBDX_STRAIN_TET)
+			PBDX_CASE(PBDX_SHAPE_MATCHING)
+		default: s = num_steps; break;
 		}
 	}
 	for (uint32_t i = threadIdx.x; i < t.n_owned; i += BLOCK)
@@ -426,6 +430,7 @@ struct DeviceSegment
 	unsigned long long *d_trace = nullptr;
 	uint32_t num_tiles = 0;
 	uint32_t lds_bytes = 0;
+	uint32_t idx_bytes = 0, params_bytes = 0, lambda_bytes = 0;
 	uint32_t type_mask = 0;
 	uint64_t algorithmic_bytes = 0;  // SURVEY 8d bytes of the DISTINCT constraints of the segment
 	uint64_t constraints = 0;
@@ -594,6 +599,9 @@ int ensure_plan(pbdx_solver *s)
 			HIPCHECK(hipMalloc(&d.d_lambda, (size_t)seg.lam_count * sizeof(float)));
 			HIPCHECK(hipMemset(d.d_lambda, 0, (size_t)seg.lam_count * sizeof(float)));
 		}
+		d.idx_bytes = (uint32_t)(seg.idx.size() * sizeof(uint16_t));
+		d.params_bytes = (uint32_t)(seg.params.size() * sizeof(float));
+		d.lambda_bytes = (uint32_t)((size_t)seg.lam_count * sizeof(float));
 		d.num_tiles = (uint32_t)seg.tiles.size();
 		d.lds_bytes = std::max(seg.max_local, 1u) * 16u + kMaxTileSteps * 32u;
 		d.type_mask = seg.type_mask;
@@ -653,6 +661,7 @@ int launch_segment(pbdx_solver *s, size_t si, int src, float dt, int first_iter)
 	a.pos_in = s->d_pos[src];
 	a.pos_out = s->d_pos[src ^ 1];
 	a.tiles = d.d_tiles; a.steps = d.d_steps; a.idx = d.d_idx; a.params = d.d_params; a.lambda = d.d_lambda; a.gid = d.d_gid;
+	a.idx_bytes = d.idx_bytes; a.params_bytes = d.params_bytes; a.lambda_bytes = d.lambda_bytes;
 	a.dt = dt;
 	a.first_iter = first_iter;
 	a.num_tiles = d.num_tiles;
