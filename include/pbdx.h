@@ -166,7 +166,8 @@ enum {
 	PBDX_OPT_FUSE_BLOCK = 6,       /* threads per workgroup of the fused kernel: 0 = auto, 256, 512, 1024 */
 	PBDX_OPT_MAX_SEGMENT_COLOURS = 7, /* upper bound on colours fused into one launch (default 16) */
 	PBDX_OPT_LDS_PARTICLES = 8,    /* LDS capacity of a tile in particles (default 10240 = 160 KiB / 16 B) */
-	PBDX_OPT_TRACE = 9             /* developer aid: fused kernels stamp wall_clock64() per tile and colour step */
+	PBDX_OPT_TRACE = 9,            /* developer aid: fused kernels stamp wall_clock64() per tile and colour step */
+	PBDX_OPT_PAIRS = 10            /* project two chunks of a colour step jointly with packed fp32 arithmetic (default 0: measured slower) */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
 

@@ -583,6 +583,7 @@ class Solver:
         return buf[: si["num_tiles"] * stride.value].reshape(si["num_tiles"], stride.value)
 
     OPT_TRACE = 9
+    OPT_PAIRS = 10
     OPT_USE_GRAPH = 1
     OPT_BLOCK_SIZE = 2
     OPT_XCD_REMAP = 3

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include "pbdx_plan.h"
 #include "pbdx_project.h"
+#include "pbdx_pair.h"
 
 namespace pbdx {
 
@@ -386,9 +387,11 @@ __device__ constexpr bool kHasLambda[PBDX_NUM_CONSTRAINT_TYPES] = { false, true,
 // has to drain the whole prefetch queue (s_waitcnt vmcnt(0)) at that instruction.
 template <int TYPE> struct Rec
 {
-	uint2 id_raw;
-	float lambda_raw;
-	float par[kParamCount[TYPE]];
+	// homogeneous raw dwords exactly as they came back from memory:
+	// [0],[1] packed 16-bit indices, [2] multiplier, [3 + k] parameter k
+	uint32_t w[3 + kParamCount[TYPE]];
+	__device__ __forceinline__ float par(int k) const { return __builtin_bit_cast(float, w[3 + k]); }
+	__device__ __forceinline__ float lambda() const { return __builtin_bit_cast(float, w[2]); }
 };
 
 template <int TYPE, class A> struct RecAccess
@@ -396,43 +399,119 @@ template <int TYPE, class A> struct RecAccess
 	const A &base;
 	const Rec<TYPE> &r;
 	int first_iter;
-	__device__ __forceinline__ uint2 idx2(uint32_t) const { return make_uint2(r.id_raw.x & 0xffffu, r.id_raw.x >> 16); }
-	__device__ __forceinline__ uint4 idx4(uint32_t) const { return make_uint4(r.id_raw.x & 0xffffu, r.id_raw.x >> 16, r.id_raw.y & 0xffffu, r.id_raw.y >> 16); }
+	__device__ __forceinline__ uint2 idx2(uint32_t) const { return make_uint2(r.w[0] & 0xffffu, r.w[0] >> 16); }
+	__device__ __forceinline__ uint4 idx4(uint32_t) const { return make_uint4(r.w[0] & 0xffffu, r.w[0] >> 16, r.w[1] & 0xffffu, r.w[1] >> 16); }
 	__device__ __forceinline__ float4 ld(uint32_t h) const { return base.ld(h); }
 	__device__ __forceinline__ void st(uint32_t h, float4 v) const { base.st(h, v); }
-	__device__ __forceinline__ float p(int k, uint32_t) const { return r.par[k]; }
+	__device__ __forceinline__ float p(int k, uint32_t) const { return r.par(k); }
 	__device__ __forceinline__ bool sym() const { return false; }      // the record holds the full matrix
-	__device__ __forceinline__ float lam_load(uint32_t) const { return r.lambda_raw; }
+	__device__ __forceinline__ float lam_load(uint32_t) const { return r.lambda(); }
 	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { base.lam_store(i, v); }
 };
 
 // only for TileAccess (packed 16-bit indices)
 template <int TYPE, class A> __device__ __forceinline__ void load_rec(const A &a, uint32_t i, Rec<TYPE> &r)
 {
-	if constexpr (kTwoBodies[TYPE]) r.id_raw = make_uint2(a.idx_raw1(i), 0u);
-	else r.id_raw = a.idx_raw2(i);
+	if constexpr (kTwoBodies[TYPE]) { r.w[0] = a.idx_raw1(i); r.w[1] = 0u; }
+	else { const uint2 v = a.idx_raw2(i); r.w[0] = v.x; r.w[1] = v.y; }
 	if constexpr (TYPE == PBDX_ISOMETRIC_BENDING || TYPE == PBDX_ISOMETRIC_BENDING_XPBD)
 	{
-		r.par[0] = a.p(0, i);
+		r.w[3] = __builtin_bit_cast(uint32_t, a.p(0, i));
 		QFull q;
 		load_q(a, i, q);
 #pragma unroll
-		for (int k = 0; k < 16; k++) r.par[1 + k] = q.q[k];
+		for (int k = 0; k < 16; k++) r.w[4 + k] = __builtin_bit_cast(uint32_t, q.q[k]);
 	}
 	else
 	{
 #pragma unroll
-		for (int k = 0; k < kParamCount[TYPE]; k++) r.par[k] = a.p(k, i);
+		for (int k = 0; k < kParamCount[TYPE]; k++) r.w[3 + k] = __builtin_bit_cast(uint32_t, a.p(k, i));
 	}
-	r.lambda_raw = 0.0f;
+	r.w[2] = 0u;
 	// unconditional load (the stream always exists; iteration 0 ignores the value): branch-free prefetch
-	if constexpr (kHasLambda[TYPE]) r.lambda_raw = a.lam_load(i);
+	if constexpr (kHasLambda[TYPE]) r.w[2] = __builtin_bit_cast(uint32_t, a.lam_load(i));
 }
 
 template <int TYPE, class A> __device__ __forceinline__ void exec_rec(const A &a, const Rec<TYPE> &r, uint32_t i, float dt, int first_iter)
 {
 	const RecAccess<TYPE, A> ra = { a, r, first_iter };
 	Project<TYPE, RecAccess<TYPE, A>>::run(ra, i, dt, first_iter);
+}
+
+// ---- two records of the same colour step, one lane (pbdx_pair.h) -------------------------------------
+// Types without a packed implementation run their two records back to back.
+#ifndef PBDX_PAIR_BENDING
+#define PBDX_PAIR_BENDING 0     // the paired bending projection needs > 128 VGPRs: not with 1024-thread workgroups
+#endif
+template <int TYPE> struct HasPair { static constexpr bool value = (TYPE == PBDX_DISTANCE_XPBD || (PBDX_PAIR_BENDING && TYPE == PBDX_ISOMETRIC_BENDING_XPBD)); };
+
+template <int TYPE, class A>
+__device__ __forceinline__ void exec_rec2(const A &a, const Rec<TYPE> &r0, const Rec<TYPE> &r1, uint32_t q0, uint32_t q1,
+	bool valid0, bool valid1, float dt, int first_iter)
+{
+	if constexpr (TYPE == PBDX_DISTANCE_XPBD)
+	{
+		const uint32_t a0 = r0.w[0] & 0xffffu, b0 = r0.w[0] >> 16, a1 = r1.w[0] & 0xffffu, b1 = r1.w[0] >> 16;
+		const float4 A0 = a.ld(a0), B0 = a.ld(b0), A1 = a.ld(a1), B1 = a.ld(b1);
+		const V3P p0 = mkp(mk(A0.x, A0.y, A0.z), mk(A1.x, A1.y, A1.z)), p1 = mkp(mk(B0.x, B0.y, B0.z), mk(B1.x, B1.y, B1.z));
+		const f2 w0 = mk2(A0.w, A1.w), w1 = mk2(B0.w, B1.w);
+		f2 lambda = first_iter ? splat(0.0f) : mk2(r0.lambda(), r1.lambda());
+		V3P c0, c1;
+		solve_distance_xpbd2(p0, w0, p1, w1, mk2(r0.par(0), r1.par(0)), mk2(r0.par(1), r1.par(1)), dt, lambda, c0, c1);
+		if (valid0)
+		{
+			apply(a, a0, lane0(p0), lane0(c0), A0.w); apply(a, b0, lane0(p1), lane0(c1), B0.w);
+			a.lam_store(q0, lambda.x);
+		}
+		if (valid1)
+		{
+			apply(a, a1, lane1(p0), lane1(c0), A1.w); apply(a, b1, lane1(p1), lane1(c1), B1.w);
+			a.lam_store(q1, lambda.y);
+		}
+	}
+	else if constexpr (TYPE == PBDX_ISOMETRIC_BENDING_XPBD)
+	{
+		const uint32_t i0[4] = { r0.w[0] & 0xffffu, r0.w[0] >> 16, r0.w[1] & 0xffffu, r0.w[1] >> 16 };
+		const uint32_t i1[4] = { r1.w[0] & 0xffffu, r1.w[0] >> 16, r1.w[1] & 0xffffu, r1.w[1] >> 16 };
+		float4 P0[4], P1[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) { P0[k] = a.ld(i0[k]); P1[k] = a.ld(i1[k]); }
+		V3P p[4], c[4]; f2 w[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+		{
+			p[k] = mkp(mk(P0[k].x, P0[k].y, P0[k].z), mk(P1[k].x, P1[k].y, P1[k].z));
+			w[k] = mk2(P0[k].w, P1[k].w);
+		}
+		f2 q[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) q[k] = mk2(r0.par(1 + k), r1.par(1 + k));
+		f2 lambda = first_iter ? splat(0.0f) : mk2(r0.lambda(), r1.lambda());
+		const B2 ok = solve_isometric_bending_xpbd2(p, w, q, mk2(r0.par(0), r1.par(0)), dt, lambda, c);
+		if (valid0)
+		{
+			if (ok.a)
+			{
+#pragma unroll
+				for (int k = 0; k < 4; k++) apply(a, i0[k], lane0(p[k]), lane0(c[k]), P0[k].w);
+			}
+			a.lam_store(q0, lambda.x);
+		}
+		if (valid1)
+		{
+			if (ok.b)
+			{
+#pragma unroll
+				for (int k = 0; k < 4; k++) apply(a, i1[k], lane1(p[k]), lane1(c[k]), P1[k].w);
+			}
+			a.lam_store(q1, lambda.y);
+		}
+	}
+	else
+	{
+		if (valid0) exec_rec<TYPE>(a, r0, q0, dt, first_iter);
+		if (valid1) exec_rec<TYPE>(a, r1, q1, dt, first_iter);
+	}
 }
 
 } // namespace pbdx

@@ -131,6 +131,7 @@ constexpr uint32_t kTraceStride = 80;
 #define PBDX_DEPTH_BIG 2       // ring depth for the wide records (bending 11-17, FEM 10-13, shape matching 24 floats)
 #endif
 template <int TYPE> struct Depth { static constexpr int value = kParamCount[TYPE] <= 2 ? PBDX_DEPTH_SMALL : PBDX_DEPTH_BIG; };
+static_assert((PBDX_DEPTH_SMALL == 2 || PBDX_DEPTH_SMALL == 4) && (PBDX_DEPTH_BIG == 2 || PBDX_DEPTH_BIG == 4), "ring depth must be 2 or 4");
 
 struct StepS { uint32_t type, count, idx_off, par_off, par_stride, lam_off, barrier; };
 
@@ -179,7 +180,7 @@ template <int TYPE, int BLOCK> struct ChunkIt
 	__device__ __forceinline__ uint32_t slot_clamped() const { const uint32_t q = slot(); return q < st.count ? q : st.count - 1; }
 };
 
-template <int TYPE, bool COMPACT, int BLOCK>
+template <int TYPE, bool COMPACT, int BLOCK, bool PAIRS>
 __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStreams &str, const uint4 *lsteps, uint32_t s0, uint32_t s_end, float4 *lpos, unsigned long long *trace)
 {
 	constexpr int D = Depth<TYPE>::value;
@@ -187,54 +188,66 @@ __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStre
 	ChunkIt<TYPE, BLOCK> ld, ex;
 	ld.start(lsteps, s0, s_end);
 	ex = ld;
-	Rec<TYPE> ring[D];
-#pragma unroll
-	for (int d = 0; d < D; d++)
+	// the ring lives in named records (not an array): keeps every record in registers
+	Rec<TYPE> r0, r1, r2, r3;
+	auto fetch = [&](Rec<TYPE> &dst)
 	{
 		const Acc acc = { lpos, str, ld.st.idx_off * 2u, ld.st.par_off * 4u, ld.st.par_stride * 4u, ld.st.lam_off * 4u, a.views[TYPE] };
-		load_rec<TYPE>(acc, ld.slot_clamped(), ring[d]);
+		load_rec<TYPE>(acc, ld.slot_clamped(), dst);
 		ld.next(lsteps);
-	}
+	};
+	fetch(r0); fetch(r1);
+	if constexpr (D == 4) { fetch(r2); fetch(r3); }
 	// Every sub-iteration issues exactly one record fetch, whether or not a projection still happens
 	// in it (single loop exit at the bottom): the number of memory operations between a fetch and its
 	// use is then the same on every path, which is what lets the compiler wait with s_waitcnt vmcnt(N>0).
+	// Two consecutive chunks of the SAME step are projected jointly, one slot of each per lane, with
+	// packed arithmetic (pbdx_pair.h); the second sub-iteration then only fetches.
+	bool paired_prev = false;
+	auto sub = [&](Rec<TYPE> &cur, Rec<TYPE> &nxt)
+	{
+		if (ex.valid && !paired_prev)
+		{
+			const Acc acc = { lpos, str, ex.st.idx_off * 2u, ex.st.par_off * 4u, ex.st.par_stride * 4u, ex.st.lam_off * 4u, a.views[TYPE] };
+			const uint32_t q = ex.slot();
+			if (PAIRS && HasPair<TYPE>::value && !ex.last_of_step())
+			{
+				const uint32_t q1 = q + BLOCK;
+				exec_rec2<TYPE>(acc, cur, nxt, q, q1, q < ex.st.count, q1 < ex.st.count, a.dt, a.first_iter);
+				ex.next(lsteps);            // consumes the partner chunk as well
+				paired_prev = true;
+			}
+			else if (q < ex.st.count)
+				exec_rec<TYPE>(acc, cur, q, a.dt, a.first_iter);
+			if (ex.last_of_step())
+			{
+				if (ex.st.barrier) __syncthreads();
+				if (trace && threadIdx.x == 0 && ex.s + 2 < kTraceStride - 1) trace[2 + ex.s] = wall_clock64();
+			}
+			ex.next(lsteps);
+		}
+		else
+			paired_prev = false;
+		fetch(cur);
+	};
 	for (;;)
 	{
-#pragma unroll
-		for (int d = 0; d < D; d++)
-		{
-			if (ex.valid)
-			{
-				const Acc acc = { lpos, str, ex.st.idx_off * 2u, ex.st.par_off * 4u, ex.st.par_stride * 4u, ex.st.lam_off * 4u, a.views[TYPE] };
-				const uint32_t q = ex.slot();
-				if (q < ex.st.count) exec_rec<TYPE>(acc, ring[d], q, a.dt, a.first_iter);
-				if (ex.last_of_step())
-				{
-					if (ex.st.barrier) __syncthreads();
-					if (trace && threadIdx.x == 0 && ex.s + 2 < kTraceStride - 1) trace[2 + ex.s] = wall_clock64();
-				}
-				ex.next(lsteps);
-			}
-			{
-				const Acc acc = { lpos, str, ld.st.idx_off * 2u, ld.st.par_off * 4u, ld.st.par_stride * 4u, ld.st.lam_off * 4u, a.views[TYPE] };
-				load_rec<TYPE>(acc, ld.slot_clamped(), ring[d]);
-				ld.next(lsteps);
-			}
-		}
+		if constexpr (D == 4) { sub(r0, r1); sub(r1, r2); sub(r2, r3); sub(r3, r0); }
+		else { sub(r0, r1); sub(r1, r0); }
 		if (!ex.valid) break;
 	}
 	return ex.s + 1;
 }
 
 #define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) { \
-		s = a.views[T].compact ? run_typed<T, true, BLOCK>(a, str, lsteps, s, num_steps, lpos, trace) \
-		                       : run_typed<T, false, BLOCK>(a, str, lsteps, s, num_steps, lpos, trace); } \
+		s = a.views[T].compact ? run_typed<T, true, BLOCK, PAIRS>(a, str, lsteps, s, num_steps, lpos, trace) \
+		                       : run_typed<T, false, BLOCK, PAIRS>(a, str, lsteps, s, num_steps, lpos, trace); } \
 	else { s = num_steps; } break;
 
 // LDS: [ step descriptors of the tile: kMaxTileSteps x 32 B ][ positions: n_local x float4 ]
 constexpr uint32_t kMaxTileSteps = 64;
 
-template <uint32_t MASK, int BLOCK>
+template <uint32_t MASK, int BLOCK, bool PAIRS>
 __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 {
 	extern __shared__ uint4 lds_raw[];
@@ -291,14 +304,19 @@ constexpr uint32_t kMaskLight = (1u << PBDX_DISTANCE) | (1u << PBDX_DISTANCE_XPB
 	(1u << PBDX_ISOMETRIC_BENDING_XPBD) | (1u << PBDX_VOLUME) | (1u << PBDX_VOLUME_XPBD) | (1u << PBDX_DIHEDRAL);
 constexpr uint32_t kMaskAll = (1u << PBDX_NUM_CONSTRAINT_TYPES) - 1u;
 
-fused_fn pick_fused_kernel(uint32_t mask, int block)
+fused_fn pick_fused_kernel(uint32_t mask, int block, bool pairs)
 {
 	if ((mask & ~kMaskClothXpbd) == 0)
-		return block == 1024 ? fused_kernel<kMaskClothXpbd, 1024> : block == 512 ? fused_kernel<kMaskClothXpbd, 512> : fused_kernel<kMaskClothXpbd, 256>;
+	{
+		if (pairs)
+			return block == 1024 ? fused_kernel<kMaskClothXpbd, 1024, true> : block == 768 ? fused_kernel<kMaskClothXpbd, 768, true> :
+				block == 512 ? fused_kernel<kMaskClothXpbd, 512, true> : fused_kernel<kMaskClothXpbd, 256, true>;
+		return block == 1024 ? fused_kernel<kMaskClothXpbd, 1024, false> : block == 512 ? fused_kernel<kMaskClothXpbd, 512, false> : fused_kernel<kMaskClothXpbd, 256, false>;
+	}
 	if ((mask & ~kMaskLight) == 0)
-		return block == 1024 ? fused_kernel<kMaskLight, 1024> : block == 512 ? fused_kernel<kMaskLight, 512> : fused_kernel<kMaskLight, 256>;
+		return block == 1024 ? fused_kernel<kMaskLight, 1024, false> : block == 512 ? fused_kernel<kMaskLight, 512, false> : fused_kernel<kMaskLight, 256, false>;
 	// heavy types (FEM / strain / shape matching) need > 128 VGPRs: at most 512 threads per workgroup
-	return block >= 512 ? fused_kernel<kMaskAll, 512> : fused_kernel<kMaskAll, 256>;
+	return block >= 512 ? fused_kernel<kMaskAll, 512, false> : fused_kernel<kMaskAll, 256, false>;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -472,6 +490,7 @@ struct pbdx_solver
 	uint32_t max_segment_colours = 16;
 	uint32_t lds_particles = 10240;
 	int trace = 0;
+	int pairs = 0;                       // measured slower: off by default
 
 	// fused plan
 	FusedPlan plan;
@@ -610,7 +629,7 @@ int ensure_plan(pbdx_solver *s)
 			if (pb.colour >= seg.colour_begin && pb.colour < seg.colour_end)
 				d.algorithmic_bytes += (uint64_t)pb.count * type_info(pb.type)->algorithmic_bytes;
 		int block = s->fuse_block;
-		if (block != 256 && block != 512 && block != 1024)
+		if (block != 256 && block != 512 && block != 768 && block != 1024)
 		{
 			// auto: enough threads to cover the largest colour step of a tile once, at most 1024
 			uint32_t widest = 0;
@@ -618,8 +637,9 @@ int ensure_plan(pbdx_solver *s)
 			block = widest > 512 ? 1024 : widest > 256 ? 512 : 256;
 		}
 		if ((seg.type_mask & ~kMaskLight) && block > 512) block = 512;
+		if (block == 768 && !((seg.type_mask & ~kMaskClothXpbd) == 0 && s->pairs)) block = 512;   // 768 exists for the paired cloth kernel only
 		d.block = block;
-		d.kernel = pick_fused_kernel(seg.type_mask, block);
+		d.kernel = pick_fused_kernel(seg.type_mask, block, s->pairs != 0);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(d.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
 		s->dsegs.push_back(d);
 	}
@@ -1027,7 +1047,7 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 		if (value < 0 || value > 10240) { set_error("tile_particles must be 0 (auto) .. 10240"); return PBDX_ERR_INVALID; }
 		s->tile_particles = (uint32_t)value; replan = true; break;
 	case PBDX_OPT_FUSE_BLOCK:
-		if (value != 0 && value != 256 && value != 512 && value != 1024) { set_error("fused block size must be 0 (auto), 256, 512 or 1024"); return PBDX_ERR_INVALID; }
+		if (value != 0 && value != 256 && value != 512 && value != 768 && value != 1024) { set_error("fused block size must be 0 (auto), 256, 512, 768 or 1024"); return PBDX_ERR_INVALID; }
 		s->fuse_block = (int)value; replan = true; break;
 	case PBDX_OPT_MAX_SEGMENT_COLOURS:
 		if (value < 1) { set_error("max_segment_colours must be >= 1"); return PBDX_ERR_INVALID; }
@@ -1036,6 +1056,7 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 		if (value < 64 || value > 10240) { set_error("lds_particles must be 64 .. 10240"); return PBDX_ERR_INVALID; }
 		s->lds_particles = (uint32_t)value; replan = true; break;
 	case PBDX_OPT_TRACE: s->trace = value != 0; break;
+	case PBDX_OPT_PAIRS: s->pairs = value != 0; replan = true; break;
 	default: set_error("unknown option %d", option); return PBDX_ERR_INVALID;
 	}
 	s->drop_graph();
