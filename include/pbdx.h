@@ -167,6 +167,9 @@ enum {
 	PBDX_OPT_MAX_SEGMENT_COLOURS = 7, /* upper bound on colours fused into one launch (default 16) */
 	PBDX_OPT_LDS_PARTICLES = 8,    /* LDS capacity of a tile in particles (default 10240 = 160 KiB / 16 B) */
 	PBDX_OPT_TRACE = 9,            /* developer aid: fused kernels stamp wall_clock64() per tile and colour step */
+	PBDX_OPT_PIN_HOST = 11,        /* page-lock (hipHostRegister) the caller's particle arrays passed to set/get_particles so that
+	                                * transfers DMA at full PCIe rate; the arrays must stay allocated until the option is cleared or the
+	                                * solver destroyed (default 0) */
 	PBDX_OPT_PAIRS = 10            /* project two chunks of a colour step jointly with packed fp32 arithmetic (default 0: measured slower) */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
@@ -265,8 +268,12 @@ int pbdx_model_set_mass(pbdx_model *m, uint32_t i, float mass);        /* setMas
 /* which: 0=x 1=x0 2=v 3=a 4=oldX 5=lastX (xyz triples); 6=mass 7=invMass (scalars) */
 int pbdx_model_get_array(const pbdx_model *m, int which, float *out);
 int pbdx_model_set_array(pbdx_model *m, int which, const float *in);
-/* zero-copy pointer to the packed position array (pypbd getVertices analogue) */
+/* zero-copy pointer to the packed position array (pypbd getVertices analogue).  Writes through this
+ * pointer cannot be seen by the engine: call pbdx_model_mark_state_dirty afterwards. */
 float *pbdx_model_positions_ptr(pbdx_model *m);
+/* Dirty tracking of the host particle state: every pbdx_model_set_array bumps an internal version;
+ * pbdx_timestep_step_resident re-uploads the host state when it is newer than the device image. */
+int pbdx_model_mark_state_dirty(pbdx_model *m);
 
 /* Per-constraint builders (SimulationModel.cpp:565-806); return 1 on success, 0 if
  * the reference's initConstraint would have returned false. */
@@ -360,6 +367,8 @@ int pbdx_timestep_step(pbdx_timestep *ts, pbdx_model *m);
  * writes the state back into the model. */
 int pbdx_timestep_step_resident(pbdx_timestep *ts, pbdx_model *m, uint32_t num_steps);
 int pbdx_timestep_sync_to_host(pbdx_timestep *ts, pbdx_model *m);
+/* explicit upload of the model's host particle state (and of a stale schedule) without stepping */
+int pbdx_timestep_sync_from_host(pbdx_timestep *ts, pbdx_model *m);
 int pbdx_timestep_invalidate(pbdx_timestep *ts);
 /* Known-answer / teacher-forced entry: upload the model's host state, run only the projection
  * loop of one substep (`iterations` Gauss-Seidel sweeps over the colour groups, lambda reset at

@@ -174,6 +174,10 @@ class ParticleData:
         ptr = lib.pbdx_model_positions_ptr(self._m._h)
         return np.ctypeslib.as_array(ptr, shape=(n, 3))
 
+    def markDirty(self):
+        """Tell the engine that the host state was written through a zero-copy view (getVertices)."""
+        check(lib.pbdx_model_mark_state_dirty(self._m._h), "pbdx_model_mark_state_dirty")
+
     # bulk helpers (not in pypbd; used by tests / bench)
     def positions(self):
         return self._arr(0)
@@ -455,6 +459,9 @@ class TimeStepController:
     def syncToHost(self, model):
         check(lib.pbdx_timestep_sync_to_host(self._h, model._h), "syncToHost")
 
+    def syncFromHost(self, model):
+        check(lib.pbdx_timestep_sync_from_host(self._h, model._h), "TimeStepController.syncFromHost")
+
     def invalidate(self):
         check(lib.pbdx_timestep_invalidate(self._h), "invalidate")
 
@@ -584,6 +591,7 @@ class Solver:
 
     OPT_TRACE = 9
     OPT_PAIRS = 10
+    OPT_PIN_HOST = 11
     OPT_USE_GRAPH = 1
     OPT_BLOCK_SIZE = 2
     OPT_XCD_REMAP = 3

@@ -118,6 +118,7 @@ SIGNATURES = [
     ("pbdx_timestep_get_time_step_size", f32, vp), ("pbdx_timestep_get_time", f32, vp),
     ("pbdx_timestep_reset", C.c_int, vp), ("pbdx_timestep_step", C.c_int, vp, vp),
     ("pbdx_timestep_step_resident", C.c_int, vp, vp, u32), ("pbdx_timestep_sync_to_host", C.c_int, vp, vp),
+    ("pbdx_timestep_sync_from_host", C.c_int, vp, vp), ("pbdx_model_mark_state_dirty", C.c_int, vp),
     ("pbdx_timestep_invalidate", C.c_int, vp), ("pbdx_timestep_project", C.c_int, vp, vp, u32), ("pbdx_timestep_solver", vp, vp),
 ]
 

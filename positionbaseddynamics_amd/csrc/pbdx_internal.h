@@ -65,6 +65,7 @@ struct pbdx_model
 	bool groups_initialized = false;
 	uint64_t topology_version = 0;   // bumped by every add*/cleanup: device image invalidation
 	uint64_t params_version = 0;     // bumped by set_constraint_params / set_mass
+	uint64_t state_version = 0;      // bumped when the host particle state (x, v, a, oldX, lastX) is written through the API
 
 	uint32_t size() const { return (uint32_t)mass.size(); }
 };

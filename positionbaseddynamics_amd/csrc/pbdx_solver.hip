@@ -490,6 +490,9 @@ struct pbdx_solver
 	uint32_t max_segment_colours = 16;
 	uint32_t lds_particles = 10240;
 	int trace = 0;
+	int pin_host = 0;                    // hipHostRegister the caller's particle arrays (opt-in: they must outlive the solver or be unpinned)
+	struct Pin { const void *p; size_t bytes; };
+	std::vector<Pin> pins;
 	int pairs = 0;                       // measured slower: off by default
 
 	// fused plan
@@ -556,6 +559,32 @@ struct pbdx_solver
 		n = 0;
 	}
 	bool fused_active() const { return fuse && plan_ok && !dsegs.empty(); }
+	void unpin_all()
+	{
+		for (const Pin &pn : pins) (void)hipHostUnregister(const_cast<void *>(pn.p));
+		pins.clear();
+	}
+	// Page-lock a caller buffer so that hipMemcpyAsync DMAs straight from / into it.  Failure is not an
+	// error (the copy then goes through the driver's staging path).
+	void pin(const void *p, size_t bytes)
+	{
+		if (!pin_host || !p || !bytes) return;
+		for (size_t i = 0; i < pins.size(); i++)
+		{
+			if (pins[i].p == p && pins[i].bytes == bytes) return;
+			const char *a = static_cast<const char *>(pins[i].p), *b = static_cast<const char *>(p);
+			if (a < b + bytes && b < a + pins[i].bytes)     // stale overlapping registration
+			{
+				(void)hipHostUnregister(const_cast<void *>(pins[i].p));
+				pins.erase(pins.begin() + i);
+				i--;
+			}
+		}
+		if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess)
+			pins.push_back({ p, bytes });
+		else
+			(void)hipGetLastError();
+	}
 };
 
 namespace {
@@ -852,6 +881,7 @@ void pbdx_solver_destroy(pbdx_solver *s)
 	s->drop_graph();
 	s->free_batches();
 	s->free_particles();
+	s->unpin_all();
 	for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
 	if (s->ev_start) (void)hipEventDestroy(s->ev_start);
 	if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
@@ -887,6 +917,7 @@ int pbdx_solver_set_particles(pbdx_solver *s, uint32_t n, const float *x, const 
 	float *st_x = s->d_stage, *st_v = st_x + (size_t)3 * n, *st_o = st_v + (size_t)3 * n, *st_l = st_o + (size_t)3 * n;
 	float *st_m = st_l + (size_t)3 * n, *st_w = st_m + n;
 	const size_t b3 = (size_t)3 * n * sizeof(float), b1 = (size_t)n * sizeof(float);
+	s->pin(x, b3); s->pin(v, b3); s->pin(old_x, b3); s->pin(last_x, b3); s->pin(mass, b1); s->pin(inv_mass, b1);
 	HIPCHECK(hipMemcpyAsync(st_x, x, b3, hipMemcpyHostToDevice, s->stream));
 	if (v) HIPCHECK(hipMemcpyAsync(st_v, v, b3, hipMemcpyHostToDevice, s->stream));
 	if (old_x) HIPCHECK(hipMemcpyAsync(st_o, old_x, b3, hipMemcpyHostToDevice, s->stream));
@@ -928,6 +959,7 @@ int pbdx_solver_get_particles(pbdx_solver *s, uint32_t n, float *x, float *v, fl
 	{
 		float *st = s->d_stage + (size_t)3 * n * k++;
 		if (!j.dst) continue;
+		s->pin(j.dst, b3);
 		hipLaunchKernelGGL(unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, j.src, st, n);
 		HIPCHECK(hipGetLastError());
 		HIPCHECK(hipMemcpyAsync(j.dst, st, b3, hipMemcpyDeviceToHost, s->stream));
@@ -1057,6 +1089,7 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 		s->lds_particles = (uint32_t)value; replan = true; break;
 	case PBDX_OPT_TRACE: s->trace = value != 0; break;
 	case PBDX_OPT_PAIRS: s->pairs = value != 0; replan = true; break;
+	case PBDX_OPT_PIN_HOST: s->pin_host = value != 0; if (!s->pin_host) s->unpin_all(); break;
 	default: set_error("unknown option %d", option); return PBDX_ERR_INVALID;
 	}
 	s->drop_graph();

@@ -25,6 +25,7 @@ struct pbdx_timestep
 	uint64_t topo = ~0ull, params = ~0ull;
 	bool schedule_valid = false;
 	bool device_ahead = false;   // device state newer than the host model (resident stepping)
+	uint64_t state_seen = ~0ull; // model->state_version of the host state the device image was built from / synced to
 };
 
 namespace {
@@ -77,11 +78,14 @@ int refresh_image(pbdx_timestep *ts, pbdx_model *m, bool force_particles)
 {
 	const bool stale_topology = !ts->schedule_valid || ts->image_of != m || ts->topo != m->topology_version || !m->groups_initialized;
 	const bool stale_params = ts->params != m->params_version;
-	if (stale_topology || stale_params || force_particles)
+	// dirty tracking: the host state was written through the model API since the last upload / sync
+	const bool host_dirty = ts->state_seen != m->state_version;
+	if (stale_topology || stale_params || force_particles || host_dirty)
 	{
 		int r = upload_particles(ts, m);
 		if (r) return r;
 		ts->device_ahead = false;
+		ts->state_seen = m->state_version;
 	}
 	if (stale_topology || stale_params)
 	{
@@ -210,7 +214,7 @@ int pbdx_timestep_set_gravity(pbdx_timestep *ts, const float g[3])
 int pbdx_timestep_set_time_step_size(pbdx_timestep *ts, float h) { if (!ts) return PBDX_ERR_INVALID; ts->h = h; return PBDX_OK; }
 float pbdx_timestep_get_time_step_size(const pbdx_timestep *ts) { return ts ? ts->h : 0.0f; }
 float pbdx_timestep_get_time(const pbdx_timestep *ts) { return ts ? ts->time : 0.0f; }
-int pbdx_timestep_reset(pbdx_timestep *ts) { if (!ts) return PBDX_ERR_INVALID; ts->time = 0.0f; ts->schedule_valid = false; ts->device_ahead = false; return PBDX_OK; }
+int pbdx_timestep_reset(pbdx_timestep *ts) { if (!ts) return PBDX_ERR_INVALID; ts->time = 0.0f; ts->schedule_valid = false; ts->device_ahead = false; ts->state_seen = ~0ull; return PBDX_OK; }
 int pbdx_timestep_invalidate(pbdx_timestep *ts) { if (!ts) return PBDX_ERR_INVALID; ts->schedule_valid = false; return PBDX_OK; }
 pbdx_solver *pbdx_timestep_solver(pbdx_timestep *ts) { return ts ? ts->solver : nullptr; }
 
@@ -220,7 +224,14 @@ int pbdx_timestep_sync_to_host(pbdx_timestep *ts, pbdx_model *m)
 	int r = pbdx_solver_get_particles(ts->solver, m->size(), m->x.data(), m->v.data(), m->old_x.data(), m->last_x.data());
 	if (r) return r;
 	ts->device_ahead = false;
+	ts->state_seen = m->state_version;     // host mirror == device state
 	return PBDX_OK;
+}
+
+int pbdx_timestep_sync_from_host(pbdx_timestep *ts, pbdx_model *m)
+{
+	if (!ts || !m) return PBDX_ERR_INVALID;
+	return refresh_image(ts, m, /*force_particles=*/true);
 }
 
 int pbdx_timestep_step(pbdx_timestep *ts, pbdx_model *m)

@@ -373,3 +373,69 @@ def test_c4_ensemble_block_of_instances_vs_reference(pbd):
     xr = util.oracle_positions(ops, 2, 1, 10, "f32", threads=8).astype(np.float32)
     m, ts = util.mine_run(ops, 2, 1, 10, resident=True)
     assert util.bitwise_equal(m.getParticles().positions(), xr)
+
+
+# ---------------------------------------------------------------------------
+# device-resident ParticleData, dirty tracking, pinned host mirror
+# ---------------------------------------------------------------------------
+def test_resident_state_dirty_tracking_and_explicit_sync(pbd):
+    """Resident stepping keeps the state on the device; a host write through the model API (or through
+    the zero-copy getVertices view + markDirty) is picked up by the next resident step; the result
+    equals the upload-every-step contract of TimeStep::step."""
+    ops = util.cloth_spec(40, 40, 4, 3)
+
+    def fresh():
+        m = util.build_mine(ops)
+        pbd.TimeManager.setCurrent(pbd.TimeManager())
+        ts = pbd.TimeStepController()
+        ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+        ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 5)
+        return m, ts
+
+    def poke(m, via_view):
+        pd = m.getParticles()
+        if via_view:
+            v = pd.getVertices()
+            v[100:110, 1] += np.float32(0.05)
+            pd.markDirty()
+        else:
+            x = pd.positions()
+            x[100:110, 1] += np.float32(0.05)
+            pd.set_array(0, x)
+
+    # ground truth: host-authoritative stepping
+    m0, t0 = fresh()
+    for _ in range(3):
+        t0.step(m0)
+    poke(m0, False)
+    for _ in range(3):
+        t0.step(m0)
+    want = m0.getParticles().positions()
+
+    for via_view in (False, True):
+        m, ts = fresh()
+        ts.stepResident(m, 3)
+        ts.syncToHost(m)                     # host mirror := device state
+        poke(m, via_view)                    # host becomes newer than the device
+        ts.stepResident(m, 3)                # must re-upload by itself
+        ts.syncToHost(m)
+        assert util.bitwise_equal(m.getParticles().positions(), want), "dirty host state was not uploaded (via_view=%s)" % via_view
+
+    # explicit syncFromHost + pinned host arrays give the same bits
+    m, ts = fresh()
+    ts.solver().set_option(pbd.Solver.OPT_PIN_HOST, 1)
+    ts.stepResident(m, 3)
+    ts.syncToHost(m)
+    poke(m, True)
+    ts.syncFromHost(m)
+    ts.stepResident(m, 3)
+    ts.syncToHost(m)
+    assert util.bitwise_equal(m.getParticles().positions(), want)
+    # and a resident run without any host write does NOT re-upload: device stays ahead of the stale host copy
+    m, ts = fresh()
+    ts.stepResident(m, 2)
+    stale = m.getParticles().positions().copy()
+    ts.stepResident(m, 2)
+    assert np.array_equal(m.getParticles().positions(), stale)      # host untouched until syncToHost
+    ts.syncToHost(m)
+    assert not np.array_equal(m.getParticles().positions(), stale)
