@@ -439,3 +439,59 @@ def test_resident_state_dirty_tracking_and_explicit_sync(pbd):
     assert np.array_equal(m.getParticles().positions(), stale)      # host untouched until syncToHost
     ts.syncToHost(m)
     assert not np.array_equal(m.getParticles().positions(), stale)
+
+
+# ---------------------------------------------------------------------------
+# edge cases
+# ---------------------------------------------------------------------------
+def test_particles_without_constraints_free_fall(pbd):
+    """No constraints at all: the step is integrate + velocity update only (no schedule, no plan)."""
+    ops = [("vertex", (0.1 * i, 1.0 + 0.01 * i, -0.2 * i)) for i in range(37)] + [("mass", 3, 0.0)]
+    xr = util.oracle_positions(ops, 7, 3, 4, "f32")
+    m, ts = util.mine_run(ops, 7, 3, 4)
+    assert ts.solver().plan_info()["active"] == 0
+    assert util.bitwise_equal(m.getParticles().positions(), xr.astype(np.float32))
+    m2, _ = util.mine_run(ops, 7, 3, 4, resident=True, vel_method=1)
+    xr2 = util.oracle_positions(ops, 7, 3, 4, "f32", vel_method=1)
+    assert util.bitwise_equal(m2.getParticles().positions(), xr2.astype(np.float32))
+
+
+def test_isolated_particles_next_to_constrained_ones(pbd):
+    """Particles that no constraint touches are owned by a tile and must be carried through every
+    fused segment untouched by the projections (they still integrate)."""
+    ops = util.cloth_spec(20, 20, 4, 3) + [("vertex", (3.0 + i, 5.0, 1.0)) for i in range(9)]
+    xr = util.oracle_positions(ops, 5, 1, 6, "f32")
+    for tile in (0, 50):
+        m, ts = util.mine_run(ops, 5, 1, 6, options={pbd.Solver.OPT_TILE_PARTICLES: tile})
+        assert ts.solver().plan_info()["active"] == 1
+        assert util.bitwise_equal(m.getParticles().positions(), xr.astype(np.float32))
+
+
+def test_single_constraint_and_single_tile(pbd):
+    ops = [("vertex", (0.0, 0.0, 0.0)), ("vertex", (1.0, 0.2, 0.0)), ("constraint", "distance_xpbd", [0, 1], 1000.0)]
+    xr = util.oracle_positions(ops, 4, 2, 3, "f32")
+    m, ts = util.mine_run(ops, 4, 2, 3)
+    assert util.bitwise_equal(m.getParticles().positions(), xr.astype(np.float32))
+
+
+def test_topology_change_between_steps_rebuilds_the_device_image(pbd):
+    """Adding constraints after stepping (every add* clears m_groupsInitialized, SimulationModel.cpp:572)
+    must invalidate the schedule and the fused plan."""
+    base = util.cloth_spec(24, 24, 4, 0)
+    ref = util.get_oracle("f32")
+    util.apply_ref(ref, base)
+    ref.set_time_step_size(0.005); ref.set_gravity(util.GRAVITY); ref.set_params(1, 5, 0); ref.set_num_threads(1)
+    ref.step(3)
+    ref.add_bending_constraints(0, 3, 100.0)
+    ref.step(3)
+    m = util.build_mine(base)
+    pbd.TimeManager.setCurrent(pbd.TimeManager())
+    ts = pbd.TimeStepController()
+    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 5)
+    for _ in range(3):
+        ts.step(m)
+    m.addBendingConstraints(m.getTriangleModels()[0], 3, 100.0)
+    for _ in range(3):
+        ts.step(m)
+    assert util.bitwise_equal(m.getParticles().positions(), ref.positions().astype(np.float32))
