@@ -152,6 +152,45 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations);
 int pbdx_solver_synchronize(pbdx_solver *s);
 
+/* ---- contacts with static rigid bodies ------------------------------------------
+ * Particle vs static rigid body contacts with analytic distance fields, i.e. the part of
+ * DistanceFieldCollisionDetection::collisionDetection (DistanceFieldCollisionDetection.cpp:26-197,281-358)
+ * and of TimeStepController::velocityConstraintProjection (TimeStepController.cpp:298-355) that concerns
+ * ParticleRigidBodyContactConstraints (Constraints.cpp:2115-2189) when every rigid body is static
+ * (mass 0): collision detection once per step after the substeps, then `max_iterations_v` velocity
+ * sweeps.  With static bodies the contact list decomposes into independent per-particle chains, so the
+ * device result equals the reference's sequential sweep.  Assumption (true for the reference's demos):
+ * the collision object's AABB covers the region where its distance field is negative, so the
+ * reference's bounding-volume culling never removes a penetrating particle. */
+enum {
+	PBDX_SHAPE_BOX = 0,            /* params: half extents (m_box = 0.5 * box)          DistanceFieldCollisionBox */
+	PBDX_SHAPE_SPHERE = 1,         /* params[0] radius                                   DistanceFieldCollisionSphere */
+	PBDX_SHAPE_TORUS = 2,          /* params[0..1] radii                                 DistanceFieldCollisionTorus */
+	PBDX_SHAPE_CYLINDER = 3,       /* params[0] radius, [1] half height (m_dim)          DistanceFieldCollisionCylinder */
+	PBDX_SHAPE_HOLLOW_SPHERE = 4,  /* params[0] radius, [1] thickness                    DistanceFieldCollisionHollowSphere */
+	PBDX_SHAPE_HOLLOW_BOX = 5      /* params[0..2] half extents, [3] thickness           DistanceFieldCollisionHollowBox */
+};
+typedef struct pbdx_collider {
+	int shape;
+	int invert;                    /* m_invertSDF == -1 */
+	float params[4];
+	float com[3];                  /* RigidBody::getPosition() */
+	float R[9];                    /* RigidBody::getTransformationR(), row-major: x_local = R (x_world - com) + v1 */
+	float v1[3], v2[3];            /* getTransformationV1 / V2:  x_world = R^T x_local + v2 */
+	float restitution, friction;   /* of the rigid body */
+	float body_v[3], body_omega[3];/* velocity / angular velocity of the (static or kinematic) body */
+	uint32_t body_index;
+} pbdx_collider;
+/* particles [first, first+count) belong to a triangle / tet model registered as a collision object */
+typedef struct pbdx_collision_range { uint32_t first, count; float restitution, friction; } pbdx_collision_range;
+int pbdx_solver_set_colliders(pbdx_solver *s, uint32_t n, const pbdx_collider *colliders);
+int pbdx_solver_set_collision_ranges(pbdx_solver *s, uint32_t n, const pbdx_collision_range *ranges);
+/* tolerance = CollisionDetection::m_tolerance (default 0.01), contact_stiffness =
+ * SimulationModel::m_contactStiffnessParticleRigidBody (default 100), max_iterations_v = "maxIterationsV" (default 5) */
+int pbdx_solver_set_contact_params(pbdx_solver *s, float tolerance, float contact_stiffness, uint32_t max_iterations_v);
+/* contacts found by the last step (sum over particles); PBDX_ERR_INVALID if a particle exceeded 8 simultaneous contacts */
+int pbdx_solver_get_num_contacts(pbdx_solver *s, uint32_t *out);
+
 /* XPBD multipliers of batch `batch_index` (order of add_batch calls). */
 int pbdx_solver_get_lambdas(pbdx_solver *s, uint32_t batch_index, uint32_t count, float *out);
 

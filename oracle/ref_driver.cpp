@@ -17,6 +17,9 @@
 #include "Simulation/TimeManager.h"
 #include "Simulation/TimeStepController.h"
 #include "Simulation/Constraints.h"
+#include "Simulation/DistanceFieldCollisionDetection.h"
+#include "Simulation/RigidBody.h"
+#include "Utils/IndexedFaceMesh.h"
 #include "Utils/Logger.h"
 #include "Utils/Timing.h"
 #include <chrono>
@@ -41,6 +44,30 @@ namespace {
 			Simulation::getCurrent()->setModel(g_model);
 		}
 		return g_model;
+	}
+
+	// collision detection of the scene (Demos/DistanceFieldDemos/ClothCollisionDemo.cpp:40,163-180)
+	DistanceFieldCollisionDetection *g_cd = nullptr;
+	DistanceFieldCollisionDetection &cd()
+	{
+		if (!g_cd) g_cd = new DistanceFieldCollisionDetection();
+		return *g_cd;
+	}
+
+	// unit cube surface mesh (data/models/cube.obj: +-0.5), used as the geometry of every static collider
+	// (scaled to the bounding box of its analytic distance field, like the demo scales cube.obj / torus.obj)
+	void cubeMesh(VertexData &vd, Utilities::IndexedFaceMesh &mesh)
+	{
+		static const Real V[8][3] = { {-0.5,-0.5,0.5}, {0.5,-0.5,0.5}, {-0.5,0.5,0.5}, {0.5,0.5,0.5}, {-0.5,0.5,-0.5}, {0.5,0.5,-0.5}, {-0.5,-0.5,-0.5}, {0.5,-0.5,-0.5} };
+		static const int F[12][3] = { {0,1,2}, {2,1,3}, {2,3,4}, {4,3,5}, {4,5,6}, {6,5,7}, {6,7,0}, {0,7,1}, {1,7,3}, {3,7,5}, {6,0,4}, {4,0,2} };
+		mesh.release();
+		mesh.initMesh(8, 24, 12);
+		vd.reserve(8);
+		for (int i = 0; i < 8; i++) vd.addVertex(Vector3r(V[i][0], V[i][1], V[i][2]));
+		for (int i = 0; i < 12; i++) { int f[3] = { F[i][0], F[i][1], F[i][2] }; mesh.addFace(&f[0]); }
+		mesh.buildNeighbors();
+		mesh.updateNormals(vd, 0);
+		mesh.updateVertexNormals(vd);
 	}
 
 	TimeStepController *tsc() { return static_cast<TimeStepController*>(Simulation::getCurrent()->getTimeStep()); }
@@ -83,6 +110,8 @@ void refdrv_reset_all()
 	}
 	delete g_model;
 	g_model = nullptr;
+	delete g_cd;
+	g_cd = nullptr;
 	model();
 	TimeManager::getCurrent()->setTimeStepSize(static_cast<Real>(0.005));
 	TimeManager::getCurrent()->setTime(static_cast<Real>(0.0));
@@ -377,6 +406,131 @@ void refdrv_solve_position_constraints_grouped(unsigned iter)
 }
 
 void refdrv_model_reset() { Simulation::getCurrent()->reset(); }
+
+// ---- static colliders + distance-field collision detection (particle vs rigid body contacts) -------------
+// A static rigid body (mass 0) at pos / quaternion (w,x,y,z) whose geometry is the unit cube scaled to
+// `bbox`, with an analytic distance field of the given shape attached:
+//   shape 0 box(dims = p[0..2]); 1 sphere(radius p[0]); 2 torus(radii p[0], p[1]); 3 cylinder(radius p[0], height p[1]);
+//   4 hollow sphere(radius p[0], thickness p[1]); 5 hollow box(dims p[0..2], thickness p[3])
+// Returns the rigid body index.
+int refdrv_add_static_collider(int shape, const double *pos, const double *quat, const double *bbox, const double *p,
+	double restitution, double friction, int invertSDF)
+{
+	SimulationModel *m = model();
+	VertexData vd; Utilities::IndexedFaceMesh mesh;
+	cubeMesh(vd, mesh);
+	RigidBody *rb = new RigidBody();
+	rb->initBody(static_cast<Real>(1.0), v3(pos), Quaternionr((Real)quat[0], (Real)quat[1], (Real)quat[2], (Real)quat[3]), vd, mesh, v3(bbox));
+	rb->setMass(0.0);
+	rb->setRestitutionCoeff((Real)restitution);
+	rb->setFrictionCoeff((Real)friction);
+	SimulationModel::RigidBodyVector &rbs = m->getRigidBodies();
+	rbs.push_back(rb);
+	const unsigned int idx = (unsigned int)rbs.size() - 1;
+	const std::vector<Vector3r> &verts = rb->getGeometry().getVertexDataLocal().getVertices();
+	const unsigned int nv = (unsigned int)verts.size();
+	const unsigned int T = CollisionDetection::CollisionObject::RigidBodyCollisionObjectType;
+	switch (shape)
+	{
+	case 0: cd().addCollisionBox(idx, T, verts.data(), nv, Vector3r((Real)p[0], (Real)p[1], (Real)p[2]), true, invertSDF != 0); break;
+	case 1: cd().addCollisionSphere(idx, T, verts.data(), nv, (Real)p[0], true, invertSDF != 0); break;
+	case 2: cd().addCollisionTorus(idx, T, verts.data(), nv, Vector2r((Real)p[0], (Real)p[1]), true, invertSDF != 0); break;
+	case 3: cd().addCollisionCylinder(idx, T, verts.data(), nv, Vector2r((Real)p[0], (Real)p[1]), true, invertSDF != 0); break;
+	case 4: cd().addCollisionHollowSphere(idx, T, verts.data(), nv, (Real)p[0], (Real)p[1], true, invertSDF != 0); break;
+	case 5: cd().addCollisionHollowBox(idx, T, verts.data(), nv, Vector3r((Real)p[0], (Real)p[1], (Real)p[2]), (Real)p[3], true, invertSDF != 0); break;
+	default: return -1;
+	}
+	return (int)idx;
+}
+
+// Register every triangle / tet model as a collision object without geometry (its particles are tested
+// against the colliders) and attach the collision detection to the time step
+// (ClothCollisionDemo.cpp:163-180).
+void refdrv_enable_collisions(double tolerance, double modelRestitution, double modelFriction)
+{
+	SimulationModel *m = model();
+	cd().setTolerance((Real)tolerance);
+	ParticleData &pd = m->getParticles();
+	SimulationModel::TriangleModelVector &tms = m->getTriangleModels();
+	for (unsigned int i = 0; i < tms.size(); i++)
+	{
+		tms[i]->setRestitutionCoeff((Real)modelRestitution);
+		tms[i]->setFrictionCoeff((Real)modelFriction);
+		cd().addCollisionObjectWithoutGeometry(i, CollisionDetection::CollisionObject::TriangleModelCollisionObjectType,
+			&pd.getPosition(tms[i]->getIndexOffset()), tms[i]->getParticleMesh().numVertices(), true);
+	}
+	SimulationModel::TetModelVector &tets = m->getTetModels();
+	for (unsigned int i = 0; i < tets.size(); i++)
+	{
+		tets[i]->setRestitutionCoeff((Real)modelRestitution);
+		tets[i]->setFrictionCoeff((Real)modelFriction);
+		cd().addCollisionObjectWithoutGeometry(i, CollisionDetection::CollisionObject::TetModelCollisionObjectType,
+			&pd.getPosition(tets[i]->getIndexOffset()), tets[i]->getParticleMesh().numVertices(), true);
+	}
+	Simulation::getCurrent()->getTimeStep()->setCollisionDetection(*m, &cd());
+}
+
+// Collision object i as numbers (for feeding the product's raw collider API in tests):
+// out[0] body type (0 rigid body, 1 triangle model, 2 tet model), [1] shape (0..5, -1 = without geometry), [2] invertSDF,
+// [3..6] shape parameters AS STORED (m_box, m_radius, m_radii, m_dim, thickness), [7..9] body position, [10..18] transformation R
+// (row-major), [19..21] v1, [22..24] v2, [25] restitution, [26] friction, [27] body index, [28] first particle, [29] particle count,
+// [30] body mass, [31] tolerance
+unsigned refdrv_num_collision_objects() { return (unsigned)cd().getCollisionObjects().size(); }
+void refdrv_get_collision_object(unsigned i, double *out)
+{
+	typedef DistanceFieldCollisionDetection D;
+	SimulationModel *m = model();
+	CollisionDetection::CollisionObject *co = cd().getCollisionObjects()[i];
+	for (int k = 0; k < 32; k++) out[k] = 0.0;
+	out[27] = co->m_bodyIndex;
+	out[31] = (double)cd().getTolerance();
+	const int t = co->getTypeId();
+	int shape = -1;
+	if (t == D::DistanceFieldCollisionBox::TYPE_ID) { shape = 0; auto *c = (D::DistanceFieldCollisionBox*)co; for (int k = 0; k < 3; k++) out[3 + k] = (double)c->m_box[k]; }
+	else if (t == D::DistanceFieldCollisionSphere::TYPE_ID) { shape = 1; out[3] = (double)((D::DistanceFieldCollisionSphere*)co)->m_radius; }
+	else if (t == D::DistanceFieldCollisionTorus::TYPE_ID) { shape = 2; auto *c = (D::DistanceFieldCollisionTorus*)co; out[3] = (double)c->m_radii[0]; out[4] = (double)c->m_radii[1]; }
+	else if (t == D::DistanceFieldCollisionCylinder::TYPE_ID) { shape = 3; auto *c = (D::DistanceFieldCollisionCylinder*)co; out[3] = (double)c->m_dim[0]; out[4] = (double)c->m_dim[1]; }
+	else if (t == D::DistanceFieldCollisionHollowSphere::TYPE_ID) { shape = 4; auto *c = (D::DistanceFieldCollisionHollowSphere*)co; out[3] = (double)c->m_radius; out[4] = (double)c->m_thickness; }
+	else if (t == D::DistanceFieldCollisionHollowBox::TYPE_ID) { shape = 5; auto *c = (D::DistanceFieldCollisionHollowBox*)co; for (int k = 0; k < 3; k++) out[3 + k] = (double)c->m_box[k]; out[6] = (double)c->m_thickness; }
+	out[1] = shape;
+	if (shape >= 0) out[2] = (((D::DistanceFieldCollisionObject*)co)->m_invertSDF < 0) ? 1.0 : 0.0;
+	if (co->m_bodyType == CollisionDetection::CollisionObject::RigidBodyCollisionObjectType)
+	{
+		out[0] = 0;
+		RigidBody *rb = m->getRigidBodies()[co->m_bodyIndex];
+		for (int k = 0; k < 3; k++) out[7 + k] = (double)rb->getPosition()[k];
+		const Matrix3r &R = rb->getTransformationR();
+		for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out[10 + 3 * r + c] = (double)R(r, c);
+		for (int k = 0; k < 3; k++) { out[19 + k] = (double)rb->getTransformationV1()[k]; out[22 + k] = (double)rb->getTransformationV2()[k]; }
+		out[25] = (double)rb->getRestitutionCoeff(); out[26] = (double)rb->getFrictionCoeff(); out[30] = (double)rb->getMass();
+	}
+	else if (co->m_bodyType == CollisionDetection::CollisionObject::TriangleModelCollisionObjectType)
+	{
+		out[0] = 1;
+		TriangleModel *tm = m->getTriangleModels()[co->m_bodyIndex];
+		out[25] = (double)tm->getRestitutionCoeff(); out[26] = (double)tm->getFrictionCoeff();
+		out[28] = tm->getIndexOffset(); out[29] = tm->getParticleMesh().numVertices();
+	}
+	else
+	{
+		out[0] = 2;
+		TetModel *tm = m->getTetModels()[co->m_bodyIndex];
+		out[25] = (double)tm->getRestitutionCoeff(); out[26] = (double)tm->getFrictionCoeff();
+		out[28] = tm->getIndexOffset(); out[29] = tm->getParticleMesh().numVertices();
+	}
+}
+double refdrv_contact_stiffness_particle_rigid_body() { return (double)model()->getContactStiffnessParticleRigidBody(); }
+
+unsigned refdrv_num_particle_rigid_body_contacts() { return (unsigned)model()->getParticleRigidBodyContactConstraints().size(); }
+// contact i: out[0] particle, out[1] rigid body (as doubles), out[2..16] constraintInfo (3x5, column-major), out[17] sum of impulses
+void refdrv_get_particle_rigid_body_contact(unsigned i, double *out)
+{
+	ParticleRigidBodyContactConstraint &c = model()->getParticleRigidBodyContactConstraints()[i];
+	out[0] = c.m_bodies[0]; out[1] = c.m_bodies[1];
+	for (int col = 0; col < 5; col++) for (int r = 0; r < 3; r++) out[2 + 3 * col + r] = (double)c.m_constraintInfo(r, col);
+	out[17] = (double)c.m_sum_impulses;
+}
+void refdrv_set_max_iterations_v(unsigned n) { model(); tsc()->setValue<unsigned int>(TimeStepController::MAX_ITERATIONS_V, n); }
 
 // The currently installed TimeStep object (opaque; for plug-in side counters).
 void *refdrv_get_timestep() { model(); return (void*)Simulation::getCurrent()->getTimeStep(); }

@@ -87,6 +87,12 @@ class Ref:
         lib.refdrv_get_group.argtypes = [_u, _pu]
         lib.refdrv_install_timestep_plugin.argtypes = [C.c_char_p, C.c_char_p]
         lib.refdrv_get_timestep.restype = C.c_void_p
+        lib.refdrv_add_static_collider.argtypes = [_i, _pd, _pd, _pd, _pd, _d, _d, _i]
+        lib.refdrv_enable_collisions.argtypes = [_d, _d, _d]
+        lib.refdrv_get_particle_rigid_body_contact.argtypes = [_u, _pd]
+        lib.refdrv_set_max_iterations_v.argtypes = [_u]
+        lib.refdrv_get_collision_object.argtypes = [_u, _pd]
+        lib.refdrv_contact_stiffness_particle_rigid_body.restype = _d
         cls._cache[variant] = self
         return self
 
@@ -239,6 +245,42 @@ class Ref:
 
     def model_reset(self):
         self.lib.refdrv_model_reset()
+
+    # -- static colliders / contacts --------------------------------------------------------
+    SHAPES = {"box": 0, "sphere": 1, "torus": 2, "cylinder": 3, "hollow_sphere": 4, "hollow_box": 5}
+
+    def add_static_collider(self, shape, pos, quat, bbox, params, restitution=0.6, friction=0.2, invert=False):
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (pos, quat, bbox, list(params) + [0.0] * (4 - len(params)))]
+        return self.lib.refdrv_add_static_collider(self.SHAPES[shape], _dp(a[0]), _dp(a[1]), _dp(a[2]), _dp(a[3]),
+                                                   float(restitution), float(friction), int(bool(invert)))
+
+    def enable_collisions(self, tolerance=0.05, restitution=0.6, friction=0.1):
+        self.lib.refdrv_enable_collisions(float(tolerance), float(restitution), float(friction))
+
+    def set_max_iterations_v(self, n):
+        self.lib.refdrv_set_max_iterations_v(int(n))
+
+    def collision_objects(self):
+        """(colliders, ranges, tolerance, contact stiffness) in the form the product's raw API takes."""
+        colliders, ranges, tol = [], [], 0.01
+        for i in range(self.lib.refdrv_num_collision_objects()):
+            o = np.zeros(32, dtype=np.float64)
+            self.lib.refdrv_get_collision_object(i, _dp(o))
+            tol = o[31]
+            if o[0] == 0:
+                assert o[30] == 0.0, "only static rigid bodies"
+                colliders.append(dict(shape=int(o[1]), invert=bool(o[2]), params=list(o[3:7]), com=o[7:10], R=o[10:19], v1=o[19:22], v2=o[22:25],
+                                      restitution=o[25], friction=o[26], body_index=int(o[27])))
+            else:
+                ranges.append((int(o[28]), int(o[29]), o[25], o[26]))
+        return colliders, ranges, tol, self.lib.refdrv_contact_stiffness_particle_rigid_body()
+
+    def contacts(self):
+        n = self.lib.refdrv_num_particle_rigid_body_contacts()
+        out = np.empty((n, 18), dtype=np.float64)
+        for i in range(n):
+            self.lib.refdrv_get_particle_rigid_body_contact(i, _dp(out[i]))
+        return out
 
     def install_timestep_plugin(self, path, symbol="pbdx_create_timestep_hip"):
         return self.lib.refdrv_install_timestep_plugin(path.encode(), symbol.encode())

@@ -569,6 +569,42 @@ class Solver:
         check(lib.pbdx_solver_describe(self._h, buf, 512), "describe")
         return buf.value.decode()
 
+    SHAPES = {"box": 0, "sphere": 1, "torus": 2, "cylinder": 3, "hollow_sphere": 4, "hollow_box": 5}
+
+    def set_colliders(self, colliders):
+        """colliders: list of dicts with the fields of pbdx_collider (shape by name or number)."""
+        arr = (_ffi.Collider * max(len(colliders), 1))()
+        for i, c in enumerate(colliders):
+            k = arr[i]
+            k.shape = self.SHAPES.get(c["shape"], c["shape"]) if isinstance(c["shape"], str) else int(c["shape"])
+            k.invert = int(bool(c.get("invert", False)))
+            par = list(c["params"]) + [0.0] * (4 - len(c["params"]))
+            for j in range(4):
+                k.params[j] = par[j]
+            for name, n in (("com", 3), ("R", 9), ("v1", 3), ("v2", 3), ("body_v", 3), ("body_omega", 3)):
+                vals = np.asarray(c.get(name, np.zeros(n)), dtype=np.float32).reshape(-1)
+                for j in range(n):
+                    getattr(k, name)[j] = vals[j]
+            k.restitution = c.get("restitution", 0.6)
+            k.friction = c.get("friction", 0.2)
+            k.body_index = int(c.get("body_index", i))
+        check(lib.pbdx_solver_set_colliders(self._h, len(colliders), arr), "set_colliders")
+
+    def set_collision_ranges(self, ranges):
+        """ranges: list of (first, count, restitution, friction)."""
+        arr = (_ffi.CollisionRange * max(len(ranges), 1))()
+        for i, r in enumerate(ranges):
+            arr[i].first, arr[i].count, arr[i].restitution, arr[i].friction = int(r[0]), int(r[1]), float(r[2]), float(r[3])
+        check(lib.pbdx_solver_set_collision_ranges(self._h, len(ranges), arr), "set_collision_ranges")
+
+    def set_contact_params(self, tolerance=0.01, contact_stiffness=100.0, max_iterations_v=5):
+        check(lib.pbdx_solver_set_contact_params(self._h, float(tolerance), float(contact_stiffness), int(max_iterations_v)), "set_contact_params")
+
+    def num_contacts(self):
+        n = C.c_uint32()
+        check(lib.pbdx_solver_get_num_contacts(self._h, C.byref(n)), "get_num_contacts")
+        return n.value
+
     def plan_info(self):
         """The colour-fused tile schedule planned for the current constraint schedule."""
         pi = _ffi.PlanInfo()

@@ -31,6 +31,16 @@ class StepStats(C.Structure):
                 ("projections", C.c_uint64), ("kernel_launches", C.c_uint64), ("algorithmic_bytes", C.c_uint64)]
 
 
+class Collider(C.Structure):
+    _fields_ = [("shape", C.c_int), ("invert", C.c_int), ("params", C.c_float * 4), ("com", C.c_float * 3), ("R", C.c_float * 9),
+                ("v1", C.c_float * 3), ("v2", C.c_float * 3), ("restitution", C.c_float), ("friction", C.c_float),
+                ("body_v", C.c_float * 3), ("body_omega", C.c_float * 3), ("body_index", C.c_uint32)]
+
+
+class CollisionRange(C.Structure):
+    _fields_ = [("first", C.c_uint32), ("count", C.c_uint32), ("restitution", C.c_float), ("friction", C.c_float)]
+
+
 class PlanInfo(C.Structure):
     _fields_ = [("built", C.c_int), ("active", C.c_int), ("num_segments", C.c_uint32), ("num_tiles", C.c_uint32),
                 ("num_colours", C.c_uint32), ("max_local", C.c_uint32), ("slots_per_sweep", C.c_uint64),
@@ -74,6 +84,10 @@ SIGNATURES = [
     ("pbdx_solver_get_plan_info", C.c_int, vp, C.POINTER(PlanInfo)),
     ("pbdx_solver_get_segment_info", C.c_int, vp, u32, C.POINTER(SegmentInfo)),
     ("pbdx_solver_get_trace", C.c_int, vp, u32, C.POINTER(C.c_uint64), u32, C.POINTER(u32)),
+    ("pbdx_solver_set_colliders", C.c_int, vp, u32, C.POINTER(Collider)),
+    ("pbdx_solver_set_collision_ranges", C.c_int, vp, u32, C.POINTER(CollisionRange)),
+    ("pbdx_solver_set_contact_params", C.c_int, vp, f32, f32, u32),
+    ("pbdx_solver_get_num_contacts", C.c_int, vp, C.POINTER(u32)),
     ("pbdx_debug_stream", C.c_int, C.c_int, C.c_uint64, C.c_int),
     ("pbdx_model_plan_check", C.c_int, vp, u32, u32, u32, C.POINTER(PlanInfo)),
     ("pbdx_model_create", C.c_int, C.POINTER(vp)), ("pbdx_model_destroy", None, vp),

@@ -30,6 +30,7 @@
 #include "pbdx_internal.h"
 #include "pbdx_access.h"
 #include "pbdx_plan.h"
+#include "pbdx_contact.h"
 #include <algorithm>
 #include <string.h>
 
@@ -399,6 +400,36 @@ __global__ __launch_bounds__(256) void set_xyz_kernel(const float *__restrict__ 
 	dst[i] = v;
 }
 
+// ---- contacts with static colliders: one particle per lane (pbdx_contact.h) -----------------------------
+struct ContactArgs
+{
+	const float4 *pos;
+	float4 *vel;
+	const pbdx_collider *colliders;
+	uint32_t num_colliders;
+	uint32_t first, count;          // particle range of one collision model
+	float tolerance, stiffness, restitution, friction;
+	uint32_t iterations;
+	unsigned int *counters;         // [0] contacts, [1] overflow flag
+};
+__global__ __launch_bounds__(256) void contact_kernel(ContactArgs a)
+{
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= a.count) return;
+	const uint32_t i = a.first + k;
+	const float4 p = a.pos[i];
+	float4 vv = a.vel[i];
+	V3 v = mk(vv.x, vv.y, vv.z);
+	const int nc = particle_contacts(mk(p.x, p.y, p.z), v, p.w, vv.w, a.colliders, a.num_colliders, a.tolerance, a.stiffness,
+		a.restitution, a.friction, a.iterations);
+	if (nc < 0) { atomicExch(&a.counters[1], 1u); return; }
+	if (nc > 0)
+	{
+		atomicAdd(&a.counters[0], (unsigned int)nc);
+		a.vel[i] = make_float4(v.x, v.y, v.z, vv.w);
+	}
+}
+
 // ---- counter calibration kernels (pbdx_debug_stream): known byte counts in this engine's own access
 // widths, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be turned into bytes (MI355X_MICROARCH.md, HBM)
 __global__ __launch_bounds__(256) void calib_read_b32(const float *__restrict__ src, float *__restrict__ sink, size_t n)
@@ -494,6 +525,15 @@ struct pbdx_solver
 	struct Pin { const void *p; size_t bytes; };
 	std::vector<Pin> pins;
 	int pairs = 0;                       // measured slower: off by default
+
+	// contacts with static colliders
+	std::vector<pbdx_collider> colliders;
+	std::vector<pbdx_collision_range> ranges;
+	pbdx_collider *d_colliders = nullptr;
+	unsigned int *d_contact_counters = nullptr;
+	float contact_tolerance = 0.01f, contact_stiffness = 100.0f;
+	uint32_t max_iterations_v = 5;
+	uint64_t contact_version = 0;
 
 	// fused plan
 	FusedPlan plan;
@@ -807,6 +847,27 @@ int enqueue_substep(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int v
 	return PBDX_OK;
 }
 
+// collision detection + velocity constraint projection of the contacts, once per step after the
+// substeps (TimeStepController.cpp:216-223)
+int enqueue_contacts(pbdx_solver *s)
+{
+	if (s->colliders.empty() || s->ranges.empty() || !s->n) return PBDX_OK;
+	HIPCHECK(hipMemsetAsync(s->d_contact_counters, 0, 2 * sizeof(unsigned int), s->stream));
+	for (const pbdx_collision_range &r : s->ranges)
+	{
+		if (!r.count) continue;
+		ContactArgs a;
+		a.pos = s->d_pos[0]; a.vel = s->d_vel; a.colliders = s->d_colliders; a.num_colliders = (uint32_t)s->colliders.size();
+		a.first = r.first; a.count = r.count;
+		a.tolerance = s->contact_tolerance; a.stiffness = s->contact_stiffness; a.restitution = r.restitution; a.friction = r.friction;
+		a.iterations = s->max_iterations_v;
+		a.counters = s->d_contact_counters;
+		hipLaunchKernelGGL(contact_kernel, dim3((r.count + 255) / 256), dim3(256), 0, s->stream, a);
+		HIPCHECK(hipGetLastError());
+	}
+	return PBDX_OK;
+}
+
 int collect_profile(pbdx_solver *s, ProfCursor *pc)
 {
 	HIPCHECK(hipStreamSynchronize(s->stream));
@@ -882,6 +943,8 @@ void pbdx_solver_destroy(pbdx_solver *s)
 	s->free_batches();
 	s->free_particles();
 	s->unpin_all();
+	if (s->d_colliders) (void)hipFree(s->d_colliders);
+	if (s->d_contact_counters) (void)hipFree(s->d_contact_counters);
 	for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
 	if (s->ev_start) (void)hipEventDestroy(s->ev_start);
 	if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
@@ -1147,6 +1210,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 			if (r) return r;
 			r = collect_profile(s, &pc);
 			if (r) return r;
+			if ((k + 1) % sub_steps == 0) { r = enqueue_contacts(s); if (r) return r; }
 		}
 		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
 	}
@@ -1169,7 +1233,10 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		}
 		HIPCHECK(hipEventRecord(s->ev_start, s->stream));
 		for (uint64_t k2 = 0; k2 < substeps_total; k2++)
+		{
 			HIPCHECK(hipGraphLaunch(s->graph_exec, s->stream));
+			if ((k2 + 1) % sub_steps == 0) { int r = enqueue_contacts(s); if (r) return r; }
+		}
 		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
 	}
 	else
@@ -1179,6 +1246,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		{
 			int r = enqueue_substep(s, hs, inv_h, max_iterations, vel, gravity, nullptr);
 			if (r) return r;
+			if ((k + 1) % sub_steps == 0) { r = enqueue_contacts(s); if (r) return r; }
 		}
 		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
 	}
@@ -1209,6 +1277,60 @@ int pbdx_solver_synchronize(pbdx_solver *s)
 	if (!s) return PBDX_ERR_INVALID;
 	HIPCHECK(hipSetDevice(s->device));
 	HIPCHECK(hipStreamSynchronize(s->stream));
+	return PBDX_OK;
+}
+
+int pbdx_solver_set_colliders(pbdx_solver *s, uint32_t n, const pbdx_collider *colliders)
+{
+	if (!s || (n && !colliders)) { set_error("set_colliders: bad arguments"); return PBDX_ERR_INVALID; }
+	for (uint32_t i = 0; i < n; i++)
+		if (colliders[i].shape < PBDX_SHAPE_BOX || colliders[i].shape > PBDX_SHAPE_HOLLOW_BOX) { set_error("set_colliders: unknown shape %d", colliders[i].shape); return PBDX_ERR_UNSUPPORTED; }
+	HIPCHECK(hipSetDevice(s->device));
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	if (s->d_colliders) { (void)hipFree(s->d_colliders); s->d_colliders = nullptr; }
+	s->colliders.assign(colliders, colliders + n);
+	if (n)
+	{
+		HIPCHECK(hipMalloc(&s->d_colliders, (size_t)n * sizeof(pbdx_collider)));
+		HIPCHECK(hipMemcpy(s->d_colliders, colliders, (size_t)n * sizeof(pbdx_collider), hipMemcpyHostToDevice));
+	}
+	if (!s->d_contact_counters)
+	{
+		HIPCHECK(hipMalloc(&s->d_contact_counters, 2 * sizeof(unsigned int)));
+		HIPCHECK(hipMemset(s->d_contact_counters, 0, 2 * sizeof(unsigned int)));
+	}
+	return PBDX_OK;
+}
+
+int pbdx_solver_set_collision_ranges(pbdx_solver *s, uint32_t n, const pbdx_collision_range *ranges)
+{
+	if (!s || (n && !ranges)) { set_error("set_collision_ranges: bad arguments"); return PBDX_ERR_INVALID; }
+	for (uint32_t i = 0; i < n; i++)
+		if ((uint64_t)ranges[i].first + ranges[i].count > s->n) { set_error("set_collision_ranges: range %u exceeds the %u uploaded particles", i, s->n); return PBDX_ERR_INVALID; }
+	HIPCHECK(hipSetDevice(s->device));
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	s->ranges.assign(ranges, ranges + n);
+	return PBDX_OK;
+}
+
+int pbdx_solver_set_contact_params(pbdx_solver *s, float tolerance, float contact_stiffness, uint32_t max_iterations_v)
+{
+	if (!s) return PBDX_ERR_INVALID;
+	s->contact_tolerance = tolerance; s->contact_stiffness = contact_stiffness; s->max_iterations_v = max_iterations_v;
+	return PBDX_OK;
+}
+
+int pbdx_solver_get_num_contacts(pbdx_solver *s, uint32_t *out)
+{
+	if (!s || !out) return PBDX_ERR_INVALID;
+	*out = 0;
+	if (!s->d_contact_counters) return PBDX_OK;
+	HIPCHECK(hipSetDevice(s->device));
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	unsigned int c[2] = { 0, 0 };
+	HIPCHECK(hipMemcpy(c, s->d_contact_counters, sizeof(c), hipMemcpyDeviceToHost));
+	*out = c[0];
+	if (c[1]) { set_error("a particle had more than %d simultaneous contacts", PBDX_MAX_CONTACTS_PER_PARTICLE); return PBDX_ERR_INVALID; }
 	return PBDX_OK;
 }
 
