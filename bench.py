@@ -234,6 +234,7 @@ def main():
     ap.add_argument("--fuse-block", type=int, default=None)
     ap.add_argument("--max-seg", type=int, default=None, help="max colours fused into one launch")
     ap.add_argument("--lds-particles", type=int, default=None)
+    ap.add_argument("--contacts", action="store_true", help="also time the step with two static colliders (contact detection + velocity solve per step)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -324,6 +325,24 @@ def main():
         t_pcie_pinned = (time.perf_counter() - t1) / 3
         sol.set_option(pbd.Solver.OPT_PIN_HOST, 0)
 
+    contact_info = None
+    if rank == 0 and args.contacts:
+        # a floor box under the sheet and a sphere it falls onto; identity collider frames
+        eye = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+        sol.set_colliders([dict(shape="box", params=[50.0, 0.5, 50.0], com=[0, -6.0, 0], R=eye, v1=[0, 0, 0], v2=[0, -6.0, 0], restitution=0.6, friction=0.2),
+                           dict(shape="sphere", params=[2.0], com=[5.0, -2.0, 0.0], R=eye, v1=[0, 0, 0], v2=[5.0, -2.0, 0.0], restitution=0.6, friction=0.1)])
+        sol.set_collision_ranges([(0, n_particles, 0.6, 0.1)])
+        sol.set_contact_params(0.05, 100.0, 5)
+        ts.stepResident(model, 3)
+        t1 = time.perf_counter()
+        ts.stepResident(model, args.steps)
+        torch.cuda.synchronize()
+        t_c = (time.perf_counter() - t1) / args.steps
+        contact_info = {"ms_per_step_with_contact_pass": 1e3 * t_c, "contacts_last_step": sol.num_contacts(),
+                        "colliders": 2, "note": "detection + 5 velocity sweeps for every particle against 2 static colliders, once per step"}
+        sol.set_colliders([])
+        sol.set_collision_ranges([])
+
     out = {
         "metric": "constraint-projections/s", "value": value, "unit": "projections/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -336,7 +355,7 @@ def main():
                    "state_ok": ok, "device_event_ms_per_substep": stats["total_ms"] / max(args.steps, 1),
                    "algorithmic_GB_per_substep": stats["algorithmic_bytes"] / max(args.steps, 1) / 1e9,
                    "whole_substep_algorithmic_GBs": stats["algorithmic_bytes"] / max(stats["total_ms"], 1e-9) / 1e6,
-                   "host_scene_build_s": t_build, "pcie_inclusive_ms_per_step": None if t_pcie is None else 1e3 * t_pcie,
+                   "host_scene_build_s": t_build, "contacts": contact_info, "pcie_inclusive_ms_per_step": None if t_pcie is None else 1e3 * t_pcie,
                    "pcie_inclusive_pinned_ms_per_step": None if t_pcie_pinned is None else 1e3 * t_pcie_pinned, "plan": plan, "engine": sol.describe()},
     }
 

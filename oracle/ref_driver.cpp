@@ -475,6 +475,8 @@ void refdrv_enable_collisions(double tolerance, double modelRestitution, double 
 // [3..6] shape parameters AS STORED (m_box, m_radius, m_radii, m_dim, thickness), [7..9] body position, [10..18] transformation R
 // (row-major), [19..21] v1, [22..24] v2, [25] restitution, [26] friction, [27] body index, [28] first particle, [29] particle count,
 // [30] body mass, [31] tolerance
+// (re)attach the scene's collision detection to the CURRENT time step (after installing a plug-in)
+void refdrv_attach_collision_detection() { Simulation::getCurrent()->getTimeStep()->setCollisionDetection(*model(), &cd()); }
 unsigned refdrv_num_collision_objects() { return (unsigned)cd().getCollisionObjects().size(); }
 void refdrv_get_collision_object(unsigned i, double *out)
 {

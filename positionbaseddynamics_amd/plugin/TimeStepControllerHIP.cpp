@@ -2,9 +2,12 @@
 #include "Simulation/Simulation.h"
 #include "Simulation/TimeManager.h"
 #include "Simulation/Constraints.h"
+#include "Simulation/DistanceFieldCollisionDetection.h"
+#include "Simulation/RigidBody.h"
 #include "Utils/Logger.h"
 #include "Utils/Timing.h"
 #include <stdio.h>
+#include <string.h>
 
 using namespace PBD;
 
@@ -112,13 +115,103 @@ void TimeStepControllerHIP::reset()
 bool TimeStepControllerHIP::supported(SimulationModel &model) const
 {
 	if (!m_solver) return false;
-	if (!model.getRigidBodies().empty() || model.getOrientations().size() != 0) return false;
-	if (!model.getParticleSolidContactConstraints().empty() || !model.getParticleRigidBodyContactConstraints().empty() ||
-		!model.getRigidBodyContactConstraints().empty()) return false;
-	if (m_collisionDetection != NULL) return false;       // contacts are produced per step on the CPU
+	if (model.getOrientations().size() != 0) return false;
+	// rigid bodies: only static ones (mass 0), as colliders of a distance-field collision detection
+	for (RigidBody *rb : model.getRigidBodies())
+		if (rb->getMass() != 0.0) return false;
+	if (!model.getRigidBodies().empty() && m_collisionDetection == NULL) return false;
+	if (m_collisionDetection != NULL && dynamic_cast<DistanceFieldCollisionDetection*>(m_collisionDetection) == NULL) return false;
+	if (m_collisionDetection != NULL)
+	{
+		typedef DistanceFieldCollisionDetection D;
+		for (CollisionDetection::CollisionObject *co : m_collisionDetection->getCollisionObjects())
+		{
+			const int t = co->getTypeId();
+			if (co->m_bodyType == CollisionDetection::CollisionObject::RigidBodyCollisionObjectType)
+			{
+				if (t != D::DistanceFieldCollisionBox::TYPE_ID && t != D::DistanceFieldCollisionSphere::TYPE_ID && t != D::DistanceFieldCollisionTorus::TYPE_ID &&
+					t != D::DistanceFieldCollisionCylinder::TYPE_ID && t != D::DistanceFieldCollisionHollowSphere::TYPE_ID && t != D::DistanceFieldCollisionHollowBox::TYPE_ID)
+					return false;                             // e.g. cubic SDF (Discregrid) colliders
+			}
+			else if (t != D::DistanceFieldCollisionObjectWithoutGeometry::TYPE_ID)
+				return false;                                 // deformable vs deformable contacts (ParticleTetContactConstraint)
+		}
+		// more than one tet model registered => solid-solid contacts are possible: not handled
+		unsigned int tetObjects = 0;
+		for (CollisionDetection::CollisionObject *co : m_collisionDetection->getCollisionObjects())
+			if (co->m_bodyType == CollisionDetection::CollisionObject::TetModelCollisionObjectType) tetObjects++;
+		if (tetObjects > 1) return false;
+	}
 	for (Constraint *c : model.getConstraints())
 		if (engineType(c) < 0) return false;                // e.g. GenericConstraints, joints, rods
 	return true;
+}
+
+// Colliders = the rigid-body collision objects of the reference's DistanceFieldCollisionDetection, with
+// the transformation the reference keeps per rigid body (RigidBody::getTransformationR/V1/V2); collision
+// ranges = the triangle / tet models registered with testMesh (DistanceFieldCollisionDetection.cpp:124-154).
+bool TimeStepControllerHIP::uploadColliders(SimulationModel &model)
+{
+	std::vector<pbdx_collider> cols;
+	std::vector<pbdx_collision_range> ranges;
+	float tolerance = 0.01f;
+	if (m_collisionDetection != NULL)
+	{
+		typedef DistanceFieldCollisionDetection D;
+		tolerance = (float)m_collisionDetection->getTolerance();
+		for (CollisionDetection::CollisionObject *co : m_collisionDetection->getCollisionObjects())
+		{
+			const int t = co->getTypeId();
+			if (co->m_bodyType == CollisionDetection::CollisionObject::RigidBodyCollisionObjectType)
+			{
+				pbdx_collider c;
+				memset(&c, 0, sizeof(c));
+				D::DistanceFieldCollisionObject *dco = (D::DistanceFieldCollisionObject*)co;
+				c.invert = dco->m_invertSDF < 0 ? 1 : 0;
+				if (t == D::DistanceFieldCollisionBox::TYPE_ID) { c.shape = PBDX_SHAPE_BOX; for (int k = 0; k < 3; k++) c.params[k] = (float)((D::DistanceFieldCollisionBox*)co)->m_box[k]; }
+				else if (t == D::DistanceFieldCollisionSphere::TYPE_ID) { c.shape = PBDX_SHAPE_SPHERE; c.params[0] = (float)((D::DistanceFieldCollisionSphere*)co)->m_radius; }
+				else if (t == D::DistanceFieldCollisionTorus::TYPE_ID) { c.shape = PBDX_SHAPE_TORUS; c.params[0] = (float)((D::DistanceFieldCollisionTorus*)co)->m_radii[0]; c.params[1] = (float)((D::DistanceFieldCollisionTorus*)co)->m_radii[1]; }
+				else if (t == D::DistanceFieldCollisionCylinder::TYPE_ID) { c.shape = PBDX_SHAPE_CYLINDER; c.params[0] = (float)((D::DistanceFieldCollisionCylinder*)co)->m_dim[0]; c.params[1] = (float)((D::DistanceFieldCollisionCylinder*)co)->m_dim[1]; }
+				else if (t == D::DistanceFieldCollisionHollowSphere::TYPE_ID) { c.shape = PBDX_SHAPE_HOLLOW_SPHERE; c.params[0] = (float)((D::DistanceFieldCollisionHollowSphere*)co)->m_radius; c.params[1] = (float)((D::DistanceFieldCollisionHollowSphere*)co)->m_thickness; }
+				else { c.shape = PBDX_SHAPE_HOLLOW_BOX; for (int k = 0; k < 3; k++) c.params[k] = (float)((D::DistanceFieldCollisionHollowBox*)co)->m_box[k]; c.params[3] = (float)((D::DistanceFieldCollisionHollowBox*)co)->m_thickness; }
+				RigidBody *rb = model.getRigidBodies()[co->m_bodyIndex];
+				const Matrix3r &R = rb->getTransformationR();
+				for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) c.R[3 * r + k] = (float)R(r, k);
+				for (int k = 0; k < 3; k++)
+				{
+					c.com[k] = (float)rb->getPosition()[k];
+					c.v1[k] = (float)rb->getTransformationV1()[k];
+					c.v2[k] = (float)rb->getTransformationV2()[k];
+					c.body_v[k] = (float)rb->getVelocity()[k];
+					c.body_omega[k] = (float)rb->getAngularVelocity()[k];
+				}
+				c.restitution = (float)rb->getRestitutionCoeff();
+				c.friction = (float)rb->getFrictionCoeff();
+				c.body_index = co->m_bodyIndex;
+				cols.push_back(c);
+			}
+			else if (((D::DistanceFieldCollisionObject*)co)->m_testMesh)
+			{
+				pbdx_collision_range r;
+				if (co->m_bodyType == CollisionDetection::CollisionObject::TriangleModelCollisionObjectType)
+				{
+					TriangleModel *tm = model.getTriangleModels()[co->m_bodyIndex];
+					r.first = tm->getIndexOffset(); r.count = tm->getParticleMesh().numVertices();
+					r.restitution = (float)tm->getRestitutionCoeff(); r.friction = (float)tm->getFrictionCoeff();
+				}
+				else
+				{
+					TetModel *tm = model.getTetModels()[co->m_bodyIndex];
+					r.first = tm->getIndexOffset(); r.count = tm->getParticleMesh().numVertices();
+					r.restitution = (float)tm->getRestitutionCoeff(); r.friction = (float)tm->getFrictionCoeff();
+				}
+				ranges.push_back(r);
+			}
+		}
+	}
+	if (pbdx_solver_set_colliders(m_solver, (uint32_t)cols.size(), cols.data()) != PBDX_OK) return false;
+	if (pbdx_solver_set_collision_ranges(m_solver, (uint32_t)ranges.size(), ranges.data()) != PBDX_OK) return false;
+	return pbdx_solver_set_contact_params(m_solver, tolerance, (float)model.getContactStiffnessParticleRigidBody(), m_maxIterationsV) == PBDX_OK;
 }
 
 bool TimeStepControllerHIP::uploadParticles(SimulationModel &model)
@@ -205,6 +298,8 @@ void TimeStepControllerHIP::step(SimulationModel &model)
 	if (ok && (!m_scheduleValid || !model.m_groupsInitialized || m_numConstraints != model.getConstraints().size()))
 		ok = buildSchedule(model);
 	if (ok)
+		ok = uploadColliders(model);                        // cheap; poses / coefficients are host-mutable between steps
+	if (ok)
 	{
 		clearAccelerations(model);                          // host-visible side effect of TimeStepController.cpp:84
 		Simulation *sim = Simulation::getCurrent();
@@ -216,7 +311,13 @@ void TimeStepControllerHIP::step(SimulationModel &model)
 		m_iterations = m_maxIterations;
 	}
 	if (ok)
+	{
+		// TimeStepController.cpp:216-223: the reference rebuilds the contact lists every step; the device keeps
+		// its contacts to itself, so the host lists are emptied (counts: pbdx_solver_get_num_contacts)
+		if (m_collisionDetection != NULL) model.resetContacts();
+		m_iterationsV = m_maxIterationsV;
 		ok = downloadParticles(model);
+	}
 	if (!ok)
 	{
 		STOP_TIMING_AVG;

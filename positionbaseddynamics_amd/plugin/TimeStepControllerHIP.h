@@ -12,8 +12,10 @@
 //     Simulation::getCurrent()->setTimeStep(new PBD::TimeStepControllerHIP());
 //     Simulation::getCurrent()->getTimeStep()->init();
 //
-// Scope: models whose constraints are all particle constraints known to the engine and that
-// contain no rigid bodies / orientations / contacts.  There is NO silent CPU path: a step the
+// Scope: models whose constraints are all particle constraints known to the engine.  Rigid bodies are
+// accepted when they are all static (mass 0) colliders of a DistanceFieldCollisionDetection with analytic
+// distance fields (box, sphere, torus, cylinder, hollow sphere / box): the particle vs rigid body contacts
+// are then detected and solved on the GPU as well.  No dynamic rigid bodies, joints, orientations.  There is NO silent CPU path: a step the
 // engine cannot run (no HIP device, HIP error, unsupported model) logs an error, leaves the
 // model untouched and is counted in numFailedSteps().  A host application that prefers the
 // reference's own CPU TimeStepController for such models opts in explicitly with
@@ -52,6 +54,7 @@ namespace PBD
 		bool supported(SimulationModel &model) const;
 		bool buildSchedule(SimulationModel &model);
 		bool uploadParticles(SimulationModel &model);
+		bool uploadColliders(SimulationModel &model);
 		bool downloadParticles(SimulationModel &model);
 
 		pbdx_solver *m_solver;

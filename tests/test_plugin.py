@@ -100,3 +100,37 @@ def test_plugin_f64_host_envelope():
     err = util.max_err(x_gpu, x_cpu)
     print("plug-in in a double host: max |dx| vs double CPU path after 10 steps = %.3e" % err)
     assert err <= 2e-4
+
+
+@pytest.mark.gpu
+def test_plugin_with_static_colliders_and_contacts():
+    """ClothCollisionDemo restated: the reference owns the rigid bodies and the DistanceFieldCollisionDetection;
+    the plug-in reads the colliders from it and runs detection + contact velocity solve on the GPU."""
+    refdrv, path = _plugin("f32")
+    ops = util.cloth_spec(30, 30, 4, 3, T=(-5, 4, -5), pin=False)
+
+    def scene(ref):
+        _setup(ref, ops, 1, 5)
+        ref.add_static_collider("box", (0, -2.5, 0), (1, 0, 0, 0), (100, 1, 100), (100, 1, 100), 0.6, 0.2)
+        ref.add_static_collider("torus", (0, 1.5, 0), (1, 0, 0, 0), (6, 2, 6), (2, 1), 0.6, 0.1)
+        ref.enable_collisions(0.05, 0.6, 0.1)
+
+    ref = refdrv.Ref("f32")
+    scene(ref)
+    ref.set_params(1, 5, 0)
+    ref.step(200)
+    assert len(ref.contacts()) > 0
+    x_cpu, v_cpu = ref.positions().copy(), ref.get_array(2).copy()
+    scene(ref)
+    assert ref.install_timestep_plugin(path) == 0
+    # the collision detection was attached to the previous time step object: attach it to the plug-in
+    ref.lib.refdrv_attach_collision_detection()
+    ref.set_params(1, 5, 0)
+    ref.step(200)
+    lib, cnt = _counters(path)
+    ts = C.c_void_p(ref.lib.refdrv_get_timestep())
+    assert cnt["gpu_steps"](ts) == 200 and cnt["failed_steps"](ts) == 0 and cnt["fallback_steps"](ts) == 0
+    x_gpu, v_gpu = ref.positions().copy(), ref.get_array(2).copy()
+    ref.reset_all()
+    assert util.bitwise_equal(x_gpu, x_cpu), "max err %.3e" % util.max_err(x_gpu, x_cpu)
+    assert util.bitwise_equal(v_gpu, v_cpu)
