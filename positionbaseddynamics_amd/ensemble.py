@@ -40,6 +40,8 @@ class Ensemble:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            # PBDX_DIST_BACKEND: smoke-testing the N>1 path on a box with fewer GPUs than ranks (gloo)
+            backend = backend or os.environ.get("PBDX_DIST_BACKEND") or None
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             if backend == "nccl":
@@ -49,6 +51,9 @@ class Ensemble:
             else:
                 self.device = torch.device("cpu")
                 dist.init_process_group(backend=backend)
+                # ranks may share a GPU in this mode: PBDX_DEVICE_OVERRIDE pins the HIP device index
+                if os.environ.get("PBDX_DEVICE_OVERRIDE") is not None:
+                    self.local_rank = int(os.environ["PBDX_DEVICE_OVERRIDE"])
             self.dist = dist
         self.backend = backend
 
