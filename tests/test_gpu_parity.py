@@ -139,6 +139,7 @@ SCENES.update({
     "irregular Delaunay cloth FEM tri + dihedral": (util.delaunay_cloth_spec(500, cloth_method=2, bending_method=1), 1, 5, [(1, 1e-5), (5, 1e-4)]),
     "irregular Delaunay tets FEM (2)": (util.delaunay_solid_spec(400, solid_method=2), 1, 10, [(1, 1e-6), (10, 1e-5)]),
     "irregular Delaunay tets XPBD dist+vol (6)": (util.delaunay_solid_spec(400, solid_method=6), 1, 10, [(1, 1e-6), (10, 1e-5)]),
+    "kitchen sink: all 13 constraint types in one model, mixed-type colours": (util.kitchen_sink_spec(), 2, 3, [(1, 1e-5), (6, 1e-4)]),
 })
 
 

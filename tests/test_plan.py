@@ -18,6 +18,7 @@ CASES = {
     "bar 20x6x6 XPBD dist+vol": util.bar_spec(20, 6, 6, 6),
     "bar 12x5x5 shape matching": util.bar_spec(12, 5, 5, 5),
     "irregular Delaunay cloth": util.delaunay_cloth_spec(600),
+    "kitchen sink (all 13 types, mixed-type colours)": util.kitchen_sink_spec(),
     "irregular Delaunay tets, FEM": util.delaunay_solid_spec(250, solid_method=2),
     "irregular Delaunay tets, distance+volume": util.delaunay_solid_spec(250, solid_method=1),
 }

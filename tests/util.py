@@ -94,6 +94,40 @@ def delaunay_solid_spec(n_points=400, seed=5, solid_method=2):
     return ops
 
 
+def kitchen_sink_spec():
+    """One model with EVERY particle constraint type, so that colour groups mix types (a colour becomes
+    several (colour, type) batches / tile steps): a cloth with FEM-triangle + distance + dihedral + PBD
+    isometric bending, a second cloth with strain-triangle + XPBD distance + XPBD bending, a tet bar with
+    FEM + volume + distance, a second bar with XPBD FEM + XPBD volume + strain + shape matching, plus
+    extra XPBD distance constraints stitching the two cloths together."""
+    ops = []
+    R = rot_x_half_pi()
+    ops.append(("tri", 14, 12, (0.0, 2.0, 0.0), R, (4.0, 3.0)))
+    ops.append(("tri", 10, 11, (0.5, 2.6, 0.2), R, (3.0, 3.0)))
+    ops.append(("tet", 7, 4, 3, (5.0, 0.0, 0.0), None, (3.0, 1.0, 0.8)))
+    ops.append(("tet", 5, 3, 3, (5.0, 2.0, 0.0), None, (2.0, 0.8, 0.8)))
+    n0, n1 = 14 * 12, 10 * 11
+    ops += [("mass", 0, 0.0), ("mass", 13, 0.0), ("mass", n0, 0.0)]
+    for j in range(4 * 3):
+        ops.append(("mass", n0 + n1 + j, 0.0))
+    ops.append(("cloth", 0, 2, 1.0, 1.0, 1.0, 1.0, 0.3, 0.3, False, False))      # FEM triangle
+    ops.append(("cloth", 0, 1, 0.8, 1.0, 1.0, 1.0, 0.3, 0.3, False, False))      # distance
+    ops.append(("bending", 0, 1, 0.02))                                          # dihedral
+    ops.append(("bending", 0, 2, 0.01))                                          # isometric bending
+    ops.append(("cloth", 1, 3, 1.0, 1.0, 1.0, 1.0, 0.3, 0.3, True, False))       # strain triangle
+    ops.append(("cloth", 1, 4, 50000.0, 1.0, 1.0, 1.0, 0.3, 0.3, False, False))  # XPBD distance
+    ops.append(("bending", 1, 3, 50.0))                                          # XPBD isometric bending
+    ops.append(("solid", 0, 2, 1.0, 0.3, 1.0, False, False))                     # FEM tet
+    ops.append(("solid", 0, 1, 0.9, 0.3, 0.7, False, False))                     # distance + volume
+    ops.append(("solid", 1, 3, 100000.0, 0.3, 1.0, False, False))                # XPBD FEM tet
+    ops.append(("solid", 1, 6, 50000.0, 0.3, 50000.0, False, False))             # XPBD distance + volume
+    ops.append(("solid", 1, 4, 1.0, 0.3, 1.0, False, True))                      # strain tet
+    ops.append(("solid", 1, 5, 0.5, 0.3, 1.0, False, False))                     # shape matching
+    for k in range(8):
+        ops.append(("constraint", "distance_xpbd", [20 + 14 * (k % 3) + k, n0 + 10 * (k % 4) + k], 2000.0))
+    return ops
+
+
 _CONSTRAINT_ADD = {
     "distance": "addDistanceConstraint", "distance_xpbd": "addDistanceConstraint_XPBD",
     "dihedral": "addDihedralConstraint", "isometric_bending": "addIsometricBendingConstraint",
