@@ -385,57 +385,60 @@ __device__ constexpr bool kHasLambda[PBDX_NUM_CONSTRAINT_TYPES] = { false, true,
 // A record keeps exactly what came back from memory (packed 16-bit indices, raw multiplier): no
 // instruction may touch a prefetched value before its slot is projected, otherwise the compiler
 // has to drain the whole prefetch queue (s_waitcnt vmcnt(0)) at that instruction.
-template <int TYPE> struct Rec
+// Only the STREAMED parameters of the layout are kept (plane order); scalars of the compact layout are
+// read from the view at use (loop-invariant for the compiler: e.g. the XPBD compliance 1/(k dt^2) is
+// hoisted out of the slot loop), mirrored Q entries come from their upper-triangle twin.
+template <int TYPE, bool COMPACT> struct Rec
 {
 	// homogeneous raw dwords exactly as they came back from memory:
-	// [0],[1] packed 16-bit indices, [2] multiplier, [3 + k] parameter k
-	uint32_t w[3 + kParamCount[TYPE]];
-	__device__ __forceinline__ float par(int k) const { return __builtin_bit_cast(float, w[3 + k]); }
+	// [0],[1] packed 16-bit indices, [2] multiplier, [3 + p] streamed parameter plane p
+	uint32_t w[3 + num_planes(TYPE, COMPACT)];
+	__device__ __forceinline__ float plane(int p) const { return __builtin_bit_cast(float, w[3 + p]); }
 	__device__ __forceinline__ float lambda() const { return __builtin_bit_cast(float, w[2]); }
 };
 
-template <int TYPE, class A> struct RecAccess
+template <int TYPE, bool COMPACT, class A> struct RecAccess
 {
 	const A &base;
-	const Rec<TYPE> &r;
+	const Rec<TYPE, COMPACT> &r;
 	int first_iter;
 	__device__ __forceinline__ uint2 idx2(uint32_t) const { return make_uint2(r.w[0] & 0xffffu, r.w[0] >> 16); }
 	__device__ __forceinline__ uint4 idx4(uint32_t) const { return make_uint4(r.w[0] & 0xffffu, r.w[0] >> 16, r.w[1] & 0xffffu, r.w[1] >> 16); }
 	__device__ __forceinline__ float4 ld(uint32_t h) const { return base.ld(h); }
 	__device__ __forceinline__ void st(uint32_t h, float4 v) const { base.st(h, v); }
-	__device__ __forceinline__ float p(int k, uint32_t) const { return r.par(k); }
-	__device__ __forceinline__ bool sym() const { return false; }      // the record holds the full matrix
+	__device__ __forceinline__ float p(int k, uint32_t) const
+	{
+		if (is_scalar_param(TYPE, COMPACT, k)) return base.view.u[k];
+		if (is_mirrored_q(TYPE, COMPACT, k))
+		{
+			const int c = (k - 1) / 4, rr = (k - 1) % 4;            // Q(rr, c) with rr > c  ->  Q(c, rr)
+			return r.plane(kPlanes.plane[1][TYPE][1 + rr * 4 + c]);
+		}
+		return r.plane(kPlanes.plane[COMPACT ? 1 : 0][TYPE][k]);
+	}
+	__device__ __forceinline__ bool sym() const { return false; }      // p() resolves the mirrored entries itself
 	__device__ __forceinline__ float lam_load(uint32_t) const { return r.lambda(); }
 	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { base.lam_store(i, v); }
 };
 
 // only for TileAccess (packed 16-bit indices)
-template <int TYPE, class A> __device__ __forceinline__ void load_rec(const A &a, uint32_t i, Rec<TYPE> &r)
+template <int TYPE, bool COMPACT, class A> __device__ __forceinline__ void load_rec(const A &a, uint32_t i, Rec<TYPE, COMPACT> &r)
 {
 	if constexpr (kTwoBodies[TYPE]) { r.w[0] = a.idx_raw1(i); r.w[1] = 0u; }
 	else { const uint2 v = a.idx_raw2(i); r.w[0] = v.x; r.w[1] = v.y; }
-	if constexpr (TYPE == PBDX_ISOMETRIC_BENDING || TYPE == PBDX_ISOMETRIC_BENDING_XPBD)
-	{
-		r.w[3] = __builtin_bit_cast(uint32_t, a.p(0, i));
-		QFull q;
-		load_q(a, i, q);
 #pragma unroll
-		for (int k = 0; k < 16; k++) r.w[4 + k] = __builtin_bit_cast(uint32_t, q.q[k]);
-	}
-	else
-	{
-#pragma unroll
-		for (int k = 0; k < kParamCount[TYPE]; k++) r.w[3 + k] = __builtin_bit_cast(uint32_t, a.p(k, i));
-	}
+	for (int k = 0; k < kParamCount[TYPE]; k++)
+		if (param_streams(TYPE, COMPACT, k))
+			r.w[3 + kPlanes.plane[COMPACT ? 1 : 0][TYPE][k]] = __builtin_bit_cast(uint32_t, a.p(k, i));
 	r.w[2] = 0u;
 	// unconditional load (the stream always exists; iteration 0 ignores the value): branch-free prefetch
 	if constexpr (kHasLambda[TYPE]) r.w[2] = __builtin_bit_cast(uint32_t, a.lam_load(i));
 }
 
-template <int TYPE, class A> __device__ __forceinline__ void exec_rec(const A &a, const Rec<TYPE> &r, uint32_t i, float dt, int first_iter)
+template <int TYPE, bool COMPACT, class A> __device__ __forceinline__ void exec_rec(const A &a, const Rec<TYPE, COMPACT> &r, uint32_t i, float dt, int first_iter)
 {
-	const RecAccess<TYPE, A> ra = { a, r, first_iter };
-	Project<TYPE, RecAccess<TYPE, A>>::run(ra, i, dt, first_iter);
+	const RecAccess<TYPE, COMPACT, A> ra = { a, r, first_iter };
+	Project<TYPE, RecAccess<TYPE, COMPACT, A>>::run(ra, i, dt, first_iter);
 }
 
 // ---- two records of the same colour step, one lane (pbdx_pair.h) -------------------------------------
@@ -445,10 +448,11 @@ template <int TYPE, class A> __device__ __forceinline__ void exec_rec(const A &a
 #endif
 template <int TYPE> struct HasPair { static constexpr bool value = (TYPE == PBDX_DISTANCE_XPBD || (PBDX_PAIR_BENDING && TYPE == PBDX_ISOMETRIC_BENDING_XPBD)); };
 
-template <int TYPE, class A>
-__device__ __forceinline__ void exec_rec2(const A &a, const Rec<TYPE> &r0, const Rec<TYPE> &r1, uint32_t q0, uint32_t q1,
+template <int TYPE, bool COMPACT, class A>
+__device__ __forceinline__ void exec_rec2(const A &a, const Rec<TYPE, COMPACT> &r0, const Rec<TYPE, COMPACT> &r1, uint32_t q0, uint32_t q1,
 	bool valid0, bool valid1, float dt, int first_iter)
 {
+	const RecAccess<TYPE, COMPACT, A> ra0 = { a, r0, first_iter }, ra1 = { a, r1, first_iter };
 	if constexpr (TYPE == PBDX_DISTANCE_XPBD)
 	{
 		const uint32_t a0 = r0.w[0] & 0xffffu, b0 = r0.w[0] >> 16, a1 = r1.w[0] & 0xffffu, b1 = r1.w[0] >> 16;
@@ -457,7 +461,7 @@ __device__ __forceinline__ void exec_rec2(const A &a, const Rec<TYPE> &r0, const
 		const f2 w0 = mk2(A0.w, A1.w), w1 = mk2(B0.w, B1.w);
 		f2 lambda = first_iter ? splat(0.0f) : mk2(r0.lambda(), r1.lambda());
 		V3P c0, c1;
-		solve_distance_xpbd2(p0, w0, p1, w1, mk2(r0.par(0), r1.par(0)), mk2(r0.par(1), r1.par(1)), dt, lambda, c0, c1);
+		solve_distance_xpbd2(p0, w0, p1, w1, mk2(ra0.p(0, 0), ra1.p(0, 0)), mk2(ra0.p(1, 0), ra1.p(1, 0)), dt, lambda, c0, c1);
 		if (valid0)
 		{
 			apply(a, a0, lane0(p0), lane0(c0), A0.w); apply(a, b0, lane0(p1), lane0(c1), B0.w);
@@ -485,9 +489,9 @@ __device__ __forceinline__ void exec_rec2(const A &a, const Rec<TYPE> &r0, const
 		}
 		f2 q[16];
 #pragma unroll
-		for (int k = 0; k < 16; k++) q[k] = mk2(r0.par(1 + k), r1.par(1 + k));
+		for (int k = 0; k < 16; k++) q[k] = mk2(ra0.p(1 + k, 0), ra1.p(1 + k, 0));
 		f2 lambda = first_iter ? splat(0.0f) : mk2(r0.lambda(), r1.lambda());
-		const B2 ok = solve_isometric_bending_xpbd2(p, w, q, mk2(r0.par(0), r1.par(0)), dt, lambda, c);
+		const B2 ok = solve_isometric_bending_xpbd2(p, w, q, mk2(ra0.p(0, 0), ra1.p(0, 0)), dt, lambda, c);
 		if (valid0)
 		{
 			if (ok.a)
@@ -509,8 +513,8 @@ __device__ __forceinline__ void exec_rec2(const A &a, const Rec<TYPE> &r0, const
 	}
 	else
 	{
-		if (valid0) exec_rec<TYPE>(a, r0, q0, dt, first_iter);
-		if (valid1) exec_rec<TYPE>(a, r1, q1, dt, first_iter);
+		if (valid0) exec_rec<TYPE, COMPACT>(a, r0, q0, dt, first_iter);
+		if (valid1) exec_rec<TYPE, COMPACT>(a, r1, q1, dt, first_iter);
 	}
 }
 

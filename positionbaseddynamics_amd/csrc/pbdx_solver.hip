@@ -190,11 +190,11 @@ __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStre
 	ld.start(lsteps, s0, s_end);
 	ex = ld;
 	// the ring lives in named records (not an array): keeps every record in registers
-	Rec<TYPE> r0, r1, r2, r3;
-	auto fetch = [&](Rec<TYPE> &dst)
+	Rec<TYPE, COMPACT> r0, r1, r2, r3;
+	auto fetch = [&](Rec<TYPE, COMPACT> &dst)
 	{
 		const Acc acc = { lpos, str, ld.st.idx_off * 2u, ld.st.par_off * 4u, ld.st.par_stride * 4u, ld.st.lam_off * 4u, a.views[TYPE] };
-		load_rec<TYPE>(acc, ld.slot_clamped(), dst);
+		load_rec<TYPE, COMPACT>(acc, ld.slot_clamped(), dst);
 		ld.next(lsteps);
 	};
 	fetch(r0); fetch(r1);
@@ -205,7 +205,7 @@ __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStre
 	// Two consecutive chunks of the SAME step are projected jointly, one slot of each per lane, with
 	// packed arithmetic (pbdx_pair.h); the second sub-iteration then only fetches.
 	bool paired_prev = false;
-	auto sub = [&](Rec<TYPE> &cur, Rec<TYPE> &nxt)
+	auto sub = [&](Rec<TYPE, COMPACT> &cur, Rec<TYPE, COMPACT> &nxt)
 	{
 		if (ex.valid && !paired_prev)
 		{
@@ -214,12 +214,12 @@ __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStre
 			if (PAIRS && HasPair<TYPE>::value && !ex.last_of_step())
 			{
 				const uint32_t q1 = q + BLOCK;
-				exec_rec2<TYPE>(acc, cur, nxt, q, q1, q < ex.st.count, q1 < ex.st.count, a.dt, a.first_iter);
+				exec_rec2<TYPE, COMPACT>(acc, cur, nxt, q, q1, q < ex.st.count, q1 < ex.st.count, a.dt, a.first_iter);
 				ex.next(lsteps);            // consumes the partner chunk as well
 				paired_prev = true;
 			}
 			else if (q < ex.st.count)
-				exec_rec<TYPE>(acc, cur, q, a.dt, a.first_iter);
+				exec_rec<TYPE, COMPACT>(acc, cur, q, a.dt, a.first_iter);
 			if (ex.last_of_step())
 			{
 				if (ex.st.barrier) __syncthreads();
