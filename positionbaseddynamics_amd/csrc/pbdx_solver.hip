@@ -465,7 +465,7 @@ struct Batch
 	uint32_t par_stride = 0;
 	TypeView view;
 	std::vector<uint32_t> h_idx;    // kept for validate_schedule and the planner
-	std::vector<float> h_params;    // kept until the fused plan is built
+	std::vector<float> h_params;    // host image of the parameter records (planner, lazy device arrays)
 };
 
 struct DeviceSegment
@@ -652,7 +652,6 @@ int ensure_plan(pbdx_solver *s)
 	{
 		const Batch &b = s->batches[s->order[oi]];
 		if (oi && b.group != s->batches[s->order[oi - 1]].group) colour++;
-		if (b.h_params.empty() && type_info(b.type)->param_stride) { s->plan_why = "host parameters released"; return PBDX_OK; }
 		pbs.push_back({ b.type, colour, b.count, b.h_idx.data(), b.h_params.data() });
 	}
 	PlanOptions opt;
@@ -666,26 +665,27 @@ int ensure_plan(pbdx_solver *s)
 	opt.max_segment_colours = s->max_segment_colours;
 	if (!build_fused_plan(s->n, s->h_x.data(), pbs, opt, s->plan, s->plan_why))
 		return PBDX_OK;
-	// per-segment device image
+	// per-segment device image (pushed first, so that free_plan() releases a partially built one)
 	for (const FusedSegment &seg : s->plan.segs)
 	{
-		DeviceSegment d;
+		s->dsegs.emplace_back();
+		DeviceSegment &d = s->dsegs.back();
 		int r = upload(&d.d_tiles, seg.tiles);
 		if (!r) r = upload(&d.d_steps, seg.steps);
 		if (!r) r = upload(&d.d_idx, seg.idx);
 		if (!r) r = upload(&d.d_params, seg.params);
 		if (!r) r = upload(&d.d_gid, seg.gid);
+		if (!r && seg.lam_count)
+		{
+			hipError_t e = hipMalloc(&d.d_lambda, (size_t)seg.lam_count * sizeof(float));
+			if (e == hipSuccess) e = hipMemset(d.d_lambda, 0, (size_t)seg.lam_count * sizeof(float));
+			if (e != hipSuccess) { set_error("lambda stream allocation failed: %s", hipGetErrorString(e)); r = PBDX_ERR_HIP; }
+		}
 		if (r)
 		{
-			s->dsegs.push_back(d);
 			s->free_plan();
 			s->plan_built = true;
 			return r;
-		}
-		if (seg.lam_count)
-		{
-			HIPCHECK(hipMalloc(&d.d_lambda, (size_t)seg.lam_count * sizeof(float)));
-			HIPCHECK(hipMemset(d.d_lambda, 0, (size_t)seg.lam_count * sizeof(float)));
 		}
 		d.idx_bytes = (uint32_t)(seg.idx.size() * sizeof(uint16_t));
 		d.params_bytes = (uint32_t)(seg.params.size() * sizeof(float));
@@ -710,11 +710,59 @@ int ensure_plan(pbdx_solver *s)
 		d.block = block;
 		d.kernel = pick_fused_kernel(seg.type_mask, block, s->pairs != 0);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(d.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
-		s->dsegs.push_back(d);
 	}
-	// the planner's copies of the parameter records are no longer needed
-	for (Batch &b : s->batches) { std::vector<float>().swap(b.h_params); }
 	s->plan_ok = true;
+	return PBDX_OK;
+}
+
+// Device arrays of the per-colour schedule (B), created the first time that schedule actually runs.
+int ensure_device_batches(pbdx_solver *s)
+{
+	for (Batch &b : s->batches)
+	{
+		if (b.d_idx) continue;
+		const TypeInfo *ti = type_info(b.type);
+		const uint32_t nb = ti->num_bodies, np = ti->param_stride, count = b.count;
+		// indices: uint2 for 2-body, uint4 (padded) for 3- and 4-body constraints
+		const uint32_t iw = (nb == 2) ? 2 : 4;
+		std::vector<uint32_t> idx((size_t)count * iw, 0);
+		for (uint32_t i = 0; i < count; i++)
+			for (uint32_t k = 0; k < nb; k++) idx[(size_t)i * iw + k] = b.h_idx[(size_t)i * nb + k];
+		HIPCHECK(hipMalloc(&b.d_idx, idx.size() * sizeof(uint32_t)));
+		HIPCHECK(hipMemcpy(b.d_idx, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		// parameters: planar streams of the layout chosen for this batch (compact / full)
+		const bool compact = b.view.compact != 0;
+		if (num_planes(b.type, compact) && !b.d_params)
+		{
+			std::vector<float> planar((size_t)num_planes(b.type, compact) * b.par_stride, 0.0f);
+			for (uint32_t k = 0; k < np; k++)
+			{
+				if (!param_streams(b.type, compact, (int)k)) continue;
+				float *dst = &planar[(size_t)param_plane(b.type, compact, (int)k) * b.par_stride];
+				for (uint32_t i = 0; i < count; i++) dst[i] = b.h_params[(size_t)i * np + k];
+			}
+			HIPCHECK(hipMalloc(&b.d_params, planar.size() * sizeof(float)));
+			HIPCHECK(hipMemcpy(b.d_params, planar.data(), planar.size() * sizeof(float), hipMemcpyHostToDevice));
+		}
+		if (ti->xpbd && !b.d_lambda)
+		{
+			HIPCHECK(hipMalloc(&b.d_lambda, (size_t)count * sizeof(float)));
+			HIPCHECK(hipMemset(b.d_lambda, 0, (size_t)count * sizeof(float)));
+		}
+	}
+	return PBDX_OK;
+}
+
+// trace buffers are allocated before anything is enqueued (no hipMalloc inside a stream capture)
+int ensure_trace(pbdx_solver *s)
+{
+	if (!s->trace) return PBDX_OK;
+	for (DeviceSegment &d : s->dsegs)
+		if (!d.d_trace)
+		{
+			HIPCHECK(hipMalloc(&d.d_trace, (size_t)d.num_tiles * kTraceStride * sizeof(unsigned long long)));
+			HIPCHECK(hipMemset(d.d_trace, 0, (size_t)d.num_tiles * kTraceStride * sizeof(unsigned long long)));
+		}
 	return PBDX_OK;
 }
 
@@ -741,11 +789,6 @@ int launch_batch(pbdx_solver *s, const Batch &b, float dt, int first_iter)
 int launch_segment(pbdx_solver *s, size_t si, int src, float dt, int first_iter)
 {
 	DeviceSegment &d = s->dsegs[si];
-	if (s->trace && !d.d_trace)
-	{
-		HIPCHECK(hipMalloc(&d.d_trace, (size_t)d.num_tiles * kTraceStride * sizeof(unsigned long long)));
-		HIPCHECK(hipMemset(d.d_trace, 0, (size_t)d.num_tiles * kTraceStride * sizeof(unsigned long long)));
-	}
 	FusedArgs a;
 	a.pos_in = s->d_pos[src];
 	a.pos_out = s->d_pos[src ^ 1];
@@ -1057,43 +1100,15 @@ int pbdx_solver_add_batch(pbdx_solver *s, uint32_t group, int type, uint32_t cou
 		if (indices[i] >= s->n) { set_error("add_batch: particle index %u out of range (%u particles uploaded)", indices[i], s->n); return PBDX_ERR_INVALID; }
 	HIPCHECK(hipSetDevice(s->device));
 
-	Batch b;
-	b.type = type; b.group = group; b.count = count; b.seq = (uint32_t)s->batches.size();
+	// host image only: the device arrays of schedule (B) are created on first use (ensure_device_batches);
+	// the fused schedule (A) never needs them
+	s->batches.emplace_back();
+	Batch &b = s->batches.back();
+	b.type = type; b.group = group; b.count = count; b.seq = (uint32_t)s->batches.size() - 1;
 	b.h_idx.assign(indices, indices + (size_t)count * nb);
 	b.h_params.assign(params, params + (size_t)count * ti->param_stride);
-
-	// indices: uint2 for 2-body, uint4 (padded) for 3- and 4-body constraints
-	const uint32_t iw = (nb == 2) ? 2 : 4;
-	std::vector<uint32_t> idx((size_t)count * iw, 0);
-	for (uint32_t i = 0; i < count; i++)
-		for (uint32_t k = 0; k < nb; k++) idx[(size_t)i * iw + k] = indices[(size_t)i * nb + k];
-	HIPCHECK(hipMalloc(&b.d_idx, idx.size() * sizeof(uint32_t)));
-	HIPCHECK(hipMemcpy(b.d_idx, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-
-	// parameters: detect batch-uniform ones (and symmetric Q), lay the rest out planar
-	const uint32_t np = ti->param_stride;
-	const uint32_t stride = (count + 3u) & ~3u;
 	compute_type_view(type, { { params, count } }, b.view);
-	b.par_stride = stride;
-	const bool compact = b.view.compact != 0;
-	if (num_planes(type, compact))
-	{
-		std::vector<float> planar((size_t)num_planes(type, compact) * stride, 0.0f);
-		for (uint32_t k = 0; k < np; k++)
-		{
-			if (!param_streams(type, compact, (int)k)) continue;
-			float *dst = &planar[(size_t)param_plane(type, compact, (int)k) * stride];
-			for (uint32_t i = 0; i < count; i++) dst[i] = params[(size_t)i * np + k];
-		}
-		HIPCHECK(hipMalloc(&b.d_params, planar.size() * sizeof(float)));
-		HIPCHECK(hipMemcpy(b.d_params, planar.data(), planar.size() * sizeof(float), hipMemcpyHostToDevice));
-	}
-	if (ti->xpbd)
-	{
-		HIPCHECK(hipMalloc(&b.d_lambda, (size_t)count * sizeof(float)));
-		HIPCHECK(hipMemset(b.d_lambda, 0, (size_t)count * sizeof(float)));
-	}
-	s->batches.push_back(std::move(b));
+	b.par_stride = (count + 3u) & ~3u;
 	return PBDX_OK;
 }
 
@@ -1158,10 +1173,6 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 	s->drop_graph();
 	if (replan && s->plan_built)
 	{
-		// the planner needs the host parameter records, which are released after a successful plan
-		bool have = true;
-		for (const Batch &b : s->batches) if (b.h_params.empty() && type_info(b.type)->param_stride) have = false;
-		if (!have) { set_error("option %d must be set before the first step of a schedule", option); return PBDX_ERR_INVALID; }
 		HIPCHECK(hipSetDevice(s->device));
 		HIPCHECK(hipStreamSynchronize(s->stream));
 		s->free_plan();
@@ -1183,6 +1194,8 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	if (s->schedule_open) { set_error("step: schedule still open"); return PBDX_ERR_INVALID; }
 	HIPCHECK(hipSetDevice(s->device));
 	int rp = ensure_plan(s);
+	if (!rp) rp = ensure_trace(s);
+	if (!rp && !s->fused_active()) rp = ensure_device_batches(s);
 	if (rp) return rp;
 	const float hs = h / (float)sub_steps;                  // TimeStepController.cpp:91
 	const float inv_h = (float)(1.0 / (double)hs);          // TimeIntegration.cpp:50 evaluates 1.0/h in double
@@ -1262,6 +1275,8 @@ int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
 	if (!s || s->schedule_open) { set_error("project: bad state"); return PBDX_ERR_INVALID; }
 	HIPCHECK(hipSetDevice(s->device));
 	int r = ensure_plan(s);
+	if (!r) r = ensure_trace(s);
+	if (!r && !s->fused_active()) r = ensure_device_batches(s);
 	if (r) return r;
 	const int start = (int)sweep_flips(s, iterations);
 	if (start)
@@ -1338,11 +1353,12 @@ int pbdx_solver_get_lambdas(pbdx_solver *s, uint32_t batch_index, uint32_t count
 {
 	if (!s || !out || batch_index >= s->batches.size()) { set_error("get_lambdas: bad batch"); return PBDX_ERR_INVALID; }
 	const Batch &b = s->batches[batch_index];
-	if (!b.d_lambda || count != b.count) { set_error("get_lambdas: batch has no multipliers or count mismatch"); return PBDX_ERR_INVALID; }
+	if (!type_info(b.type)->xpbd || count != b.count) { set_error("get_lambdas: batch has no multipliers or count mismatch"); return PBDX_ERR_INVALID; }
 	HIPCHECK(hipSetDevice(s->device));
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	if (!s->fused_active())
 	{
+		if (!b.d_lambda) { memset(out, 0, (size_t)count * sizeof(float)); return PBDX_OK; }     // schedule never ran
 		HIPCHECK(hipMemcpy(out, b.d_lambda, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
 		return PBDX_OK;
 	}
