@@ -72,12 +72,13 @@ template <int TYPE, bool COMPACT> struct TileAccess
 {
 	float4 *pos;               // LDS
 	const TileStreams &str;
-	uint32_t idx_soff;         // byte offsets of this (tile, colour, type) run inside the streams
+	uint32_t idx_soff;         // BYTE offsets of the current chunk inside the streams (SGPRs)
 	uint32_t par_soff;
-	uint32_t par_stride_b;     // bytes between parameter planes
 	uint32_t lam_soff;
+	uint32_t v_par;            // per-lane byte offset inside a chunk's parameter block: wave * nplanes * 256 + lane * 4
 	const TypeView &view;
 
+	// `i` = lane's slot inside the chunk (threadIdx.x): the per-lane offsets are the same for every chunk
 	__device__ __forceinline__ uint32_t idx_raw1(uint32_t i) const { return __builtin_amdgcn_raw_buffer_load_b32(str.idx, (int)(i * 4u), (int)idx_soff, 0); }
 	__device__ __forceinline__ uint2 idx_raw2(uint32_t i) const
 	{
@@ -97,11 +98,12 @@ template <int TYPE, bool COMPACT> struct TileAccess
 	}
 	__device__ __forceinline__ float4 ld(uint32_t h) const { return pos[h]; }
 	__device__ __forceinline__ void st(uint32_t h, float4 v) const { pos[h] = v; }
-	__device__ __forceinline__ float p(int k, uint32_t i) const
+	__device__ __forceinline__ float p(int k, uint32_t) const
 	{
 		if (is_scalar_param(TYPE, COMPACT, k)) return view.u[k];
 		const uint32_t plane = (uint32_t)kPlanes.plane[COMPACT ? 1 : 0][TYPE][k];
-		return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.par, (int)(i * 4u), (int)(par_soff + plane * par_stride_b), 0));
+		// plane * 256 is a compile-time constant: folded into the instruction's immediate offset
+		return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.par, (int)(v_par + plane * 256u), (int)par_soff, 0));
 	}
 	__device__ __forceinline__ bool sym() const { return COMPACT; }
 	__device__ __forceinline__ float lam_load(uint32_t i) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.lam, (int)(i * 4u), (int)lam_soff, 0)); }
@@ -449,14 +451,16 @@ template <int TYPE, bool COMPACT, class A> __device__ __forceinline__ void exec_
 template <int TYPE> struct HasPair { static constexpr bool value = (TYPE == PBDX_DISTANCE_XPBD || (PBDX_PAIR_BENDING && TYPE == PBDX_ISOMETRIC_BENDING_XPBD)); };
 
 template <int TYPE, bool COMPACT, class A>
-__device__ __forceinline__ void exec_rec2(const A &a, const Rec<TYPE, COMPACT> &r0, const Rec<TYPE, COMPACT> &r1, uint32_t q0, uint32_t q1,
+__device__ __forceinline__ void exec_rec2(const A &a, const A &a1, const Rec<TYPE, COMPACT> &r0, const Rec<TYPE, COMPACT> &r1, uint32_t q,
 	bool valid0, bool valid1, float dt, int first_iter)
 {
-	const RecAccess<TYPE, COMPACT, A> ra0 = { a, r0, first_iter }, ra1 = { a, r1, first_iter };
+	// a / a1: accessors of the two chunks (different stream offsets, same lane slot q)
+	const uint32_t q0 = q, q1 = q;
+	const RecAccess<TYPE, COMPACT, A> ra0 = { a, r0, first_iter }, ra1 = { a1, r1, first_iter };
 	if constexpr (TYPE == PBDX_DISTANCE_XPBD)
 	{
-		const uint32_t a0 = r0.w[0] & 0xffffu, b0 = r0.w[0] >> 16, a1 = r1.w[0] & 0xffffu, b1 = r1.w[0] >> 16;
-		const float4 A0 = a.ld(a0), B0 = a.ld(b0), A1 = a.ld(a1), B1 = a.ld(b1);
+		const uint32_t a0 = r0.w[0] & 0xffffu, b0 = r0.w[0] >> 16, a1i = r1.w[0] & 0xffffu, b1 = r1.w[0] >> 16;
+		const float4 A0 = a.ld(a0), B0 = a.ld(b0), A1 = a.ld(a1i), B1 = a.ld(b1);
 		const V3P p0 = mkp(mk(A0.x, A0.y, A0.z), mk(A1.x, A1.y, A1.z)), p1 = mkp(mk(B0.x, B0.y, B0.z), mk(B1.x, B1.y, B1.z));
 		const f2 w0 = mk2(A0.w, A1.w), w1 = mk2(B0.w, B1.w);
 		f2 lambda = first_iter ? splat(0.0f) : mk2(r0.lambda(), r1.lambda());
@@ -469,8 +473,8 @@ __device__ __forceinline__ void exec_rec2(const A &a, const Rec<TYPE, COMPACT> &
 		}
 		if (valid1)
 		{
-			apply(a, a1, lane1(p0), lane1(c0), A1.w); apply(a, b1, lane1(p1), lane1(c1), B1.w);
-			a.lam_store(q1, lambda.y);
+			apply(a, a1i, lane1(p0), lane1(c0), A1.w); apply(a, b1, lane1(p1), lane1(c1), B1.w);
+			a1.lam_store(q1, lambda.y);
 		}
 	}
 	else if constexpr (TYPE == PBDX_ISOMETRIC_BENDING_XPBD)
@@ -508,13 +512,13 @@ __device__ __forceinline__ void exec_rec2(const A &a, const Rec<TYPE, COMPACT> &
 #pragma unroll
 				for (int k = 0; k < 4; k++) apply(a, i1[k], lane1(p[k]), lane1(c[k]), P1[k].w);
 			}
-			a.lam_store(q1, lambda.y);
+			a1.lam_store(q1, lambda.y);
 		}
 	}
 	else
 	{
 		if (valid0) exec_rec<TYPE, COMPACT>(a, r0, q0, dt, first_iter);
-		if (valid1) exec_rec<TYPE, COMPACT>(a, r1, q1, dt, first_iter);
+		if (valid1) exec_rec<TYPE, COMPACT>(a1, r1, q1, dt, first_iter);
 	}
 }
 

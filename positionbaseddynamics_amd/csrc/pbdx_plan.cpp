@@ -406,13 +406,15 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 					st.count = (uint32_t)(e - a);
 					st.idx_off = (uint32_t)o.idx.size();
 					st.par_off = (uint32_t)o.params.size();
-					st.par_stride = round_up(st.count, 4);
+					st.par_stride = 0;
+					const uint32_t np_stream = (uint32_t)num_planes(pb.type, v.compact != 0);
+					const uint32_t groups64 = (st.count + 63) / 64;
 					st.lam_off = o.lam_count;
 					st.barrier = (e == bk.size()) ? 1u : 0u;
 					st.cid_off = (uint32_t)o.slot_cid.size();
 					const uint32_t iw = ti->num_bodies == 2 ? 2 : 4;
 					o.idx.resize(o.idx.size() + round_up(st.count * iw, 8), 0);
-					o.params.resize(o.params.size() + (size_t)num_planes(pb.type, v.compact != 0) * st.par_stride, 0.0f);
+					o.params.resize(o.params.size() + (size_t)groups64 * np_stream * 64, 0.0f);
 					for (size_t q = a; q < e; q++)
 					{
 						const uint32_t cid = bk[q];
@@ -422,7 +424,8 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 							o.idx[st.idx_off + slot * iw + j] = (uint16_t)s.local_of[pb.idx[(size_t)i * ti->num_bodies + j]];
 						for (uint32_t p = 0; p < ti->param_stride; p++)
 							if (param_streams(pb.type, v.compact != 0, (int)p))
-								o.params[st.par_off + (size_t)param_plane(pb.type, v.compact != 0, (int)p) * st.par_stride + slot] = pb.params[(size_t)i * ti->param_stride + p];
+								o.params[st.par_off + (size_t)(slot / 64) * (np_stream * 64) + (size_t)param_plane(pb.type, v.compact != 0, (int)p) * 64 + (slot % 64)] =
+									pb.params[(size_t)i * ti->param_stride + p];
 						o.slot_cid.push_back(cid);
 					}
 					if (ti->xpbd) o.lam_count += round_up(st.count, 4);

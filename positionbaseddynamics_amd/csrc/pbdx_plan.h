@@ -111,8 +111,10 @@ struct FusedStep      // one (colour, type) run of a tile; 32 bytes, read with s
 	uint32_t type;
 	uint32_t count;
 	uint32_t idx_off;     // into the segment's uint16 index stream (2 or 4 entries per slot)
-	uint32_t par_off;     // into the segment's float parameter stream (planar: plane p at par_off + p*par_stride)
-	uint32_t par_stride;
+	uint32_t par_off;     // into the segment's float parameter stream; "wave-tiled" layout: slot q, plane p at
+	                      //   par_off + (q / 64) * (nplanes * 64) + p * 64 + (q % 64)
+	                      // i.e. one wave reads 256 contiguous bytes per plane and the plane offset is an immediate
+	uint32_t par_stride;  // unused (kept for layout stability)
 	uint32_t lam_off;     // into the segment's lambda stream (XPBD types)
 	uint32_t barrier;     // workgroup barrier after this step (last step of a colour)
 	uint32_t cid_off;     // host only: into slot_cid
@@ -125,7 +127,17 @@ struct FusedTile      // 32 bytes
 	uint32_t n_owned;
 	uint32_t gid_off;     // into the segment's global-id stream
 	uint32_t slots;       // constraints executed by this tile in this segment
-	uint32_t pad0, pad1;
+	uint32_t chunk_begin, chunk_end;   // filled by the engine once the workgroup size is chosen (FusedChunk list)
+};
+
+// One workgroup-wide pass over (part of) a step: lanes [0, valid) project slot k*BLOCK + lane of the step.
+// 16 bytes, staged in LDS, read as scalars.
+struct FusedChunk
+{
+	uint32_t info;        // type (bits 0-7) | barrier after this chunk (bit 8) | last chunk of its step (bit 9) | valid lanes (bits 16-31)
+	uint32_t idx_boff;    // BYTE offsets of the chunk's first slot in the three streams
+	uint32_t par_boff;
+	uint32_t lam_boff;
 };
 
 struct FusedSegment

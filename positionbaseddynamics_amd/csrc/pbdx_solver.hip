@@ -101,7 +101,7 @@ struct FusedArgs
 	const float4 *pos_in;
 	float4 *pos_out;
 	const FusedTile *tiles;
-	const FusedStep *steps;
+	const FusedChunk *chunks;
 	const uint16_t *idx;
 	const float *params;
 	float *lambda;
@@ -118,13 +118,21 @@ struct FusedArgs
 };
 constexpr uint32_t kTraceStride = 80;
 
-// ---- software pipeline over the steps of a tile ---------------------------------------------------
-// A tile's steps are walked in "chunks" of BLOCK slots (slot = threadIdx.x + k * BLOCK).  The record
-// of a slot (indices, parameters, multiplier) only depends on read-only streams, so it may be
-// fetched long before the positions it will be applied to are final: every thread keeps a ring of
-// D records and fetches the chunk D positions ahead -- across colour barriers -- while it projects
-// the current one.  This decouples the HBM latency of the streams from the barrier-synchronised
-// colour sweep.  The pipeline runs over maximal runs of steps of one constraint type.
+// ---- software pipeline over the chunks of a tile --------------------------------------------------
+// A tile's steps are expanded on the host into "chunks": one workgroup-wide pass in which lane l projects
+// slot k * BLOCK + l of a step (FusedChunk, pbdx_plan.h).  The record of a slot (indices, parameter
+// planes, multiplier) only depends on read-only streams, so it may be fetched long before the positions it
+// will be applied to are final: every thread keeps a ring of D records and fetches the chunk D positions
+// ahead -- across colour barriers -- while it projects the current one.  This decouples the HBM latency of
+// the streams from the barrier-synchronised colour sweep.  The pipeline runs over maximal runs of chunks of
+// one constraint type.
+//
+// Everything address-like is either a per-lane constant of the run (VGPR offsets: lane * 4 / * 8 and the
+// wave-tiled parameter offset) or a scalar of the chunk descriptor (SGPR stream offsets), and the plane
+// offset is an instruction immediate: a fetch costs no VALU and a handful of SALU instructions.  Loads are
+// unconditional (lanes beyond a chunk's valid count read neighbouring or out-of-range stream bytes, which the
+// buffer descriptor turns into zeros, and are never projected), which lets the compiler wait with an exact
+// s_waitcnt vmcnt(N) instead of draining every outstanding prefetch.
 #ifndef PBDX_DEPTH_SMALL
 #define PBDX_DEPTH_SMALL 4     // ring depth for 2-parameter records (distance, volume, dihedral)
 #endif
@@ -134,98 +142,77 @@ constexpr uint32_t kTraceStride = 80;
 template <int TYPE> struct Depth { static constexpr int value = kParamCount[TYPE] <= 2 ? PBDX_DEPTH_SMALL : PBDX_DEPTH_BIG; };
 static_assert((PBDX_DEPTH_SMALL == 2 || PBDX_DEPTH_SMALL == 4) && (PBDX_DEPTH_BIG == 2 || PBDX_DEPTH_BIG == 4), "ring depth must be 2 or 4");
 
-struct StepS { uint32_t type, count, idx_off, par_off, par_stride, lam_off, barrier; };
-
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// step descriptors are staged in LDS (uniform address -> broadcast read -> SGPRs)
-__device__ __forceinline__ StepS load_step(const uint4 *lsteps, uint32_t s)
+struct ChunkS { uint32_t info, idx_boff, par_boff, lam_boff; };
+// chunk descriptors are staged in LDS (uniform address -> broadcast read -> SGPRs)
+__device__ __forceinline__ ChunkS load_chunk(const uint4 *lchunks, uint32_t c)
 {
-	const uint4 a = lsteps[2 * s], b = lsteps[2 * s + 1];
-	StepS r;
-	r.type = rfl(a.x); r.count = rfl(a.y); r.idx_off = rfl(a.z); r.par_off = rfl(a.w);
-	r.par_stride = rfl(b.x); r.lam_off = rfl(b.y); r.barrier = rfl(b.z);
+	const uint4 v = lchunks[c];
+	ChunkS r;
+	r.info = rfl(v.x); r.idx_boff = rfl(v.y); r.par_boff = rfl(v.z); r.lam_boff = rfl(v.w);
 	return r;
 }
-
-// walks the chunks (step s, k-th group of BLOCK slots) of a run of steps of one type; once it has
-// run off the end it stays on the last chunk (valid == false), so that a prefetch issued from it is
-// a harmless re-load: the loads of the pipeline are unconditional, which lets the compiler wait
-// with an exact vmcnt(N) instead of draining every outstanding prefetch.
-template <int TYPE, int BLOCK> struct ChunkIt
-{
-	uint32_t s, k, s_end;
-	bool valid;
-	StepS st;
-	__device__ __forceinline__ void start(const uint4 *lsteps, uint32_t s0, uint32_t s_end_)
-	{
-		s = s0; k = 0; s_end = s_end_;
-		st = load_step(lsteps, s);
-		valid = true;
-	}
-	__device__ __forceinline__ bool last_of_step() const { return (k + 1) * BLOCK >= st.count; }
-	__device__ __forceinline__ void next(const uint4 *lsteps)
-	{
-		if (!valid) return;
-		if (!last_of_step()) { k++; return; }
-		if (s + 1 < s_end && rfl(lsteps[2 * (s + 1)].x) == (uint32_t)TYPE)
-		{
-			s++; k = 0;
-			st = load_step(lsteps, s);
-		}
-		else
-			valid = false;
-	}
-	// slot of this thread in the chunk, clamped into the step (clamped slots are fetched, never projected)
-	__device__ __forceinline__ uint32_t slot() const { return threadIdx.x + k * BLOCK; }
-	__device__ __forceinline__ uint32_t slot_clamped() const { const uint32_t q = slot(); return q < st.count ? q : st.count - 1; }
-};
+__device__ __forceinline__ uint32_t chunk_type(uint32_t info) { return info & 0xffu; }
+__device__ __forceinline__ uint32_t chunk_valid(uint32_t info) { return info >> 16; }
+__device__ __forceinline__ bool chunk_barrier(uint32_t info) { return (info >> 8) & 1u; }
+__device__ __forceinline__ bool chunk_last_of_step(uint32_t info) { return (info >> 9) & 1u; }
 
 template <int TYPE, bool COMPACT, int BLOCK, bool PAIRS>
-__device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStreams &str, const uint4 *lsteps, uint32_t s0, uint32_t s_end, float4 *lpos, unsigned long long *trace)
+__device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStreams &str, const uint4 *lchunks, uint32_t c0, uint32_t c_end,
+	float4 *lpos, unsigned long long *trace, uint32_t &step_counter)
 {
 	constexpr int D = Depth<TYPE>::value;
 	typedef TileAccess<TYPE, COMPACT> Acc;
-	ChunkIt<TYPE, BLOCK> ld, ex;
-	ld.start(lsteps, s0, s_end);
-	ex = ld;
+	// per-lane constants of the run
+	const uint32_t lane_slot = threadIdx.x;
+	const uint32_t v_par = (threadIdx.x >> 6) * (uint32_t)(num_planes(TYPE, COMPACT) * 256) + (threadIdx.x & 63u) * 4u;
+	// end of the run: first chunk of another type
+	uint32_t run_end = c0 + 1;
+	while (run_end < c_end && chunk_type(rfl(lchunks[run_end].x)) == (uint32_t)TYPE) run_end++;
+
+	uint32_t c_ld = c0, c_ex = c0;
 	// the ring lives in named records (not an array): keeps every record in registers
 	Rec<TYPE, COMPACT> r0, r1, r2, r3;
 	auto fetch = [&](Rec<TYPE, COMPACT> &dst)
 	{
-		const Acc acc = { lpos, str, ld.st.idx_off * 2u, ld.st.par_off * 4u, ld.st.par_stride * 4u, ld.st.lam_off * 4u, a.views[TYPE] };
-		load_rec<TYPE, COMPACT>(acc, ld.slot_clamped(), dst);
-		ld.next(lsteps);
+		// beyond the run the last chunk is fetched again (harmless): the fetch itself stays unconditional
+		const ChunkS ch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
+		const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, a.views[TYPE] };
+		load_rec<TYPE, COMPACT>(acc, lane_slot, dst);
+		c_ld++;
 	};
 	fetch(r0); fetch(r1);
 	if constexpr (D == 4) { fetch(r2); fetch(r3); }
-	// Every sub-iteration issues exactly one record fetch, whether or not a projection still happens
-	// in it (single loop exit at the bottom): the number of memory operations between a fetch and its
-	// use is then the same on every path, which is what lets the compiler wait with s_waitcnt vmcnt(N>0).
-	// Two consecutive chunks of the SAME step are projected jointly, one slot of each per lane, with
-	// packed arithmetic (pbdx_pair.h); the second sub-iteration then only fetches.
+	// Every sub-iteration issues exactly one record fetch, whether or not a projection still happens in it
+	// (single loop exit at the bottom): the number of memory operations between a fetch and its use is then
+	// the same on every path.  Two consecutive chunks of the SAME step may be projected jointly with packed
+	// arithmetic (PAIRS, pbdx_pair.h); the second sub-iteration then only fetches.
 	bool paired_prev = false;
 	auto sub = [&](Rec<TYPE, COMPACT> &cur, Rec<TYPE, COMPACT> &nxt)
 	{
-		if (ex.valid && !paired_prev)
+		if (c_ex < run_end && !paired_prev)
 		{
-			const Acc acc = { lpos, str, ex.st.idx_off * 2u, ex.st.par_off * 4u, ex.st.par_stride * 4u, ex.st.lam_off * 4u, a.views[TYPE] };
-			const uint32_t q = ex.slot();
-			if (PAIRS && HasPair<TYPE>::value && !ex.last_of_step())
+			ChunkS ch = load_chunk(lchunks, c_ex);
+			const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, a.views[TYPE] };
+			if (PAIRS && HasPair<TYPE>::value && !chunk_last_of_step(ch.info))
 			{
-				const uint32_t q1 = q + BLOCK;
-				exec_rec2<TYPE, COMPACT>(acc, cur, nxt, q, q1, q < ex.st.count, q1 < ex.st.count, a.dt, a.first_iter);
-				ex.next(lsteps);            // consumes the partner chunk as well
+				const ChunkS ch1 = load_chunk(lchunks, c_ex + 1);
+				const Acc acc1 = { lpos, str, ch1.idx_boff, ch1.par_boff, ch1.lam_boff, v_par, a.views[TYPE] };
+				exec_rec2<TYPE, COMPACT>(acc, acc1, cur, nxt, lane_slot, lane_slot < chunk_valid(ch.info), lane_slot < chunk_valid(ch1.info), a.dt, a.first_iter);
+				ch = ch1;
+				c_ex++;                     // consumes the partner chunk as well
 				paired_prev = true;
 			}
-			else if (q < ex.st.count)
-				exec_rec<TYPE, COMPACT>(acc, cur, q, a.dt, a.first_iter);
-			if (ex.last_of_step())
+			else if (lane_slot < chunk_valid(ch.info))
+				exec_rec<TYPE, COMPACT>(acc, cur, lane_slot, a.dt, a.first_iter);
+			if (chunk_last_of_step(ch.info))
 			{
-				if (ex.st.barrier) __syncthreads();
-				if (trace && threadIdx.x == 0 && ex.s + 2 < kTraceStride - 1) trace[2 + ex.s] = wall_clock64();
+				if (chunk_barrier(ch.info)) __syncthreads();
+				if (trace && threadIdx.x == 0 && step_counter + 2 < kTraceStride - 1) trace[2 + step_counter] = wall_clock64();
+				step_counter++;
 			}
-			ex.next(lsteps);
+			c_ex++;
 		}
 		else
 			paired_prev = false;
@@ -235,34 +222,36 @@ __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStre
 	{
 		if constexpr (D == 4) { sub(r0, r1); sub(r1, r2); sub(r2, r3); sub(r3, r0); }
 		else { sub(r0, r1); sub(r1, r0); }
-		if (!ex.valid) break;
+		if (c_ex >= run_end) break;
 	}
-	return ex.s + 1;
+	return run_end;
 }
 
 #define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) { \
-		s = a.views[T].compact ? run_typed<T, true, BLOCK, PAIRS>(a, str, lsteps, s, num_steps, lpos, trace) \
-		                       : run_typed<T, false, BLOCK, PAIRS>(a, str, lsteps, s, num_steps, lpos, trace); } \
-	else { s = num_steps; } break;
+		c = a.views[T].compact ? run_typed<T, true, BLOCK, PAIRS>(a, str, lchunks, c, num_chunks, lpos, trace, step_counter) \
+		                       : run_typed<T, false, BLOCK, PAIRS>(a, str, lchunks, c, num_chunks, lpos, trace, step_counter); } \
+	else { c = num_chunks; } break;
 
-// LDS: [ step descriptors of the tile: kMaxTileSteps x 32 B ][ positions: n_local x float4 ]
+// LDS: [ chunk descriptors of the tile: kMaxTileChunks x 16 B ][ positions: n_local x float4 ]
+constexpr uint32_t kMaxTileChunks = 256;
 constexpr uint32_t kMaxTileSteps = 64;
 
 template <uint32_t MASK, int BLOCK, bool PAIRS>
 __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 {
 	extern __shared__ uint4 lds_raw[];
-	uint4 *lsteps = lds_raw;
-	float4 *lpos = reinterpret_cast<float4 *>(lds_raw + 2 * kMaxTileSteps);
+	uint4 *lchunks = lds_raw;
+	float4 *lpos = reinterpret_cast<float4 *>(lds_raw + kMaxTileChunks);
 	const uint32_t tile_index = logical_block(a.num_tiles, a.xcd_remap);
 	const FusedTile t = a.tiles[tile_index];
 	unsigned long long *trace = a.trace ? a.trace + (size_t)tile_index * kTraceStride : nullptr;
 	if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
 	const uint32_t *gid = a.gid + t.gid_off;
+	const uint32_t num_chunks = t.chunk_end - t.chunk_begin;
 	{
-		const uint4 *src = reinterpret_cast<const uint4 *>(a.steps + t.step_begin);
-		for (uint32_t i = threadIdx.x; i < 2 * (t.step_end - t.step_begin); i += BLOCK)
-			lsteps[i] = src[i];
+		const uint4 *src = reinterpret_cast<const uint4 *>(a.chunks + t.chunk_begin);
+		for (uint32_t i = threadIdx.x; i < num_chunks; i += BLOCK)
+			lchunks[i] = src[i];
 	}
 	for (uint32_t i = threadIdx.x; i < t.n_local; i += BLOCK)
 		lpos[i] = a.pos_in[gid[i]];
@@ -273,12 +262,11 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 	str.idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.idx), 0, a.idx_bytes, 0x00020000);
 	str.par = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.params), 0, a.params_bytes, 0x00020000);
 	str.lam = __builtin_amdgcn_make_buffer_rsrc(a.lambda, 0, a.lambda_bytes, 0x00020000);
-	// steps are addressed relative to the tile from here on (they sit at lsteps[0 .. num_steps))
-	const uint32_t num_steps = t.step_end - t.step_begin;
-	uint32_t s = 0;
-	while (s < num_steps)
+	// chunks are addressed relative to the tile from here on (they sit at lchunks[0 .. num_chunks))
+	uint32_t c = 0, step_counter = 0;
+	while (c < num_chunks)
 	{
-		const uint32_t type = rfl(lsteps[2 * s].x);
+		const uint32_t type = chunk_type(rfl(lchunks[c].x));
 		switch (type)
 		{
 			PBDX_CASE(PBDX_DISTANCE) PBDX_CASE(PBDX_DISTANCE_XPBD) PBDX_CASE(PBDX_DIHEDRAL)
@@ -287,7 +275,7 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 			PBDX_CASE(PBDX_VOLUME) PBDX_CASE(PBDX_VOLUME_XPBD)
 			PBDX_CASE(PBDX_FEM_TET) PBDX_CASE(PBDX_FEM_TET_XPBD) PBDX_CASE(PBDX_STRAIN_TET)
 			PBDX_CASE(PBDX_SHAPE_MATCHING)
-		default: s = num_steps; break;
+		default: c = num_chunks; break;
 		}
 	}
 	for (uint32_t i = threadIdx.x; i < t.n_owned; i += BLOCK)
@@ -471,7 +459,7 @@ struct Batch
 struct DeviceSegment
 {
 	FusedTile *d_tiles = nullptr;
-	FusedStep *d_steps = nullptr;
+	FusedChunk *d_chunks = nullptr;
 	uint16_t *d_idx = nullptr;
 	float *d_params = nullptr;
 	float *d_lambda = nullptr;
@@ -560,7 +548,7 @@ struct pbdx_solver
 		for (DeviceSegment &d : dsegs)
 		{
 			if (d.d_tiles) (void)hipFree(d.d_tiles);
-			if (d.d_steps) (void)hipFree(d.d_steps);
+			if (d.d_chunks) (void)hipFree(d.d_chunks);
 			if (d.d_idx) (void)hipFree(d.d_idx);
 			if (d.d_params) (void)hipFree(d.d_params);
 			if (d.d_lambda) (void)hipFree(d.d_lambda);
@@ -658,7 +646,7 @@ int ensure_plan(pbdx_solver *s)
 	opt.tile_particles = s->tile_particles;
 	{
 		const size_t lds = s->prop.maxSharedMemoryPerMultiProcessor ? s->prop.maxSharedMemoryPerMultiProcessor : s->prop.sharedMemPerBlock;
-		opt.max_local = std::min<uint32_t>(s->lds_particles, (uint32_t)(lds / 16) - kMaxTileSteps * 2);
+		opt.max_local = std::min<uint32_t>(s->lds_particles, (uint32_t)(lds / 16) - kMaxTileChunks);
 		opt.max_tile_steps = kMaxTileSteps;
 	}
 	opt.num_cus = (uint32_t)std::max(1, s->prop.multiProcessorCount);
@@ -670,8 +658,56 @@ int ensure_plan(pbdx_solver *s)
 	{
 		s->dsegs.emplace_back();
 		DeviceSegment &d = s->dsegs.back();
-		int r = upload(&d.d_tiles, seg.tiles);
-		if (!r) r = upload(&d.d_steps, seg.steps);
+		// workgroup size: enough threads to cover the largest colour step of a tile once, at most 1024
+		int block = s->fuse_block;
+		if (block != 256 && block != 512 && block != 768 && block != 1024)
+		{
+			uint32_t widest = 0;
+			for (const FusedStep &st : seg.steps) widest = std::max(widest, st.count);
+			block = widest > 512 ? 1024 : widest > 256 ? 512 : 256;
+		}
+		if ((seg.type_mask & ~kMaskLight) && block > 512) block = 512;   // heavy types need > 128 VGPRs
+		if (block == 768 && !((seg.type_mask & ~kMaskClothXpbd) == 0 && s->pairs)) block = 512;   // 768 exists for the paired cloth kernel only
+		d.block = block;
+		// expand every tile's steps into workgroup-wide chunks (FusedChunk) for this workgroup size
+		std::vector<FusedTile> tiles = seg.tiles;
+		std::vector<FusedChunk> chunks;
+		bool too_many = false;
+		for (FusedTile &t : tiles)
+		{
+			t.chunk_begin = (uint32_t)chunks.size();
+			for (uint32_t si = t.step_begin; si < t.step_end; si++)
+			{
+				const FusedStep &st = seg.steps[si];
+				const TypeInfo *ti = type_info((int)st.type);
+				const uint32_t nplanes = (uint32_t)num_planes((int)st.type, s->plan.views[st.type].compact != 0);
+				const uint32_t slot_idx_bytes = ti->num_bodies == 2 ? 4u : 8u;
+				const uint32_t nchunks = (st.count + (uint32_t)block - 1) / (uint32_t)block;
+				for (uint32_t k = 0; k < nchunks; k++)
+				{
+					const uint32_t first = k * (uint32_t)block;
+					const uint32_t valid = std::min<uint32_t>((uint32_t)block, st.count - first);
+					const bool last = (k + 1 == nchunks);
+					FusedChunk c;
+					c.info = st.type | ((last && st.barrier) ? 0x100u : 0u) | (last ? 0x200u : 0u) | (valid << 16);
+					c.idx_boff = st.idx_off * 2u + first * slot_idx_bytes;
+					c.par_boff = (st.par_off + (first / 64u) * nplanes * 64u) * 4u;
+					c.lam_boff = (st.lam_off + first) * 4u;
+					chunks.push_back(c);
+				}
+			}
+			t.chunk_end = (uint32_t)chunks.size();
+			if (t.chunk_end - t.chunk_begin > kMaxTileChunks) too_many = true;
+		}
+		if (too_many)
+		{
+			s->free_plan();
+			s->plan_built = true;
+			s->plan_why = "a tile needs more chunk descriptors than fit the LDS header: use smaller segments or larger workgroups";
+			return PBDX_OK;
+		}
+		int r = upload(&d.d_tiles, tiles);
+		if (!r) r = upload(&d.d_chunks, chunks);
 		if (!r) r = upload(&d.d_idx, seg.idx);
 		if (!r) r = upload(&d.d_params, seg.params);
 		if (!r) r = upload(&d.d_gid, seg.gid);
@@ -691,24 +727,13 @@ int ensure_plan(pbdx_solver *s)
 		d.params_bytes = (uint32_t)(seg.params.size() * sizeof(float));
 		d.lambda_bytes = (uint32_t)((size_t)seg.lam_count * sizeof(float));
 		d.num_tiles = (uint32_t)seg.tiles.size();
-		d.lds_bytes = std::max(seg.max_local, 1u) * 16u + kMaxTileSteps * 32u;
+		d.lds_bytes = std::max(seg.max_local, 1u) * 16u + kMaxTileChunks * 16u;
 		d.type_mask = seg.type_mask;
 		d.constraints = seg.constraints;
 		for (const PlanBatch &pb : pbs)
 			if (pb.colour >= seg.colour_begin && pb.colour < seg.colour_end)
 				d.algorithmic_bytes += (uint64_t)pb.count * type_info(pb.type)->algorithmic_bytes;
-		int block = s->fuse_block;
-		if (block != 256 && block != 512 && block != 768 && block != 1024)
-		{
-			// auto: enough threads to cover the largest colour step of a tile once, at most 1024
-			uint32_t widest = 0;
-			for (const FusedStep &st : seg.steps) widest = std::max(widest, st.count);
-			block = widest > 512 ? 1024 : widest > 256 ? 512 : 256;
-		}
-		if ((seg.type_mask & ~kMaskLight) && block > 512) block = 512;
-		if (block == 768 && !((seg.type_mask & ~kMaskClothXpbd) == 0 && s->pairs)) block = 512;   // 768 exists for the paired cloth kernel only
-		d.block = block;
-		d.kernel = pick_fused_kernel(seg.type_mask, block, s->pairs != 0);
+		d.kernel = pick_fused_kernel(seg.type_mask, d.block, s->pairs != 0);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(d.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
 	}
 	s->plan_ok = true;
@@ -792,7 +817,7 @@ int launch_segment(pbdx_solver *s, size_t si, int src, float dt, int first_iter)
 	FusedArgs a;
 	a.pos_in = s->d_pos[src];
 	a.pos_out = s->d_pos[src ^ 1];
-	a.tiles = d.d_tiles; a.steps = d.d_steps; a.idx = d.d_idx; a.params = d.d_params; a.lambda = d.d_lambda; a.gid = d.d_gid;
+	a.tiles = d.d_tiles; a.chunks = d.d_chunks; a.idx = d.d_idx; a.params = d.d_params; a.lambda = d.d_lambda; a.gid = d.d_gid;
 	a.idx_bytes = d.idx_bytes; a.params_bytes = d.params_bytes; a.lambda_bytes = d.lambda_bytes;
 	a.dt = dt;
 	a.first_iter = first_iter;
