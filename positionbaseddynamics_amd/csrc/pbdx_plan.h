@@ -134,7 +134,8 @@ struct FusedTile      // 32 bytes
 // 16 bytes, staged in LDS, read as scalars.
 struct FusedChunk
 {
-	uint32_t info;        // type (bits 0-7) | barrier after this chunk (bit 8) | last chunk of its step (bit 9) | valid lanes (bits 16-31)
+	uint32_t info;        // type (bits 0-5) | barrier after this chunk (bit 6) | last chunk of its step (bit 7) |
+	                      // valid lanes (bits 8-18) | chunks left in this run of equal type, this one included (bits 19-31)
 	uint32_t idx_boff;    // BYTE offsets of the chunk's first slot in the three streams
 	uint32_t par_boff;
 	uint32_t lam_boff;

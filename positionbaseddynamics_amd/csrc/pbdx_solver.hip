@@ -153,10 +153,11 @@ __device__ __forceinline__ ChunkS load_chunk(const uint4 *lchunks, uint32_t c)
 	r.info = rfl(v.x); r.idx_boff = rfl(v.y); r.par_boff = rfl(v.z); r.lam_boff = rfl(v.w);
 	return r;
 }
-__device__ __forceinline__ uint32_t chunk_type(uint32_t info) { return info & 0xffu; }
-__device__ __forceinline__ uint32_t chunk_valid(uint32_t info) { return info >> 16; }
-__device__ __forceinline__ bool chunk_barrier(uint32_t info) { return (info >> 8) & 1u; }
-__device__ __forceinline__ bool chunk_last_of_step(uint32_t info) { return (info >> 9) & 1u; }
+__device__ __forceinline__ uint32_t chunk_type(uint32_t info) { return info & 0x3fu; }
+__device__ __forceinline__ bool chunk_barrier(uint32_t info) { return (info >> 6) & 1u; }
+__device__ __forceinline__ bool chunk_last_of_step(uint32_t info) { return (info >> 7) & 1u; }
+__device__ __forceinline__ uint32_t chunk_valid(uint32_t info) { return (info >> 8) & 0x7ffu; }
+__device__ __forceinline__ uint32_t chunk_run_left(uint32_t info) { return info >> 19; }
 
 template <int TYPE, bool COMPACT, int BLOCK, bool PAIRS>
 __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStreams &str, const uint4 *lchunks, uint32_t c0, uint32_t c_end,
@@ -167,9 +168,9 @@ __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStre
 	// per-lane constants of the run
 	const uint32_t lane_slot = threadIdx.x;
 	const uint32_t v_par = (threadIdx.x >> 6) * (uint32_t)(num_planes(TYPE, COMPACT) * 256) + (threadIdx.x & 63u) * 4u;
-	// end of the run: first chunk of another type
-	uint32_t run_end = c0 + 1;
-	while (run_end < c_end && chunk_type(rfl(lchunks[run_end].x)) == (uint32_t)TYPE) run_end++;
+	// end of the run (first chunk of another type): precomputed on the host
+	const uint32_t run_end = c0 + chunk_run_left(rfl(lchunks[c0].x));
+	(void)c_end;
 
 	uint32_t c_ld = c0, c_ex = c0;
 	// the ring lives in named records (not an array): keeps every record in registers
@@ -689,7 +690,7 @@ int ensure_plan(pbdx_solver *s)
 					const uint32_t valid = std::min<uint32_t>((uint32_t)block, st.count - first);
 					const bool last = (k + 1 == nchunks);
 					FusedChunk c;
-					c.info = st.type | ((last && st.barrier) ? 0x100u : 0u) | (last ? 0x200u : 0u) | (valid << 16);
+					c.info = st.type | ((last && st.barrier) ? 0x40u : 0u) | (last ? 0x80u : 0u) | (valid << 8);
 					c.idx_boff = st.idx_off * 2u + first * slot_idx_bytes;
 					c.par_boff = (st.par_off + (first / 64u) * nplanes * 64u) * 4u;
 					c.lam_boff = (st.lam_off + first) * 4u;
@@ -698,6 +699,14 @@ int ensure_plan(pbdx_solver *s)
 			}
 			t.chunk_end = (uint32_t)chunks.size();
 			if (t.chunk_end - t.chunk_begin > kMaxTileChunks) too_many = true;
+			// chunks left in each run of equal type (a tile never has more than kMaxTileChunks < 8192)
+			uint32_t left = 0;
+			for (uint32_t ci = t.chunk_end; ci-- > t.chunk_begin;)
+			{
+				const bool same = (ci + 1 < t.chunk_end) && ((chunks[ci + 1].info & 0x3fu) == (chunks[ci].info & 0x3fu));
+				left = same ? left + 1 : 1;
+				chunks[ci].info |= std::min(left, 8191u) << 19;
+			}
 		}
 		if (too_many)
 		{
