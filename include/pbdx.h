@@ -112,7 +112,9 @@ void pbdx_solver_destroy(pbdx_solver *s);
  * `last_x` may be NULL (=> 0, x, x).  Accelerations are not uploaded: the
  * reference overwrites them with gravity for every dynamic particle at the
  * start of each step (TimeStep::clearAccelerations, TimeStep.cpp:28-62).
- * A particle is static iff mass == 0 (TimeIntegration.cpp:14). */
+ * A particle is static iff mass == 0 (TimeIntegration.cpp:14).
+ * Changing the particle COUNT drops the constraint schedule (its indices refer to the old image): re-add it.
+ * A pbdx_solver is not thread-safe; use one per host thread / device stream. */
 int pbdx_solver_set_particles(pbdx_solver *s, uint32_t n,
 	const float *x, const float *v, const float *old_x, const float *last_x,
 	const float *mass, const float *inv_mass);

@@ -1039,7 +1039,8 @@ int pbdx_solver_set_particles(pbdx_solver *s, uint32_t n, const float *x, const 
 		HIPCHECK(hipStreamSynchronize(s->stream));
 		s->free_particles();
 		s->drop_graph();
-		s->free_plan();
+		s->free_batches();         // a schedule refers to particle indices of the old image: it must be re-added
+		s->schedule_version++;
 		if (n)
 		{
 			HIPCHECK(hipMalloc(&s->d_pos[0], (size_t)n * sizeof(float4)));

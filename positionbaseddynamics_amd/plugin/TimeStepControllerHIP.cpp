@@ -231,6 +231,7 @@ bool TimeStepControllerHIP::uploadParticles(SimulationModel &model)
 		m_mass[i] = (float)pd.getMass(i);
 		m_invMass[i] = (float)pd.getInvMass(i);
 	}
+	if (n != m_numParticles) m_scheduleValid = false;      // the engine drops its schedule with the old particle image
 	m_numParticles = n;
 	return pbdx_solver_set_particles(m_solver, n, m_x.data(), m_v.data(), m_old.data(), m_last.data(), m_mass.data(), m_invMass.data()) == PBDX_OK;
 }
