@@ -299,6 +299,12 @@ uint32_t pbdx_model_tet_model_index_offset(const pbdx_model *m, uint32_t tm);
 uint32_t pbdx_model_triangle_model_num_edges(const pbdx_model *m, uint32_t tm);
 /* out: num_edges * 4 values (vert0, vert1, face0, face1), 0xffffffff = no face */
 int pbdx_model_triangle_model_get_edges(const pbdx_model *m, uint32_t tm, uint32_t *out);
+uint32_t pbdx_model_triangle_model_num_vertices(const pbdx_model *m, uint32_t tm);
+uint32_t pbdx_model_triangle_model_num_faces(const pbdx_model *m, uint32_t tm);
+int pbdx_model_triangle_model_get_faces(const pbdx_model *m, uint32_t tm, uint32_t *out); /* num_faces*3, model-local vertex ids */
+uint32_t pbdx_model_tet_model_num_vertices(const pbdx_model *m, uint32_t tm);
+uint32_t pbdx_model_tet_model_num_tets(const pbdx_model *m, uint32_t tm);
+int pbdx_model_tet_model_get_tets(const pbdx_model *m, uint32_t tm, uint32_t *out);       /* num_tets*4 */
 uint32_t pbdx_model_tet_model_num_edges(const pbdx_model *m, uint32_t tm);
 int pbdx_model_tet_model_get_edges(const pbdx_model *m, uint32_t tm, uint32_t *out); /* num_edges*2 */
 
@@ -386,6 +392,8 @@ enum {
 	PBDX_TS_VELOCITY_UPDATE_METHOD = 3  /* "velocityUpdateMethod" */
 };
 
+/* Creating a time step and setting its parameters needs no GPU; the engine on HIP device `device` is created
+ * by the first call that steps / uploads (PBDX_ERR_NO_DEVICE there if none is visible: there is no CPU path). */
 int pbdx_timestep_create(pbdx_timestep **out, int device);
 void pbdx_timestep_destroy(pbdx_timestep *ts);
 int pbdx_timestep_set_param(pbdx_timestep *ts, int id, int64_t value);
@@ -415,7 +423,7 @@ int pbdx_timestep_invalidate(pbdx_timestep *ts);
  * loop of one substep (`iterations` Gauss-Seidel sweeps over the colour groups, lambda reset at
  * sweep 0, XPBD dt = h/subSteps), download positions.  No integration, no velocity update. */
 int pbdx_timestep_project(pbdx_timestep *ts, pbdx_model *m, uint32_t iterations);
-/* the engine underneath (owned by the timestep) */
+/* the engine underneath (owned by the timestep; created on demand, NULL without a HIP device) */
 pbdx_solver *pbdx_timestep_solver(pbdx_timestep *ts);
 
 #ifdef __cplusplus

@@ -27,7 +27,7 @@ from . import _ffi
 from ._ffi import lib, check, PbdxError, StepStats  # noqa: F401
 
 __all__ = ["Simulation", "SimulationModel", "ParticleData", "TimeManager", "TimeStepController",
-           "TriangleModel", "TetModel", "Solver", "ConstraintType", "PbdxError", "device_count"]
+           "TriangleModel", "TetModel", "Solver", "ConstraintType", "PbdxError", "device_count", "Logger", "LogLevel"]
 
 
 def device_count():
@@ -198,10 +198,62 @@ class _MeshModel:
         self._m = model
         self._i = index
 
+    def __index__(self):                 # usable wherever the reference API takes the model (or its index)
+        return self._i
+
+    def updateMeshNormals(self, pd):     # rendering only in the reference (TriangleModel::updateMeshNormals)
+        pass
+
+
+class _FaceMeshView:
+    """The part of Utilities::IndexedFaceMesh a pypbd script reads (numFaces, numVertices, getFaces, getEdges)."""
+
+    def __init__(self, tm):
+        self._tm = tm
+
+    def numVertices(self):
+        return lib.pbdx_model_triangle_model_num_vertices(self._tm._m._h, self._tm._i)
+
+    def numFaces(self):
+        return lib.pbdx_model_triangle_model_num_faces(self._tm._m._h, self._tm._i)
+
+    def numEdges(self):
+        return lib.pbdx_model_triangle_model_num_edges(self._tm._m._h, self._tm._i)
+
+    def getFaces(self):
+        out = np.empty(3 * self.numFaces(), dtype=np.uint32)
+        check(lib.pbdx_model_triangle_model_get_faces(self._tm._m._h, self._tm._i, _u(out)), "get_faces")
+        return out
+
+    def getEdges(self):
+        return self._tm.getEdges()
+
+
+class _TetMeshView:
+    def __init__(self, tm):
+        self._tm = tm
+
+    def numVertices(self):
+        return lib.pbdx_model_tet_model_num_vertices(self._tm._m._h, self._tm._i)
+
+    def numTets(self):
+        return lib.pbdx_model_tet_model_num_tets(self._tm._m._h, self._tm._i)
+
+    def numEdges(self):
+        return lib.pbdx_model_tet_model_num_edges(self._tm._m._h, self._tm._i)
+
+    def getTets(self):
+        out = np.empty(4 * self.numTets(), dtype=np.uint32)
+        check(lib.pbdx_model_tet_model_get_tets(self._tm._m._h, self._tm._i, _u(out)), "get_tets")
+        return out
+
 
 class TriangleModel(_MeshModel):
     def getIndexOffset(self):
         return lib.pbdx_model_triangle_model_index_offset(self._m._h, self._i)
+
+    def getParticleMesh(self):
+        return _FaceMeshView(self)
 
     def getEdges(self):
         n = lib.pbdx_model_triangle_model_num_edges(self._m._h, self._i)
@@ -214,11 +266,30 @@ class TetModel(_MeshModel):
     def getIndexOffset(self):
         return lib.pbdx_model_tet_model_index_offset(self._m._h, self._i)
 
+    def getParticleMesh(self):
+        return _TetMeshView(self)
+
     def getEdges(self):
         n = lib.pbdx_model_tet_model_num_edges(self._m._h, self._i)
         out = np.empty((n, 2), dtype=np.uint32)
         check(lib.pbdx_model_tet_model_get_edges(self._m._h, self._i, _u(out)), "get_edges")
         return out
+
+
+class LogLevel:
+    DEBUG, INFO, WARN, ERR = range(4)
+
+
+class Logger:
+    """pypbd.Logger stand-in: the engine reports through status codes / pbdx_last_error()."""
+
+    @staticmethod
+    def addConsoleSink(level):
+        pass
+
+    @staticmethod
+    def addFileSink(level, path):
+        pass
 
 
 def _idx(tm):
@@ -261,35 +332,35 @@ class SimulationModel:
         return [TetModel(self, i) for i in range(lib.pbdx_model_num_tet_models(self._h))]
 
     # -- meshes --
-    def addRegularTriangleModel(self, width, height, translation=(0, 0, 0), rotation=None, scale=(1, 1)):
+    def addRegularTriangleModel(self, width, height, translation=(0, 0, 0), rotation=None, scale=(1, 1), testMesh=False):
         R = np.eye(3, dtype=np.float32) if rotation is None else np.ascontiguousarray(rotation, dtype=np.float32)
         r = lib.pbdx_model_add_regular_triangle_model(self._h, int(width), int(height), _f(_vec(translation, 3)), _f(_vec(R, 9)), _f(_vec(scale, 2)))
         if r < 0:
             raise PbdxError(r, "addRegularTriangleModel")
-        return r
+        return TriangleModel(self, r)
 
-    def addTriangleModel(self, points, indices):
+    def addTriangleModel(self, points, indices, testMesh=False):
         p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
         f = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
         r = lib.pbdx_model_add_triangle_model(self._h, len(p), len(f), _f(p), _u(f))
         if r < 0:
             raise PbdxError(r, "addTriangleModel")
-        return r
+        return TriangleModel(self, r)
 
-    def addRegularTetModel(self, width, height, depth, translation=(0, 0, 0), rotation=None, scale=(1, 1, 1)):
+    def addRegularTetModel(self, width, height, depth, translation=(0, 0, 0), rotation=None, scale=(1, 1, 1), testMesh=False):
         R = np.eye(3, dtype=np.float32) if rotation is None else np.ascontiguousarray(rotation, dtype=np.float32)
         r = lib.pbdx_model_add_regular_tet_model(self._h, int(width), int(height), int(depth), _f(_vec(translation, 3)), _f(_vec(R, 9)), _f(_vec(scale, 3)))
         if r < 0:
             raise PbdxError(r, "addRegularTetModel")
-        return r
+        return TetModel(self, r)
 
-    def addTetModel(self, points, indices):
+    def addTetModel(self, points, indices, testMesh=False):
         p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
         t = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 4)
         r = lib.pbdx_model_add_tet_model(self._h, len(p), len(t), _f(p), _u(t))
         if r < 0:
             raise PbdxError(r, "addTetModel")
-        return r
+        return TetModel(self, r)
 
     # -- per-constraint builders (return bool like the reference) --
     def addDistanceConstraint(self, p1, p2, stiffness):
@@ -471,7 +542,10 @@ class TimeStepController:
         check(lib.pbdx_timestep_project(self._h, model._h, int(iterations)), "TimeStepController.project")
 
     def solver(self):
-        return Solver(handle=lib.pbdx_timestep_solver(self._h), owner=self)
+        h = lib.pbdx_timestep_solver(self._h)
+        if not h:
+            raise PbdxError(2, "TimeStepController.solver")      # PBDX_ERR_NO_DEVICE: no CPU path
+        return Solver(handle=h, owner=self)
 
 
 class Solver:

@@ -99,6 +99,10 @@ SIGNATURES = [
     ("pbdx_model_num_triangle_models", u32, vp), ("pbdx_model_num_tet_models", u32, vp),
     ("pbdx_model_triangle_model_index_offset", u32, vp, u32), ("pbdx_model_tet_model_index_offset", u32, vp, u32),
     ("pbdx_model_triangle_model_num_edges", u32, vp, u32), ("pbdx_model_triangle_model_get_edges", C.c_int, vp, u32, pu),
+    ("pbdx_model_triangle_model_num_vertices", u32, vp, u32), ("pbdx_model_triangle_model_num_faces", u32, vp, u32),
+    ("pbdx_model_triangle_model_get_faces", C.c_int, vp, u32, pu),
+    ("pbdx_model_tet_model_num_vertices", u32, vp, u32), ("pbdx_model_tet_model_num_tets", u32, vp, u32),
+    ("pbdx_model_tet_model_get_tets", C.c_int, vp, u32, pu),
     ("pbdx_model_tet_model_num_edges", u32, vp, u32), ("pbdx_model_tet_model_get_edges", C.c_int, vp, u32, pu),
     ("pbdx_model_num_particles", u32, vp), ("pbdx_model_add_vertex", C.c_int, vp, pf),
     ("pbdx_model_set_mass", C.c_int, vp, u32, f32),

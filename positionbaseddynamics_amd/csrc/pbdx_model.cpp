@@ -354,6 +354,24 @@ int pbdx_model_triangle_model_get_edges(const pbdx_model *m, uint32_t tm, uint32
 	}
 	return PBDX_OK;
 }
+// faces / tets / vertex counts (IndexedFaceMesh::numFaces/getFaces, IndexedTetMesh::numTets/getTets)
+uint32_t pbdx_model_triangle_model_num_vertices(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tri_models.size()) ? m->tri_models[tm].num_vertices : 0; }
+uint32_t pbdx_model_triangle_model_num_faces(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tri_models.size()) ? (uint32_t)(m->tri_models[tm].faces.size() / 3) : 0; }
+int pbdx_model_triangle_model_get_faces(const pbdx_model *m, uint32_t tm, uint32_t *out)
+{
+	if (!m || !out || tm >= m->tri_models.size()) { set_error("triangle_model_get_faces: bad argument"); return PBDX_ERR_INVALID; }
+	memcpy(out, m->tri_models[tm].faces.data(), m->tri_models[tm].faces.size() * sizeof(uint32_t));
+	return PBDX_OK;
+}
+uint32_t pbdx_model_tet_model_num_vertices(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tet_models.size()) ? m->tet_models[tm].num_vertices : 0; }
+uint32_t pbdx_model_tet_model_num_tets(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tet_models.size()) ? (uint32_t)(m->tet_models[tm].tets.size() / 4) : 0; }
+int pbdx_model_tet_model_get_tets(const pbdx_model *m, uint32_t tm, uint32_t *out)
+{
+	if (!m || !out || tm >= m->tet_models.size()) { set_error("tet_model_get_tets: bad argument"); return PBDX_ERR_INVALID; }
+	memcpy(out, m->tet_models[tm].tets.data(), m->tet_models[tm].tets.size() * sizeof(uint32_t));
+	return PBDX_OK;
+}
+
 uint32_t pbdx_model_tet_model_num_edges(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tet_models.size()) ? (uint32_t)m->tet_models[tm].edges.size() : 0; }
 int pbdx_model_tet_model_get_edges(const pbdx_model *m, uint32_t tm, uint32_t *out)
 {

@@ -14,7 +14,8 @@ using namespace pbdx;
 
 struct pbdx_timestep
 {
-	pbdx_solver *solver = nullptr;
+	pbdx_solver *solver = nullptr;   // created by the first call that needs the device (parameters can be set without a GPU)
+	int device = 0;
 	uint32_t sub_steps = 5, max_iterations = 1, max_iterations_v = 5;
 	int velocity_update_method = 0;
 	float gravity[3] = { 0.0f, -9.81f, 0.0f };
@@ -29,6 +30,13 @@ struct pbdx_timestep
 };
 
 namespace {
+
+// the engine is created on first use; without a HIP device this fails with PBDX_ERR_NO_DEVICE (no CPU path)
+int ensure_solver(pbdx_timestep *ts)
+{
+	if (ts->solver) return PBDX_OK;
+	return pbdx_solver_create(&ts->solver, ts->device);
+}
 
 int upload_particles(pbdx_timestep *ts, pbdx_model *m)
 {
@@ -76,6 +84,10 @@ int build_schedule(pbdx_timestep *ts, pbdx_model *m)
 
 int refresh_image(pbdx_timestep *ts, pbdx_model *m, bool force_particles)
 {
+	{
+		int r0 = ensure_solver(ts);
+		if (r0) return r0;
+	}
 	const bool stale_topology = !ts->schedule_valid || ts->image_of != m || ts->topo != m->topology_version || !m->groups_initialized;
 	const bool stale_params = ts->params != m->params_version;
 	// dirty tracking: the host state was written through the model API since the last upload / sync
@@ -153,12 +165,9 @@ int pbdx_timestep_create(pbdx_timestep **out, int device)
 {
 	if (!out) { set_error("pbdx_timestep_create: null out"); return PBDX_ERR_INVALID; }
 	*out = nullptr;
-	pbdx_solver *s = nullptr;
-	int r = pbdx_solver_create(&s, device);
-	if (r) return r;
 	pbdx_timestep *ts = new (std::nothrow) pbdx_timestep();
-	if (!ts) { pbdx_solver_destroy(s); set_error("out of memory"); return PBDX_ERR_ALLOC; }
-	ts->solver = s;
+	if (!ts) { set_error("out of memory"); return PBDX_ERR_ALLOC; }
+	ts->device = device;
 	*out = ts;
 	return PBDX_OK;
 }
@@ -216,11 +225,12 @@ float pbdx_timestep_get_time_step_size(const pbdx_timestep *ts) { return ts ? ts
 float pbdx_timestep_get_time(const pbdx_timestep *ts) { return ts ? ts->time : 0.0f; }
 int pbdx_timestep_reset(pbdx_timestep *ts) { if (!ts) return PBDX_ERR_INVALID; ts->time = 0.0f; ts->schedule_valid = false; ts->device_ahead = false; ts->state_seen = ~0ull; return PBDX_OK; }
 int pbdx_timestep_invalidate(pbdx_timestep *ts) { if (!ts) return PBDX_ERR_INVALID; ts->schedule_valid = false; return PBDX_OK; }
-pbdx_solver *pbdx_timestep_solver(pbdx_timestep *ts) { return ts ? ts->solver : nullptr; }
+pbdx_solver *pbdx_timestep_solver(pbdx_timestep *ts) { if (!ts) return nullptr; (void)ensure_solver(ts); return ts->solver; }
 
 int pbdx_timestep_sync_to_host(pbdx_timestep *ts, pbdx_model *m)
 {
 	if (!ts || !m) return PBDX_ERR_INVALID;
+	if (!ts->solver) { set_error("sync_to_host: nothing has been stepped on the device yet"); return PBDX_ERR_INVALID; }
 	int r = pbdx_solver_get_particles(ts->solver, m->size(), m->x.data(), m->v.data(), m->old_x.data(), m->last_x.data());
 	if (r) return r;
 	ts->device_ahead = false;

@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 
 from tests import util
@@ -50,9 +51,21 @@ def test_no_cpu_fallback(have_gpu):
     import positionbaseddynamics_amd as pbd
     if have_gpu:
         pytest.skip("GPU present: the refusal path is only reachable without a device")
-    with pytest.raises(pbd.PbdxError) as e:
-        pbd.TimeStepController()
-    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+    # a time step can be created and configured without a device (like the reference's), but every call
+    # that would compute refuses: step, stepResident, project, the engine handle
+    ts = pbd.TimeStepController()
+    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 7)
+    assert ts.getValueUInt(pbd.TimeStepController.MAX_ITERATIONS) == 7
+    m = pbd.SimulationModel()
+    m.addRegularTriangleModel(4, 4)
+    m.addClothConstraints(0, 4, 1000.0)
+    x0 = m.getParticles().positions().copy()
+    for call in (lambda: ts.step(m), lambda: ts.stepResident(m, 1), lambda: ts.project(m, 1), lambda: ts.solver(), lambda: ts.syncFromHost(m)):
+        with pytest.raises(pbd.PbdxError) as e:
+            call()
+        assert e.value.code == 2
+    assert "no CPU fallback" in str(e.value)
+    assert np.array_equal(m.getParticles().positions(), x0), "a refused step must not move anything"
     with pytest.raises(pbd.PbdxError):
         pbd.Solver()
 
