@@ -36,8 +36,10 @@ def build_workload(args, ens):
     from tests import util
     t0 = time.perf_counter()
     if args.workload == "c3":
-        spec = util.bar_spec(101, 21, 11, args.solid_method)
-        desc = "configs[2]: 101x21x11 regular tet bar (100000 tets), solid method %d, %d iterations, 1 substep, h=0.005" % (args.solid_method, args.iters)
+        k = args.instances if args.bars else 1
+        spec = util.bar_spec(101, 21, 11, args.solid_method, instances=k)
+        desc = "configs[2]: %s101x21x11 regular tet bar (100000 tets), solid method %d, %d iterations, 1 substep, h=0.005" % (
+            ("%d independent bars, each a " % k) if k > 1 else "", args.solid_method, args.iters)
         pins = [0]
     elif args.workload == "c4":
         begin, end = ens.shard(args.instances * ens.world)     # weak scaling: `instances` per GPU
@@ -222,6 +224,7 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2")
     ap.add_argument("--size", type=int, default=None, help="cloth is size x size particles (default 1000; 200 for c4)")
     ap.add_argument("--instances", type=int, default=64, help="c4: cloth instances per GPU")
+    ap.add_argument("--bars", action="store_true", help="c3: batch --instances independent bars per GPU (the single bar is latency-bound by construction)")
     ap.add_argument("--solid-method", type=int, default=2, help="c3: addSolidConstraints method (2 FEM tet, 4 strain tet, 6 XPBD distance+volume)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -395,19 +398,25 @@ def main():
                 if launches:
                     per_type[T.name(t)] = {"launches": launches, "avg_us": 1e3 * ms / launches, "projections": proj,
                                            "algorithmic_GBs": proj * T.algorithmic_bytes(t) / ms / 1e6}
-            ms, launches, proj = sol.type_stats(T.ISOMETRIC_BENDING_XPBD)
-            if launches:
-                bytes_per_launch = proj * T.algorithmic_bytes(T.ISOMETRIC_BENDING_XPBD) / launches
+            # dominant kernel of the per-colour schedule = the constraint type with the largest share of the time
+            dom_t, dom_ms = None, 0.0
+            for t in range(T.COUNT):
+                ms_t, launches_t, _ = sol.type_stats(t)
+                if launches_t and ms_t > dom_ms:
+                    dom_t, dom_ms = t, ms_t
+            if dom_t is not None:
+                ms, launches, proj = sol.type_stats(dom_t)
+                bytes_per_launch = proj * T.algorithmic_bytes(dom_t) / launches
                 dur_s = 1e-3 * ms / launches
                 achieved = bytes_per_launch / dur_s / 1e9
-                out["roofline"] = {"bound": "hbm", "kernel": "project_kernel<ISOMETRIC_BENDING_XPBD>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                out["roofline"] = {"bound": "hbm", "kernel": "project_kernel<%s>" % T.name(dom_t), "achieved": achieved, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                    "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": dur_s * 1e6,
                                    "launches_measured": launches, "per_type": per_type}
 
     if rank == 0 and world == 1 and "roofline" in out and not args.no_traffic and not args.pmc_child:
         child = ["--workload", args.workload, "--size", str(args.size), "--iters", str(args.iters), "--instances", str(args.instances),
-                 "--solid-method", str(args.solid_method)]
+                 "--solid-method", str(args.solid_method)] + (["--bars"] if args.bars else [])
         for flag, val in (("--fuse", args.fuse), ("--tile", args.tile), ("--fuse-block", args.fuse_block), ("--max-seg", args.max_seg),
                           ("--lds-particles", args.lds_particles), ("--xcd-remap", args.xcd_remap), ("--block", args.block)):
             if val is not None:

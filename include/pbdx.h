@@ -202,7 +202,9 @@ enum {
 	PBDX_OPT_USE_GRAPH = 1,        /* capture one substep into a hipGraph (default 1) */
 	PBDX_OPT_BLOCK_SIZE = 2,       /* threads per workgroup of the per-colour kernels: 64/128/256 (default 256) */
 	PBDX_OPT_XCD_REMAP = 3,        /* XCD-aware blockIdx -> constraint-range / tile mapping (default 1) */
-	PBDX_OPT_FUSE = 4,             /* colour-fused LDS tile schedule (default 1); 0 = one launch per (colour, type) */
+	PBDX_OPT_FUSE = 4,             /* 1 = colour-fused LDS tile schedule, 0 = one launch per (colour, type), 2 = auto (default):
+	                                * fused, except that schedules with compute-heavy types (FEM, strain, shape matching) are timed
+	                                * once both ways on scratch positions and the faster one is kept (results are identical) */
 	PBDX_OPT_TILE_PARTICLES = 5,   /* particles owned by one tile; 0 = auto (default) */
 	PBDX_OPT_FUSE_BLOCK = 6,       /* threads per workgroup of the fused kernel: 0 = auto, 256, 512, 1024 */
 	PBDX_OPT_MAX_SEGMENT_COLOURS = 7, /* upper bound on colours fused into one launch (default 16) */

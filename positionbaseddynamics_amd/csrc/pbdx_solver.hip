@@ -504,7 +504,9 @@ struct pbdx_solver
 	int block_size = 256;
 	int xcd_remap = 1;
 	int profile = 0;
-	int fuse = 1;
+	int fuse = 2;                        // 0 per-colour, 1 fused, 2 auto (fused; measured choice when compute-heavy types are present)
+	int fuse_choice = 1;                 // outcome of the auto mode for the current schedule
+	float autotune_ms[2] = { 0.0f, 0.0f }; // measured sweep time per-colour / fused (0 = not measured)
 	uint32_t tile_particles = 0;
 	int fuse_block = 0;                  // 0 = auto
 	uint32_t max_segment_colours = 16;
@@ -561,6 +563,8 @@ struct pbdx_solver
 		plan_built = false;
 		plan_ok = false;
 		plan_why.clear();
+		fuse_choice = 1;
+		autotune_ms[0] = autotune_ms[1] = 0.0f;
 	}
 	void free_batches()
 	{
@@ -587,7 +591,7 @@ struct pbdx_solver
 		if (d_stage) { (void)hipFree(d_stage); d_stage = nullptr; }
 		n = 0;
 	}
-	bool fused_active() const { return fuse && plan_ok && !dsegs.empty(); }
+	bool fused_active() const { return fuse && plan_ok && !dsegs.empty() && (fuse == 1 || fuse_choice); }
 	void unpin_all()
 	{
 		for (const Pin &pn : pins) (void)hipHostUnregister(const_cast<void *>(pn.p));
@@ -902,6 +906,47 @@ int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, Pr
 	return PBDX_OK;
 }
 
+// Auto mode: the fused schedule executes halo constraints redundantly, which pays for streaming-bound types
+// (distance, bending, volume: always faster, no measurement) but not always for compute-heavy ones (FEM,
+// strain, shape matching: ~1000 VALU instructions per projection).  For those both schedules are timed
+// once on scratch copies of the positions and the faster one is kept.  The two schedules are bit-identical,
+// so the choice can never change a result.
+int autotune_schedule(pbdx_solver *s)
+{
+	s->fuse_choice = 1;
+	if (s->fuse != 2 || !s->plan_ok || s->dsegs.empty()) return PBDX_OK;
+	uint32_t mask = 0;
+	for (const DeviceSegment &d : s->dsegs) mask |= d.type_mask;
+	if ((mask & ~kMaskLight) == 0) return PBDX_OK;
+	int r = ensure_device_batches(s);
+	if (r) return r;
+	float4 *scratch[2] = { nullptr, nullptr }, *keep[2] = { s->d_pos[0], s->d_pos[1] };
+	HIPCHECK(hipMalloc(&scratch[0], (size_t)s->n * sizeof(float4)));
+	if (hipMalloc(&scratch[1], (size_t)s->n * sizeof(float4)) != hipSuccess) { (void)hipFree(scratch[0]); set_error("autotune: out of memory"); return PBDX_ERR_HIP; }
+	float ms[2] = { 0.0f, 0.0f };
+	const float dt = 0.005f;
+	for (int choice = 0; choice < 2 && !r; choice++)
+	{
+		s->fuse_choice = choice;
+		s->d_pos[0] = scratch[0]; s->d_pos[1] = scratch[1];
+		for (int rep = 0; rep < 3 && !r; rep++)      // rep 0 = warm-up
+		{
+			if (hipMemcpyAsync(scratch[0], keep[0], (size_t)s->n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream) != hipSuccess) { r = PBDX_ERR_HIP; break; }
+			if (rep == 1) (void)hipEventRecord(s->ev_start, s->stream);
+			r = projection_sweeps(s, dt, 2, 0, nullptr);
+		}
+		(void)hipEventRecord(s->ev_stop, s->stream);
+		if (hipStreamSynchronize(s->stream) != hipSuccess) r = PBDX_ERR_HIP;
+		if (!r) (void)hipEventElapsedTime(&ms[choice], s->ev_start, s->ev_stop);
+	}
+	s->d_pos[0] = keep[0]; s->d_pos[1] = keep[1];
+	(void)hipFree(scratch[0]); (void)hipFree(scratch[1]);
+	if (r) { s->fuse_choice = 1; return r; }
+	s->fuse_choice = (ms[1] <= ms[0]) ? 1 : 0;
+	s->autotune_ms[0] = ms[0]; s->autotune_ms[1] = ms[1];
+	return PBDX_OK;
+}
+
 int enqueue_substep(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int vel, const float g[3], ProfCursor *pc)
 {
 	const uint32_t bs = 256;
@@ -1187,7 +1232,9 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 		if (value != 64 && value != 128 && value != 256) { set_error("block size must be 64, 128 or 256"); return PBDX_ERR_INVALID; }
 		s->block_size = (int)value; break;
 	case PBDX_OPT_XCD_REMAP: s->xcd_remap = value != 0; break;
-	case PBDX_OPT_FUSE: s->fuse = value != 0; break;
+	case PBDX_OPT_FUSE:
+		if (value < 0 || value > 2) { set_error("fuse must be 0 (per-colour), 1 (fused) or 2 (auto)"); return PBDX_ERR_INVALID; }
+		s->fuse = (int)value; replan = true; break;
 	case PBDX_OPT_TILE_PARTICLES:
 		if (value < 0 || value > 10240) { set_error("tile_particles must be 0 (auto) .. 10240"); return PBDX_ERR_INVALID; }
 		s->tile_particles = (uint32_t)value; replan = true; break;
@@ -1228,7 +1275,9 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	if (!s || !gravity || sub_steps == 0) { set_error("step: bad arguments"); return PBDX_ERR_INVALID; }
 	if (s->schedule_open) { set_error("step: schedule still open"); return PBDX_ERR_INVALID; }
 	HIPCHECK(hipSetDevice(s->device));
+	const bool fresh_plan = !s->plan_built;
 	int rp = ensure_plan(s);
+	if (!rp && fresh_plan) rp = autotune_schedule(s);
 	if (!rp) rp = ensure_trace(s);
 	if (!rp && !s->fused_active()) rp = ensure_device_batches(s);
 	if (rp) return rp;
@@ -1309,7 +1358,9 @@ int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
 {
 	if (!s || s->schedule_open) { set_error("project: bad state"); return PBDX_ERR_INVALID; }
 	HIPCHECK(hipSetDevice(s->device));
+	const bool fresh_plan = !s->plan_built;
 	int r = ensure_plan(s);
+	if (!r && fresh_plan) r = autotune_schedule(s);
 	if (!r) r = ensure_trace(s);
 	if (!r && !s->fused_active()) r = ensure_device_batches(s);
 	if (r) return r;
@@ -1531,11 +1582,17 @@ int pbdx_solver_describe(pbdx_solver *s, char *buf, size_t n)
 		{
 			uint32_t ml = 0;
 			for (const FusedSegment &seg : s->plan.segs) ml = std::max(ml, seg.max_local);
-			snprintf(buf + w, n - w, " schedule=fused segments=%zu tiles=%u redundancy=%.3f max_tile_particles=%u plan_s=%.2f",
+			int w2 = snprintf(buf + w, n - w, " schedule=fused segments=%zu tiles=%u redundancy=%.3f max_tile_particles=%u plan_s=%.2f",
 				s->plan.segs.size(), s->plan.num_tiles, s->plan.redundancy, ml, s->plan.build_seconds);
+			if (s->autotune_ms[1] > 0.0f && w2 > 0 && (size_t)(w + w2) < n)
+				snprintf(buf + w + w2, n - w - w2, " autotune(per-colour %.3f ms, fused %.3f ms)", s->autotune_ms[0], s->autotune_ms[1]);
 		}
 		else
-			snprintf(buf + w, n - w, " schedule=per-colour%s%s", s->plan_built && !s->plan_ok ? " plan_failed=" : "", s->plan_built && !s->plan_ok ? s->plan_why.c_str() : "");
+		{
+			int w2 = snprintf(buf + w, n - w, " schedule=per-colour%s%s", s->plan_built && !s->plan_ok ? " plan_failed=" : "", s->plan_built && !s->plan_ok ? s->plan_why.c_str() : "");
+			if (s->autotune_ms[1] > 0.0f && w2 > 0 && (size_t)(w + w2) < n)
+				snprintf(buf + w + w2, n - w - w2, " autotune(per-colour %.3f ms, fused %.3f ms)", s->autotune_ms[0], s->autotune_ms[1]);
+		}
 	}
 	return PBDX_OK;
 }

@@ -231,14 +231,14 @@ def test_resident_equals_roundtrip_and_options_are_invariant(pbd):
                       ("block 128 resident", dict(resident=True, options={S.OPT_BLOCK_SIZE: 128})),
                       ("per-colour schedule", dict(options={S.OPT_FUSE: 0})),
                       ("per-colour, no remap, eager", dict(options={S.OPT_FUSE: 0, S.OPT_XCD_REMAP: 0, S.OPT_USE_GRAPH: 0})),
-                      ("fused, 100-particle tiles", dict(options={S.OPT_TILE_PARTICLES: 100})),
-                      ("fused, 700-particle tiles, 256 threads", dict(options={S.OPT_TILE_PARTICLES: 700, S.OPT_FUSE_BLOCK: 256})),
-                      ("fused, at most 3 colours per launch", dict(options={S.OPT_MAX_SEGMENT_COLOURS: 3})),
-                      ("fused, one colour per launch, resident", dict(resident=True, options={S.OPT_MAX_SEGMENT_COLOURS: 1})),
-                      ("fused, small LDS", dict(options={S.OPT_TILE_PARTICLES: 200, S.OPT_LDS_PARTICLES: 500})),
-                      ("fused, 1024 threads, no remap", dict(options={S.OPT_FUSE_BLOCK: 1024, S.OPT_XCD_REMAP: 0})),
-                      ("fused, packed pairs", dict(options={S.OPT_PAIRS: 1})),
-                      ("fused, packed pairs, 768 threads, small tiles", dict(options={S.OPT_PAIRS: 1, S.OPT_FUSE_BLOCK: 768, S.OPT_TILE_PARTICLES: 3000}))):
+                      ("fused, 100-particle tiles", dict(options={S.OPT_FUSE: 1, S.OPT_TILE_PARTICLES: 100})),
+                      ("fused, 700-particle tiles, 256 threads", dict(options={S.OPT_FUSE: 1, S.OPT_TILE_PARTICLES: 700, S.OPT_FUSE_BLOCK: 256})),
+                      ("fused, at most 3 colours per launch", dict(options={S.OPT_FUSE: 1, S.OPT_MAX_SEGMENT_COLOURS: 3})),
+                      ("fused, one colour per launch, resident", dict(resident=True, options={S.OPT_FUSE: 1, S.OPT_MAX_SEGMENT_COLOURS: 1})),
+                      ("fused, small LDS", dict(options={S.OPT_FUSE: 1, S.OPT_TILE_PARTICLES: 200, S.OPT_LDS_PARTICLES: 500})),
+                      ("fused, 1024 threads, no remap", dict(options={S.OPT_FUSE: 1, S.OPT_FUSE_BLOCK: 1024, S.OPT_XCD_REMAP: 0})),
+                      ("fused, packed pairs", dict(options={S.OPT_FUSE: 1, S.OPT_PAIRS: 1})),
+                      ("fused, packed pairs, 768 threads, small tiles", dict(options={S.OPT_FUSE: 1, S.OPT_PAIRS: 1, S.OPT_FUSE_BLOCK: 768, S.OPT_TILE_PARTICLES: 3000}))):
         m, ts = util.mine_run(ops, 6, 2, 5, **kw)
         assert util.bitwise_equal(m.getParticles().positions(), xb), label
         assert ts.solver().plan_info()["active"] == (0 if "per-colour" in label else 1), label
@@ -253,7 +253,7 @@ def test_fused_tiles_equal_per_colour_schedule(pbd, name):
     S = pbd.Solver
     ma, tsa = util.mine_run(ops, 4, sub, iters, options={S.OPT_FUSE: 0})
     for tile in (48, 160, 0):
-        mb, tsb = util.mine_run(ops, 4, sub, iters, options={S.OPT_TILE_PARTICLES: tile})
+        mb, tsb = util.mine_run(ops, 4, sub, iters, options={S.OPT_FUSE: 1, S.OPT_TILE_PARTICLES: tile})
         info = tsb.solver().plan_info()
         assert info["active"] == 1 and info["num_tiles"] >= 1
         for which in (0, 2, 4, 5):
@@ -496,3 +496,21 @@ def test_topology_change_between_steps_rebuilds_the_device_image(pbd):
     for _ in range(3):
         ts.step(m)
     assert util.bitwise_equal(m.getParticles().positions(), ref.positions().astype(np.float32))
+
+
+def test_auto_schedule_selection_is_measured_and_result_invariant(pbd):
+    """PBDX_OPT_FUSE = 2 (default): streaming-bound types run fused without measuring; with compute-heavy
+    types (FEM tets here) both schedules are timed once and the faster is kept -- never changing a bit."""
+    S = pbd.Solver
+    cloth = util.cloth_spec(40, 40, 4, 3)
+    m, ts = util.mine_run(cloth, 2, 1, 5)
+    assert ts.solver().plan_info()["active"] == 1 and "autotune" not in ts.solver().describe()
+    bar = util.bar_spec(30, 5, 5, 2)
+    ma, tsa = util.mine_run(bar, 3, 1, 5)                                  # auto
+    d = tsa.solver().describe()
+    print(d)
+    assert "autotune(per-colour" in d
+    for forced in (0, 1):
+        mb, tsb = util.mine_run(bar, 3, 1, 5, options={S.OPT_FUSE: forced})
+        assert tsb.solver().plan_info()["active"] == forced
+        assert util.bitwise_equal(ma.getParticles().positions(), mb.getParticles().positions())

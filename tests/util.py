@@ -47,17 +47,21 @@ def cloth_spec(n_cols, n_rows, cloth_method, bending_method, cloth_k=None, bendi
 
 
 def bar_spec(width, height, depth, solid_method, k=None, kv=None, poisson=0.3, T=(5, 0, 0),
-             scale=(10.0, 1.5, 1.5), ns=False, nsh=False):
-    """Demos/BarDemo/main.cpp:130-166 generalised."""
+             scale=(10.0, 1.5, 1.5), ns=False, nsh=False, instances=1, instance_offset=(0.0, 0.0, 3.0)):
+    """Demos/BarDemo/main.cpp:130-166 generalised (and K independent bars for ensemble runs)."""
     if k is None:
         k = {3: 1000000.0, 6: 100000.0}.get(solid_method, 1.0)
     if kv is None:
         kv = 100000.0 if solid_method == 6 else 1.0
-    ops = [("tet", width, height, depth, T, None, scale)]
-    for j in range(height):
-        for q in range(depth):
-            ops.append(("mass", j * depth + q, 0.0))
-    ops.append(("solid", 0, solid_method, k, poisson, kv, ns, nsh))
+    ops = []
+    n_per = width * height * depth
+    for inst in range(instances):
+        Tk = tuple(np.float32(T[i]) + np.float32(inst) * np.float32(instance_offset[i]) for i in range(3)) if instances > 1 else T
+        ops.append(("tet", width, height, depth, Tk, None, scale))
+        for j in range(height):
+            for q in range(depth):
+                ops.append(("mass", inst * n_per + j * depth + q, 0.0))
+        ops.append(("solid", inst, solid_method, k, poisson, kv, ns, nsh))
     return ops
 
 
