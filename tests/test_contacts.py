@@ -23,6 +23,8 @@ SCENES = {
                                       [("box", (0.5, 0.0, 0.3), (0.9238795, 0.0, 0.0, 0.3826834), (3, 1, 2), (3, 1, 2), 0.5, 0.3, False),
                                        ("sphere", (-2.0, 0.5, 1.0), (1, 0, 0, 0), (2.4, 2.4, 2.4), (1.2,), 0.7, 0.05, False),
                                        ("cylinder", (2.5, -0.5, -2.0), (1, 0, 0, 0), (1.6, 3.0, 1.6), (0.8, 3.0), 0.6, 0.2, False)], 2, 4, 240),
+    "config-5-like: three FEM tet solids on a static floor, 5 substeps x 1 iteration": (
+        util.config5_like_spec(), [("box", (0, 0, 0), (1, 0, 0, 0), (100, 1, 100), (100, 1, 100), 0.6, 0.0, False)], 5, 1, 280),
     "bar inside hollow sphere": (util.bar_spec(8, 3, 3, 6, T=(-1.5, 0.5, -0.3), scale=(3.0, 0.6, 0.6))[:1] + [("solid", 0, 6, 100000.0, 0.3, 100000.0, False, False)],
                                  [("hollow_sphere", (0, 0, 0), (1, 0, 0, 0), (6.2, 6.2, 6.2), (3.0, 0.1), 0.6, 0.2, False)], 1, 5, 200),
 }
@@ -36,7 +38,7 @@ def _setup_ref(ref, ops, colliders, sub, iters, tolerance):
     ref.set_params(sub, iters, 0)
     for shape, pos, quat, bbox, params, rest, fric, inv in colliders:
         ref.add_static_collider(shape, pos, quat, bbox, params, rest, fric, inv)
-    ref.enable_collisions(tolerance, 0.6, 0.1)
+    ref.enable_collisions(tolerance, 0.1, 0.3)
 
 
 @pytest.mark.parametrize("name", list(SCENES))

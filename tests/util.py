@@ -98,6 +98,27 @@ def delaunay_solid_spec(n_points=400, seed=5, solid_method=2):
     return ops
 
 
+def config5_like_spec(n_points=220):
+    """BASELINE configs[4] (data/scenes/ArmadilloCollisionScene.json) in the form this container can pin:
+    three irregular tet solids (FEM tets, method 2, Poisson 0.2) stacked above a static floor.  The armadillo
+    surface / its Discregrid SDF (tet-tet contacts) are not in the tree, so the solids only collide with the
+    floor; they are submitted as ONE tet model with three components (a second tet collision object would make
+    the reference traverse tet-tet pairs, which need that SDF)."""
+    from scipy.spatial import Delaunay
+    all_pts, all_tets = [], []
+    offset = 0
+    for k, (ty, seed) in enumerate(((1.6, 11), (3.4, 12), (5.2, 13))):
+        rng = np.random.default_rng(seed)
+        pts = (rng.random((n_points, 3)) * np.array([1.6, 1.2, 1.4]) + np.array([-0.8 + 0.3 * k, ty, -0.7])).astype(np.float32)
+        tets = Delaunay(pts.astype(np.float64)).simplices
+        p = pts.astype(np.float64)
+        vol = np.abs(np.einsum("ij,ij->i", p[tets[:, 3]] - p[tets[:, 0]], np.cross(p[tets[:, 2]] - p[tets[:, 0]], p[tets[:, 1]] - p[tets[:, 0]]))) / 6.0
+        all_pts.append(pts)
+        all_tets.append(tets[vol > 2e-4].astype(np.uint32) + np.uint32(offset))
+        offset += n_points
+    return [("tetmesh", np.concatenate(all_pts), np.concatenate(all_tets)), ("solid", 0, 2, 1.0, 0.2, 1.0, False, False)]
+
+
 def kitchen_sink_spec():
     """One model with EVERY particle constraint type, so that colour groups mix types (a colour becomes
     several (colour, type) batches / tile steps): a cloth with FEM-triangle + distance + dihedral + PBD
