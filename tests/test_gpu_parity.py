@@ -514,3 +514,46 @@ def test_auto_schedule_selection_is_measured_and_result_invariant(pbd):
         mb, tsb = util.mine_run(bar, 3, 1, 5, options={S.OPT_FUSE: forced})
         assert tsb.solver().plan_info()["active"] == forced
         assert util.bitwise_equal(ma.getParticles().positions(), mb.getParticles().positions())
+
+
+def test_raw_solver_abi_like_a_reference_side_binding(pbd):
+    """pbdx_solver_* driven directly -- particles, one add_batch per (group, type) taken from the REFERENCE's
+    own constraint list and colour groups, step, download -- i.e. exactly what a binding inside the reference
+    does, without the product's model / time step mirrors in between."""
+    ops = util.cloth_spec(36, 28, 4, 3)
+    ref = util.get_oracle("f32")
+    util.apply_ref(ref, ops)
+    ref.set_num_threads(1); ref.set_time_step_size(0.005); ref.set_gravity(util.GRAVITY); ref.set_params(2, 6, 0)
+    x0 = ref.positions().astype(np.float32)
+    mass, inv = ref.get_array(6).astype(np.float32), ref.get_array(7).astype(np.float32)
+    types = ref.constraint_types()
+    groups = ref.groups()
+    sol = pbd.Solver()
+    sol.set_particles(x0, mass, inv)
+    sol.begin_schedule()
+    T = pbd.ConstraintType
+    for g, members in enumerate(groups):
+        for t in sorted(set(types[members].tolist())):
+            sel = [int(c) for c in members if types[c] == t]
+            idx = np.concatenate([ref.constraint_bodies(c) for c in sel]).astype(np.uint32)
+            par = np.concatenate([ref.constraint_params(c) for c in sel]).astype(np.float32)
+            sol.add_batch(g, int(t), idx, par)
+    sol.end_schedule()
+    sol.validate_schedule()
+    sol.step(0.005, 2, 6, 0, util.GRAVITY, num_steps=7)
+    x, v, old, last = sol.get_particles(len(x0))
+    ref.step(7)
+    assert util.bitwise_equal(x, ref.positions().astype(np.float32))
+    assert util.bitwise_equal(v, ref.get_array(2).astype(np.float32))
+    assert util.bitwise_equal(old, ref.get_array(4).astype(np.float32)) and util.bitwise_equal(last, ref.get_array(5).astype(np.float32))
+    info = sol.plan_info()
+    assert info["active"] == 1 and info["num_colours"] == len(groups)
+    # error paths of the raw ABI
+    with pytest.raises(pbd.PbdxError):
+        sol.add_batch(0, T.DISTANCE, np.array([0, 1], dtype=np.uint32), np.array([1.0, 1.0], dtype=np.float32))   # schedule closed
+    sol.begin_schedule()
+    with pytest.raises(pbd.PbdxError):
+        sol.add_batch(0, T.DISTANCE, np.array([0, 10 ** 6], dtype=np.uint32), np.array([1.0, 1.0], dtype=np.float32))   # index out of range
+    with pytest.raises(pbd.PbdxError):
+        sol.add_batch(0, 99, np.array([0, 1], dtype=np.uint32), np.array([1.0, 1.0], dtype=np.float32))          # unknown type
+    sol.end_schedule()
