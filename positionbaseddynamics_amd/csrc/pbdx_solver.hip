@@ -190,11 +190,14 @@ __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStre
 	// the same on every path.  Two consecutive chunks of the SAME step may be projected jointly with packed
 	// arithmetic (PAIRS, pbdx_pair.h); the second sub-iteration then only fetches.
 	bool paired_prev = false;
+	// the descriptor of the chunk to project next is read BEFORE the colour barrier of the previous one,
+	// so that the first thing after a barrier is the LDS gather of the already prefetched record
+	ChunkS ch_next = load_chunk(lchunks, c0);
 	auto sub = [&](Rec<TYPE, COMPACT> &cur, Rec<TYPE, COMPACT> &nxt)
 	{
 		if (c_ex < run_end && !paired_prev)
 		{
-			ChunkS ch = load_chunk(lchunks, c_ex);
+			ChunkS ch = ch_next;
 			const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, a.views[TYPE] };
 			if (PAIRS && HasPair<TYPE>::value && !chunk_last_of_step(ch.info))
 			{
@@ -207,13 +210,14 @@ __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStre
 			}
 			else if (lane_slot < chunk_valid(ch.info))
 				exec_rec<TYPE, COMPACT>(acc, cur, lane_slot, a.dt, a.first_iter);
+			c_ex++;
+			ch_next = load_chunk(lchunks, c_ex < run_end ? c_ex : run_end - 1);
 			if (chunk_last_of_step(ch.info))
 			{
 				if (chunk_barrier(ch.info)) __syncthreads();
 				if (trace && threadIdx.x == 0 && step_counter + 2 < kTraceStride - 1) trace[2 + step_counter] = wall_clock64();
 				step_counter++;
 			}
-			c_ex++;
 		}
 		else
 			paired_prev = false;
