@@ -310,6 +310,11 @@ def main():
     x = model.getParticles().positions()
     x0 = model.getParticles().array(1)
     ok = bool(np.all(np.isfinite(x)) and all(np.array_equal(x[p], x0[p]) for p in pins))
+    # cross-GPU parity: every rank simulated the same synthetic scene, so every rank must hold the same bits
+    # (one tiny all-reduce of per-rank checksums; the only other collectives are the barrier and the max time)
+    from positionbaseddynamics_amd.ensemble import checksum
+    sums = ens.gather_checksums([checksum(x)], world)
+    replicas_identical = len(set(sums)) == 1
 
     # PCIe-inclusive rate of the TimeStep::step contract (host ParticleData in -> step -> host ParticleData
     # out every step); reported for information only, never `value`
@@ -355,7 +360,7 @@ def main():
         "config": {"workload": workload_desc,
                    "particles": n_particles, "constraints": n_constraints, "colour_groups": n_groups,
                    "projections_per_substep": projections_per_step, "parallelism": "ensemble x%d (independent instances per GPU, no cross-GPU constraints, no data-path collective)" % world,
-                   "state_ok": ok, "device_event_ms_per_substep": stats["total_ms"] / max(args.steps, 1),
+                   "state_ok": ok, "replicas_bit_identical": replicas_identical, "state_checksum": "%016x" % sums[0], "device_event_ms_per_substep": stats["total_ms"] / max(args.steps, 1),
                    "algorithmic_GB_per_substep": stats["algorithmic_bytes"] / max(args.steps, 1) / 1e9,
                    "whole_substep_algorithmic_GBs": stats["algorithmic_bytes"] / max(stats["total_ms"], 1e-9) / 1e6,
                    "host_scene_build_s": t_build, "contacts": contact_info, "pcie_inclusive_ms_per_step": None if t_pcie is None else 1e3 * t_pcie,
