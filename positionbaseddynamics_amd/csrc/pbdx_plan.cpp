@@ -100,6 +100,13 @@ void closure(const Graph &g, Scratch &s, const uint32_t *owned, uint32_t n_owned
 	}
 }
 
+// measured on MI355X with 1024-thread tiles (ns per slot of a tile; types not measured are scaled by their
+// instruction count)
+const double kSlotNs[PBDX_NUM_CONSTRAINT_TYPES] = { 0.8, 0.83, 1.6, 1.4, 1.46, 1.8, 2.2, 1.2, 1.25, 3.0, 3.2, 4.0, 5.0 };
+const double kColourFixedNs = 900.0;
+const double kFillNsPerParticle = 0.74;
+const double kWriteBackNsPerParticle = 0.47;
+
 uint32_t slot_bytes(const TypeView &v, int type)
 {
 	const TypeInfo *ti = type_info(type);
@@ -320,12 +327,17 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 			const uint32_t c_lo = c1 > maxlen ? c1 - maxlen : 0;
 			Scratch &s = scratch[th];
 			const uint32_t n_owned = tile_begin[t + 1] - tile_begin[t];
-			double bytes = 0.0;
+			double steps_ns = 0.0;
 			closure(g, s, perm.data() + tile_begin[t], n_owned, c_lo, c1, [&](uint32_t c) {
-				for (uint32_t cid : s.bucket[c - c_lo]) bytes += slot_bytes(plan.views[g.batch_of(cid).type], g.batch_of(cid).type);
+				// time model of one tile (ns), from the per-step traces of the fused kernel: a fixed
+				// cost per colour the tile takes part in (barrier + one projection chain), a per-slot cost by type
+				// (the sweep is latency / issue bound, not byte bound), LDS fill and write-back per particle
+				const std::vector<uint32_t> &bk = s.bucket[c - c_lo];
+				if (!bk.empty()) steps_ns += kColourFixedNs;
+				for (uint32_t cid : bk) steps_ns += kSlotNs[g.batch_of(cid).type];
 				const uint32_t n_local = n_owned + (uint32_t)s.halo.size();
 				const size_t e = (size_t)c1 * maxlen + (c1 - c - 1);
-				tb[th][e] += bytes + 16.0 * (n_local + n_owned);
+				tb[th][e] += steps_ns + kFillNsPerParticle * n_local + kWriteBackNsPerParticle * n_owned;
 				tm[th][e] = std::max(tm[th][e], n_local);
 			});
 		});
@@ -336,7 +348,8 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 				seg_maxlocal[e] = std::max(seg_maxlocal[e], tm[th][e]);
 			}
 	}
-	const double scale = (double)k / nsample;
+	// tiles run concurrently, one per CU: a segment takes (mean tile time) x (waves of tiles) + one launch
+	const double scale = (double)((k + opt.num_cus - 1) / std::max(1u, opt.num_cus)) / nsample;
 	const uint32_t cap_dp = (uint32_t)(opt.max_local * (nsample < k ? 0.95 : 1.0));
 	std::vector<double> best(ncol + 1, 1e300);
 	std::vector<uint32_t> prev(ncol + 1, 0);
@@ -346,7 +359,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 		{
 			const size_t e = (size_t)c1 * maxlen + (len - 1);
 			if (len > 1 && seg_maxlocal[e] > cap_dp) break;       // closures only grow with the length
-			const double cst = best[c1 - len] + seg_bytes[e] * scale + opt.launch_cost_bytes;
+			const double cst = best[c1 - len] + seg_bytes[e] * scale + opt.launch_cost_ns;
 			if (cst < best[c1]) { best[c1] = cst; prev[c1] = c1 - len; }
 		}
 	std::vector<std::pair<uint32_t, uint32_t>> todo;

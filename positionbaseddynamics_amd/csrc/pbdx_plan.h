@@ -165,7 +165,7 @@ struct PlanOptions
 	uint32_t num_cus = 256;
 	uint32_t max_segment_colours = 16;
 	uint32_t max_tile_steps = 64;       // (colour, type) runs one tile may have in one segment
-	double launch_cost_bytes = 12.0e6;  // cost of one more launch expressed in streamed bytes
+	double launch_cost_ns = 3000.0;     // cost of one more launch (kernel boundary + tail)
 	uint32_t threads = 0;               // 0 = auto
 };
 
