@@ -23,6 +23,14 @@ namespace {
 
 const float kEps = 1e-6f;
 
+// reserve room for `extra` more elements WITHOUT defeating the vector's geometric growth (an exact
+// reserve per bulk builder call made a model of K instances cost O(K^2) to build)
+template <class T> inline void grow_for(std::vector<T> &v, size_t extra)
+{
+	const size_t need = v.size() + extra;
+	if (need > v.capacity()) v.reserve(need > 2 * v.capacity() ? need : 2 * v.capacity());
+}
+
 inline V3 ld(const std::vector<float> &a, uint32_t i) { return mk(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
 inline void st(std::vector<float> &a, uint32_t i, V3 v) { a[3 * i] = v.x; a[3 * i + 1] = v.y; a[3 * i + 2] = v.z; }
 
@@ -654,7 +662,7 @@ int pbdx_model_add_cloth_constraints(pbdx_model *m, uint32_t tmi, uint32_t metho
 	if (method == 1 || method == 4)
 	{
 		const size_t ne = m->tri_models[tmi].edges.size();
-		m->constraints.reserve(m->constraints.size() + ne);
+		grow_for(m->constraints, ne);
 		for (size_t i = 0; i < ne; i++)
 		{
 			const TriMesh::Edge e = m->tri_models[tmi].edges[i];
@@ -684,7 +692,7 @@ int pbdx_model_add_bending_constraints(pbdx_model *m, uint32_t tmi, uint32_t met
 		return PBDX_OK;
 	const uint32_t offset = m->tri_models[tmi].index_offset;
 	const size_t ne = m->tri_models[tmi].edges.size();
-	m->constraints.reserve(m->constraints.size() + ne);
+	grow_for(m->constraints, ne);
 	for (size_t i = 0; i < ne; i++)
 	{
 		const TriMesh::Edge e = m->tri_models[tmi].edges[i];
