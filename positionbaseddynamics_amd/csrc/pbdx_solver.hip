@@ -159,8 +159,66 @@ __device__ __forceinline__ bool chunk_last_of_step(uint32_t info) { return (info
 __device__ __forceinline__ uint32_t chunk_valid(uint32_t info) { return (info >> 8) & 0x7ffu; }
 __device__ __forceinline__ uint32_t chunk_run_left(uint32_t info) { return info >> 19; }
 
+// HBM -> LDS copy of 16 bytes per lane without a register in between (global_load_lds_dwordx4: lane l of the wave
+// lands at lds_wave_base + 16 l).  Issued as inline assembly on purpose: with the builtin the compiler drains
+// vmcnt to 0 in front of every such copy (it cannot order them against the other outstanding loads), which
+// serialises the batch.  The copies are therefore invisible to the compiler's wait-count bookkeeping; that is
+// safe because (a) vmcnt retires in order, so its own waits can only become stricter, and (b) lds_dma_wait()
+// drains everything before the barrier that publishes the tile.
+__device__ __forceinline__ void lds_dma16(const float4 *base, uint32_t index, float4 *lds_wave_base)
+{
+	const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4 *)lds_wave_base);
+	const uint32_t boff = index * 16u;        // scalar base + 32-bit lane offset: one address register per copy
+	uint32_t saved;      // M0 is a reserved register: preserved around the copy
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+		: "=&s"(saved) : "v"(boff), "s"(base), "s"(m0v) : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// LDS fill of a tile (called by the tile's first run once its ring is primed).  gid -> position is a dependent
+// pair of HBM round trips; written as a plain loop every thread pays that pair once per particle it stages
+// (7 x 2 serialised latencies for a 7 000-particle tile).  The loads are issued in batches instead: the chunk
+// descriptor, then kFillBatch particle ids, then their kFillBatch positions -- two exposed latencies per batch,
+// one batch for most tiles.
+constexpr uint32_t kMaxTileChunks = 256;
+template <int BLOCK> struct TileFill
+{
+	const uint4 *src;            // the tile's chunk descriptors in the plan
+	const uint32_t *gid;
+	const float4 *pos_in;
+	uint4 *lchunks;
+	float4 *lpos;
+	uint32_t num_chunks, n_local;
+	unsigned long long *trace;
+
+	// Eight particles per thread and batch.  The positions go from HBM straight into LDS (lds_dma16), so a
+	// batch holds eight ids in registers and nothing else.  All eight ids are consumed by one empty asm statement:
+	// the compiler waits for them once and places no wait (stricter than necessary, see lds_dma16) between the copies.
+	__device__ __forceinline__ void operator()() const
+	{
+		static_assert(BLOCK >= (int)kMaxTileChunks, "one chunk descriptor per thread");
+		uint4 chv = make_uint4(0u, 0u, 0u, 0u);       // this thread's chunk descriptor: in flight with the ids
+		if (threadIdx.x < num_chunks) chv = src[threadIdx.x];
+		const uint32_t last = n_local - 1u;
+		for (uint32_t base = threadIdx.x; base < n_local; base += 8u * BLOCK)
+		{
+#define PBDX_G(k) const uint32_t i##k = base + k * BLOCK; const uint32_t g##k = gid[i##k < last ? i##k : last];
+#define PBDX_D(k) if (i##k < n_local) lds_dma16(pos_in, g##k, lpos + (i##k & ~63u));
+			PBDX_G(0) PBDX_G(1) PBDX_G(2) PBDX_G(3) PBDX_G(4) PBDX_G(5) PBDX_G(6) PBDX_G(7)
+			asm volatile("" :: "v"(g0), "v"(g1), "v"(g2), "v"(g3), "v"(g4), "v"(g5), "v"(g6), "v"(g7));
+			PBDX_D(0) PBDX_D(1) PBDX_D(2) PBDX_D(3) PBDX_D(4) PBDX_D(5) PBDX_D(6) PBDX_D(7)
+#undef PBDX_G
+#undef PBDX_D
+		}
+		if (threadIdx.x < num_chunks) lchunks[threadIdx.x] = chv;
+		lds_dma_wait();
+		__syncthreads();
+		if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
+	}
+};
+
 template <int TYPE, bool COMPACT, int BLOCK, bool PAIRS>
-__device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStreams &str, const uint4 *lchunks, uint32_t c0, uint32_t c_end,
+__device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStreams &str, const uint4 *lchunks, uint32_t c0,
 	float4 *lpos, unsigned long long *trace, uint32_t &step_counter)
 {
 	constexpr int D = Depth<TYPE>::value;
@@ -170,7 +228,6 @@ __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStre
 	const uint32_t v_par = (threadIdx.x >> 6) * (uint32_t)(num_planes(TYPE, COMPACT) * 256) + (threadIdx.x & 63u) * 4u;
 	// end of the run (first chunk of another type): precomputed on the host
 	const uint32_t run_end = c0 + chunk_run_left(rfl(lchunks[c0].x));
-	(void)c_end;
 
 	uint32_t c_ld = c0, c_ex = c0;
 	// the ring lives in named records (not an array): keeps every record in registers
@@ -233,12 +290,11 @@ __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStre
 }
 
 #define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) { \
-		c = a.views[T].compact ? run_typed<T, true, BLOCK, PAIRS>(a, str, lchunks, c, num_chunks, lpos, trace, step_counter) \
-		                       : run_typed<T, false, BLOCK, PAIRS>(a, str, lchunks, c, num_chunks, lpos, trace, step_counter); } \
+		c = a.views[T].compact ? run_typed<T, true, BLOCK, PAIRS>(a, str, lchunks, c, lpos, trace, step_counter) \
+		                       : run_typed<T, false, BLOCK, PAIRS>(a, str, lchunks, c, lpos, trace, step_counter); } \
 	else { c = num_chunks; } break;
 
 // LDS: [ chunk descriptors of the tile: kMaxTileChunks x 16 B ][ positions: n_local x float4 ]
-constexpr uint32_t kMaxTileChunks = 256;
 constexpr uint32_t kMaxTileSteps = 64;
 
 template <uint32_t MASK, int BLOCK, bool PAIRS>
@@ -253,26 +309,19 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 	if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
 	const uint32_t *gid = a.gid + t.gid_off;
 	const uint32_t num_chunks = t.chunk_end - t.chunk_begin;
-	{
-		const uint4 *src = reinterpret_cast<const uint4 *>(a.chunks + t.chunk_begin);
-		for (uint32_t i = threadIdx.x; i < num_chunks; i += BLOCK)
-			lchunks[i] = src[i];
-	}
-	for (uint32_t i = threadIdx.x; i < t.n_local; i += BLOCK)
-		lpos[i] = a.pos_in[gid[i]];
-	__syncthreads();
-	if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
 	// stream descriptors, from kernel arguments only (wave-uniform by construction)
 	TileStreams str;
 	str.idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.idx), 0, a.idx_bytes, 0x00020000);
 	str.par = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.params), 0, a.params_bytes, 0x00020000);
 	str.lam = __builtin_amdgcn_make_buffer_rsrc(a.lambda, 0, a.lambda_bytes, 0x00020000);
+	const FusedChunk *gchunks = a.chunks + t.chunk_begin;
+	const TileFill<BLOCK> fill = { reinterpret_cast<const uint4 *>(gchunks), gid, a.pos_in, lchunks, lpos, num_chunks, t.n_local, trace };
+	fill();
 	// chunks are addressed relative to the tile from here on (they sit at lchunks[0 .. num_chunks))
 	uint32_t c = 0, step_counter = 0;
 	while (c < num_chunks)
 	{
-		const uint32_t type = chunk_type(rfl(lchunks[c].x));
-		switch (type)
+		switch (chunk_type(rfl(lchunks[c].x)))
 		{
 			PBDX_CASE(PBDX_DISTANCE) PBDX_CASE(PBDX_DISTANCE_XPBD) PBDX_CASE(PBDX_DIHEDRAL)
 			PBDX_CASE(PBDX_ISOMETRIC_BENDING) PBDX_CASE(PBDX_ISOMETRIC_BENDING_XPBD)
@@ -283,8 +332,19 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 		default: c = num_chunks; break;
 		}
 	}
-	for (uint32_t i = threadIdx.x; i < t.n_owned; i += BLOCK)
-		a.pos_out[gid[i]] = lpos[i];
+	// write-back of the owned particles, ids batched like the fill
+	{
+		constexpr uint32_t kWbBatch = 4;
+		const uint32_t last = t.n_owned - 1u;
+		for (uint32_t base = threadIdx.x; base < t.n_owned; base += kWbBatch * BLOCK)
+		{
+			uint32_t g[kWbBatch];
+#pragma unroll
+			for (uint32_t k = 0; k < kWbBatch; k++) { const uint32_t i = base + k * BLOCK; g[k] = gid[i < last ? i : last]; }
+#pragma unroll
+			for (uint32_t k = 0; k < kWbBatch; k++) { const uint32_t i = base + k * BLOCK; a.pos_out[g[k]] = lpos[i < last ? i : last]; }
+		}
+	}
 	if (trace && threadIdx.x == 0)
 	{
 		__builtin_amdgcn_s_waitcnt(0);
