@@ -213,7 +213,10 @@ enum {
 	PBDX_OPT_PIN_HOST = 11,        /* page-lock (hipHostRegister) the caller's particle arrays passed to set/get_particles so that
 	                                * transfers DMA at full PCIe rate; the arrays must stay allocated until the option is cleared or the
 	                                * solver destroyed (default 0) */
-	PBDX_OPT_PAIRS = 10            /* project two chunks of a colour step jointly with packed fp32 arithmetic (default 0: measured slower) */
+	PBDX_OPT_PAIRS = 10,           /* project two chunks of a colour step jointly with packed fp32 arithmetic (default 0: measured slower) */
+	PBDX_OPT_PERSISTENT = 12       /* fused schedule only: all sweeps of a substep as ONE launch; a tile starts its next pass as soon as its
+	                                * neighbouring tiles have published theirs (no kernel boundary, no chip-wide wait for the slowest tile).
+	                                * Needs every workgroup co-resident; a bounded wait turns a violation into an error status, never a hang. */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
 

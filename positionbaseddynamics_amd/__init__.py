@@ -702,6 +702,7 @@ class Solver:
     OPT_TRACE = 9
     OPT_PAIRS = 10
     OPT_PIN_HOST = 11
+    OPT_PERSISTENT = 12
     OPT_USE_GRAPH = 1
     OPT_BLOCK_SIZE = 2
     OPT_XCD_REMAP = 3

@@ -68,7 +68,10 @@ struct TileStreams
 	__amdgpu_buffer_rsrc_t idx, par, lam;
 };
 
-template <int TYPE, bool COMPACT> struct TileAccess
+// COHERENT (persistent schedule): the multiplier stream is re-read by the same workgroup one iteration later
+// INSIDE one launch; the CU's vector L1 may still hold the line from before the store (no kernel boundary
+// invalidates it), so those loads go past the L1 (sc1: served by the XCD's L2, which does see the CU's own stores).
+template <int TYPE, bool COMPACT, bool COHERENT = false> struct TileAccess
 {
 	float4 *pos;               // LDS
 	const TileStreams &str;
@@ -106,7 +109,7 @@ template <int TYPE, bool COMPACT> struct TileAccess
 		return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.par, (int)(v_par + plane * 256u), (int)par_soff, 0));
 	}
 	__device__ __forceinline__ bool sym() const { return COMPACT; }
-	__device__ __forceinline__ float lam_load(uint32_t i) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.lam, (int)(i * 4u), (int)lam_soff, 0)); }
+	__device__ __forceinline__ float lam_load(uint32_t i) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.lam, (int)(i * 4u), (int)lam_soff, COHERENT ? 16 : 0)); }
 	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), str.lam, (int)(i * 4u), (int)lam_soff, 0); }
 };
 

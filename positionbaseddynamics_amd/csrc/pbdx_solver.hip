@@ -96,10 +96,9 @@ project_fn kProjectKernels[PBDX_NUM_CONSTRAINT_TYPES][2] = {
 // ------------------------------------------------------------------------------------------------
 // (A) colour-fused tile kernel
 // ------------------------------------------------------------------------------------------------
-struct FusedArgs
+// the plan image of one segment (read-only except the multiplier stream, which is private per tile)
+struct SegArgs
 {
-	const float4 *pos_in;
-	float4 *pos_out;
 	const FusedTile *tiles;
 	const FusedChunk *chunks;
 	const uint16_t *idx;
@@ -107,14 +106,27 @@ struct FusedArgs
 	float *lambda;
 	const uint32_t *gid;
 	uint32_t idx_bytes, params_bytes, lambda_bytes;   // stream sizes (buffer descriptors)
+	uint32_t num_tiles;
+};
+struct FusedArgs
+{
+	const float4 *pos_in;
+	float4 *pos_out;
+	SegArgs seg;
 	float dt;
 	int first_iter;
-	uint32_t num_tiles;
 	int xcd_remap;
 	// developer trace (PBDX_OPT_TRACE): per tile kTraceStride wall-clock stamps (100 MHz):
 	// [0] kernel entry, [1] LDS filled, [2+i] step i done (after its barrier), [last] tile written back
 	unsigned long long *trace;
 	TypeView views[PBDX_NUM_CONSTRAINT_TYPES];
+};
+// what a run needs besides the streams
+struct RunArgs
+{
+	float dt;
+	int first_iter;
+	const TypeView *views;
 };
 constexpr uint32_t kTraceStride = 80;
 
@@ -165,13 +177,34 @@ __device__ __forceinline__ uint32_t chunk_run_left(uint32_t info) { return info 
 // serialises the batch.  The copies are therefore invisible to the compiler's wait-count bookkeeping; that is
 // safe because (a) vmcnt retires in order, so its own waits can only become stricter, and (b) lds_dma_wait()
 // drains everything before the barrier that publishes the tile.
+// COHERENT (persistent schedule, positions handed from tile to tile inside one launch): agent-scope `sc1` on
+// both sides -- sc1 stores are written through, sc1 loads are served past the CU's L1 (MI355X_MICROARCH: "16 B
+// sc1 stores AND sc1 loads" is a valid cross-XCD hand-off).
+template <bool COHERENT>
 __device__ __forceinline__ void lds_dma16(const float4 *base, uint32_t index, float4 *lds_wave_base)
 {
 	const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4 *)lds_wave_base);
 	const uint32_t boff = index * 16u;        // scalar base + 32-bit lane offset: one address register per copy
 	uint32_t saved;      // M0 is a reserved register: preserved around the copy
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-		: "=&s"(saved) : "v"(boff), "s"(base), "s"(m0v) : "memory");
+	if constexpr (COHERENT)
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+			: "=&s"(saved) : "v"(boff), "s"(base), "s"(m0v) : "memory");
+	else
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+			: "=&s"(saved) : "v"(boff), "s"(base), "s"(m0v) : "memory");
+}
+// write-back store of one position
+template <bool COHERENT>
+__device__ __forceinline__ void store_pos(float4 *base, uint32_t index, float4 v)
+{
+	if constexpr (COHERENT)
+	{
+		typedef float f4 __attribute__((ext_vector_type(4)));
+		f4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+		asm volatile("global_store_dwordx4 %0, %1, %2 sc1" :: "v"(index * 16u), "v"(w), "s"(base) : "memory");
+	}
+	else
+		base[index] = v;
 }
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -181,7 +214,7 @@ __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0
 // descriptor, then kFillBatch particle ids, then their kFillBatch positions -- two exposed latencies per batch,
 // one batch for most tiles.
 constexpr uint32_t kMaxTileChunks = 256;
-template <int BLOCK> struct TileFill
+template <int BLOCK, bool COHERENT> struct TileFill
 {
 	const uint4 *src;            // the tile's chunk descriptors in the plan
 	const uint32_t *gid;
@@ -189,27 +222,36 @@ template <int BLOCK> struct TileFill
 	uint4 *lchunks;
 	float4 *lpos;
 	uint32_t num_chunks, n_local;
+	uint32_t first;              // local particles [0, first) are already in LDS (multiple of 64; 0 = stage everything)
 	unsigned long long *trace;
 
 	// Eight particles per thread and batch.  The positions go from HBM straight into LDS (lds_dma16), so a
 	// batch holds eight ids in registers and nothing else.  All eight ids are consumed by one empty asm statement:
 	// the compiler waits for them once and places no wait (stricter than necessary, see lds_dma16) between the copies.
-	__device__ __forceinline__ void operator()() const
+	// `wait` runs after the first batch of ids is in flight and before any position is read: the persistent
+	// schedule waits for the neighbouring tiles there (the ids do not depend on them).
+	template <class Wait> __device__ __forceinline__ void operator()(const Wait &wait) const
 	{
 		static_assert(BLOCK >= (int)kMaxTileChunks, "one chunk descriptor per thread");
 		uint4 chv = make_uint4(0u, 0u, 0u, 0u);       // this thread's chunk descriptor: in flight with the ids
 		if (threadIdx.x < num_chunks) chv = src[threadIdx.x];
 		const uint32_t last = n_local - 1u;
-		for (uint32_t base = threadIdx.x; base < n_local; base += 8u * BLOCK)
-		{
 #define PBDX_G(k) const uint32_t i##k = base + k * BLOCK; const uint32_t g##k = gid[i##k < last ? i##k : last];
-#define PBDX_D(k) if (i##k < n_local) lds_dma16(pos_in, g##k, lpos + (i##k & ~63u));
-			PBDX_G(0) PBDX_G(1) PBDX_G(2) PBDX_G(3) PBDX_G(4) PBDX_G(5) PBDX_G(6) PBDX_G(7)
-			asm volatile("" :: "v"(g0), "v"(g1), "v"(g2), "v"(g3), "v"(g4), "v"(g5), "v"(g6), "v"(g7));
-			PBDX_D(0) PBDX_D(1) PBDX_D(2) PBDX_D(3) PBDX_D(4) PBDX_D(5) PBDX_D(6) PBDX_D(7)
+#define PBDX_D(k) if (i##k < n_local) lds_dma16<COHERENT>(pos_in, g##k, lpos + (i##k & ~63u));
+#define PBDX_BATCH(BETWEEN) { \
+			PBDX_G(0) PBDX_G(1) PBDX_G(2) PBDX_G(3) PBDX_G(4) PBDX_G(5) PBDX_G(6) PBDX_G(7) \
+			BETWEEN; \
+			asm volatile("" :: "v"(g0), "v"(g1), "v"(g2), "v"(g3), "v"(g4), "v"(g5), "v"(g6), "v"(g7)); \
+			PBDX_D(0) PBDX_D(1) PBDX_D(2) PBDX_D(3) PBDX_D(4) PBDX_D(5) PBDX_D(6) PBDX_D(7) }
+		// first batch: executed by every thread (ids clamped, copies guarded per lane), so that wait() -- which
+		// contains a workgroup barrier -- sits at ONE point of the program for all waves
+		uint32_t base = first + threadIdx.x;
+		PBDX_BATCH(wait())
+		for (base += 8u * BLOCK; base < n_local; base += 8u * BLOCK)
+			PBDX_BATCH((void)0)
+#undef PBDX_BATCH
 #undef PBDX_G
 #undef PBDX_D
-		}
 		if (threadIdx.x < num_chunks) lchunks[threadIdx.x] = chv;
 		lds_dma_wait();
 		__syncthreads();
@@ -217,12 +259,12 @@ template <int BLOCK> struct TileFill
 	}
 };
 
-template <int TYPE, bool COMPACT, int BLOCK, bool PAIRS>
-__device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStreams &str, const uint4 *lchunks, uint32_t c0,
+template <int TYPE, bool COMPACT, int BLOCK, bool PAIRS, bool COHERENT>
+__device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStreams &str, const uint4 *lchunks, uint32_t c0,
 	float4 *lpos, unsigned long long *trace, uint32_t &step_counter)
 {
 	constexpr int D = Depth<TYPE>::value;
-	typedef TileAccess<TYPE, COMPACT> Acc;
+	typedef TileAccess<TYPE, COMPACT, COHERENT> Acc;
 	// per-lane constants of the run
 	const uint32_t lane_slot = threadIdx.x;
 	const uint32_t v_par = (threadIdx.x >> 6) * (uint32_t)(num_planes(TYPE, COMPACT) * 256) + (threadIdx.x & 63u) * 4u;
@@ -290,33 +332,33 @@ __device__ __forceinline__ uint32_t run_typed(const FusedArgs &a, const TileStre
 }
 
 #define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) { \
-		c = a.views[T].compact ? run_typed<T, true, BLOCK, PAIRS>(a, str, lchunks, c, lpos, trace, step_counter) \
-		                       : run_typed<T, false, BLOCK, PAIRS>(a, str, lchunks, c, lpos, trace, step_counter); } \
+		c = ra.views[T].compact ? run_typed<T, true, BLOCK, PAIRS, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter) \
+		                        : run_typed<T, false, BLOCK, PAIRS, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter); } \
 	else { c = num_chunks; } break;
 
 // LDS: [ chunk descriptors of the tile: kMaxTileChunks x 16 B ][ positions: n_local x float4 ]
 constexpr uint32_t kMaxTileSteps = 64;
 
-template <uint32_t MASK, int BLOCK, bool PAIRS>
-__global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
+// One tile of one segment: LDS fill, colour sweep, write-back of the owned particles.
+// `keep_owned`: the tile's owned particles are still in LDS from its previous pass (persistent schedule, same
+// workgroup, same owned set in every segment): only the halo is staged.  `wait`: see TileFill.
+template <uint32_t MASK, int BLOCK, bool PAIRS, bool COHERENT, class Wait>
+__device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &ra, const float4 *pos_in, float4 *pos_out, uint32_t tile_index,
+	unsigned long long *trace, uint4 *lchunks, float4 *lpos, bool keep_owned, const Wait &wait)
 {
-	extern __shared__ uint4 lds_raw[];
-	uint4 *lchunks = lds_raw;
-	float4 *lpos = reinterpret_cast<float4 *>(lds_raw + kMaxTileChunks);
-	const uint32_t tile_index = logical_block(a.num_tiles, a.xcd_remap);
-	const FusedTile t = a.tiles[tile_index];
-	unsigned long long *trace = a.trace ? a.trace + (size_t)tile_index * kTraceStride : nullptr;
+	const FusedTile t = sg.tiles[tile_index];
 	if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
-	const uint32_t *gid = a.gid + t.gid_off;
+	const uint32_t *gid = sg.gid + t.gid_off;
 	const uint32_t num_chunks = t.chunk_end - t.chunk_begin;
 	// stream descriptors, from kernel arguments only (wave-uniform by construction)
 	TileStreams str;
-	str.idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.idx), 0, a.idx_bytes, 0x00020000);
-	str.par = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.params), 0, a.params_bytes, 0x00020000);
-	str.lam = __builtin_amdgcn_make_buffer_rsrc(a.lambda, 0, a.lambda_bytes, 0x00020000);
-	const FusedChunk *gchunks = a.chunks + t.chunk_begin;
-	const TileFill<BLOCK> fill = { reinterpret_cast<const uint4 *>(gchunks), gid, a.pos_in, lchunks, lpos, num_chunks, t.n_local, trace };
-	fill();
+	str.idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(sg.idx), 0, sg.idx_bytes, 0x00020000);
+	str.par = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sg.params), 0, sg.params_bytes, 0x00020000);
+	str.lam = __builtin_amdgcn_make_buffer_rsrc(sg.lambda, 0, sg.lambda_bytes, 0x00020000);
+	const FusedChunk *gchunks = sg.chunks + t.chunk_begin;
+	const TileFill<BLOCK, COHERENT> fill = { reinterpret_cast<const uint4 *>(gchunks), gid, pos_in, lchunks, lpos, num_chunks, t.n_local,
+		keep_owned ? (t.n_owned & ~63u) : 0u, trace };
+	fill(wait);
 	// chunks are addressed relative to the tile from here on (they sit at lchunks[0 .. num_chunks))
 	uint32_t c = 0, step_counter = 0;
 	while (c < num_chunks)
@@ -342,7 +384,7 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 #pragma unroll
 			for (uint32_t k = 0; k < kWbBatch; k++) { const uint32_t i = base + k * BLOCK; g[k] = gid[i < last ? i : last]; }
 #pragma unroll
-			for (uint32_t k = 0; k < kWbBatch; k++) { const uint32_t i = base + k * BLOCK; a.pos_out[g[k]] = lpos[i < last ? i : last]; }
+			for (uint32_t k = 0; k < kWbBatch; k++) { const uint32_t i = base + k * BLOCK; store_pos<COHERENT>(pos_out, g[k], lpos[i < last ? i : last]); }
 		}
 	}
 	if (trace && threadIdx.x == 0)
@@ -352,7 +394,109 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 	}
 }
 
+template <uint32_t MASK, int BLOCK, bool PAIRS>
+__global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
+{
+	extern __shared__ uint4 lds_raw[];
+	uint4 *lchunks = lds_raw;
+	float4 *lpos = reinterpret_cast<float4 *>(lds_raw + kMaxTileChunks);
+	const uint32_t tile_index = logical_block(a.seg.num_tiles, a.xcd_remap);
+	unsigned long long *trace = a.trace ? a.trace + (size_t)tile_index * kTraceStride : nullptr;
+	const RunArgs ra = { a.dt, a.first_iter, a.views };
+	process_tile<MASK, BLOCK, PAIRS, false>(a.seg, ra, a.pos_in, a.pos_out, tile_index, trace, lchunks, lpos, false, [] {});
+}
+
+// ---- (A') persistent schedule: all launches of a substep's sweeps as ONE launch ---------------------------
+// The per-segment launches of (A) are separated by kernel boundaries: ~3.2 us of dead time each plus the wait for
+// the slowest of 256 tiles (step traces: 5-10 % of a launch).  Here one workgroup per tile stays resident for all
+// `passes` = iterations x segments and a tile starts pass p as soon as the tiles it exchanges particles with have
+// finished pass p-1: per tile a completed-pass counter (`epoch`), published after the tile's positions are written
+// through (sc1 stores -> s_waitcnt vmcnt(0) -> barrier -> relaxed agent-scope store), polled by one wave of the
+// reader (relaxed agent-scope loads), whose fill then reads the positions with sc1 loads.  The dependency list
+// of (segment, tile) holds the owners of its halo (read-after-write) and the tiles that had its particles in their
+// halo one pass earlier (write-after-read on the double-buffered positions); ensure_plan() derives it from the
+// plan.  Arithmetic, order and streams are those of (A): results are bit-identical.
+// Residency: gridDim <= number of CUs and one workgroup per CU; HIP guarantees neither, so every wait is bounded
+// (kSpinLimitTicks) and a timeout raises `*error` instead of hanging -- the host then falls back to (A).
+#ifndef PBDX_KEEP_OWNED
+#define PBDX_KEEP_OWNED 1
+#endif
+constexpr uint32_t kMaxPersistSegs = 4;
+constexpr unsigned long long kSpinLimitTicks = 2000000ull;      // 20 ms of the 100 MHz wall clock
+struct PersistArgs
+{
+	float4 *pos[2];
+	SegArgs seg[kMaxPersistSegs];
+	const uint32_t *dep_off[kMaxPersistSegs];     // per segment: num_tiles + 1 offsets into dep_tile
+	const uint32_t *dep_tile[kMaxPersistSegs];
+	unsigned long long *trace[kMaxPersistSegs];   // developer trace of the LAST pass of every segment (or null)
+	uint32_t *epoch;                              // per tile: passes completed (zeroed before the launch)
+	uint32_t *error;
+	uint32_t num_segs, passes, num_tiles;
+	int start;                                    // position buffer pass 0 reads
+	float dt;
+	TypeView views[PBDX_NUM_CONSTRAINT_TYPES];
+};
+
+template <uint32_t MASK, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
+{
+	extern __shared__ uint4 lds_raw[];
+	__shared__ uint32_t s_failed;
+	uint4 *lchunks = lds_raw;
+	float4 *lpos = reinterpret_cast<float4 *>(lds_raw + kMaxTileChunks);
+	uint32_t sgi = 0;
+	if (threadIdx.x == 0) s_failed = 0u;
+	__syncthreads();
+	for (uint32_t pass = 0; pass < a.passes; pass++)
+	{
+		const SegArgs &sg = a.seg[sgi];
+		const RunArgs ra = { a.dt, pass < a.num_segs ? 1 : 0, a.views };
+		const float4 *pos_in = a.pos[(a.start + pass) & 1u];
+		float4 *pos_out = a.pos[(a.start + pass + 1u) & 1u];
+		for (uint32_t tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x)
+		{
+			// the wait for the neighbouring tiles, run by the fill once its particle ids are in flight: one wave polls
+			// the tile's dependencies, one lane each (lists are short: the adjacent tiles)
+			auto wait = [&]()
+			{
+				if (!pass) return;
+				if (threadIdx.x < 64)
+				{
+					const uint32_t d0 = a.dep_off[sgi][tile], d1 = a.dep_off[sgi][tile + 1];
+					const unsigned long long t0 = wall_clock64();
+					for (uint32_t d = d0 + threadIdx.x; d < d1; d += 64)
+					{
+						const uint32_t *flag = a.epoch + a.dep_tile[sgi][d];
+						while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pass)
+						{
+							if (wall_clock64() - t0 > kSpinLimitTicks) { s_failed = 1u; break; }
+							__builtin_amdgcn_s_sleep(1);
+						}
+					}
+				}
+				__syncthreads();
+			};
+			unsigned long long *trace = (a.trace[sgi] && pass + a.num_segs >= a.passes) ? a.trace[sgi] + (size_t)tile * kTraceStride : nullptr;
+			// one tile per workgroup: its owned particles stay in LDS from pass to pass
+			process_tile<MASK, BLOCK, false, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, PBDX_KEEP_OWNED && pass != 0 && gridDim.x == a.num_tiles, wait);
+			if (s_failed)
+			{
+				// a neighbour never arrived: the result is garbage, say so and leave (uniform: one LDS word)
+				if (threadIdx.x == 0) atomicOr(a.error, 1u);
+				return;
+			}
+			// publish: this thread's stores have left the CU, then everybody's, then the counter
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__syncthreads();
+			if (threadIdx.x == 0) __hip_atomic_store(a.epoch + tile, pass + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		sgi = sgi + 1u == a.num_segs ? 0u : sgi + 1u;
+	}
+}
+
 typedef void (*fused_fn)(FusedArgs);
+typedef void (*persist_fn)(PersistArgs);
 constexpr uint32_t kMaskClothXpbd = (1u << PBDX_DISTANCE_XPBD) | (1u << PBDX_ISOMETRIC_BENDING_XPBD);
 constexpr uint32_t kMaskLight = (1u << PBDX_DISTANCE) | (1u << PBDX_DISTANCE_XPBD) | (1u << PBDX_ISOMETRIC_BENDING) |
 	(1u << PBDX_ISOMETRIC_BENDING_XPBD) | (1u << PBDX_VOLUME) | (1u << PBDX_VOLUME_XPBD) | (1u << PBDX_DIHEDRAL);
@@ -371,6 +515,15 @@ fused_fn pick_fused_kernel(uint32_t mask, int block, bool pairs)
 		return block == 1024 ? fused_kernel<kMaskLight, 1024, false> : block == 512 ? fused_kernel<kMaskLight, 512, false> : fused_kernel<kMaskLight, 256, false>;
 	// heavy types (FEM / strain / shape matching) need > 128 VGPRs: at most 512 threads per workgroup
 	return block >= 512 ? fused_kernel<kMaskAll, 512, false> : fused_kernel<kMaskAll, 256, false>;
+}
+
+persist_fn pick_persistent_kernel(uint32_t mask, int block)
+{
+	if ((mask & ~kMaskClothXpbd) == 0)
+		return block == 1024 ? persistent_kernel<kMaskClothXpbd, 1024> : block == 512 ? persistent_kernel<kMaskClothXpbd, 512> : persistent_kernel<kMaskClothXpbd, 256>;
+	if ((mask & ~kMaskLight) == 0)
+		return block == 1024 ? persistent_kernel<kMaskLight, 1024> : block == 512 ? persistent_kernel<kMaskLight, 512> : persistent_kernel<kMaskLight, 256>;
+	return block >= 512 ? persistent_kernel<kMaskAll, 512> : persistent_kernel<kMaskAll, 256>;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -530,6 +683,7 @@ struct DeviceSegment
 	float *d_lambda = nullptr;
 	uint32_t *d_gid = nullptr;
 	unsigned long long *d_trace = nullptr;
+	uint32_t *d_dep_off = nullptr, *d_dep_tile = nullptr;   // persistent schedule: per tile, the tiles it waits for
 	uint32_t num_tiles = 0;
 	uint32_t lds_bytes = 0;
 	uint32_t idx_bytes = 0, params_bytes = 0, lambda_bytes = 0;
@@ -580,6 +734,13 @@ struct pbdx_solver
 	struct Pin { const void *p; size_t bytes; };
 	std::vector<Pin> pins;
 	int pairs = 0;                       // measured slower: off by default
+	int persistent = 0;                  // PBDX_OPT_PERSISTENT: the sweeps of a substep as one launch (A')
+	bool persist_ok = false;             // the plan is eligible (and no launch has timed out)
+	persist_fn persist_kernel = nullptr;
+	int persist_block = 0;
+	uint32_t persist_lds = 0, persist_grid = 0;
+	uint32_t *d_epoch = nullptr;
+	uint32_t *h_error = nullptr, *d_error = nullptr;   // one page-locked word the kernel raises on a timeout
 
 	// contacts with static colliders
 	std::vector<pbdx_collider> colliders;
@@ -600,7 +761,7 @@ struct pbdx_solver
 	// cached graph of one substep
 	hipGraph_t graph = nullptr;
 	hipGraphExec_t graph_exec = nullptr;
-	struct GraphKey { float h; uint32_t iters; int vel; float g[3]; uint64_t sched; int block; int remap; uint32_t n; int fused; } key = {};
+	struct GraphKey { float h; uint32_t iters; int vel; float g[3]; uint64_t sched; int block; int remap; uint32_t n; int fused; int persist; } key = {};
 	bool graph_valid = false;
 
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -621,7 +782,11 @@ struct pbdx_solver
 			if (d.d_lambda) (void)hipFree(d.d_lambda);
 			if (d.d_gid) (void)hipFree(d.d_gid);
 			if (d.d_trace) (void)hipFree(d.d_trace);
+			if (d.d_dep_off) (void)hipFree(d.d_dep_off);
+			if (d.d_dep_tile) (void)hipFree(d.d_dep_tile);
 		}
+		if (d_epoch) { (void)hipFree(d_epoch); d_epoch = nullptr; }
+		persist_ok = false;
 		dsegs.clear();
 		plan = FusedPlan();
 		plan_built = false;
@@ -656,6 +821,7 @@ struct pbdx_solver
 		n = 0;
 	}
 	bool fused_active() const { return fuse && plan_ok && !dsegs.empty() && (fuse == 1 || fuse_choice); }
+	bool persistent_active() const { return persistent && persist_ok && fused_active(); }
 	void unpin_all()
 	{
 		for (const Pin &pn : pins) (void)hipHostUnregister(const_cast<void *>(pn.p));
@@ -697,6 +863,74 @@ template <class T> int upload(T **dst, const std::vector<T> &src)
 
 // Build the colour-fused plan for the current schedule + particle positions and upload it.
 // A failure is not an error: the engine keeps schedule (B).
+// Dependency lists and launch geometry of the persistent schedule (A').  Not being eligible is not an error.
+int prepare_persistent(pbdx_solver *s)
+{
+	s->persist_ok = false;
+	const size_t nseg = s->dsegs.size();
+	const uint32_t k = s->plan.num_tiles;
+	if (!nseg || nseg > kMaxPersistSegs || !k) return PBDX_OK;
+	uint32_t mask = 0, lds = 0;
+	for (const DeviceSegment &d : s->dsegs)
+	{
+		if (d.block != s->dsegs[0].block || d.num_tiles != k) return PBDX_OK;      // one workgroup shape for all passes
+		mask |= d.type_mask;
+		lds = std::max(lds, d.lds_bytes);
+	}
+	if ((mask & ~kMaskLight) && s->dsegs[0].block > 512) return PBDX_OK;
+	// read-after-write: owners of a tile's halo in segment si
+	std::vector<std::vector<std::vector<uint32_t>>> raw(nseg, std::vector<std::vector<uint32_t>>(k));
+	for (size_t si = 0; si < nseg; si++)
+	{
+		const FusedSegment &seg = s->plan.segs[si];
+		for (uint32_t t = 0; t < k; t++)
+		{
+			const FusedTile &ft = seg.tiles[t];
+			std::vector<uint32_t> &r = raw[si][t];
+			for (uint32_t i = ft.n_owned; i < ft.n_local; i++) r.push_back(s->plan.tile_of[seg.gid[ft.gid_off + i]]);
+			std::sort(r.begin(), r.end());
+			r.erase(std::unique(r.begin(), r.end()), r.end());
+		}
+	}
+	for (size_t si = 0; si < nseg; si++)
+	{
+		// + write-after-read: the tiles that read this tile's particles one pass earlier (segment si - 1)
+		const size_t sp = (si + nseg - 1) % nseg;
+		std::vector<std::vector<uint32_t>> dep = raw[si];
+		for (uint32_t u = 0; u < k; u++)
+			for (uint32_t t : raw[sp][u]) dep[t].push_back(u);
+		std::vector<uint32_t> off(k + 1, 0), lst;
+		for (uint32_t t = 0; t < k; t++)
+		{
+			std::vector<uint32_t> &d = dep[t];
+			std::sort(d.begin(), d.end());
+			d.erase(std::unique(d.begin(), d.end()), d.end());
+			d.erase(std::remove(d.begin(), d.end(), t), d.end());      // a workgroup runs its own passes in order
+			lst.insert(lst.end(), d.begin(), d.end());
+			off[t + 1] = (uint32_t)lst.size();
+		}
+		if (lst.empty()) lst.push_back(0);
+		int r = upload(&s->dsegs[si].d_dep_off, off);
+		if (!r) r = upload(&s->dsegs[si].d_dep_tile, lst);
+		if (r) return r;
+	}
+	HIPCHECK(hipMalloc(&s->d_epoch, (size_t)k * sizeof(uint32_t)));
+	s->persist_block = s->dsegs[0].block;
+	s->persist_lds = lds;
+	s->persist_kernel = pick_persistent_kernel(mask, s->persist_block);
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(s->persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	// every workgroup must be resident: at most as many as the occupancy query admits (one per tile otherwise)
+	int per_cu = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(s->persist_kernel), s->persist_block, lds) != hipSuccess || per_cu < 1)
+	{
+		(void)hipGetLastError();
+		return PBDX_OK;
+	}
+	s->persist_grid = std::min<uint32_t>(k, (uint32_t)std::max(1, s->prop.multiProcessorCount));     // one workgroup per CU at most: leaves the margin the occupancy API lacks
+	s->persist_ok = true;
+	return PBDX_OK;
+}
+
 int ensure_plan(pbdx_solver *s)
 {
 	if (!s->fuse || s->plan_built) return PBDX_OK;
@@ -814,7 +1048,7 @@ int ensure_plan(pbdx_solver *s)
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(d.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
 	}
 	s->plan_ok = true;
-	return PBDX_OK;
+	return prepare_persistent(s);
 }
 
 // Device arrays of the per-colour schedule (B), created the first time that schedule actually runs.
@@ -888,17 +1122,63 @@ int launch_batch(pbdx_solver *s, const Batch &b, float dt, int first_iter)
 	return PBDX_OK;
 }
 
+SegArgs seg_args(const DeviceSegment &d)
+{
+	SegArgs g;
+	g.tiles = d.d_tiles; g.chunks = d.d_chunks; g.idx = d.d_idx; g.params = d.d_params; g.lambda = d.d_lambda; g.gid = d.d_gid;
+	g.idx_bytes = d.idx_bytes; g.params_bytes = d.params_bytes; g.lambda_bytes = d.lambda_bytes;
+	g.num_tiles = d.num_tiles;
+	return g;
+}
+
+// (A') all `iterations` sweeps as one launch
+int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations)
+{
+	PersistArgs a;
+	memset(&a, 0, sizeof(a));
+	a.pos[0] = s->d_pos[0]; a.pos[1] = s->d_pos[1];
+	for (size_t si = 0; si < s->dsegs.size(); si++)
+	{
+		a.seg[si] = seg_args(s->dsegs[si]);
+		a.dep_off[si] = s->dsegs[si].d_dep_off;
+		a.dep_tile[si] = s->dsegs[si].d_dep_tile;
+		a.trace[si] = s->trace ? s->dsegs[si].d_trace : nullptr;
+	}
+	a.epoch = s->d_epoch;
+	a.error = s->d_error;
+	a.num_segs = (uint32_t)s->dsegs.size();
+	a.passes = iterations * a.num_segs;
+	a.num_tiles = s->plan.num_tiles;
+	a.start = src;
+	a.dt = dt;
+	memcpy(a.views, s->plan.views, sizeof(a.views));
+	HIPCHECK(hipMemsetAsync(s->d_epoch, 0, (size_t)s->plan.num_tiles * sizeof(uint32_t), s->stream));
+	hipLaunchKernelGGL(s->persist_kernel, dim3(s->persist_grid), dim3(s->persist_block), s->persist_lds, s->stream, a);
+	HIPCHECK(hipGetLastError());
+	return PBDX_OK;
+}
+
+// after a stream synchronisation: did a persistent launch give up waiting?  The positions are garbage then; the
+// schedule is switched off for this solver and the caller gets an error (never a hang, never a silent wrong result).
+int check_persistent(pbdx_solver *s)
+{
+	if (!s->h_error || *s->h_error == 0u) return PBDX_OK;
+	*s->h_error = 0u;
+	s->persist_ok = false;
+	s->drop_graph();
+	set_error("persistent schedule: a tile timed out waiting for its neighbours (workgroups not co-resident?); the schedule is disabled for this solver and the particle state of this step is invalid -- upload it again");
+	return PBDX_ERR_HIP;
+}
+
 int launch_segment(pbdx_solver *s, size_t si, int src, float dt, int first_iter)
 {
 	DeviceSegment &d = s->dsegs[si];
 	FusedArgs a;
 	a.pos_in = s->d_pos[src];
 	a.pos_out = s->d_pos[src ^ 1];
-	a.tiles = d.d_tiles; a.chunks = d.d_chunks; a.idx = d.d_idx; a.params = d.d_params; a.lambda = d.d_lambda; a.gid = d.d_gid;
-	a.idx_bytes = d.idx_bytes; a.params_bytes = d.params_bytes; a.lambda_bytes = d.lambda_bytes;
+	a.seg = seg_args(d);
 	a.dt = dt;
 	a.first_iter = first_iter;
-	a.num_tiles = d.num_tiles;
 	a.xcd_remap = s->xcd_remap;
 	a.trace = s->trace ? d.d_trace : nullptr;
 	memcpy(a.views, s->plan.views, sizeof(a.views));
@@ -943,6 +1223,8 @@ inline uint32_t sweep_flips(const pbdx_solver *s, uint32_t iterations)
 // src ^ sweep_flips().  Per-colour: in place on buffer 0 (src must be 0).
 int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, ProfCursor *pc)
 {
+	if (s->persistent_active() && !pc && iterations)
+		return launch_persistent(s, src, dt, iterations);
 	if (s->fused_active())
 	{
 		for (uint32_t it = 0; it < iterations; it++)
@@ -1110,6 +1392,8 @@ int pbdx_solver_create(pbdx_solver **out, int device)
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreate(&s->ev_start);
 	if (e == hipSuccess) e = hipEventCreate(&s->ev_stop);
+	if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s->h_error), sizeof(uint32_t), hipHostMallocMapped);
+	if (e == hipSuccess) { *s->h_error = 0u; e = hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_error), s->h_error, 0); }
 	if (e != hipSuccess)
 	{
 		set_error("engine initialisation failed: %s", hipGetErrorString(e));
@@ -1135,6 +1419,7 @@ void pbdx_solver_destroy(pbdx_solver *s)
 	if (s->ev_start) (void)hipEventDestroy(s->ev_start);
 	if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
+	if (s->h_error) (void)hipHostFree(s->h_error);
 	delete s;
 }
 
@@ -1314,6 +1599,7 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 	case PBDX_OPT_TRACE: s->trace = value != 0; break;
 	case PBDX_OPT_PAIRS: s->pairs = value != 0; replan = true; break;
 	case PBDX_OPT_PIN_HOST: s->pin_host = value != 0; if (!s->pin_host) s->unpin_all(); break;
+	case PBDX_OPT_PERSISTENT: s->persistent = value != 0; break;
 	default: set_error("unknown option %d", option); return PBDX_ERR_INVALID;
 	}
 	s->drop_graph();
@@ -1354,7 +1640,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	const uint64_t launches_per_sweep = s->fused_active() ? s->dsegs.size() : s->order.size();
 	s->stats = pbdx_step_stats();
 	s->stats.projections = proj_per_sweep * max_iterations * substeps_total;
-	s->stats.kernel_launches = (launches_per_sweep * max_iterations + 2) * substeps_total;
+	s->stats.kernel_launches = (s->persistent_active() && !s->profile ? 3 : launches_per_sweep * max_iterations + 2) * substeps_total;
 	s->stats.algorithmic_bytes = (bytes_per_sweep * max_iterations + (uint64_t)s->n * 140) * substeps_total;
 	memset(s->type_ms, 0, sizeof(s->type_ms));
 	memset(s->type_launches, 0, sizeof(s->type_launches));
@@ -1377,7 +1663,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	}
 	else if (s->use_graph)
 	{
-		pbdx_solver::GraphKey k = { hs, max_iterations, vel, { gravity[0], gravity[1], gravity[2] }, s->schedule_version, s->block_size, s->xcd_remap, s->n, s->fused_active() ? 1 : 0 };
+		pbdx_solver::GraphKey k = { hs, max_iterations, vel, { gravity[0], gravity[1], gravity[2] }, s->schedule_version, s->block_size, s->xcd_remap, s->n, s->fused_active() ? 1 : 0, s->persistent_active() ? 1 : 0 };
 		if (!s->graph_valid || memcmp(&k, &s->key, sizeof(k)) != 0)
 		{
 			s->drop_graph();
@@ -1415,7 +1701,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	float ms = 0.0f;
 	HIPCHECK(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
 	s->stats.total_ms = ms;
-	return PBDX_OK;
+	return check_persistent(s);
 }
 
 int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
@@ -1434,7 +1720,7 @@ int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
 	r = projection_sweeps(s, h_sub, iterations, start, nullptr);
 	if (r) return r;
 	HIPCHECK(hipStreamSynchronize(s->stream));
-	return PBDX_OK;
+	return check_persistent(s);
 }
 
 int pbdx_solver_synchronize(pbdx_solver *s)
@@ -1646,8 +1932,8 @@ int pbdx_solver_describe(pbdx_solver *s, char *buf, size_t n)
 		{
 			uint32_t ml = 0;
 			for (const FusedSegment &seg : s->plan.segs) ml = std::max(ml, seg.max_local);
-			int w2 = snprintf(buf + w, n - w, " schedule=fused segments=%zu tiles=%u redundancy=%.3f max_tile_particles=%u plan_s=%.2f",
-				s->plan.segs.size(), s->plan.num_tiles, s->plan.redundancy, ml, s->plan.build_seconds);
+			int w2 = snprintf(buf + w, n - w, " schedule=%s segments=%zu tiles=%u redundancy=%.3f max_tile_particles=%u plan_s=%.2f",
+				s->persistent_active() ? "fused-persistent" : "fused", s->plan.segs.size(), s->plan.num_tiles, s->plan.redundancy, ml, s->plan.build_seconds);
 			if (s->autotune_ms[1] > 0.0f && w2 > 0 && (size_t)(w + w2) < n)
 				snprintf(buf + w + w2, n - w - w2, " autotune(per-colour %.3f ms, fused %.3f ms)", s->autotune_ms[0], s->autotune_ms[1]);
 		}

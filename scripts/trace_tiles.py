@@ -14,6 +14,8 @@ ap.add_argument("--size", type=int, default=1000)
 ap.add_argument("--max-seg", type=int, default=None)
 ap.add_argument("--tile", type=int, default=None)
 ap.add_argument("--fuse-block", type=int, default=None)
+ap.add_argument("--persistent", type=int, default=0)
+ap.add_argument("--graph", type=int, default=0, help="1: keep the hipGraph (kernel-to-kernel dead time as it is in production)")
 args = ap.parse_args()
 model = util.build_mine(util.cloth_spec(args.size, args.size, 4, 3))
 ts = pbd.TimeStepController()
@@ -23,15 +25,22 @@ sol = ts.solver()
 for v, o in ((args.max_seg, sol.OPT_MAX_SEGMENT_COLOURS), (args.tile, sol.OPT_TILE_PARTICLES), (args.fuse_block, sol.OPT_FUSE_BLOCK)):
     if v is not None:
         sol.set_option(o, v)
+sol.set_option(sol.OPT_PERSISTENT, args.persistent)
 ts.stepResident(model, 10)
 sol.set_option(sol.OPT_TRACE, 1)
-sol.set_option(sol.OPT_USE_GRAPH, 0)
+sol.set_option(sol.OPT_USE_GRAPH, args.graph)
 ts.stepResident(model, 1)
 plan = sol.plan_info()
 print(plan)
+# dead time between the last tile of a launch and the first tile of the next one (the trace holds the last
+# launch of every segment: segment s -> s+1 inside the last iteration)
+trs = [sol.trace(seg).astype(np.int64) for seg in range(plan["num_segments"])]
+for seg in range(plan["num_segments"] - 1):
+    print("dead time segment %d -> %d: %.2f us (last tile end -> first tile start); last tile end -> median tile start %.2f us" % (
+        seg, seg + 1, (trs[seg + 1][:, 0].min() - trs[seg][:, -1].max()) * 0.01, (np.median(trs[seg + 1][:, 0]) - trs[seg][:, -1].max()) * 0.01))
 for seg in range(plan["num_segments"]):
     si = sol.segment_info(seg)
-    tr = sol.trace(seg).astype(np.int64)
+    tr = trs[seg]
     t0 = tr[:, 0].min()
     start = (tr[:, 0] - t0) * 0.01
     end = (tr[:, -1] - t0) * 0.01
