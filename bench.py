@@ -237,6 +237,7 @@ def main():
     ap.add_argument("--fuse-block", type=int, default=None)
     ap.add_argument("--max-seg", type=int, default=None, help="max colours fused into one launch")
     ap.add_argument("--lds-particles", type=int, default=None)
+    ap.add_argument("--persistent", type=int, default=None, help="PBDX_OPT_PERSISTENT: 1 = one launch per substep where measured faster (default), 0 = one launch per segment, 2 = always")
     ap.add_argument("--contacts", action="store_true", help="also time the step with two static colliders (contact detection + velocity solve per step)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -280,7 +281,8 @@ def main():
     if args.no_graph:
         sol.set_option(pbd.Solver.OPT_USE_GRAPH, 0)
     for val, opt in ((args.fuse, pbd.Solver.OPT_FUSE), (args.tile, pbd.Solver.OPT_TILE_PARTICLES), (args.fuse_block, pbd.Solver.OPT_FUSE_BLOCK),
-                     (args.max_seg, pbd.Solver.OPT_MAX_SEGMENT_COLOURS), (args.lds_particles, pbd.Solver.OPT_LDS_PARTICLES)):
+                     (args.max_seg, pbd.Solver.OPT_MAX_SEGMENT_COLOURS), (args.lds_particles, pbd.Solver.OPT_LDS_PARTICLES),
+                     (args.persistent, pbd.Solver.OPT_PERSISTENT)):
         if val is not None:
             sol.set_option(opt, val)
 
@@ -297,6 +299,7 @@ def main():
     t_local = time.perf_counter() - t0
     stats = sol.stats()
     plan = sol.plan_info()
+    persist = sol.persistent_info()
     barrier()
     t_max = ens.max_time(t_local)                       # max over ranks
     total_constraints = ens.sum_count(n_constraints)    # all ranks (weak scaling: every rank owns its own instances)
@@ -364,7 +367,7 @@ def main():
                    "algorithmic_GB_per_substep": stats["algorithmic_bytes"] / max(args.steps, 1) / 1e9,
                    "whole_substep_algorithmic_GBs": stats["algorithmic_bytes"] / max(stats["total_ms"], 1e-9) / 1e6,
                    "host_scene_build_s": t_build, "contacts": contact_info, "pcie_inclusive_ms_per_step": None if t_pcie is None else 1e3 * t_pcie,
-                   "pcie_inclusive_pinned_ms_per_step": None if t_pcie_pinned is None else 1e3 * t_pcie_pinned, "plan": plan, "engine": sol.describe()},
+                   "pcie_inclusive_pinned_ms_per_step": None if t_pcie_pinned is None else 1e3 * t_pcie_pinned, "plan": plan, "persistent": persist, "engine": sol.describe()},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -375,7 +378,23 @@ def main():
         ts.stepResident(model, psteps)
         sol.set_profiling(False)
         T = pbd.ConstraintType
-        if plan["active"]:
+        pinfo = sol.persistent_info()
+        if plan["active"] and pinfo["active"] and pinfo["profiled_launches"]:
+            # one launch per substep runs all `iters` sweeps: algorithmic bytes of a launch = iters x bytes of a sweep
+            dur_s = 1e-3 * pinfo["profiled_ms"] / pinfo["profiled_launches"]
+            bytes_per_launch = pinfo["algorithmic_bytes_per_sweep"] * args.iters
+            segs = [sol.segment_info(i) for i in range(plan["num_segments"])]
+            streamed = sum(si["stream_bytes"] for si in segs) * args.iters
+            achieved = bytes_per_launch / dur_s / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "persistent_kernel (colour-fused LDS tiles, all %d sweeps x %d segments of a substep in one launch)" % (args.iters, plan["num_segments"]),
+                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "algorithmic_bytes_per_launch": bytes_per_launch, "streamed_bytes_per_launch": streamed, "avg_launch_us": dur_s * 1e6,
+                               "launches_measured": pinfo["profiled_launches"], "grid": pinfo["grid"], "block": pinfo["block"], "lds_bytes": pinfo["lds_bytes"],
+                               "segments": [{"segment": i, "colours": [si["colour_begin"], si["colour_end"]], "tiles": si["num_tiles"], "constraints": si["constraints"], "slots": si["slots"],
+                                             "algorithmic_bytes_per_pass": si["algorithmic_bytes"], "streamed_bytes_per_pass": si["stream_bytes"]} for i, si in enumerate(segs)],
+                               "note": "achieved = SURVEY 8d algorithmic bytes of the launch's distinct constraint projections / event-measured launch time; "
+                                       "positions stay in LDS within a pass (and the owned ones between passes), so the bytes actually streamed from HBM (streamed_*) are lower"}
+        elif plan["active"]:
             segs = [sol.segment_info(i) for i in range(plan["num_segments"])]
             rows = []
             for i, si in enumerate(segs):
@@ -423,13 +442,15 @@ def main():
         child = ["--workload", args.workload, "--size", str(args.size), "--iters", str(args.iters), "--instances", str(args.instances),
                  "--solid-method", str(args.solid_method)] + (["--bars"] if args.bars else [])
         for flag, val in (("--fuse", args.fuse), ("--tile", args.tile), ("--fuse-block", args.fuse_block), ("--max-seg", args.max_seg),
-                          ("--lds-particles", args.lds_particles), ("--xcd-remap", args.xcd_remap), ("--block", args.block)):
+                          ("--lds-particles", args.lds_particles), ("--xcd-remap", args.xcd_remap), ("--block", args.block),
+                          ("--persistent", 2 if persist["active"] else 0)):
             if val is not None:
                 child += [flag, str(val)]
-        tr = collect_traffic(child, "fused_kernel" if plan["active"] else "project_kernel")
+        kname = "persistent_kernel" if persist["active"] else "fused_kernel" if plan["active"] else "project_kernel"
+        tr = collect_traffic(child, kname)
         if tr is not None:
             r = out["roofline"]
-            if plan["active"]:
+            if plan["active"] and not persist["active"]:
                 # the PMC mean runs over the launches of ALL segments: compare with the mean over segments
                 rows = r["segments"]
                 nl = sum(x["launches"] for x in rows)
@@ -438,12 +459,12 @@ def main():
                 r["streamed_bytes_per_launch_mean"] = sum(x["streamed_bytes_per_launch"] * x["launches"] for x in rows) / nl
             r["traffic"] = tr["bytes_per_launch"]
             r["traffic_detail"] = {k: tr[k] for k in ("fetch_bytes", "write_bytes", "raw")}
-        kd = rocprof_kernel_durations(child, "fused_kernel" if plan["active"] else "project_kernel")
+        kd = rocprof_kernel_durations(child, kname)
         if kd is not None:
             r = out["roofline"]
             r["rocprofv3_mean_kernel_us"] = kd[0] / 1e3
             r["rocprofv3_dispatches"] = kd[1]
-            if plan["active"]:
+            if plan["active"] and not persist["active"]:
                 rows = r["segments"]
                 nl = sum(x["launches"] for x in rows)
                 r["event_mean_launch_us_all_segments"] = sum(x["avg_us"] * x["launches"] for x in rows) / nl

@@ -216,7 +216,10 @@ enum {
 	PBDX_OPT_PAIRS = 10,           /* project two chunks of a colour step jointly with packed fp32 arithmetic (default 0: measured slower) */
 	PBDX_OPT_PERSISTENT = 12       /* fused schedule only: all sweeps of a substep as ONE launch; a tile starts its next pass as soon as its
 	                                * neighbouring tiles have published theirs (no kernel boundary, no chip-wide wait for the slowest tile).
-	                                * Needs every workgroup co-resident; a bounded wait turns a violation into an error status, never a hang. */
+	                                * 1 (default) = used where a one-off measurement on scratch positions finds it faster than one launch per
+	                                * segment, 0 = never, 2 = always (if the plan is eligible), 3 = self-test (the launch is made to refuse).  Needs every workgroup co-resident: the
+	                                * launch first checks that (bounded handshake); if not, it modifies nothing, the engine completes the step
+	                                * with one launch per segment and stops using the schedule (pbdx_solver_describe: persistent_refusals). */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
 
@@ -240,6 +243,17 @@ typedef struct pbdx_segment_info {
 	uint64_t profiled_launches;
 } pbdx_segment_info;
 int pbdx_solver_get_segment_info(pbdx_solver *s, uint32_t segment, pbdx_segment_info *out);
+/* The one-launch form of the fused schedule (PBDX_OPT_PERSISTENT). */
+typedef struct pbdx_persistent_info {
+	int eligible, active;          /* the plan can run as one launch per substep / that is the schedule in use */
+	uint32_t grid, block, lds_bytes; /* launch geometry */
+	uint32_t refusals;             /* launches that found their workgroups not co-resident (the engine then fell back for good) */
+	double autotune_fused_ms, autotune_persistent_ms; /* the one-off measurement: 12 sweeps on scratch positions, 0 = not measured */
+	double profiled_ms;            /* last profiled pbdx_solver_step: summed duration and number of persistent launches */
+	uint64_t profiled_launches;
+	uint64_t algorithmic_bytes_per_sweep; /* SURVEY 8d bytes of one Gauss-Seidel sweep (a launch runs `iterations` sweeps) */
+} pbdx_persistent_info;
+int pbdx_solver_get_persistent_info(pbdx_solver *s, pbdx_persistent_info *out);
 /* Developer trace of the LAST launch of `segment` (PBDX_OPT_TRACE): num_tiles * stride stamps of the
  * 100 MHz wall clock; per tile [0] kernel entry, [1] LDS filled, [2+i] colour step i finished,
  * [stride-1] tile written back. */

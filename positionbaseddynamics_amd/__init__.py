@@ -690,6 +690,12 @@ class Solver:
         check(lib.pbdx_solver_get_segment_info(self._h, int(segment), C.byref(si)), "get_segment_info")
         return {k: getattr(si, k) for k, _ in _ffi.SegmentInfo._fields_}
 
+    def persistent_info(self):
+        """The one-launch form of the fused schedule (OPT_PERSISTENT): eligibility, use, launch geometry, measurements."""
+        pi = _ffi.PersistentInfo()
+        check(lib.pbdx_solver_get_persistent_info(self._h, C.byref(pi)), "get_persistent_info")
+        return {k: getattr(pi, k) for k, _ in _ffi.PersistentInfo._fields_}
+
     def trace(self, segment):
         """(num_tiles, stride) array of 100 MHz wall-clock stamps of the last launch of `segment`."""
         si = self.segment_info(segment)

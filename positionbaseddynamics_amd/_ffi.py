@@ -54,6 +54,12 @@ class SegmentInfo(C.Structure):
                 ("profiled_launches", C.c_uint64)]
 
 
+class PersistentInfo(C.Structure):
+    _fields_ = [("eligible", C.c_int), ("active", C.c_int), ("grid", C.c_uint32), ("block", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("refusals", C.c_uint32), ("autotune_fused_ms", C.c_double), ("autotune_persistent_ms", C.c_double),
+                ("profiled_ms", C.c_double), ("profiled_launches", C.c_uint64), ("algorithmic_bytes_per_sweep", C.c_uint64)]
+
+
 def _sig(name, restype, *argtypes):
     fn = getattr(lib, name)
     fn.restype = restype
@@ -83,6 +89,7 @@ SIGNATURES = [
     ("pbdx_solver_describe", C.c_int, vp, C.c_char_p, C.c_size_t),
     ("pbdx_solver_get_plan_info", C.c_int, vp, C.POINTER(PlanInfo)),
     ("pbdx_solver_get_segment_info", C.c_int, vp, u32, C.POINTER(SegmentInfo)),
+    ("pbdx_solver_get_persistent_info", C.c_int, vp, C.POINTER(PersistentInfo)),
     ("pbdx_solver_get_trace", C.c_int, vp, u32, C.POINTER(C.c_uint64), u32, C.POINTER(u32)),
     ("pbdx_solver_set_colliders", C.c_int, vp, u32, C.POINTER(Collider)),
     ("pbdx_solver_set_collision_ranges", C.c_int, vp, u32, C.POINTER(CollisionRange)),

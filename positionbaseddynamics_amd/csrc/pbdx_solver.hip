@@ -59,6 +59,9 @@ struct BatchArgs
 // blockIdx -> logical block: with xcd_remap the 8 XCDs (hardware places block b on XCD b%8) each
 // walk one contiguous eighth of the batch / of the tile list, so the particles a chiplet touches
 // stay the same from launch to launch (per-XCD L2 locality); speed only, never correctness.
+// control block of the persistent schedule (device words; see persistent_kernel)
+enum { kCtlAbort = 0, kCtlFailedSubstep = 1, kCtlSubstep = 2, kCtlWords = 4 };
+
 __device__ __forceinline__ uint32_t logical_block(uint32_t num_blocks, int xcd_remap)
 {
 	const uint32_t b = blockIdx.x;
@@ -421,8 +424,9 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 #ifndef PBDX_KEEP_OWNED
 #define PBDX_KEEP_OWNED 1
 #endif
-constexpr uint32_t kMaxPersistSegs = 4;
+constexpr uint32_t kMaxPersistSegs = 8;
 constexpr unsigned long long kSpinLimitTicks = 2000000ull;      // 20 ms of the 100 MHz wall clock
+constexpr unsigned long long kArriveLimitTicks = 100000ull;     // 1 ms: all workgroups of a launch must have started by then
 struct PersistArgs
 {
 	float4 *pos[2];
@@ -430,9 +434,11 @@ struct PersistArgs
 	const uint32_t *dep_off[kMaxPersistSegs];     // per segment: num_tiles + 1 offsets into dep_tile
 	const uint32_t *dep_tile[kMaxPersistSegs];
 	unsigned long long *trace[kMaxPersistSegs];   // developer trace of the LAST pass of every segment (or null)
-	uint32_t *epoch;                              // per tile: passes completed (zeroed before the launch)
-	uint32_t *error;
+	uint32_t *epoch;                              // per tile: passes completed; then [num_tiles] arrivals, [num_tiles + 1] decision (all zeroed before the launch)
+	uint32_t *ctl;                                // kCtl* words (device)
+	uint32_t *error;                              // page-locked host words: [0] a dependency wait timed out, [1] launch refused, [2] at which substep
 	uint32_t num_segs, passes, num_tiles;
+	uint32_t expect;                              // arrivals that mean "everybody is here" (gridDim.x; one more in the self-test)
 	int start;                                    // position buffer pass 0 reads
 	float dt;
 	TypeView views[PBDX_NUM_CONSTRAINT_TYPES];
@@ -442,12 +448,43 @@ template <uint32_t MASK, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 {
 	extern __shared__ uint4 lds_raw[];
-	__shared__ uint32_t s_failed;
+	__shared__ uint32_t s_failed, s_go;
 	uint4 *lchunks = lds_raw;
 	float4 *lpos = reinterpret_cast<float4 *>(lds_raw + kMaxTileChunks);
 	uint32_t sgi = 0;
-	if (threadIdx.x == 0) s_failed = 0u;
+	// Residency handshake, before anything is modified: every workgroup announces itself; the last one to arrive
+	// decides GO, a workgroup that has waited kArriveLimitTicks decides ABORT (one compare-and-swap settles it for
+	// everybody).  After GO all gridDim.x workgroups are running and stay until the end, so no later wait can
+	// starve.  After ABORT nobody touches the state, the rest of the step's kernels turn into no-ops (ctl) and the
+	// host completes the step with one launch per segment.
+	if (threadIdx.x == 0)
+	{
+		s_failed = 0u;
+		uint32_t go = 0u;
+		if (__hip_atomic_load(a.ctl + kCtlAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+		{
+			uint32_t *arrive = a.epoch + a.num_tiles, *decision = arrive + 1;
+			if (atomicAdd(arrive, 1u) + 1u == a.expect) atomicCAS(decision, 0u, 1u);
+			const unsigned long long t0 = wall_clock64();
+			uint32_t d;
+			while ((d = __hip_atomic_load(decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u)
+			{
+				if (wall_clock64() - t0 > kArriveLimitTicks) atomicCAS(decision, 0u, 2u);
+				__builtin_amdgcn_s_sleep(1);
+			}
+			go = d == 1u ? 1u : 0u;
+			if (!go && atomicCAS(a.ctl + kCtlAbort, 0u, 1u) == 0u)
+			{
+				const uint32_t k = __hip_atomic_load(a.ctl + kCtlSubstep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				a.ctl[kCtlFailedSubstep] = k;
+				a.error[2] = k;
+				__hip_atomic_store(a.error + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+		}
+		s_go = go;
+	}
 	__syncthreads();
+	if (!s_go) return;
 	for (uint32_t pass = 0; pass < a.passes; pass++)
 	{
 		const SegArgs &sg = a.seg[sgi];
@@ -533,9 +570,13 @@ persist_fn pick_persistent_kernel(uint32_t mask, int block)
 // TimeStepController.cpp:112-118 + TimeIntegration.cpp:7-19 (acceleration == gravity for every
 // dynamic particle, TimeStep.cpp:28-62).  Reads pos_in, writes pos_out (the same buffer, or the
 // buffer the first fused segment of the substep reads).
+// `ctl` (or null): control block of the persistent schedule; once a persistent launch has refused to start
+// (ctl[kCtlAbort]) every later kernel of the same pbdx_solver_step call is a no-op, so that the host finds the state
+// exactly as it was when the refusal happened and completes the step with the multi-launch schedule.
 __global__ __launch_bounds__(256) void integrate_kernel(const float4 *pos_in, float4 *pos_out, float4 *__restrict__ vel,
-	float4 *__restrict__ old, float4 *__restrict__ last, uint32_t n, float h, float gx, float gy, float gz)
+	float4 *__restrict__ old, float4 *__restrict__ last, uint32_t n, float h, float gx, float gy, float gz, const uint32_t *ctl)
 {
+	if (ctl && ctl[kCtlAbort]) return;
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const float4 o = old[i];
@@ -554,9 +595,11 @@ __global__ __launch_bounds__(256) void integrate_kernel(const float4 *pos_in, fl
 
 // TimeIntegration::velocityUpdateFirstOrder / SecondOrder  TimeIntegration.cpp:42-51, 69-79
 __global__ __launch_bounds__(256) void velocity_kernel(const float4 *__restrict__ pos, float4 *__restrict__ vel,
-	const float4 *__restrict__ old, const float4 *__restrict__ last, uint32_t n, float inv_h, int second_order)
+	const float4 *__restrict__ old, const float4 *__restrict__ last, uint32_t n, float inv_h, int second_order, uint32_t *ctl)
 {
+	if (ctl && ctl[kCtlAbort]) return;
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (ctl && i == 0) ctl[kCtlSubstep] = ctl[kCtlSubstep] + 1u;      // substeps completed in this call (single writer)
 	if (i >= n) return;
 	float4 v = vel[i];
 	if (v.w == 0.0f) return;
@@ -617,9 +660,11 @@ struct ContactArgs
 	float tolerance, stiffness, restitution, friction;
 	uint32_t iterations;
 	unsigned int *counters;         // [0] contacts, [1] overflow flag
+	const uint32_t *ctl;            // see integrate_kernel
 };
 __global__ __launch_bounds__(256) void contact_kernel(ContactArgs a)
 {
+	if (a.ctl && a.ctl[kCtlAbort]) return;
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= a.count) return;
 	const uint32_t i = a.first + k;
@@ -724,7 +769,8 @@ struct pbdx_solver
 	int profile = 0;
 	int fuse = 2;                        // 0 per-colour, 1 fused, 2 auto (fused; measured choice when compute-heavy types are present)
 	int fuse_choice = 1;                 // outcome of the auto mode for the current schedule
-	float autotune_ms[2] = { 0.0f, 0.0f }; // measured sweep time per-colour / fused (0 = not measured)
+	float autotune_ms[3] = { 0.0f, 0.0f, 0.0f }; // measured time of 12 sweeps: per-colour / fused / fused persistent (0 = not measured)
+	bool persist_choice = false;         // outcome of the measurement for the one-launch form
 	uint32_t tile_particles = 0;
 	int fuse_block = 0;                  // 0 = auto
 	uint32_t max_segment_colours = 16;
@@ -734,13 +780,17 @@ struct pbdx_solver
 	struct Pin { const void *p; size_t bytes; };
 	std::vector<Pin> pins;
 	int pairs = 0;                       // measured slower: off by default
-	int persistent = 0;                  // PBDX_OPT_PERSISTENT: the sweeps of a substep as one launch (A')
-	bool persist_ok = false;             // the plan is eligible (and no launch has timed out)
+	int persistent = 1;                  // PBDX_OPT_PERSISTENT: the sweeps of a substep as one launch (A'): 0 never, 1 where measured faster, 2 always, 3 self-test
+	bool persist_ok = false;             // the plan is eligible (and no launch has been refused or has timed out)
+	uint32_t persist_refusals = 0;
+	double persist_ms = 0.0;             // last profiled step: summed duration / number of persistent launches
+	uint64_t persist_launches = 0;
 	persist_fn persist_kernel = nullptr;
 	int persist_block = 0;
 	uint32_t persist_lds = 0, persist_grid = 0;
 	uint32_t *d_epoch = nullptr;
-	uint32_t *h_error = nullptr, *d_error = nullptr;   // one page-locked word the kernel raises on a timeout
+	uint32_t *h_error = nullptr, *d_error = nullptr;   // page-locked host words the persistent kernel raises: [0] timeout, [1] launch refused, [2] at substep
+	uint32_t *d_ctl = nullptr;           // kCtl* device words
 
 	// contacts with static colliders
 	std::vector<pbdx_collider> colliders;
@@ -793,7 +843,8 @@ struct pbdx_solver
 		plan_ok = false;
 		plan_why.clear();
 		fuse_choice = 1;
-		autotune_ms[0] = autotune_ms[1] = 0.0f;
+		autotune_ms[0] = autotune_ms[1] = autotune_ms[2] = 0.0f;
+		persist_choice = false;
 	}
 	void free_batches()
 	{
@@ -821,7 +872,7 @@ struct pbdx_solver
 		n = 0;
 	}
 	bool fused_active() const { return fuse && plan_ok && !dsegs.empty() && (fuse == 1 || fuse_choice); }
-	bool persistent_active() const { return persistent && persist_ok && fused_active(); }
+	bool persistent_active() const { return persistent && persist_ok && persist_choice && fused_active(); }
 	void unpin_all()
 	{
 		for (const Pin &pn : pins) (void)hipHostUnregister(const_cast<void *>(pn.p));
@@ -869,7 +920,8 @@ int prepare_persistent(pbdx_solver *s)
 	s->persist_ok = false;
 	const size_t nseg = s->dsegs.size();
 	const uint32_t k = s->plan.num_tiles;
-	if (!nseg || nseg > kMaxPersistSegs || !k) return PBDX_OK;
+	if (!nseg || nseg > kMaxPersistSegs || !k || s->pairs) return PBDX_OK;
+	if (s->dsegs[0].block != 256 && s->dsegs[0].block != 512 && s->dsegs[0].block != 1024) return PBDX_OK;
 	uint32_t mask = 0, lds = 0;
 	for (const DeviceSegment &d : s->dsegs)
 	{
@@ -914,7 +966,7 @@ int prepare_persistent(pbdx_solver *s)
 		if (!r) r = upload(&s->dsegs[si].d_dep_tile, lst);
 		if (r) return r;
 	}
-	HIPCHECK(hipMalloc(&s->d_epoch, (size_t)k * sizeof(uint32_t)));
+	HIPCHECK(hipMalloc(&s->d_epoch, ((size_t)k + 2) * sizeof(uint32_t)));      // + arrivals, decision
 	s->persist_block = s->dsegs[0].block;
 	s->persist_lds = lds;
 	s->persist_kernel = pick_persistent_kernel(mask, s->persist_block);
@@ -956,12 +1008,12 @@ int ensure_plan(pbdx_solver *s)
 	opt.max_segment_colours = s->max_segment_colours;
 	if (!build_fused_plan(s->n, s->h_x.data(), pbs, opt, s->plan, s->plan_why))
 		return PBDX_OK;
-	// per-segment device image (pushed first, so that free_plan() releases a partially built one)
+	// workgroup size per segment: enough threads to cover the largest colour step of a tile once, at most 1024
+	std::vector<int> blocks;
+	uint32_t all_mask = 0;
+	for (const FusedSegment &seg : s->plan.segs) all_mask |= seg.type_mask;
 	for (const FusedSegment &seg : s->plan.segs)
 	{
-		s->dsegs.emplace_back();
-		DeviceSegment &d = s->dsegs.back();
-		// workgroup size: enough threads to cover the largest colour step of a tile once, at most 1024
 		int block = s->fuse_block;
 		if (block != 256 && block != 512 && block != 768 && block != 1024)
 		{
@@ -971,6 +1023,23 @@ int ensure_plan(pbdx_solver *s)
 		}
 		if ((seg.type_mask & ~kMaskLight) && block > 512) block = 512;   // heavy types need > 128 VGPRs
 		if (block == 768 && !((seg.type_mask & ~kMaskClothXpbd) == 0 && s->pairs)) block = 512;   // 768 exists for the paired cloth kernel only
+		blocks.push_back(block);
+	}
+	if (s->persistent && !s->pairs)
+	{
+		// the persistent schedule runs every segment in one launch: one workgroup shape for all of them
+		int widest = *std::max_element(blocks.begin(), blocks.end());
+		if ((all_mask & ~kMaskLight) && widest > 512) widest = 512;
+		if (widest == 768) widest = 1024;
+		std::fill(blocks.begin(), blocks.end(), widest);
+	}
+	// per-segment device image (pushed first, so that free_plan() releases a partially built one)
+	for (size_t segi = 0; segi < s->plan.segs.size(); segi++)
+	{
+		const FusedSegment &seg = s->plan.segs[segi];
+		s->dsegs.emplace_back();
+		DeviceSegment &d = s->dsegs.back();
+		const int block = blocks[segi];
 		d.block = block;
 		// expand every tile's steps into workgroup-wide chunks (FusedChunk) for this workgroup size
 		std::vector<FusedTile> tiles = seg.tiles;
@@ -1145,14 +1214,16 @@ int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations)
 		a.trace[si] = s->trace ? s->dsegs[si].d_trace : nullptr;
 	}
 	a.epoch = s->d_epoch;
+	a.ctl = s->d_ctl;
 	a.error = s->d_error;
 	a.num_segs = (uint32_t)s->dsegs.size();
 	a.passes = iterations * a.num_segs;
 	a.num_tiles = s->plan.num_tiles;
+	a.expect = s->persist_grid + (s->persistent == 3 ? 1u : 0u);     // 3 = self-test: the handshake cannot complete
 	a.start = src;
 	a.dt = dt;
 	memcpy(a.views, s->plan.views, sizeof(a.views));
-	HIPCHECK(hipMemsetAsync(s->d_epoch, 0, (size_t)s->plan.num_tiles * sizeof(uint32_t), s->stream));
+	HIPCHECK(hipMemsetAsync(s->d_epoch, 0, ((size_t)s->plan.num_tiles + 2) * sizeof(uint32_t), s->stream));
 	hipLaunchKernelGGL(s->persist_kernel, dim3(s->persist_grid), dim3(s->persist_block), s->persist_lds, s->stream, a);
 	HIPCHECK(hipGetLastError());
 	return PBDX_OK;
@@ -1162,8 +1233,8 @@ int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations)
 // schedule is switched off for this solver and the caller gets an error (never a hang, never a silent wrong result).
 int check_persistent(pbdx_solver *s)
 {
-	if (!s->h_error || *s->h_error == 0u) return PBDX_OK;
-	*s->h_error = 0u;
+	if (!s->h_error || s->h_error[0] == 0u) return PBDX_OK;
+	s->h_error[0] = 0u;
 	s->persist_ok = false;
 	s->drop_graph();
 	set_error("persistent schedule: a tile timed out waiting for its neighbours (workgroups not co-resident?); the schedule is disabled for this solver and the particle state of this step is invalid -- upload it again");
@@ -1190,7 +1261,7 @@ int launch_segment(pbdx_solver *s, size_t si, int src, float dt, int first_iter)
 // event bookkeeping for the profiled (eager) mode: one event right before and one right after every
 // projection launch; elapsed(before, after) is charged to the launch (kernel duration on the
 // engine's stream, without the host-side gap to the next launch).
-// kind >= 0: constraint type of a per-colour launch; kind <= -2: fused segment (-2 - kind)
+// kind >= 0: constraint type of a per-colour launch; kind <= -2: fused segment (-2 - kind); -1: persistent launch
 struct ProfCursor { pbdx_solver *s; size_t next = 0; std::vector<int> kinds; std::vector<uint32_t> counts; };
 
 int prof_event(ProfCursor *pc)
@@ -1223,8 +1294,13 @@ inline uint32_t sweep_flips(const pbdx_solver *s, uint32_t iterations)
 // src ^ sweep_flips().  Per-colour: in place on buffer 0 (src must be 0).
 int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, ProfCursor *pc)
 {
-	if (s->persistent_active() && !pc && iterations)
-		return launch_persistent(s, src, dt, iterations);
+	if (s->persistent_active() && iterations)
+	{
+		if (pc) { int r = prof_begin(pc, -1, 0); if (r) return r; }
+		int r = launch_persistent(s, src, dt, iterations);
+		if (r) return r;
+		return pc ? prof_end(pc) : PBDX_OK;
+	}
 	if (s->fused_active())
 	{
 		for (uint32_t it = 0; it < iterations; it++)
@@ -1252,44 +1328,96 @@ int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, Pr
 	return PBDX_OK;
 }
 
-// Auto mode: the fused schedule executes halo constraints redundantly, which pays for streaming-bound types
-// (distance, bending, volume: always faster, no measurement) but not always for compute-heavy ones (FEM,
-// strain, shape matching: ~1000 VALU instructions per projection).  For those both schedules are timed
-// once on scratch copies of the positions and the faster one is kept.  The two schedules are bit-identical,
-// so the choice can never change a result.
+// Schedule selection by measurement.  (1) PBDX_OPT_FUSE = 2: the fused schedule executes halo constraints
+// redundantly, which pays for streaming-bound types (distance, bending, volume: always faster, no measurement) but
+// not always for compute-heavy ones (FEM, strain, shape matching: ~1000 VALU instructions per projection); for those
+// the per-colour schedule is a candidate.  (2) PBDX_OPT_PERSISTENT = 1: the one-launch form of the fused schedule
+// wins on large scenes (no kernel boundaries) and loses where a pass is shorter than a tile-to-tile hand-off.
+// Every candidate is timed once on scratch copies of the positions and the fastest is kept.  All schedules are
+// bit-identical, so the choice can never change a result.
 int autotune_schedule(pbdx_solver *s)
 {
 	s->fuse_choice = 1;
-	if (s->fuse != 2 || !s->plan_ok || s->dsegs.empty()) return PBDX_OK;
+	s->persist_choice = s->persistent >= 2;      // 2 = always, 3 = self-test (always try, and be refused)
+	s->autotune_ms[0] = s->autotune_ms[1] = s->autotune_ms[2] = 0.0f;
+	if (!s->plan_ok || s->dsegs.empty()) return PBDX_OK;
 	uint32_t mask = 0;
 	for (const DeviceSegment &d : s->dsegs) mask |= d.type_mask;
-	if ((mask & ~kMaskLight) == 0) return PBDX_OK;
-	int r = ensure_device_batches(s);
+	const bool try_percolour = s->fuse == 2 && (mask & ~kMaskLight) != 0;
+	const bool try_persistent = s->persistent == 1 && s->persist_ok;
+	if (!try_percolour && !try_persistent) return PBDX_OK;
+	int r = try_percolour ? ensure_device_batches(s) : PBDX_OK;
 	if (r) return r;
 	float4 *scratch[2] = { nullptr, nullptr }, *keep[2] = { s->d_pos[0], s->d_pos[1] };
 	HIPCHECK(hipMalloc(&scratch[0], (size_t)s->n * sizeof(float4)));
 	if (hipMalloc(&scratch[1], (size_t)s->n * sizeof(float4)) != hipSuccess) { (void)hipFree(scratch[0]); set_error("autotune: out of memory"); return PBDX_ERR_HIP; }
-	float ms[2] = { 0.0f, 0.0f };
+	float ms[3] = { 0.0f, 0.0f, 0.0f };      // per-colour, fused (one launch per segment), fused persistent
 	const float dt = 0.005f;
-	for (int choice = 0; choice < 2 && !r; choice++)
-	{
-		s->fuse_choice = choice;
-		s->d_pos[0] = scratch[0]; s->d_pos[1] = scratch[1];
-		for (int rep = 0; rep < 3 && !r; rep++)      // rep 0 = warm-up
+	const uint32_t sweeps = 12;
+	bool use[3] = { try_percolour, true, try_persistent };
+	s->d_pos[0] = scratch[0]; s->d_pos[1] = scratch[1];
+	// The candidates are measured in turns (round 0 = warm-up, then the minimum over two rounds): the clock of the
+	// first milliseconds after an idle period would otherwise favour whichever candidate runs first.  One measured
+	// run is long (12 sweeps), so that the fixed cost of an eager launch sequence (copies, memsets) does not decide
+	// between one launch and twenty-four.
+	for (int round = 0; round < 3 && !r; round++)
+		for (int cand = 0; cand < 3 && !r; cand++)
 		{
+			if (!use[cand]) continue;
+			s->fuse_choice = cand == 0 ? 0 : 1;
+			s->persist_choice = cand == 2;
 			if (hipMemcpyAsync(scratch[0], keep[0], (size_t)s->n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream) != hipSuccess) { r = PBDX_ERR_HIP; break; }
-			if (rep == 1) (void)hipEventRecord(s->ev_start, s->stream);
-			r = projection_sweeps(s, dt, 2, 0, nullptr);
+			if (cand == 2 && hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream) != hipSuccess) { r = PBDX_ERR_HIP; break; }
+			(void)hipEventRecord(s->ev_start, s->stream);
+			r = projection_sweeps(s, dt, round == 0 ? 2u : sweeps, 0, nullptr);
+			(void)hipEventRecord(s->ev_stop, s->stream);
+			if (hipStreamSynchronize(s->stream) != hipSuccess) r = PBDX_ERR_HIP;
+			float t = 0.0f;
+			if (!r) (void)hipEventElapsedTime(&t, s->ev_start, s->ev_stop);
+			if (round > 0) ms[cand] = ms[cand] == 0.0f ? t : std::min(ms[cand], t);
+			if (cand == 2 && (s->h_error[0] || s->h_error[1]))
+			{
+				// refused or timed out on the scratch copy: not a candidate (nothing of the real state was touched)
+				s->h_error[0] = s->h_error[1] = s->h_error[2] = 0u;
+				(void)hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream);
+				s->persist_ok = false;
+				s->persist_refusals++;
+				use[2] = false;
+				ms[2] = 0.0f;
+			}
 		}
-		(void)hipEventRecord(s->ev_stop, s->stream);
-		if (hipStreamSynchronize(s->stream) != hipSuccess) r = PBDX_ERR_HIP;
-		if (!r) (void)hipEventElapsedTime(&ms[choice], s->ev_start, s->ev_stop);
-	}
 	s->d_pos[0] = keep[0]; s->d_pos[1] = keep[1];
 	(void)hipFree(scratch[0]); (void)hipFree(scratch[1]);
-	if (r) { s->fuse_choice = 1; return r; }
-	s->fuse_choice = (ms[1] <= ms[0]) ? 1 : 0;
-	s->autotune_ms[0] = ms[0]; s->autotune_ms[1] = ms[1];
+	s->fuse_choice = 1;
+	s->persist_choice = s->persistent >= 2;
+	if (r) return r;
+	for (int i = 0; i < 3; i++) s->autotune_ms[i] = ms[i];
+	// the one-launch form must win by a margin: on a tie the simpler schedule stays
+	if (ms[2] > 0.0f && ms[2] < 0.99f * ms[1]) s->persist_choice = true;
+	const float fused_best = s->persist_choice ? ms[2] : ms[1];
+	if (ms[0] > 0.0f && ms[0] < fused_best) { s->fuse_choice = 0; s->persist_choice = false; }
+	if (s->persistent >= 2 && s->fuse_choice) s->persist_choice = true;
+	return PBDX_OK;
+}
+
+// the control block is handed to the particle kernels only while the persistent schedule runs (captured graphs are
+// rebuilt when that changes: GraphKey::persist)
+inline uint32_t *ctl_of(pbdx_solver *s, ProfCursor *) { return s->persistent_active() ? s->d_ctl : nullptr; }
+
+// second half of a substep: the sweeps and the velocity update
+int enqueue_substep_tail(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int vel, ProfCursor *pc)
+{
+	const uint32_t bs = 256;
+	const uint32_t nb = (s->n + bs - 1) / bs;
+	const int start = (int)sweep_flips(s, iters);
+	uint32_t *ctl = ctl_of(s, pc);
+	int r = projection_sweeps(s, hs, iters, start, pc);
+	if (r) return r;
+	if (s->n)
+	{
+		hipLaunchKernelGGL(velocity_kernel, dim3(nb), dim3(bs), 0, s->stream, s->d_pos[0], s->d_vel, s->d_old, s->d_last, s->n, inv_h, vel != 0, ctl);
+		HIPCHECK(hipGetLastError());
+	}
 	return PBDX_OK;
 }
 
@@ -1302,17 +1430,11 @@ int enqueue_substep(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int v
 	const int start = (int)sweep_flips(s, iters);
 	if (s->n)
 	{
-		hipLaunchKernelGGL(integrate_kernel, dim3(nb), dim3(bs), 0, s->stream, s->d_pos[0], s->d_pos[start], s->d_vel, s->d_old, s->d_last, s->n, hs, g[0], g[1], g[2]);
+		hipLaunchKernelGGL(integrate_kernel, dim3(nb), dim3(bs), 0, s->stream, s->d_pos[0], s->d_pos[start], s->d_vel, s->d_old, s->d_last, s->n, hs, g[0], g[1], g[2],
+			(const uint32_t *)ctl_of(s, pc));
 		HIPCHECK(hipGetLastError());
 	}
-	int r = projection_sweeps(s, hs, iters, start, pc);
-	if (r) return r;
-	if (s->n)
-	{
-		hipLaunchKernelGGL(velocity_kernel, dim3(nb), dim3(bs), 0, s->stream, s->d_pos[0], s->d_vel, s->d_old, s->d_last, s->n, inv_h, vel != 0);
-		HIPCHECK(hipGetLastError());
-	}
-	return PBDX_OK;
+	return enqueue_substep_tail(s, hs, inv_h, iters, vel, pc);
 }
 
 // collision detection + velocity constraint projection of the contacts, once per step after the
@@ -1330,6 +1452,7 @@ int enqueue_contacts(pbdx_solver *s)
 		a.tolerance = s->contact_tolerance; a.stiffness = s->contact_stiffness; a.restitution = r.restitution; a.friction = r.friction;
 		a.iterations = s->max_iterations_v;
 		a.counters = s->d_contact_counters;
+		a.ctl = ctl_of(s, nullptr);
 		hipLaunchKernelGGL(contact_kernel, dim3((r.count + 255) / 256), dim3(256), 0, s->stream, a);
 		HIPCHECK(hipGetLastError());
 	}
@@ -1349,6 +1472,11 @@ int collect_profile(pbdx_solver *s, ProfCursor *pc)
 			s->type_ms[t] += ms;
 			s->type_launches[t]++;
 			s->type_projections[t] += pc->counts[i];
+		}
+		else if (t == -1)
+		{
+			s->persist_ms += ms;
+			s->persist_launches++;
 		}
 		else
 		{
@@ -1392,8 +1520,10 @@ int pbdx_solver_create(pbdx_solver **out, int device)
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreate(&s->ev_start);
 	if (e == hipSuccess) e = hipEventCreate(&s->ev_stop);
-	if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s->h_error), sizeof(uint32_t), hipHostMallocMapped);
-	if (e == hipSuccess) { *s->h_error = 0u; e = hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_error), s->h_error, 0); }
+	if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s->h_error), 4 * sizeof(uint32_t), hipHostMallocMapped);
+	if (e == hipSuccess) { memset(s->h_error, 0, 4 * sizeof(uint32_t)); e = hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_error), s->h_error, 0); }
+	if (e == hipSuccess) e = hipMalloc(&s->d_ctl, kCtlWords * sizeof(uint32_t));
+	if (e == hipSuccess) e = hipMemset(s->d_ctl, 0, kCtlWords * sizeof(uint32_t));
 	if (e != hipSuccess)
 	{
 		set_error("engine initialisation failed: %s", hipGetErrorString(e));
@@ -1420,6 +1550,7 @@ void pbdx_solver_destroy(pbdx_solver *s)
 	if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
 	if (s->h_error) (void)hipHostFree(s->h_error);
+	if (s->d_ctl) (void)hipFree(s->d_ctl);
 	delete s;
 }
 
@@ -1599,7 +1730,9 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 	case PBDX_OPT_TRACE: s->trace = value != 0; break;
 	case PBDX_OPT_PAIRS: s->pairs = value != 0; replan = true; break;
 	case PBDX_OPT_PIN_HOST: s->pin_host = value != 0; if (!s->pin_host) s->unpin_all(); break;
-	case PBDX_OPT_PERSISTENT: s->persistent = value != 0; break;
+	case PBDX_OPT_PERSISTENT:
+		if (value < 0 || value > 3) { set_error("persistent must be 0 .. 3"); return PBDX_ERR_INVALID; }
+		s->persistent = (int)value; replan = true; break;
 	default: set_error("unknown option %d", option); return PBDX_ERR_INVALID;
 	}
 	s->drop_graph();
@@ -1640,13 +1773,16 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	const uint64_t launches_per_sweep = s->fused_active() ? s->dsegs.size() : s->order.size();
 	s->stats = pbdx_step_stats();
 	s->stats.projections = proj_per_sweep * max_iterations * substeps_total;
-	s->stats.kernel_launches = (s->persistent_active() && !s->profile ? 3 : launches_per_sweep * max_iterations + 2) * substeps_total;
+	s->stats.kernel_launches = (s->persistent_active() ? 3 : launches_per_sweep * max_iterations + 2) * substeps_total;
 	s->stats.algorithmic_bytes = (bytes_per_sweep * max_iterations + (uint64_t)s->n * 140) * substeps_total;
 	memset(s->type_ms, 0, sizeof(s->type_ms));
 	memset(s->type_launches, 0, sizeof(s->type_launches));
 	memset(s->type_projections, 0, sizeof(s->type_projections));
 	for (DeviceSegment &d : s->dsegs) { d.ms = 0.0; d.launches = 0; }
+	s->persist_ms = 0.0; s->persist_launches = 0;
 
+	if (s->persistent_active())
+		HIPCHECK(hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream));
 	if (s->profile)
 	{
 		HIPCHECK(hipEventRecord(s->ev_start, s->stream));
@@ -1698,6 +1834,28 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
 	}
 	HIPCHECK(hipStreamSynchronize(s->stream));
+	if (s->h_error[1])
+	{
+		// A persistent launch refused to start (its workgroups were not all resident within kArriveLimitTicks): the
+		// integrate of substep `k` ran, nothing after it did.  Complete that substep and the remaining ones with one
+		// launch per segment -- the result is the one an undisturbed run produces -- and stop using the schedule.
+		const uint64_t k = s->h_error[2];
+		s->h_error[1] = s->h_error[2] = 0u;
+		s->persist_ok = false;
+		s->persist_refusals++;
+		s->drop_graph();
+		HIPCHECK(hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream));
+		int r = enqueue_substep_tail(s, hs, inv_h, max_iterations, vel, nullptr);
+		if (!r && (k + 1) % sub_steps == 0) r = enqueue_contacts(s);
+		for (uint64_t k2 = k + 1; !r && k2 < substeps_total; k2++)
+		{
+			r = enqueue_substep(s, hs, inv_h, max_iterations, vel, gravity, nullptr);
+			if (!r && (k2 + 1) % sub_steps == 0) r = enqueue_contacts(s);
+		}
+		if (r) return r;
+		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
+		HIPCHECK(hipStreamSynchronize(s->stream));
+	}
 	float ms = 0.0f;
 	HIPCHECK(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
 	s->stats.total_ms = ms;
@@ -1717,9 +1875,22 @@ int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
 	const int start = (int)sweep_flips(s, iterations);
 	if (start)
 		HIPCHECK(hipMemcpyAsync(s->d_pos[1], s->d_pos[0], (size_t)s->n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+	if (s->persistent_active())
+		HIPCHECK(hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream));
 	r = projection_sweeps(s, h_sub, iterations, start, nullptr);
 	if (r) return r;
 	HIPCHECK(hipStreamSynchronize(s->stream));
+	if (s->h_error[1])
+	{
+		// the persistent launch refused to start and modified nothing: sweep with one launch per segment instead
+		s->h_error[1] = s->h_error[2] = 0u;
+		s->persist_ok = false;
+		s->persist_refusals++;
+		HIPCHECK(hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream));
+		r = projection_sweeps(s, h_sub, iterations, start, nullptr);
+		if (r) return r;
+		HIPCHECK(hipStreamSynchronize(s->stream));
+	}
 	return check_persistent(s);
 }
 
@@ -1881,6 +2052,22 @@ int pbdx_solver_get_segment_info(pbdx_solver *s, uint32_t segment, pbdx_segment_
 	return PBDX_OK;
 }
 
+int pbdx_solver_get_persistent_info(pbdx_solver *s, pbdx_persistent_info *out)
+{
+	if (!s || !out) return PBDX_ERR_INVALID;
+	memset(out, 0, sizeof(*out));
+	out->eligible = s->persist_ok ? 1 : 0;
+	out->active = s->persistent_active() ? 1 : 0;
+	out->grid = s->persist_grid; out->block = (uint32_t)s->persist_block; out->lds_bytes = s->persist_lds;
+	out->refusals = s->persist_refusals;
+	out->autotune_fused_ms = s->autotune_ms[1];
+	out->autotune_persistent_ms = s->autotune_ms[2];
+	out->profiled_ms = s->persist_ms;
+	out->profiled_launches = s->persist_launches;
+	for (const DeviceSegment &d : s->dsegs) out->algorithmic_bytes_per_sweep += d.algorithmic_bytes;
+	return PBDX_OK;
+}
+
 int pbdx_solver_get_trace(pbdx_solver *s, uint32_t segment, uint64_t *out, uint32_t capacity, uint32_t *stride)
 {
 	if (!s || !out || !s->plan_ok || segment >= s->dsegs.size() || !s->dsegs[segment].d_trace) { set_error("get_trace: no trace for this segment (set PBDX_OPT_TRACE and step once)"); return PBDX_ERR_INVALID; }
@@ -1934,8 +2121,10 @@ int pbdx_solver_describe(pbdx_solver *s, char *buf, size_t n)
 			for (const FusedSegment &seg : s->plan.segs) ml = std::max(ml, seg.max_local);
 			int w2 = snprintf(buf + w, n - w, " schedule=%s segments=%zu tiles=%u redundancy=%.3f max_tile_particles=%u plan_s=%.2f",
 				s->persistent_active() ? "fused-persistent" : "fused", s->plan.segs.size(), s->plan.num_tiles, s->plan.redundancy, ml, s->plan.build_seconds);
-			if (s->autotune_ms[1] > 0.0f && w2 > 0 && (size_t)(w + w2) < n)
-				snprintf(buf + w + w2, n - w - w2, " autotune(per-colour %.3f ms, fused %.3f ms)", s->autotune_ms[0], s->autotune_ms[1]);
+			if (s->persist_refusals && w2 > 0 && (size_t)(w + w2) < n)
+				w2 += snprintf(buf + w + w2, n - w - w2, " persistent_refusals=%u", s->persist_refusals);
+			if ((s->autotune_ms[1] > 0.0f || s->autotune_ms[2] > 0.0f) && w2 > 0 && (size_t)(w + w2) < n)
+				snprintf(buf + w + w2, n - w - w2, " autotune(per-colour %.3f ms, fused %.3f ms, persistent %.3f ms)", s->autotune_ms[0], s->autotune_ms[1], s->autotune_ms[2]);
 		}
 		else
 		{

@@ -39,7 +39,10 @@ for name, (spec, steps) in scenes.items():
     if only and not any(o in name for o in only):
         continue
     x0, v0, t0, plan, d0 = run(spec, 0, steps)
-    x1, v1, t1, _, d1 = run(spec, 1, steps)
+    x1, v1, t1, _, d1 = run(spec, 2, steps)
+    x2, v2, t2, _, d2 = run(spec, 3, steps)      # self-test: the first persistent launch is refused, the engine recovers
+    rec = np.array_equal(x0.view(np.uint32), x2.view(np.uint32)) and np.array_equal(v0.view(np.uint32), v2.view(np.uint32))
+    print("   refused-launch recovery bit-identical: %s  [%s]" % (rec, d2[d2.find("schedule="):][:120]))
     same = np.array_equal(x0.view(np.uint32), x1.view(np.uint32)) and np.array_equal(v0.view(np.uint32), v1.view(np.uint32))
     print("%-40s tiles %4d segs %d  multi-launch %.4f ms  persistent %.4f ms  (%.3fx)  bit-identical: %s" % (
         name, plan["num_tiles"], plan["num_segments"], 1e3 * t0, 1e3 * t1, t0 / t1, same), flush=True)

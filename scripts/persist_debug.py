@@ -20,7 +20,7 @@ inst = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 spec = util.cloth_spec(200, 200, 4, 3, instances=inst, instance_offset=(0.0, 0.0, 12.0))
 for iters in (1, 2):
     x0, plan = run(spec, 0, 1, iters)
-    x1, _ = run(spec, 1, 1, iters)
+    x1, _ = run(spec, 2, 1, iters)
     d = np.nonzero((x0.view(np.uint32) != x1.view(np.uint32)).any(axis=1))[0]
     print("iters", iters, "tiles", plan["num_tiles"], "differing", len(d))
     if len(d):

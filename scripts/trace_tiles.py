@@ -14,7 +14,7 @@ ap.add_argument("--size", type=int, default=1000)
 ap.add_argument("--max-seg", type=int, default=None)
 ap.add_argument("--tile", type=int, default=None)
 ap.add_argument("--fuse-block", type=int, default=None)
-ap.add_argument("--persistent", type=int, default=0)
+ap.add_argument("--persistent", type=int, default=0, help="0 one launch per segment, 2 one launch per substep")
 ap.add_argument("--graph", type=int, default=0, help="1: keep the hipGraph (kernel-to-kernel dead time as it is in production)")
 args = ap.parse_args()
 model = util.build_mine(util.cloth_spec(args.size, args.size, 4, 3))

@@ -504,7 +504,8 @@ def test_auto_schedule_selection_is_measured_and_result_invariant(pbd):
     S = pbd.Solver
     cloth = util.cloth_spec(40, 40, 4, 3)
     m, ts = util.mine_run(cloth, 2, 1, 5)
-    assert ts.solver().plan_info()["active"] == 1 and "autotune" not in ts.solver().describe()
+    # (only the two forms of the fused schedule are timed against each other: PBDX_OPT_PERSISTENT)
+    assert ts.solver().plan_info()["active"] == 1 and "autotune(per-colour 0.000 ms" in ts.solver().describe()
     bar = util.bar_spec(30, 5, 5, 2)
     ma, tsa = util.mine_run(bar, 3, 1, 5)                                  # auto
     d = tsa.solver().describe()
@@ -557,3 +558,46 @@ def test_raw_solver_abi_like_a_reference_side_binding(pbd):
     with pytest.raises(pbd.PbdxError):
         sol.add_batch(0, 99, np.array([0, 1], dtype=np.uint32), np.array([1.0, 1.0], dtype=np.float32))          # unknown type
     sol.end_schedule()
+
+
+@pytest.mark.gpu
+def test_persistent_schedule_is_bit_identical_and_recovers_from_a_refused_launch(pbd):
+    """PBDX_OPT_PERSISTENT: all sweeps of a substep as ONE launch (tile-to-tile hand-off inside the launch) must not
+    change a bit against one launch per segment -- cloth, an irregular mesh with every light type, a FEM bar, many
+    tiles per workgroup -- and a launch that finds its workgroups not co-resident (self-test, value 3) must leave the
+    state untouched so that the engine completes the very same step with the multi-launch schedule."""
+    S = pbd.Solver
+    scenes = [("xpbd cloth 90x90", util.cloth_spec(90, 90, 4, 3), 4, 2, 6, {}),
+              ("pbd cloth, second-order velocities", util.cloth_spec(40, 40, 1, 2), 5, 1, 4, {"vel_method": 1}),
+              ("kitchen sink", util.kitchen_sink_spec(), 4, 2, 4, {}),
+              ("fem bar", util.bar_spec(30, 6, 6, 2), 4, 1, 5, {}),
+              ("xpbd cloth 120x120, 60-particle tiles (more tiles than CUs)", util.cloth_spec(120, 120, 4, 3), 3, 1, 4, {"opts": {S.OPT_TILE_PARTICLES: 48}})]
+    for label, ops, steps, sub, iters, extra in scenes:
+        opts = dict(extra.get("opts", {}))
+        opts[S.OPT_FUSE] = 1
+        kw = dict(vel_method=extra.get("vel_method", 0))
+        ref, tsr = util.mine_run(ops, steps, sub, iters, options={**opts, S.OPT_PERSISTENT: 0}, **kw)
+        assert tsr.solver().plan_info()["active"] == 1, label
+        xr, vr = ref.getParticles().positions(), ref.getParticles().array(2)
+        for mode, resident in ((2, False), (2, True), (3, False), (3, True)):
+            m, ts = util.mine_run(ops, steps, sub, iters, resident=resident, options={**opts, S.OPT_PERSISTENT: mode}, **kw)
+            info = ts.solver().persistent_info()
+            # (a plan with more than 8 segments -- the kitchen sink -- is not eligible and runs one launch per segment)
+            eligible_before = info["eligible"] == 1 or info["refusals"] >= 1
+            if label != "kitchen sink":
+                assert eligible_before, (label, info)
+            if mode == 2:
+                assert info["active"] == info["eligible"] and info["refusals"] == 0, (label, info)
+            else:
+                assert info["active"] == 0 and info["refusals"] == (1 if eligible_before else 0), (label, info)
+            assert util.bitwise_equal(m.getParticles().positions(), xr), (label, mode, resident)
+            assert util.bitwise_equal(m.getParticles().array(2), vr), (label, mode, resident)
+
+
+@pytest.mark.gpu
+def test_persistent_schedule_auto_mode_reports_its_measurement(pbd):
+    """Default (1): the one-launch form is timed once against one launch per segment on scratch positions."""
+    m, ts = util.mine_run(util.cloth_spec(64, 64, 4, 3), 2, 1, 5)
+    info = ts.solver().persistent_info()
+    assert info["eligible"] == 1 and info["autotune_fused_ms"] > 0 and info["autotune_persistent_ms"] > 0
+    assert info["active"] == (1 if info["autotune_persistent_ms"] < 0.99 * info["autotune_fused_ms"] else 0)
