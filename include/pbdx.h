@@ -216,7 +216,7 @@ enum {
 	PBDX_OPT_PAIRS = 10,           /* project two chunks of a colour step jointly with packed fp32 arithmetic (default 0: measured slower) */
 	PBDX_OPT_PERSISTENT = 12       /* fused schedule only: all sweeps of a substep as ONE launch; a tile starts its next pass as soon as its
 	                                * neighbouring tiles have published theirs (no kernel boundary, no chip-wide wait for the slowest tile).
-	                                * 1 (default) = used where a one-off measurement on scratch positions finds it faster than one launch per
+	                                * 1 (default) = used unless a one-off measurement on scratch positions finds it clearly slower than one launch per
 	                                * segment, 0 = never, 2 = always (if the plan is eligible), 3 = self-test (the launch is made to refuse).  Needs every workgroup co-resident: the
 	                                * launch first checks that (bounded handshake); if not, it modifies nothing, the engine completes the step
 	                                * with one launch per segment and stops using the schedule (pbdx_solver_describe: persistent_refusals). */

@@ -1392,8 +1392,10 @@ int autotune_schedule(pbdx_solver *s)
 	s->persist_choice = s->persistent >= 2;
 	if (r) return r;
 	for (int i = 0; i < 3; i++) s->autotune_ms[i] = ms[i];
-	// the one-launch form must win by a margin: on a tie the simpler schedule stays
-	if (ms[2] > 0.0f && ms[2] < 0.99f * ms[1]) s->persist_choice = true;
+	// The short run on scratch positions understates the one-launch form (measured 1-3 % ahead here where whole
+	// substeps are 5-8 % faster: its launch-time costs are spread over 12 sweeps, not over a substep loop), so it
+	// is only rejected where it is clearly behind.
+	if (ms[2] > 0.0f && ms[2] < 1.02f * ms[1]) s->persist_choice = true;
 	const float fused_best = s->persist_choice ? ms[2] : ms[1];
 	if (ms[0] > 0.0f && ms[0] < fused_best) { s->fuse_choice = 0; s->persist_choice = false; }
 	if (s->persistent >= 2 && s->fuse_choice) s->persist_choice = true;

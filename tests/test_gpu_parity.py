@@ -600,4 +600,4 @@ def test_persistent_schedule_auto_mode_reports_its_measurement(pbd):
     m, ts = util.mine_run(util.cloth_spec(64, 64, 4, 3), 2, 1, 5)
     info = ts.solver().persistent_info()
     assert info["eligible"] == 1 and info["autotune_fused_ms"] > 0 and info["autotune_persistent_ms"] > 0
-    assert info["active"] == (1 if info["autotune_persistent_ms"] < 0.99 * info["autotune_fused_ms"] else 0)
+    assert info["active"] == (1 if info["autotune_persistent_ms"] < 1.02 * info["autotune_fused_ms"] else 0)
