@@ -348,7 +348,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 				for (uint32_t cid : bk) steps_ns += kSlotNs[g.batch_of(cid).type];
 				const uint32_t n_local = n_owned + (uint32_t)s.halo.size();
 				const size_t e = (size_t)c1 * maxlen + (c1 - c - 1);
-				tb[th][e] += steps_ns + kFillNsPerParticle * n_local + kWriteBackNsPerParticle * n_owned;
+				tb[th][e] += steps_ns + kFillNsPerParticle * (opt.owned_stay_in_lds ? n_local - n_owned : n_local) + kWriteBackNsPerParticle * n_owned;
 				tm[th][e] = std::max(tm[th][e], n_local);
 			});
 		});

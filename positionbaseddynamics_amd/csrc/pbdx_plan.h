@@ -166,6 +166,7 @@ struct PlanOptions
 	uint32_t max_segment_colours = 16;
 	uint32_t max_tile_steps = 64;       // (colour, type) runs one tile may have in one segment
 	double launch_cost_ns = 3000.0;     // cost of one more launch (kernel boundary + tail)
+	bool owned_stay_in_lds = false;     // persistent schedule: a pass stages only the halo, and a pass boundary is a tile-to-tile hand-off
 	uint32_t threads = 0;               // 0 = auto
 };
 

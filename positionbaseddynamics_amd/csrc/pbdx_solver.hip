@@ -930,6 +930,11 @@ int prepare_persistent(pbdx_solver *s)
 		lds = std::max(lds, d.lds_bytes);
 	}
 	if ((mask & ~kMaskLight) && s->dsegs[0].block > 512) return PBDX_OK;
+	{
+		// the kernel keeps two flag words in static LDS next to the dynamic tile image
+		const size_t cap = s->prop.maxSharedMemoryPerMultiProcessor ? s->prop.maxSharedMemoryPerMultiProcessor : s->prop.sharedMemPerBlock;
+		if ((size_t)lds + 64 > cap) return PBDX_OK;
+	}
 	// read-after-write: owners of a tile's halo in segment si
 	std::vector<std::vector<std::vector<uint32_t>>> raw(nseg, std::vector<std::vector<uint32_t>>(k));
 	for (size_t si = 0; si < nseg; si++)
@@ -1006,6 +1011,16 @@ int ensure_plan(pbdx_solver *s)
 	}
 	opt.num_cus = (uint32_t)std::max(1, s->prop.multiProcessorCount);
 	opt.max_segment_colours = s->max_segment_colours;
+	if (s->persistent && !s->pairs && (uint64_t)s->n > (uint64_t)opt.num_cus * 1024u)
+	{
+		// (large tiles only: with the 512-particle tiles of small scenes a pass is a few short colour steps and the
+		// hand-off is what an extra pass costs -- measured 7 % slower on a 300x300 cloth and on the FEM bar)
+		// planned for the one-launch schedule: a pass boundary costs a tile-to-tile hand-off (publish, poll, halo fill),
+		// not a kernel boundary plus a full fill -- shorter segments with less halo redundancy pay off
+		// (1 M cloth: 3 passes per sweep at redundancy 1.23 instead of 2 at 1.40, measured 2.6 % faster)
+		opt.launch_cost_ns = 1500.0;
+		opt.owned_stay_in_lds = true;
+	}
 	if (!build_fused_plan(s->n, s->h_x.data(), pbs, opt, s->plan, s->plan_why))
 		return PBDX_OK;
 	// workgroup size per segment: enough threads to cover the largest colour step of a tile once, at most 1024
