@@ -20,6 +20,9 @@
 //      streams 16-bit tile-local indices, the planar parameter records and the XPBD multiplier
 //      once from HBM; positions never leave the CU during the segment.  A 27-colour cloth sweep
 //      becomes 2-4 launches instead of 29.
+//  (A') the same tiles and passes as ONE persistent launch per substep: a tile starts its next pass as
+//      soon as its neighbouring tiles have published theirs (persistent_kernel; default where measured
+//      faster; needs every workgroup resident, checked by a handshake before anything is modified).
 //  (B) one launch per (colour, type) batch straight on the HBM/L2-resident position array
 //      (32-bit indices).  Used when a plan cannot be built, for per-type profiling, and as the
 //      cross-check of (A) in the tests (the two are bit-identical by construction).
@@ -211,7 +214,7 @@ __device__ __forceinline__ void store_pos(float4 *base, uint32_t index, float4 v
 }
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// LDS fill of a tile (called by the tile's first run once its ring is primed).  gid -> position is a dependent
+// LDS fill of a tile.  gid -> position is a dependent
 // pair of HBM round trips; written as a plain loop every thread pays that pair once per particle it stages
 // (7 x 2 serialised latencies for a 7 000-particle tile).  The loads are issued in batches instead: the chunk
 // descriptor, then kFillBatch particle ids, then their kFillBatch positions -- two exposed latencies per batch,
@@ -421,9 +424,6 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 // plan.  Arithmetic, order and streams are those of (A): results are bit-identical.
 // Residency: gridDim <= number of CUs and one workgroup per CU; HIP guarantees neither, so every wait is bounded
 // (kSpinLimitTicks) and a timeout raises `*error` instead of hanging -- the host then falls back to (A).
-#ifndef PBDX_KEEP_OWNED
-#define PBDX_KEEP_OWNED 1
-#endif
 constexpr uint32_t kMaxPersistSegs = 8;
 constexpr unsigned long long kSpinLimitTicks = 2000000ull;      // 20 ms of the 100 MHz wall clock
 constexpr unsigned long long kArriveLimitTicks = 100000ull;     // 1 ms: all workgroups of a launch must have started by then
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 			};
 			unsigned long long *trace = (a.trace[sgi] && pass + a.num_segs >= a.passes) ? a.trace[sgi] + (size_t)tile * kTraceStride : nullptr;
 			// one tile per workgroup: its owned particles stay in LDS from pass to pass
-			process_tile<MASK, BLOCK, false, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, PBDX_KEEP_OWNED && pass != 0 && gridDim.x == a.num_tiles, wait);
+			process_tile<MASK, BLOCK, false, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && gridDim.x == a.num_tiles, wait);
 			if (s_failed)
 			{
 				// a neighbour never arrived: the result is garbage, say so and leave (uniform: one LDS word)
