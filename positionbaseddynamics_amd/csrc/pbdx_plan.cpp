@@ -609,4 +609,124 @@ bool check_fused_plan(uint32_t n, const std::vector<PlanBatch> &batches, const F
 	return true;
 }
 
+void build_persistent_deps(const FusedPlan &plan, PersistentDeps &out)
+{
+	const size_t nseg = plan.segs.size();
+	const uint32_t k = plan.num_tiles;
+	out.off.assign(nseg, std::vector<uint32_t>());
+	out.tile.assign(nseg, std::vector<uint32_t>());
+	// read-after-write: owners of a tile's halo in segment si
+	std::vector<std::vector<std::vector<uint32_t>>> raw(nseg, std::vector<std::vector<uint32_t>>(k));
+	for (size_t si = 0; si < nseg; si++)
+	{
+		const FusedSegment &seg = plan.segs[si];
+		for (uint32_t t = 0; t < k; t++)
+		{
+			const FusedTile &ft = seg.tiles[t];
+			std::vector<uint32_t> &r = raw[si][t];
+			for (uint32_t i = ft.n_owned; i < ft.n_local; i++) r.push_back(plan.tile_of[seg.gid[ft.gid_off + i]]);
+			std::sort(r.begin(), r.end());
+			r.erase(std::unique(r.begin(), r.end()), r.end());
+		}
+	}
+	for (size_t si = 0; si < nseg; si++)
+	{
+		// + write-after-read: the tiles that read this tile's particles one pass earlier (segment si - 1)
+		const size_t sp = (si + nseg - 1) % nseg;
+		std::vector<std::vector<uint32_t>> dep = raw[si];
+		for (uint32_t u = 0; u < k; u++)
+			for (uint32_t t : raw[sp][u]) dep[t].push_back(u);
+		out.off[si].assign(k + 1, 0);
+		for (uint32_t t = 0; t < k; t++)
+		{
+			std::vector<uint32_t> &d = dep[t];
+			std::sort(d.begin(), d.end());
+			d.erase(std::unique(d.begin(), d.end()), d.end());
+			d.erase(std::remove(d.begin(), d.end(), t), d.end());
+			out.tile[si].insert(out.tile[si].end(), d.begin(), d.end());
+			out.off[si][t + 1] = (uint32_t)out.tile[si].size();
+		}
+	}
+}
+
+bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, uint32_t passes, std::string &why)
+{
+	const size_t nseg = plan.segs.size();
+	const uint32_t k = plan.num_tiles, n = plan.num_particles;
+	if (!nseg || !k || deps.off.size() != nseg || deps.tile.size() != nseg) { why = "persistent deps: shape"; return false; }
+	for (size_t si = 0; si < nseg; si++)
+		if (deps.off[si].size() != (size_t)k + 1 || deps.off[si][k] != deps.tile[si].size()) { why = "persistent deps: CSR"; return false; }
+	// scheduler strategies: 0 most advanced tile first, 1 least advanced first, 2 pseudo-random, 3.. hold tile (strategy - 3) back
+	const uint32_t held_samples = std::min(k, 6u);
+	for (uint32_t strategy = 0; strategy < 3 + held_samples; strategy++)
+	{
+		const uint32_t held = strategy >= 3 ? (uint32_t)(((uint64_t)(strategy - 3) * k) / held_samples) : 0xffffffffu;
+		// version of every particle in the two position buffers: the pass that wrote it (-1 = initial state, -2 = never written)
+		std::vector<int32_t> ver[2] = { std::vector<int32_t>(n, -1), std::vector<int32_t>(n, -2) };
+		std::vector<uint32_t> done(k, 0);          // passes published
+		std::vector<uint8_t> filled(k, 0);         // FILL of pass done[t] has happened, WRITE-BACK has not
+		uint64_t rng = 0x9e3779b97f4a7c15ull + strategy;
+		uint64_t remaining = (uint64_t)k * passes * 2;
+		while (remaining)
+		{
+			// enabled events
+			uint32_t pick = 0xffffffffu, pick_held = 0xffffffffu;
+			uint32_t best_key = 0;
+			uint32_t seen = 0;
+			for (uint32_t t = 0; t < k; t++)
+			{
+				if (done[t] >= passes) continue;
+				bool enabled = true;
+				if (!filled[t] && done[t] > 0)
+				{
+					const uint32_t p = done[t], si = p % (uint32_t)nseg;
+					for (uint32_t d = deps.off[si][t]; d < deps.off[si][t + 1] && enabled; d++)
+						if (done[deps.tile[si][d]] < p) enabled = false;
+				}
+				if (!enabled) continue;
+				if (t == held) { pick_held = t; continue; }
+				const uint32_t prog = done[t] * 2 + filled[t];
+				seen++;
+				bool take = false;
+				if (pick == 0xffffffffu) take = true;
+				else if (strategy == 1) take = prog < best_key;
+				else if (strategy == 2) { rng = rng * 6364136223846793005ull + 1442695040888963407ull; take = (rng >> 33) % seen == 0; }
+				else take = prog > best_key;       // most advanced first (also while a tile is held back)
+				if (take) { pick = t; best_key = prog; }
+			}
+			if (pick == 0xffffffffu) pick = pick_held;     // the held tile only moves when nothing else can
+			if (pick == 0xffffffffu) { why = "persistent deps: the schedule deadlocks"; return false; }
+			const uint32_t t = pick, p = done[t], si = p % (uint32_t)nseg;
+			const FusedSegment &seg = plan.segs[si];
+			const FusedTile &ft = seg.tiles[t];
+			if (!filled[t])
+			{
+				const std::vector<int32_t> &in = ver[p & 1u];
+				for (uint32_t i = 0; i < ft.n_local; i++)
+				{
+					const uint32_t g = seg.gid[ft.gid_off + i];
+					if (in[g] != (int32_t)p - 1)
+					{
+						char buf[256];
+						snprintf(buf, sizeof(buf), "persistent deps: tile %u pass %u (segment %u) reads particle %u of tile %u at version %d, expected %d (scheduler %u)",
+							t, p, si, g, plan.tile_of[g], in[g], (int32_t)p - 1, strategy);
+						why = buf;
+						return false;
+					}
+				}
+				filled[t] = 1;
+			}
+			else
+			{
+				std::vector<int32_t> &outv = ver[(p + 1) & 1u];
+				for (uint32_t i = 0; i < ft.n_owned; i++) outv[seg.gid[ft.gid_off + i]] = (int32_t)p;
+				filled[t] = 0;
+				done[t] = p + 1;
+			}
+			remaining--;
+		}
+	}
+	return true;
+}
+
 } // namespace pbdx

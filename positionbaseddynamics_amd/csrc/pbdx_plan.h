@@ -193,6 +193,26 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 // every particle is owned exactly once and that every local index is in range.
 bool check_fused_plan(uint32_t n, const std::vector<PlanBatch> &batches, const FusedPlan &plan, std::string &why);
 
+// ---- persistent schedule (all passes of a substep in one launch, tiles synchronised pairwise) -------------
+// Per segment a CSR list: the tiles whose pass p-1 must be complete before tile t may start pass p when that
+// pass runs segment s.  = owners of t's halo in s (read-after-write) + tiles that had particles of t in their
+// halo in the previous segment (write-after-read on the double-buffered positions); t itself never listed
+// (a workgroup runs its own passes in order).
+struct PersistentDeps
+{
+	std::vector<std::vector<uint32_t>> off;    // [segment][tile + 1]
+	std::vector<std::vector<uint32_t>> tile;   // [segment][...]
+};
+void build_persistent_deps(const FusedPlan &plan, PersistentDeps &out);
+
+// Asynchronous-execution check of the lists: a host simulation in which every tile alternates FILL (reads its
+// local particles from the pass's input buffer) and WRITE-BACK (writes its owned particles to the other buffer,
+// then publishes the pass), tiles advancing in adversarial orders (most advanced first, least advanced first,
+// one tile held back for as long as the lists allow, pseudo-random) subject only to the lists.  Every FILL must
+// find, for every particle it reads, the version written by pass p-1 (or the initial state for pass 0).
+// `passes` = iterations x segments to simulate.
+bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, uint32_t passes, std::string &why);
+
 } // namespace pbdx
 
 #endif

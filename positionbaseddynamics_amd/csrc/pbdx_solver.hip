@@ -935,39 +935,15 @@ int prepare_persistent(pbdx_solver *s)
 		const size_t cap = s->prop.maxSharedMemoryPerMultiProcessor ? s->prop.maxSharedMemoryPerMultiProcessor : s->prop.sharedMemPerBlock;
 		if ((size_t)lds + 64 > cap) return PBDX_OK;
 	}
-	// read-after-write: owners of a tile's halo in segment si
-	std::vector<std::vector<std::vector<uint32_t>>> raw(nseg, std::vector<std::vector<uint32_t>>(k));
+	// per (segment, tile) the tiles it waits for (pbdx_plan.cpp; checked by an asynchronous-execution simulation in
+	// pbdx_model_plan_check / tests/test_plan.py)
+	PersistentDeps deps;
+	build_persistent_deps(s->plan, deps);
 	for (size_t si = 0; si < nseg; si++)
 	{
-		const FusedSegment &seg = s->plan.segs[si];
-		for (uint32_t t = 0; t < k; t++)
-		{
-			const FusedTile &ft = seg.tiles[t];
-			std::vector<uint32_t> &r = raw[si][t];
-			for (uint32_t i = ft.n_owned; i < ft.n_local; i++) r.push_back(s->plan.tile_of[seg.gid[ft.gid_off + i]]);
-			std::sort(r.begin(), r.end());
-			r.erase(std::unique(r.begin(), r.end()), r.end());
-		}
-	}
-	for (size_t si = 0; si < nseg; si++)
-	{
-		// + write-after-read: the tiles that read this tile's particles one pass earlier (segment si - 1)
-		const size_t sp = (si + nseg - 1) % nseg;
-		std::vector<std::vector<uint32_t>> dep = raw[si];
-		for (uint32_t u = 0; u < k; u++)
-			for (uint32_t t : raw[sp][u]) dep[t].push_back(u);
-		std::vector<uint32_t> off(k + 1, 0), lst;
-		for (uint32_t t = 0; t < k; t++)
-		{
-			std::vector<uint32_t> &d = dep[t];
-			std::sort(d.begin(), d.end());
-			d.erase(std::unique(d.begin(), d.end()), d.end());
-			d.erase(std::remove(d.begin(), d.end(), t), d.end());      // a workgroup runs its own passes in order
-			lst.insert(lst.end(), d.begin(), d.end());
-			off[t + 1] = (uint32_t)lst.size();
-		}
+		std::vector<uint32_t> lst = deps.tile[si];
 		if (lst.empty()) lst.push_back(0);
-		int r = upload(&s->dsegs[si].d_dep_off, off);
+		int r = upload(&s->dsegs[si].d_dep_off, deps.off[si]);
 		if (!r) r = upload(&s->dsegs[si].d_dep_tile, lst);
 		if (r) return r;
 	}

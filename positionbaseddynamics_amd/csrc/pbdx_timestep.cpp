@@ -142,6 +142,32 @@ int pbdx_model_plan_check(pbdx_model *m, uint32_t tile_particles, uint32_t lds_p
 	std::string why;
 	if (!build_fused_plan(m->size(), m->x.data(), pbs, opt, plan, why)) { set_error("plan: %s", why.c_str()); return PBDX_ERR_INVALID; }
 	if (!check_fused_plan(m->size(), pbs, plan, why)) { set_error("plan check: %s", why.c_str()); return PBDX_ERR_INVALID; }
+	{
+		// the persistent schedule's tile-to-tile dependency lists: asynchronous-execution check (three sweeps), and the
+		// check of the check -- with one dependency removed the simulation must find the stale read
+		PersistentDeps deps;
+		build_persistent_deps(plan, deps);
+		const uint32_t passes = 3 * (uint32_t)plan.segs.size();
+		if (!check_persistent_deps(plan, deps, passes, why)) { set_error("plan check: %s", why.c_str()); return PBDX_ERR_INVALID; }
+		PersistentDeps broken = deps;
+		bool removed = false;
+		for (uint32_t t = 1; t < plan.num_tiles && !removed; t++)
+			for (size_t si = 0; si < broken.off.size(); si++)
+			{
+				std::vector<uint32_t> &lst = broken.tile[si];
+				std::vector<uint32_t> &off = broken.off[si];
+				for (uint32_t d = off[t]; d < off[t + 1]; d++)
+					if (lst[d] == 0u)       // tile 0 is one of the tiles the checker holds back
+					{
+						lst.erase(lst.begin() + d);
+						for (uint32_t q = t + 1; q <= plan.num_tiles; q++) off[q]--;
+						removed = true;
+						break;
+					}
+			}
+		if (removed && check_persistent_deps(plan, broken, passes, why))
+		{ set_error("plan check: the asynchronous-execution check accepted dependency lists with a missing entry"); return PBDX_ERR_INVALID; }
+	}
 	if (out)
 	{
 		memset(out, 0, sizeof(*out));

@@ -4,7 +4,13 @@ pbdx_model_plan_check packs the model's colour groups exactly as the time step d
 segments and then EXECUTES the plan symbolically (every particle carries a hash of its update
 history): the fused schedule must hand every particle the history of the reference's
 colour-sequential sweep (TimeStepController.cpp:270-286), every particle must be owned by exactly
-one tile per segment and every tile-local index must map to the right particle."""
+one tile per segment and every tile-local index must map to the right particle.
+
+It also checks the tile-to-tile dependency lists of the persistent schedule (all passes of a substep in one
+launch): a host simulation lets the tiles run asynchronously in adversarial orders (most advanced first, least
+advanced first, pseudo-random, one tile held back) subject only to the lists and requires every LDS fill to find
+the particle versions of the previous pass in the double-buffered positions; and it checks the checker -- with
+one list entry removed the simulation must report the stale read."""
 import pytest
 
 from tests import util
