@@ -345,13 +345,108 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 // LDS: [ chunk descriptors of the tile: kMaxTileChunks x 16 B ][ positions: n_local x float4 ]
 constexpr uint32_t kMaxTileSteps = 64;
 
+// Integration and velocity update folded into the persistent launch (first / last pass of a substep): the two
+// streaming kernels around the sweeps, their kernel boundaries and one round trip of the positions disappear.
+// The arithmetic is that of integrate_kernel / velocity_kernel, operation for operation; a tile integrates its halo
+// particles redundantly (same inputs, same operations as their owners) and stores state only for the ones it owns.
+struct FoldArgs
+{
+	float4 *vel, *old, *last;
+	uint32_t state_bytes;          // n * 16 (buffer descriptors)
+	float h, gx, gy, gz, inv_h;
+	int second_order;
+};
+__device__ __forceinline__ float4 load_f4_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t index)
+{
+	typedef float f4 __attribute__((ext_vector_type(4)));
+	// sc1: past the CU's L1, which may still hold the line from before this workgroup's own store earlier in the launch
+	const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(index * 16u), 0, 16));
+	return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// pass 0 of a substep: stage x + v' h (TimeIntegration.cpp:7-19, v' = v + g h) for every local particle; for the owned
+// ones also last <- old, old <- x (TimeStepController.cpp:112-118).  The state arrays were written by
+// earlier launches: plain loads.
+template <int BLOCK>
+__device__ __forceinline__ void integrate_fill(const FoldArgs &f, const uint4 *src, const uint32_t *gid, const float4 *pos_in, uint4 *lchunks, float4 *lpos,
+	uint32_t num_chunks, uint32_t n_local, uint32_t n_owned, unsigned long long *trace)
+{
+	uint4 chv = make_uint4(0u, 0u, 0u, 0u);
+	if (threadIdx.x < num_chunks) chv = src[threadIdx.x];
+	const uint32_t last_i = n_local - 1u;
+	for (uint32_t base = threadIdx.x; base < n_local; base += 4u * BLOCK)
+	{
+		uint32_t g[4];
+		float4 x[4], v[4];
+#pragma unroll
+		for (uint32_t k = 0; k < 4; k++) { const uint32_t i = base + k * BLOCK; g[k] = gid[i < last_i ? i : last_i]; }
+#pragma unroll
+		for (uint32_t k = 0; k < 4; k++) { x[k] = pos_in[g[k]]; v[k] = f.vel[g[k]]; }
+#pragma unroll
+		for (uint32_t k = 0; k < 4; k++)
+		{
+			const uint32_t i = base + k * BLOCK;
+			if (i >= n_local) continue;
+			float4 p = x[k], w = v[k];
+			if (w.w != 0.0f)   // mass != 0
+			{
+				w.x = w.x + f.gx * f.h; w.y = w.y + f.gy * f.h; w.z = w.z + f.gz * f.h;
+				p.x = p.x + w.x * f.h; p.y = p.y + w.y * f.h; p.z = p.z + w.z * f.h;
+			}
+			lpos[i] = p;
+			if (i < n_owned)
+			{
+				f.last[g[k]] = f.old[g[k]];
+				f.old[g[k]] = x[k];
+				// v' is NOT stored: neighbouring tiles integrate this particle as part of their halo from the same v
+				// (possibly later than this tile), and the velocity update of the last pass overwrites vel anyway
+			}
+		}
+	}
+	if (threadIdx.x < num_chunks) lchunks[threadIdx.x] = chv;
+	__syncthreads();
+	if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
+}
+
+// last pass of a substep: final positions + TimeIntegration::velocityUpdateFirstOrder / SecondOrder (TimeIntegration.cpp:42-51,
+// 69-79) for the owned particles.  old / last / vel were written by this workgroup in pass 0 of the same launch: sc1 loads.
+template <int BLOCK>
+__device__ __forceinline__ void velocity_write_back(const FoldArgs &f, const uint32_t *gid, float4 *pos_out, const float4 *lpos, uint32_t n_owned)
+{
+	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(f.vel, 0, f.state_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(f.old, 0, f.state_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(f.last, 0, f.state_bytes, 0x00020000);
+	for (uint32_t i = threadIdx.x; i < n_owned; i += BLOCK)
+	{
+		const uint32_t g = gid[i];
+		const float4 p = lpos[i];
+		float4 v = load_f4_sc1(rv, g);
+		const float4 o = load_f4_sc1(ro, g);
+		store_pos<true>(pos_out, g, p);
+		if (v.w == 0.0f) continue;
+		if (!f.second_order)
+		{
+			v.x = f.inv_h * (p.x - o.x); v.y = f.inv_h * (p.y - o.y); v.z = f.inv_h * (p.z - o.z);
+		}
+		else
+		{
+			const float4 l = load_f4_sc1(rl, g);
+			v.x = f.inv_h * (1.5f * p.x - 2.0f * o.x + 0.5f * l.x);
+			v.y = f.inv_h * (1.5f * p.y - 2.0f * o.y + 0.5f * l.y);
+			v.z = f.inv_h * (1.5f * p.z - 2.0f * o.z + 0.5f * l.z);
+		}
+		f.vel[g] = v;
+	}
+}
+
 // One tile of one segment: LDS fill, colour sweep, write-back of the owned particles.
 // `keep_owned`: the tile's owned particles are still in LDS from its previous pass (persistent schedule, same
 // workgroup, same owned set in every segment): only the halo is staged.  `wait`: see TileFill.
 template <uint32_t MASK, int BLOCK, bool PAIRS, bool COHERENT, class Wait>
 __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &ra, const float4 *pos_in, float4 *pos_out, uint32_t tile_index,
-	unsigned long long *trace, uint4 *lchunks, float4 *lpos, bool keep_owned, const Wait &wait)
+	unsigned long long *trace, uint4 *lchunks, float4 *lpos, bool keep_owned, const Wait &wait, const FoldArgs *fold = nullptr, uint32_t fold_phase = 0)
 {
+	// fold_phase (persistent schedule only): bit 0 = this pass integrates while it stages, bit 1 = it updates the velocities
 	const FusedTile t = sg.tiles[tile_index];
 	if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
 	const uint32_t *gid = sg.gid + t.gid_off;
@@ -364,7 +459,14 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	const FusedChunk *gchunks = sg.chunks + t.chunk_begin;
 	const TileFill<BLOCK, COHERENT> fill = { reinterpret_cast<const uint4 *>(gchunks), gid, pos_in, lchunks, lpos, num_chunks, t.n_local,
 		keep_owned ? (t.n_owned & ~63u) : 0u, trace };
-	fill(wait);
+	bool staged = false;
+	if constexpr (COHERENT)
+		if (fold_phase & 1u)
+		{
+			integrate_fill<BLOCK>(*fold, reinterpret_cast<const uint4 *>(gchunks), gid, pos_in, lchunks, lpos, num_chunks, t.n_local, t.n_owned, trace);
+			staged = true;
+		}
+	if (!staged) fill(wait);
 	// chunks are addressed relative to the tile from here on (they sit at lchunks[0 .. num_chunks))
 	uint32_t c = 0, step_counter = 0;
 	while (c < num_chunks)
@@ -380,7 +482,15 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 		default: c = num_chunks; break;
 		}
 	}
+	bool written = false;
+	if constexpr (COHERENT)
+		if (fold_phase & 2u)
+		{
+			velocity_write_back<BLOCK>(*fold, gid, pos_out, lpos, t.n_owned);
+			written = true;
+		}
 	// write-back of the owned particles, ids batched like the fill
+	if (!written)
 	{
 		constexpr uint32_t kWbBatch = 4;
 		const uint32_t last = t.n_owned - 1u;
@@ -439,6 +549,8 @@ struct PersistArgs
 	uint32_t *error;                              // page-locked host words: [0] a dependency wait timed out, [1] launch refused, [2] at which substep
 	uint32_t num_segs, passes, num_tiles;
 	uint32_t expect;                              // arrivals that mean "everybody is here" (gridDim.x; one more in the self-test)
+	int folded;                                   // pass 0 integrates, the last pass updates the velocities (FoldArgs)
+	FoldArgs fold;
 	int start;                                    // position buffer pass 0 reads
 	float dt;
 	TypeView views[PBDX_NUM_CONSTRAINT_TYPES];
@@ -516,7 +628,8 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 			};
 			unsigned long long *trace = (a.trace[sgi] && pass + a.num_segs >= a.passes) ? a.trace[sgi] + (size_t)tile * kTraceStride : nullptr;
 			// one tile per workgroup: its owned particles stay in LDS from pass to pass
-			process_tile<MASK, BLOCK, false, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && gridDim.x == a.num_tiles, wait);
+			const uint32_t fold_phase = a.folded ? ((pass == 0 ? 1u : 0u) | (pass + 1u == a.passes ? 2u : 0u)) : 0u;
+			process_tile<MASK, BLOCK, false, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && gridDim.x == a.num_tiles, wait, &a.fold, fold_phase);
 			if (s_failed)
 			{
 				// a neighbour never arrived: the result is garbage, say so and leave (uniform: one LDS word)
@@ -530,6 +643,8 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 		}
 		sgi = sgi + 1u == a.num_segs ? 0u : sgi + 1u;
 	}
+	// substeps completed in this call (velocity_kernel counts them when the launch is not folded)
+	if (a.folded && blockIdx.x == 0 && threadIdx.x == 0) a.ctl[kCtlSubstep] = a.ctl[kCtlSubstep] + 1u;
 }
 
 typedef void (*fused_fn)(FusedArgs);
@@ -783,6 +898,7 @@ struct pbdx_solver
 	int persistent = 1;                  // PBDX_OPT_PERSISTENT: the sweeps of a substep as one launch (A'): 0 never, 1 where measured faster, 2 always, 3 self-test
 	bool persist_ok = false;             // the plan is eligible (and no launch has been refused or has timed out)
 	uint32_t persist_refusals = 0;
+	bool last_folded = false;            // the substeps enqueued last ran integrate / velocity update inside the persistent launch
 	double persist_ms = 0.0;             // last profiled step: summed duration / number of persistent launches
 	uint64_t persist_launches = 0;
 	persist_fn persist_kernel = nullptr;
@@ -1191,8 +1307,8 @@ SegArgs seg_args(const DeviceSegment &d)
 	return g;
 }
 
-// (A') all `iterations` sweeps as one launch
-int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations)
+// (A') all `iterations` sweeps as one launch; with `fold` also the integration before and the velocity update after them
+int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations, const FoldArgs *fold = nullptr)
 {
 	PersistArgs a;
 	memset(&a, 0, sizeof(a));
@@ -1213,6 +1329,7 @@ int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations)
 	a.expect = s->persist_grid + (s->persistent == 3 ? 1u : 0u);     // 3 = self-test: the handshake cannot complete
 	a.start = src;
 	a.dt = dt;
+	if (fold) { a.folded = 1; a.fold = *fold; }
 	memcpy(a.views, s->plan.views, sizeof(a.views));
 	HIPCHECK(hipMemsetAsync(s->d_epoch, 0, ((size_t)s->plan.num_tiles + 2) * sizeof(uint32_t), s->stream));
 	hipLaunchKernelGGL(s->persist_kernel, dim3(s->persist_grid), dim3(s->persist_block), s->persist_lds, s->stream, a);
@@ -1421,6 +1538,22 @@ int enqueue_substep(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int v
 	// the state lives in buffer 0 between substeps; integrate writes the buffer from which an odd
 	// number of fused launches ends in buffer 0 again
 	const int start = (int)sweep_flips(s, iters);
+	s->last_folded = false;
+	if (s->persistent_active() && iters && s->n && start == 0)
+	{
+		// The whole substep as ONE launch: pass 0 integrates while it stages, the last pass updates the velocities.
+		// Only with an even number of passes: pass 0 then reads the state buffer (0) and writes the other one, so no
+		// tile can overwrite state a neighbour has not integrated yet, and the last pass ends in buffer 0.
+		FoldArgs f;
+		f.vel = s->d_vel; f.old = s->d_old; f.last = s->d_last;
+		f.state_bytes = s->n * 16u;
+		f.h = hs; f.gx = g[0]; f.gy = g[1]; f.gz = g[2]; f.inv_h = inv_h; f.second_order = vel != 0;
+		s->last_folded = true;
+		if (pc) { int r = prof_begin(pc, -1, 0); if (r) return r; }
+		int r = launch_persistent(s, 0, hs, iters, &f);
+		if (r) return r;
+		return pc ? prof_end(pc) : PBDX_OK;
+	}
 	if (s->n)
 	{
 		hipLaunchKernelGGL(integrate_kernel, dim3(nb), dim3(bs), 0, s->stream, s->d_pos[0], s->d_pos[start], s->d_vel, s->d_old, s->d_last, s->n, hs, g[0], g[1], g[2],
@@ -1766,7 +1899,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	const uint64_t launches_per_sweep = s->fused_active() ? s->dsegs.size() : s->order.size();
 	s->stats = pbdx_step_stats();
 	s->stats.projections = proj_per_sweep * max_iterations * substeps_total;
-	s->stats.kernel_launches = (s->persistent_active() ? 3 : launches_per_sweep * max_iterations + 2) * substeps_total;
+	s->stats.kernel_launches = (s->persistent_active() ? ((((uint64_t)max_iterations * s->dsegs.size()) & 1u) ? 3 : 1) : launches_per_sweep * max_iterations + 2) * substeps_total;
 	s->stats.algorithmic_bytes = (bytes_per_sweep * max_iterations + (uint64_t)s->n * 140) * substeps_total;
 	memset(s->type_ms, 0, sizeof(s->type_ms));
 	memset(s->type_launches, 0, sizeof(s->type_launches));
@@ -1833,12 +1966,13 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		// integrate of substep `k` ran, nothing after it did.  Complete that substep and the remaining ones with one
 		// launch per segment -- the result is the one an undisturbed run produces -- and stop using the schedule.
 		const uint64_t k = s->h_error[2];
+		const bool folded = s->last_folded;      // then not even the integration of substep k has happened
 		s->h_error[1] = s->h_error[2] = 0u;
 		s->persist_ok = false;
 		s->persist_refusals++;
 		s->drop_graph();
 		HIPCHECK(hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream));
-		int r = enqueue_substep_tail(s, hs, inv_h, max_iterations, vel, nullptr);
+		int r = folded ? enqueue_substep(s, hs, inv_h, max_iterations, vel, gravity, nullptr) : enqueue_substep_tail(s, hs, inv_h, max_iterations, vel, nullptr);
 		if (!r && (k + 1) % sub_steps == 0) r = enqueue_contacts(s);
 		for (uint64_t k2 = k + 1; !r && k2 < substeps_total; k2++)
 		{
