@@ -383,10 +383,15 @@ def main():
             # one launch per substep runs all `iters` sweeps: algorithmic bytes of a launch = iters x bytes of a sweep
             dur_s = 1e-3 * pinfo["profiled_ms"] / pinfo["profiled_launches"]
             bytes_per_launch = pinfo["algorithmic_bytes_per_sweep"] * args.iters
+            # with an even number of passes the launch also integrates and updates the velocities (140 B per particle)
+            folded = (args.iters * plan["num_segments"]) % 2 == 0
+            if folded:
+                bytes_per_launch += n_particles * 140
             segs = [sol.segment_info(i) for i in range(plan["num_segments"])]
             streamed = sum(si["stream_bytes"] for si in segs) * args.iters
             achieved = bytes_per_launch / dur_s / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "persistent_kernel (colour-fused LDS tiles, all %d sweeps x %d segments of a substep in one launch)" % (args.iters, plan["num_segments"]),
+            out["roofline"] = {"bound": "hbm", "kernel": "persistent_kernel (colour-fused LDS tiles, all %d sweeps x %d segments of a substep in one launch%s)" % (
+                                   args.iters, plan["num_segments"], ", integration and velocity update included" if folded else ""),
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                "algorithmic_bytes_per_launch": bytes_per_launch, "streamed_bytes_per_launch": streamed, "avg_launch_us": dur_s * 1e6,
                                "launches_measured": pinfo["profiled_launches"], "grid": pinfo["grid"], "block": pinfo["block"], "lds_bytes": pinfo["lds_bytes"],
