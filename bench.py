@@ -5,15 +5,28 @@ bending constraints; 27 colour groups), 10 solver iterations, 1 substep per step
 
 A "step" is one substep of the hot path (integrate -> 10 x colour-ordered projection sweeps ->
 velocity update) over the whole sheet, device-resident (inputs already in HBM when the timed
-region starts).  With --gpus N every rank owns one independent sheet (ensemble sharding, no
-data-path collective; RCCL only for the barrier and the max-over-ranks time): weak scaling,
-value = total projections of all ranks / max time.
+region starts).
 
-Prints ONE JSON line on rank 0.
+Multi-GPU: a single sheet does not shard; what shards is the ensemble of independent
+instances.  `--gpus N` = one process per GPU, no data-path collective; RCCL carries the barrier, the
+max-over-ranks time, the counts and per-rank checksums only.  Launched either by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment) or, when WORLD_SIZE is not set, by this script itself:
+`python bench.py --gpus N` spawns the N ranks and prints their one line.
+    --workload c2 (default)   every rank owns one 1000x1000 sheet                         (weak scaling)
+    --workload c4             BASELINE configs[3]: --instances 200x200 sheets per GPU     (weak scaling)
+    --workload c4 --scaling strong --total-instances 512
+                              the 512 instances sharded contiguously over the ranks       (strong scaling)
+value = projections of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.  The line carries `roofline` and `cpu_baseline` (N = 1 only), the
+parity of the timed engine against the reference on the headline scene (`config.parity_vs_reference`)
+and the other BASELINE workloads that fit one GPU as `extra_workloads`.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,120 +37,83 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
-
-
-def build_workload(args, ens):
-    """Returns (model, build seconds, workload description, check function).  Workloads:
-       c2  (default, the headline config) one size x size cloth per GPU
-       c4  BASELINE configs[3]: `--instances` independent size x size cloths (512 x 200x200 over 8 GPUs
-           = 64 per GPU); the global instance list is sharded contiguously over the ranks
-       c3  BASELINE configs[2]: 101x21x11 FEM-tet bar (100 000 tets), one per GPU -- latency-bound by
-           construction (40 colours x 10 iterations over 23 331 particles), reported, not the headline"""
-    from tests import util
-    t0 = time.perf_counter()
-    if args.workload == "c3":
-        k = args.instances if args.bars else 1
-        spec = util.bar_spec(101, 21, 11, args.solid_method, instances=k)
-        desc = "configs[2]: %s101x21x11 regular tet bar (100000 tets), solid method %d, %d iterations, 1 substep, h=0.005" % (
-            ("%d independent bars, each a " % k) if k > 1 else "", args.solid_method, args.iters)
-        pins = [0]
-    elif args.workload == "c4":
-        begin, end = ens.shard(args.instances * ens.world)     # weak scaling: `instances` per GPU
-        k = end - begin
-        spec = util.cloth_spec(args.size, args.size, 4, 3, instances=k, instance_offset=(0.0, 0.0, 12.0))
-        desc = "configs[3]: %d independent %dx%d cloth instances per GPU (XPBD distance + XPBD isometric bending), %d iterations, 1 substep, h=0.005" % (
-            k, args.size, args.size, args.iters)
-        pins = [0, args.size - 1]
-    else:
-        spec = util.cloth_spec(args.size, args.size, 4, 3)
-        desc = "configs[1]: single %dx%d cloth sheet per GPU (XPBD distance k=1e5 + XPBD isometric bending k=100), %d iterations, 1 substep, h=0.005" % (
-            args.size, args.size, args.iters)
-        pins = [0, args.size - 1]
-    model = util.build_mine(spec)
-    model.initConstraintGroups()
-    return model, time.perf_counter() - t0, desc, pins
-
-
-def cpu_baseline(n, iters, budget_s=30.0):
-    """The reference's own TimeStepController::step (oracle/_ref, release-like build) timed on the
-    host cores of this box on a BOUNDED sample of the same workload: a 400x400 sheet of the same
-    cloth (XPBD distance + XPBD isometric bending, same iteration count; projections/s on the CPU
-    is size-insensitive), at 1 OpenMP thread and at a few multi-thread
-    settings -- the reference forks/joins one parallel region per colour group, which makes large
-    thread counts SLOWER, so the best setting is reported as `value`."""
-    try:
-        from oracle import refdrv
-        from tests import util
-    except Exception as e:  # pragma: no cover
-        return {"value": None, "unit": "projections/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
-    variant = "fast" if refdrv.available("fast") else ("f32" if refdrv.available("f32") else None)
-    if variant is None:
-        from oracle import port
-        o = port.Port("f32")
-        kind = "port"
-        thread_settings = [1]
-    else:
-        o = refdrv.Ref(variant)
-        kind = "reference"
-        ncpu = os.cpu_count() or 1
-        thread_settings = sorted(set([1, min(8, ncpu), min(32, ncpu)]))
-    size = min(n, 400)
-    t_setup = time.perf_counter()
-    util.apply_ref(o, util.cloth_spec(size, size, 4, 3))
-    o.set_time_step_size(0.005)
-    o.set_params(1, iters, 0)
-    nc = o.num_constraints()
-    o.set_num_threads(1)
-    o.step(1)   # warm-up: includes the one-off colouring
-    t_setup = time.perf_counter() - t_setup
-    results = {}
-    t_used = 0.0
-    for th in thread_settings:
-        if t_used > budget_s:
-            break
-        o.set_num_threads(th)
-        o.step(1)
-        steps, t = 0, 0.0
-        while steps < 2 or (t < 3.0 and steps < 10):
-            t += o.time_steps(1)
-            steps += 1
-            if t > budget_s / len(thread_settings):
-                break
-        t_used += t
-        results[th] = (nc * iters * steps / t, 1e3 * t / steps, steps)
-    best = max(results, key=lambda k: results[k][0])
-    return {"value": results[best][0], "unit": "projections/s", "cores": best, "kind": kind,
-            "ms_per_substep": results[best][1],
-            "by_threads": {str(k): {"projections_per_s": v[0], "ms_per_substep": v[1], "timed_steps": v[2]} for k, v in results.items()},
-            "sample": "%dx%d cloth (same constraints as the GPU workload, %d constraints), %d iterations x 1 substep, >=2 timed steps per thread setting after warm-up; %s%s; best of OMP threads %s (host reports %d logical CPUs); setup %.1fs" % (
-                size, size, nc, iters, "reference build '%s'" % variant if variant else "plain-C port",
-                " (-O3 -march=x86-64-v3 -fopenmp, float)" if variant == "fast" else "", sorted(results), os.cpu_count() or 1, t_setup)}
-
-
+HBM_COPY_GBS = 6290.0   # the same guide: float4 copy ceiling
 CALIB_BYTES = 1 << 28
 
 
-def _pmc_pass(counter, child_args, timeout_s=240):
-    """One `rocprofv3 --pmc <counter>` pass over a short child run of this script (its own process:
-    counters and traces are never combined, and the profiled run is never the timed one).
-    Returns {kernel_name: [counter values per dispatch]} or None."""
-    import csv
-    import glob
+# ---------------------------------------------------------------------------------------------------
+# workloads (scene specifications: positionbaseddynamics_amd/scenes.py)
+# ---------------------------------------------------------------------------------------------------
+def workload_spec(w, ens):
+    """w: dict(workload, size, instances, bars, solid_method, iters, scaling, total_instances).
+    Returns (ops, description, pinned particle ids of instance 0)."""
+    from positionbaseddynamics_amd import scenes
+    if w["workload"] == "c3":
+        k = w["instances"] if w["bars"] else 1
+        ops = scenes.bar_spec(101, 21, 11, w["solid_method"], instances=k)
+        desc = "configs[2]: %s101x21x11 regular tet bar (100000 tets), solid method %d (%s), %d iterations, 1 substep, h=0.005" % (
+            ("%d independent bars, each a " % k) if k > 1 else "", w["solid_method"],
+            {2: "FEM tets", 3: "XPBD FEM tets", 4: "strain tets", 6: "XPBD distance + volume"}.get(w["solid_method"], "?"), w["iters"])
+        return ops, desc, [0]
+    if w["workload"] == "c4":
+        if w["scaling"] == "strong":
+            begin, end = ens.shard(w["total_instances"])
+        else:
+            begin, end = ens.shard(w["instances"] * ens.world)     # weak scaling: `instances` per GPU
+        k = end - begin
+        ops = scenes.cloth_spec(w["size"], w["size"], 4, 3, instances=k, instance_offset=(0.0, 0.0, 12.0))
+        desc = "configs[3]: %d independent %dx%d cloth instances on this GPU (%s; XPBD distance + XPBD isometric bending), %d iterations, 1 substep, h=0.005" % (
+            k, w["size"], w["size"], ("strong scaling: %d instances over %d GPUs" % (w["total_instances"], ens.world)) if w["scaling"] == "strong" else "weak scaling", w["iters"])
+        return ops, desc, [0, w["size"] - 1]
+    ops = scenes.cloth_spec(w["size"], w["size"], 4, 3)
+    desc = "configs[1]: single %dx%d cloth sheet per GPU (XPBD distance k=1e5 + XPBD isometric bending k=100), %d iterations, 1 substep, h=0.005" % (
+        w["size"], w["size"], w["iters"])
+    return ops, desc, [0, w["size"] - 1]
+
+
+def child_flags(w, fused_active, persist_active, opts):
+    """Command line that reproduces workload `w` with the same schedule in a profiled child run of this script; the
+    schedule the parent measured its way to is FORCED in the child, so that no autotune launch shows up in its trace."""
+    child = ["--workload", w["workload"], "--size", str(w["size"]), "--iters", str(w["iters"]), "--instances", str(w["instances"]),
+             "--solid-method", str(w["solid_method"])] + (["--bars"] if w["bars"] else [])
+    for flag, val in (("--fuse", 1 if fused_active else 0), ("--tile", opts.get("tile")), ("--fuse-block", opts.get("fuse_block")), ("--max-seg", opts.get("max_seg")),
+                      ("--lds-particles", opts.get("lds_particles")), ("--xcd-remap", opts.get("xcd_remap")), ("--block", opts.get("block")),
+                      ("--persistent", 2 if persist_active else 0)):
+        if val is not None:
+            child += [flag, str(val)]
+    return child
+
+
+# ---------------------------------------------------------------------------------------------------
+# rocprofv3 child passes (counters and traces are never combined; the profiled run is never the timed one)
+# ---------------------------------------------------------------------------------------------------
+def _rocprof_child(extra_args, child_args, prefix, timeout_s=300):
     import shutil
-    import subprocess
     import tempfile
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None
-    outdir = tempfile.mkdtemp(prefix="pbdx_pmc_", dir="/tmp")
-    cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "-o", "pmc", "--",
-           sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args
+    outdir = tempfile.mkdtemp(prefix=prefix, dir="/tmp")
+    cmd = [exe] + extra_args + ["--output-format", "csv", "-d", outdir, "-o", "out", "--",
+                                sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     try:
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
     except Exception:
+        shutil.rmtree(outdir, ignore_errors=True)
+        return None
+    return outdir
+
+
+def _pmc_pass(counter, child_args):
+    """One `rocprofv3 --pmc <counter>` pass over a short child run.  Returns {kernel_name: [values per dispatch]} or None."""
+    import csv
+    import glob
+    import shutil
+    outdir = _rocprof_child(["--pmc", counter, "--kernel-trace"], child_args, "pbdx_pmc_")
+    if outdir is None:
         return None
     vals = {}
     for f in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
@@ -149,26 +125,15 @@ def _pmc_pass(counter, child_args, timeout_s=240):
     return vals or None
 
 
-def rocprof_kernel_durations(child_args, kernel_substring, timeout_s=240):
-    """Cross-check of the event-measured launch durations: a `rocprofv3 --kernel-trace` child pass (no
-    counters) of a short run of the same configuration; returns (mean ns, dispatches) of the dominant kernel."""
+def rocprof_kernel_durations(child_args, kernel_substring):
+    """Cross-check of the event-measured launch durations: a `rocprofv3 --kernel-trace` child pass (no counters) of a
+    short run of the same configuration with the schedule FORCED (no autotune launches in the trace): every dispatch
+    of the dominant kernel in it is one of the timed kind.  Returns dict(mean_us, min_us, max_us, dispatches)."""
     import csv
     import glob
     import shutil
-    import subprocess
-    import tempfile
-    exe = shutil.which("rocprofv3")
-    if exe is None:
-        return None
-    outdir = tempfile.mkdtemp(prefix="pbdx_trace_", dir="/tmp")
-    cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", outdir, "-o", "trace", "--",
-           sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args
-    env = dict(os.environ, TMPDIR="/tmp")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
-        env.pop(k, None)
-    try:
-        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
-    except Exception:
+    outdir = _rocprof_child(["--kernel-trace"], child_args, "pbdx_trace_")
+    if outdir is None:
         return None
     durs = []
     for f in glob.glob(os.path.join(outdir, "**", "*kernel_trace.csv"), recursive=True):
@@ -179,15 +144,16 @@ def rocprof_kernel_durations(child_args, kernel_substring, timeout_s=240):
     shutil.rmtree(outdir, ignore_errors=True)
     if not durs:
         return None
-    return sum(durs) / len(durs), len(durs)
+    return {"mean_us": sum(durs) / len(durs) / 1e3, "min_us": min(durs) / 1e3, "max_us": max(durs) / 1e3, "dispatches": len(durs)}
 
 
 def collect_traffic(child_args, kernel_substring):
-    """HBM bytes per launch of the dominant kernel from the PMC counters, as MI355X_MICROARCH.md (HBM)
+    """HBM-side bytes per launch of the dominant kernel from the PMC counters, as MI355X_MICROARCH.md (HBM)
     prescribes: FETCH_SIZE and WRITE_SIZE in separate passes; the counters are turned into bytes with
     factors calibrated IN THE SAME PASS on streaming kernels of known size in this engine's own access
     widths (the guide: gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read; other widths
-    and WRITE_SIZE must be calibrated).  Infinity-Cache hits are counted as traffic."""
+    and WRITE_SIZE must be calibrated).  Infinity-Cache hits are counted as traffic (the guide: these are
+    the L2's fabric-side request counters), so this is an UPPER bound of the HBM bytes."""
     res = {}
     for counter, calib in (("FETCH_SIZE", ("calib_read_b32", "calib_read_b128")), ("WRITE_SIZE", ("calib_write_b32", "calib_write_b128"))):
         vals = _pmc_pass(counter, child_args)
@@ -212,8 +178,344 @@ def collect_traffic(child_args, kernel_substring):
     fb = out["fetch_bytes"].get("calib_read_b32", next(iter(out["fetch_bytes"].values())))
     wb = out["write_bytes"].get("calib_write_b32", next(iter(out["write_bytes"].values())))
     out["bytes_per_launch"] = fb + wb
+    out["launches"] = res["FETCH_SIZE"]["launches"]
     out["raw"] = res
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# one workload on this rank's GPU
+# ---------------------------------------------------------------------------------------------------
+def run_workload(w, opts, ens, steps, warmup, with_roofline, with_traffic, with_pcie=False, with_contacts=False):
+    """Builds the scene, steps it device-resident (untimed warm-up, then EXACTLY `steps` steps bracketed by a barrier +
+    device synchronisation on both sides), returns the measurements of this rank plus -- rank 0 -- the roofline record."""
+    import torch
+    import positionbaseddynamics_amd as pbd
+    from positionbaseddynamics_amd import scenes
+    from positionbaseddynamics_amd.ensemble import checksum
+    S = pbd.Solver
+    ops, desc, pins = workload_spec(w, ens)
+    t0 = time.perf_counter()
+    model = scenes.build_model(ops)
+    model.initConstraintGroups()
+    t_build = time.perf_counter() - t0
+    n_particles = model.getParticles().size()
+    n_constraints = model.numConstraints()
+    n_groups = len(model.getConstraintGroups())
+    iters = w["iters"]
+
+    pbd.TimeManager.getCurrent().setTimeStepSize(0.005)
+    ts = pbd.TimeStepController(device=ens.hip_device)
+    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, iters)
+    sol = ts.solver()
+    for key, opt in (("xcd_remap", S.OPT_XCD_REMAP), ("block", S.OPT_BLOCK_SIZE), ("fuse", S.OPT_FUSE), ("tile", S.OPT_TILE_PARTICLES),
+                     ("fuse_block", S.OPT_FUSE_BLOCK), ("max_seg", S.OPT_MAX_SEGMENT_COLOURS), ("lds_particles", S.OPT_LDS_PARTICLES),
+                     ("persistent", S.OPT_PERSISTENT)):
+        if opts.get(key) is not None:
+            sol.set_option(opt, opts[key])
+    if opts.get("no_graph"):
+        sol.set_option(S.OPT_USE_GRAPH, 0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        ens.barrier()
+
+    # warm-up (untimed): uploads the device image, plans, measures the schedule candidates, instantiates the hipGraph
+    ts.stepResident(model, max(warmup, 1))
+    barrier()
+    t0 = time.perf_counter()
+    ts.stepResident(model, steps)          # synchronises its own stream before returning
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    stats = sol.stats()
+    plan = sol.plan_info()
+    persist = sol.persistent_info()
+    barrier()
+
+    # sanity of the timed state: finite, pinned corners unmoved; checksum for the cross-rank comparison
+    ts.syncToHost(model)
+    x = model.getParticles().positions()
+    x0 = model.getParticles().array(1)
+    ok = bool(np.all(np.isfinite(x)) and all(np.array_equal(x[p], x0[p]) for p in pins))
+    res = {"desc": desc, "t_local": t_local, "n_particles": n_particles, "n_constraints": n_constraints, "n_groups": n_groups,
+           "t_build": t_build, "stats": stats, "plan": plan, "persistent": persist, "state_ok": ok, "checksum": checksum(x),
+           "engine": sol.describe(), "steps_done": max(warmup, 1) + steps}
+
+    if with_pcie and ens.rank == 0:
+        # PCIe-inclusive rate of the TimeStep::step contract (host ParticleData in -> step -> host ParticleData out every
+        # step); reported for information only, never `value`
+        ts.step(model)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ts.step(model)
+        res["pcie_ms"] = 1e3 * (time.perf_counter() - t1) / 3
+        sol.set_option(S.OPT_PIN_HOST, 1)      # page-locked host mirror: transfers at full PCIe rate
+        ts.step(model)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ts.step(model)
+        res["pcie_pinned_ms"] = 1e3 * (time.perf_counter() - t1) / 3
+        sol.set_option(S.OPT_PIN_HOST, 0)
+
+    if with_contacts and ens.rank == 0:
+        # SURVEY 8f rank 2: a floor box under the sheet and a sphere it falls onto; identity collider frames
+        eye = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+        sol.set_colliders([dict(shape="box", params=[50.0, 0.5, 50.0], com=[0, -6.0, 0], R=eye, v1=[0, 0, 0], v2=[0, -6.0, 0], restitution=0.6, friction=0.2),
+                           dict(shape="sphere", params=[2.0], com=[5.0, -2.0, 0.0], R=eye, v1=[0, 0, 0], v2=[5.0, -2.0, 0.0], restitution=0.6, friction=0.1)])
+        sol.set_collision_ranges([(0, n_particles, 0.6, 0.1)])
+        sol.set_contact_params(0.05, 100.0, 5)
+        ts.stepResident(model, 3)
+        t1 = time.perf_counter()
+        ts.stepResident(model, steps)
+        torch.cuda.synchronize()
+        t_c = (time.perf_counter() - t1) / steps
+        res["contacts"] = {"ms_per_step_with_contact_pass": 1e3 * t_c, "contacts_last_step": sol.num_contacts(),
+                           "colliders": 2, "note": "detection + 5 velocity sweeps for every particle against 2 static colliders, once per step"}
+        sol.set_colliders([])
+        sol.set_collision_ranges([])
+
+    if with_roofline and ens.rank == 0:
+        res["roofline"] = roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles)
+        if with_traffic and res["roofline"] is not None and ens.world == 1:
+            add_profiled_passes(res["roofline"], w, opts, plan, persist)
+    return res
+
+
+def roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles):
+    """Dominant kernel of the workload: duration measured live with HIP events on the engine's own stream (eager
+    launches, one event pair around every projection launch), bytes as SURVEY 8d defines them."""
+    iters = w["iters"]
+    sol.set_profiling(True)
+    psteps = max(2, min(5, steps))
+    ts.stepResident(model, psteps)
+    sol.set_profiling(False)
+    T = pbd.ConstraintType
+    pinfo = sol.persistent_info()
+    if plan["active"] and pinfo["active"] and pinfo["profiled_launches"]:
+        # one launch per substep runs all `iters` sweeps: algorithmic bytes of a launch = iters x bytes of a sweep
+        dur_s = 1e-3 * pinfo["profiled_ms"] / pinfo["profiled_launches"]
+        bytes_per_launch = pinfo["algorithmic_bytes_per_sweep"] * iters
+        folded = bool(pinfo["last_folded"])
+        if folded:      # the launch also integrates and updates the velocities (SURVEY 8d: 140 B per particle)
+            bytes_per_launch += n_particles * 140
+        segs = [sol.segment_info(i) for i in range(plan["num_segments"])]
+        streamed = sum(si["stream_bytes"] for si in segs) * iters
+        compulsory = plan["compulsory_stream_bytes_per_sweep"] * iters + n_particles * 140
+        achieved = bytes_per_launch / dur_s / 1e9
+        return {"bound": "hbm", "kernel": "persistent_kernel (colour-fused LDS tiles, all %d sweeps x %d segments of a substep in one launch%s)" % (
+                    iters, plan["num_segments"], ", integration and velocity update included" if folded else ""),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "streamed_bytes_per_launch": streamed,
+                "compulsory_bytes_per_launch": compulsory, "avg_launch_us": dur_s * 1e6,
+                "launches_measured": pinfo["profiled_launches"], "grid": pinfo["grid"], "block": pinfo["block"], "lds_bytes": pinfo["lds_bytes"], "folded": folded,
+                "segments": [{"segment": i, "colours": [si["colour_begin"], si["colour_end"]], "tiles": si["num_tiles"], "constraints": si["constraints"], "slots": si["slots"],
+                              "algorithmic_bytes_per_pass": si["algorithmic_bytes"], "streamed_bytes_per_pass": si["stream_bytes"]} for i, si in enumerate(segs)],
+                "note": "frac = SURVEY 8d ALGORITHMIC bytes (every endpoint position read and written once per projection, 32-bit indices, no cache credit) / "
+                        "event-measured launch time / 8 TB/s: it can exceed 1 because the kernel keeps positions in LDS and streams 16-bit indices. "
+                        "frac_traffic = counter-measured fabric bytes (upper bound of HBM bytes: Infinity-Cache hits are counted) / the same time / 8 TB/s is the "
+                        "physically bounded figure; compulsory_bytes = every distinct constraint record once per sweep + one particle-state pass; "
+                        "traffic_over_compulsory is the redundancy left to remove"}
+    if plan["active"]:
+        segs = [sol.segment_info(i) for i in range(plan["num_segments"])]
+        rows = []
+        for i, si in enumerate(segs):
+            if not si["profiled_launches"]:
+                continue
+            dur_s = 1e-3 * si["profiled_ms"] / si["profiled_launches"]
+            rows.append({"segment": i, "colours": [si["colour_begin"], si["colour_end"]], "tiles": si["num_tiles"], "block": si["block"],
+                         "lds_bytes": si["lds_bytes"], "constraints": si["constraints"], "slots": si["slots"],
+                         "launches": si["profiled_launches"], "avg_us": dur_s * 1e6,
+                         "algorithmic_bytes_per_launch": si["algorithmic_bytes"], "streamed_bytes_per_launch": si["stream_bytes"],
+                         "algorithmic_GBs": si["algorithmic_bytes"] / dur_s / 1e9, "streamed_GBs": si["stream_bytes"] / dur_s / 1e9})
+        if not rows:
+            return None
+        dom = max(rows, key=lambda r: r["avg_us"] * r["launches"])
+        return {"bound": "hbm", "kernel": "fused_kernel (colour-fused LDS tiles), segment %d = colours [%d,%d)" % (dom["segment"], dom["colours"][0], dom["colours"][1]),
+                "achieved": dom["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["algorithmic_GBs"] / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                "streamed_bytes_per_launch": dom["streamed_bytes_per_launch"], "avg_launch_us": dom["avg_us"],
+                "launches_measured": dom["launches"], "segments": rows,
+                "note": "achieved = SURVEY 8d algorithmic bytes of the segment's distinct constraints / event-measured launch time; "
+                        "positions stay in LDS for the whole segment, so the bytes actually streamed from HBM (streamed_*) are lower"}
+    per_type = {}
+    dom_t, dom_ms = None, 0.0
+    for t in range(T.COUNT):
+        ms, launches, proj = sol.type_stats(t)
+        if launches:
+            per_type[T.name(t)] = {"launches": launches, "avg_us": 1e3 * ms / launches, "projections": proj,
+                                   "algorithmic_GBs": proj * T.algorithmic_bytes(t) / ms / 1e6}
+            if ms > dom_ms:
+                dom_t, dom_ms = t, ms
+    if dom_t is None:
+        return None
+    ms, launches, proj = sol.type_stats(dom_t)
+    bytes_per_launch = proj * T.algorithmic_bytes(dom_t) / launches
+    dur_s = 1e-3 * ms / launches
+    achieved = bytes_per_launch / dur_s / 1e9
+    return {"bound": "hbm", "kernel": "project_kernel<%s>" % T.name(dom_t), "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": dur_s * 1e6,
+            "launches_measured": launches, "per_type": per_type}
+
+
+def add_profiled_passes(r, w, opts, plan, persist):
+    """roofline.traffic (PMC child passes) and the rocprofv3 kernel-trace cross-check of the event-measured duration."""
+    child = child_flags(w, plan["active"], persist["active"], opts)
+    kname = "persistent_kernel" if persist["active"] else "fused_kernel" if plan["active"] else "project_kernel"
+    tr = collect_traffic(child, kname)
+    if tr is not None:
+        if plan["active"] and not persist["active"]:
+            # the PMC mean runs over the launches of ALL segments: compare with the mean over segments
+            rows = r["segments"]
+            nl = sum(x["launches"] for x in rows)
+            r["traffic_scope"] = "mean over the launches of all %d segments of a sweep" % len(rows)
+            r["algorithmic_bytes_per_launch_mean"] = sum(x["algorithmic_bytes_per_launch"] * x["launches"] for x in rows) / nl
+            r["streamed_bytes_per_launch_mean"] = sum(x["streamed_bytes_per_launch"] * x["launches"] for x in rows) / nl
+        r["traffic"] = tr["bytes_per_launch"]
+        r["traffic_detail"] = {k: tr[k] for k in ("fetch_bytes", "write_bytes", "launches", "raw")}
+    kd = rocprof_kernel_durations(child, kname)
+    if kd is not None:
+        r["rocprofv3_mean_kernel_us"] = kd["mean_us"]
+        r["rocprofv3_min_kernel_us"] = kd["min_us"]
+        r["rocprofv3_max_kernel_us"] = kd["max_us"]
+        r["rocprofv3_dispatches"] = kd["dispatches"]
+        if plan["active"] and not persist["active"]:
+            rows = r["segments"]
+            nl = sum(x["launches"] for x in rows)
+            r["event_mean_launch_us_all_segments"] = sum(x["avg_us"] * x["launches"] for x in rows) / nl
+    dur_us = r["avg_launch_us"] if persist["active"] else r.get("event_mean_launch_us_all_segments") if plan["active"] else None
+    if r.get("traffic") and dur_us:
+        dur_s = dur_us * 1e-6
+        r["traffic_GBs"] = r["traffic"] / dur_s / 1e9
+        r["frac_traffic"] = r["traffic_GBs"] / HBM_PEAK_GBS
+        r["frac_traffic_of_copy_ceiling"] = r["traffic_GBs"] / HBM_COPY_GBS
+        r["traffic_over_algorithmic"] = r["traffic"] / r.get("algorithmic_bytes_per_launch_mean", r["algorithmic_bytes_per_launch"])
+        if r.get("compulsory_bytes_per_launch"):
+            r["traffic_over_compulsory"] = r["traffic"] / r["compulsory_bytes_per_launch"]
+            r["frac_compulsory"] = r["compulsory_bytes_per_launch"] / dur_s / 1e9 / HBM_PEAK_GBS
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU side: the reference itself on this box's host cores (timing) and as the checker of the timed engine (parity)
+# ---------------------------------------------------------------------------------------------------
+def cpu_baseline(size, iters, opts, hip_device, parity_steps=3, timed_steps=3):
+    """(1) TIMING.  The reference's own TimeStepController::step (oracle/_ref, release-like build: -O3 -fopenmp and the
+    widest -march level this host executes, oracle/refdrv.py:best_timing_variant) on the SAME scene as the GPU workload
+    (size x size cloth, XPBD distance + XPBD isometric bending, same iteration count): `timed_steps` steps at 1 OpenMP
+    thread and at a few multi-thread settings after a warm-up step (which includes the one-off colouring).  The reference
+    forks/joins one parallel region per colour group, so large thread counts can be SLOWER; the best setting is `value`.
+    (2) PARITY.  The contraction-free float build of the reference (oracle/_ref f32: the build the engine is bit-identical
+    to; the release-like build contracts a*b+c into fused multiply-adds) steps the same scene `parity_steps` steps on the host;
+    the GPU engine, with the options of the timed run, steps a fresh copy of the scene the same number of steps; all
+    positions and velocities are compared bit for bit.  Returns (cpu_baseline record, parity record)."""
+    try:
+        from oracle import refdrv
+        from oracle.scene_ref import apply_ref
+        from positionbaseddynamics_amd import scenes
+    except Exception as e:  # pragma: no cover
+        return {"value": None, "unit": "projections/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}, None
+    ncpu = os.cpu_count() or 1
+    ops = scenes.cloth_spec(size, size, 4, 3)
+    variant = refdrv.best_timing_variant()
+    if variant is None:
+        from oracle import port
+        o = port.Port("f32")
+        kind, thread_settings, flags = "port", [1], "plain-C port, gcc -O2"
+    else:
+        o = refdrv.Ref(variant)
+        kind = "reference"
+        thread_settings = sorted(set([1, min(16, ncpu), min(32, ncpu), min(64, ncpu)]))
+        flags = {"v4": "-O3 -march=x86-64-v4 -fopenmp, float", "fast": "-O3 -march=x86-64-v3 -fopenmp, float"}[variant]
+    t_setup = time.perf_counter()
+    apply_ref(o, ops)
+    o.set_time_step_size(0.005)
+    o.set_params(1, iters, 0)
+    nc = o.num_constraints()
+    o.set_num_threads(max(thread_settings))
+    o.step(1)   # warm-up: includes the one-off colouring
+    t_setup = time.perf_counter() - t_setup
+    results = {}
+    for th in reversed(thread_settings):      # multi-thread settings first: the 1-thread leg is the long one
+        o.set_num_threads(th)
+        t = 0.0
+        n = timed_steps
+        for _ in range(n):
+            t += o.time_steps(1)
+        results[th] = (nc * iters * n / t, 1e3 * t / n, n)
+    best = max(results, key=lambda k: results[k][0])
+    rec = {"value": results[best][0], "unit": "projections/s", "cores": best, "kind": kind,
+           "ms_per_substep": results[best][1], "variant": variant, "host_logical_cpus": ncpu,
+           "single_thread": {"projections_per_s": results[1][0], "ms_per_substep": results[1][1]} if 1 in results else None,
+           "by_threads": {str(k): {"projections_per_s": v[0], "ms_per_substep": v[1], "timed_steps": v[2]} for k, v in sorted(results.items())},
+           "sample": "the GPU workload itself: %dx%d cloth (%d constraints), %d iterations x 1 substep; %d timed steps per thread setting after one warm-up step; "
+                     "reference build '%s' (%s); OMP threads tried %s, best = %d (host reports %d logical CPUs); scene build + colouring + warm-up %.1fs" % (
+                         size, size, nc, iters, timed_steps, variant, flags, sorted(results), best, ncpu, t_setup)}
+    o.reset_all()
+
+    parity = None
+    if refdrv.available("f32") and parity_steps > 0:
+        import positionbaseddynamics_amd as pbd
+        S = pbd.Solver
+        ref = refdrv.Ref("f32")
+        apply_ref(ref, ops)
+        ref.set_time_step_size(0.005)
+        ref.set_gravity(scenes.GRAVITY)
+        ref.set_params(1, iters, 0)
+        ref.set_num_threads(min(32, ncpu))
+        t0 = time.perf_counter()
+        ref.step(parity_steps)
+        t_ref = time.perf_counter() - t0
+        xr, vr = ref.positions().astype(np.float32), ref.get_array(2).astype(np.float32)
+        ref.reset_all()
+        model = scenes.build_model(ops)
+        pbd.TimeManager.getCurrent().setTimeStepSize(0.005)
+        ts = pbd.TimeStepController(device=hip_device)
+        ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+        ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, iters)
+        sol = ts.solver()
+        for key, opt in (("xcd_remap", S.OPT_XCD_REMAP), ("fuse", S.OPT_FUSE), ("tile", S.OPT_TILE_PARTICLES), ("fuse_block", S.OPT_FUSE_BLOCK),
+                         ("max_seg", S.OPT_MAX_SEGMENT_COLOURS), ("lds_particles", S.OPT_LDS_PARTICLES), ("persistent", S.OPT_PERSISTENT)):
+            if opts.get(key) is not None:
+                sol.set_option(opt, opts[key])
+        ts.stepResident(model, parity_steps)
+        ts.syncToHost(model)
+        xg, vg = model.getParticles().positions(), model.getParticles().array(2)
+        pi = sol.persistent_info()
+        same = bool(np.array_equal(xg.view(np.uint32), xr.view(np.uint32)) and np.array_equal(vg.view(np.uint32), vr.view(np.uint32)))
+        parity = {"scene": "%dx%d cloth, %d iterations x 1 substep (the timed workload)" % (size, size, iters), "steps": parity_steps,
+                  "reference": "oracle/_ref f32 (unmodified reference sources, -O2 -ffp-contract=off), %d OpenMP threads, %.1f s" % (min(32, ncpu), t_ref),
+                  "bit_identical": same, "max_abs": float(np.max(np.abs(xg.astype(np.float64) - xr.astype(np.float64)))),
+                  "max_abs_velocity": float(np.max(np.abs(vg.astype(np.float64) - vr.astype(np.float64)))),
+                  "compared_values": int(xg.size + vg.size),
+                  "engine_schedule": {"fused": sol.plan_info()["active"], "persistent": pi["active"], "folded": pi["last_folded"], "refusals": pi["refusals"], "timeouts": pi["timeouts"]}}
+    return rec, parity
+
+
+# ---------------------------------------------------------------------------------------------------
+# N ranks from one command
+# ---------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, exactly what torch.distributed.run provides), pass
+    rank 0's JSON line through, fail if any rank fails."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PBDX_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    for line in out0.splitlines():      # the ONE JSON line goes to stdout; library chatter of the rank (gloo / RCCL banners) to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %r" % (rcs,))
 
 
 def main():
@@ -223,12 +525,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2")
     ap.add_argument("--size", type=int, default=None, help="cloth is size x size particles (default 1000; 200 for c4)")
-    ap.add_argument("--instances", type=int, default=64, help="c4: cloth instances per GPU")
+    ap.add_argument("--instances", type=int, default=64, help="c4 (weak scaling): cloth instances per GPU; c3 --bars: bars per GPU")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="c4: fixed instances per GPU (weak) or --total-instances sharded over the GPUs (strong)")
+    ap.add_argument("--total-instances", type=int, default=512, help="c4 --scaling strong: instances of the whole job (BASELINE configs[3]: 512)")
     ap.add_argument("--bars", action="store_true", help="c3: batch --instances independent bars per GPU (the single bar is latency-bound by construction)")
     ap.add_argument("--solid-method", type=int, default=2, help="c3: addSolidConstraints method (2 FEM tet, 4 strain tet, 6 XPBD distance+volume)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra_workloads (configs[2] variants, configs[3] block)")
     ap.add_argument("--xcd-remap", type=int, default=None)
     ap.add_argument("--block", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph")
@@ -240,242 +545,116 @@ def main():
     ap.add_argument("--persistent", type=int, default=None, help="PBDX_OPT_PERSISTENT: 1 = one launch per substep where measured faster (default), 0 = one launch per segment, 2 = always")
     ap.add_argument("--contacts", action="store_true", help="also time the step with two static colliders (contact detection + velocity solve per step)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
+    ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than GPUs (ranks share devices; smoke test of the N>1 path, not a measurement)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rank-selftest", action="store_true", help="launcher self-test: the ranks rendezvous, exchange their rank numbers and exit (no GPU work, no metric)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        return spawn_ranks(args.gpus, sys.argv[1:])
+
+    if args.rank_selftest:
+        from positionbaseddynamics_amd.ensemble import Ensemble
+        ens = Ensemble(backend=os.environ.get("PBDX_DIST_BACKEND") or "gloo")
+        ranks = ens.gather_floats(ens.rank)
+        t = ens.max_time(0.5 + ens.rank)
+        ens.barrier()
+        if ens.rank == 0:
+            print(json.dumps({"selftest": "ranks", "n_gpus": None, "rccl_ranks": ens.world, "ranks": ranks, "max_time": t, "spawned_by_bench": os.environ.get("PBDX_SPAWNED") == "1"}), flush=True)
+        ens.close()
+        return
 
     if args.size is None:
         args.size = 200 if args.workload == "c4" else 1000
     import torch
+    import positionbaseddynamics_amd as pbd
     from positionbaseddynamics_amd.ensemble import Ensemble
-    ens = Ensemble()
-    rank, local_rank, world, dist = ens.rank, ens.local_rank, ens.world, ens.dist
+    ndev = pbd.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env > ndev and not args.oversubscribe:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible; one process per GPU (use --oversubscribe only to smoke-test the N>1 path)" % (world_env, ndev))
+    ens = Ensemble(oversubscribe=args.oversubscribe, num_devices=ndev)
+    rank, world = ens.rank, ens.world
     if world == 1:
         torch.cuda.set_device(0)
-        local_rank = 0
-
-    import positionbaseddynamics_amd as pbd
-    if pbd.device_count() < 1:
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
 
     if args.pmc_child:
         from positionbaseddynamics_amd import _ffi
         for mode in range(4):
-            _ffi.check(_ffi.lib.pbdx_debug_stream(local_rank, CALIB_BYTES, mode), "pbdx_debug_stream")
-        args.no_roofline = args.no_cpu_baseline = True
+            _ffi.check(_ffi.lib.pbdx_debug_stream(ens.hip_device, CALIB_BYTES, mode), "pbdx_debug_stream")
+        args.no_roofline = args.no_cpu_baseline = args.no_extras = True
         args.steps, args.warmup = 2, 1
 
-    model, t_build, workload_desc, pins = build_workload(args, ens)
-    n_particles = model.getParticles().size()
-    n_constraints = model.numConstraints()
-    n_groups = len(model.getConstraintGroups())
+    w = {"workload": args.workload, "size": args.size, "instances": args.instances, "bars": args.bars, "solid_method": args.solid_method,
+         "iters": args.iters, "scaling": args.scaling, "total_instances": args.total_instances}
+    opts = {"xcd_remap": args.xcd_remap, "block": args.block, "fuse": args.fuse, "tile": args.tile, "fuse_block": args.fuse_block,
+            "max_seg": args.max_seg, "lds_particles": args.lds_particles, "persistent": args.persistent, "no_graph": args.no_graph}
 
-    pbd.TimeManager.getCurrent().setTimeStepSize(0.005)
-    ts = pbd.TimeStepController(device=local_rank)
-    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
-    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, args.iters)
-    sol = ts.solver()
-    if args.xcd_remap is not None:
-        sol.set_option(pbd.Solver.OPT_XCD_REMAP, args.xcd_remap)
-    if args.block is not None:
-        sol.set_option(pbd.Solver.OPT_BLOCK_SIZE, args.block)
-    if args.no_graph:
-        sol.set_option(pbd.Solver.OPT_USE_GRAPH, 0)
-    for val, opt in ((args.fuse, pbd.Solver.OPT_FUSE), (args.tile, pbd.Solver.OPT_TILE_PARTICLES), (args.fuse_block, pbd.Solver.OPT_FUSE_BLOCK),
-                     (args.max_seg, pbd.Solver.OPT_MAX_SEGMENT_COLOURS), (args.lds_particles, pbd.Solver.OPT_LDS_PARTICLES),
-                     (args.persistent, pbd.Solver.OPT_PERSISTENT)):
-        if val is not None:
-            sol.set_option(opt, val)
+    res = run_workload(w, opts, ens, args.steps, args.warmup, with_roofline=not args.no_roofline, with_traffic=not args.no_traffic and not args.pmc_child,
+                       with_pcie=not args.pmc_child, with_contacts=args.contacts)
+    t_max = ens.max_time(res["t_local"])                               # max over ranks
+    total_constraints = ens.sum_count(res["n_constraints"])            # all ranks
+    per_rank_ms = ens.gather_floats(1e3 * res["t_local"] / args.steps)
+    # cross-GPU parity: ranks that simulate the same scene (c2, c3: replicas; c4: identical instance blocks when the blocks
+    # have equal size) must hold the same bits -- one tiny all-reduce of per-rank checksums
+    sums = ens.gather_checksums([res["checksum"]], world)
+    replicas_identical = len(set(sums)) == 1
+    all_ok = ens.sum_count(1 if res["state_ok"] else 0) == world
 
-    def barrier():
-        torch.cuda.synchronize()
-        ens.barrier()
-
-    # warm-up (untimed): uploads the device image, instantiates the hipGraph, activates the constraints
-    ts.stepResident(model, max(args.warmup, 1))
-    barrier()
-    t0 = time.perf_counter()
-    ts.stepResident(model, args.steps)     # synchronises its own stream before returning
-    torch.cuda.synchronize()
-    t_local = time.perf_counter() - t0
-    stats = sol.stats()
-    plan = sol.plan_info()
-    persist = sol.persistent_info()
-    barrier()
-    t_max = ens.max_time(t_local)                       # max over ranks
-    total_constraints = ens.sum_count(n_constraints)    # all ranks (weak scaling: every rank owns its own instances)
-
-    projections_per_step = n_constraints * args.iters
     value = total_constraints * args.iters * args.steps / t_max
     ms_per_step = 1e3 * t_max / args.steps
-
-    # sanity: the state must be finite and the pinned corners must not have moved
-    ts.syncToHost(model)
-    x = model.getParticles().positions()
-    x0 = model.getParticles().array(1)
-    ok = bool(np.all(np.isfinite(x)) and all(np.array_equal(x[p], x0[p]) for p in pins))
-    # cross-GPU parity: every rank simulated the same synthetic scene, so every rank must hold the same bits
-    # (one tiny all-reduce of per-rank checksums; the only other collectives are the barrier and the max time)
-    from positionbaseddynamics_amd.ensemble import checksum
-    sums = ens.gather_checksums([checksum(x)], world)
-    replicas_identical = len(set(sums)) == 1
-
-    # PCIe-inclusive rate of the TimeStep::step contract (host ParticleData in -> step -> host ParticleData
-    # out every step); reported for information only, never `value`
-    t_pcie = t_pcie_pinned = None
-    if rank == 0:
-        ts.step(model)
-        t1 = time.perf_counter()
-        for _ in range(3):
-            ts.step(model)
-        t_pcie = (time.perf_counter() - t1) / 3
-        sol.set_option(pbd.Solver.OPT_PIN_HOST, 1)      # page-locked host mirror: transfers at full PCIe rate
-        ts.step(model)
-        t1 = time.perf_counter()
-        for _ in range(3):
-            ts.step(model)
-        t_pcie_pinned = (time.perf_counter() - t1) / 3
-        sol.set_option(pbd.Solver.OPT_PIN_HOST, 0)
-
-    contact_info = None
-    if rank == 0 and args.contacts:
-        # a floor box under the sheet and a sphere it falls onto; identity collider frames
-        eye = [1, 0, 0, 0, 1, 0, 0, 0, 1]
-        sol.set_colliders([dict(shape="box", params=[50.0, 0.5, 50.0], com=[0, -6.0, 0], R=eye, v1=[0, 0, 0], v2=[0, -6.0, 0], restitution=0.6, friction=0.2),
-                           dict(shape="sphere", params=[2.0], com=[5.0, -2.0, 0.0], R=eye, v1=[0, 0, 0], v2=[5.0, -2.0, 0.0], restitution=0.6, friction=0.1)])
-        sol.set_collision_ranges([(0, n_particles, 0.6, 0.1)])
-        sol.set_contact_params(0.05, 100.0, 5)
-        ts.stepResident(model, 3)
-        t1 = time.perf_counter()
-        ts.stepResident(model, args.steps)
-        torch.cuda.synchronize()
-        t_c = (time.perf_counter() - t1) / args.steps
-        contact_info = {"ms_per_step_with_contact_pass": 1e3 * t_c, "contacts_last_step": sol.num_contacts(),
-                        "colliders": 2, "note": "detection + 5 velocity sweeps for every particle against 2 static colliders, once per step"}
-        sol.set_colliders([])
-        sol.set_collision_ranges([])
-
+    stats = res["stats"]
+    n_physical = min(world, ndev) if args.oversubscribe else world
     out = {
         "metric": "constraint-projections/s", "value": value, "unit": "projections/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": n_physical, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "ms_per_substep": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling if args.workload == "c4" else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload_desc,
-                   "particles": n_particles, "constraints": n_constraints, "colour_groups": n_groups,
-                   "projections_per_substep": projections_per_step, "parallelism": "ensemble x%d (independent instances per GPU, no cross-GPU constraints, no data-path collective)" % world,
-                   "state_ok": ok, "replicas_bit_identical": replicas_identical, "state_checksum": "%016x" % sums[0], "device_event_ms_per_substep": stats["total_ms"] / max(args.steps, 1),
+        "config": {"workload": res["desc"],
+                   "particles": res["n_particles"], "constraints": res["n_constraints"], "colour_groups": res["n_groups"],
+                   "constraints_all_ranks": total_constraints,
+                   "projections_per_substep": res["n_constraints"] * args.iters,
+                   "parallelism": "ensemble x%d (independent instances per GPU, no cross-GPU constraints, no data-path collective)" % world,
+                   "rccl_ranks": world, "dist_backend": ens.backend, "oversubscribed": bool(args.oversubscribe and world > ndev),
+                   "per_rank_ms_per_step": per_rank_ms, "replica_checksums": ["%016x" % c for c in sums],
+                   "state_ok": all_ok, "replicas_bit_identical": replicas_identical, "state_checksum": "%016x" % sums[0],
+                   "device_event_ms_per_substep": stats["total_ms"] / max(args.steps, 1),
                    "algorithmic_GB_per_substep": stats["algorithmic_bytes"] / max(args.steps, 1) / 1e9,
                    "whole_substep_algorithmic_GBs": stats["algorithmic_bytes"] / max(stats["total_ms"], 1e-9) / 1e6,
-                   "host_scene_build_s": t_build, "contacts": contact_info, "pcie_inclusive_ms_per_step": None if t_pcie is None else 1e3 * t_pcie,
-                   "pcie_inclusive_pinned_ms_per_step": None if t_pcie_pinned is None else 1e3 * t_pcie_pinned, "plan": plan, "persistent": persist, "engine": sol.describe()},
+                   "host_scene_build_s": res["t_build"], "contacts": res.get("contacts"),
+                   "pcie_inclusive_ms_per_step": res.get("pcie_ms"), "pcie_inclusive_pinned_ms_per_step": res.get("pcie_pinned_ms"),
+                   "plan": res["plan"], "persistent": res["persistent"], "engine": res["engine"]},
     }
-
-    if rank == 0 and not args.no_roofline:
-        # kernel durations measured live with HIP events on the engine's own stream (eager launches, one
-        # event in front of every projection launch of the timed configuration)
-        sol.set_profiling(True)
-        psteps = max(2, min(5, args.steps))
-        ts.stepResident(model, psteps)
-        sol.set_profiling(False)
-        T = pbd.ConstraintType
-        pinfo = sol.persistent_info()
-        if plan["active"] and pinfo["active"] and pinfo["profiled_launches"]:
-            # one launch per substep runs all `iters` sweeps: algorithmic bytes of a launch = iters x bytes of a sweep
-            dur_s = 1e-3 * pinfo["profiled_ms"] / pinfo["profiled_launches"]
-            bytes_per_launch = pinfo["algorithmic_bytes_per_sweep"] * args.iters
-            # with an even number of passes the launch also integrates and updates the velocities (140 B per particle)
-            folded = (args.iters * plan["num_segments"]) % 2 == 0
-            if folded:
-                bytes_per_launch += n_particles * 140
-            segs = [sol.segment_info(i) for i in range(plan["num_segments"])]
-            streamed = sum(si["stream_bytes"] for si in segs) * args.iters
-            achieved = bytes_per_launch / dur_s / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "persistent_kernel (colour-fused LDS tiles, all %d sweeps x %d segments of a substep in one launch%s)" % (
-                                   args.iters, plan["num_segments"], ", integration and velocity update included" if folded else ""),
-                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "algorithmic_bytes_per_launch": bytes_per_launch, "streamed_bytes_per_launch": streamed, "avg_launch_us": dur_s * 1e6,
-                               "launches_measured": pinfo["profiled_launches"], "grid": pinfo["grid"], "block": pinfo["block"], "lds_bytes": pinfo["lds_bytes"],
-                               "segments": [{"segment": i, "colours": [si["colour_begin"], si["colour_end"]], "tiles": si["num_tiles"], "constraints": si["constraints"], "slots": si["slots"],
-                                             "algorithmic_bytes_per_pass": si["algorithmic_bytes"], "streamed_bytes_per_pass": si["stream_bytes"]} for i, si in enumerate(segs)],
-                               "note": "achieved = SURVEY 8d algorithmic bytes of the launch's distinct constraint projections / event-measured launch time; "
-                                       "positions stay in LDS within a pass (and the owned ones between passes), so the bytes actually streamed from HBM (streamed_*) are lower"}
-        elif plan["active"]:
-            segs = [sol.segment_info(i) for i in range(plan["num_segments"])]
-            rows = []
-            for i, si in enumerate(segs):
-                if not si["profiled_launches"]:
-                    continue
-                dur_s = 1e-3 * si["profiled_ms"] / si["profiled_launches"]
-                rows.append({"segment": i, "colours": [si["colour_begin"], si["colour_end"]], "tiles": si["num_tiles"], "block": si["block"],
-                             "lds_bytes": si["lds_bytes"], "constraints": si["constraints"], "slots": si["slots"],
-                             "launches": si["profiled_launches"], "avg_us": dur_s * 1e6,
-                             "algorithmic_bytes_per_launch": si["algorithmic_bytes"], "streamed_bytes_per_launch": si["stream_bytes"],
-                             "algorithmic_GBs": si["algorithmic_bytes"] / dur_s / 1e9, "streamed_GBs": si["stream_bytes"] / dur_s / 1e9})
-            if rows:
-                dom = max(rows, key=lambda r: r["avg_us"] * r["launches"])
-                out["roofline"] = {"bound": "hbm", "kernel": "fused_kernel (colour-fused LDS tiles), segment %d = colours [%d,%d)" % (dom["segment"], dom["colours"][0], dom["colours"][1]),
-                                   "achieved": dom["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["algorithmic_GBs"] / HBM_PEAK_GBS,
-                                   "traffic": None, "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                                   "streamed_bytes_per_launch": dom["streamed_bytes_per_launch"], "avg_launch_us": dom["avg_us"],
-                                   "launches_measured": dom["launches"], "segments": rows,
-                                   "note": "achieved = SURVEY 8d algorithmic bytes of the segment's distinct constraints / event-measured launch time; "
-                                           "positions stay in LDS for the whole segment, so the bytes actually streamed from HBM (streamed_*) are lower"}
-        else:
-            per_type = {}
-            for t in range(T.COUNT):
-                ms, launches, proj = sol.type_stats(t)
-                if launches:
-                    per_type[T.name(t)] = {"launches": launches, "avg_us": 1e3 * ms / launches, "projections": proj,
-                                           "algorithmic_GBs": proj * T.algorithmic_bytes(t) / ms / 1e6}
-            # dominant kernel of the per-colour schedule = the constraint type with the largest share of the time
-            dom_t, dom_ms = None, 0.0
-            for t in range(T.COUNT):
-                ms_t, launches_t, _ = sol.type_stats(t)
-                if launches_t and ms_t > dom_ms:
-                    dom_t, dom_ms = t, ms_t
-            if dom_t is not None:
-                ms, launches, proj = sol.type_stats(dom_t)
-                bytes_per_launch = proj * T.algorithmic_bytes(dom_t) / launches
-                dur_s = 1e-3 * ms / launches
-                achieved = bytes_per_launch / dur_s / 1e9
-                out["roofline"] = {"bound": "hbm", "kernel": "project_kernel<%s>" % T.name(dom_t), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                                   "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": dur_s * 1e6,
-                                   "launches_measured": launches, "per_type": per_type}
-
-    if rank == 0 and world == 1 and "roofline" in out and not args.no_traffic and not args.pmc_child:
-        child = ["--workload", args.workload, "--size", str(args.size), "--iters", str(args.iters), "--instances", str(args.instances),
-                 "--solid-method", str(args.solid_method)] + (["--bars"] if args.bars else [])
-        for flag, val in (("--fuse", args.fuse), ("--tile", args.tile), ("--fuse-block", args.fuse_block), ("--max-seg", args.max_seg),
-                          ("--lds-particles", args.lds_particles), ("--xcd-remap", args.xcd_remap), ("--block", args.block),
-                          ("--persistent", 2 if persist["active"] else 0)):
-            if val is not None:
-                child += [flag, str(val)]
-        kname = "persistent_kernel" if persist["active"] else "fused_kernel" if plan["active"] else "project_kernel"
-        tr = collect_traffic(child, kname)
-        if tr is not None:
-            r = out["roofline"]
-            if plan["active"] and not persist["active"]:
-                # the PMC mean runs over the launches of ALL segments: compare with the mean over segments
-                rows = r["segments"]
-                nl = sum(x["launches"] for x in rows)
-                r["traffic_scope"] = "mean over the launches of all %d segments of a sweep" % len(rows)
-                r["algorithmic_bytes_per_launch_mean"] = sum(x["algorithmic_bytes_per_launch"] * x["launches"] for x in rows) / nl
-                r["streamed_bytes_per_launch_mean"] = sum(x["streamed_bytes_per_launch"] * x["launches"] for x in rows) / nl
-            r["traffic"] = tr["bytes_per_launch"]
-            r["traffic_detail"] = {k: tr[k] for k in ("fetch_bytes", "write_bytes", "raw")}
-        kd = rocprof_kernel_durations(child, kname)
-        if kd is not None:
-            r = out["roofline"]
-            r["rocprofv3_mean_kernel_us"] = kd[0] / 1e3
-            r["rocprofv3_dispatches"] = kd[1]
-            if plan["active"] and not persist["active"]:
-                rows = r["segments"]
-                nl = sum(x["launches"] for x in rows)
-                r["event_mean_launch_us_all_segments"] = sum(x["avg_us"] * x["launches"] for x in rows) / nl
+    if res.get("roofline"):
+        out["roofline"] = res["roofline"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.size if args.workload != "c3" else 400, args.iters)
+        size = args.size if args.workload == "c2" else 400
+        cb, parity = cpu_baseline(size, args.iters, opts, ens.hip_device)
+        out["cpu_baseline"] = cb
+        out["config"]["parity_vs_reference"] = parity
+
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "c2" and not args.pmc_child:
+        # the other BASELINE workloads that fit one GPU, witnessed in the same line (shorter runs; same engine, defaults)
+        extras = []
+        base = {"size": 200, "instances": 64, "bars": False, "solid_method": 2, "iters": args.iters, "scaling": "weak", "total_instances": 512}
+        for ew, want_traffic in (({**base, "workload": "c3", "solid_method": 2}, True), ({**base, "workload": "c3", "solid_method": 4}, False),
+                                 ({**base, "workload": "c3", "solid_method": 6}, False), ({**base, "workload": "c4"}, True)):
+            try:
+                r = run_workload(ew, {}, ens, max(10, min(args.steps, 30)), 5, with_roofline=not args.no_roofline, with_traffic=want_traffic and not args.no_traffic)
+            except Exception as e:  # an extra must never cost the headline line
+                extras.append({"workload": ew["workload"], "error": repr(e)})
+                continue
+            nsteps = max(10, min(args.steps, 30))
+            ms = 1e3 * r["t_local"] / nsteps
+            extras.append({"workload": r["desc"], "particles": r["n_particles"], "constraints": r["n_constraints"], "colour_groups": r["n_groups"],
+                           "steps": nsteps, "ms_per_substep": ms, "projections_per_s": r["n_constraints"] * ew["iters"] * nsteps / r["t_local"],
+                           "state_ok": r["state_ok"], "host_scene_build_s": r["t_build"], "plan": r["plan"], "persistent": r["persistent"],
+                           "engine": r["engine"], "roofline": r.get("roofline")})
+        out["extra_workloads"] = extras
 
     if rank == 0:
         print(json.dumps(out), flush=True)

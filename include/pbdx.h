@@ -190,7 +190,8 @@ int pbdx_solver_set_collision_ranges(pbdx_solver *s, uint32_t n, const pbdx_coll
 /* tolerance = CollisionDetection::m_tolerance (default 0.01), contact_stiffness =
  * SimulationModel::m_contactStiffnessParticleRigidBody (default 100), max_iterations_v = "maxIterationsV" (default 5) */
 int pbdx_solver_set_contact_params(pbdx_solver *s, float tolerance, float contact_stiffness, uint32_t max_iterations_v);
-/* contacts found by the last step (sum over particles); PBDX_ERR_INVALID if a particle exceeded 8 simultaneous contacts */
+/* contacts found by the last step (sum over particles).  A particle with more than 8 simultaneous contacts is an error:
+ * pbdx_solver_step itself returns PBDX_ERR_UNSUPPORTED for such a call (the reference has no per-particle limit). */
 int pbdx_solver_get_num_contacts(pbdx_solver *s, uint32_t *out);
 
 /* XPBD multipliers of batch `batch_index` (order of add_batch calls). */
@@ -214,12 +215,17 @@ enum {
 	                                * transfers DMA at full PCIe rate; the arrays must stay allocated until the option is cleared or the
 	                                * solver destroyed (default 0) */
 	PBDX_OPT_PAIRS = 10,           /* project two chunks of a colour step jointly with packed fp32 arithmetic (default 0: measured slower) */
-	PBDX_OPT_PERSISTENT = 12       /* fused schedule only: all sweeps of a substep as ONE launch; a tile starts its next pass as soon as its
+	PBDX_OPT_PERSISTENT = 12,      /* fused schedule only: all sweeps of a substep as ONE launch; a tile starts its next pass as soon as its
 	                                * neighbouring tiles have published theirs (no kernel boundary, no chip-wide wait for the slowest tile).
 	                                * 1 (default) = used unless a one-off measurement on scratch positions finds it clearly slower than one launch per
-	                                * segment, 0 = never, 2 = always (if the plan is eligible), 3 = self-test (the launch is made to refuse).  Needs every workgroup co-resident: the
+	                                * segment, 0 = never, 2 = always (if the plan is eligible), 3 = self-test (the launch is made to refuse),
+	                                * 4 = self-test (a tile is made to time out waiting for its neighbour).  Needs every workgroup co-resident: the
 	                                * launch first checks that (bounded handshake); if not, it modifies nothing, the engine completes the step
-	                                * with one launch per segment and stops using the schedule (pbdx_solver_describe: persistent_refusals). */
+	                                * with one launch per segment and stops using the schedule (pbdx_solver_describe: persistent_refusals).
+	                                * A wait inside the launch is bounded as well (PBDX_OPT_PERSISTENT_TIMEOUT_MS): if it expires, the engine restores the
+	                                * particle state it saved at the start of the call, repeats the call with one launch per segment and stops
+	                                * using the schedule (pbdx_persistent_info::timeouts) -- the caller sees the result of an undisturbed run. */
+	PBDX_OPT_PERSISTENT_TIMEOUT_MS = 13 /* bound of a tile-to-tile wait inside the persistent launch in milliseconds, 1 .. 10000 (default 250) */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
 
@@ -233,6 +239,8 @@ typedef struct pbdx_plan_info {
 	uint64_t stream_bytes_per_sweep; /* index + parameter + multiplier bytes streamed from HBM per sweep */
 	double redundancy;             /* slots / distinct constraints */
 	double build_seconds;
+	uint64_t compulsory_stream_bytes_per_sweep; /* the same streams without halo redundancy: every distinct constraint's record (16-bit
+	                                * indices, streamed parameter planes, multiplier read + write) exactly once per sweep */
 } pbdx_plan_info;
 int pbdx_solver_get_plan_info(pbdx_solver *s, pbdx_plan_info *out);
 typedef struct pbdx_segment_info {
@@ -248,6 +256,8 @@ typedef struct pbdx_persistent_info {
 	int eligible, active;          /* the plan can run as one launch per substep / that is the schedule in use */
 	uint32_t grid, block, lds_bytes; /* launch geometry */
 	uint32_t refusals;             /* launches that found their workgroups not co-resident (the engine then fell back for good) */
+	uint32_t timeouts;             /* calls in which a tile-to-tile wait expired (state restored, call repeated with one launch per segment) */
+	int last_folded;               /* the substeps enqueued last ran integration and velocity update inside the persistent launch (one launch per substep) */
 	double autotune_fused_ms, autotune_persistent_ms; /* the one-off measurement: 12 sweeps on scratch positions, 0 = not measured */
 	double profiled_ms;            /* last profiled pbdx_solver_step: summed duration and number of persistent launches */
 	uint64_t profiled_launches;

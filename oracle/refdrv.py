@@ -27,6 +27,25 @@ def available(variant="f32"):
     return os.path.exists(os.path.join(REF_DIR, "libpbdref_%s.so" % variant))
 
 
+def best_timing_variant():
+    """The release-like reference build for CPU timing that THIS host can execute: 'v4' (-O3 -march=x86-64-v4, AVX-512) if
+    /proc/cpuinfo lists the level's features, else 'fast' (-O3 -march=x86-64-v3), else None.  The reference's own flags
+    are -O3 -march=native (CMake/Common.cmake:66); a native build of the build container cannot travel to another host."""
+    need = {"avx512f", "avx512bw", "avx512cd", "avx512dq", "avx512vl"}
+    flags = set()
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("flags"):
+                    flags = set(line.split(":", 1)[1].split())
+                    break
+    except OSError:
+        pass
+    if need <= flags and available("v4"):
+        return "v4"
+    return "fast" if available("fast") else None
+
+
 def _dp(a):
     return a.ctypes.data_as(_pd)
 

@@ -44,7 +44,8 @@ class CollisionRange(C.Structure):
 class PlanInfo(C.Structure):
     _fields_ = [("built", C.c_int), ("active", C.c_int), ("num_segments", C.c_uint32), ("num_tiles", C.c_uint32),
                 ("num_colours", C.c_uint32), ("max_local", C.c_uint32), ("slots_per_sweep", C.c_uint64),
-                ("stream_bytes_per_sweep", C.c_uint64), ("redundancy", C.c_double), ("build_seconds", C.c_double)]
+                ("stream_bytes_per_sweep", C.c_uint64), ("redundancy", C.c_double), ("build_seconds", C.c_double),
+                ("compulsory_stream_bytes_per_sweep", C.c_uint64)]
 
 
 class SegmentInfo(C.Structure):
@@ -56,7 +57,7 @@ class SegmentInfo(C.Structure):
 
 class PersistentInfo(C.Structure):
     _fields_ = [("eligible", C.c_int), ("active", C.c_int), ("grid", C.c_uint32), ("block", C.c_uint32), ("lds_bytes", C.c_uint32),
-                ("refusals", C.c_uint32), ("autotune_fused_ms", C.c_double), ("autotune_persistent_ms", C.c_double),
+                ("refusals", C.c_uint32), ("timeouts", C.c_uint32), ("last_folded", C.c_int), ("autotune_fused_ms", C.c_double), ("autotune_persistent_ms", C.c_double),
                 ("profiled_ms", C.c_double), ("profiled_launches", C.c_uint64), ("algorithmic_bytes_per_sweep", C.c_uint64)]
 
 

@@ -66,6 +66,8 @@ struct pbdx_model
 	uint64_t topology_version = 0;   // bumped by every add*/cleanup: device image invalidation
 	uint64_t params_version = 0;     // bumped by set_constraint_params / set_mass
 	uint64_t state_version = 0;      // bumped when the host particle state (x, v, a, oldX, lastX) is written through the API
+	uint32_t dirty_arrays = 0;       // bit `which` (pbdx_model_get_array numbering) set: that host array was written since the device image last
+	                                 // agreed with the host (a resident time step pulls the OTHER arrays from the device before it re-uploads)
 
 	uint32_t size() const { return (uint32_t)mass.size(); }
 };

@@ -207,6 +207,8 @@ int pbdx_model_reset(pbdx_model *m)
 	std::fill(m->v.begin(), m->v.end(), 0.0f);
 	std::fill(m->a.begin(), m->a.end(), 0.0f);
 	m->params_version++;
+	m->state_version++;              // the host state is authoritative again (a device-resident image is stale)
+	m->dirty_arrays |= 0x3fu;
 	return PBDX_OK;
 }
 
@@ -438,11 +440,12 @@ int pbdx_model_set_array(pbdx_model *m, int which, const float *in)
 	if (!a || which == 7) { set_error("set_array: bad selector %d", which); return PBDX_ERR_INVALID; }
 	memcpy(a->data(), in, a->size() * sizeof(float));
 	m->state_version++;
+	m->dirty_arrays |= 1u << which;
 	return PBDX_OK;
 }
 
 float *pbdx_model_positions_ptr(pbdx_model *m) { return m ? m->x.data() : nullptr; }
-int pbdx_model_mark_state_dirty(pbdx_model *m) { if (!m) return PBDX_ERR_INVALID; m->state_version++; return PBDX_OK; }
+int pbdx_model_mark_state_dirty(pbdx_model *m) { if (!m) return PBDX_ERR_INVALID; m->state_version++; m->dirty_arrays |= 1u; return PBDX_OK; }
 
 // ---- per-constraint builders -----------------------------------------------------------
 int pbdx_model_add_distance_constraint(pbdx_model *m, uint32_t p1, uint32_t p2, float stiffness)

@@ -533,9 +533,10 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 // halo one pass earlier (write-after-read on the double-buffered positions); ensure_plan() derives it from the
 // plan.  Arithmetic, order and streams are those of (A): results are bit-identical.
 // Residency: gridDim <= number of CUs and one workgroup per CU; HIP guarantees neither, so every wait is bounded
-// (kSpinLimitTicks) and a timeout raises `*error` instead of hanging -- the host then falls back to (A).
+// (PersistArgs::spin_limit) and a timeout raises `*error` instead of hanging -- the host then restores the state it
+// saved at the start of the call and repeats the call with schedule (A).
 constexpr uint32_t kMaxPersistSegs = 8;
-constexpr unsigned long long kSpinLimitTicks = 2000000ull;      // 20 ms of the 100 MHz wall clock
+constexpr unsigned long long kTicksPerMs = 100000ull;           // the wall clock runs at 100 MHz
 constexpr unsigned long long kArriveLimitTicks = 100000ull;     // 1 ms: all workgroups of a launch must have started by then
 struct PersistArgs
 {
@@ -549,6 +550,8 @@ struct PersistArgs
 	uint32_t *error;                              // page-locked host words: [0] a dependency wait timed out, [1] launch refused, [2] at which substep
 	uint32_t num_segs, passes, num_tiles;
 	uint32_t expect;                              // arrivals that mean "everybody is here" (gridDim.x; one more in the self-test)
+	unsigned long long spin_limit;                // bound of a dependency wait in wall-clock ticks (PBDX_OPT_PERSISTENT_TIMEOUT_MS)
+	int mute_tile0;                               // self-test of the timeout path: tile 0 never publishes its first pass
 	int folded;                                   // pass 0 integrates, the last pass updates the velocities (FoldArgs)
 	FoldArgs fold;
 	int start;                                    // position buffer pass 0 reads
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 						const uint32_t *flag = a.epoch + a.dep_tile[sgi][d];
 						while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pass)
 						{
-							if (wall_clock64() - t0 > kSpinLimitTicks) { s_failed = 1u; break; }
+							if (wall_clock64() - t0 > a.spin_limit) { s_failed = 1u; break; }
 							__builtin_amdgcn_s_sleep(1);
 						}
 					}
@@ -632,14 +635,16 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 			process_tile<MASK, BLOCK, false, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && gridDim.x == a.num_tiles, wait, &a.fold, fold_phase);
 			if (s_failed)
 			{
-				// a neighbour never arrived: the result is garbage, say so and leave (uniform: one LDS word)
-				if (threadIdx.x == 0) atomicOr(a.error, 1u);
+				// a neighbour never arrived: the state of this step is garbage.  Say so, turn every later kernel of the call
+				// into a no-op (ctl) and leave (uniform: one LDS word); the host restores the snapshot it took at the start
+				// of the call and repeats the call with one launch per segment.
+				if (threadIdx.x == 0) { atomicOr(a.error, 1u); atomicExch(a.ctl + kCtlAbort, 1u); }
 				return;
 			}
 			// publish: this thread's stores have left the CU, then everybody's, then the counter
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__syncthreads();
-			if (threadIdx.x == 0) __hip_atomic_store(a.epoch + tile, pass + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (threadIdx.x == 0 && !(a.mute_tile0 && tile == 0u)) __hip_atomic_store(a.epoch + tile, pass + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		sgi = sgi + 1u == a.num_segs ? 0u : sgi + 1u;
 	}
@@ -898,6 +903,9 @@ struct pbdx_solver
 	int persistent = 1;                  // PBDX_OPT_PERSISTENT: the sweeps of a substep as one launch (A'): 0 never, 1 where measured faster, 2 always, 3 self-test
 	bool persist_ok = false;             // the plan is eligible (and no launch has been refused or has timed out)
 	uint32_t persist_refusals = 0;
+	uint32_t persist_timeouts = 0;       // calls in which a tile gave up waiting for a neighbour (state restored, call repeated with schedule (A))
+	uint32_t persist_timeout_ms = 250;   // PBDX_OPT_PERSISTENT_TIMEOUT_MS
+	float4 *d_snap[4] = { nullptr, nullptr, nullptr, nullptr };   // pos / vel / old / last as they were when the current call started (persistent schedule only)
 	bool last_folded = false;            // the substeps enqueued last ran integrate / velocity update inside the persistent launch
 	double persist_ms = 0.0;             // last profiled step: summed duration / number of persistent launches
 	uint64_t persist_launches = 0;
@@ -985,6 +993,7 @@ struct pbdx_solver
 		for (float4 **p : { &d_pos[0], &d_pos[1], &d_vel, &d_old, &d_last })
 			if (*p) { (void)hipFree(*p); *p = nullptr; }
 		if (d_stage) { (void)hipFree(d_stage); d_stage = nullptr; }
+		for (float4 *&p : d_snap) if (p) { (void)hipFree(p); p = nullptr; }
 		n = 0;
 	}
 	bool fused_active() const { return fuse && plan_ok && !dsegs.empty() && (fuse == 1 || fuse_choice); }
@@ -1327,6 +1336,8 @@ int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations, co
 	a.passes = iterations * a.num_segs;
 	a.num_tiles = s->plan.num_tiles;
 	a.expect = s->persist_grid + (s->persistent == 3 ? 1u : 0u);     // 3 = self-test: the handshake cannot complete
+	a.spin_limit = (unsigned long long)s->persist_timeout_ms * kTicksPerMs;
+	a.mute_tile0 = s->persistent == 4 ? 1 : 0;                       // 4 = self-test of the timeout path
 	a.start = src;
 	a.dt = dt;
 	if (fold) { a.folded = 1; a.fold = *fold; }
@@ -1337,16 +1348,40 @@ int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations, co
 	return PBDX_OK;
 }
 
-// after a stream synchronisation: did a persistent launch give up waiting?  The positions are garbage then; the
-// schedule is switched off for this solver and the caller gets an error (never a hang, never a silent wrong result).
-int check_persistent(pbdx_solver *s)
+// The persistent schedule can fail in one way that touches the state: a tile gives up waiting for a neighbour
+// (PersistArgs::spin_limit; a GPU shared with another process, a profiler, pre-emption).  The positions are then
+// garbage.  While the schedule is active every call therefore starts by saving pos / vel / old / last on the device
+// (four stream-ordered copies, 64 B per particle per CALL, not per substep); a timed-out call restores them, stops
+// using the schedule and is repeated with one launch per segment -- the caller sees the result of an undisturbed
+// run (self-test: PBDX_OPT_PERSISTENT = 4).
+int snapshot_state(pbdx_solver *s, bool positions_only)
 {
-	if (!s->h_error || s->h_error[0] == 0u) return PBDX_OK;
-	s->h_error[0] = 0u;
+	if (!s->n) return PBDX_OK;
+	float4 *src[4] = { s->d_pos[0], s->d_vel, s->d_old, s->d_last };
+	for (int k = 0; k < (positions_only ? 1 : 4); k++)
+	{
+		if (!s->d_snap[k]) HIPCHECK(hipMalloc(&s->d_snap[k], (size_t)s->n * sizeof(float4)));
+		HIPCHECK(hipMemcpyAsync(s->d_snap[k], src[k], (size_t)s->n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+	}
+	return PBDX_OK;
+}
+// after a stream synchronisation: did a persistent launch time out?  Then: state := snapshot, schedule off.
+// Returns 1 if the caller has to repeat its work, 0 if nothing happened, < 0 on error (-status).
+int recover_persistent(pbdx_solver *s, bool positions_only)
+{
+	if (!s->h_error || s->h_error[0] == 0u) return 0;
+	s->h_error[0] = s->h_error[1] = s->h_error[2] = 0u;
 	s->persist_ok = false;
+	s->persist_timeouts++;
 	s->drop_graph();
-	set_error("persistent schedule: a tile timed out waiting for its neighbours (workgroups not co-resident?); the schedule is disabled for this solver and the particle state of this step is invalid -- upload it again");
-	return PBDX_ERR_HIP;
+	float4 *dst[4] = { s->d_pos[0], s->d_vel, s->d_old, s->d_last };
+	for (int k = 0; k < (positions_only ? 1 : 4); k++)
+	{
+		if (!s->d_snap[k]) { set_error("persistent schedule: a tile timed out and no snapshot exists"); return -PBDX_ERR_HIP; }
+		if (hipMemcpyAsync(dst[k], s->d_snap[k], (size_t)s->n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream) != hipSuccess) return -PBDX_ERR_HIP;
+	}
+	if (hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream) != hipSuccess) return -PBDX_ERR_HIP;
+	return 1;
 }
 
 int launch_segment(pbdx_solver *s, size_t si, int src, float dt, int first_iter)
@@ -1568,7 +1603,7 @@ int enqueue_substep(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int v
 int enqueue_contacts(pbdx_solver *s)
 {
 	if (s->colliders.empty() || s->ranges.empty() || !s->n) return PBDX_OK;
-	HIPCHECK(hipMemsetAsync(s->d_contact_counters, 0, 2 * sizeof(unsigned int), s->stream));
+	HIPCHECK(hipMemsetAsync(s->d_contact_counters, 0, sizeof(unsigned int), s->stream));      // [0] contacts of this step; [1] (overflow) is reset per call
 	for (const pbdx_collision_range &r : s->ranges)
 	{
 		if (!r.count) continue;
@@ -1857,8 +1892,11 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 	case PBDX_OPT_PAIRS: s->pairs = value != 0; replan = true; break;
 	case PBDX_OPT_PIN_HOST: s->pin_host = value != 0; if (!s->pin_host) s->unpin_all(); break;
 	case PBDX_OPT_PERSISTENT:
-		if (value < 0 || value > 3) { set_error("persistent must be 0 .. 3"); return PBDX_ERR_INVALID; }
+		if (value < 0 || value > 4) { set_error("persistent must be 0 .. 4"); return PBDX_ERR_INVALID; }
 		s->persistent = (int)value; replan = true; break;
+	case PBDX_OPT_PERSISTENT_TIMEOUT_MS:
+		if (value < 1 || value > 10000) { set_error("persistent timeout must be 1 .. 10000 ms"); return PBDX_ERR_INVALID; }
+		s->persist_timeout_ms = (uint32_t)value; break;
 	default: set_error("unknown option %d", option); return PBDX_ERR_INVALID;
 	}
 	s->drop_graph();
@@ -1908,7 +1946,13 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	s->persist_ms = 0.0; s->persist_launches = 0;
 
 	if (s->persistent_active())
+	{
 		HIPCHECK(hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream));
+		int r = snapshot_state(s, false);
+		if (r) return r;
+	}
+	if (s->d_contact_counters && !s->colliders.empty())
+		HIPCHECK(hipMemsetAsync(s->d_contact_counters, 0, 2 * sizeof(unsigned int), s->stream));     // [1] = overflow flag, sticky for the whole call
 	if (s->profile)
 	{
 		HIPCHECK(hipEventRecord(s->ev_start, s->stream));
@@ -1983,10 +2027,41 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
 		HIPCHECK(hipStreamSynchronize(s->stream));
 	}
+	{
+		// a tile of a persistent launch timed out: the state was restored from the snapshot; repeat the whole call
+		// with one launch per segment
+		const int rec = recover_persistent(s, false);
+		if (rec < 0) { set_error("persistent schedule: recovery after a timed-out launch failed"); return -rec; }
+		if (rec > 0)
+		{
+			if (s->d_contact_counters && !s->colliders.empty())
+				HIPCHECK(hipMemsetAsync(s->d_contact_counters, 0, 2 * sizeof(unsigned int), s->stream));
+			int r = PBDX_OK;
+			for (uint64_t k2 = 0; !r && k2 < substeps_total; k2++)
+			{
+				r = enqueue_substep(s, hs, inv_h, max_iterations, vel, gravity, nullptr);
+				if (!r && (k2 + 1) % sub_steps == 0) r = enqueue_contacts(s);
+			}
+			if (r) return r;
+			HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
+			HIPCHECK(hipStreamSynchronize(s->stream));
+		}
+	}
 	float ms = 0.0f;
 	HIPCHECK(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
 	s->stats.total_ms = ms;
-	return check_persistent(s);
+	if (s->d_contact_counters && !s->colliders.empty())
+	{
+		// the reference has no per-particle contact limit: exceeding the engine's is an error, not a silent divergence
+		unsigned int c[2] = { 0, 0 };
+		HIPCHECK(hipMemcpy(c, s->d_contact_counters, sizeof(c), hipMemcpyDeviceToHost));
+		if (c[1])
+		{
+			set_error("a particle had more than %d simultaneous contacts: its contact response was skipped (the reference has no such limit)", PBDX_MAX_CONTACTS_PER_PARTICLE);
+			return PBDX_ERR_UNSUPPORTED;
+		}
+	}
+	return PBDX_OK;
 }
 
 int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
@@ -2003,7 +2078,11 @@ int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
 	if (start)
 		HIPCHECK(hipMemcpyAsync(s->d_pos[1], s->d_pos[0], (size_t)s->n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
 	if (s->persistent_active())
+	{
 		HIPCHECK(hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream));
+		r = snapshot_state(s, true);
+		if (r) return r;
+	}
 	r = projection_sweeps(s, h_sub, iterations, start, nullptr);
 	if (r) return r;
 	HIPCHECK(hipStreamSynchronize(s->stream));
@@ -2018,7 +2097,17 @@ int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
 		if (r) return r;
 		HIPCHECK(hipStreamSynchronize(s->stream));
 	}
-	return check_persistent(s);
+	const int rec = recover_persistent(s, true);
+	if (rec < 0) { set_error("persistent schedule: recovery after a timed-out launch failed"); return -rec; }
+	if (rec > 0)
+	{
+		if (start)
+			HIPCHECK(hipMemcpyAsync(s->d_pos[1], s->d_pos[0], (size_t)s->n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+		r = projection_sweeps(s, h_sub, iterations, start, nullptr);
+		if (r) return r;
+		HIPCHECK(hipStreamSynchronize(s->stream));
+	}
+	return PBDX_OK;
 }
 
 int pbdx_solver_synchronize(pbdx_solver *s)
@@ -2162,6 +2251,13 @@ int pbdx_solver_get_plan_info(pbdx_solver *s, pbdx_plan_info *out)
 		out->stream_bytes_per_sweep += seg.stream_bytes;
 		out->slots_per_sweep += seg.slots;
 	}
+	// what one sweep has to stream if no constraint were executed twice: every distinct constraint's record once
+	for (const Batch &b : s->batches)
+	{
+		const TypeInfo *ti = type_info(b.type);
+		const uint32_t rec = (ti->num_bodies == 2 ? 4u : 8u) + (uint32_t)num_planes(b.type, s->plan.views[b.type].compact != 0) * 4u + (ti->xpbd ? 8u : 0u);
+		out->compulsory_stream_bytes_per_sweep += (uint64_t)b.count * rec;
+	}
 	return PBDX_OK;
 }
 
@@ -2187,6 +2283,8 @@ int pbdx_solver_get_persistent_info(pbdx_solver *s, pbdx_persistent_info *out)
 	out->active = s->persistent_active() ? 1 : 0;
 	out->grid = s->persist_grid; out->block = (uint32_t)s->persist_block; out->lds_bytes = s->persist_lds;
 	out->refusals = s->persist_refusals;
+	out->timeouts = s->persist_timeouts;
+	out->last_folded = s->last_folded ? 1 : 0;
 	out->autotune_fused_ms = s->autotune_ms[1];
 	out->autotune_persistent_ms = s->autotune_ms[2];
 	out->profiled_ms = s->persist_ms;

@@ -27,6 +27,7 @@ struct pbdx_timestep
 	bool schedule_valid = false;
 	bool device_ahead = false;   // device state newer than the host model (resident stepping)
 	uint64_t state_seen = ~0ull; // model->state_version of the host state the device image was built from / synced to
+	uint32_t image_n = 0;        // particles in the device image
 };
 
 namespace {
@@ -82,6 +83,11 @@ int build_schedule(pbdx_timestep *ts, pbdx_model *m)
 	return pbdx_solver_end_schedule(ts->solver);
 }
 
+// Bring the device image up to date with the model.  Particle state: the host arrays are uploaded when they were
+// written through the model API (state_version), when masses / parameters / topology changed, or on demand.  If the
+// device is AHEAD of the host at that moment (resident stepping without sync_to_host), the arrays the host did NOT
+// write are first pulled from the device, so that a parameter edit, a setMass or a partial host write (positions
+// only, say) between resident steps never rolls the simulation back to a stale host mirror.
 int refresh_image(pbdx_timestep *ts, pbdx_model *m, bool force_particles)
 {
 	{
@@ -94,10 +100,20 @@ int refresh_image(pbdx_timestep *ts, pbdx_model *m, bool force_particles)
 	const bool host_dirty = ts->state_seen != m->state_version;
 	if (stale_topology || stale_params || force_particles || host_dirty)
 	{
+		if (ts->device_ahead && ts->image_of == m && ts->image_n && ts->image_n <= m->size())
+		{
+			// (particles appended on the host since then exist only there; the packed arrays take the device's first image_n entries)
+			const uint32_t d = host_dirty ? m->dirty_arrays : 0u;
+			int r = pbdx_solver_get_particles(ts->solver, ts->image_n, (d & 1u) ? nullptr : m->x.data(), (d & 4u) ? nullptr : m->v.data(),
+				(d & 16u) ? nullptr : m->old_x.data(), (d & 32u) ? nullptr : m->last_x.data());
+			if (r) return r;
+		}
 		int r = upload_particles(ts, m);
 		if (r) return r;
+		ts->image_n = m->size();
 		ts->device_ahead = false;
 		ts->state_seen = m->state_version;
+		m->dirty_arrays = 0;
 	}
 	if (stale_topology || stale_params)
 	{
@@ -261,6 +277,7 @@ int pbdx_timestep_sync_to_host(pbdx_timestep *ts, pbdx_model *m)
 	if (r) return r;
 	ts->device_ahead = false;
 	ts->state_seen = m->state_version;     // host mirror == device state
+	m->dirty_arrays = 0;
 	return PBDX_OK;
 }
 

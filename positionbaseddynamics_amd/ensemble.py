@@ -30,12 +30,18 @@ def checksum(positions):
 class Ensemble:
     """Process-group plumbing shared by bench.py and the tests."""
 
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, oversubscribe=False, num_devices=None):
+        """oversubscribe: more ranks than GPUs are allowed to share devices (gloo backend, HIP device = local_rank mod
+        num_devices): a smoke test of the N>1 code path on a box with fewer GPUs, never a measurement."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = None
+        self.hip_device = self.local_rank if self.world > 1 else 0
+        if oversubscribe and num_devices and self.world > num_devices:
+            backend = backend or "gloo"
+            self.hip_device = self.local_rank % num_devices
         if self.world > 1:
             import torch
             import torch.distributed as dist
@@ -54,6 +60,7 @@ class Ensemble:
                 # ranks may share a GPU in this mode: PBDX_DEVICE_OVERRIDE pins the HIP device index
                 if os.environ.get("PBDX_DEVICE_OVERRIDE") is not None:
                     self.local_rank = int(os.environ["PBDX_DEVICE_OVERRIDE"])
+                    self.hip_device = self.local_rank
             self.dist = dist
         self.backend = backend
 
@@ -86,6 +93,16 @@ class Ensemble:
     def sum_count(self, n):
         import torch
         return int(self._reduce(int(n), "SUM", torch.int64))
+
+    def gather_floats(self, value):
+        """One float per rank, returned as the list over ranks on every rank (SUM all-reduce of a one-hot vector)."""
+        if self.dist is None:
+            return [float(value)]
+        import torch
+        v = torch.zeros(self.world, dtype=torch.float64, device=self.device)
+        v[self.rank] = float(value)
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM)
+        return [float(x) for x in v.cpu().tolist()]
 
     def gather_checksums(self, local, total):
         """All ranks contribute the checksums of their instances; returns the full list (length `total`)

@@ -94,3 +94,29 @@ def test_world_size_2_gloo_ensemble(tmp_path):
     assert res["sums"] == want                                      # every instance exactly once, bit-exact
     assert res["total_proj"] == proj
     assert len(set(want)) == 5
+
+
+def test_bench_gpus_n_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment must start two ranks itself (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* as torch.distributed.run would), rendezvous and print ONE line from rank 0.  The launcher self-test stops
+    after the rendezvous (no GPU here); the same spawner carries the real run on a GPU box (profiles/: bench --gpus 2)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--rank-selftest"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["rccl_ranks"] == 2 and res["ranks"] == [0.0, 1.0] and res["max_time"] == pytest.approx(1.5) and res["spawned_by_bench"]
+    # under a launcher (WORLD_SIZE set) the script must NOT spawn again
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        e2 = dict(env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--rank-selftest"], env=e2,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [q.communicate(timeout=300) for q in procs]
+    assert all(q.returncode == 0 for q in procs), outs[0][1][-2000:]
+    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert res["rccl_ranks"] == 2 and not res["spawned_by_bench"] and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]

@@ -111,8 +111,10 @@ def test_fem_tet_inversion_branch(pbd):
         assert np.all(np.isfinite(xg))
         assert util.max_err(xr, x_start) > 1e-3
         err = util.max_err(xg, xr)
-        print("inversion branch %-14s max |dx| = %.3e  bit-exact=%s" % (tname, err, util.bitwise_equal(xg, xr.astype(np.float32))))
-        assert err <= 1e-6, "%s inversion branch: %.3e" % (tname, err)
+        exact = util.bitwise_equal(xg, xr.astype(np.float32))
+        print("inversion branch %-14s max |dx| = %.3e  bit-exact=%s" % (tname, err, exact))
+        # the Jacobi SVD with inversion handling is restated operation for operation (no libm call inside): bitwise
+        assert exact, "%s inversion branch: max err %.3e, %d ulp" % (tname, err, util.ulp_diff(xg, xr.astype(np.float32)))
 
 
 # ---------------------------------------------------------------------------
@@ -330,30 +332,101 @@ def test_schedule_validator_and_lambdas(pbd):
     assert np.allclose(lam, lam_ref, rtol=1e-5, atol=1e-9)
 
 
+def test_xpbd_multipliers_bitwise_vs_reference_on_a_320x320_cloth(pbd):
+    """The XPBD multipliers (m_lambda, Constraints.cpp:1241,1448) of every constraint of the first distance colour, of a
+    late distance colour and of the last bending colour after 3 steps x 10 iterations: bit-identical to the reference's."""
+    ops = util.cloth_spec(320, 320, 4, 3)
+    o = util.oracle_run(ops, 3, 1, 10, "f32", threads=8)
+    m, ts = util.mine_run(ops, 3, 1, 10, resident=True)
+    sol = ts.solver()
+    assert sol.plan_info()["active"] == 1
+    assert util.bitwise_equal(m.getParticles().positions(), o.positions().astype(np.float32))
+    groups = m.getConstraintGroups()
+    types = m.constraintTypes()
+    # batches are added per (group, type) in group order: find the batch index of (group, first type of the group)
+    batch_of = {}
+    b = 0
+    for g, members in enumerate(groups):
+        for t in sorted(set(int(types[c]) for c in members)):
+            batch_of[(g, t)] = b
+            b += 1
+    checked = 0
+    for g in (0, 5, len(groups) - 1):
+        t = int(types[groups[g][0]])
+        ids = [int(c) for c in groups[g] if types[c] == t]
+        lam = sol.get_lambdas(batch_of[(g, t)], len(ids))
+        lam_ref = np.array([o.constraint_lambda(c) for c in ids], dtype=np.float32)
+        assert np.any(lam_ref != 0)
+        assert np.array_equal(lam.view(np.uint32), lam_ref.view(np.uint32)), "group %d: %d of %d multipliers differ" % (
+            g, int(np.sum(lam.view(np.uint32) != lam_ref.view(np.uint32))), len(ids))
+        checked += len(ids)
+    print("multipliers compared bitwise with the reference: %d" % checked)
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json full sizes
 # ---------------------------------------------------------------------------
+def _reference_states(ops, iters, horizons, threads=16):
+    """positions / velocities of the float reference after each horizon (cumulative steps)."""
+    ref = util.get_oracle("f32")
+    util.apply_ref(ref, ops)
+    ref.set_num_threads(threads); ref.set_time_step_size(0.005); ref.set_gravity(util.GRAVITY); ref.set_params(1, iters, 0)
+    out, done = {}, 0
+    for h in horizons:
+        ref.step(h - done)
+        done = h
+        out[h] = (ref.positions().astype(np.float32), ref.get_array(2).astype(np.float32))
+    ref.reset_all()
+    return out
+
+
 def test_full_size_c2_million_particle_cloth_vs_reference(pbd):
-    """configs[1] at full size: 1000x1000 cloth, 5 988 006 constraints, 27 colours, 10 iterations.
-    Two steps through the default (colour-fused) schedule against the reference's own float build
-    run on the host cores: every one of the 3 000 000 coordinates bit-identical; then the
-    per-colour schedule against the fused one (size-independent cross-check of the two device paths)."""
+    """configs[1] at full size: 1000x1000 cloth, 5 988 006 constraints, 27 colours, 10 iterations -- every one of the
+    3 000 000 coordinates and 3 000 000 velocity components bit-identical to the reference's own float build run on the
+    host cores, after 10 steps, on EXACTLY the schedule bench.py times: the persistent one-launch-per-substep form is
+    forced and asserted (active, folded, no refusal, no timeout), then one launch per segment, then (2 steps) the
+    per-colour schedule."""
+    S = pbd.Solver
     ops = util.cloth_spec(1000, 1000, 4, 3)
-    ref = util.oracle_run(ops, 2, 1, 10, "f32", threads=16)
-    xr, vr = ref.positions().astype(np.float32), ref.get_array(2).astype(np.float32)
-    m, ts = util.mine_run(ops, 2, 1, 10, resident=True)
-    info = ts.solver().plan_info()
-    print("C2 full size plan:", info)
-    assert info["active"] == 1 and info["max_local"] <= 10240
-    xg, vg = m.getParticles().positions(), m.getParticles().array(2)
-    assert util.bitwise_equal(xg, xr), "max err %.3e" % util.max_err(xg, xr)
-    assert util.bitwise_equal(vg, vr)
-    m2, ts2 = util.mine_run(ops, 2, 1, 10, resident=True, options={pbd.Solver.OPT_FUSE: 0})
-    assert ts2.solver().plan_info()["active"] == 0
-    assert util.bitwise_equal(m2.getParticles().positions(), xg)
-    # pinned corners never move, state finite
-    x0 = m.getParticles().array(1)
-    assert np.array_equal(xg[0], x0[0]) and np.array_equal(xg[999], x0[999]) and np.all(np.isfinite(xg))
+    want = _reference_states(ops, 10, [2, 10])
+    x0 = None
+    for label, options, steps in (("persistent, folded", {S.OPT_PERSISTENT: 2}, 10), ("one launch per segment", {S.OPT_PERSISTENT: 0}, 10),
+                                  ("default (measured choice)", {}, 10), ("per-colour", {S.OPT_FUSE: 0}, 2)):
+        m, ts = util.mine_run(ops, steps, 1, 10, resident=True, options=options)
+        sol = ts.solver()
+        info, pinfo = sol.plan_info(), sol.persistent_info()
+        print("C2 full size [%s]: %s | %s" % (label, info, pinfo))
+        if label == "per-colour":
+            assert info["active"] == 0
+        else:
+            assert info["active"] == 1 and info["max_local"] <= 10240
+        if label == "persistent, folded":
+            assert pinfo["eligible"] == 1 and pinfo["active"] == 1 and pinfo["refusals"] == 0 and pinfo["timeouts"] == 0
+            assert pinfo["last_folded"] == 1, "30 passes per substep: integration and velocity update must run inside the launch"
+        if label == "one launch per segment":
+            assert pinfo["active"] == 0 and pinfo["last_folded"] == 0
+        xg, vg = m.getParticles().positions(), m.getParticles().array(2)
+        xr, vr = want[steps]
+        assert util.bitwise_equal(xg, xr), "%s: max err %.3e" % (label, util.max_err(xg, xr))
+        assert util.bitwise_equal(vg, vr), label
+        x0 = m.getParticles().array(1)
+        # pinned corners never move, state finite
+        assert np.array_equal(xg[0], x0[0]) and np.array_equal(xg[999], x0[999]) and np.all(np.isfinite(xg))
+
+
+def test_full_size_c2_odd_pass_count(pbd):
+    """5 iterations x 3 segments = 15 passes per substep (odd): the persistent launch at the 1 M size with the other
+    parity of the position double buffer, 4 steps, bit-identical to the reference."""
+    S = pbd.Solver
+    ops = util.cloth_spec(1000, 1000, 4, 3)
+    want = _reference_states(ops, 5, [4])
+    m, ts = util.mine_run(ops, 4, 1, 5, resident=True, options={S.OPT_PERSISTENT: 2})
+    info, pinfo = ts.solver().plan_info(), ts.solver().persistent_info()
+    print("C2 full size, 5 iterations:", info, pinfo)
+    assert pinfo["active"] == 1 and pinfo["refusals"] == 0 and pinfo["timeouts"] == 0
+    assert (5 * info["num_segments"]) % 2 == 1 or pinfo["last_folded"] == 1
+    assert util.bitwise_equal(m.getParticles().positions(), want[4][0])
+    assert util.bitwise_equal(m.getParticles().array(2), want[4][1])
 
 
 @pytest.mark.parametrize("method,iters,sub", [(2, 10, 1), (6, 10, 1), (4, 10, 1)])
@@ -368,12 +441,15 @@ def test_full_size_c3_100k_tet_bar_vs_reference(pbd, method, iters, sub):
 
 
 def test_c4_ensemble_block_of_instances_vs_reference(pbd):
-    """configs[3] in one GPU's share, reduced: 8 independent 200x200 sheets in one model (the per-GPU
-    block of the 512-instance ensemble is 64 of them) against the reference on the same model."""
-    ops = util.cloth_spec(200, 200, 4, 3, instances=8, instance_offset=(0.0, 0.0, 12.0))
-    xr = util.oracle_positions(ops, 2, 1, 10, "f32", threads=8).astype(np.float32)
+    """configs[3], one GPU's FULL share: 64 independent 200x200 sheets in one model (2 560 000 particles, 15 206 784
+    constraints) against the reference on the same model, 2 steps x 10 iterations, bit-identical."""
+    ops = util.cloth_spec(200, 200, 4, 3, instances=64, instance_offset=(0.0, 0.0, 12.0))
+    want = _reference_states(ops, 10, [2], threads=32)
     m, ts = util.mine_run(ops, 2, 1, 10, resident=True)
-    assert util.bitwise_equal(m.getParticles().positions(), xr)
+    print("C4 block plan:", ts.solver().plan_info(), ts.solver().persistent_info())
+    assert m.getParticles().size() == 64 * 40000
+    assert util.bitwise_equal(m.getParticles().positions(), want[2][0])
+    assert util.bitwise_equal(m.getParticles().array(2), want[2][1])
 
 
 # ---------------------------------------------------------------------------
@@ -601,3 +677,88 @@ def test_persistent_schedule_auto_mode_reports_its_measurement(pbd):
     info = ts.solver().persistent_info()
     assert info["eligible"] == 1 and info["autotune_fused_ms"] > 0 and info["autotune_persistent_ms"] > 0
     assert info["active"] == (1 if info["autotune_persistent_ms"] < 1.02 * info["autotune_fused_ms"] else 0)
+
+
+def test_parameter_edit_between_resident_steps_keeps_the_device_state(pbd):
+    """after stepResident the device is ahead of the host mirror; a constraint-parameter edit, a setMass or a
+    write of ONE host array must not roll the simulation back to the stale mirror.  Ground truth: host-authoritative stepping."""
+    ops = util.cloth_spec(36, 36, 4, 3)
+
+    def fresh():
+        m = util.build_mine(ops)
+        pbd.TimeManager.setCurrent(pbd.TimeManager())
+        ts = pbd.TimeStepController()
+        ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+        ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 5)
+        return m, ts
+
+    def edit(m, what):
+        if what == "params":
+            for c in range(0, 200, 7):
+                p = m.constraintParams(c)
+                p[1] = p[1] * np.float32(0.25)          # stiffness of XPBD distance constraints
+                m.setConstraintParams(c, p)
+        elif what == "mass":
+            m.getParticles().setMass(500, 0.0)
+        else:
+            v = np.zeros((m.getParticles().size(), 3), dtype=np.float32)
+            v[300:320, 1] = np.float32(0.5)
+            m.getParticles().set_array(2, v)            # velocities replaced, nothing else: positions / oldX / lastX stay the device's
+
+    for what in ("params", "mass", "velocity"):
+        m0, t0 = fresh()
+        for _ in range(3):
+            t0.step(m0)
+        edit(m0, what)
+        for _ in range(3):
+            t0.step(m0)
+        want_x, want_v = m0.getParticles().positions(), m0.getParticles().array(2)
+        m, ts = fresh()
+        ts.stepResident(m, 3)                 # no syncToHost: the host mirror still holds the initial state
+        edit(m, what)
+        ts.stepResident(m, 3)
+        ts.syncToHost(m)
+        assert util.bitwise_equal(m.getParticles().positions(), want_x), what
+        assert util.bitwise_equal(m.getParticles().array(2), want_v), what
+
+
+def test_persistent_schedule_recovers_from_a_timed_out_tile(pbd):
+    """a tile that gives up waiting for a neighbour used to leave garbage in a device-resident state.  Self-test
+    (PBDX_OPT_PERSISTENT = 4: tile 0 never publishes its first pass; 5 ms bound): the engine restores the state it saved at
+    the start of the call, repeats the call with one launch per segment and reports it -- the result is bit-identical."""
+    S = pbd.Solver
+    ops = util.cloth_spec(90, 90, 4, 3)
+    ref, _ = util.mine_run(ops, 4, 2, 6, options={S.OPT_FUSE: 1, S.OPT_PERSISTENT: 0})
+    xr, vr = ref.getParticles().positions(), ref.getParticles().array(2)
+    for resident in (False, True):
+        m, ts = util.mine_run(ops, 4, 2, 6, resident=resident, options={S.OPT_FUSE: 1, S.OPT_PERSISTENT: 4, S.OPT_PERSISTENT_TIMEOUT_MS: 5})
+        info = ts.solver().persistent_info()
+        assert info["timeouts"] == 1 and info["active"] == 0 and info["eligible"] == 0, info
+        assert util.bitwise_equal(m.getParticles().positions(), xr), resident
+        assert util.bitwise_equal(m.getParticles().array(2), vr), resident
+        for which in (4, 5):
+            assert util.bitwise_equal(m.getParticles().array(which), ref.getParticles().array(which)), which
+
+
+def test_more_contacts_per_particle_than_the_engine_keeps_is_an_error(pbd):
+    """the reference has no per-particle contact limit; the engine keeps 8.  Exceeding it must fail the step
+    loudly (PBDX_ERR_UNSUPPORTED from pbdx_solver_step), not skip the particle's contact response silently."""
+    ops = util.cloth_spec(8, 8, 4, 3, pin=False)
+    m = util.build_mine(ops)
+    pbd.TimeManager.setCurrent(pbd.TimeManager())
+    ts = pbd.TimeStepController()
+    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 2)
+    sol = ts.solver()
+    eye = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    floor = dict(shape="box", params=[50.0, 0.5, 50.0], com=[0, 0.49, 0], R=eye, v1=[0, 0, 0], v2=[0, 0.49, 0], restitution=0.6, friction=0.2)
+    ts.stepResident(m, 1)                      # uploads the particles (collision ranges are checked against them)
+    sol.set_collision_ranges([(0, m.getParticles().size(), 0.6, 0.1)])
+    sol.set_contact_params(0.05, 100.0, 5)
+    sol.set_colliders([floor] * 8)
+    ts.stepResident(m, 1)                      # 8 simultaneous contacts per particle: fine
+    assert sol.num_contacts() == 8 * 64
+    sol.set_colliders([floor] * 9)
+    with pytest.raises(pbd.PbdxError) as e:
+        ts.stepResident(m, 1)
+    assert e.value.code == 4 and "simultaneous contacts" in str(e.value)

@@ -11,223 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-GRAVITY = (0.0, -9.81, 0.0)
+from positionbaseddynamics_amd.scenes import (GRAVITY, rot_x_half_pi, cloth_spec, bar_spec, delaunay_cloth_spec,  # noqa: E402,F401
+                                              delaunay_solid_spec, config5_like_spec, kitchen_sink_spec, build_model)
+from oracle.scene_ref import apply_ref  # noqa: E402,F401
 
-
-def rot_x_half_pi():
-    """AngleAxisr(M_PI*0.5, (1,0,0)).matrix() in a float build (Demos/ClothDemo/main.cpp:136):
-    cos(float(pi/2)) = -4.371139e-08, sin = 1."""
-    a = np.float32(np.pi * 0.5)
-    c = np.float32(np.cos(a))
-    s = np.float32(np.sin(a))
-    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float32)
-
-
-def cloth_spec(n_cols, n_rows, cloth_method, bending_method, cloth_k=None, bending_k=None,
-               width=10.0, height=10.0, T=(0, 1, 0), pin=True, instances=1, instance_offset=(0, 0, 0)):
-    """Demos/ClothDemo/main.cpp:132-162 generalised to n_cols x n_rows and K instances."""
-    if cloth_k is None:
-        cloth_k = 100000.0 if cloth_method == 4 else 1.0
-    if bending_k is None:
-        bending_k = 100.0 if bending_method == 3 else 0.01
-    ops = []
-    R = rot_x_half_pi()
-    for k in range(instances):
-        off = k * n_cols * n_rows
-        Tk = tuple(np.float32(T[i]) + np.float32(k) * np.float32(instance_offset[i]) for i in range(3))
-        ops.append(("tri", n_cols, n_rows, Tk, R, (width, height)))
-        if pin:
-            ops.append(("mass", off, 0.0))
-            ops.append(("mass", off + n_rows - 1, 0.0))
-        if cloth_method:
-            ops.append(("cloth", k, cloth_method, cloth_k, 1.0, 1.0, 1.0, 0.3, 0.3, False, False))
-        if bending_method:
-            ops.append(("bending", k, bending_method, bending_k))
-    return ops
-
-
-def bar_spec(width, height, depth, solid_method, k=None, kv=None, poisson=0.3, T=(5, 0, 0),
-             scale=(10.0, 1.5, 1.5), ns=False, nsh=False, instances=1, instance_offset=(0.0, 0.0, 3.0)):
-    """Demos/BarDemo/main.cpp:130-166 generalised (and K independent bars for ensemble runs)."""
-    if k is None:
-        k = {3: 1000000.0, 6: 100000.0}.get(solid_method, 1.0)
-    if kv is None:
-        kv = 100000.0 if solid_method == 6 else 1.0
-    ops = []
-    n_per = width * height * depth
-    for inst in range(instances):
-        Tk = tuple(np.float32(T[i]) + np.float32(inst) * np.float32(instance_offset[i]) for i in range(3)) if instances > 1 else T
-        ops.append(("tet", width, height, depth, Tk, None, scale))
-        for j in range(height):
-            for q in range(depth):
-                ops.append(("mass", inst * n_per + j * depth + q, 0.0))
-        ops.append(("solid", inst, solid_method, k, poisson, kv, ns, nsh))
-    return ops
-
-
-def delaunay_cloth_spec(n_points=900, seed=3, cloth_method=4, bending_method=3):
-    """An IRREGULAR triangle mesh (2-D Delaunay triangulation of random points, lifted to a wavy sheet):
-    vertex valences 3..12, no grid structure, boundary edges.  Deterministic."""
-    from scipy.spatial import Delaunay
-    rng = np.random.default_rng(seed)
-    uv = rng.random((n_points, 2)) * 8.0
-    tri = Delaunay(uv)
-    pts = np.stack([uv[:, 0], 0.3 * np.sin(uv[:, 0]) * np.cos(uv[:, 1]) + 1.0, uv[:, 1]], axis=1).astype(np.float32)
-    faces = tri.simplices.astype(np.uint32)
-    ops = [("trimesh", pts, faces), ("mass", 0, 0.0), ("mass", 1, 0.0)]
-    ops.append(("cloth", 0, cloth_method, 100000.0 if cloth_method == 4 else 1.0, 1.0, 1.0, 1.0, 0.3, 0.3, False, False))
-    if bending_method:
-        ops.append(("bending", 0, bending_method, 100.0 if bending_method == 3 else 0.01))
-    return ops
-
-
-def delaunay_solid_spec(n_points=400, seed=5, solid_method=2):
-    """An irregular tetrahedral mesh (3-D Delaunay of random points in a box), slivers removed."""
-    from scipy.spatial import Delaunay
-    rng = np.random.default_rng(seed)
-    pts = (rng.random((n_points, 3)) * np.array([4.0, 1.5, 1.5])).astype(np.float32)
-    tets = Delaunay(pts.astype(np.float64)).simplices
-    p = pts.astype(np.float64)
-    vol = np.abs(np.einsum("ij,ij->i", p[tets[:, 3]] - p[tets[:, 0]], np.cross(p[tets[:, 2]] - p[tets[:, 0]], p[tets[:, 1]] - p[tets[:, 0]]))) / 6.0
-    tets = tets[vol > 1e-3].astype(np.uint32)
-    k = {3: 1000000.0, 6: 100000.0}.get(solid_method, 1.0)
-    ops = [("tetmesh", pts, tets)]
-    for i in np.nonzero(pts[:, 0] < 0.3)[0]:
-        ops.append(("mass", int(i), 0.0))
-    ops.append(("solid", 0, solid_method, k, 0.3, 100000.0 if solid_method == 6 else 1.0, False, False))
-    return ops
-
-
-def config5_like_spec(n_points=220):
-    """BASELINE configs[4] (data/scenes/ArmadilloCollisionScene.json) in the form this container can pin:
-    three irregular tet solids (FEM tets, method 2, Poisson 0.2) stacked above a static floor.  The armadillo
-    surface / its Discregrid SDF (tet-tet contacts) are not in the tree, so the solids only collide with the
-    floor; they are submitted as ONE tet model with three components (a second tet collision object would make
-    the reference traverse tet-tet pairs, which need that SDF)."""
-    from scipy.spatial import Delaunay
-    all_pts, all_tets = [], []
-    offset = 0
-    for k, (ty, seed) in enumerate(((1.6, 11), (3.4, 12), (5.2, 13))):
-        rng = np.random.default_rng(seed)
-        pts = (rng.random((n_points, 3)) * np.array([1.6, 1.2, 1.4]) + np.array([-0.8 + 0.3 * k, ty, -0.7])).astype(np.float32)
-        tets = Delaunay(pts.astype(np.float64)).simplices
-        p = pts.astype(np.float64)
-        vol = np.abs(np.einsum("ij,ij->i", p[tets[:, 3]] - p[tets[:, 0]], np.cross(p[tets[:, 2]] - p[tets[:, 0]], p[tets[:, 1]] - p[tets[:, 0]]))) / 6.0
-        all_pts.append(pts)
-        all_tets.append(tets[vol > 2e-4].astype(np.uint32) + np.uint32(offset))
-        offset += n_points
-    return [("tetmesh", np.concatenate(all_pts), np.concatenate(all_tets)), ("solid", 0, 2, 1.0, 0.2, 1.0, False, False)]
-
-
-def kitchen_sink_spec():
-    """One model with EVERY particle constraint type, so that colour groups mix types (a colour becomes
-    several (colour, type) batches / tile steps): a cloth with FEM-triangle + distance + dihedral + PBD
-    isometric bending, a second cloth with strain-triangle + XPBD distance + XPBD bending, a tet bar with
-    FEM + volume + distance, a second bar with XPBD FEM + XPBD volume + strain + shape matching, plus
-    extra XPBD distance constraints stitching the two cloths together."""
-    ops = []
-    R = rot_x_half_pi()
-    ops.append(("tri", 14, 12, (0.0, 2.0, 0.0), R, (4.0, 3.0)))
-    ops.append(("tri", 10, 11, (0.5, 2.6, 0.2), R, (3.0, 3.0)))
-    ops.append(("tet", 7, 4, 3, (5.0, 0.0, 0.0), None, (3.0, 1.0, 0.8)))
-    ops.append(("tet", 5, 3, 3, (5.0, 2.0, 0.0), None, (2.0, 0.8, 0.8)))
-    n0, n1 = 14 * 12, 10 * 11
-    ops += [("mass", 0, 0.0), ("mass", 13, 0.0), ("mass", n0, 0.0)]
-    for j in range(4 * 3):
-        ops.append(("mass", n0 + n1 + j, 0.0))
-    ops.append(("cloth", 0, 2, 1.0, 1.0, 1.0, 1.0, 0.3, 0.3, False, False))      # FEM triangle
-    ops.append(("cloth", 0, 1, 0.8, 1.0, 1.0, 1.0, 0.3, 0.3, False, False))      # distance
-    ops.append(("bending", 0, 1, 0.02))                                          # dihedral
-    ops.append(("bending", 0, 2, 0.01))                                          # isometric bending
-    ops.append(("cloth", 1, 3, 1.0, 1.0, 1.0, 1.0, 0.3, 0.3, True, False))       # strain triangle
-    ops.append(("cloth", 1, 4, 50000.0, 1.0, 1.0, 1.0, 0.3, 0.3, False, False))  # XPBD distance
-    ops.append(("bending", 1, 3, 50.0))                                          # XPBD isometric bending
-    ops.append(("solid", 0, 2, 1.0, 0.3, 1.0, False, False))                     # FEM tet
-    ops.append(("solid", 0, 1, 0.9, 0.3, 0.7, False, False))                     # distance + volume
-    ops.append(("solid", 1, 3, 100000.0, 0.3, 1.0, False, False))                # XPBD FEM tet
-    ops.append(("solid", 1, 6, 50000.0, 0.3, 50000.0, False, False))             # XPBD distance + volume
-    ops.append(("solid", 1, 4, 1.0, 0.3, 1.0, False, True))                      # strain tet
-    ops.append(("solid", 1, 5, 0.5, 0.3, 1.0, False, False))                     # shape matching
-    for k in range(8):
-        ops.append(("constraint", "distance_xpbd", [20 + 14 * (k % 3) + k, n0 + 10 * (k % 4) + k], 2000.0))
-    return ops
-
-
-_CONSTRAINT_ADD = {
-    "distance": "addDistanceConstraint", "distance_xpbd": "addDistanceConstraint_XPBD",
-    "dihedral": "addDihedralConstraint", "isometric_bending": "addIsometricBendingConstraint",
-    "isometric_bending_xpbd": "addIsometricBendingConstraint_XPBD", "fem_triangle": "addFEMTriangleConstraint",
-    "strain_triangle": "addStrainTriangleConstraint", "volume": "addVolumeConstraint",
-    "volume_xpbd": "addVolumeConstraint_XPBD", "fem_tet": "addFEMTetConstraint", "fem_tet_xpbd": "addFEMTetConstraint_XPBD",
-    "strain_tet": "addStrainTetConstraint",
-}
-
-
-def apply_ref(ref, ops):
-    """Apply a scene to an oracle.refdrv.Ref / oracle port object (same builder API)."""
-    ref.reset_all()
-    for op in ops:
-        k = op[0]
-        if k == "tri":
-            ref.add_regular_triangle_model(op[1], op[2], op[3], op[4], op[5])
-        elif k == "tet":
-            ref.add_regular_tet_model(op[1], op[2], op[3], op[4], op[5], op[6])
-        elif k == "trimesh":
-            ref.add_triangle_model(op[1], op[2])
-        elif k == "tetmesh":
-            ref.add_tet_model(op[1], op[2])
-        elif k == "vertex":
-            ref.add_vertex(op[1])
-        elif k == "mass":
-            ref.set_mass(op[1], op[2])
-        elif k == "cloth":
-            ref.add_cloth_constraints(*op[1:])
-        elif k == "bending":
-            ref.add_bending_constraints(*op[1:])
-        elif k == "solid":
-            ref.add_solid_constraints(*op[1:])
-        elif k == "constraint":
-            ok = ref.add_constraint(op[1], op[2], *op[3:])
-            assert ok, "oracle rejected constraint %r" % (op,)
-        else:
-            raise ValueError(k)
-    return ref
-
-
-def build_mine(ops):
-    """Build the same scene with the product's SimulationModel mirror."""
-    import positionbaseddynamics_amd as pbd
-    m = pbd.SimulationModel()
-    for op in ops:
-        k = op[0]
-        if k == "tri":
-            m.addRegularTriangleModel(op[1], op[2], op[3], op[4], op[5])
-        elif k == "tet":
-            m.addRegularTetModel(op[1], op[2], op[3], op[4], op[5], op[6])
-        elif k == "trimesh":
-            m.addTriangleModel(op[1], op[2])
-        elif k == "tetmesh":
-            m.addTetModel(op[1], op[2])
-        elif k == "vertex":
-            m.getParticles().addVertex(op[1])
-        elif k == "mass":
-            m.getParticles().setMass(op[1], op[2])
-        elif k == "cloth":
-            m.addClothConstraints(*op[1:])
-        elif k == "bending":
-            m.addBendingConstraints(*op[1:])
-        elif k == "solid":
-            m.addSolidConstraints(*op[1:])
-        elif k == "constraint":
-            if op[1] == "shape_matching":
-                ok = m.addShapeMatchingConstraint(len(op[2]), op[2], op[3], op[4])
-            else:
-                ok = getattr(m, _CONSTRAINT_ADD[op[1]])(*[int(b) for b in op[2]], *op[3:])
-            assert ok, "model rejected constraint %r" % (op,)
-        else:
-            raise ValueError(k)
-    return m
-
+build_mine = build_model
 
 def get_oracle(variant="f32"):
     """The strongest oracle available: the reference itself (oracle/_ref) if its library was
