@@ -118,6 +118,13 @@ void pbdx_solver_destroy(pbdx_solver *s);
 int pbdx_solver_set_particles(pbdx_solver *s, uint32_t n,
 	const float *x, const float *v, const float *old_x, const float *last_x,
 	const float *mass, const float *inv_mass);
+/* The same for a host whose Real is double (the reference's default build, Common/Common.h:10-28): the arrays are copied
+ * as they are and converted to the device's fp32 by one kernel (one rounding per value, like a (float) cast on the host). */
+int pbdx_solver_set_particles_f64(pbdx_solver *s, uint32_t n,
+	const double *x, const double *v, const double *old_x, const double *last_x,
+	const double *mass, const double *inv_mass);
+int pbdx_solver_get_particles_f64(pbdx_solver *s, uint32_t n,
+	double *x, double *v, double *old_x, double *last_x);
 /* Overwrite positions only (n must match); used for teacher-forced parity. */
 int pbdx_solver_set_positions(pbdx_solver *s, uint32_t n, const float *x);
 
@@ -137,6 +144,13 @@ int pbdx_solver_begin_schedule(pbdx_solver *s);
 int pbdx_solver_add_batch(pbdx_solver *s, uint32_t group, int type, uint32_t count,
 	const uint32_t *indices, const float *params, uint32_t param_stride);
 int pbdx_solver_end_schedule(pbdx_solver *s);
+/* Run-time parameter edits (the reference's setClothStiffness / m_stiffness / m_restLength edits between steps,
+ * SimulationModel.h setConstraintValue<>): replace the parameter records of batch `batch_index` (order of add_batch calls;
+ * same count and stride) and commit.  The committed schedule keeps its colouring, tiles and launch plan -- only the
+ * parameter streams and scalar kernel arguments are refreshed (no replanning, no re-measurement) unless the edit changes
+ * whether a type's shared parameters are uniform (then the plan is rebuilt by the next step). */
+int pbdx_solver_update_batch_params(pbdx_solver *s, uint32_t batch_index, uint32_t count, const float *params, uint32_t param_stride);
+int pbdx_solver_commit_params(pbdx_solver *s);
 /* Debug validator: every group's batches touch pairwise-disjoint particles
  * (the invariant data-race freedom rests on).  Returns PBDX_OK or PBDX_ERR_INVALID. */
 int pbdx_solver_validate_schedule(pbdx_solver *s);

@@ -536,6 +536,24 @@ void refdrv_set_max_iterations_v(unsigned n) { model(); tsc()->setValue<unsigned
 
 // The currently installed TimeStep object (opaque; for plug-in side counters).
 void *refdrv_get_timestep() { model(); return (void*)Simulation::getCurrent()->getTimeStep(); }
+void *refdrv_get_model() { return (void*)model(); }
+// the run-time parameter edits a demo GUI makes between steps (SimulationModel::setClothStiffness / setClothBendingStiffness,
+// SimulationModel.cpp -> setConstraintValue<>): every constraint of the scene keeps its topology, only m_stiffness changes
+void refdrv_set_cloth_stiffness(double k) { model()->setClothStiffness((Real)k); }
+void refdrv_set_cloth_bending_stiffness(double k) { model()->setClothBendingStiffness((Real)k); }
+// edit of ONE constraint's stiffness behind the model's back (python: constraint.stiffness = ...)
+void refdrv_set_constraint_stiffness(unsigned ci, double k)
+{
+	Constraint *c = model()->getConstraints()[ci];
+	switch (mapType(c))
+	{
+	case 0: ((DistanceConstraint*)c)->m_stiffness = (Real)k; break;
+	case 1: ((DistanceConstraint_XPBD*)c)->m_stiffness = (Real)k; break;
+	case 3: ((IsometricBendingConstraint*)c)->m_stiffness = (Real)k; break;
+	case 4: ((IsometricBendingConstraint_XPBD*)c)->m_stiffness = (Real)k; break;
+	default: break;
+	}
+}
 
 // Install a TimeStep plug-in from a shared library: the library must export
 //   extern "C" PBD::TimeStep *<symbol>();

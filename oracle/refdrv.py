@@ -301,6 +301,26 @@ class Ref:
             self.lib.refdrv_get_particle_rigid_body_contact(i, _dp(out[i]))
         return out
 
+    def set_cloth_stiffness(self, k):
+        self.lib.refdrv_set_cloth_stiffness.argtypes = [_d]
+        self.lib.refdrv_set_cloth_stiffness(float(k))
+
+    def set_cloth_bending_stiffness(self, k):
+        self.lib.refdrv_set_cloth_bending_stiffness.argtypes = [_d]
+        self.lib.refdrv_set_cloth_bending_stiffness(float(k))
+
+    def set_constraint_stiffness(self, c, k):
+        self.lib.refdrv_set_constraint_stiffness.argtypes = [_u, _d]
+        self.lib.refdrv_set_constraint_stiffness(int(c), float(k))
+
+    def model_ptr(self):
+        self.lib.refdrv_get_model.restype = C.c_void_p
+        return C.c_void_p(self.lib.refdrv_get_model())
+
+    def timestep_ptr(self):
+        self.lib.refdrv_get_timestep.restype = C.c_void_p
+        return C.c_void_p(self.lib.refdrv_get_timestep())
+
     def install_timestep_plugin(self, path, symbol="pbdx_create_timestep_hip"):
         return self.lib.refdrv_install_timestep_plugin(path.encode(), symbol.encode())
 

@@ -24,6 +24,7 @@ f32 = C.c_float
 vp = C.c_void_p
 pf = C.POINTER(C.c_float)
 pu = C.POINTER(C.c_uint32)
+pd_ = C.POINTER(C.c_double)
 
 
 class StepStats(C.Structure):
@@ -75,6 +76,9 @@ SIGNATURES = [
     ("pbdx_last_error", C.c_char_p), ("pbdx_version", C.c_int), ("pbdx_device_count", C.c_int),
     ("pbdx_solver_create", C.c_int, C.POINTER(vp), C.c_int), ("pbdx_solver_destroy", None, vp),
     ("pbdx_solver_set_particles", C.c_int, vp, u32, pf, pf, pf, pf, pf, pf),
+    ("pbdx_solver_set_particles_f64", C.c_int, vp, u32, pd_, pd_, pd_, pd_, pd_, pd_),
+    ("pbdx_solver_get_particles_f64", C.c_int, vp, u32, pd_, pd_, pd_, pd_),
+    ("pbdx_solver_update_batch_params", C.c_int, vp, u32, u32, pf, u32), ("pbdx_solver_commit_params", C.c_int, vp),
     ("pbdx_solver_set_positions", C.c_int, vp, u32, pf),
     ("pbdx_solver_get_particles", C.c_int, vp, u32, pf, pf, pf, pf),
     ("pbdx_solver_begin_schedule", C.c_int, vp),

@@ -741,24 +741,29 @@ __global__ __launch_bounds__(256) void velocity_kernel(const float4 *__restrict_
 
 // ---- host boundary: packed xyz (std::vector<Vector3r> of a float build, ParticleData.h:91-100) <-> float4
 // `src`/`dst` are device staging copies of the caller's arrays; w = inv_mass / mass / 0
-__global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ xyz, const float *__restrict__ w, float4 *__restrict__ dst, uint32_t n)
+// (T = float: a float build of the reference; T = double: the default build -- the conversion to the device's fp32 happens
+// here, on the device, as one rounding per value exactly like a host-side (float) cast)
+template <class T>
+__global__ __launch_bounds__(256) void pack_kernel(const T *__restrict__ xyz, const T *__restrict__ w, float4 *__restrict__ dst, uint32_t n)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	dst[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], w ? w[i] : 0.0f);
+	dst[i] = make_float4((float)xyz[3 * (size_t)i], (float)xyz[3 * (size_t)i + 1], (float)xyz[3 * (size_t)i + 2], w ? (float)w[i] : 0.0f);
 }
-__global__ __launch_bounds__(256) void pack_zero_kernel(const float *__restrict__ w, float4 *__restrict__ dst, uint32_t n)
+template <class T>
+__global__ __launch_bounds__(256) void pack_zero_kernel(const T *__restrict__ w, float4 *__restrict__ dst, uint32_t n)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	dst[i] = make_float4(0.0f, 0.0f, 0.0f, w[i]);
+	dst[i] = make_float4(0.0f, 0.0f, 0.0f, (float)w[i]);
 }
-__global__ __launch_bounds__(256) void unpack_kernel(const float4 *__restrict__ src, float *__restrict__ xyz, uint32_t n)
+template <class T>
+__global__ __launch_bounds__(256) void unpack_kernel(const float4 *__restrict__ src, T *__restrict__ xyz, uint32_t n)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const float4 v = src[i];
-	xyz[3 * (size_t)i] = v.x; xyz[3 * (size_t)i + 1] = v.y; xyz[3 * (size_t)i + 2] = v.z;
+	xyz[3 * (size_t)i] = (T)v.x; xyz[3 * (size_t)i + 1] = (T)v.y; xyz[3 * (size_t)i + 2] = (T)v.z;
 }
 __global__ __launch_bounds__(256) void set_xyz_kernel(const float *__restrict__ xyz, float4 *__restrict__ dst, uint32_t n)
 {
@@ -875,12 +880,14 @@ struct pbdx_solver
 	uint32_t n = 0;
 	float4 *d_pos[2] = { nullptr, nullptr };
 	float4 *d_vel = nullptr, *d_old = nullptr, *d_last = nullptr;
-	float *d_stage = nullptr;            // 4 x 3n + 2n floats: device staging of the caller's packed arrays
+	float *d_stage = nullptr;            // 4 x 3n + 2n values: device staging of the caller's packed arrays (floats; doubles once a double host called)
+	size_t stage_elem = sizeof(float);
 	std::vector<float> h_x;              // positions at upload time (tile partition only)
 	std::vector<Batch> batches;          // in add order
 	std::vector<uint32_t> order;         // batch indices sorted by (group, seq)
 	bool schedule_open = false;
 	uint64_t schedule_version = 0;
+	bool params_dirty = false;           // pbdx_solver_update_batch_params since the last commit
 
 	// options
 	int use_graph = 1;
@@ -1651,6 +1658,93 @@ int collect_profile(pbdx_solver *s, ProfCursor *pc)
 	return PBDX_OK;
 }
 
+// the staging buffer holds the caller's packed arrays in the caller's scalar type
+int ensure_stage(pbdx_solver *s, size_t elem)
+{
+	if (elem <= s->stage_elem || !s->n) return PBDX_OK;
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	if (s->d_stage) { (void)hipFree(s->d_stage); s->d_stage = nullptr; }
+	HIPCHECK(hipMalloc(&s->d_stage, (size_t)s->n * 14 * elem));
+	s->stage_elem = elem;
+	return PBDX_OK;
+}
+
+template <class T>
+int set_particles_impl(pbdx_solver *s, uint32_t n, const T *x, const T *v, const T *old_x, const T *last_x, const T *mass, const T *inv_mass)
+{
+	if (!s || !x || !mass || !inv_mass) { set_error("set_particles: x, mass and inv_mass are required"); return PBDX_ERR_INVALID; }
+	HIPCHECK(hipSetDevice(s->device));
+	if (n != s->n)
+	{
+		HIPCHECK(hipStreamSynchronize(s->stream));
+		s->free_particles();
+		s->drop_graph();
+		s->free_batches();         // a schedule refers to particle indices of the old image: it must be re-added
+		s->schedule_version++;
+		if (n)
+		{
+			HIPCHECK(hipMalloc(&s->d_pos[0], (size_t)n * sizeof(float4)));
+			HIPCHECK(hipMalloc(&s->d_pos[1], (size_t)n * sizeof(float4)));
+			HIPCHECK(hipMalloc(&s->d_vel, (size_t)n * sizeof(float4)));
+			HIPCHECK(hipMalloc(&s->d_old, (size_t)n * sizeof(float4)));
+			HIPCHECK(hipMalloc(&s->d_last, (size_t)n * sizeof(float4)));
+			HIPCHECK(hipMalloc(&s->d_stage, (size_t)n * 14 * sizeof(float)));
+		}
+		s->n = n;
+	}
+	if (!n) return PBDX_OK;
+	if (!s->plan_ok)     // tile partition input (first upload wins)
+	{
+		s->h_x.resize((size_t)3 * n);
+		for (size_t i = 0; i < (size_t)3 * n; i++) s->h_x[i] = (float)x[i];
+	}
+	// raw packed arrays -> device staging (stream ordered), repacked into float4 on the device
+	T *st_x = reinterpret_cast<T *>(s->d_stage), *st_v = st_x + (size_t)3 * n, *st_o = st_v + (size_t)3 * n, *st_l = st_o + (size_t)3 * n;
+	T *st_m = st_l + (size_t)3 * n, *st_w = st_m + n;
+	const size_t b3 = (size_t)3 * n * sizeof(T), b1 = (size_t)n * sizeof(T);
+	s->pin(x, b3); s->pin(v, b3); s->pin(old_x, b3); s->pin(last_x, b3); s->pin(mass, b1); s->pin(inv_mass, b1);
+	HIPCHECK(hipMemcpyAsync(st_x, x, b3, hipMemcpyHostToDevice, s->stream));
+	if (v) HIPCHECK(hipMemcpyAsync(st_v, v, b3, hipMemcpyHostToDevice, s->stream));
+	if (old_x) HIPCHECK(hipMemcpyAsync(st_o, old_x, b3, hipMemcpyHostToDevice, s->stream));
+	if (last_x) HIPCHECK(hipMemcpyAsync(st_l, last_x, b3, hipMemcpyHostToDevice, s->stream));
+	HIPCHECK(hipMemcpyAsync(st_m, mass, b1, hipMemcpyHostToDevice, s->stream));
+	HIPCHECK(hipMemcpyAsync(st_w, inv_mass, b1, hipMemcpyHostToDevice, s->stream));
+	const dim3 grid((n + 255) / 256), block(256);
+	hipLaunchKernelGGL(pack_kernel<T>, grid, block, 0, s->stream, (const T *)st_x, (const T *)st_w, s->d_pos[0], n);
+	if (v) hipLaunchKernelGGL(pack_kernel<T>, grid, block, 0, s->stream, (const T *)st_v, (const T *)st_m, s->d_vel, n);
+	else hipLaunchKernelGGL(pack_zero_kernel<T>, grid, block, 0, s->stream, (const T *)st_m, s->d_vel, n);
+	hipLaunchKernelGGL(pack_kernel<T>, grid, block, 0, s->stream, (const T *)(old_x ? st_o : st_x), (const T *)nullptr, s->d_old, n);
+	hipLaunchKernelGGL(pack_kernel<T>, grid, block, 0, s->stream, (const T *)(last_x ? st_l : st_x), (const T *)nullptr, s->d_last, n);
+	HIPCHECK(hipGetLastError());
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	return PBDX_OK;
+}
+
+
+template <class T>
+int get_particles_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, T *last_x)
+{
+	if (!s || n != s->n) { set_error("get_particles: particle count mismatch (%u vs %u)", n, s ? s->n : 0); return PBDX_ERR_INVALID; }
+	if (!n) return PBDX_OK;
+	HIPCHECK(hipSetDevice(s->device));
+	{ int rs = ensure_stage(s, sizeof(T)); if (rs) return rs; }
+	struct { T *dst; const float4 *src; } jobs[4] = { { x, s->d_pos[0] }, { v, s->d_vel }, { old_x, s->d_old }, { last_x, s->d_last } };
+	const size_t b3 = (size_t)3 * n * sizeof(T);
+	int k = 0;
+	for (auto &j : jobs)
+	{
+		T *st = reinterpret_cast<T *>(s->d_stage) + (size_t)3 * n * k++;
+		if (!j.dst) continue;
+		s->pin(j.dst, b3);
+		hipLaunchKernelGGL(unpack_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s->stream, j.src, st, n);
+		HIPCHECK(hipGetLastError());
+		HIPCHECK(hipMemcpyAsync(j.dst, st, b3, hipMemcpyDeviceToHost, s->stream));
+	}
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	return PBDX_OK;
+}
+
+
 } // namespace
 
 extern "C" {
@@ -1718,48 +1812,12 @@ void pbdx_solver_destroy(pbdx_solver *s)
 int pbdx_solver_set_particles(pbdx_solver *s, uint32_t n, const float *x, const float *v, const float *old_x,
 	const float *last_x, const float *mass, const float *inv_mass)
 {
-	if (!s || !x || !mass || !inv_mass) { set_error("set_particles: x, mass and inv_mass are required"); return PBDX_ERR_INVALID; }
-	HIPCHECK(hipSetDevice(s->device));
-	if (n != s->n)
-	{
-		HIPCHECK(hipStreamSynchronize(s->stream));
-		s->free_particles();
-		s->drop_graph();
-		s->free_batches();         // a schedule refers to particle indices of the old image: it must be re-added
-		s->schedule_version++;
-		if (n)
-		{
-			HIPCHECK(hipMalloc(&s->d_pos[0], (size_t)n * sizeof(float4)));
-			HIPCHECK(hipMalloc(&s->d_pos[1], (size_t)n * sizeof(float4)));
-			HIPCHECK(hipMalloc(&s->d_vel, (size_t)n * sizeof(float4)));
-			HIPCHECK(hipMalloc(&s->d_old, (size_t)n * sizeof(float4)));
-			HIPCHECK(hipMalloc(&s->d_last, (size_t)n * sizeof(float4)));
-			HIPCHECK(hipMalloc(&s->d_stage, (size_t)n * 14 * sizeof(float)));
-		}
-		s->n = n;
-	}
-	if (!n) return PBDX_OK;
-	if (!s->plan_ok) s->h_x.assign(x, x + (size_t)3 * n);     // tile partition input (first upload wins)
-	// raw packed arrays -> device staging (stream ordered), repacked into float4 on the device
-	float *st_x = s->d_stage, *st_v = st_x + (size_t)3 * n, *st_o = st_v + (size_t)3 * n, *st_l = st_o + (size_t)3 * n;
-	float *st_m = st_l + (size_t)3 * n, *st_w = st_m + n;
-	const size_t b3 = (size_t)3 * n * sizeof(float), b1 = (size_t)n * sizeof(float);
-	s->pin(x, b3); s->pin(v, b3); s->pin(old_x, b3); s->pin(last_x, b3); s->pin(mass, b1); s->pin(inv_mass, b1);
-	HIPCHECK(hipMemcpyAsync(st_x, x, b3, hipMemcpyHostToDevice, s->stream));
-	if (v) HIPCHECK(hipMemcpyAsync(st_v, v, b3, hipMemcpyHostToDevice, s->stream));
-	if (old_x) HIPCHECK(hipMemcpyAsync(st_o, old_x, b3, hipMemcpyHostToDevice, s->stream));
-	if (last_x) HIPCHECK(hipMemcpyAsync(st_l, last_x, b3, hipMemcpyHostToDevice, s->stream));
-	HIPCHECK(hipMemcpyAsync(st_m, mass, b1, hipMemcpyHostToDevice, s->stream));
-	HIPCHECK(hipMemcpyAsync(st_w, inv_mass, b1, hipMemcpyHostToDevice, s->stream));
-	const dim3 grid((n + 255) / 256), block(256);
-	hipLaunchKernelGGL(pack_kernel, grid, block, 0, s->stream, st_x, st_w, s->d_pos[0], n);
-	if (v) hipLaunchKernelGGL(pack_kernel, grid, block, 0, s->stream, st_v, st_m, s->d_vel, n);
-	else hipLaunchKernelGGL(pack_zero_kernel, grid, block, 0, s->stream, st_m, s->d_vel, n);
-	hipLaunchKernelGGL(pack_kernel, grid, block, 0, s->stream, old_x ? st_o : st_x, (const float *)nullptr, s->d_old, n);
-	hipLaunchKernelGGL(pack_kernel, grid, block, 0, s->stream, last_x ? st_l : st_x, (const float *)nullptr, s->d_last, n);
-	HIPCHECK(hipGetLastError());
-	HIPCHECK(hipStreamSynchronize(s->stream));
-	return PBDX_OK;
+	return set_particles_impl<float>(s, n, x, v, old_x, last_x, mass, inv_mass);
+}
+int pbdx_solver_set_particles_f64(pbdx_solver *s, uint32_t n, const double *x, const double *v, const double *old_x,
+	const double *last_x, const double *mass, const double *inv_mass)
+{
+	return set_particles_impl<double>(s, n, x, v, old_x, last_x, mass, inv_mass);
 }
 
 int pbdx_solver_set_positions(pbdx_solver *s, uint32_t n, const float *x)
@@ -1776,23 +1834,11 @@ int pbdx_solver_set_positions(pbdx_solver *s, uint32_t n, const float *x)
 
 int pbdx_solver_get_particles(pbdx_solver *s, uint32_t n, float *x, float *v, float *old_x, float *last_x)
 {
-	if (!s || n != s->n) { set_error("get_particles: particle count mismatch (%u vs %u)", n, s ? s->n : 0); return PBDX_ERR_INVALID; }
-	if (!n) return PBDX_OK;
-	HIPCHECK(hipSetDevice(s->device));
-	struct { float *dst; const float4 *src; } jobs[4] = { { x, s->d_pos[0] }, { v, s->d_vel }, { old_x, s->d_old }, { last_x, s->d_last } };
-	const size_t b3 = (size_t)3 * n * sizeof(float);
-	int k = 0;
-	for (auto &j : jobs)
-	{
-		float *st = s->d_stage + (size_t)3 * n * k++;
-		if (!j.dst) continue;
-		s->pin(j.dst, b3);
-		hipLaunchKernelGGL(unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, j.src, st, n);
-		HIPCHECK(hipGetLastError());
-		HIPCHECK(hipMemcpyAsync(j.dst, st, b3, hipMemcpyDeviceToHost, s->stream));
-	}
-	HIPCHECK(hipStreamSynchronize(s->stream));
-	return PBDX_OK;
+	return get_particles_impl<float>(s, n, x, v, old_x, last_x);
+}
+int pbdx_solver_get_particles_f64(pbdx_solver *s, uint32_t n, double *x, double *v, double *old_x, double *last_x)
+{
+	return get_particles_impl<double>(s, n, x, v, old_x, last_x);
 }
 
 int pbdx_solver_begin_schedule(pbdx_solver *s)
@@ -1841,6 +1887,75 @@ int pbdx_solver_end_schedule(pbdx_solver *s)
 	std::stable_sort(s->order.begin(), s->order.end(), [s](uint32_t a, uint32_t b) { return s->batches[a].group < s->batches[b].group; });
 	s->schedule_open = false;
 	s->schedule_version++;
+	return PBDX_OK;
+}
+
+// ---- parameter refresh without replanning (run-time edits of stiffness / rest data in the host application) ----------
+int pbdx_solver_update_batch_params(pbdx_solver *s, uint32_t batch_index, uint32_t count, const float *params, uint32_t param_stride)
+{
+	if (!s || s->schedule_open || batch_index >= s->batches.size() || !params) { set_error("update_batch_params: bad batch / schedule open"); return PBDX_ERR_INVALID; }
+	Batch &b = s->batches[batch_index];
+	if (count != b.count || param_stride != type_info(b.type)->param_stride) { set_error("update_batch_params: count / stride do not match the batch"); return PBDX_ERR_INVALID; }
+	b.h_params.assign(params, params + (size_t)count * param_stride);
+	s->params_dirty = true;
+	return PBDX_OK;
+}
+
+int pbdx_solver_commit_params(pbdx_solver *s)
+{
+	if (!s || s->schedule_open) return PBDX_ERR_INVALID;
+	if (!s->params_dirty) return PBDX_OK;
+	HIPCHECK(hipSetDevice(s->device));
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	s->params_dirty = false;
+	s->drop_graph();                       // the scalar parameters (TypeView::u) are kernel arguments of the captured launches
+	s->schedule_version++;
+	// schedule (B): the planar parameter arrays are rebuilt from the host image the next time that schedule runs
+	for (Batch &b : s->batches)
+	{
+		compute_type_view(b.type, { { b.h_params.data(), b.count } }, b.view);
+		if (b.d_params) { (void)hipFree(b.d_params); b.d_params = nullptr; }
+		if (b.d_idx) { (void)hipFree(b.d_idx); b.d_idx = nullptr; }
+	}
+	if (!s->plan_ok) return PBDX_OK;
+	// schedule (A): same tiles, same slots; only the parameter streams and the scalar views change -- unless a type's
+	// records stopped (or started) being compactable, which changes the stream layout: then the plan is rebuilt
+	TypeView views[PBDX_NUM_CONSTRAINT_TYPES];
+	bool same_layout = true;
+	for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++)
+	{
+		std::vector<ParamSpan> spans;
+		for (uint32_t bi : s->order) if (s->batches[bi].type == t && s->batches[bi].count) spans.push_back({ s->batches[bi].h_params.data(), s->batches[bi].count });
+		compute_type_view(t, spans, views[t]);
+		if (views[t].compact != s->plan.views[t].compact) same_layout = false;
+	}
+	if (!same_layout) { s->free_plan(); return PBDX_OK; }
+	for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++) s->plan.views[t] = views[t];
+	for (size_t si = 0; si < s->plan.segs.size(); si++)
+	{
+		FusedSegment &seg = s->plan.segs[si];
+		for (const FusedStep &st : seg.steps)
+		{
+			const int type = (int)st.type;
+			const TypeInfo *ti = type_info(type);
+			const bool compact = s->plan.views[type].compact != 0;
+			const uint32_t np_stream = (uint32_t)num_planes(type, compact);
+			if (!np_stream) continue;
+			for (uint32_t q = 0; q < st.count; q++)
+			{
+				const uint32_t cid = seg.slot_cid[st.cid_off + q];
+				// execution-order batch of the constraint: the last batch_base <= cid
+				const size_t pos = (size_t)(std::upper_bound(s->plan.batch_base.begin(), s->plan.batch_base.end(), cid) - s->plan.batch_base.begin()) - 1;
+				const Batch &b = s->batches[s->order[pos]];
+				const float *rec = b.h_params.data() + (size_t)(cid - s->plan.batch_base[pos]) * ti->param_stride;
+				for (uint32_t k = 0; k < ti->param_stride; k++)
+					if (param_streams(type, compact, (int)k))
+						seg.params[st.par_off + (size_t)(q / 64) * (np_stream * 64) + (size_t)param_plane(type, compact, (int)k) * 64 + (q % 64)] = rec[k];
+			}
+		}
+		if (!seg.params.empty())
+			HIPCHECK(hipMemcpy(s->dsegs[si].d_params, seg.params.data(), seg.params.size() * sizeof(float), hipMemcpyHostToDevice));
+	}
 	return PBDX_OK;
 }
 

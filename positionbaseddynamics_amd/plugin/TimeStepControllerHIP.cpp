@@ -72,12 +72,34 @@ namespace
 		default: break;
 		}
 	}
+
+	// FNV-1a over raw bytes
+	inline uint64_t fnv(uint64_t h, const void *p, size_t n)
+	{
+		const unsigned char *b = (const unsigned char *)p;
+		for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+		return h;
+	}
+	// hash of a strided sample (at most ~4096 elements of `elem` bytes, first and last always included) of a packed array
+	inline uint64_t sampleHash(const void *base, size_t count, size_t elem)
+	{
+		uint64_t h = 1469598103934665603ull ^ (uint64_t)count;
+		if (!count) return h;
+		const size_t stride = count > 4096 ? count / 4096 : 1;
+		const unsigned char *b = (const unsigned char *)base;
+		for (size_t i = 0; i < count; i += stride) h = fnv(h, b + i * elem, elem);
+		return fnv(h, b + (count - 1) * elem, elem);
+	}
+	static_assert(sizeof(Vector3r) == 3 * sizeof(Real), "ParticleData's std::vector<Vector3r> must be a packed Real[3] array (Common/Common.h:31, Eigen::DontAlign)");
 }
 
 TimeStepControllerHIP::TimeStepControllerHIP(int device) :
 	TimeStepController(), m_solver(nullptr), m_device(device), m_scheduleValid(false),
-	m_numConstraints(0), m_numParticles(0), m_gpuSteps(0), m_fallbackSteps(0), m_failedSteps(0), m_allowFallback(false)
+	m_numConstraints(0), m_numParticles(0), m_gpuSteps(0), m_fallbackSteps(0), m_failedSteps(0), m_paramRefreshes(0), m_scheduleBuilds(0), m_uploads(0),
+	m_allowFallback(false), m_deviceAhead(false), m_hostDirty(false), m_imageValid(false), m_paramsDirty(false), m_paramHash(0),
+	m_supportedFor(nullptr), m_supportedConstraints(0), m_supportedBodies(0), m_supportedObjects(0), m_supported(false)
 {
+	for (int k = 0; k < 5; k++) m_hostHash[k] = 0;
 	if (pbdx_solver_create(&m_solver, device) != PBDX_OK)
 	{
 		LOG_ERR << "TimeStepControllerHIP: " << pbdx_last_error() << " -- every step() will fail (no CPU path)";
@@ -93,7 +115,9 @@ void TimeStepControllerHIP::refuse(SimulationModel &model, const char *why)
 	{
 		LOG_WARN << "TimeStepControllerHIP: " << why << " -- running this step on the reference CPU path (opted in)";
 		m_fallbackSteps++;
+		if (m_deviceAhead) syncToHost(model);               // the CPU path continues from the newest state
 		TimeStepController::step(model);
+		m_hostDirty = true;
 		return;
 	}
 	LOG_ERR << "TimeStepControllerHIP: " << why << " -- step NOT executed (call setAllowReferenceFallback(true) to use the CPU TimeStepController)";
@@ -110,11 +134,22 @@ void TimeStepControllerHIP::reset()
 {
 	TimeStepController::reset();
 	m_scheduleValid = false;
+	// Simulation::reset resets the model on the host (SimulationModel::reset): the host is authoritative again
+	m_deviceAhead = false;
+	m_hostDirty = true;
 }
 
-bool TimeStepControllerHIP::supported(SimulationModel &model) const
+// The scan over all constraints (one virtual call each) is repeated only when the model's make-up changed.
+bool TimeStepControllerHIP::supported(SimulationModel &model)
 {
 	if (!m_solver) return false;
+	const size_t nObjects = m_collisionDetection != NULL ? m_collisionDetection->getCollisionObjects().size() : 0;
+	if (m_supportedFor == (const void *)&model && m_supportedConstraints == model.getConstraints().size() &&
+		m_supportedBodies == model.getRigidBodies().size() && m_supportedObjects == nObjects && model.m_groupsInitialized && m_scheduleValid)
+		return m_supported;
+	m_supportedFor = (const void *)&model; m_supportedConstraints = model.getConstraints().size();
+	m_supportedBodies = model.getRigidBodies().size(); m_supportedObjects = nObjects;
+	m_supported = false;
 	if (model.getOrientations().size() != 0) return false;
 	// rigid bodies: only static ones (mass 0), as colliders of a distance-field collision detection
 	for (RigidBody *rb : model.getRigidBodies())
@@ -144,6 +179,7 @@ bool TimeStepControllerHIP::supported(SimulationModel &model) const
 	}
 	for (Constraint *c : model.getConstraints())
 		if (engineType(c) < 0) return false;                // e.g. GenericConstraints, joints, rods
+	m_supported = true;
 	return true;
 }
 
@@ -214,72 +250,191 @@ bool TimeStepControllerHIP::uploadColliders(SimulationModel &model)
 	return pbdx_solver_set_contact_params(m_solver, tolerance, (float)model.getContactStiffnessParticleRigidBody(), m_maxIterationsV) == PBDX_OK;
 }
 
+// ParticleData's arrays go to the engine as they are: std::vector<Vector3r> is a packed Real[3] array
+// (ParticleData.h:91-100), so &getPosition(0)[0] is what pbdx_solver_set_particles expects in a float host; a double
+// host hands the same pointers to the _f64 entry point and the conversion happens on the device.  Only the inverse
+// masses have no reference accessor (ParticleData.h:248 returns by value): they are gathered into a scratch array.
 bool TimeStepControllerHIP::uploadParticles(SimulationModel &model)
 {
 	ParticleData &pd = model.getParticles();
 	const unsigned int n = pd.size();
-	m_x.resize(3 * n); m_v.resize(3 * n); m_old.resize(3 * n); m_last.resize(3 * n); m_mass.resize(n); m_invMass.resize(n);
-	for (unsigned int i = 0; i < n; i++)
-	{
-		for (int k = 0; k < 3; k++)
-		{
-			m_x[3 * i + k] = (float)pd.getPosition(i)[k];
-			m_v[3 * i + k] = (float)pd.getVelocity(i)[k];
-			m_old[3 * i + k] = (float)pd.getOldPosition(i)[k];
-			m_last[3 * i + k] = (float)pd.getLastPosition(i)[k];
-		}
-		m_mass[i] = (float)pd.getMass(i);
-		m_invMass[i] = (float)pd.getInvMass(i);
-	}
 	if (n != m_numParticles) m_scheduleValid = false;      // the engine drops its schedule with the old particle image
 	m_numParticles = n;
-	return pbdx_solver_set_particles(m_solver, n, m_x.data(), m_v.data(), m_old.data(), m_last.data(), m_mass.data(), m_invMass.data()) == PBDX_OK;
+	m_uploads++;
+	int r;
+#ifdef USE_DOUBLE
+	m_invMass64.resize(n);
+	for (unsigned int i = 0; i < n; i++) m_invMass64[i] = pd.getInvMass(i);
+	r = n ? pbdx_solver_set_particles_f64(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0],
+		&pd.getMass(0), m_invMass64.data()) : PBDX_OK;
+#else
+	m_invMass32.resize(n);
+	for (unsigned int i = 0; i < n; i++) m_invMass32[i] = pd.getInvMass(i);
+	r = n ? pbdx_solver_set_particles(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0],
+		&pd.getMass(0), m_invMass32.data()) : PBDX_OK;
+#endif
+	if (r != PBDX_OK) return false;
+	m_imageValid = true;
+	m_deviceAhead = false;
+	m_hostDirty = false;
+	hashHostState(model, m_hostHash);
+	return true;
 }
 
 bool TimeStepControllerHIP::downloadParticles(SimulationModel &model)
 {
 	ParticleData &pd = model.getParticles();
 	const unsigned int n = pd.size();
-	if (pbdx_solver_get_particles(m_solver, n, m_x.data(), m_v.data(), m_old.data(), m_last.data()) != PBDX_OK)
+	if (!n) return true;
+#ifdef USE_DOUBLE
+	if (pbdx_solver_get_particles_f64(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0]) != PBDX_OK)
 		return false;
-	for (unsigned int i = 0; i < n; i++)
-		for (int k = 0; k < 3; k++)
-		{
-			pd.getPosition(i)[k] = (Real)m_x[3 * i + k];
-			pd.getVelocity(i)[k] = (Real)m_v[3 * i + k];
-			pd.getOldPosition(i)[k] = (Real)m_old[3 * i + k];
-			pd.getLastPosition(i)[k] = (Real)m_last[3 * i + k];
-		}
+#else
+	if (pbdx_solver_get_particles(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0]) != PBDX_OK)
+		return false;
+#endif
+	m_deviceAhead = false;
+	m_hostDirty = false;
+	hashHostState(model, m_hostHash);
 	return true;
 }
 
-bool TimeStepControllerHIP::buildSchedule(SimulationModel &model)
+// sampled hashes of the host arrays: x, v, oldX, lastX, masses (dirty tracking of a host the plug-in cannot instrument)
+void TimeStepControllerHIP::hashHostState(SimulationModel &model, uint64_t out[5]) const
+{
+	ParticleData &pd = model.getParticles();
+	const size_t n = pd.size();
+	if (!n) { for (int k = 0; k < 5; k++) out[k] = 0; return; }
+	out[0] = sampleHash(&pd.getPosition(0)[0], n, sizeof(Vector3r));
+	out[1] = sampleHash(&pd.getVelocity(0)[0], n, sizeof(Vector3r));
+	out[2] = sampleHash(&pd.getOldPosition(0)[0], n, sizeof(Vector3r));
+	out[3] = sampleHash(&pd.getLastPosition(0)[0], n, sizeof(Vector3r));
+	out[4] = sampleHash(&pd.getMass(0), n, sizeof(Real));
+}
+
+// hash over a sample of the constraints' parameter records (what pushParams would hand to the engine)
+uint64_t TimeStepControllerHIP::hashParameters(SimulationModel &model) const
+{
+	SimulationModel::ConstraintVector &constraints = model.getConstraints();
+	const size_t nc = constraints.size();
+	uint64_t h = 1469598103934665603ull ^ (uint64_t)nc;
+	if (!nc) return h;
+	const size_t stride = nc > 4096 ? nc / 4096 : 1;
+	std::vector<float> rec;
+	for (size_t i = 0; i < nc; i += stride)
+	{
+		rec.clear();
+		pushParams(rec, engineType(constraints[i]), constraints[i]);
+		h = fnv(h, rec.data(), rec.size() * sizeof(float));
+	}
+	rec.clear();
+	pushParams(rec, engineType(constraints[nc - 1]), constraints[nc - 1]);
+	return fnv(h, rec.data(), rec.size() * sizeof(float));
+}
+
+// One pass over every colour group: its constraints are bucketed by type (creation order kept inside a bucket) and each
+// non-empty (group, type) bucket becomes one engine batch, in (group, type) order -- the order the engine numbers batches
+// in.  paramsOnly: the same walk, but only the parameter records are refreshed (pbdx_solver_update_batch_params):
+// colouring, tiles and launch plan stay.
+bool TimeStepControllerHIP::buildSchedule(SimulationModel &model, bool paramsOnly)
 {
 	model.initConstraintGroups();                          // TimeStepController.cpp:256
 	SimulationModel::ConstraintVector &constraints = model.getConstraints();
 	SimulationModel::ConstraintGroupVector &groups = model.getConstraintGroups();
-	if (pbdx_solver_begin_schedule(m_solver) != PBDX_OK) return false;
-	std::vector<unsigned int> idx;
-	std::vector<float> par;
+	if (!paramsOnly && pbdx_solver_begin_schedule(m_solver) != PBDX_OK) return false;
+	std::vector<unsigned int> idx[PBDX_NUM_CONSTRAINT_TYPES];
+	std::vector<float> par[PBDX_NUM_CONSTRAINT_TYPES];
+	unsigned int batch = 0;
 	for (unsigned int g = 0; g < groups.size(); g++)
+	{
+		for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++) { idx[t].clear(); par[t].clear(); }
+		for (unsigned int ci : groups[g])
+		{
+			Constraint *c = constraints[ci];
+			const int type = engineType(c);
+			if (type < 0) return false;
+			if (!paramsOnly) idx[type].insert(idx[type].end(), c->m_bodies.begin(), c->m_bodies.end());
+			pushParams(par[type], type, c);
+		}
 		for (int type = 0; type < PBDX_NUM_CONSTRAINT_TYPES; type++)
 		{
-			idx.clear(); par.clear();
-			for (unsigned int ci : groups[g])
-			{
-				Constraint *c = constraints[ci];
-				if (engineType(c) != type) continue;
-				idx.insert(idx.end(), c->m_bodies.begin(), c->m_bodies.end());
-				pushParams(par, type, c);
-			}
-			if (idx.empty()) continue;
-			const unsigned int count = (unsigned int)(idx.size() / pbdx_type_num_bodies(type));
-			if (pbdx_solver_add_batch(m_solver, g, type, count, idx.data(), par.data(), pbdx_type_param_stride(type)) != PBDX_OK)
-				return false;
+			if (par[type].empty()) continue;
+			const unsigned int count = (unsigned int)(par[type].size() / pbdx_type_param_stride(type));
+			const int r = paramsOnly ? pbdx_solver_update_batch_params(m_solver, batch, count, par[type].data(), pbdx_type_param_stride(type))
+			                         : pbdx_solver_add_batch(m_solver, g, type, count, idx[type].data(), par[type].data(), pbdx_type_param_stride(type));
+			if (r != PBDX_OK) return false;
+			batch++;
 		}
-	if (pbdx_solver_end_schedule(m_solver) != PBDX_OK) return false;
+	}
+	if (paramsOnly) { if (pbdx_solver_commit_params(m_solver) != PBDX_OK) return false; m_paramRefreshes++; }
+	else { if (pbdx_solver_end_schedule(m_solver) != PBDX_OK) return false; m_scheduleBuilds++; }
 	m_numConstraints = constraints.size();
 	m_scheduleValid = true;
+	m_paramsDirty = false;
+	m_paramHash = hashParameters(model);
+	return true;
+}
+
+// Bring the device image up to date: particles (when the host is newer, or on demand), schedule (topology change),
+// parameters (run-time edits), colliders.  If the device is ahead of the host and the host changed only some arrays, the
+// unchanged ones are first pulled from the device (a partial host write must not roll the rest back).
+bool TimeStepControllerHIP::prepare(SimulationModel &model, bool forceUpload)
+{
+	bool upload = forceUpload || !m_imageValid || model.getParticles().size() != m_numParticles;
+	if (!upload)
+	{
+		uint64_t h[5];
+		hashHostState(model, h);
+		bool changed[5];
+		bool any = m_hostDirty;
+		for (int k = 0; k < 5; k++) { changed[k] = h[k] != m_hostHash[k]; any = any || changed[k]; }
+		if (any)
+		{
+			if (m_deviceAhead && !m_hostDirty)
+			{
+				// pull what the host did not touch (markHostDirty() = "everything on the host is newer": nothing is pulled)
+				ParticleData &pd = model.getParticles();
+				const unsigned int n = pd.size();
+#ifdef USE_DOUBLE
+				if (pbdx_solver_get_particles_f64(m_solver, n, changed[0] ? NULL : &pd.getPosition(0)[0], changed[1] ? NULL : &pd.getVelocity(0)[0],
+					changed[2] ? NULL : &pd.getOldPosition(0)[0], changed[3] ? NULL : &pd.getLastPosition(0)[0]) != PBDX_OK) return false;
+#else
+				if (pbdx_solver_get_particles(m_solver, n, changed[0] ? NULL : &pd.getPosition(0)[0], changed[1] ? NULL : &pd.getVelocity(0)[0],
+					changed[2] ? NULL : &pd.getOldPosition(0)[0], changed[3] ? NULL : &pd.getLastPosition(0)[0]) != PBDX_OK) return false;
+#endif
+			}
+			upload = true;
+		}
+	}
+	if (upload && !uploadParticles(model)) return false;
+	// topology change: groups re-initialised (every add* clears m_groupsInitialized), counts changed
+	if (!m_scheduleValid || !model.m_groupsInitialized || m_numConstraints != model.getConstraints().size())
+	{
+		if (!buildSchedule(model, false)) return false;
+	}
+	else if (m_paramsDirty || hashParameters(model) != m_paramHash)
+	{
+		if (!buildSchedule(model, true)) return false;      // parameter streams only: no replanning, no re-measurement
+	}
+	return uploadColliders(model);                          // cheap; poses / coefficients are host-mutable between steps
+}
+
+bool TimeStepControllerHIP::runSteps(SimulationModel &model, unsigned int numSteps)
+{
+	TimeManager *tm = TimeManager::getCurrent();
+	const Real h = tm->getTimeStepSize();
+	Simulation *sim = Simulation::getCurrent();
+	const Real *gr = sim->getVecValue<Real>(Simulation::GRAVITATION);
+	const float g[3] = { (float)gr[0], (float)gr[1], (float)gr[2] };
+	START_TIMING("position constraints projection");
+	const bool ok = pbdx_solver_step(m_solver, (float)h, m_subSteps, m_maxIterations, m_velocityUpdateMethod, g, numSteps) == PBDX_OK;
+	STOP_TIMING_AVG;
+	if (!ok) return false;
+	m_iterations = m_maxIterations;
+	m_iterationsV = m_maxIterationsV;
+	m_deviceAhead = true;
+	m_gpuSteps += numSteps;
+	for (unsigned int i = 0; i < numSteps; i++) tm->setTime(tm->getTime() + h);     // TimeStepController.cpp:239
 	return true;
 }
 
@@ -291,44 +446,67 @@ void TimeStepControllerHIP::step(SimulationModel &model)
 		return;
 	}
 	START_TIMING("simulation step");
-	TimeManager *tm = TimeManager::getCurrent();
-	const Real h = tm->getTimeStepSize();
-
-	bool ok = uploadParticles(model);
-	// topology change: groups re-initialised (every add* clears m_groupsInitialized), counts changed
-	if (ok && (!m_scheduleValid || !model.m_groupsInitialized || m_numConstraints != model.getConstraints().size()))
-		ok = buildSchedule(model);
-	if (ok)
-		ok = uploadColliders(model);                        // cheap; poses / coefficients are host-mutable between steps
+	// TimeStep::step contract: the host ParticleData is authoritative on entry and up to date on exit.  (If the device
+	// is ahead -- a stepResident without syncToHost -- prepare() merges instead of overwriting.)
+	bool ok = prepare(model, /*forceUpload=*/!m_deviceAhead);
 	if (ok)
 	{
 		clearAccelerations(model);                          // host-visible side effect of TimeStepController.cpp:84
-		Simulation *sim = Simulation::getCurrent();
-		const Real *gr = sim->getVecValue<Real>(Simulation::GRAVITATION);
-		const float g[3] = { (float)gr[0], (float)gr[1], (float)gr[2] };
-		START_TIMING("position constraints projection");
-		ok = pbdx_solver_step(m_solver, (float)h, m_subSteps, m_maxIterations, m_velocityUpdateMethod, g, 1) == PBDX_OK;
-		STOP_TIMING_AVG;
-		m_iterations = m_maxIterations;
+		ok = runSteps(model, 1);
 	}
 	if (ok)
 	{
 		// TimeStepController.cpp:216-223: the reference rebuilds the contact lists every step; the device keeps
 		// its contacts to itself, so the host lists are emptied (counts: pbdx_solver_get_num_contacts)
 		if (m_collisionDetection != NULL) model.resetContacts();
-		m_iterationsV = m_maxIterationsV;
 		ok = downloadParticles(model);
 	}
 	if (!ok)
 	{
 		STOP_TIMING_AVG;
 		m_scheduleValid = false;
+		m_imageValid = false;
 		refuse(model, pbdx_last_error());
 		return;
 	}
-	m_gpuSteps++;
-	tm->setTime(tm->getTime() + h);                         // TimeStepController.cpp:239
 	STOP_TIMING_AVG;
+}
+
+bool TimeStepControllerHIP::stepResident(SimulationModel &model, unsigned int numSteps)
+{
+	if (!supported(model))
+	{
+		refuse(model, m_solver ? "model contains rigid bodies / contacts / constraint types outside the engine's scope" : "no HIP engine");
+		return false;
+	}
+	if (!numSteps) return true;
+	START_TIMING("simulation step");
+	bool ok = prepare(model, false);
+	if (ok) ok = runSteps(model, numSteps);
+	STOP_TIMING_AVG;
+	if (!ok)
+	{
+		m_scheduleValid = false;
+		m_imageValid = false;
+		refuse(model, pbdx_last_error());
+		return false;
+	}
+	return true;
+}
+
+bool TimeStepControllerHIP::syncToHost(SimulationModel &model)
+{
+	if (!m_solver || !m_imageValid || model.getParticles().size() != m_numParticles) return false;
+	if (!downloadParticles(model)) return false;
+	clearAccelerations(model);
+	if (m_collisionDetection != NULL) model.resetContacts();
+	return true;
+}
+
+bool TimeStepControllerHIP::syncFromHost(SimulationModel &model)
+{
+	if (!m_solver) return false;
+	return prepare(model, true);
 }
 
 extern "C" PBD::TimeStep *pbdx_create_timestep_hip()
@@ -340,3 +518,11 @@ extern "C" unsigned int pbdx_timestep_hip_gpu_steps(PBD::TimeStep *ts) { return 
 extern "C" unsigned int pbdx_timestep_hip_fallback_steps(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numFallbackSteps(); }
 extern "C" unsigned int pbdx_timestep_hip_failed_steps(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numFailedSteps(); }
 extern "C" void pbdx_timestep_hip_allow_reference_fallback(PBD::TimeStep *ts, int allow) { static_cast<PBD::TimeStepControllerHIP*>(ts)->setAllowReferenceFallback(allow != 0); }
+extern "C" unsigned int pbdx_timestep_hip_param_refreshes(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numParameterRefreshes(); }
+extern "C" unsigned int pbdx_timestep_hip_schedule_builds(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numScheduleBuilds(); }
+extern "C" unsigned int pbdx_timestep_hip_uploads(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numUploads(); }
+extern "C" int pbdx_timestep_hip_step_resident(PBD::TimeStep *ts, PBD::SimulationModel *model, unsigned int n) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->stepResident(*model, n) ? 0 : 1; }
+extern "C" int pbdx_timestep_hip_sync_to_host(PBD::TimeStep *ts, PBD::SimulationModel *model) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->syncToHost(*model) ? 0 : 1; }
+extern "C" int pbdx_timestep_hip_sync_from_host(PBD::TimeStep *ts, PBD::SimulationModel *model) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->syncFromHost(*model) ? 0 : 1; }
+extern "C" void pbdx_timestep_hip_mark_host_dirty(PBD::TimeStep *ts) { static_cast<PBD::TimeStepControllerHIP*>(ts)->markHostDirty(); }
+extern "C" void *pbdx_timestep_hip_solver(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->solver(); }

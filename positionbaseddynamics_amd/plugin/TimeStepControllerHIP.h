@@ -12,6 +12,15 @@
 //     Simulation::getCurrent()->setTimeStep(new PBD::TimeStepControllerHIP());
 //     Simulation::getCurrent()->getTimeStep()->init();
 //
+// Two ways to step:
+//   step(model)               TimeStep::step's contract: host ParticleData in -> one step on the device -> host
+//                             ParticleData out.  The ParticleData arrays (std::vector<Vector3r>, packed Real[3],
+//                             ParticleData.h:91-100) are handed to the engine as they are -- no per-element
+//                             conversion loops; a double host is converted on the device.
+//   stepResident(model, n)    SURVEY 8f rank 1: n steps with the state resident in HBM; nothing is downloaded until
+//                             syncToHost(model).  Host writes to ParticleData in between are picked up by a sampled
+//                             hash of the arrays (or explicitly: markHostDirty()).
+//
 // Scope: models whose constraints are all particle constraints known to the engine.  Rigid bodies are
 // accepted when they are all static (mass 0) colliders of a DistanceFieldCollisionDetection with analytic
 // distance fields (box, sphere, torus, cylinder, hollow sphere / box): the particle vs rigid body contacts
@@ -27,6 +36,7 @@
 
 #include "Simulation/TimeStepController.h"
 #include "../../include/pbdx.h"
+#include <stdint.h>
 #include <vector>
 
 namespace PBD
@@ -40,32 +50,69 @@ namespace PBD
 		virtual void step(SimulationModel &model);
 		virtual void reset();
 
-		/** Drop the device image (call after editing constraint parameters in place). */
+		/** n steps with the particle state resident on the device (no download).  Returns false (and counts a failed step)
+		 * if the engine cannot run the model.  Host-visible side effects that cost a pass over all particles
+		 * (clearAccelerations) are applied by syncToHost. */
+		bool stepResident(SimulationModel &model, unsigned int numSteps = 1);
+		/** device state -> ParticleData (x, v, oldX, lastX); accelerations as TimeStep::clearAccelerations leaves them */
+		bool syncToHost(SimulationModel &model);
+		/** ParticleData -> device, unconditionally (the host is authoritative) */
+		bool syncFromHost(SimulationModel &model);
+		/** tell the plug-in that ParticleData was written on the host since the last sync (the sampled hash can miss a
+		 * single-particle edit in a large model) */
+		void markHostDirty() { m_hostDirty = true; }
+		/** the device holds a newer state than ParticleData */
+		bool deviceAhead() const { return m_deviceAhead; }
+
+		/** Drop the device image (call after editing the topology behind the model's back). */
 		void invalidate() { m_scheduleValid = false; }
+		/** Run-time parameter edits (setClothStiffness, m_stiffness / m_restLength edits, SimulationModel.h
+		 * setConstraintValue<>): every step compares a hash over a sample of the constraints' parameter records with the one
+		 * the device image was built from and, on a change, refreshes ONLY the parameter streams (no replanning).  An edit
+		 * of a single constraint in a large model can fall between the samples: call refreshParameters() then. */
+		void refreshParameters() { m_paramsDirty = true; }
 		/** Number of steps that ran on the GPU / fell back to the reference's CPU path. */
 		unsigned int numGpuSteps() const { return m_gpuSteps; }
 		unsigned int numFallbackSteps() const { return m_fallbackSteps; }
 		unsigned int numFailedSteps() const { return m_failedSteps; }
+		unsigned int numParameterRefreshes() const { return m_paramRefreshes; }
+		unsigned int numScheduleBuilds() const { return m_scheduleBuilds; }
+		unsigned int numUploads() const { return m_uploads; }
 		/** Opt in to running unsupported models / failed steps on the reference's CPU path (default off). */
 		void setAllowReferenceFallback(bool b) { m_allowFallback = b; }
 		pbdx_solver *solver() { return m_solver; }
 
 	protected:
-		bool supported(SimulationModel &model) const;
-		bool buildSchedule(SimulationModel &model);
+		bool supported(SimulationModel &model);
+		bool buildSchedule(SimulationModel &model, bool paramsOnly);
 		bool uploadParticles(SimulationModel &model);
 		bool uploadColliders(SimulationModel &model);
 		bool downloadParticles(SimulationModel &model);
+		bool prepare(SimulationModel &model, bool forceUpload);
+		bool runSteps(SimulationModel &model, unsigned int numSteps);
+		uint64_t hashParameters(SimulationModel &model) const;
+		void hashHostState(SimulationModel &model, uint64_t out[5]) const;
+		void refuse(SimulationModel &model, const char *why);
 
 		pbdx_solver *m_solver;
 		int m_device;
 		bool m_scheduleValid;
 		size_t m_numConstraints;
 		unsigned int m_numParticles;
-		unsigned int m_gpuSteps, m_fallbackSteps, m_failedSteps;
+		unsigned int m_gpuSteps, m_fallbackSteps, m_failedSteps, m_paramRefreshes, m_scheduleBuilds, m_uploads;
 		bool m_allowFallback;
-		void refuse(SimulationModel &model, const char *why);
-		std::vector<float> m_x, m_v, m_old, m_last, m_mass, m_invMass;
+		// device-resident state
+		bool m_deviceAhead;            // device state newer than ParticleData
+		bool m_hostDirty;              // markHostDirty()
+		bool m_imageValid;             // particles were uploaded at least once for the current model
+		uint64_t m_hostHash[5];        // sampled hashes of x, v, oldX, lastX, masses as of the last upload / download
+		// parameters
+		bool m_paramsDirty;
+		uint64_t m_paramHash;
+		// what `supported` was last evaluated for
+		const void *m_supportedFor; size_t m_supportedConstraints, m_supportedBodies, m_supportedObjects; bool m_supported;
+		std::vector<float> m_invMass32;
+		std::vector<double> m_invMass64;
 	};
 }
 

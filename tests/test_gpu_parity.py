@@ -744,21 +744,24 @@ def test_more_contacts_per_particle_than_the_engine_keeps_is_an_error(pbd):
     """the reference has no per-particle contact limit; the engine keeps 8.  Exceeding it must fail the step
     loudly (PBDX_ERR_UNSUPPORTED from pbdx_solver_step), not skip the particle's contact response silently."""
     ops = util.cloth_spec(8, 8, 4, 3, pin=False)
-    m = util.build_mine(ops)
-    pbd.TimeManager.setCurrent(pbd.TimeManager())
-    ts = pbd.TimeStepController()
-    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
-    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 2)
-    sol = ts.solver()
     eye = [1, 0, 0, 0, 1, 0, 0, 0, 1]
     floor = dict(shape="box", params=[50.0, 0.5, 50.0], com=[0, 0.49, 0], R=eye, v1=[0, 0, 0], v2=[0, 0.49, 0], restitution=0.6, friction=0.2)
-    ts.stepResident(m, 1)                      # uploads the particles (collision ranges are checked against them)
-    sol.set_collision_ranges([(0, m.getParticles().size(), 0.6, 0.1)])
-    sol.set_contact_params(0.05, 100.0, 5)
-    sol.set_colliders([floor] * 8)
-    ts.stepResident(m, 1)                      # 8 simultaneous contacts per particle: fine
-    assert sol.num_contacts() == 8 * 64
-    sol.set_colliders([floor] * 9)
-    with pytest.raises(pbd.PbdxError) as e:
+
+    def run(num_colliders):
+        m = util.build_mine(ops)
+        pbd.TimeManager.setCurrent(pbd.TimeManager())
+        ts = pbd.TimeStepController()
+        ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+        ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 2)
+        sol = ts.solver()
+        ts.syncFromHost(m)                         # uploads the particles (collision ranges are checked against them)
+        sol.set_collision_ranges([(0, m.getParticles().size(), 0.6, 0.1)])
+        sol.set_contact_params(0.05, 100.0, 5)
+        sol.set_colliders([floor] * num_colliders)
         ts.stepResident(m, 1)
+        return sol.num_contacts()
+
+    assert run(8) == 8 * 64                        # 8 simultaneous contacts per particle: fine
+    with pytest.raises(pbd.PbdxError) as e:
+        run(9)
     assert e.value.code == 4 and "simultaneous contacts" in str(e.value)

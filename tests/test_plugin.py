@@ -29,11 +29,20 @@ def _plugin(variant):
 def _counters(path):
     lib = C.CDLL(path)
     out = {}
-    for name in ("gpu_steps", "fallback_steps", "failed_steps"):
+    for name in ("gpu_steps", "fallback_steps", "failed_steps", "param_refreshes", "schedule_builds", "uploads"):
         f = getattr(lib, "pbdx_timestep_hip_" + name)
         f.argtypes = [C.c_void_p]
         f.restype = C.c_uint
         out[name] = f
+    for name, args in (("step_resident", [C.c_void_p, C.c_void_p, C.c_uint]), ("sync_to_host", [C.c_void_p, C.c_void_p]),
+                       ("sync_from_host", [C.c_void_p, C.c_void_p])):
+        f = getattr(lib, "pbdx_timestep_hip_" + name)
+        f.argtypes = args
+        f.restype = C.c_int
+        out[name] = f
+    lib.pbdx_timestep_hip_mark_host_dirty.argtypes = [C.c_void_p]
+    lib.pbdx_timestep_hip_mark_host_dirty.restype = None
+    out["mark_host_dirty"] = lib.pbdx_timestep_hip_mark_host_dirty
     return lib, out
 
 
@@ -134,3 +143,124 @@ def test_plugin_with_static_colliders_and_contacts():
     ref.reset_all()
     assert util.bitwise_equal(x_gpu, x_cpu), "max err %.3e" % util.max_err(x_gpu, x_cpu)
     assert util.bitwise_equal(v_gpu, v_cpu)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["f32", "f64"])
+def test_plugin_resident_mode_and_dirty_tracking(variant):
+    """SURVEY 8f rank 1 on the reference side: TimeStepControllerHIP::stepResident keeps the state in HBM (one upload, no
+    download), syncToHost brings ParticleData up to date, a host write in between is seen (sampled hash of the arrays) and
+    merged -- the arrays the host did not write are taken from the device, not rolled back."""
+    refdrv, path = _plugin(variant)
+    ops = util.cloth_spec(40, 30, 4, 3)
+
+    def run(resident):
+        ref = refdrv.Ref(variant)
+        _setup(ref, ops, 1, 10)
+        assert ref.install_timestep_plugin(path) == 0
+        ref.set_params(1, 10, 0)
+        lib, cnt = _counters(path)
+        ts, model = ref.timestep_ptr(), ref.model_ptr()
+        if resident:
+            assert cnt["step_resident"](ts, model, 4) == 0
+            assert cnt["uploads"](ts) == 1 and cnt["gpu_steps"](ts) == 4
+            x_before = ref.positions().copy()
+            assert np.array_equal(x_before, ref.get_array(1))             # host mirror untouched: still the initial state
+            # host edit of the velocities only, while the device is ahead
+            v = np.zeros_like(ref.get_array(2)); v[100:120, 1] = 0.25
+            ref.set_array(2, v)
+            assert cnt["step_resident"](ts, model, 3) == 0
+            assert cnt["uploads"](ts) == 2                                 # the edit was noticed
+            assert cnt["step_resident"](ts, model, 2) == 0
+            assert cnt["uploads"](ts) == 2                                 # ... and nothing else was re-uploaded
+            assert cnt["sync_to_host"](ts, model) == 0
+        else:
+            ref.step(4)
+            v = np.zeros_like(ref.get_array(2)); v[100:120, 1] = 0.25
+            ref.set_array(2, v)
+            ref.step(5)
+        assert cnt["failed_steps"](ts) == 0 and cnt["fallback_steps"](ts) == 0 and cnt["schedule_builds"](ts) == 1
+        out = [ref.get_array(k).copy() for k in (0, 2, 4, 5)]
+        ref.reset_all()
+        return out
+
+    a, b = run(False), run(True)
+    for k in range(4):
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_plugin_picks_up_runtime_parameter_edits_without_replanning():
+    """ADVICE r1: SimulationModel::setClothStiffness / setClothBendingStiffness between steps (what the demos' GUI does)
+    change neither the constraint count nor m_groupsInitialized.  The plug-in notices (parameter hash), refreshes only the
+    parameter streams -- no schedule rebuild -- and stays bit-identical to the CPU reference making the same edit."""
+    refdrv, path = _plugin("f32")
+    ops = util.cloth_spec(40, 30, 4, 3)
+
+    def run(gpu):
+        ref = refdrv.Ref("f32")
+        _setup(ref, ops, 1, 8)
+        if gpu:
+            assert ref.install_timestep_plugin(path) == 0
+        ref.set_params(1, 8, 0)
+        ref.step(3)
+        ref.set_cloth_stiffness(2500.0)
+        ref.step(3)
+        ref.set_cloth_bending_stiffness(7.0)
+        ref.set_constraint_stiffness(11, 123.0)       # one constraint differs from the rest: the shared stiffness is no longer uniform
+        ref.step(3)
+        x, v = ref.positions().copy(), ref.get_array(2).copy()
+        if gpu:
+            lib, cnt = _counters(path)
+            ts = ref.timestep_ptr()
+            assert cnt["gpu_steps"](ts) == 9 and cnt["failed_steps"](ts) == 0
+            assert cnt["schedule_builds"](ts) == 1 and cnt["param_refreshes"](ts) == 2
+        ref.reset_all()
+        return x, v
+
+    xc, vc = run(False)
+    xg, vg = run(True)
+    assert util.bitwise_equal(xg, xc), "max err %.3e" % util.max_err(xg, xc)
+    assert util.bitwise_equal(vg, vc)
+
+
+@pytest.mark.gpu
+def test_plugin_full_size_c2_reference_model():
+    """The 1000x1000 REFERENCE model (the reference's own SimulationModel, 5 988 006 heap constraints) stepped through the
+    plug-in: bit-identical to the CPU path after 2 steps; plug-in cost per step printed for the round trip
+    (TimeStep::step contract) and for resident stepping."""
+    import time
+    refdrv, path = _plugin("f32")
+    ops = util.cloth_spec(1000, 1000, 4, 3)
+    ref = refdrv.Ref("f32")
+    _setup(ref, ops, 1, 10)
+    ref.set_num_threads(32)
+    ref.set_params(1, 10, 0)
+    ref.step(2)
+    x_cpu, v_cpu = ref.positions().copy(), ref.get_array(2).copy()
+    _setup(ref, ops, 1, 10)
+    assert ref.install_timestep_plugin(path) == 0
+    ref.set_params(1, 10, 0)
+    t0 = time.perf_counter()
+    ref.step(1)
+    t_first = time.perf_counter() - t0
+    ref.step(1)
+    lib, cnt = _counters(path)
+    ts, model = ref.timestep_ptr(), ref.model_ptr()
+    assert cnt["gpu_steps"](ts) == 2 and cnt["failed_steps"](ts) == 0
+    assert util.bitwise_equal(ref.positions(), x_cpu) and util.bitwise_equal(ref.get_array(2), v_cpu)
+    t0 = time.perf_counter()
+    ref.step(10)
+    t_round = (time.perf_counter() - t0) / 10
+    assert cnt["step_resident"](ts, model, 5) == 0
+    t0 = time.perf_counter()
+    assert cnt["step_resident"](ts, model, 50) == 0
+    t_res = (time.perf_counter() - t0) / 50
+    t0 = time.perf_counter()
+    assert cnt["sync_to_host"](ts, model) == 0
+    t_sync = time.perf_counter() - t0
+    assert cnt["schedule_builds"](ts) == 1 and cnt["param_refreshes"](ts) == 0
+    print("plug-in at 1000x1000: first step (schedule build + plan + autotune) %.2f s; round trip %.3f ms/step; resident %.3f ms/step; syncToHost %.2f ms" % (
+        t_first, 1e3 * t_round, 1e3 * t_res, 1e3 * t_sync))
+    ref.reset_all()
+    assert t_res < 1.5e-3 and t_round < 8e-3
