@@ -78,6 +78,7 @@ def child_flags(w, fused_active, persist_active, opts):
              "--solid-method", str(w["solid_method"])] + (["--bars"] if w["bars"] else [])
     for flag, val in (("--fuse", 1 if fused_active else 0), ("--tile", opts.get("tile")), ("--fuse-block", opts.get("fuse_block")), ("--max-seg", opts.get("max_seg")),
                       ("--lds-particles", opts.get("lds_particles")), ("--xcd-remap", opts.get("xcd_remap")), ("--block", opts.get("block")),
+                      ("--wgs-per-cu", opts.get("wgs_per_cu")),
                       ("--persistent", 2 if persist_active else 0)):
         if val is not None:
             child += [flag, str(val)]
@@ -211,7 +212,7 @@ def run_workload(w, opts, ens, steps, warmup, with_roofline, with_traffic, with_
     sol = ts.solver()
     for key, opt in (("xcd_remap", S.OPT_XCD_REMAP), ("block", S.OPT_BLOCK_SIZE), ("fuse", S.OPT_FUSE), ("tile", S.OPT_TILE_PARTICLES),
                      ("fuse_block", S.OPT_FUSE_BLOCK), ("max_seg", S.OPT_MAX_SEGMENT_COLOURS), ("lds_particles", S.OPT_LDS_PARTICLES),
-                     ("persistent", S.OPT_PERSISTENT)):
+                     ("wgs_per_cu", S.OPT_PERSISTENT_WGS_PER_CU), ("persistent", S.OPT_PERSISTENT)):
         if opts.get(key) is not None:
             sol.set_option(opt, opts[key])
     if opts.get("no_graph"):
@@ -543,6 +544,7 @@ def main():
     ap.add_argument("--max-seg", type=int, default=None, help="max colours fused into one launch")
     ap.add_argument("--lds-particles", type=int, default=None)
     ap.add_argument("--persistent", type=int, default=None, help="PBDX_OPT_PERSISTENT: 1 = one launch per substep where measured faster (default), 0 = one launch per segment, 2 = always")
+    ap.add_argument("--wgs-per-cu", type=int, default=None, help="PBDX_OPT_PERSISTENT_WGS_PER_CU: tiles resident per CU in the one-launch schedule")
     ap.add_argument("--contacts", action="store_true", help="also time the step with two static colliders (contact detection + velocity solve per step)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than GPUs (ranks share devices; smoke test of the N>1 path, not a measurement)")
@@ -590,7 +592,7 @@ def main():
     w = {"workload": args.workload, "size": args.size, "instances": args.instances, "bars": args.bars, "solid_method": args.solid_method,
          "iters": args.iters, "scaling": args.scaling, "total_instances": args.total_instances}
     opts = {"xcd_remap": args.xcd_remap, "block": args.block, "fuse": args.fuse, "tile": args.tile, "fuse_block": args.fuse_block,
-            "max_seg": args.max_seg, "lds_particles": args.lds_particles, "persistent": args.persistent, "no_graph": args.no_graph}
+            "max_seg": args.max_seg, "lds_particles": args.lds_particles, "persistent": args.persistent, "no_graph": args.no_graph, "wgs_per_cu": args.wgs_per_cu}
 
     res = run_workload(w, opts, ens, args.steps, args.warmup, with_roofline=not args.no_roofline, with_traffic=not args.no_traffic and not args.pmc_child,
                        with_pcie=not args.pmc_child, with_contacts=args.contacts)

@@ -228,7 +228,7 @@ enum {
 	PBDX_OPT_PIN_HOST = 11,        /* page-lock (hipHostRegister) the caller's particle arrays passed to set/get_particles so that
 	                                * transfers DMA at full PCIe rate; the arrays must stay allocated until the option is cleared or the
 	                                * solver destroyed (default 0) */
-	PBDX_OPT_PAIRS = 10,           /* project two chunks of a colour step jointly with packed fp32 arithmetic (default 0: measured slower) */
+	PBDX_OPT_PAIRS = 10,           /* removed (round 2): projected two chunks of a colour step jointly with packed fp32 arithmetic, measured 10-30 % slower; accepted, ignored */
 	PBDX_OPT_PERSISTENT = 12,      /* fused schedule only: all sweeps of a substep as ONE launch; a tile starts its next pass as soon as its
 	                                * neighbouring tiles have published theirs (no kernel boundary, no chip-wide wait for the slowest tile).
 	                                * 1 (default) = used unless a one-off measurement on scratch positions finds it clearly slower than one launch per
@@ -239,7 +239,9 @@ enum {
 	                                * A wait inside the launch is bounded as well (PBDX_OPT_PERSISTENT_TIMEOUT_MS): if it expires, the engine restores the
 	                                * particle state it saved at the start of the call, repeats the call with one launch per segment and stops
 	                                * using the schedule (pbdx_persistent_info::timeouts) -- the caller sees the result of an undisturbed run. */
-	PBDX_OPT_PERSISTENT_TIMEOUT_MS = 13 /* bound of a tile-to-tile wait inside the persistent launch in milliseconds, 1 .. 10000 (default 250) */
+	PBDX_OPT_PERSISTENT_TIMEOUT_MS = 13, /* bound of a tile-to-tile wait inside the persistent launch in milliseconds, 1 .. 10000 (default 250) */
+	PBDX_OPT_PERSISTENT_WGS_PER_CU = 14  /* tiles (workgroups) the persistent launch keeps resident per CU, 1 .. 4 (default 1): with k > 1 the LDS is split k ways
+	                                * (smaller tiles, more halo) and one tile's fill / hand-off overlaps another tile's colour sweep on the same CU */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
 

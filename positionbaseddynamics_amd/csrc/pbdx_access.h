@@ -12,7 +12,6 @@
 #include <hip/hip_runtime.h>
 #include "pbdx_plan.h"
 #include "pbdx_project.h"
-#include "pbdx_pair.h"
 
 namespace pbdx {
 
@@ -444,85 +443,6 @@ template <int TYPE, bool COMPACT, class A> __device__ __forceinline__ void exec_
 {
 	const RecAccess<TYPE, COMPACT, A> ra = { a, r, first_iter };
 	Project<TYPE, RecAccess<TYPE, COMPACT, A>>::run(ra, i, dt, first_iter);
-}
-
-// ---- two records of the same colour step, one lane (pbdx_pair.h) -------------------------------------
-// Types without a packed implementation run their two records back to back.
-#ifndef PBDX_PAIR_BENDING
-#define PBDX_PAIR_BENDING 0     // the paired bending projection needs > 128 VGPRs: not with 1024-thread workgroups
-#endif
-template <int TYPE> struct HasPair { static constexpr bool value = (TYPE == PBDX_DISTANCE_XPBD || (PBDX_PAIR_BENDING && TYPE == PBDX_ISOMETRIC_BENDING_XPBD)); };
-
-template <int TYPE, bool COMPACT, class A>
-__device__ __forceinline__ void exec_rec2(const A &a, const A &a1, const Rec<TYPE, COMPACT> &r0, const Rec<TYPE, COMPACT> &r1, uint32_t q,
-	bool valid0, bool valid1, float dt, int first_iter)
-{
-	// a / a1: accessors of the two chunks (different stream offsets, same lane slot q)
-	const uint32_t q0 = q, q1 = q;
-	const RecAccess<TYPE, COMPACT, A> ra0 = { a, r0, first_iter }, ra1 = { a1, r1, first_iter };
-	if constexpr (TYPE == PBDX_DISTANCE_XPBD)
-	{
-		const uint32_t a0 = r0.w[0] & 0xffffu, b0 = r0.w[0] >> 16, a1i = r1.w[0] & 0xffffu, b1 = r1.w[0] >> 16;
-		const float4 A0 = a.ld(a0), B0 = a.ld(b0), A1 = a.ld(a1i), B1 = a.ld(b1);
-		const V3P p0 = mkp(mk(A0.x, A0.y, A0.z), mk(A1.x, A1.y, A1.z)), p1 = mkp(mk(B0.x, B0.y, B0.z), mk(B1.x, B1.y, B1.z));
-		const f2 w0 = mk2(A0.w, A1.w), w1 = mk2(B0.w, B1.w);
-		f2 lambda = first_iter ? splat(0.0f) : mk2(r0.lambda(), r1.lambda());
-		V3P c0, c1;
-		solve_distance_xpbd2(p0, w0, p1, w1, mk2(ra0.p(0, 0), ra1.p(0, 0)), mk2(ra0.p(1, 0), ra1.p(1, 0)), dt, lambda, c0, c1);
-		if (valid0)
-		{
-			apply(a, a0, lane0(p0), lane0(c0), A0.w); apply(a, b0, lane0(p1), lane0(c1), B0.w);
-			a.lam_store(q0, lambda.x);
-		}
-		if (valid1)
-		{
-			apply(a, a1i, lane1(p0), lane1(c0), A1.w); apply(a, b1, lane1(p1), lane1(c1), B1.w);
-			a1.lam_store(q1, lambda.y);
-		}
-	}
-	else if constexpr (TYPE == PBDX_ISOMETRIC_BENDING_XPBD)
-	{
-		const uint32_t i0[4] = { r0.w[0] & 0xffffu, r0.w[0] >> 16, r0.w[1] & 0xffffu, r0.w[1] >> 16 };
-		const uint32_t i1[4] = { r1.w[0] & 0xffffu, r1.w[0] >> 16, r1.w[1] & 0xffffu, r1.w[1] >> 16 };
-		float4 P0[4], P1[4];
-#pragma unroll
-		for (int k = 0; k < 4; k++) { P0[k] = a.ld(i0[k]); P1[k] = a.ld(i1[k]); }
-		V3P p[4], c[4]; f2 w[4];
-#pragma unroll
-		for (int k = 0; k < 4; k++)
-		{
-			p[k] = mkp(mk(P0[k].x, P0[k].y, P0[k].z), mk(P1[k].x, P1[k].y, P1[k].z));
-			w[k] = mk2(P0[k].w, P1[k].w);
-		}
-		f2 q[16];
-#pragma unroll
-		for (int k = 0; k < 16; k++) q[k] = mk2(ra0.p(1 + k, 0), ra1.p(1 + k, 0));
-		f2 lambda = first_iter ? splat(0.0f) : mk2(r0.lambda(), r1.lambda());
-		const B2 ok = solve_isometric_bending_xpbd2(p, w, q, mk2(ra0.p(0, 0), ra1.p(0, 0)), dt, lambda, c);
-		if (valid0)
-		{
-			if (ok.a)
-			{
-#pragma unroll
-				for (int k = 0; k < 4; k++) apply(a, i0[k], lane0(p[k]), lane0(c[k]), P0[k].w);
-			}
-			a.lam_store(q0, lambda.x);
-		}
-		if (valid1)
-		{
-			if (ok.b)
-			{
-#pragma unroll
-				for (int k = 0; k < 4; k++) apply(a, i1[k], lane1(p[k]), lane1(c[k]), P1[k].w);
-			}
-			a1.lam_store(q1, lambda.y);
-		}
-	}
-	else
-	{
-		if (valid0) exec_rec<TYPE, COMPACT>(a, r0, q0, dt, first_iter);
-		if (valid1) exec_rec<TYPE, COMPACT>(a1, r1, q1, dt, first_iter);
-	}
 }
 
 } // namespace pbdx

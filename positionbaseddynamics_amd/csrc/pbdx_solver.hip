@@ -265,7 +265,7 @@ template <int BLOCK, bool COHERENT> struct TileFill
 	}
 };
 
-template <int TYPE, bool COMPACT, int BLOCK, bool PAIRS, bool COHERENT>
+template <int TYPE, bool COMPACT, int BLOCK, bool COHERENT>
 __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStreams &str, const uint4 *lchunks, uint32_t c0,
 	float4 *lpos, unsigned long long *trace, uint32_t &step_counter)
 {
@@ -292,28 +292,17 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 	if constexpr (D == 4) { fetch(r2); fetch(r3); }
 	// Every sub-iteration issues exactly one record fetch, whether or not a projection still happens in it
 	// (single loop exit at the bottom): the number of memory operations between a fetch and its use is then
-	// the same on every path.  Two consecutive chunks of the SAME step may be projected jointly with packed
-	// arithmetic (PAIRS, pbdx_pair.h); the second sub-iteration then only fetches.
-	bool paired_prev = false;
+	// the same on every path.
 	// the descriptor of the chunk to project next is read BEFORE the colour barrier of the previous one,
 	// so that the first thing after a barrier is the LDS gather of the already prefetched record
 	ChunkS ch_next = load_chunk(lchunks, c0);
-	auto sub = [&](Rec<TYPE, COMPACT> &cur, Rec<TYPE, COMPACT> &nxt)
+	auto sub = [&](Rec<TYPE, COMPACT> &cur)
 	{
-		if (c_ex < run_end && !paired_prev)
+		if (c_ex < run_end)
 		{
-			ChunkS ch = ch_next;
+			const ChunkS ch = ch_next;
 			const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, a.views[TYPE] };
-			if (PAIRS && HasPair<TYPE>::value && !chunk_last_of_step(ch.info))
-			{
-				const ChunkS ch1 = load_chunk(lchunks, c_ex + 1);
-				const Acc acc1 = { lpos, str, ch1.idx_boff, ch1.par_boff, ch1.lam_boff, v_par, a.views[TYPE] };
-				exec_rec2<TYPE, COMPACT>(acc, acc1, cur, nxt, lane_slot, lane_slot < chunk_valid(ch.info), lane_slot < chunk_valid(ch1.info), a.dt, a.first_iter);
-				ch = ch1;
-				c_ex++;                     // consumes the partner chunk as well
-				paired_prev = true;
-			}
-			else if (lane_slot < chunk_valid(ch.info))
+			if (lane_slot < chunk_valid(ch.info))
 				exec_rec<TYPE, COMPACT>(acc, cur, lane_slot, a.dt, a.first_iter);
 			c_ex++;
 			ch_next = load_chunk(lchunks, c_ex < run_end ? c_ex : run_end - 1);
@@ -324,22 +313,20 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 				step_counter++;
 			}
 		}
-		else
-			paired_prev = false;
 		fetch(cur);
 	};
 	for (;;)
 	{
-		if constexpr (D == 4) { sub(r0, r1); sub(r1, r2); sub(r2, r3); sub(r3, r0); }
-		else { sub(r0, r1); sub(r1, r0); }
+		if constexpr (D == 4) { sub(r0); sub(r1); sub(r2); sub(r3); }
+		else { sub(r0); sub(r1); }
 		if (c_ex >= run_end) break;
 	}
 	return run_end;
 }
 
 #define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) { \
-		c = ra.views[T].compact ? run_typed<T, true, BLOCK, PAIRS, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter) \
-		                        : run_typed<T, false, BLOCK, PAIRS, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter); } \
+		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter) \
+		                        : run_typed<T, false, BLOCK, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter); } \
 	else { c = num_chunks; } break;
 
 // LDS: [ chunk descriptors of the tile: kMaxTileChunks x 16 B ][ positions: n_local x float4 ]
@@ -442,7 +429,7 @@ __device__ __forceinline__ void velocity_write_back(const FoldArgs &f, const uin
 // One tile of one segment: LDS fill, colour sweep, write-back of the owned particles.
 // `keep_owned`: the tile's owned particles are still in LDS from its previous pass (persistent schedule, same
 // workgroup, same owned set in every segment): only the halo is staged.  `wait`: see TileFill.
-template <uint32_t MASK, int BLOCK, bool PAIRS, bool COHERENT, class Wait>
+template <uint32_t MASK, int BLOCK, bool COHERENT, class Wait>
 __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &ra, const float4 *pos_in, float4 *pos_out, uint32_t tile_index,
 	unsigned long long *trace, uint4 *lchunks, float4 *lpos, bool keep_owned, const Wait &wait, const FoldArgs *fold = nullptr, uint32_t fold_phase = 0)
 {
@@ -510,7 +497,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	}
 }
 
-template <uint32_t MASK, int BLOCK, bool PAIRS>
+template <uint32_t MASK, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 {
 	extern __shared__ uint4 lds_raw[];
@@ -519,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 	const uint32_t tile_index = logical_block(a.seg.num_tiles, a.xcd_remap);
 	unsigned long long *trace = a.trace ? a.trace + (size_t)tile_index * kTraceStride : nullptr;
 	const RunArgs ra = { a.dt, a.first_iter, a.views };
-	process_tile<MASK, BLOCK, PAIRS, false>(a.seg, ra, a.pos_in, a.pos_out, tile_index, trace, lchunks, lpos, false, [] {});
+	process_tile<MASK, BLOCK, false>(a.seg, ra, a.pos_in, a.pos_out, tile_index, trace, lchunks, lpos, false, [] {});
 }
 
 // ---- (A') persistent schedule: all launches of a substep's sweeps as ONE launch ---------------------------
@@ -632,7 +619,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 			unsigned long long *trace = (a.trace[sgi] && pass + a.num_segs >= a.passes) ? a.trace[sgi] + (size_t)tile * kTraceStride : nullptr;
 			// one tile per workgroup: its owned particles stay in LDS from pass to pass
 			const uint32_t fold_phase = a.folded ? ((pass == 0 ? 1u : 0u) | (pass + 1u == a.passes ? 2u : 0u)) : 0u;
-			process_tile<MASK, BLOCK, false, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && gridDim.x == a.num_tiles, wait, &a.fold, fold_phase);
+			process_tile<MASK, BLOCK, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && gridDim.x == a.num_tiles, wait, &a.fold, fold_phase);
 			if (s_failed)
 			{
 				// a neighbour never arrived: the state of this step is garbage.  Say so, turn every later kernel of the call
@@ -659,19 +646,14 @@ constexpr uint32_t kMaskLight = (1u << PBDX_DISTANCE) | (1u << PBDX_DISTANCE_XPB
 	(1u << PBDX_ISOMETRIC_BENDING_XPBD) | (1u << PBDX_VOLUME) | (1u << PBDX_VOLUME_XPBD) | (1u << PBDX_DIHEDRAL);
 constexpr uint32_t kMaskAll = (1u << PBDX_NUM_CONSTRAINT_TYPES) - 1u;
 
-fused_fn pick_fused_kernel(uint32_t mask, int block, bool pairs)
+fused_fn pick_fused_kernel(uint32_t mask, int block)
 {
 	if ((mask & ~kMaskClothXpbd) == 0)
-	{
-		if (pairs)
-			return block == 1024 ? fused_kernel<kMaskClothXpbd, 1024, true> : block == 768 ? fused_kernel<kMaskClothXpbd, 768, true> :
-				block == 512 ? fused_kernel<kMaskClothXpbd, 512, true> : fused_kernel<kMaskClothXpbd, 256, true>;
-		return block == 1024 ? fused_kernel<kMaskClothXpbd, 1024, false> : block == 512 ? fused_kernel<kMaskClothXpbd, 512, false> : fused_kernel<kMaskClothXpbd, 256, false>;
-	}
+		return block == 1024 ? fused_kernel<kMaskClothXpbd, 1024> : block == 512 ? fused_kernel<kMaskClothXpbd, 512> : fused_kernel<kMaskClothXpbd, 256>;
 	if ((mask & ~kMaskLight) == 0)
-		return block == 1024 ? fused_kernel<kMaskLight, 1024, false> : block == 512 ? fused_kernel<kMaskLight, 512, false> : fused_kernel<kMaskLight, 256, false>;
+		return block == 1024 ? fused_kernel<kMaskLight, 1024> : block == 512 ? fused_kernel<kMaskLight, 512> : fused_kernel<kMaskLight, 256>;
 	// heavy types (FEM / strain / shape matching) need > 128 VGPRs: at most 512 threads per workgroup
-	return block >= 512 ? fused_kernel<kMaskAll, 512, false> : fused_kernel<kMaskAll, 256, false>;
+	return block >= 512 ? fused_kernel<kMaskAll, 512> : fused_kernel<kMaskAll, 256>;
 }
 
 persist_fn pick_persistent_kernel(uint32_t mask, int block)
@@ -906,12 +888,12 @@ struct pbdx_solver
 	int pin_host = 0;                    // hipHostRegister the caller's particle arrays (opt-in: they must outlive the solver or be unpinned)
 	struct Pin { const void *p; size_t bytes; };
 	std::vector<Pin> pins;
-	int pairs = 0;                       // measured slower: off by default
 	int persistent = 1;                  // PBDX_OPT_PERSISTENT: the sweeps of a substep as one launch (A'): 0 never, 1 where measured faster, 2 always, 3 self-test
 	bool persist_ok = false;             // the plan is eligible (and no launch has been refused or has timed out)
 	uint32_t persist_refusals = 0;
 	uint32_t persist_timeouts = 0;       // calls in which a tile gave up waiting for a neighbour (state restored, call repeated with schedule (A))
 	uint32_t persist_timeout_ms = 250;   // PBDX_OPT_PERSISTENT_TIMEOUT_MS
+	uint32_t persist_wgs_per_cu = 1;     // PBDX_OPT_PERSISTENT_WGS_PER_CU: tiles resident per CU in the one-launch schedule
 	float4 *d_snap[4] = { nullptr, nullptr, nullptr, nullptr };   // pos / vel / old / last as they were when the current call started (persistent schedule only)
 	bool last_folded = false;            // the substeps enqueued last ran integrate / velocity update inside the persistent launch
 	double persist_ms = 0.0;             // last profiled step: summed duration / number of persistent launches
@@ -1052,7 +1034,7 @@ int prepare_persistent(pbdx_solver *s)
 	s->persist_ok = false;
 	const size_t nseg = s->dsegs.size();
 	const uint32_t k = s->plan.num_tiles;
-	if (!nseg || nseg > kMaxPersistSegs || !k || s->pairs) return PBDX_OK;
+	if (!nseg || nseg > kMaxPersistSegs || !k) return PBDX_OK;
 	if (s->dsegs[0].block != 256 && s->dsegs[0].block != 512 && s->dsegs[0].block != 1024) return PBDX_OK;
 	uint32_t mask = 0, lds = 0;
 	for (const DeviceSegment &d : s->dsegs)
@@ -1091,7 +1073,10 @@ int prepare_persistent(pbdx_solver *s)
 		(void)hipGetLastError();
 		return PBDX_OK;
 	}
-	s->persist_grid = std::min<uint32_t>(k, (uint32_t)std::max(1, s->prop.multiProcessorCount));     // one workgroup per CU at most: leaves the margin the occupancy API lacks
+	if ((uint32_t)per_cu < s->persist_wgs_per_cu) return PBDX_OK;
+	// `wgs_per_cu` workgroups per CU at most (default one: leaves the margin the occupancy API lacks; the handshake of the
+	// launch is what actually guards residency)
+	s->persist_grid = std::min<uint32_t>(k, (uint32_t)std::max(1, s->prop.multiProcessorCount) * s->persist_wgs_per_cu);
 	s->persist_ok = true;
 	return PBDX_OK;
 }
@@ -1114,12 +1099,13 @@ int ensure_plan(pbdx_solver *s)
 	opt.tile_particles = s->tile_particles;
 	{
 		const size_t lds = s->prop.maxSharedMemoryPerMultiProcessor ? s->prop.maxSharedMemoryPerMultiProcessor : s->prop.sharedMemPerBlock;
-		opt.max_local = std::min<uint32_t>(s->lds_particles, (uint32_t)(lds / 16) - kMaxTileChunks);
+		const uint32_t wgs = s->persistent ? s->persist_wgs_per_cu : 1u;
+		opt.max_local = std::min<uint32_t>(s->lds_particles, (uint32_t)(lds / 16 / wgs) - kMaxTileChunks - (wgs > 1 ? 8u : 0u));
 		opt.max_tile_steps = kMaxTileSteps;
 	}
-	opt.num_cus = (uint32_t)std::max(1, s->prop.multiProcessorCount);
+	opt.num_cus = (uint32_t)std::max(1, s->prop.multiProcessorCount) * (s->persistent ? s->persist_wgs_per_cu : 1u);
 	opt.max_segment_colours = s->max_segment_colours;
-	if (s->persistent && !s->pairs && (uint64_t)s->n > (uint64_t)opt.num_cus * 1024u)
+	if (s->persistent && (uint64_t)s->n > (uint64_t)opt.num_cus * 1024u)
 	{
 		// (large tiles only: with the 512-particle tiles of small scenes a pass is a few short colour steps and the
 		// hand-off is what an extra pass costs -- measured 7 % slower on a 300x300 cloth and on the FEM bar)
@@ -1138,17 +1124,17 @@ int ensure_plan(pbdx_solver *s)
 	for (const FusedSegment &seg : s->plan.segs)
 	{
 		int block = s->fuse_block;
-		if (block != 256 && block != 512 && block != 768 && block != 1024)
+		if (block != 256 && block != 512 && block != 1024)
 		{
 			uint32_t widest = 0;
 			for (const FusedStep &st : seg.steps) widest = std::max(widest, st.count);
 			block = widest > 512 ? 1024 : widest > 256 ? 512 : 256;
 		}
 		if ((seg.type_mask & ~kMaskLight) && block > 512) block = 512;   // heavy types need > 128 VGPRs
-		if (block == 768 && !((seg.type_mask & ~kMaskClothXpbd) == 0 && s->pairs)) block = 512;   // 768 exists for the paired cloth kernel only
+		if (block == 768) block = 512;
 		blocks.push_back(block);
 	}
-	if (s->persistent && !s->pairs)
+	if (s->persistent)
 	{
 		// the persistent schedule runs every segment in one launch: one workgroup shape for all of them
 		int widest = *std::max_element(blocks.begin(), blocks.end());
@@ -1236,7 +1222,7 @@ int ensure_plan(pbdx_solver *s)
 		for (const PlanBatch &pb : pbs)
 			if (pb.colour >= seg.colour_begin && pb.colour < seg.colour_end)
 				d.algorithmic_bytes += (uint64_t)pb.count * type_info(pb.type)->algorithmic_bytes;
-		d.kernel = pick_fused_kernel(seg.type_mask, d.block, s->pairs != 0);
+		d.kernel = pick_fused_kernel(seg.type_mask, d.block);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(d.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
 	}
 	s->plan_ok = true;
@@ -1688,11 +1674,13 @@ int set_particles_impl(pbdx_solver *s, uint32_t n, const T *x, const T *v, const
 			HIPCHECK(hipMalloc(&s->d_vel, (size_t)n * sizeof(float4)));
 			HIPCHECK(hipMalloc(&s->d_old, (size_t)n * sizeof(float4)));
 			HIPCHECK(hipMalloc(&s->d_last, (size_t)n * sizeof(float4)));
-			HIPCHECK(hipMalloc(&s->d_stage, (size_t)n * 14 * sizeof(float)));
+			HIPCHECK(hipMalloc(&s->d_stage, (size_t)n * 14 * sizeof(T)));
+			s->stage_elem = sizeof(T);
 		}
 		s->n = n;
 	}
 	if (!n) return PBDX_OK;
+	{ int rs = ensure_stage(s, sizeof(T)); if (rs) return rs; }
 	if (!s->plan_ok)     // tile partition input (first upload wins)
 	{
 		s->h_x.resize((size_t)3 * n);
@@ -2004,11 +1992,14 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 		if (value < 64 || value > 10240) { set_error("lds_particles must be 64 .. 10240"); return PBDX_ERR_INVALID; }
 		s->lds_particles = (uint32_t)value; replan = true; break;
 	case PBDX_OPT_TRACE: s->trace = value != 0; break;
-	case PBDX_OPT_PAIRS: s->pairs = value != 0; replan = true; break;
+	case PBDX_OPT_PAIRS: break;        // removed (the packed two-slots-per-lane projection measured 10-30 % slower): accepted and ignored
 	case PBDX_OPT_PIN_HOST: s->pin_host = value != 0; if (!s->pin_host) s->unpin_all(); break;
 	case PBDX_OPT_PERSISTENT:
 		if (value < 0 || value > 4) { set_error("persistent must be 0 .. 4"); return PBDX_ERR_INVALID; }
 		s->persistent = (int)value; replan = true; break;
+	case PBDX_OPT_PERSISTENT_WGS_PER_CU:
+		if (value < 1 || value > 4) { set_error("persistent workgroups per CU must be 1 .. 4"); return PBDX_ERR_INVALID; }
+		s->persist_wgs_per_cu = (uint32_t)value; replan = true; break;
 	case PBDX_OPT_PERSISTENT_TIMEOUT_MS:
 		if (value < 1 || value > 10000) { set_error("persistent timeout must be 1 .. 10000 ms"); return PBDX_ERR_INVALID; }
 		s->persist_timeout_ms = (uint32_t)value; break;

@@ -11,13 +11,14 @@ from tests import util
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=1000)
+ap.add_argument("--bar", type=int, default=0, help="trace the configs[2] bar (101x21x11 tets) with this solid method instead of the cloth")
 ap.add_argument("--max-seg", type=int, default=None)
 ap.add_argument("--tile", type=int, default=None)
 ap.add_argument("--fuse-block", type=int, default=None)
 ap.add_argument("--persistent", type=int, default=0, help="0 one launch per segment, 2 one launch per substep")
 ap.add_argument("--graph", type=int, default=0, help="1: keep the hipGraph (kernel-to-kernel dead time as it is in production)")
 args = ap.parse_args()
-model = util.build_mine(util.cloth_spec(args.size, args.size, 4, 3))
+model = util.build_mine(util.bar_spec(101, 21, 11, args.bar) if args.bar else util.cloth_spec(args.size, args.size, 4, 3))
 ts = pbd.TimeStepController()
 ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
 ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 10)

@@ -239,8 +239,7 @@ def test_resident_equals_roundtrip_and_options_are_invariant(pbd):
                       ("fused, one colour per launch, resident", dict(resident=True, options={S.OPT_FUSE: 1, S.OPT_MAX_SEGMENT_COLOURS: 1})),
                       ("fused, small LDS", dict(options={S.OPT_FUSE: 1, S.OPT_TILE_PARTICLES: 200, S.OPT_LDS_PARTICLES: 500})),
                       ("fused, 1024 threads, no remap", dict(options={S.OPT_FUSE: 1, S.OPT_FUSE_BLOCK: 1024, S.OPT_XCD_REMAP: 0})),
-                      ("fused, packed pairs", dict(options={S.OPT_FUSE: 1, S.OPT_PAIRS: 1})),
-                      ("fused, packed pairs, 768 threads, small tiles", dict(options={S.OPT_FUSE: 1, S.OPT_PAIRS: 1, S.OPT_FUSE_BLOCK: 768, S.OPT_TILE_PARTICLES: 3000}))):
+                      ("fused, 512 threads, small tiles", dict(options={S.OPT_FUSE: 1, S.OPT_FUSE_BLOCK: 512, S.OPT_TILE_PARTICLES: 3000}))):
         m, ts = util.mine_run(ops, 6, 2, 5, **kw)
         assert util.bitwise_equal(m.getParticles().positions(), xb), label
         assert ts.solver().plan_info()["active"] == (0 if "per-colour" in label else 1), label
