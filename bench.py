@@ -50,7 +50,7 @@ def workload_spec(w, ens):
     from positionbaseddynamics_amd import scenes
     if w["workload"] == "c3":
         k = w["instances"] if w["bars"] else 1
-        ops = scenes.bar_spec(101, 21, 11, w["solid_method"], instances=k)
+        ops = scenes.bar_spec(101, 21, 11, w["solid_method"], instances=k, instanced=True)
         desc = "configs[2]: %s101x21x11 regular tet bar (100000 tets), solid method %d (%s), %d iterations, 1 substep, h=0.005" % (
             ("%d independent bars, each a " % k) if k > 1 else "", w["solid_method"],
             {2: "FEM tets", 3: "XPBD FEM tets", 4: "strain tets", 6: "XPBD distance + volume"}.get(w["solid_method"], "?"), w["iters"])
@@ -61,7 +61,8 @@ def workload_spec(w, ens):
         else:
             begin, end = ens.shard(w["instances"] * ens.world)     # weak scaling: `instances` per GPU
         k = end - begin
-        ops = scenes.cloth_spec(w["size"], w["size"], 4, 3, instances=k, instance_offset=(0.0, 0.0, 12.0))
+        # one prototype + SimulationModel.addInstances: built, coloured and planned once, replicated
+        ops = scenes.cloth_spec(w["size"], w["size"], 4, 3, instances=k, instance_offset=(0.0, 0.0, 12.0), instanced=True)
         desc = "configs[3]: %d independent %dx%d cloth instances on this GPU (%s; XPBD distance + XPBD isometric bending), %d iterations, 1 substep, h=0.005" % (
             k, w["size"], w["size"], ("strong scaling: %d instances over %d GPUs" % (w["total_instances"], ens.world)) if w["scaling"] == "strong" else "weak scaling", w["iters"])
         return ops, desc, [0, w["size"] - 1]

@@ -151,6 +151,12 @@ int pbdx_solver_end_schedule(pbdx_solver *s);
  * whether a type's shared parameters are uniform (then the plan is rebuilt by the next step). */
 int pbdx_solver_update_batch_params(pbdx_solver *s, uint32_t batch_index, uint32_t count, const float *params, uint32_t param_stride);
 int pbdx_solver_commit_params(pbdx_solver *s);
+/* Hint for ensemble schedules: the particles are `instances` blocks of `particles_per_instance`, and every batch holds the
+ * constraints of instance 0, then of instance 1, ... with the same block-local particle indices (what K rounds of the same
+ * builder calls produce).  The engine verifies the hint when it plans; if it holds, ONE instance is planned and the tile
+ * schedule replicated (set-up time of one instance); if not, the whole schedule is planned as usual.  instances <= 1 clears
+ * the hint.  Never changes a result. */
+int pbdx_solver_set_instancing(pbdx_solver *s, uint32_t particles_per_instance, uint32_t instances);
 /* Debug validator: every group's batches touch pairwise-disjoint particles
  * (the invariant data-race freedom rests on).  Returns PBDX_OK or PBDX_ERR_INVALID. */
 int pbdx_solver_validate_schedule(pbdx_solver *s);
@@ -335,6 +341,17 @@ int pbdx_model_add_regular_tet_model(pbdx_model *m, int width, int height, int d
 /* addTetModel SimulationModel.cpp:903-919 */
 int pbdx_model_add_tet_model(pbdx_model *m, uint32_t n_points, uint32_t n_tets,
 	const float *points, const uint32_t *indices);
+
+/* Instances (the ensemble workloads are K calls of the same builders with K translations).
+ * Appends `count` congruent copies of everything the model holds; copy k (1..count) is what the reference builds when the
+ * same mesh and constraint builders are called again with translation T + offsets[3(k-1)..] (regular models: positions
+ * re-evaluated as R p + T_k; explicit-point models and loose particles: prototype position + offset).  Particles, mesh
+ * models, constraints and colour groups are numbered exactly as those K+1 rounds of builder calls would number them, and
+ * the colouring is the one the reference computes for them (first-fit colouring of disjoint congruent copies appended in
+ * order repeats the prototype's colouring) -- but topology, constraints and groups are stored once and expanded on demand,
+ * so set-up cost no longer grows with the instance count.  The model is sealed afterwards (no further add*). */
+int pbdx_model_add_instances(pbdx_model *m, uint32_t count, const float *offsets);
+uint32_t pbdx_model_num_instances(const pbdx_model *m);   /* 1 for a model without instances */
 
 /* Mesh topology queries (Utils/IndexedFaceMesh.cpp:118-226, IndexedTetMesh.cpp:55-182). */
 uint32_t pbdx_model_num_triangle_models(const pbdx_model *m);

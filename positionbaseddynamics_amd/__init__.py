@@ -362,6 +362,16 @@ class SimulationModel:
             raise PbdxError(r, "addTetModel")
         return TetModel(self, r)
 
+    def addInstances(self, offsets):
+        """Append len(offsets) congruent copies of everything the model holds (an extension over pypbd for the ensemble
+        workloads): copy k is what calling the same builders again with translation T + offsets[k] would build --
+        same particle / constraint / group numbering, same colouring -- stored once.  The model is sealed afterwards."""
+        o = np.ascontiguousarray(offsets, dtype=np.float32).reshape(-1, 3)
+        check(lib.pbdx_model_add_instances(self._h, len(o), _f(o)), "add_instances")
+
+    def numInstances(self):
+        return lib.pbdx_model_num_instances(self._h)
+
     # -- per-constraint builders (return bool like the reference) --
     def addDistanceConstraint(self, p1, p2, stiffness):
         return bool(lib.pbdx_model_add_distance_constraint(self._h, p1, p2, stiffness))

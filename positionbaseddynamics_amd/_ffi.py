@@ -83,6 +83,7 @@ SIGNATURES = [
     ("pbdx_solver_get_particles", C.c_int, vp, u32, pf, pf, pf, pf),
     ("pbdx_solver_begin_schedule", C.c_int, vp),
     ("pbdx_solver_add_batch", C.c_int, vp, u32, C.c_int, u32, pu, pf, u32),
+    ("pbdx_solver_set_instancing", C.c_int, vp, u32, u32),
     ("pbdx_solver_end_schedule", C.c_int, vp), ("pbdx_solver_validate_schedule", C.c_int, vp),
     ("pbdx_solver_step", C.c_int, vp, f32, u32, u32, C.c_int, pf, u32),
     ("pbdx_solver_project", C.c_int, vp, f32, u32), ("pbdx_solver_synchronize", C.c_int, vp),
@@ -108,6 +109,7 @@ SIGNATURES = [
     ("pbdx_model_add_triangle_model", C.c_int, vp, u32, u32, pf, pu),
     ("pbdx_model_add_regular_tet_model", C.c_int, vp, C.c_int, C.c_int, C.c_int, pf, pf, pf),
     ("pbdx_model_add_tet_model", C.c_int, vp, u32, u32, pf, pu),
+    ("pbdx_model_add_instances", C.c_int, vp, u32, pf), ("pbdx_model_num_instances", u32, vp),
     ("pbdx_model_num_triangle_models", u32, vp), ("pbdx_model_num_tet_models", u32, vp),
     ("pbdx_model_triangle_model_index_offset", u32, vp, u32), ("pbdx_model_tet_model_index_offset", u32, vp, u32),
     ("pbdx_model_triangle_model_num_edges", u32, vp, u32), ("pbdx_model_triangle_model_get_edges", C.c_int, vp, u32, pu),

@@ -32,8 +32,21 @@ struct HostConstraint
 	float params[24];
 };
 
+// how a mesh model's rest positions were produced: needed to give an INSTANCE of the model the positions the reference's
+// builder would have given it (addRegularTriangleModel / addRegularTetModel evaluate R * p + T in Real; an instance
+// re-evaluates that with its own T)
+struct MeshRecipe
+{
+	int regular = 0;             // 0: explicit points (an instance's points = the prototype's + offset), 1: regular grid
+	int dims[3] = { 0, 0, 0 };
+	float R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+	float T[3] = { 0, 0, 0 };
+	float scale[3] = { 1, 1, 1 };
+};
+
 struct TriMesh
 {
+	MeshRecipe recipe;
 	uint32_t index_offset;
 	uint32_t num_vertices;
 	std::vector<uint32_t> faces;            // 3 per face
@@ -43,6 +56,7 @@ struct TriMesh
 
 struct TetMesh
 {
+	MeshRecipe recipe;
 	uint32_t index_offset;
 	uint32_t num_vertices;
 	std::vector<uint32_t> tets;             // 4 per tet
@@ -69,7 +83,26 @@ struct pbdx_model
 	uint32_t dirty_arrays = 0;       // bit `which` (pbdx_model_get_array numbering) set: that host array was written since the device image last
 	                                 // agreed with the host (a resident time step pulls the OTHER arrays from the device before it re-uploads)
 
+	// Instanced models (pbdx_model_add_instances): the model holds inst_count congruent copies of a PROTOTYPE (= its first
+	// inst_particles particles, the mesh models and the constraints it contained when the instances were added).  Particle
+	// state is materialised for every instance; mesh topology, constraints and colour groups are stored once -- instance k's
+	// constraint i is the prototype's with particle indices + k * inst_particles and rest data evaluated at ITS rest
+	// positions (constraint index k * nc + i, as if the builders had been called instance after instance); colour group g
+	// holds the prototype's members of g for instance 0, then for instance 1, ... (the reference's first-fit colouring of
+	// K disjoint congruent instances appended in order is exactly that).
+	uint32_t inst_count = 1;
+	uint32_t inst_particles = 0;
+	std::vector<float> inst_offset;  // 3 per instance (instance 0: zeros)
+
 	uint32_t size() const { return (uint32_t)mass.size(); }
+	uint64_t num_constraints() const { return (uint64_t)constraints.size() * inst_count; }
+	uint32_t num_tri_models() const { return (uint32_t)tri_models.size() * inst_count; }
+	uint32_t num_tet_models() const { return (uint32_t)tet_models.size() * inst_count; }
 };
+
+namespace pbdx {
+// constraint `c` of the (possibly instanced) model by value; false if an instance's element is degenerate
+bool model_constraint(const pbdx_model *m, uint64_t c, HostConstraint &out);
+}
 
 #endif

@@ -15,6 +15,9 @@
 #include "pbdx_vec.h"
 #include <math.h>
 #include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <thread>
 #include <unordered_map>
 
 using namespace pbdx;
@@ -162,6 +165,38 @@ void init_isometric_Q(V3 p0, V3 p1, V3 p2, V3 p3, float Q[16] /*col-major*/)
 	}
 }
 
+// rest positions of the regular mesh builders (SimulationModel.cpp:840-862, 932-958): R * (grid point) + T, in float
+void regular_tri_points(int width, int height, const M3 &rot, V3 t, const float scale[2], float *points)
+{
+	const float dy = scale[1] / (float)(height - 1);
+	const float dx = scale[0] / (float)(width - 1);
+	for (int i = 0; i < height; i++)
+		for (int j = 0; j < width; j++)
+		{
+			const float y = dy * i;
+			const float x = dx * j;
+			const V3 p = mul(rot, mk(x, y, 0.0f)) + t;
+			const size_t k = (size_t)i * width + j;
+			points[3 * k] = p.x; points[3 * k + 1] = p.y; points[3 * k + 2] = p.z;
+		}
+}
+void regular_tet_points(int width, int height, int depth, const M3 &rot, V3 T, const float scale[3], float *points)
+{
+	const float dx = scale[0] / (float)(width - 1);
+	const float dy = scale[1] / (float)(height - 1);
+	const float dz = scale[2] / (float)(depth - 1);
+	const V3 t = mk(T.x - 0.5f * scale[0], T.y - 0.5f * scale[1], T.z - 0.5f * scale[2]);
+	for (int i = 0; i < width; i++)
+		for (int j = 0; j < height; j++)
+			for (int k = 0; k < depth; k++)
+			{
+				const float x = dx * i, y = dy * j, z = dz * k;
+				const V3 p = mul(rot, mk(x, y, z)) + t;
+				const size_t q = (size_t)i * height * depth + (size_t)j * depth + k;
+				points[3 * q] = p.x; points[3 * q + 1] = p.y; points[3 * q + 2] = p.z;
+			}
+}
+
 M3 from_cols(V3 c0, V3 c1, V3 c2)
 {
 	M3 A;
@@ -195,6 +230,7 @@ int pbdx_model_cleanup(pbdx_model *m)
 	m->mass.clear(); m->inv_mass.clear();
 	m->x0.clear(); m->x.clear(); m->v.clear(); m->a.clear(); m->old_x.clear(); m->last_x.clear();
 	m->tri_models.clear(); m->tet_models.clear(); m->constraints.clear(); m->groups.clear();
+	m->inst_count = 1; m->inst_particles = 0; m->inst_offset.clear();
 	m->groups_initialized = false;
 	m->topology_version++;
 	return PBDX_OK;
@@ -215,6 +251,7 @@ int pbdx_model_reset(pbdx_model *m)
 int pbdx_model_add_triangle_model(pbdx_model *m, uint32_t n_points, uint32_t n_faces, const float *points, const uint32_t *indices)
 {
 	if (!m || !points || !indices) { set_error("add_triangle_model: null argument"); return -1; }
+	if (m->inst_count > 1) { set_error("the model holds instances (pbdx_model_add_instances): nothing can be added any more"); return -1; }
 	for (uint32_t i = 0; i < 3 * n_faces; i++)
 		if (indices[i] >= n_points) { set_error("add_triangle_model: face index out of range"); return -1; }
 	TriMesh tm;
@@ -244,15 +281,8 @@ int pbdx_model_add_regular_triangle_model(pbdx_model *m, int width, int height,
 	const float dy = scale[1] / (float)(height - 1);
 	const float dx = scale[0] / (float)(width - 1);
 	std::vector<float> points((size_t)width * height * 3);
-	for (int i = 0; i < height; i++)
-		for (int j = 0; j < width; j++)
-		{
-			const float y = dy * i;
-			const float x = dx * j;
-			const V3 p = mul(rot, mk(x, y, 0.0f)) + t;
-			const size_t k = (size_t)i * width + j;
-			points[3 * k] = p.x; points[3 * k + 1] = p.y; points[3 * k + 2] = p.z;
-		}
+	regular_tri_points(width, height, rot, t, scale, points.data());
+	(void)dx; (void)dy;
 	std::vector<uint32_t> indices((size_t)6 * (height - 1) * (width - 1));
 	size_t index = 0;
 	for (int i = 0; i < height - 1; i++)
@@ -270,6 +300,11 @@ int pbdx_model_add_regular_triangle_model(pbdx_model *m, int width, int height,
 		}
 	const int res = pbdx_model_add_triangle_model(m, (uint32_t)(width * height), (uint32_t)(indices.size() / 3), points.data(), indices.data());
 	if (res < 0) return res;
+	{
+		MeshRecipe &rc = m->tri_models[res].recipe;
+		rc.regular = 1; rc.dims[0] = width; rc.dims[1] = height;
+		memcpy(rc.R, R, sizeof(rc.R)); memcpy(rc.T, T, sizeof(rc.T)); rc.scale[0] = scale[0]; rc.scale[1] = scale[1];
+	}
 	const uint32_t off = m->tri_models[res].index_offset;
 	for (uint32_t i = off; i < off + m->tri_models[res].num_vertices; i++) set_mass(m, i, 1.0f);
 	return res;
@@ -278,6 +313,7 @@ int pbdx_model_add_regular_triangle_model(pbdx_model *m, int width, int height,
 int pbdx_model_add_tet_model(pbdx_model *m, uint32_t n_points, uint32_t n_tets, const float *points, const uint32_t *indices)
 {
 	if (!m || !points || !indices) { set_error("add_tet_model: null argument"); return -1; }
+	if (m->inst_count > 1) { set_error("the model holds instances (pbdx_model_add_instances): nothing can be added any more"); return -1; }
 	for (uint32_t i = 0; i < 4 * n_tets; i++)
 		if (indices[i] >= n_points) { set_error("add_tet_model: tet index out of range"); return -1; }
 	TetMesh tm;
@@ -308,15 +344,8 @@ int pbdx_model_add_regular_tet_model(pbdx_model *m, int width, int height, int d
 	const float dz = scale[2] / (float)(depth - 1);
 	const V3 t = mk(T[0] - 0.5f * scale[0], T[1] - 0.5f * scale[1], T[2] - 0.5f * scale[2]);
 	std::vector<float> points((size_t)width * height * depth * 3);
-	for (int i = 0; i < width; i++)
-		for (int j = 0; j < height; j++)
-			for (int k = 0; k < depth; k++)
-			{
-				const float x = dx * i, y = dy * j, z = dz * k;
-				const V3 p = mul(rot, mk(x, y, z)) + t;
-				const size_t q = (size_t)i * height * depth + (size_t)j * depth + k;
-				points[3 * q] = p.x; points[3 * q + 1] = p.y; points[3 * q + 2] = p.z;
-			}
+	regular_tet_points(width, height, depth, rot, mk(T[0], T[1], T[2]), scale, points.data());
+	(void)dx; (void)dy; (void)dz; (void)t;
 	std::vector<uint32_t> idx;
 	idx.reserve((size_t)(width - 1) * (height - 1) * (depth - 1) * 20);
 	for (int i = 0; i < width - 1; i++)
@@ -344,20 +373,44 @@ int pbdx_model_add_regular_tet_model(pbdx_model *m, int width, int height, int d
 			}
 	const int res = pbdx_model_add_tet_model(m, (uint32_t)(width * height * depth), (uint32_t)(idx.size() / 4), points.data(), idx.data());
 	if (res < 0) return res;
+	{
+		MeshRecipe &rc = m->tet_models[res].recipe;
+		rc.regular = 1; rc.dims[0] = width; rc.dims[1] = height; rc.dims[2] = depth;
+		memcpy(rc.R, R, sizeof(rc.R)); memcpy(rc.T, T, sizeof(rc.T)); memcpy(rc.scale, scale, sizeof(rc.scale));
+	}
 	const uint32_t off = m->tet_models[res].index_offset;
 	for (uint32_t i = off; i < off + m->tet_models[res].num_vertices; i++) set_mass(m, i, 1.0f);
 	return res;
 }
 
-uint32_t pbdx_model_num_triangle_models(const pbdx_model *m) { return m ? (uint32_t)m->tri_models.size() : 0; }
-uint32_t pbdx_model_num_tet_models(const pbdx_model *m) { return m ? (uint32_t)m->tet_models.size() : 0; }
-uint32_t pbdx_model_triangle_model_index_offset(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tri_models.size()) ? m->tri_models[tm].index_offset : 0; }
-uint32_t pbdx_model_tet_model_index_offset(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tet_models.size()) ? m->tet_models[tm].index_offset : 0; }
-uint32_t pbdx_model_triangle_model_num_edges(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tri_models.size()) ? (uint32_t)m->tri_models[tm].edges.size() : 0; }
+// Mesh model `tm` of a (possibly instanced) model: instance k's models are numbered k * (#prototype models) + j and share the
+// prototype's topology; their particles start k * inst_particles later.
+static const TriMesh *tri_of(const pbdx_model *m, uint32_t tm, uint32_t *offset)
+{
+	if (!m || tm >= m->num_tri_models()) return nullptr;
+	const uint32_t np = (uint32_t)m->tri_models.size();
+	const TriMesh &t = m->tri_models[tm % np];
+	if (offset) *offset = t.index_offset + (tm / np) * m->inst_particles;
+	return &t;
+}
+static const TetMesh *tet_of(const pbdx_model *m, uint32_t tm, uint32_t *offset)
+{
+	if (!m || tm >= m->num_tet_models()) return nullptr;
+	const uint32_t np = (uint32_t)m->tet_models.size();
+	const TetMesh &t = m->tet_models[tm % np];
+	if (offset) *offset = t.index_offset + (tm / np) * m->inst_particles;
+	return &t;
+}
+uint32_t pbdx_model_num_triangle_models(const pbdx_model *m) { return m ? m->num_tri_models() : 0; }
+uint32_t pbdx_model_num_tet_models(const pbdx_model *m) { return m ? m->num_tet_models() : 0; }
+uint32_t pbdx_model_triangle_model_index_offset(const pbdx_model *m, uint32_t tm) { uint32_t o = 0; return tri_of(m, tm, &o) ? o : 0; }
+uint32_t pbdx_model_tet_model_index_offset(const pbdx_model *m, uint32_t tm) { uint32_t o = 0; return tet_of(m, tm, &o) ? o : 0; }
+uint32_t pbdx_model_triangle_model_num_edges(const pbdx_model *m, uint32_t tm) { const TriMesh *t = tri_of(m, tm, nullptr); return t ? (uint32_t)t->edges.size() : 0; }
 int pbdx_model_triangle_model_get_edges(const pbdx_model *m, uint32_t tm, uint32_t *out)
 {
-	if (!m || !out || tm >= m->tri_models.size()) { set_error("triangle_model_get_edges: bad argument"); return PBDX_ERR_INVALID; }
-	const auto &e = m->tri_models[tm].edges;
+	const TriMesh *t = tri_of(m, tm, nullptr);
+	if (!t || !out) { set_error("triangle_model_get_edges: bad argument"); return PBDX_ERR_INVALID; }
+	const auto &e = t->edges;
 	for (size_t i = 0; i < e.size(); i++)
 	{
 		out[4 * i] = e[i].vert[0]; out[4 * i + 1] = e[i].vert[1]; out[4 * i + 2] = e[i].face[0]; out[4 * i + 3] = e[i].face[1];
@@ -365,37 +418,138 @@ int pbdx_model_triangle_model_get_edges(const pbdx_model *m, uint32_t tm, uint32
 	return PBDX_OK;
 }
 // faces / tets / vertex counts (IndexedFaceMesh::numFaces/getFaces, IndexedTetMesh::numTets/getTets)
-uint32_t pbdx_model_triangle_model_num_vertices(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tri_models.size()) ? m->tri_models[tm].num_vertices : 0; }
-uint32_t pbdx_model_triangle_model_num_faces(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tri_models.size()) ? (uint32_t)(m->tri_models[tm].faces.size() / 3) : 0; }
+uint32_t pbdx_model_triangle_model_num_vertices(const pbdx_model *m, uint32_t tm) { const TriMesh *t = tri_of(m, tm, nullptr); return t ? t->num_vertices : 0; }
+uint32_t pbdx_model_triangle_model_num_faces(const pbdx_model *m, uint32_t tm) { const TriMesh *t = tri_of(m, tm, nullptr); return t ? (uint32_t)(t->faces.size() / 3) : 0; }
 int pbdx_model_triangle_model_get_faces(const pbdx_model *m, uint32_t tm, uint32_t *out)
 {
-	if (!m || !out || tm >= m->tri_models.size()) { set_error("triangle_model_get_faces: bad argument"); return PBDX_ERR_INVALID; }
-	memcpy(out, m->tri_models[tm].faces.data(), m->tri_models[tm].faces.size() * sizeof(uint32_t));
+	const TriMesh *t = tri_of(m, tm, nullptr);
+	if (!t || !out) { set_error("triangle_model_get_faces: bad argument"); return PBDX_ERR_INVALID; }
+	memcpy(out, t->faces.data(), t->faces.size() * sizeof(uint32_t));
 	return PBDX_OK;
 }
-uint32_t pbdx_model_tet_model_num_vertices(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tet_models.size()) ? m->tet_models[tm].num_vertices : 0; }
-uint32_t pbdx_model_tet_model_num_tets(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tet_models.size()) ? (uint32_t)(m->tet_models[tm].tets.size() / 4) : 0; }
+uint32_t pbdx_model_tet_model_num_vertices(const pbdx_model *m, uint32_t tm) { const TetMesh *t = tet_of(m, tm, nullptr); return t ? t->num_vertices : 0; }
+uint32_t pbdx_model_tet_model_num_tets(const pbdx_model *m, uint32_t tm) { const TetMesh *t = tet_of(m, tm, nullptr); return t ? (uint32_t)(t->tets.size() / 4) : 0; }
 int pbdx_model_tet_model_get_tets(const pbdx_model *m, uint32_t tm, uint32_t *out)
 {
-	if (!m || !out || tm >= m->tet_models.size()) { set_error("tet_model_get_tets: bad argument"); return PBDX_ERR_INVALID; }
-	memcpy(out, m->tet_models[tm].tets.data(), m->tet_models[tm].tets.size() * sizeof(uint32_t));
+	const TetMesh *t = tet_of(m, tm, nullptr);
+	if (!t || !out) { set_error("tet_model_get_tets: bad argument"); return PBDX_ERR_INVALID; }
+	memcpy(out, t->tets.data(), t->tets.size() * sizeof(uint32_t));
 	return PBDX_OK;
 }
 
-uint32_t pbdx_model_tet_model_num_edges(const pbdx_model *m, uint32_t tm) { return (m && tm < m->tet_models.size()) ? (uint32_t)m->tet_models[tm].edges.size() : 0; }
+uint32_t pbdx_model_tet_model_num_edges(const pbdx_model *m, uint32_t tm) { const TetMesh *t = tet_of(m, tm, nullptr); return t ? (uint32_t)t->edges.size() : 0; }
 int pbdx_model_tet_model_get_edges(const pbdx_model *m, uint32_t tm, uint32_t *out)
 {
-	if (!m || !out || tm >= m->tet_models.size()) { set_error("tet_model_get_edges: bad argument"); return PBDX_ERR_INVALID; }
-	const auto &e = m->tet_models[tm].edges;
+	const TetMesh *t = tet_of(m, tm, nullptr);
+	if (!t || !out) { set_error("tet_model_get_edges: bad argument"); return PBDX_ERR_INVALID; }
+	const auto &e = t->edges;
 	for (size_t i = 0; i < e.size(); i++) { out[2 * i] = e[i].vert[0]; out[2 * i + 1] = e[i].vert[1]; }
 	return PBDX_OK;
 }
+
+// ---- instances -------------------------------------------------------------------------------------
+// Append `count` congruent copies of everything the model holds (the 512-instance ensemble is 512
+// calls of the same builders with a different translation).  What the reference would have done for copy k -- call the
+// mesh builders with translation T + offset_k, then the constraint builders, then re-colour everything -- is reproduced
+// exactly, but stored once: rest positions are re-evaluated per instance with the builders' own formula (explicit-point
+// models and loose particles: prototype position + offset), constraints and colour groups stay the prototype's and are
+// expanded on demand (model_constraint, pbdx_model_get_group).  Set-up cost and memory no longer grow with the instance
+// count except for the particle arrays.  Afterwards the model is sealed: no further add*.
+int pbdx_model_add_instances(pbdx_model *m, uint32_t count, const float *offsets)
+{
+	if (!m || (count && !offsets)) { set_error("add_instances: null argument"); return PBDX_ERR_INVALID; }
+	if (m->inst_count > 1) { set_error("add_instances: the model already holds instances"); return PBDX_ERR_INVALID; }
+	if (!count) return PBDX_OK;
+	const uint32_t np = m->size();
+	if (!np) { set_error("add_instances: empty model"); return PBDX_ERR_INVALID; }
+	if ((uint64_t)np * (count + 1) > 0xffffffffull || (uint64_t)m->constraints.size() * (count + 1) > 0xffffffffull)
+	{ set_error("add_instances: more than 2^32 particles or constraints"); return PBDX_ERR_INVALID; }
+	const uint32_t K = count + 1;
+	std::vector<float> x0((size_t)3 * np * K);
+	memcpy(x0.data(), m->x0.data(), (size_t)3 * np * sizeof(float));
+	for (uint32_t k = 1; k < K; k++)
+	{
+		const float *off = offsets + 3 * (size_t)(k - 1);
+		float *dst = x0.data() + (size_t)3 * np * k;
+		for (uint32_t i = 0; i < np; i++)
+			for (int d = 0; d < 3; d++) dst[3 * i + d] = m->x0[3 * i + d] + off[d];
+		for (const TriMesh &t : m->tri_models)
+			if (t.recipe.regular)
+			{
+				M3 rot;
+				for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) rot.m[r][c] = t.recipe.R[3 * r + c];
+				regular_tri_points(t.recipe.dims[0], t.recipe.dims[1], rot, mk(t.recipe.T[0] + off[0], t.recipe.T[1] + off[1], t.recipe.T[2] + off[2]),
+					t.recipe.scale, dst + (size_t)3 * t.index_offset);
+			}
+		for (const TetMesh &t : m->tet_models)
+			if (t.recipe.regular)
+			{
+				M3 rot;
+				for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) rot.m[r][c] = t.recipe.R[3 * r + c];
+				regular_tet_points(t.recipe.dims[0], t.recipe.dims[1], t.recipe.dims[2], rot, mk(t.recipe.T[0] + off[0], t.recipe.T[1] + off[1], t.recipe.T[2] + off[2]),
+					t.recipe.scale, dst + (size_t)3 * t.index_offset);
+			}
+	}
+	// commit: particle state of the copies = their rest state; masses as the prototype's
+	std::vector<float> mass((size_t)np * K), inv((size_t)np * K);
+	for (uint32_t k = 0; k < K; k++)
+	{
+		memcpy(mass.data() + (size_t)np * k, m->mass.data(), (size_t)np * sizeof(float));
+		memcpy(inv.data() + (size_t)np * k, m->inv_mass.data(), (size_t)np * sizeof(float));
+	}
+	auto extend = [&](std::vector<float> &a, bool zero)
+	{
+		a.resize((size_t)3 * np * K, 0.0f);
+		if (!zero) memcpy(a.data() + (size_t)3 * np, x0.data() + (size_t)3 * np, (size_t)3 * np * (K - 1) * sizeof(float));
+	};
+	extend(m->x, false); extend(m->old_x, false); extend(m->last_x, false); extend(m->v, true); extend(m->a, true);
+	m->x0.swap(x0);
+	m->mass.swap(mass); m->inv_mass.swap(inv);
+	m->inst_count = K;
+	m->inst_particles = np;
+	m->inst_offset.assign((size_t)3 * K, 0.0f);
+	memcpy(m->inst_offset.data() + 3, offsets, (size_t)3 * count * sizeof(float));
+	// every instance must be congruent to the prototype: an element that is degenerate in one copy only (the reference
+	// would have dropped that one constraint) cannot be represented
+	{
+		const uint64_t nc = m->constraints.size(), total = m->num_constraints();
+		std::atomic<uint64_t> bad(~0ull);
+		auto scan = [&](uint64_t a, uint64_t b)
+		{
+			HostConstraint c;
+			for (uint64_t ci = a; ci < b; ci++)
+				if (!model_constraint(m, ci, c)) { uint64_t cur = bad.load(); while (ci < cur && !bad.compare_exchange_weak(cur, ci)) {} return; }
+		};
+		const uint32_t threads = (total - nc > 200000) ? std::min<uint32_t>(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+		if (threads <= 1) scan(nc, total);
+		else
+		{
+			std::vector<std::thread> pool;
+			for (uint32_t t = 0; t < threads; t++) pool.emplace_back(scan, nc + (total - nc) * t / threads, nc + (total - nc) * (t + 1) / threads);
+			for (std::thread &t : pool) t.join();
+		}
+		if (bad.load() != ~0ull)
+		{
+			m->x0.resize((size_t)3 * np); m->x.resize((size_t)3 * np); m->old_x.resize((size_t)3 * np); m->last_x.resize((size_t)3 * np);
+			m->v.resize((size_t)3 * np); m->a.resize((size_t)3 * np); m->mass.resize(np); m->inv_mass.resize(np);
+			m->inst_count = 1; m->inst_particles = 0; m->inst_offset.clear();
+			set_error("add_instances: constraint %llu of the prototype is degenerate in a copy: the instances are not congruent", (unsigned long long)(bad.load() % nc));
+			return PBDX_ERR_INVALID;
+		}
+	}
+	m->topology_version++;
+	m->state_version++;
+	m->dirty_arrays |= 0x3fu;
+	return PBDX_OK;
+}
+uint32_t pbdx_model_num_instances(const pbdx_model *m) { return m ? m->inst_count : 0; }
 
 uint32_t pbdx_model_num_particles(const pbdx_model *m) { return m ? m->size() : 0; }
 
 int pbdx_model_add_vertex(pbdx_model *m, const float x[3])
 {
 	if (!m || !x) return -1;
+	if (m->inst_count > 1) { set_error("the model holds instances (pbdx_model_add_instances): nothing can be added any more"); return -1; }
 	m->topology_version++;
 	return (int)add_vertex(m, mk(x[0], x[1], x[2]));
 }
@@ -448,64 +602,172 @@ float *pbdx_model_positions_ptr(pbdx_model *m) { return m ? m->x.data() : nullpt
 int pbdx_model_mark_state_dirty(pbdx_model *m) { if (!m) return PBDX_ERR_INVALID; m->state_version++; m->dirty_arrays |= 1u; return PBDX_OK; }
 
 // ---- per-constraint builders -----------------------------------------------------------
-int pbdx_model_add_distance_constraint(pbdx_model *m, uint32_t p1, uint32_t p2, float stiffness)
+// The rest data of a constraint (Constraints.cpp initConstraint + init_* in PositionBasedDynamics.cpp) is a function of the
+// rest positions x0 of its particles only.  init_geometry fills those entries of c.params for c.type / c.bodies, leaving the
+// user parameters (stiffness, Poisson ratio, flags ...) that the caller put there; false = the reference's initConstraint
+// would have returned false (degenerate element).  The same function serves the add* calls and the instanced model
+// (an instance's constraint = the prototype's with offset particles and ITS OWN rest data).
+static float rest_volume(const pbdx_model *m, const uint32_t p[4])
 {
-	const uint32_t p[2] = { p1, p2 };
-	if (!m || !check_particles(m, p, 2)) return 0;
-	HostConstraint c = {};
-	c.type = PBDX_DISTANCE; c.bodies[0] = p1; c.bodies[1] = p2;
-	c.params[0] = norm(ld(m->x0, p2) - ld(m->x0, p1));
-	c.params[1] = stiffness;
+	const V3 p0 = ld(m->x0, p[0]), p1 = ld(m->x0, p[1]), p2 = ld(m->x0, p[2]), p3 = ld(m->x0, p[3]);
+	return fabsf((float)(1.0 / 6.0) * dot(p3 - p0, cross(p2 - p0, p1 - p0)));
+}
+
+static bool init_geometry(const pbdx_model *m, HostConstraint &c)
+{
+	const uint32_t *b = c.bodies;
+	switch (c.type)
+	{
+	case PBDX_DISTANCE: case PBDX_DISTANCE_XPBD:
+		c.params[0] = norm(ld(m->x0, b[1]) - ld(m->x0, b[0]));
+		return true;
+	case PBDX_DIHEDRAL:
+	{
+		const V3 p0 = ld(m->x0, b[0]), p1 = ld(m->x0, b[1]), p2 = ld(m->x0, b[2]), p3 = ld(m->x0, b[3]);
+		const V3 e = p3 - p2;
+		const float elen = norm(e);
+		if ((double)elen < 1e-6)
+			return false;
+		V3 n1 = cross(p2 - p0, p3 - p0); n1 = n1 / sqn(n1);
+		V3 n2 = cross(p3 - p1, p2 - p1); n2 = n2 / sqn(n2);
+		n1 = normalized(n1);
+		n2 = normalized(n2);
+		float d = dot(n1, n2);
+		if (d < -1.0f) d = -1.0f;
+		if (d > 1.0f) d = 1.0f;
+		c.params[0] = acosf(d);
+		return true;
+	}
+	case PBDX_ISOMETRIC_BENDING: case PBDX_ISOMETRIC_BENDING_XPBD:
+		init_isometric_Q(ld(m->x0, b[0]), ld(m->x0, b[1]), ld(m->x0, b[2]), ld(m->x0, b[3]), &c.params[1]);
+		return true;
+	case PBDX_FEM_TRIANGLE:
+	{
+		// init_FEMTriangleConstraint  PositionBasedDynamics.cpp:808-841
+		const V3 p0 = ld(m->x0, b[0]), p1 = ld(m->x0, b[1]), p2 = ld(m->x0, b[2]);
+		const V3 normal0 = cross(p1 - p0, p2 - p0);
+		const float area = norm(normal0) * 0.5f;
+		const V3 axis0_1 = normalized(p1 - p0);
+		const V3 axis0_2 = normalized(cross(normal0, axis0_1));
+		const float q[3][2] = { { dot(p0, axis0_2), dot(p0, axis0_1) }, { dot(p1, axis0_2), dot(p1, axis0_1) }, { dot(p2, axis0_2), dot(p2, axis0_1) } };
+		const float P00 = q[0][0] - q[2][0], P10 = q[0][1] - q[2][1], P01 = q[1][0] - q[2][0], P11 = q[1][1] - q[2][1];
+		const float det = P00 * P11 - P10 * P01;
+		if (!(fabsf(det) > kEps))
+			return false;
+		const float invdet = 1.0f / det;
+		c.params[0] = area;
+		c.params[1] = P11 * invdet;    // (0,0)
+		c.params[2] = -P10 * invdet;   // (1,0)
+		c.params[3] = -P01 * invdet;   // (0,1)
+		c.params[4] = P00 * invdet;    // (1,1)
+		return true;
+	}
+	case PBDX_STRAIN_TRIANGLE:
+	{
+		// StrainTriangleConstraint::initConstraint flattens to the x-z plane (Constraints.cpp:1563-1568),
+		// then init_StrainTriangleConstraint  PositionBasedDynamics.cpp:562-581
+		const V3 x1 = ld(m->x0, b[0]), x2 = ld(m->x0, b[1]), x3 = ld(m->x0, b[2]);
+		const float a = x2.x - x1.x, bb = x3.x - x1.x;
+		const float cc = x2.z - x1.z, d = x3.z - x1.z;
+		const float det = a * d - bb * cc;
+		if (fabsf(det) < kEps)
+			return false;
+		const float s = 1.0f / det;
+		c.params[0] = d * s;     // (0,0)
+		c.params[1] = -cc * s;   // (1,0)
+		c.params[2] = -bb * s;   // (0,1)
+		c.params[3] = a * s;     // (1,1)
+		return true;
+	}
+	case PBDX_VOLUME: case PBDX_VOLUME_XPBD:
+		c.params[0] = rest_volume(m, b);
+		return true;
+	case PBDX_FEM_TET: case PBDX_FEM_TET_XPBD:
+	{
+		// init_FEMTetraConstraint  PositionBasedDynamics.cpp:933-955
+		const V3 p0 = ld(m->x0, b[0]), p1 = ld(m->x0, b[1]), p2 = ld(m->x0, b[2]), p3 = ld(m->x0, b[3]);
+		const M3 mat = from_cols(p0 - p3, p1 - p3, p2 - p3);
+		const float dt = det(mat);
+		if (!(fabsf(dt) > kEps))
+			return false;
+		c.params[0] = rest_volume(m, b);
+		store_colmajor(inverse(mat), &c.params[1]);
+		return true;
+	}
+	case PBDX_STRAIN_TET:
+	{
+		// init_StrainTetraConstraint  PositionBasedDynamics.cpp:691-710
+		const V3 p0 = ld(m->x0, b[0]), p1 = ld(m->x0, b[1]), p2 = ld(m->x0, b[2]), p3 = ld(m->x0, b[3]);
+		const M3 mat = from_cols(p1 - p0, p2 - p0, p3 - p0);
+		const float dt = det(mat);
+		if (!(fabsf(dt) > kEps))
+			return false;
+		store_colmajor(inverse(mat), &c.params[0]);
+		return true;
+	}
+	case PBDX_SHAPE_MATCHING:
+	{
+		// init_ShapeMatchingConstraint  PositionBasedDynamics.cpp:481-498 (c.params[20..23] = numClusters set by the caller)
+		V3 restCm = mk(0.0f, 0.0f, 0.0f);
+		float wsum = 0.0f;
+		for (int i = 0; i < 4; i++)
+		{
+			const V3 x0 = ld(m->x0, b[i]);
+			const float w = m->inv_mass[b[i]];
+			c.params[4 + 3 * i] = x0.x; c.params[5 + 3 * i] = x0.y; c.params[6 + 3 * i] = x0.z;
+			c.params[16 + i] = w;
+			const float wi = 1.0f / (w + kEps);
+			restCm = restCm + x0 * wi;
+			wsum += wi;
+		}
+		if (wsum == 0.0f)
+			return false;
+		restCm = restCm / wsum;
+		c.params[1] = restCm.x; c.params[2] = restCm.y; c.params[3] = restCm.z;
+		return true;
+	}
+	default:
+		return false;
+	}
+}
+
+// common tail of every add*Constraint: range check, rest data, append
+static int add_constraint(pbdx_model *m, HostConstraint &c)
+{
+	if (!m) return 0;
+	if (m->inst_count > 1) { set_error("the model holds instances (pbdx_model_add_instances): no constraints can be added any more"); return 0; }
+	if (!check_particles(m, c.bodies, type_info(c.type)->num_bodies)) return 0;
+	if (!init_geometry(m, c)) return 0;
 	push_constraint(m, c);
 	return 1;
+}
+
+int pbdx_model_add_distance_constraint(pbdx_model *m, uint32_t p1, uint32_t p2, float stiffness)
+{
+	HostConstraint c = {};
+	c.type = PBDX_DISTANCE; c.bodies[0] = p1; c.bodies[1] = p2; c.params[1] = stiffness;
+	return add_constraint(m, c);
 }
 
 int pbdx_model_add_distance_constraint_xpbd(pbdx_model *m, uint32_t p1, uint32_t p2, float stiffness)
 {
-	const uint32_t p[2] = { p1, p2 };
-	if (!m || !check_particles(m, p, 2)) return 0;
 	HostConstraint c = {};
-	c.type = PBDX_DISTANCE_XPBD; c.bodies[0] = p1; c.bodies[1] = p2;
-	c.params[0] = norm(ld(m->x0, p2) - ld(m->x0, p1));
-	c.params[1] = stiffness;
-	push_constraint(m, c);
-	return 1;
+	c.type = PBDX_DISTANCE_XPBD; c.bodies[0] = p1; c.bodies[1] = p2; c.params[1] = stiffness;
+	return add_constraint(m, c);
 }
 
 int pbdx_model_add_dihedral_constraint(pbdx_model *m, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3, float stiffness)
 {
-	const uint32_t p[4] = { i0, i1, i2, i3 };
-	if (!m || !check_particles(m, p, 4)) return 0;
-	const V3 p0 = ld(m->x0, i0), p1 = ld(m->x0, i1), p2 = ld(m->x0, i2), p3 = ld(m->x0, i3);
-	const V3 e = p3 - p2;
-	const float elen = norm(e);
-	if ((double)elen < 1e-6)
-		return 0;
-	V3 n1 = cross(p2 - p0, p3 - p0); n1 = n1 / sqn(n1);
-	V3 n2 = cross(p3 - p1, p2 - p1); n2 = n2 / sqn(n2);
-	n1 = normalized(n1);
-	n2 = normalized(n2);
-	float d = dot(n1, n2);
-	if (d < -1.0f) d = -1.0f;
-	if (d > 1.0f) d = 1.0f;
 	HostConstraint c = {};
-	c.type = PBDX_DIHEDRAL; memcpy(c.bodies, p, sizeof(p));
-	c.params[0] = acosf(d);
-	c.params[1] = stiffness;
-	push_constraint(m, c);
-	return 1;
+	c.type = PBDX_DIHEDRAL; c.bodies[0] = i0; c.bodies[1] = i1; c.bodies[2] = i2; c.bodies[3] = i3; c.params[1] = stiffness;
+	return add_constraint(m, c);
 }
 
 static int add_isometric(pbdx_model *m, int type, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3, float stiffness)
 {
-	const uint32_t p[4] = { i0, i1, i2, i3 };
-	if (!m || !check_particles(m, p, 4)) return 0;
 	HostConstraint c = {};
-	c.type = type; memcpy(c.bodies, p, sizeof(p));
-	c.params[0] = stiffness;
-	init_isometric_Q(ld(m->x0, i0), ld(m->x0, i1), ld(m->x0, i2), ld(m->x0, i3), &c.params[1]);
-	push_constraint(m, c);
-	return 1;
+	c.type = type; c.bodies[0] = i0; c.bodies[1] = i1; c.bodies[2] = i2; c.bodies[3] = i3; c.params[0] = stiffness;
+	return add_constraint(m, c);
 }
 int pbdx_model_add_isometric_bending_constraint(pbdx_model *m, uint32_t a, uint32_t b, uint32_t c, uint32_t d, float k)
 { return add_isometric(m, PBDX_ISOMETRIC_BENDING, a, b, c, d, k); }
@@ -515,94 +777,36 @@ int pbdx_model_add_isometric_bending_constraint_xpbd(pbdx_model *m, uint32_t a, 
 int pbdx_model_add_fem_triangle_constraint(pbdx_model *m, uint32_t i0, uint32_t i1, uint32_t i2,
 	float xx, float yy, float xy, float xyP, float yxP)
 {
-	const uint32_t p[3] = { i0, i1, i2 };
-	if (!m || !check_particles(m, p, 3)) return 0;
-	// init_FEMTriangleConstraint  PositionBasedDynamics.cpp:808-841
-	const V3 p0 = ld(m->x0, i0), p1 = ld(m->x0, i1), p2 = ld(m->x0, i2);
-	const V3 normal0 = cross(p1 - p0, p2 - p0);
-	const float area = norm(normal0) * 0.5f;
-	const V3 axis0_1 = normalized(p1 - p0);
-	const V3 axis0_2 = normalized(cross(normal0, axis0_1));
-	const float q[3][2] = { { dot(p0, axis0_2), dot(p0, axis0_1) }, { dot(p1, axis0_2), dot(p1, axis0_1) }, { dot(p2, axis0_2), dot(p2, axis0_1) } };
-	const float P00 = q[0][0] - q[2][0], P10 = q[0][1] - q[2][1], P01 = q[1][0] - q[2][0], P11 = q[1][1] - q[2][1];
-	const float det = P00 * P11 - P10 * P01;
-	if (!(fabsf(det) > kEps))
-		return 0;
-	const float invdet = 1.0f / det;
 	HostConstraint c = {};
-	c.type = PBDX_FEM_TRIANGLE; memcpy(c.bodies, p, sizeof(p));
-	c.params[0] = area;
-	c.params[1] = P11 * invdet;    // (0,0)
-	c.params[2] = -P10 * invdet;   // (1,0)
-	c.params[3] = -P01 * invdet;   // (0,1)
-	c.params[4] = P00 * invdet;    // (1,1)
+	c.type = PBDX_FEM_TRIANGLE; c.bodies[0] = i0; c.bodies[1] = i1; c.bodies[2] = i2;
 	c.params[5] = xx; c.params[6] = yy; c.params[7] = xy; c.params[8] = xyP; c.params[9] = yxP;
-	push_constraint(m, c);
-	return 1;
+	return add_constraint(m, c);
 }
 
 int pbdx_model_add_strain_triangle_constraint(pbdx_model *m, uint32_t i0, uint32_t i1, uint32_t i2,
 	float xx, float yy, float xy, int ns, int nsh)
 {
-	const uint32_t p[3] = { i0, i1, i2 };
-	if (!m || !check_particles(m, p, 3)) return 0;
-	// StrainTriangleConstraint::initConstraint flattens to the x-z plane (Constraints.cpp:1563-1568),
-	// then init_StrainTriangleConstraint  PositionBasedDynamics.cpp:562-581
-	const V3 x1 = ld(m->x0, i0), x2 = ld(m->x0, i1), x3 = ld(m->x0, i2);
-	const float a = x2.x - x1.x, b = x3.x - x1.x;
-	const float cc = x2.z - x1.z, d = x3.z - x1.z;
-	const float det = a * d - b * cc;
-	if (fabsf(det) < kEps)
-		return 0;
-	const float s = 1.0f / det;
 	HostConstraint c = {};
-	c.type = PBDX_STRAIN_TRIANGLE; memcpy(c.bodies, p, sizeof(p));
-	c.params[0] = d * s;     // (0,0)
-	c.params[1] = -cc * s;   // (1,0)
-	c.params[2] = -b * s;    // (0,1)
-	c.params[3] = a * s;     // (1,1)
+	c.type = PBDX_STRAIN_TRIANGLE; c.bodies[0] = i0; c.bodies[1] = i1; c.bodies[2] = i2;
 	c.params[4] = xx; c.params[5] = yy; c.params[6] = xy; c.params[7] = ns ? 1.0f : 0.0f; c.params[8] = nsh ? 1.0f : 0.0f;
-	push_constraint(m, c);
-	return 1;
-}
-
-static float rest_volume(pbdx_model *m, const uint32_t p[4])
-{
-	const V3 p0 = ld(m->x0, p[0]), p1 = ld(m->x0, p[1]), p2 = ld(m->x0, p[2]), p3 = ld(m->x0, p[3]);
-	return fabsf((float)(1.0 / 6.0) * dot(p3 - p0, cross(p2 - p0, p1 - p0)));
+	return add_constraint(m, c);
 }
 
 static int add_volume(pbdx_model *m, int type, uint32_t a, uint32_t b, uint32_t c_, uint32_t d, float k)
 {
-	const uint32_t p[4] = { a, b, c_, d };
-	if (!m || !check_particles(m, p, 4)) return 0;
 	HostConstraint c = {};
-	c.type = type; memcpy(c.bodies, p, sizeof(p));
-	c.params[0] = rest_volume(m, p);
-	c.params[1] = k;
-	push_constraint(m, c);
-	return 1;
+	c.type = type; c.bodies[0] = a; c.bodies[1] = b; c.bodies[2] = c_; c.bodies[3] = d; c.params[1] = k;
+	return add_constraint(m, c);
 }
 int pbdx_model_add_volume_constraint(pbdx_model *m, uint32_t a, uint32_t b, uint32_t c, uint32_t d, float k) { return add_volume(m, PBDX_VOLUME, a, b, c, d, k); }
 int pbdx_model_add_volume_constraint_xpbd(pbdx_model *m, uint32_t a, uint32_t b, uint32_t c, uint32_t d, float k) { return add_volume(m, PBDX_VOLUME_XPBD, a, b, c, d, k); }
 
 static int add_fem_tet(pbdx_model *m, int type, uint32_t a, uint32_t b, uint32_t c_, uint32_t d, float k, float nu)
 {
-	const uint32_t p[4] = { a, b, c_, d };
-	if (!m || !check_particles(m, p, 4)) return 0;
-	// init_FEMTetraConstraint  PositionBasedDynamics.cpp:933-955
-	const V3 p0 = ld(m->x0, a), p1 = ld(m->x0, b), p2 = ld(m->x0, c_), p3 = ld(m->x0, d);
-	const M3 mat = from_cols(p0 - p3, p1 - p3, p2 - p3);
-	const float dt = det(mat);
-	if (!(fabsf(dt) > kEps))
-		return 0;
 	HostConstraint c = {};
-	c.type = type; memcpy(c.bodies, p, sizeof(p));
-	c.params[0] = rest_volume(m, p);
-	store_colmajor(inverse(mat), &c.params[1]);
+	c.type = type; c.bodies[0] = a; c.bodies[1] = b; c.bodies[2] = c_; c.bodies[3] = d;
 	c.params[10] = k; c.params[11] = nu;
-	push_constraint(m, c);
-	return 1;
+	return add_constraint(m, c);
 }
 int pbdx_model_add_fem_tet_constraint(pbdx_model *m, uint32_t a, uint32_t b, uint32_t c, uint32_t d, float k, float nu) { return add_fem_tet(m, PBDX_FEM_TET, a, b, c, d, k, nu); }
 int pbdx_model_add_fem_tet_constraint_xpbd(pbdx_model *m, uint32_t a, uint32_t b, uint32_t c, uint32_t d, float k, float nu) { return add_fem_tet(m, PBDX_FEM_TET_XPBD, a, b, c, d, k, nu); }
@@ -610,56 +814,28 @@ int pbdx_model_add_fem_tet_constraint_xpbd(pbdx_model *m, uint32_t a, uint32_t b
 int pbdx_model_add_strain_tet_constraint(pbdx_model *m, uint32_t a, uint32_t b, uint32_t c_, uint32_t d,
 	float stretch, float shear, int ns, int nsh)
 {
-	const uint32_t p[4] = { a, b, c_, d };
-	if (!m || !check_particles(m, p, 4)) return 0;
-	// init_StrainTetraConstraint  PositionBasedDynamics.cpp:691-710
-	const V3 p0 = ld(m->x0, a), p1 = ld(m->x0, b), p2 = ld(m->x0, c_), p3 = ld(m->x0, d);
-	const M3 mat = from_cols(p1 - p0, p2 - p0, p3 - p0);
-	const float dt = det(mat);
-	if (!(fabsf(dt) > kEps))
-		return 0;
 	HostConstraint c = {};
-	c.type = PBDX_STRAIN_TET; memcpy(c.bodies, p, sizeof(p));
-	store_colmajor(inverse(mat), &c.params[0]);
+	c.type = PBDX_STRAIN_TET; c.bodies[0] = a; c.bodies[1] = b; c.bodies[2] = c_; c.bodies[3] = d;
 	c.params[9] = stretch; c.params[10] = shear; c.params[11] = ns ? 1.0f : 0.0f; c.params[12] = nsh ? 1.0f : 0.0f;
-	push_constraint(m, c);
-	return 1;
+	return add_constraint(m, c);
 }
 
 int pbdx_model_add_shape_matching_constraint(pbdx_model *m, uint32_t n, const uint32_t *particles, const uint32_t *num_clusters, float stiffness)
 {
 	if (!m || !particles || !num_clusters) return 0;
 	if (n != 4) { set_error("shape matching: only 4-particle clusters are on the path (addSolidConstraints method 5)"); return 0; }
-	if (!check_particles(m, particles, 4)) return 0;
 	HostConstraint c = {};
 	c.type = PBDX_SHAPE_MATCHING; memcpy(c.bodies, particles, 4 * sizeof(uint32_t));
 	c.params[0] = stiffness;
-	// init_ShapeMatchingConstraint  PositionBasedDynamics.cpp:481-498
-	V3 restCm = mk(0.0f, 0.0f, 0.0f);
-	float wsum = 0.0f;
-	for (int i = 0; i < 4; i++)
-	{
-		const V3 x0 = ld(m->x0, particles[i]);
-		const float w = m->inv_mass[particles[i]];
-		c.params[4 + 3 * i] = x0.x; c.params[5 + 3 * i] = x0.y; c.params[6 + 3 * i] = x0.z;
-		c.params[16 + i] = w;
-		c.params[20 + i] = (float)num_clusters[i];
-		const float wi = 1.0f / (w + kEps);
-		restCm = restCm + x0 * wi;
-		wsum += wi;
-	}
-	if (wsum == 0.0f)
-		return 0;
-	restCm = restCm / wsum;
-	c.params[1] = restCm.x; c.params[2] = restCm.y; c.params[3] = restCm.z;
-	push_constraint(m, c);
-	return 1;
+	for (int i = 0; i < 4; i++) c.params[20 + i] = (float)num_clusters[i];
+	return add_constraint(m, c);
 }
 
 // ---- bulk builders ---------------------------------------------------------------------
 int pbdx_model_add_cloth_constraints(pbdx_model *m, uint32_t tmi, uint32_t method,
 	float k, float xx, float yy, float xy, float xyP, float yxP, int ns, int nsh)
 {
+	if (m && m->inst_count > 1) { set_error("the model holds instances (pbdx_model_add_instances): no constraints can be added any more"); return PBDX_ERR_INVALID; }
 	if (!m || tmi >= m->tri_models.size()) { set_error("add_cloth_constraints: bad triangle model"); return PBDX_ERR_INVALID; }
 	const uint32_t offset = m->tri_models[tmi].index_offset;
 	if (method == 1 || method == 4)
@@ -759,23 +935,30 @@ int pbdx_model_add_solid_constraints(pbdx_model *m, uint32_t tmi, uint32_t metho
 }
 
 // ---- inspection ----------------------------------------------------------------------------
-uint32_t pbdx_model_num_constraints(const pbdx_model *m) { return m ? (uint32_t)m->constraints.size() : 0; }
-int pbdx_model_constraint_type(const pbdx_model *m, uint32_t c) { return (m && c < m->constraints.size()) ? m->constraints[c].type : -1; }
+uint32_t pbdx_model_num_constraints(const pbdx_model *m) { return m ? (uint32_t)m->num_constraints() : 0; }
+int pbdx_model_constraint_type(const pbdx_model *m, uint32_t c) { return (m && c < m->num_constraints()) ? m->constraints[c % m->constraints.size()].type : -1; }
 int pbdx_model_constraint_bodies(const pbdx_model *m, uint32_t c, uint32_t *out)
 {
-	if (!m || !out || c >= m->constraints.size()) return PBDX_ERR_INVALID;
-	memcpy(out, m->constraints[c].bodies, type_info(m->constraints[c].type)->num_bodies * sizeof(uint32_t));
+	if (!m || !out || c >= m->num_constraints()) return PBDX_ERR_INVALID;
+	const HostConstraint &p = m->constraints[c % m->constraints.size()];
+	const uint32_t shift = (uint32_t)(c / m->constraints.size()) * m->inst_particles;
+	for (uint32_t j = 0; j < type_info(p.type)->num_bodies; j++) out[j] = p.bodies[j] + shift;
 	return PBDX_OK;
 }
 int pbdx_model_constraint_params(const pbdx_model *m, uint32_t c, float *out)
 {
-	if (!m || !out || c >= m->constraints.size()) return PBDX_ERR_INVALID;
-	memcpy(out, m->constraints[c].params, type_info(m->constraints[c].type)->param_stride * sizeof(float));
+	if (!m || !out || c >= m->num_constraints()) return PBDX_ERR_INVALID;
+	HostConstraint k;
+	if (!model_constraint(m, c, k)) { set_error("constraint %u is degenerate in its instance", c); return PBDX_ERR_INVALID; }
+	memcpy(out, k.params, type_info(k.type)->param_stride * sizeof(float));
 	return PBDX_OK;
 }
+// In an instanced model the user parameters (stiffness ...) live in the prototype: an edit of prototype constraint i applies to
+// constraint i of every instance; the rest data of the copies is always derived from their rest positions.
 int pbdx_model_set_constraint_params(pbdx_model *m, uint32_t c, const float *in)
 {
-	if (!m || !in || c >= m->constraints.size()) return PBDX_ERR_INVALID;
+	if (!m || !in || c >= m->num_constraints()) return PBDX_ERR_INVALID;
+	if (c >= m->constraints.size()) { set_error("set_constraint_params: in an instanced model edit the prototype's constraint (index %u)", (uint32_t)(c % m->constraints.size())); return PBDX_ERR_UNSUPPORTED; }
 	memcpy(m->constraints[c].params, in, type_info(m->constraints[c].type)->param_stride * sizeof(float));
 	m->params_version++;
 	return PBDX_OK;
@@ -787,7 +970,8 @@ int pbdx_model_init_constraint_groups(pbdx_model *m)
 	if (!m) return PBDX_ERR_INVALID;
 	if (m->groups_initialized)
 		return PBDX_OK;
-	const uint32_t n = m->size();
+	// (instanced model: the prototype is coloured; group g of the model = the prototype's group g, instance after instance)
+	const uint32_t n = m->inst_count > 1 ? m->inst_particles : m->size();
 	const size_t nc = m->constraints.size();
 	m->groups.clear();
 	// used[p*words + w]: bit g set <=> particle p is already touched by a constraint of group g
@@ -833,12 +1017,28 @@ int pbdx_model_init_constraint_groups(pbdx_model *m)
 
 int pbdx_model_groups_initialized(const pbdx_model *m) { return m && m->groups_initialized; }
 uint32_t pbdx_model_num_groups(const pbdx_model *m) { return m ? (uint32_t)m->groups.size() : 0; }
-uint32_t pbdx_model_group_size(const pbdx_model *m, uint32_t g) { return (m && g < m->groups.size()) ? (uint32_t)m->groups[g].size() : 0; }
+uint32_t pbdx_model_group_size(const pbdx_model *m, uint32_t g) { return (m && g < m->groups.size()) ? (uint32_t)m->groups[g].size() * m->inst_count : 0; }
 int pbdx_model_get_group(const pbdx_model *m, uint32_t g, uint32_t *out)
 {
 	if (!m || !out || g >= m->groups.size()) return PBDX_ERR_INVALID;
-	memcpy(out, m->groups[g].data(), m->groups[g].size() * sizeof(uint32_t));
+	const size_t n = m->groups[g].size();
+	memcpy(out, m->groups[g].data(), n * sizeof(uint32_t));
+	const uint32_t nc = (uint32_t)m->constraints.size();
+	for (uint32_t k = 1; k < m->inst_count; k++)
+		for (size_t i = 0; i < n; i++) out[(size_t)k * n + i] = m->groups[g][i] + k * nc;
 	return PBDX_OK;
 }
 
 } // extern "C"
+
+namespace pbdx {
+bool model_constraint(const pbdx_model *m, uint64_t c, HostConstraint &out)
+{
+	const size_t nc = m->constraints.size();
+	out = m->constraints[c % nc];
+	if (c < nc) return true;
+	const uint32_t shift = (uint32_t)(c / nc) * m->inst_particles;
+	for (uint32_t j = 0; j < type_info(out.type)->num_bodies; j++) out.bodies[j] += shift;
+	return init_geometry(m, out);
+}
+}

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <thread>
 
@@ -322,6 +324,11 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	for (Scratch &s : scratch) s.init(g);
 
 	// ---- segment boundaries: dynamic programme over a sample of tiles ---------------------------
+	// (developer aid: PBDX_PLAN_SLOT_SCALE / PBDX_PLAN_FIXED_NS / PBDX_PLAN_LAUNCH_NS rescale the time model to explore other
+	// segmentations on the GPU; never set in production)
+	const double slot_scale = getenv("PBDX_PLAN_SLOT_SCALE") ? atof(getenv("PBDX_PLAN_SLOT_SCALE")) : 1.0;
+	const double fixed_ns = getenv("PBDX_PLAN_FIXED_NS") ? atof(getenv("PBDX_PLAN_FIXED_NS")) : kColourFixedNs;
+	const double launch_ns = getenv("PBDX_PLAN_LAUNCH_NS") ? atof(getenv("PBDX_PLAN_LAUNCH_NS")) : opt.launch_cost_ns;
 	const uint32_t maxlen = std::max(1u, std::min(opt.max_segment_colours, ncol));
 	const uint32_t nsample = std::min(k, 8u);
 	std::vector<uint32_t> sample(nsample);
@@ -344,8 +351,8 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 				// cost per colour the tile takes part in (barrier + one projection chain), a per-slot cost by type
 				// (the sweep is latency / issue bound, not byte bound), LDS fill and write-back per particle
 				const std::vector<uint32_t> &bk = s.bucket[c - c_lo];
-				if (!bk.empty()) steps_ns += kColourFixedNs;
-				for (uint32_t cid : bk) steps_ns += kSlotNs[g.batch_of(cid).type];
+				if (!bk.empty()) steps_ns += fixed_ns;
+				for (uint32_t cid : bk) steps_ns += slot_scale * kSlotNs[g.batch_of(cid).type];
 				const uint32_t n_local = n_owned + (uint32_t)s.halo.size();
 				const size_t e = (size_t)c1 * maxlen + (c1 - c - 1);
 				tb[th][e] += steps_ns + kFillNsPerParticle * (opt.owned_stay_in_lds ? n_local - n_owned : n_local) + kWriteBackNsPerParticle * n_owned;
@@ -370,7 +377,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 		{
 			const size_t e = (size_t)c1 * maxlen + (len - 1);
 			if (len > 1 && seg_maxlocal[e] > cap_dp) break;       // closures only grow with the length
-			const double cst = best[c1 - len] + seg_bytes[e] * scale + opt.launch_cost_ns;
+			const double cst = best[c1 - len] + seg_bytes[e] * scale + launch_ns;
 			if (cst < best[c1]) { best[c1] = cst; prev[c1] = c1 - len; }
 		}
 	std::vector<std::pair<uint32_t, uint32_t>> todo;
@@ -608,6 +615,161 @@ bool check_fused_plan(uint32_t n, const std::vector<PlanBatch> &batches, const F
 		if (cur[p] != want[p]) { snprintf(msg, sizeof(msg), "particle %u: fused schedule differs from the colour-sequential sweep", p); why = msg; return false; }
 	return true;
 }
+
+// ------------------------------------------------------------------------------------------------
+// instanced schedules
+// ------------------------------------------------------------------------------------------------
+bool check_instancing(uint32_t n_proto, uint32_t K, const std::vector<PlanBatch> &batches)
+{
+	if (K < 2 || !n_proto) return false;
+	for (const PlanBatch &b : batches) if (b.count % K) return false;
+	std::atomic<int> bad(0);
+	const uint32_t threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	parallel_for(K - 1, threads, [&](uint32_t kk, uint32_t) {
+		const uint32_t k = kk + 1;
+		if (bad.load()) return;
+		for (const PlanBatch &b : batches)
+		{
+			const uint32_t nb = type_info(b.type)->num_bodies;
+			const size_t len = (size_t)(b.count / K) * nb;
+			const uint32_t *p0 = b.idx, *pk = b.idx + (size_t)k * len;
+			const uint32_t shift = k * n_proto;
+			for (size_t i = 0; i < len; i++)
+				if (p0[i] >= n_proto || pk[i] != p0[i] + shift) { bad.store(1); return; }
+		}
+	});
+	return !bad.load();
+}
+
+bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const std::vector<PlanBatch> &batches,
+	const PlanOptions &opt, FusedPlan &plan, std::string &why)
+{
+	const auto t_start = std::chrono::steady_clock::now();
+	const bool verbose = getenv("PBDX_PLAN_VERBOSE") != nullptr;
+	auto lap = [&](const char *what) { if (verbose) fprintf(stderr, "[plan] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
+	if (!check_instancing(n_proto, K, batches)) { why = "the schedule is not K congruent instances"; return false; }
+	lap("congruence check");
+	// views over ALL instances (a parameter that is uniform within the prototype need not be uniform across the copies)
+	TypeView full_views[16];
+	for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++)
+	{
+		std::vector<ParamSpan> spans;
+		for (const PlanBatch &pb : batches) if (pb.type == t && pb.count) spans.push_back({ pb.params, pb.count });
+		compute_type_view(t, spans, full_views[t]);
+	}
+	lap("views over all instances");
+	// the prototype's share of the schedule and of the tiles
+	std::vector<PlanBatch> proto(batches);
+	for (PlanBatch &b : proto) b.count /= K;
+	PlanOptions po = opt;
+	if (!po.tile_particles)
+	{
+		// tile count of the whole as the planner would choose it (whole waves of num_cus tiles at the largest tile the LDS
+		// allows), divided among the instances
+		const uint32_t cus = std::max(1u, opt.num_cus);
+		const uint32_t t_max = std::max(512u, std::min(5200u, opt.max_local / 2 + opt.max_local / 50));
+		const uint64_t n = (uint64_t)n_proto * K;
+		const uint64_t k_all = n <= (uint64_t)cus * 512u ? (n + 511) / 512 : (uint64_t)cus * ((n + (uint64_t)cus * t_max - 1) / ((uint64_t)cus * t_max));
+		const uint32_t k_proto = (uint32_t)std::max<uint64_t>(1, (k_all + K / 2) / K);
+		po.tile_particles = std::min<uint32_t>(opt.max_local, (n_proto + k_proto - 1) / k_proto);
+	}
+	FusedPlan pp;
+	if (!build_fused_plan(n_proto, x, proto, po, pp, why)) return false;
+	for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++)
+		if (pp.views[t].compact != full_views[t].compact) { why = "a shared parameter is uniform in the prototype but not across the instances"; return false; }
+
+	lap("prototype planned");
+	plan = FusedPlan();
+	for (int t = 0; t < 16; t++) plan.views[t] = t < PBDX_NUM_CONSTRAINT_TYPES ? full_views[t] : pp.views[t];
+	const uint32_t kt = pp.num_tiles;
+	plan.num_tiles = kt * K;
+	plan.num_colours = pp.num_colours;
+	plan.num_particles = n_proto * K;
+	plan.num_constraints = pp.num_constraints * K;
+	plan.redundancy = pp.redundancy;
+	plan.batch_base.resize(batches.size() + 1);
+	{
+		uint64_t total = 0;
+		for (size_t b = 0; b < batches.size(); b++) { plan.batch_base[b] = (uint32_t)total; total += batches[b].count; }
+		if (total >= 0xffffffffull) { why = "too many constraints"; return false; }
+		plan.batch_base[batches.size()] = (uint32_t)total;
+	}
+	plan.tile_of.resize((size_t)n_proto * K);
+	for (uint32_t k = 0; k < K; k++)
+		for (uint32_t p = 0; p < n_proto; p++) plan.tile_of[(size_t)k * n_proto + p] = pp.tile_of[p] + k * kt;
+	const uint32_t threads = opt.threads ? opt.threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	plan.segs.resize(pp.segs.size());
+	for (size_t si = 0; si < pp.segs.size(); si++)
+	{
+		const FusedSegment &ps = pp.segs[si];
+		FusedSegment &seg = plan.segs[si];
+		const size_t n_idx = ps.idx.size(), n_par = ps.params.size(), n_gid = ps.gid.size(), n_cid = ps.slot_cid.size(), n_steps = ps.steps.size();
+		if ((uint64_t)n_idx * K * 2 >= 0xfffffff0ull || (uint64_t)n_par * K * 4 >= 0xfffffff0ull || (uint64_t)ps.lam_count * K * 4 >= 0xfffffff0ull)
+		{ why = "a segment stream exceeds 4 GiB"; return false; }
+		seg.colour_begin = ps.colour_begin; seg.colour_end = ps.colour_end;
+		seg.lam_count = ps.lam_count * K;
+		seg.max_local = ps.max_local;
+		seg.type_mask = ps.type_mask;
+		seg.slots = ps.slots * K; seg.constraints = ps.constraints * K; seg.stream_bytes = ps.stream_bytes * K;
+		seg.tiles.resize((size_t)kt * K);
+		seg.steps.resize(n_steps * K);
+		seg.idx.resize(n_idx * K);
+		seg.params.resize(n_par * K);
+		seg.gid.resize(n_gid * K);
+		seg.slot_cid.resize(n_cid * K);
+		parallel_for(K, threads, [&](uint32_t k, uint32_t) {
+			for (uint32_t t = 0; t < kt; t++)
+			{
+				FusedTile ft = ps.tiles[t];
+				ft.step_begin += (uint32_t)(k * n_steps); ft.step_end += (uint32_t)(k * n_steps);
+				ft.gid_off += (uint32_t)(k * n_gid);
+				seg.tiles[(size_t)k * kt + t] = ft;
+			}
+			memcpy(&seg.idx[k * n_idx], ps.idx.data(), n_idx * sizeof(uint16_t));
+			for (size_t i = 0; i < n_gid; i++) seg.gid[k * n_gid + i] = ps.gid[i] + k * n_proto;
+			// padding words of the parameter stream stay zero, like the prototype's
+			if (n_par) memset(&seg.params[k * n_par], 0, n_par * sizeof(float));
+			for (size_t s2 = 0; s2 < n_steps; s2++)
+			{
+				FusedStep st = ps.steps[s2];
+				const int type = (int)st.type;
+				const TypeInfo *ti = type_info(type);
+				const bool compact = plan.views[type].compact != 0;
+				const uint32_t np_stream = (uint32_t)num_planes(type, compact);
+				const uint32_t par_off0 = st.par_off, cid_off0 = st.cid_off;
+				st.idx_off += (uint32_t)(k * n_idx); st.par_off += (uint32_t)(k * n_par); st.lam_off += k * ps.lam_count; st.cid_off += (uint32_t)(k * n_cid);
+				seg.steps[k * n_steps + s2] = st;
+				if (!st.count) continue;
+				// a step is a run of ONE batch (one colour, one type): resolve the batch and the plane table once
+				const uint32_t cid_first = ps.slot_cid[cid_off0];
+				const size_t b = (size_t)(std::upper_bound(pp.batch_base.begin(), pp.batch_base.end(), cid_first) - pp.batch_base.begin()) - 1;
+				const uint32_t base_p = pp.batch_base[b], cnt_p = proto[b].count, base_full = plan.batch_base[b] + k * cnt_p;
+				int plane_of[PBDX_MAX_PARAMS];
+				for (uint32_t pk = 0; pk < ti->param_stride; pk++)
+					plane_of[pk] = param_streams(type, compact, (int)pk) ? param_plane(type, compact, (int)pk) : -1;
+				const float *recs = batches[b].params + (size_t)k * cnt_p * ti->param_stride;
+				float *dst0 = np_stream ? &seg.params[k * n_par + par_off0] : nullptr;
+				uint32_t *cid_dst = &seg.slot_cid[k * n_cid + cid_off0];
+				for (uint32_t q = 0; q < st.count; q++)
+				{
+					const uint32_t i = ps.slot_cid[cid_off0 + q] - base_p;       // position in the prototype's batch
+					cid_dst[q] = base_full + i;
+					if (np_stream)
+					{
+						const float *rec = recs + (size_t)i * ti->param_stride;
+						float *dst = dst0 + (size_t)(q / 64) * (np_stream * 64) + (q % 64);
+						for (uint32_t pk = 0; pk < ti->param_stride; pk++)
+							if (plane_of[pk] >= 0) dst[(size_t)plane_of[pk] * 64] = rec[pk];
+					}
+				}
+			}
+		});
+	}
+	lap("replicated");
+	plan.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+	return true;
+}
+
 
 void build_persistent_deps(const FusedPlan &plan, PersistentDeps &out)
 {

@@ -188,6 +188,15 @@ struct FusedPlan
 bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &batches,
 	const PlanOptions &opt, FusedPlan &out, std::string &why);
 
+// Instanced schedules (K congruent, disjoint copies of a prototype with `n_proto` particles, appended instance after instance:
+// every batch holds the prototype's constraints K times, copy k's particle indices = the prototype's + k * n_proto).
+// check_instancing verifies exactly that (a few host threads; O(total indices)).  build_instanced_plan plans the PROTOTYPE
+// (its share of the tiles) and replicates tiles, steps and streams K times with offset particle ids and every copy's own
+// parameter records: same kernels, same per-tile work as a plan of the whole -- set-up cost of one instance.
+bool check_instancing(uint32_t n_proto, uint32_t K, const std::vector<PlanBatch> &batches);
+bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const std::vector<PlanBatch> &batches,
+	const PlanOptions &opt, FusedPlan &out, std::string &why);
+
 // Symbolic execution: every particle carries a hash of its update history; the fused schedule must
 // produce, for every particle, the hash the colour-sequential sweep produces.  Also checks that
 // every particle is owned exactly once and that every local index is in range.

@@ -870,6 +870,7 @@ struct pbdx_solver
 	bool schedule_open = false;
 	uint64_t schedule_version = 0;
 	bool params_dirty = false;           // pbdx_solver_update_batch_params since the last commit
+	uint32_t inst_particles = 0, inst_count = 1;   // pbdx_solver_set_instancing: the schedule is inst_count congruent instances (hint, verified)
 
 	// options
 	int use_graph = 1;
@@ -917,6 +918,7 @@ struct pbdx_solver
 	// fused plan
 	FusedPlan plan;
 	std::vector<DeviceSegment> dsegs;
+	bool plan_instanced = false;         // the plan is one instance's, replicated
 	bool plan_built = false;             // an attempt was made for the current schedule
 	bool plan_ok = false;
 	std::string plan_why;
@@ -954,6 +956,7 @@ struct pbdx_solver
 		plan = FusedPlan();
 		plan_built = false;
 		plan_ok = false;
+		plan_instanced = false;
 		plan_why.clear();
 		fuse_choice = 1;
 		autotune_ms[0] = autotune_ms[1] = autotune_ms[2] = 0.0f;
@@ -1115,7 +1118,15 @@ int ensure_plan(pbdx_solver *s)
 		opt.launch_cost_ns = 1500.0;
 		opt.owned_stay_in_lds = true;
 	}
-	if (!build_fused_plan(s->n, s->h_x.data(), pbs, opt, s->plan, s->plan_why))
+	bool planned = false;
+	if (s->inst_count > 1 && (uint64_t)s->inst_particles * s->inst_count == s->n)
+	{
+		// K congruent instances: plan one, replicate (falls through to the plan of the whole if the hint does not hold)
+		std::string why_inst;
+		planned = build_instanced_plan(s->inst_particles, s->inst_count, s->h_x.data(), pbs, opt, s->plan, why_inst);
+		s->plan_instanced = planned;
+	}
+	if (!planned && !build_fused_plan(s->n, s->h_x.data(), pbs, opt, s->plan, s->plan_why))
 		return PBDX_OK;
 	// workgroup size per segment: enough threads to cover the largest colour step of a tile once, at most 1024
 	std::vector<int> blocks;
@@ -1947,6 +1958,22 @@ int pbdx_solver_commit_params(pbdx_solver *s)
 	return PBDX_OK;
 }
 
+int pbdx_solver_set_instancing(pbdx_solver *s, uint32_t particles_per_instance, uint32_t instances)
+{
+	if (!s) return PBDX_ERR_INVALID;
+	if (instances > 1 && !particles_per_instance) { set_error("set_instancing: particles_per_instance must be positive"); return PBDX_ERR_INVALID; }
+	const uint32_t k = instances ? instances : 1u;
+	if (k != s->inst_count || (k > 1 && particles_per_instance != s->inst_particles))
+	{
+		HIPCHECK(hipSetDevice(s->device));
+		HIPCHECK(hipStreamSynchronize(s->stream));
+		s->inst_count = k; s->inst_particles = k > 1 ? particles_per_instance : 0;
+		s->drop_graph();
+		if (s->plan_built) s->free_plan();
+	}
+	return PBDX_OK;
+}
+
 int pbdx_solver_validate_schedule(pbdx_solver *s)
 {
 	if (!s) return PBDX_ERR_INVALID;
@@ -2450,8 +2477,9 @@ int pbdx_solver_describe(pbdx_solver *s, char *buf, size_t n)
 		{
 			uint32_t ml = 0;
 			for (const FusedSegment &seg : s->plan.segs) ml = std::max(ml, seg.max_local);
-			int w2 = snprintf(buf + w, n - w, " schedule=%s segments=%zu tiles=%u redundancy=%.3f max_tile_particles=%u plan_s=%.2f",
-				s->persistent_active() ? "fused-persistent" : "fused", s->plan.segs.size(), s->plan.num_tiles, s->plan.redundancy, ml, s->plan.build_seconds);
+			int w2 = snprintf(buf + w, n - w, " schedule=%s segments=%zu tiles=%u redundancy=%.3f max_tile_particles=%u plan_s=%.2f%s",
+				s->persistent_active() ? "fused-persistent" : "fused", s->plan.segs.size(), s->plan.num_tiles, s->plan.redundancy, ml, s->plan.build_seconds,
+				s->plan_instanced ? " (one instance planned, replicated)" : "");
 			if (s->persist_refusals && w2 > 0 && (size_t)(w + w2) < n)
 				w2 += snprintf(buf + w + w2, n - w - w2, " persistent_refusals=%u", s->persist_refusals);
 			if ((s->autotune_ms[1] > 0.0f || s->autotune_ms[2] > 0.0f) && w2 > 0 && (size_t)(w + w2) < n)

@@ -8,7 +8,10 @@
 #include "pbdx_internal.h"
 #include "pbdx_plan.h"
 #include <string.h>
+#include <atomic>
 #include <memory>
+#include <thread>
+#include <algorithm>
 
 using namespace pbdx;
 
@@ -45,36 +48,65 @@ int upload_particles(pbdx_timestep *ts, pbdx_model *m)
 		m->mass.data(), m->inv_mass.data());
 }
 
-// Walk the model's colour groups, bucket each group by constraint type (creation order kept inside
-// a bucket) and hand every non-empty (group, type) batch to `emit`.
+// Walk the model's colour groups ONCE, bucket each group by constraint type (creation order kept inside a bucket) and hand
+// every non-empty (group, type) batch to `emit`.  An instanced model (pbdx_model_add_instances) emits the prototype's bucket
+// for instance 0, 1, ... in one batch (that IS the creation order of the colour group); the rest data of the copies is
+// evaluated here, straight into the batch arrays, by a few host threads (one slice of instances each).
 template <class F> int for_each_batch(pbdx_model *m, F &&emit)
 {
 	int r = pbdx_model_init_constraint_groups(m);        // TimeStepController.cpp:256
 	if (r) return r;
+	const uint32_t K = m->inst_count;
+	const uint32_t ncp = (uint32_t)m->constraints.size();
+	std::vector<uint32_t> members[PBDX_NUM_CONSTRAINT_TYPES];
 	std::vector<uint32_t> idx;
 	std::vector<float> par;
 	for (uint32_t g = 0; g < m->groups.size(); g++)
+	{
+		for (auto &v : members) v.clear();
+		for (uint32_t ci : m->groups[g]) members[m->constraints[ci].type].push_back(ci);
 		for (int type = 0; type < PBDX_NUM_CONSTRAINT_TYPES; type++)
 		{
+			const std::vector<uint32_t> &mem = members[type];
+			if (mem.empty()) continue;
 			const TypeInfo *ti = type_info(type);
-			idx.clear(); par.clear();
-			for (uint32_t ci : m->groups[g])
+			const uint32_t nb = ti->num_bodies, np = ti->param_stride;
+			const size_t cnt = mem.size();
+			idx.resize(cnt * K * nb);
+			par.resize(cnt * K * np);
+			std::atomic<int> bad(0);
+			auto fill = [&](uint32_t k0, uint32_t k1)
 			{
-				const HostConstraint &c = m->constraints[ci];
-				if (c.type != type) continue;
-				idx.insert(idx.end(), c.bodies, c.bodies + ti->num_bodies);
-				par.insert(par.end(), c.params, c.params + ti->param_stride);
+				HostConstraint c;
+				for (uint32_t k = k0; k < k1; k++)
+					for (size_t i = 0; i < cnt; i++)
+					{
+						if (!model_constraint(m, (uint64_t)k * ncp + mem[i], c)) { bad.store(1); continue; }
+						memcpy(&idx[((size_t)k * cnt + i) * nb], c.bodies, nb * sizeof(uint32_t));
+						memcpy(&par[((size_t)k * cnt + i) * np], c.params, np * sizeof(float));
+					}
+			};
+			const uint32_t threads = (K > 1 && cnt * K > 65536) ? std::min<uint32_t>(std::min<uint32_t>(K, 16u), std::max(1u, std::thread::hardware_concurrency())) : 1u;
+			if (threads <= 1) fill(0, K);
+			else
+			{
+				std::vector<std::thread> pool;
+				for (uint32_t t = 0; t < threads; t++) pool.emplace_back(fill, (uint32_t)((uint64_t)K * t / threads), (uint32_t)((uint64_t)K * (t + 1) / threads));
+				for (std::thread &t : pool) t.join();
 			}
-			if (idx.empty()) continue;
-			r = emit(g, type, (uint32_t)(idx.size() / ti->num_bodies), idx, par);
+			if (bad.load()) { set_error("an instance of the model is not congruent to its prototype (degenerate element)"); return PBDX_ERR_INVALID; }
+			r = emit(g, type, (uint32_t)(cnt * K), idx, par);
 			if (r) return r;
 		}
+	}
 	return PBDX_OK;
 }
 
 int build_schedule(pbdx_timestep *ts, pbdx_model *m)
 {
-	int r = pbdx_solver_begin_schedule(ts->solver);
+	int r = pbdx_solver_set_instancing(ts->solver, m->inst_particles, m->inst_count);
+	if (r) return r;
+	r = pbdx_solver_begin_schedule(ts->solver);
 	if (r) return r;
 	r = for_each_batch(m, [&](uint32_t g, int type, uint32_t count, const std::vector<uint32_t> &idx, const std::vector<float> &par) {
 		return pbdx_solver_add_batch(ts->solver, g, type, count, idx.data(), par.data(), type_info(type)->param_stride);
@@ -156,7 +188,12 @@ int pbdx_model_plan_check(pbdx_model *m, uint32_t tile_particles, uint32_t lds_p
 	if (max_segment_colours) opt.max_segment_colours = max_segment_colours;
 	FusedPlan plan;
 	std::string why;
-	if (!build_fused_plan(m->size(), m->x.data(), pbs, opt, plan, why)) { set_error("plan: %s", why.c_str()); return PBDX_ERR_INVALID; }
+	if (m->inst_count > 1)
+	{
+		// instanced model: the plan is one instance's, replicated; the checks below run on the replicated plan of the WHOLE
+		if (!build_instanced_plan(m->inst_particles, m->inst_count, m->x.data(), pbs, opt, plan, why)) { set_error("instanced plan: %s", why.c_str()); return PBDX_ERR_INVALID; }
+	}
+	else if (!build_fused_plan(m->size(), m->x.data(), pbs, opt, plan, why)) { set_error("plan: %s", why.c_str()); return PBDX_ERR_INVALID; }
 	if (!check_fused_plan(m->size(), pbs, plan, why)) { set_error("plan check: %s", why.c_str()); return PBDX_ERR_INVALID; }
 	{
 		// the persistent schedule's tile-to-tile dependency lists: asynchronous-execution check (three sweeps), and the

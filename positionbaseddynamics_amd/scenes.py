@@ -20,8 +20,14 @@ def rot_x_half_pi():
 
 
 def cloth_spec(n_cols, n_rows, cloth_method, bending_method, cloth_k=None, bending_k=None,
-               width=10.0, height=10.0, T=(0, 1, 0), pin=True, instances=1, instance_offset=(0, 0, 0)):
-    """Demos/ClothDemo/main.cpp:132-162 generalised to n_cols x n_rows and K instances."""
+               width=10.0, height=10.0, T=(0, 1, 0), pin=True, instances=1, instance_offset=(0, 0, 0), instanced=False):
+    """Demos/ClothDemo/main.cpp:132-162 generalised to n_cols x n_rows and K instances.  instanced=True: the K - 1 copies
+    are one ("instances", offsets) operation (SimulationModel.addInstances: built, coloured and stored once) instead of
+    K - 1 more rounds of builder calls; both describe the same model."""
+    if instanced and instances > 1:
+        ops = cloth_spec(n_cols, n_rows, cloth_method, bending_method, cloth_k, bending_k, width, height, T, pin)
+        offs = [tuple(np.float32(k) * np.float32(instance_offset[i]) for i in range(3)) for k in range(1, instances)]
+        return ops + [("instances", offs)]
     if cloth_k is None:
         cloth_k = 100000.0 if cloth_method == 4 else 1.0
     if bending_k is None:
@@ -43,8 +49,13 @@ def cloth_spec(n_cols, n_rows, cloth_method, bending_method, cloth_k=None, bendi
 
 
 def bar_spec(width, height, depth, solid_method, k=None, kv=None, poisson=0.3, T=(5, 0, 0),
-             scale=(10.0, 1.5, 1.5), ns=False, nsh=False, instances=1, instance_offset=(0.0, 0.0, 3.0)):
-    """Demos/BarDemo/main.cpp:130-166 generalised (and K independent bars for ensemble runs)."""
+             scale=(10.0, 1.5, 1.5), ns=False, nsh=False, instances=1, instance_offset=(0.0, 0.0, 3.0), instanced=False):
+    """Demos/BarDemo/main.cpp:130-166 generalised (and K independent bars for ensemble runs; instanced: see cloth_spec)."""
+    if instanced and instances > 1:
+        # (the plain K-instance form takes T as given for instance 0 and float32 arithmetic for the others: the same here)
+        ops = bar_spec(width, height, depth, solid_method, k, kv, poisson, tuple(np.float32(t) for t in T), scale, ns, nsh)
+        offs = [tuple(np.float32(q) * np.float32(instance_offset[i]) for i in range(3)) for q in range(1, instances)]
+        return ops + [("instances", offs)]
     if k is None:
         k = {3: 1000000.0, 6: 100000.0}.get(solid_method, 1.0)
     if kv is None:
@@ -184,6 +195,8 @@ def build_model(ops):
             m.addBendingConstraints(*op[1:])
         elif k == "solid":
             m.addSolidConstraints(*op[1:])
+        elif k == "instances":
+            m.addInstances(op[1])
         elif k == "constraint":
             if op[1] == "shape_matching":
                 ok = m.addShapeMatchingConstraint(len(op[2]), op[2], op[3], op[4])

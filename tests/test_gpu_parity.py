@@ -442,13 +442,26 @@ def test_full_size_c3_100k_tet_bar_vs_reference(pbd, method, iters, sub):
 def test_c4_ensemble_block_of_instances_vs_reference(pbd):
     """configs[3], one GPU's FULL share: 64 independent 200x200 sheets in one model (2 560 000 particles, 15 206 784
     constraints) against the reference on the same model, 2 steps x 10 iterations, bit-identical."""
-    ops = util.cloth_spec(200, 200, 4, 3, instances=64, instance_offset=(0.0, 0.0, 12.0))
-    want = _reference_states(ops, 10, [2], threads=32)
+    import time
+    ops = util.cloth_spec(200, 200, 4, 3, instances=64, instance_offset=(0.0, 0.0, 12.0), instanced=True)
+    want = _reference_states(ops, 10, [2], threads=32)           # the reference builds the 64 sheets one after the other
+    t0 = time.perf_counter()
+    m = util.build_mine(ops)
+    m.initConstraintGroups()
+    t_build = time.perf_counter() - t0
     m, ts = util.mine_run(ops, 2, 1, 10, resident=True)
+    d = ts.solver().describe()
+    print("C4 block: host build + colouring %.3f s; %s" % (t_build, d))
     print("C4 block plan:", ts.solver().plan_info(), ts.solver().persistent_info())
+    assert m.numInstances() == 64 and "one instance planned, replicated" in d
     assert m.getParticles().size() == 64 * 40000
     assert util.bitwise_equal(m.getParticles().positions(), want[2][0])
     assert util.bitwise_equal(m.getParticles().array(2), want[2][1])
+    # the same block built the long way round (64 rounds of builder calls, planned as a whole) gives the same bits
+    from oracle.scene_ref import expand_instances
+    m2, ts2 = util.mine_run(expand_instances(ops), 2, 1, 10, resident=True)
+    assert "replicated" not in ts2.solver().describe()
+    assert util.bitwise_equal(m2.getParticles().positions(), want[2][0])
 
 
 # ---------------------------------------------------------------------------

@@ -94,3 +94,63 @@ def test_empty_model_and_reset():
     assert np.array_equal(m.getParticles().positions(), x0) and not m.getParticles().velocities().any()
     m.cleanup()
     assert m.getParticles().size() == 0 and m.numConstraints() == 0
+
+
+# ---------------------------------------------------------------------------
+# instanced models (SimulationModel.addInstances): SURVEY 8e / 8f rank 3
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("spec", ["cloth", "bar_fem", "bar_distvol", "mixed"])
+def test_instanced_model_equals_the_reference_built_instance_after_instance(spec):
+    """One prototype + addInstances(K - 1 offsets) must BE the model the reference builds when the same builders are called K
+    times with translated meshes: particle arrays, constraint order, per-instance rest data (bitwise: every copy's rest
+    lengths / matrices are evaluated at ITS rest positions) and the colour groups -- integer-exact at K = 3 -- although
+    topology, constraints and groups are stored once."""
+    if spec == "cloth":
+        ops = util.cloth_spec(21, 17, 4, 3, width=7.0, height=3.0, instances=3, instance_offset=(0.37, 0.0, 12.1), instanced=True)
+    elif spec == "bar_fem":
+        ops = util.bar_spec(9, 4, 3, 2, instances=3, instance_offset=(0.0, 0.1, 3.3), instanced=True)
+    elif spec == "bar_distvol":
+        ops = util.bar_spec(8, 3, 3, 6, instances=3, instanced=True)
+    else:
+        rng = np.random.default_rng(11)
+        pts = rng.standard_normal((10, 3)).astype(np.float32)
+        faces = [(0, 1, 2), (0, 2, 3), (0, 3, 4), (2, 1, 6), (6, 1, 7), (3, 2, 9), (9, 2, 6), (4, 3, 8), (8, 3, 9), (5, 0, 4)]
+        ops = [("tri", 6, 5, (0.0, 1.0, 0.0), util.rot_x_half_pi(), (2.0, 2.0)), ("trimesh", pts, faces), ("vertex", (3.0, 3.0, 3.0)),
+               ("mass", 0, 0.0), ("cloth", 0, 4, 5e4, 1.0, 1.0, 1.0, 0.3, 0.3, False, False), ("bending", 0, 3, 50.0),
+               ("cloth", 1, 2, 1.0, 0.9, 1.1, 0.8, 0.25, 0.2, False, False), ("bending", 1, 1, 0.02),
+               ("constraint", "distance", [3, 30 + 10], 0.5),
+               ("instances", [(0.0, 0.0, 5.5), (7.25, 0.0, -3.0)])]
+    o, m = _compare(ops, sample=100000)          # every constraint
+    assert m.numInstances() == 3
+    # the same model built the long way round
+    from oracle.scene_ref import expand_instances
+    plain = util.build_mine(expand_instances(ops))
+    assert plain.numInstances() == 1 and plain.numConstraints() == m.numConstraints()
+    for which in (0, 1, 2, 4, 5, 6, 7):
+        assert util.bitwise_equal(plain.getParticles().array(which), m.getParticles().array(which)), which
+    assert [list(g) for g in plain.getConstraintGroups()] == [list(g) for g in m.getConstraintGroups()]
+    assert len(plain.getTriangleModels()) == len(m.getTriangleModels()) and len(plain.getTetModels()) == len(m.getTetModels())
+    for a, b in zip(plain.getTriangleModels(), m.getTriangleModels()):
+        assert a.getIndexOffset() == b.getIndexOffset() and np.array_equal(a.getEdges(), b.getEdges()) and np.array_equal(a.getParticleMesh().getFaces(), b.getParticleMesh().getFaces())
+    for a, b in zip(plain.getTetModels(), m.getTetModels()):
+        assert a.getIndexOffset() == b.getIndexOffset() and np.array_equal(a.getEdges(), b.getEdges())
+
+
+def test_instanced_model_is_sealed_and_rejects_non_congruent_copies():
+    import positionbaseddynamics_amd as pbd
+    m = util.build_mine(util.cloth_spec(6, 6, 4, 3, instances=2, instance_offset=(0, 0, 3.0), instanced=True))
+    nc = m.numConstraints()
+    assert not m.addDistanceConstraint(0, 1, 1.0) and m.numConstraints() == nc
+    with pytest.raises(pbd.PbdxError):
+        m.addRegularTriangleModel(3, 3)
+    with pytest.raises(pbd.PbdxError):
+        m.addInstances([(1.0, 0.0, 0.0)])
+    # user parameters live in the prototype: editing prototype constraint 5 changes constraint 5 of every copy
+    p = m.constraintParams(5)
+    p[1] = 77.0
+    m.setConstraintParams(5, p)
+    assert m.constraintParams(5 + nc // 2)[1] == 77.0
+    with pytest.raises(pbd.PbdxError):
+        m.setConstraintParams(5 + nc // 2, p)
+    m.cleanup()
+    assert m.numInstances() == 1 and m.numConstraints() == 0

@@ -85,3 +85,32 @@ def test_plan_star_graph_more_than_64_colours_and_huge_valence():
         info = m.planCheck(tile_particles=tile)
         assert info["num_colours"] == n
         assert info["num_segments"] >= n // 16      # default cap: 16 colours per launch
+
+
+@pytest.mark.parametrize("name,ops,tile", [
+    ("5 instanced cloths, 60 x 60", util.cloth_spec(60, 60, 4, 3, instances=5, instance_offset=(0.0, 0.0, 12.0), instanced=True), 0),
+    ("5 instanced cloths, small tiles", util.cloth_spec(30, 30, 4, 3, instances=5, instance_offset=(0.3, 0.0, 5.0), instanced=True), 100),
+    ("3 instanced FEM bars", util.bar_spec(14, 5, 4, 2, instances=3, instanced=True), 0),
+    ("4 instanced bars, XPBD distance + volume", util.bar_spec(10, 4, 4, 6, instances=4, instanced=True), 64),
+])
+def test_instanced_plan_is_one_instance_replicated_and_exact(name, ops, tile):
+    """for K congruent instances the planner plans ONE and replicates tiles / steps / streams with offset
+    particle ids and every copy's own parameter records.  The replicated plan of the WHOLE goes through the same symbolic
+    execution and asynchronous-execution checks as any other plan; it has K x the tiles and slots of the one-instance plan
+    and the same redundancy."""
+    from oracle.scene_ref import expand_instances
+    m = util.build_mine(ops)
+    K = m.numInstances()
+    assert K > 1
+    info = m.planCheck(tile_particles=tile)
+    single = util.build_mine([op for op in ops if op[0] != "instances"])
+    n1 = single.getParticles().size()
+    t1 = info["num_tiles"] // K
+    one = single.planCheck(tile_particles=tile if tile else (n1 + t1 - 1) // t1)
+    assert info["num_tiles"] == K * one["num_tiles"] and info["slots_per_sweep"] == K * one["slots_per_sweep"]
+    assert info["num_segments"] == one["num_segments"] and info["max_local"] == one["max_local"]
+    assert abs(info["redundancy"] - one["redundancy"]) < 1e-12
+    # the same scene built the long way (K rounds of builder calls) plans to the same amount of work per sweep when it is
+    # given the same tile size (its tiles may straddle instances, so only the totals are comparable)
+    plain = util.build_mine(expand_instances(ops))
+    assert plain.numInstances() == 1 and plain.numConstraints() == m.numConstraints()
