@@ -897,6 +897,7 @@ struct pbdx_solver
 	uint32_t persist_wgs_per_cu = 1;     // PBDX_OPT_PERSISTENT_WGS_PER_CU: tiles resident per CU in the one-launch schedule
 	float4 *d_snap[4] = { nullptr, nullptr, nullptr, nullptr };   // pos / vel / old / last as they were when the current call started (persistent schedule only)
 	bool last_folded = false;            // the substeps enqueued last ran integrate / velocity update inside the persistent launch
+	bool last_flips = false;             // ... and ended in the other position buffer (odd number of passes): swap_state() after each
 	double persist_ms = 0.0;             // last profiled step: summed duration / number of persistent launches
 	uint64_t persist_launches = 0;
 	persist_fn persist_kernel = nullptr;
@@ -924,10 +925,13 @@ struct pbdx_solver
 	std::string plan_why;
 
 	// cached graph of one substep
-	hipGraph_t graph = nullptr;
-	hipGraphExec_t graph_exec = nullptr;
+	// (two: with an odd number of passes per substep the folded launch ends in the OTHER position buffer, so the state
+	// alternates between the two physical buffers from substep to substep and the captured launch exists in both orientations)
+	hipGraph_t graph[2] = { nullptr, nullptr };
+	hipGraphExec_t graph_exec[2] = { nullptr, nullptr };
+	int phys = 0;                        // which physical buffer d_pos[0] (= the state, by name) currently is
 	struct GraphKey { float h; uint32_t iters; int vel; float g[3]; uint64_t sched; int block; int remap; uint32_t n; int fused; int persist; } key = {};
-	bool graph_valid = false;
+	bool graph_valid[2] = { false, false };
 
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 	std::vector<hipEvent_t> prof_events;
@@ -976,9 +980,12 @@ struct pbdx_solver
 	}
 	void drop_graph()
 	{
-		if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
-		if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
-		graph_valid = false;
+		for (int i = 0; i < 2; i++)
+		{
+			if (graph_exec[i]) { (void)hipGraphExecDestroy(graph_exec[i]); graph_exec[i] = nullptr; }
+			if (graph[i]) { (void)hipGraphDestroy(graph[i]); graph[i] = nullptr; }
+			graph_valid[i] = false;
+		}
 	}
 	void free_particles()
 	{
@@ -988,6 +995,9 @@ struct pbdx_solver
 		for (float4 *&p : d_snap) if (p) { (void)hipFree(p); p = nullptr; }
 		n = 0;
 	}
+	// the position buffers change roles: d_pos[0] is always the state by NAME (everything enqueued later sees the new roles;
+	// kernels already enqueued carry their own pointer values)
+	void swap_state() { std::swap(d_pos[0], d_pos[1]); phys ^= 1; }
 	bool fused_active() const { return fuse && plan_ok && !dsegs.empty() && (fuse == 1 || fuse_choice); }
 	bool persistent_active() const { return persistent && persist_ok && persist_choice && fused_active(); }
 	void unpin_all()
@@ -1578,11 +1588,15 @@ int enqueue_substep(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int v
 	// number of fused launches ends in buffer 0 again
 	const int start = (int)sweep_flips(s, iters);
 	s->last_folded = false;
-	if (s->persistent_active() && iters && s->n && start == 0)
+	s->last_flips = false;
+	if (s->persistent_active() && iters && s->n)
 	{
 		// The whole substep as ONE launch: pass 0 integrates while it stages, the last pass updates the velocities.
-		// Only with an even number of passes: pass 0 then reads the state buffer (0) and writes the other one, so no
-		// tile can overwrite state a neighbour has not integrated yet, and the last pass ends in buffer 0.
+		// Pass 0 reads the state buffer and writes the other one, so no tile can overwrite state a neighbour has not
+		// integrated yet.  With an even number of passes the last pass ends in the state buffer again; with an odd number it
+		// ends in the other one, and the two buffers change roles after the substep (the CALLER swaps them once the launch is
+		// enqueued: swap_state; a captured launch exists in both orientations).
+		s->last_flips = start != 0;
 		FoldArgs f;
 		f.vel = s->d_vel; f.old = s->d_old; f.last = s->d_last;
 		f.state_bytes = s->n * 16u;
@@ -2070,7 +2084,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	const uint64_t launches_per_sweep = s->fused_active() ? s->dsegs.size() : s->order.size();
 	s->stats = pbdx_step_stats();
 	s->stats.projections = proj_per_sweep * max_iterations * substeps_total;
-	s->stats.kernel_launches = (s->persistent_active() ? ((((uint64_t)max_iterations * s->dsegs.size()) & 1u) ? 3 : 1) : launches_per_sweep * max_iterations + 2) * substeps_total;
+	s->stats.kernel_launches = (s->persistent_active() ? 1 : launches_per_sweep * max_iterations + 2) * substeps_total;
 	s->stats.algorithmic_bytes = (bytes_per_sweep * max_iterations + (uint64_t)s->n * 140) * substeps_total;
 	memset(s->type_ms, 0, sizeof(s->type_ms));
 	memset(s->type_launches, 0, sizeof(s->type_launches));
@@ -2094,6 +2108,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 			ProfCursor pc; pc.s = s;
 			int r = enqueue_substep(s, hs, inv_h, max_iterations, vel, gravity, &pc);
 			if (r) return r;
+			if (s->last_flips) s->swap_state();
 			r = collect_profile(s, &pc);
 			if (r) return r;
 			if ((k + 1) % sub_steps == 0) { r = enqueue_contacts(s); if (r) return r; }
@@ -2103,24 +2118,34 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	else if (s->use_graph)
 	{
 		pbdx_solver::GraphKey k = { hs, max_iterations, vel, { gravity[0], gravity[1], gravity[2] }, s->schedule_version, s->block_size, s->xcd_remap, s->n, s->fused_active() ? 1 : 0, s->persistent_active() ? 1 : 0 };
-		if (!s->graph_valid || memcmp(&k, &s->key, sizeof(k)) != 0)
+		if (memcmp(&k, &s->key, sizeof(k)) != 0) { s->drop_graph(); s->key = k; }
+		bool flips = false;
+		auto capture = [&]() -> int
 		{
-			s->drop_graph();
+			// one substep in the orientation of the position buffers that holds now
 			HIPCHECK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
 			int r = enqueue_substep(s, hs, inv_h, max_iterations, vel, gravity, nullptr);
 			hipGraph_t g = nullptr;
 			hipError_t e = hipStreamEndCapture(s->stream, &g);
 			if (r) { if (g) (void)hipGraphDestroy(g); return r; }
 			if (e != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return PBDX_ERR_HIP; }
-			s->graph = g;
-			HIPCHECK(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
-			s->key = k;
-			s->graph_valid = true;
-		}
+			s->graph[s->phys] = g;
+			HIPCHECK(hipGraphInstantiate(&s->graph_exec[s->phys], g, nullptr, nullptr, 0));
+			s->graph_valid[s->phys] = true;
+			return PBDX_OK;
+		};
+		if (!s->graph_valid[s->phys]) { int r = capture(); if (r) return r; }
+		else (void)0;
+		// (last_flips is a property of the schedule, set by enqueue_substep during a capture; recompute it for a cached graph)
+		flips = s->persistent_active() && max_iterations && s->n && sweep_flips(s, max_iterations) != 0;
+		s->last_folded = s->persistent_active() && max_iterations && s->n;
+		s->last_flips = flips;
 		HIPCHECK(hipEventRecord(s->ev_start, s->stream));
 		for (uint64_t k2 = 0; k2 < substeps_total; k2++)
 		{
-			HIPCHECK(hipGraphLaunch(s->graph_exec, s->stream));
+			if (!s->graph_valid[s->phys]) { int r = capture(); if (r) return r; }
+			HIPCHECK(hipGraphLaunch(s->graph_exec[s->phys], s->stream));
+			if (flips) s->swap_state();
 			if ((k2 + 1) % sub_steps == 0) { int r = enqueue_contacts(s); if (r) return r; }
 		}
 		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
@@ -2132,6 +2157,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		{
 			int r = enqueue_substep(s, hs, inv_h, max_iterations, vel, gravity, nullptr);
 			if (r) return r;
+			if (s->last_flips) s->swap_state();
 			if ((k + 1) % sub_steps == 0) { r = enqueue_contacts(s); if (r) return r; }
 		}
 		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
@@ -2144,6 +2170,9 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		// launch per segment -- the result is the one an undisturbed run produces -- and stop using the schedule.
 		const uint64_t k = s->h_error[2];
 		const bool folded = s->last_folded;      // then not even the integration of substep k has happened
+		// substeps k .. end were no-ops, but the host swapped the buffer roles once per enqueued substep if the launch flips:
+		// the state still sits where it was when substep k started
+		if (s->last_flips && ((substeps_total - k) & 1u)) s->swap_state();
 		s->h_error[1] = s->h_error[2] = 0u;
 		s->persist_ok = false;
 		s->persist_refusals++;

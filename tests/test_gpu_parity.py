@@ -423,7 +423,8 @@ def test_full_size_c2_odd_pass_count(pbd):
     info, pinfo = ts.solver().plan_info(), ts.solver().persistent_info()
     print("C2 full size, 5 iterations:", info, pinfo)
     assert pinfo["active"] == 1 and pinfo["refusals"] == 0 and pinfo["timeouts"] == 0
-    assert (5 * info["num_segments"]) % 2 == 1 or pinfo["last_folded"] == 1
+    assert pinfo["last_folded"] == 1, "integration and velocity update run inside the launch for any pass count"
+    print("passes per substep: %d" % (5 * info["num_segments"]))
     assert util.bitwise_equal(m.getParticles().positions(), want[4][0])
     assert util.bitwise_equal(m.getParticles().array(2), want[4][1])
 
@@ -660,6 +661,13 @@ def test_persistent_schedule_is_bit_identical_and_recovers_from_a_refused_launch
               ("kitchen sink", util.kitchen_sink_spec(), 4, 2, 4, {}),
               ("fem bar", util.bar_spec(30, 6, 6, 2), 4, 1, 5, {}),
               ("xpbd cloth 120x120, 60-particle tiles (more tiles than CUs)", util.cloth_spec(120, 120, 4, 3), 3, 1, 4, {"opts": {S.OPT_TILE_PARTICLES: 48}})]
+    # both parities of the number of passes per substep (iterations x segments) must be covered: with an odd number the
+    # folded launch ends in the other position buffer and the two buffers change roles from substep to substep
+    scenes += [("xpbd cloth 70x70, 5 iterations", util.cloth_spec(70, 70, 4, 3), 5, 3, 5, {}),
+               ("xpbd cloth 70x70, 5 iterations, at most 5 colours per pass", util.cloth_spec(70, 70, 4, 3), 3, 2, 5, {"opts": {S.OPT_MAX_SEGMENT_COLOURS: 5}}),
+               ("xpbd cloth 70x70, 5 iterations, at most 9 colours per pass", util.cloth_spec(70, 70, 4, 3), 3, 2, 5, {"opts": {S.OPT_MAX_SEGMENT_COLOURS: 9}}),
+               ("xpbd cloth 70x70, 4 iterations, at most 5 colours per pass", util.cloth_spec(70, 70, 4, 3), 3, 2, 4, {"opts": {S.OPT_MAX_SEGMENT_COLOURS: 5}})]
+    parities = set()
     for label, ops, steps, sub, iters, extra in scenes:
         opts = dict(extra.get("opts", {}))
         opts[S.OPT_FUSE] = 1
@@ -676,10 +684,14 @@ def test_persistent_schedule_is_bit_identical_and_recovers_from_a_refused_launch
                 assert eligible_before, (label, info)
             if mode == 2:
                 assert info["active"] == info["eligible"] and info["refusals"] == 0, (label, info)
+                if info["active"]:
+                    assert info["last_folded"] == 1, (label, info)
+                    parities.add((iters * ts.solver().plan_info()["num_segments"]) % 2)
             else:
                 assert info["active"] == 0 and info["refusals"] == (1 if eligible_before else 0), (label, info)
             assert util.bitwise_equal(m.getParticles().positions(), xr), (label, mode, resident)
             assert util.bitwise_equal(m.getParticles().array(2), vr), (label, mode, resident)
+    assert parities == {0, 1}, "both parities of the pass count must have been exercised: %r" % (parities,)
 
 
 @pytest.mark.gpu
