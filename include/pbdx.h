@@ -311,7 +311,9 @@ int pbdx_solver_set_profiling(pbdx_solver *s, int profile_kernels);
 int pbdx_solver_get_type_stats(pbdx_solver *s, int type, double *ms, uint64_t *launches, uint64_t *projections);
 /* Counter calibration (developer aid for rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): one streaming
  * kernel over `nbytes` of HBM in one of the engine's access widths.  mode 0: 4-byte reads
- * (kernel calib_read_b32), 1: 16-byte reads (calib_read_b128), 2: 4-byte writes, 3: 16-byte writes. */
+ * (kernel calib_read_b32), 1: 16-byte reads (calib_read_b128), 2: 4-byte writes, 3: 16-byte writes, 4: the buffer read EIGHT times in
+ * one launch with 16-byte loads (calib_reread_b128: with a buffer between the L2 and the Infinity-Cache size this tells whether a
+ * counter sees Infinity-Cache hits). */
 int pbdx_debug_stream(int device, uint64_t nbytes, int mode);
 /* SURVEY 8d algorithmic bytes per projection of a type. */
 uint32_t pbdx_type_algorithmic_bytes(int type);

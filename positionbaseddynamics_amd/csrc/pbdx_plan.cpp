@@ -326,7 +326,13 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	// ---- segment boundaries: dynamic programme over a sample of tiles ---------------------------
 	// (developer aid: PBDX_PLAN_SLOT_SCALE / PBDX_PLAN_FIXED_NS / PBDX_PLAN_LAUNCH_NS rescale the time model to explore other
 	// segmentations on the GPU; never set in production)
-	const double slot_scale = getenv("PBDX_PLAN_SLOT_SCALE") ? atof(getenv("PBDX_PLAN_SLOT_SCALE")) : 1.0;
+	// Small scenes (512-particle tiles, fewer tiles than CUs): a colour step of a tile holds fewer slots than the workgroup has
+	// lanes, so its duration is one projection chain of a lone wave whatever the slot count (step traces of the 100 k-tet bar:
+	// 1.00 us for every step of 100-250 FEM slots; lone-wave VALU issue interval 4.5 cycles, scripts/microbench/valu_single.hip)
+	// and redundant halo slots are nearly free: the per-slot cost is discounted, which makes segments longer (fewer tile-to-tile
+	// hand-offs per sweep).  Measured on the bar: 5 -> 4 passes per sweep, -3 % (FEM), -3 % (XPBD distance + volume).
+	const bool latency_bound = (uint64_t)n <= (uint64_t)std::max(1u, opt.num_cus) * 512u;
+	const double slot_scale = getenv("PBDX_PLAN_SLOT_SCALE") ? atof(getenv("PBDX_PLAN_SLOT_SCALE")) : (latency_bound ? 0.3 : 1.0);
 	const double fixed_ns = getenv("PBDX_PLAN_FIXED_NS") ? atof(getenv("PBDX_PLAN_FIXED_NS")) : kColourFixedNs;
 	const double launch_ns = getenv("PBDX_PLAN_LAUNCH_NS") ? atof(getenv("PBDX_PLAN_LAUNCH_NS")) : opt.launch_cost_ns;
 	const uint32_t maxlen = std::max(1u, std::min(opt.max_segment_colours, ncol));

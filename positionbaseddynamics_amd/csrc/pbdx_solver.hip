@@ -802,6 +802,19 @@ __global__ __launch_bounds__(256) void calib_read_b128(const float4 *__restrict_
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { const float4 v = src[i]; acc += v.x + v.w; }
 	if (acc == 123.456f) sink[0] = acc;
 }
+// the same buffer read `passes` times in one launch: larger than the L2s, smaller than the 256 MiB Infinity Cache -- tells
+// whether a memory-side counter sees Infinity-Cache hits (scripts/mall_counters.sh)
+__global__ __launch_bounds__(256) void calib_reread_b128(const float4 *__restrict__ src, float *__restrict__ sink, size_t n, int passes)
+{
+	float acc = 0.0f;
+	for (int p = 0; p < passes; p++)
+		for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+		{
+			const float4 v = src[(i + (size_t)p * 977) % n];
+			acc += v.x + v.w;
+		}
+	if (acc == 123.456f) sink[0] = acc;
+}
 __global__ __launch_bounds__(256) void calib_write_b32(float *__restrict__ dst, size_t n)
 {
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = 1.0f;
@@ -2484,7 +2497,8 @@ int pbdx_debug_stream(int device, uint64_t nbytes, int mode)
 	case 1: hipLaunchKernelGGL(calib_read_b128, grid, block, 0, 0, reinterpret_cast<const float4 *>(buf), sink, (size_t)(nbytes / 16)); break;
 	case 2: hipLaunchKernelGGL(calib_write_b32, grid, block, 0, 0, buf, (size_t)(nbytes / 4)); break;
 	case 3: hipLaunchKernelGGL(calib_write_b128, grid, block, 0, 0, reinterpret_cast<float4 *>(buf), (size_t)(nbytes / 16)); break;
-	default: (void)hipFree(buf); (void)hipFree(sink); set_error("debug_stream: mode 0..3"); return PBDX_ERR_INVALID;
+	case 4: hipLaunchKernelGGL(calib_reread_b128, grid, block, 0, 0, reinterpret_cast<const float4 *>(buf), sink, (size_t)(nbytes / 16), 8); break;
+	default: (void)hipFree(buf); (void)hipFree(sink); set_error("debug_stream: mode 0..4"); return PBDX_ERR_INVALID;
 	}
 	HIPCHECK(hipGetLastError());
 	HIPCHECK(hipDeviceSynchronize());

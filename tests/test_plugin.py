@@ -264,3 +264,79 @@ def test_plugin_full_size_c2_reference_model():
         t_first, 1e3 * t_round, 1e3 * t_res, 1e3 * t_sync))
     ref.reset_all()
     assert t_res < 1.5e-3 and t_round < 8e-3
+
+
+# ---------------------------------------------------------------------------
+# the compiled python side: a reduced pypbd module with TimeStepControllerHIP registered (plugin/pypbd_reduced.cpp)
+# ---------------------------------------------------------------------------
+_PYPBD_RUN = r'''
+import sys, json, importlib.util
+import numpy as np
+spec = importlib.util.spec_from_file_location("ex", %(example)r)
+ex = importlib.util.module_from_spec(spec); spec.loader.exec_module(ex)
+pbd = ex.pbd
+out = {}
+for sim_model, bend in ((2, 2), (4, 3)):
+    xs = {}
+    for gpu in %(modes)r:
+        pbd.Simulation.setCurrent(pbd.Simulation())
+        pbd.TimeManager.getCurrent().setTime(0.0)
+        ex.buildModel(sim_model, bend, gpu)
+        x0 = np.array(pbd.Simulation.getCurrent().getModel().getParticles().getVertices(), copy=True)
+        for frame in range(2):
+            ex.timeStep()
+        x = np.array(pbd.Simulation.getCurrent().getModel().getParticles().getVertices(), copy=True)
+        ts = pbd.Simulation.getCurrent().getTimeStep()
+        xs[gpu] = x
+        out["%%d%%d_%%s" %% (sim_model, bend, "gpu" if gpu else "cpu")] = dict(
+            type=type(ts).__name__, moved=bool(np.abs(x - x0).max() > 0), finite=bool(np.isfinite(x).all()),
+            gpu_steps=ts.numGpuSteps() if gpu else None, failed=ts.numFailedSteps() if gpu else None,
+            is_controller=isinstance(ts, pbd.TimeStepController))
+    if True in xs and False in xs:
+        a, b = xs[True].astype(np.float32), xs[False].astype(np.float32)
+        out["%%d%%d_bitwise" %% (sim_model, bend)] = bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+        out["%%d%%d_maxabs" %% (sim_model, bend)] = float(np.abs(a - b).max())
+print("RESULT " + json.dumps(out))
+'''
+
+
+def _run_pypbd(modes):
+    import glob
+    import json
+    import subprocess
+    import sys
+    if not glob.glob(os.path.join(PLUGIN_DIR, "pypbd*.so")):
+        pytest.skip("reduced pypbd module not built (needs /root/reference at build time)")
+    code = _PYPBD_RUN % {"example": os.path.join(util.ROOT, "examples", "cloth_model_pypbd.py"), "modes": modes}
+    # own process: the module shares the reference's singletons (Simulation::current ...) with oracle/refdrv
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+def test_compiled_pypbd_registers_the_hip_time_step(have_gpu):
+    """`pypbd.TimeStepControllerHIP` exists in a compiled pypbd module, is a TimeStepController, is accepted by
+    Simulation.setTimeStep, inherits the parameter ids (setValueUInt(NUM_SUB_STEPS, 3) in the example) -- and without a GPU
+    refuses every step instead of computing anything on the host."""
+    if have_gpu:
+        pytest.skip("GPU present: covered by the gpu test")
+    res = _run_pypbd([True])
+    for key in ("22_gpu", "43_gpu"):
+        r = res[key]
+        assert r["type"] == "TimeStepControllerHIP" and r["is_controller"]
+        assert r["gpu_steps"] == 0 and r["failed"] == 16 and not r["moved"] and r["finite"]
+
+
+@pytest.mark.gpu
+def test_reference_python_example_through_compiled_pypbd_on_the_gpu():
+    """pyPBD/examples/cloth_model.py's logic, `import pypbd as pbd` unchanged, three lines added to install the GPU time
+    step: 16 steps x 3 substeps for the example's default (FEM triangles + isometric bending) and for the XPBD variant,
+    bit-identical to the same script with the reference's own TimeStepController left in place (same float host)."""
+    res = _run_pypbd([True, False])
+    for key in ("22", "43"):
+        g, c = res[key + "_gpu"], res[key + "_cpu"]
+        assert g["type"] == "TimeStepControllerHIP" and c["type"] == "TimeStepController"
+        assert g["gpu_steps"] == 16 and g["failed"] == 0 and g["moved"] and c["moved"]
+        print("compiled pypbd, model %s: bitwise %s, max abs %.3e" % (key, res[key + "_bitwise"], res[key + "_maxabs"]))
+        assert res[key + "_bitwise"], res[key + "_maxabs"]
