@@ -36,10 +36,9 @@ def rotation_matrix(angle, axis):
 def buildModel(simModel=2, bendingModel=2, gpu=True):
     sim = pbd.Simulation.getCurrent()
     sim.initDefault()
-    if gpu:
-        ts = pbd.TimeStepControllerHIP()      # <-- the drop-in: three lines
-        sim.setTimeStep(ts)                   # <--
-        ts.init()                             # <--
+    ts = pbd.TimeStepControllerHIP() if gpu else pbd.TimeStepController()      # <-- the drop-in: the class name ...
+    sim.setTimeStep(ts)                                                        # <-- ... installed like any custom time step
+    ts.init()                                                                  # <--
     createMesh(simModel, bendingModel)
     ts = sim.getTimeStep()
     ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 3)

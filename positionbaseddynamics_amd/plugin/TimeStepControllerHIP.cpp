@@ -97,14 +97,18 @@ TimeStepControllerHIP::TimeStepControllerHIP(int device) :
 	TimeStepController(), m_solver(nullptr), m_device(device), m_scheduleValid(false),
 	m_numConstraints(0), m_numParticles(0), m_gpuSteps(0), m_fallbackSteps(0), m_failedSteps(0), m_paramRefreshes(0), m_scheduleBuilds(0), m_uploads(0),
 	m_allowFallback(false), m_deviceAhead(false), m_hostDirty(false), m_imageValid(false), m_paramsDirty(false), m_paramHash(0),
-	m_supportedFor(nullptr), m_supportedConstraints(0), m_supportedBodies(0), m_supportedObjects(0), m_supported(false)
+	m_supportedFor(nullptr), m_supportedConstraints(0), m_supportedBodies(0), m_supportedObjects(0), m_supported(false), m_accelValid(false)
 {
+	m_accelGravity[0] = m_accelGravity[1] = m_accelGravity[2] = 0;
 	for (int k = 0; k < 5; k++) m_hostHash[k] = 0;
 	if (pbdx_solver_create(&m_solver, device) != PBDX_OK)
 	{
 		LOG_ERR << "TimeStepControllerHIP: " << pbdx_last_error() << " -- every step() will fail (no CPU path)";
 		m_solver = nullptr;
 	}
+	// ParticleData's arrays are handed to the engine in place: page-lock them (hipHostRegister) so that the per-step round trip
+	// of step() runs at the PCIe rate (setPinHostArrays(false) switches that off)
+	if (m_solver) pbdx_solver_set_option(m_solver, PBDX_OPT_PIN_HOST, 1);
 }
 
 // A step the engine cannot run: loud error, model untouched -- unless the host opted in to the
@@ -137,6 +141,7 @@ void TimeStepControllerHIP::reset()
 	// Simulation::reset resets the model on the host (SimulationModel::reset): the host is authoritative again
 	m_deviceAhead = false;
 	m_hostDirty = true;
+	m_accelValid = false;
 }
 
 // The scan over all constraints (one virtual call each) is repeated only when the model's make-up changed.
@@ -258,18 +263,27 @@ bool TimeStepControllerHIP::uploadParticles(SimulationModel &model)
 {
 	ParticleData &pd = model.getParticles();
 	const unsigned int n = pd.size();
-	if (n != m_numParticles) m_scheduleValid = false;      // the engine drops its schedule with the old particle image
+	if (n != m_numParticles) { m_scheduleValid = false; m_accelValid = false; m_invMass32.clear(); m_invMass64.clear(); }      // the engine drops its schedule with the old particle image
 	m_numParticles = n;
 	m_uploads++;
 	int r;
 #ifdef USE_DOUBLE
-	m_invMass64.resize(n);
-	for (unsigned int i = 0; i < n; i++) m_invMass64[i] = pd.getInvMass(i);
+	if (m_invMass64.size() != n || m_hostDirty || (n && sampleHash(&pd.getMass(0), n, sizeof(Real)) != m_hostHash[4]))
+	{
+		m_invMass64.resize(n);
+		for (unsigned int i = 0; i < n; i++) m_invMass64[i] = pd.getInvMass(i);
+		m_accelValid = false;
+	}
 	r = n ? pbdx_solver_set_particles_f64(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0],
 		&pd.getMass(0), m_invMass64.data()) : PBDX_OK;
 #else
-	m_invMass32.resize(n);
-	for (unsigned int i = 0; i < n; i++) m_invMass32[i] = pd.getInvMass(i);
+	// (gathered again only when the masses changed: sampled hash, or markHostDirty())
+	if (m_invMass32.size() != n || m_hostDirty || (n && sampleHash(&pd.getMass(0), n, sizeof(Real)) != m_hostHash[4]))
+	{
+		m_invMass32.resize(n);
+		for (unsigned int i = 0; i < n; i++) m_invMass32[i] = pd.getInvMass(i);
+		m_accelValid = false;
+	}
 	r = n ? pbdx_solver_set_particles(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0],
 		&pd.getMass(0), m_invMass32.data()) : PBDX_OK;
 #endif
@@ -419,6 +433,18 @@ bool TimeStepControllerHIP::prepare(SimulationModel &model, bool forceUpload)
 	return uploadColliders(model);                          // cheap; poses / coefficients are host-mutable between steps
 }
 
+// TimeStep::clearAccelerations (TimeStep.cpp:28-62) writes a_i = gravity for every dynamic particle, every step -- a serial pass
+// over all particles whose result only changes when the gravity vector or the masses do: it is repeated only then.
+void TimeStepControllerHIP::refreshAccelerations(SimulationModel &model)
+{
+	Simulation *sim = Simulation::getCurrent();
+	const Real *gr = sim->getVecValue<Real>(Simulation::GRAVITATION);
+	if (m_accelValid && gr[0] == m_accelGravity[0] && gr[1] == m_accelGravity[1] && gr[2] == m_accelGravity[2]) return;
+	clearAccelerations(model);
+	m_accelGravity[0] = gr[0]; m_accelGravity[1] = gr[1]; m_accelGravity[2] = gr[2];
+	m_accelValid = true;
+}
+
 bool TimeStepControllerHIP::runSteps(SimulationModel &model, unsigned int numSteps)
 {
 	TimeManager *tm = TimeManager::getCurrent();
@@ -451,7 +477,7 @@ void TimeStepControllerHIP::step(SimulationModel &model)
 	bool ok = prepare(model, /*forceUpload=*/!m_deviceAhead);
 	if (ok)
 	{
-		clearAccelerations(model);                          // host-visible side effect of TimeStepController.cpp:84
+		refreshAccelerations(model);                        // host-visible side effect of TimeStepController.cpp:84
 		ok = runSteps(model, 1);
 	}
 	if (ok)
@@ -498,7 +524,7 @@ bool TimeStepControllerHIP::syncToHost(SimulationModel &model)
 {
 	if (!m_solver || !m_imageValid || model.getParticles().size() != m_numParticles) return false;
 	if (!downloadParticles(model)) return false;
-	clearAccelerations(model);
+	refreshAccelerations(model);
 	if (m_collisionDetection != NULL) model.resetContacts();
 	return true;
 }

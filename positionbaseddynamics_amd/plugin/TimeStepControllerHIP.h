@@ -60,7 +60,9 @@ namespace PBD
 		bool syncFromHost(SimulationModel &model);
 		/** tell the plug-in that ParticleData was written on the host since the last sync (the sampled hash can miss a
 		 * single-particle edit in a large model) */
-		void markHostDirty() { m_hostDirty = true; }
+		void markHostDirty() { m_hostDirty = true; m_accelValid = false; }
+		/** page-lock ParticleData's arrays for the transfers of step() (default on) */
+		void setPinHostArrays(bool b) { if (m_solver) pbdx_solver_set_option(m_solver, PBDX_OPT_PIN_HOST, b ? 1 : 0); }
 		/** the device holds a newer state than ParticleData */
 		bool deviceAhead() const { return m_deviceAhead; }
 
@@ -93,6 +95,7 @@ namespace PBD
 		uint64_t hashParameters(SimulationModel &model) const;
 		void hashHostState(SimulationModel &model, uint64_t out[5]) const;
 		void refuse(SimulationModel &model, const char *why);
+		void refreshAccelerations(SimulationModel &model);
 
 		pbdx_solver *m_solver;
 		int m_device;
@@ -111,6 +114,7 @@ namespace PBD
 		uint64_t m_paramHash;
 		// what `supported` was last evaluated for
 		const void *m_supportedFor; size_t m_supportedConstraints, m_supportedBodies, m_supportedObjects; bool m_supported;
+		bool m_accelValid; Real m_accelGravity[3];
 		std::vector<float> m_invMass32;
 		std::vector<double> m_invMass64;
 	};

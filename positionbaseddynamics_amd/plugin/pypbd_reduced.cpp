@@ -94,12 +94,14 @@ PYBIND11_MODULE(pypbd, m)
 		.def("addBendingConstraints", &SimulationModel::addBendingConstraints)
 		.def("numConstraints", [](SimulationModel &model) { return model.getConstraints().size(); });
 
-	py::class_<TimeStep, GenParam::ParameterObject>(m, "TimeStep")
+	// (py::nodelete on the time step classes: Simulation::setTimeStep takes ownership and ~Simulation deletes its time step,
+	// Simulation.cpp:22-28 -- the pattern of Demos/PositionBasedElasticRodsDemo/PositionBasedElasticRodsDemo.cpp:51-54)
+	py::class_<TimeStep, GenParam::ParameterObject, std::unique_ptr<TimeStep, py::nodelete>>(m, "TimeStep")
 		.def("step", &TimeStep::step)
 		.def("reset", &TimeStep::reset)
 		.def("init", &TimeStep::init);
 
-	py::class_<TimeStepController, TimeStep>(m, "TimeStepController")
+	py::class_<TimeStepController, TimeStep, std::unique_ptr<TimeStepController, py::nodelete>>(m, "TimeStepController")
 		.def_readwrite_static("NUM_SUB_STEPS", &TimeStepController::NUM_SUB_STEPS)
 		.def_readwrite_static("MAX_ITERATIONS", &TimeStepController::MAX_ITERATIONS)
 		.def_readwrite_static("MAX_ITERATIONS_V", &TimeStepController::MAX_ITERATIONS_V)
@@ -109,8 +111,6 @@ PYBIND11_MODULE(pypbd, m)
 		.def(py::init<>());
 
 	// ---- the addition to pypbd ---------------------------------------------------------------------------------------
-	// (py::nodelete: Simulation::setTimeStep takes ownership and deletes its time step in ~Simulation, Simulation.cpp:24 --
-	// the pattern of Demos/PositionBasedElasticRodsDemo/PositionBasedElasticRodsDemo.cpp:51-54)
 	py::class_<TimeStepControllerHIP, TimeStepController, std::unique_ptr<TimeStepControllerHIP, py::nodelete>>(m, "TimeStepControllerHIP")
 		.def(py::init<int>(), py::arg("device") = 0)
 		.def("stepResident", &TimeStepControllerHIP::stepResident, py::arg("model"), py::arg("numSteps") = 1)

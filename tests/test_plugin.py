@@ -279,7 +279,7 @@ out = {}
 for sim_model, bend in ((2, 2), (4, 3)):
     xs = {}
     for gpu in %(modes)r:
-        pbd.Simulation.setCurrent(pbd.Simulation())
+        # (Simulation.getCurrent() creates AND initialises the singleton, Simulation.cpp:30-38; every leg installs its own time step)
         pbd.TimeManager.getCurrent().setTime(0.0)
         ex.buildModel(sim_model, bend, gpu)
         x0 = np.array(pbd.Simulation.getCurrent().getModel().getParticles().getVertices(), copy=True)
@@ -309,7 +309,10 @@ def _run_pypbd(modes):
         pytest.skip("reduced pypbd module not built (needs /root/reference at build time)")
     code = _PYPBD_RUN % {"example": os.path.join(util.ROOT, "examples", "cloth_model_pypbd.py"), "modes": modes}
     # own process: the module shares the reference's singletons (Simulation::current ...) with oracle/refdrv
-    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    # (OMP_NUM_THREADS=1: the reference forks / joins one parallel region per colour group; on a 256-thread host that costs more
+    # than the 2 500-particle sheet it distributes)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240,
+                       env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert p.returncode == 0, p.stderr[-3000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     return json.loads(line[7:])
