@@ -214,6 +214,53 @@ int pbdx_solver_set_contact_params(pbdx_solver *s, float tolerance, float contac
  * pbdx_solver_step itself returns PBDX_ERR_UNSUPPORTED for such a call (the reference has no per-particle limit). */
 int pbdx_solver_get_num_contacts(pbdx_solver *s, uint32_t *out);
 
+/* ---- contacts between deformable solids (second half) -----------------------------------------------------
+ * Tet models that carry an analytic distance field in their rest frame (DistanceFieldCollisionDetection::addCollisionBox / ...
+ * on a TetModelCollisionObjectType body + initTetBVH, DistanceFieldCollisionDetection.cpp:496-509,730-742) colliding with the
+ * particles of the other tet models: detection = collisionDetectionSolidSolid (:361-483: dual bounding-sphere-hierarchy traversal,
+ * point-in-tet, rest-frame distance field, findRefTetAt :744-812) once per step after the substeps; the resulting
+ * ParticleTetContactConstraints are solved sequentially inside the iteration loop of the NEXT step
+ * (TimeStepController.cpp:288-291, Constraints.cpp:2236-2277, PositionBasedDynamics.cpp:1220-1265).
+ * The bounding-sphere hierarchies are built by the host application (the reference constructs them with std::sort on tied
+ * coordinates when the collision object is registered): the engine takes their structure -- entity order, nodes = (child0, child1,
+ * begin, count), -1 = no child -- and refreshes the spheres every step like KDTree::update; the rest-pose tet hierarchy also needs its
+ * (static) spheres.  Contacts are produced, and solved, in the reference's list order for ONE OpenMP thread (the reference's own
+ * order is thread-count dependent, DistanceFieldCollisionDetection.cpp:176-196).  Friction of these contacts must be 0: the
+ * reference's friction impulse reads an uninitialised multiplier (see pbdx_tetcontact.h); with 0 the velocity solve is a no-op.
+ * While tet colliders are set the sweeps of a substep run as one launch per segment / colour (the contact solve sits between
+ * the iterations). */
+typedef struct pbdx_bvh
+{
+	uint32_t num_nodes, num_entities;
+	const uint32_t *entities;      /* kd-tree entity order (m_lst) */
+	const int32_t *nodes;          /* 4 per node: child0, child1, begin, count */
+	const float *hulls;            /* 4 per node (centre, radius): required for the rest-pose hierarchy, ignored for the others */
+} pbdx_bvh;
+typedef struct pbdx_tet_collider
+{
+	int shape, invert;             /* PBDX_SHAPE_*, m_invertSDF == -1 */
+	float params[4];               /* as pbdx_collider */
+	uint32_t first_particle, num_vertices, num_tets;
+	const uint32_t *tets;          /* 4 model-local vertex indices per tet (IndexedTetMesh::getTets) */
+	float initial_x[3], initial_R[9]; /* TetModel::getInitialX / getInitialR (row-major): rest frame of the distance field */
+	float restitution, friction;   /* of the tet model (friction must be 0) */
+	int test_mesh;                 /* m_testMesh: the model's particles are tested against the other solids */
+	uint32_t body_index;           /* tet model index (reported in the contacts) */
+	pbdx_bvh points, tets_bvh, tets_rest; /* m_bvh, m_bvhTets, m_bvhTets0 */
+} pbdx_tet_collider;
+/* tolerance = CollisionDetection::m_tolerance.  Needs rest positions: pbdx_solver_set_rest_positions (default: the positions of
+ * the first pbdx_solver_set_particles call). */
+int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_collider *colliders, float tolerance);
+int pbdx_solver_set_rest_positions(pbdx_solver *s, uint32_t n, const float *x0);   /* ParticleData::m_x0, packed xyz */
+/* The contact list of the last detection, 30 floats per contact: particle, solid, tet, bary[3], normal[3], 1/(J M^-1 J^T),
+ * m_x[4][3], m_invMasses[4], tet vertex particle ids[4] (indices as floats).  *count = number of contacts (may exceed capacity). */
+#define PBDX_TET_CONTACT_FLOATS 30
+int pbdx_solver_get_tet_contacts(pbdx_solver *s, uint32_t capacity, uint32_t *count, float *out);
+/* The same detection evaluated on the HOST by the same code (pbdx_tetcontact.h is host + device): developer / test aid, no GPU
+ * needed.  pos4 / rest4: n x (x, y, z, invMass) records. */
+int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float *rest4, uint32_t n, const pbdx_tet_collider *colliders,
+	float tolerance, uint32_t capacity, uint32_t *count, float *out);
+
 /* XPBD multipliers of batch `batch_index` (order of add_batch calls). */
 int pbdx_solver_get_lambdas(pbdx_solver *s, uint32_t batch_index, uint32_t count, float *out);
 

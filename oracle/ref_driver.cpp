@@ -95,6 +95,29 @@ namespace {
 	}
 }
 
+// nodes of a bounding-sphere hierarchy are numbered in creation order; their number is found by walking the tree
+template <class BVH> static unsigned dumpBvh(const BVH &bvh, unsigned ne, unsigned *lst, unsigned lstCap, int *nodes, double *hulls, unsigned nodeCap)
+{
+	if (!ne) return 0;
+	std::vector<unsigned> stack; stack.push_back(0);
+	unsigned maxIdx = 0;
+	while (!stack.empty())
+	{
+		const unsigned n = stack.back(); stack.pop_back();
+		if (n > maxIdx) maxIdx = n;
+		if (!bvh.node(n).is_leaf()) { stack.push_back((unsigned)bvh.node(n).children[0]); stack.push_back((unsigned)bvh.node(n).children[1]); }
+	}
+	const unsigned nNodes = maxIdx + 1;
+	if (lst && ne <= lstCap) for (unsigned i = 0; i < ne; i++) lst[i] = bvh.entity(i);
+	if (nodes && hulls && nNodes <= nodeCap)
+		for (unsigned i = 0; i < nNodes; i++)
+		{
+			nodes[4 * i] = bvh.node(i).children[0]; nodes[4 * i + 1] = bvh.node(i).children[1]; nodes[4 * i + 2] = (int)bvh.node(i).begin; nodes[4 * i + 3] = (int)bvh.node(i).n;
+			hulls[4 * i] = (double)bvh.hull(i).x()[0]; hulls[4 * i + 1] = (double)bvh.hull(i).x()[1]; hulls[4 * i + 2] = (double)bvh.hull(i).x()[2]; hulls[4 * i + 3] = (double)bvh.hull(i).r();
+		}
+	return nNodes;
+}
+
 extern "C" {
 
 int refdrv_real_size() { return (int)sizeof(Real); }
@@ -521,6 +544,87 @@ void refdrv_get_collision_object(unsigned i, double *out)
 		out[28] = tm->getIndexOffset(); out[29] = tm->getParticleMesh().numVertices();
 	}
 }
+// ---- deformable vs deformable: tet models with an ANALYTIC box distance field in their rest frame ----------------------------
+// (what the demos do with Discregrid SDFs -- SceneLoaderDemo.cpp:740-760, pyPBD/SimulationModelModule.cpp:175-200 -- with
+// DistanceFieldCollisionDetection::addCollisionBox on a TetModelCollisionObjectType body + initTetBVH; the box is evaluated at
+// R0^T (X - X0) with X the point mapped into the tet model's rest configuration, DistanceFieldCollisionDetection.cpp:419-430.)
+// box = full side lengths; the tet model's initial transform must describe where that box sits: set_tet_model_initial_transform.
+int refdrv_add_tet_collision_box(unsigned tetModel, const double *box, int testMesh, double restitution, double friction)
+{
+	SimulationModel *m = model();
+	if (tetModel >= m->getTetModels().size()) return -1;
+	TetModel *tm = m->getTetModels()[tetModel];
+	tm->setRestitutionCoeff((Real)restitution);
+	tm->setFrictionCoeff((Real)friction);
+	ParticleData &pd = m->getParticles();
+	const unsigned int offset = tm->getIndexOffset();
+	const Utilities::IndexedTetMesh &mesh = tm->getParticleMesh();
+	cd().addCollisionBox(tetModel, CollisionDetection::CollisionObject::TetModelCollisionObjectType, &pd.getPosition(offset), mesh.numVertices(),
+		Vector3r((Real)box[0], (Real)box[1], (Real)box[2]), testMesh != 0, false);
+	const unsigned int index = (unsigned int)cd().getCollisionObjects().size() - 1;
+	((DistanceFieldCollisionDetection::DistanceFieldCollisionObject*)cd().getCollisionObjects()[index])->initTetBVH(&pd.getPosition(offset), mesh.numVertices(),
+		mesh.getTets().data(), mesh.numTets(), cd().getTolerance());
+	return (int)index;
+}
+void refdrv_set_tet_model_initial_transform(unsigned tetModel, const double *x, const double *R /*row-major*/)
+{
+	TetModel *tm = model()->getTetModels()[tetModel];
+	tm->setInitialX(v3(x));
+	Matrix3r r;
+	for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r(i, j) = (Real)R[3 * i + j];
+	tm->setInitialR(r);
+}
+// tet model tm: out[0] index offset, [1] #vertices, [2] #tets, [3..5] initialX, [6..14] initialR (row-major); tets: 4 per tet
+void refdrv_tet_model_info(unsigned tmIdx, double *out, unsigned *tets, unsigned tetCap)
+{
+	TetModel *tm = model()->getTetModels()[tmIdx];
+	const Utilities::IndexedTetMesh &mesh = tm->getParticleMesh();
+	out[0] = tm->getIndexOffset(); out[1] = mesh.numVertices(); out[2] = mesh.numTets();
+	for (int k = 0; k < 3; k++) out[3 + k] = (double)tm->getInitialX()[k];
+	for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out[6 + 3 * i + j] = (double)tm->getInitialR()(i, j);
+	if (tets && 4 * mesh.numTets() <= tetCap) for (unsigned i = 0; i < 4 * mesh.numTets(); i++) tets[i] = mesh.getTets()[i];
+}
+void refdrv_set_collision_tolerance(double t) { cd().setTolerance((Real)t); }
+unsigned refdrv_num_particle_solid_contacts() { return (unsigned)model()->getParticleSolidContactConstraints().size(); }
+// contact i: out[0] particle, [1] solid (tet model), [2] tet, [3..5] bary, [6..14] constraintInfo (3x3, column-major), [15] friction,
+// [16..27] m_x (4 x 3), [28..31] m_invMasses, [32] m_lambda
+void refdrv_get_particle_solid_contact(unsigned i, double *out)
+{
+	ParticleTetContactConstraint &c = model()->getParticleSolidContactConstraints()[i];
+	out[0] = c.m_bodies[0]; out[1] = c.m_solidIndex; out[2] = c.m_tetIndex;
+	for (int k = 0; k < 3; k++) out[3 + k] = (double)c.m_bary[k];
+	for (int col = 0; col < 3; col++) for (int r = 0; r < 3; r++) out[6 + 3 * col + r] = (double)c.m_constraintInfo(r, col);
+	out[15] = (double)c.m_frictionCoeff;
+	for (int v = 0; v < 4; v++) for (int k = 0; k < 3; k++) out[16 + 3 * v + k] = (double)c.m_x[v][k];
+	for (int v = 0; v < 4; v++) out[28 + v] = (double)c.m_invMasses[v];
+	out[32] = (double)c.m_lambda;
+}
+// the bounding-sphere hierarchies of collision object `co` as the reference constructed them (kd-tree construction uses
+// std::sort on tied coordinates: the structure is taken from the reference, never rebuilt):
+//   which = 0 point cloud (m_bvh), 1 tets (m_bvhTets), 2 tets in the rest pose (m_bvhTets0)
+// returns the number of nodes; lst: entity order (numEntities), nodes: 4 ints per node (child0, child1, begin, n), hulls: 4 doubles per node (x, y, z, r)
+unsigned refdrv_get_bvh(unsigned co, int which, unsigned *lst, unsigned lstCap, int *nodes, double *hulls, unsigned nodeCap, unsigned *numEntities)
+{
+	typedef DistanceFieldCollisionDetection::DistanceFieldCollisionObject DCO;
+	DCO *o = (DCO*)cd().getCollisionObjects()[co];
+	SimulationModel *m = model();
+	unsigned nv = 0, nt = 0;
+	if (o->m_bodyType == CollisionDetection::CollisionObject::TetModelCollisionObjectType)
+	{
+		TetModel *tm = m->getTetModels()[o->m_bodyIndex];
+		nv = tm->getParticleMesh().numVertices(); nt = tm->getParticleMesh().numTets();
+	}
+	else if (o->m_bodyType == CollisionDetection::CollisionObject::TriangleModelCollisionObjectType)
+		nv = m->getTriangleModels()[o->m_bodyIndex]->getParticleMesh().numVertices();
+	unsigned nNodes = 0;
+	if (which == 0) { nNodes = dumpBvh(o->m_bvh, nv, lst, lstCap, nodes, hulls, nodeCap); if (numEntities) *numEntities = nv; }
+	else if (which == 1) { nNodes = dumpBvh(o->m_bvhTets, nt, lst, lstCap, nodes, hulls, nodeCap); if (numEntities) *numEntities = nt; }
+	else { nNodes = dumpBvh(o->m_bvhTets0, nt, lst, lstCap, nodes, hulls, nodeCap); if (numEntities) *numEntities = nt; }
+	return nNodes;
+}
+// run ONLY the collision detection on the current state (fills the contact lists; no velocity solve)
+void refdrv_collision_detection_only() { cd().collisionDetection(*model()); }
+
 double refdrv_contact_stiffness_particle_rigid_body() { return (double)model()->getContactStiffnessParticleRigidBody(); }
 
 unsigned refdrv_num_particle_rigid_body_contacts() { return (unsigned)model()->getParticleRigidBodyContactConstraints().size(); }

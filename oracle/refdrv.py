@@ -116,7 +116,13 @@ class Ref:
         return self
 
     # -- lifecycle -----------------------------------------------------------
+    _tet_boxes = {}
+
     def reset_all(self):
+        self._tet_boxes = {}
+        self._reset_all()
+
+    def _reset_all(self):
         self.lib.refdrv_reset_all()
 
     @property
@@ -320,6 +326,66 @@ class Ref:
     def timestep_ptr(self):
         self.lib.refdrv_get_timestep.restype = C.c_void_p
         return C.c_void_p(self.lib.refdrv_get_timestep())
+
+    # ---- deformable vs deformable contacts (tet models with an analytic box in their rest frame) ----
+    def add_tet_collision_box(self, tet_model, box, test_mesh=True, restitution=0.6, friction=0.0):
+        self.lib.refdrv_add_tet_collision_box.argtypes = [_u, _pd, _i, _d, _d]
+        b = np.ascontiguousarray(box, dtype=np.float64)
+        if not hasattr(self, "_tet_boxes"):
+            self._tet_boxes = {}
+        self._tet_boxes[int(tet_model)] = b.copy()
+        return self.lib.refdrv_add_tet_collision_box(int(tet_model), _dp(b), int(bool(test_mesh)), float(restitution), float(friction))
+
+    def set_tet_model_initial_transform(self, tet_model, x, R=None):
+        self.lib.refdrv_set_tet_model_initial_transform.argtypes = [_u, _pd, _pd]
+        xx = np.ascontiguousarray(x, dtype=np.float64)
+        rr = np.ascontiguousarray(np.eye(3) if R is None else R, dtype=np.float64)
+        self.lib.refdrv_set_tet_model_initial_transform(int(tet_model), _dp(xx), _dp(rr))
+
+    def tet_model_info(self, tm):
+        self.lib.refdrv_tet_model_info.argtypes = [_u, _pd, _pu, _u]
+        out = np.zeros(16, dtype=np.float64)
+        self.lib.refdrv_tet_model_info(int(tm), _dp(out), None, 0)
+        tets = np.zeros(4 * int(out[2]), dtype=np.uint32)
+        self.lib.refdrv_tet_model_info(int(tm), _dp(out), _up(tets), len(tets))
+        return {"offset": int(out[0]), "num_vertices": int(out[1]), "num_tets": int(out[2]), "initial_x": out[3:6].copy(),
+                "initial_R": out[6:15].copy(), "tets": tets, "box": self._tet_boxes.get(int(tm))}
+
+    def set_collision_tolerance(self, t):
+        self.lib.refdrv_set_collision_tolerance.argtypes = [_d]
+        self.lib.refdrv_set_collision_tolerance(float(t))
+
+    def attach_collision_detection(self):
+        self.lib.refdrv_attach_collision_detection()
+
+    def collision_detection_only(self):
+        self.lib.refdrv_collision_detection_only()
+
+    def num_particle_solid_contacts(self):
+        return int(self.lib.refdrv_num_particle_solid_contacts())
+
+    def particle_solid_contacts(self):
+        """(n, 33) array: particle, solid, tet, bary[3], constraintInfo[9] (column-major), friction, m_x[12], m_invMasses[4], m_lambda"""
+        n = self.lib.refdrv_num_particle_solid_contacts()
+        out = np.zeros((n, 33), dtype=np.float64)
+        self.lib.refdrv_get_particle_solid_contact.argtypes = [_u, _pd]
+        for i in range(n):
+            self.lib.refdrv_get_particle_solid_contact(i, _dp(out[i]))
+        return out
+
+    def bvh(self, co, which):
+        """The reference's own bounding-sphere hierarchy of collision object `co` (which: 0 points, 1 tets, 2 tets at rest):
+        dict(lst, nodes (n, 4: child0, child1, begin, count), hulls (n, 4: centre, radius))."""
+        f = self.lib.refdrv_get_bvh
+        f.argtypes = [_u, _i, _pu, _u, C.POINTER(C.c_int), _pd, _u, _pu]
+        f.restype = _u
+        ne = C.c_uint(0)
+        nn = f(int(co), int(which), None, 0, None, None, 0, C.byref(ne))
+        lst = np.zeros(max(ne.value, 1), dtype=np.uint32)
+        nodes = np.zeros((max(nn, 1), 4), dtype=np.int32)
+        hulls = np.zeros((max(nn, 1), 4), dtype=np.float64)
+        f(int(co), int(which), _up(lst), ne.value, nodes.ctypes.data_as(C.POINTER(C.c_int)), _dp(hulls), nn, C.byref(ne))
+        return {"lst": lst[:ne.value], "nodes": nodes[:nn], "hulls": hulls[:nn]}
 
     def install_timestep_plugin(self, path, symbol="pbdx_create_timestep_hip"):
         return self.lib.refdrv_install_timestep_plugin(path.encode(), symbol.encode())

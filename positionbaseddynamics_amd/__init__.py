@@ -684,6 +684,23 @@ class Solver:
     def set_contact_params(self, tolerance=0.01, contact_stiffness=100.0, max_iterations_v=5):
         check(lib.pbdx_solver_set_contact_params(self._h, float(tolerance), float(contact_stiffness), int(max_iterations_v)), "set_contact_params")
 
+    def set_rest_positions(self, x0):
+        """ParticleData::m_x0 (what findRefTetAt of the deformable contacts reads); defaults to the first uploaded positions."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float32).reshape(-1, 3)
+        check(lib.pbdx_solver_set_rest_positions(self._h, len(x0), x0.ctypes.data_as(_ffi.pf)), "set_rest_positions")
+
+    def set_tet_colliders(self, records, count, tolerance):
+        """records: ctypes array of _ffi.TetCollider (distance field in the rest frame + the three bounding-sphere hierarchies
+        the host application built for the tet model); friction must be 0."""
+        check(lib.pbdx_solver_set_tet_colliders(self._h, int(count), records, float(tolerance)), "set_tet_colliders")
+
+    def tet_contacts(self, capacity=1 << 16):
+        """Contact list of the last detection between deformable solids: (count, 30) float records (include/pbdx.h)."""
+        out = np.zeros((capacity, _ffi.TET_CONTACT_FLOATS), dtype=np.float32)
+        n = C.c_uint32()
+        check(lib.pbdx_solver_get_tet_contacts(self._h, capacity, C.byref(n), out.ctypes.data_as(_ffi.pf)), "get_tet_contacts")
+        return out[:min(n.value, capacity)].copy()
+
     def num_contacts(self):
         n = C.c_uint32()
         check(lib.pbdx_solver_get_num_contacts(self._h, C.byref(n)), "get_num_contacts")

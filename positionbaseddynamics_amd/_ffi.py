@@ -42,6 +42,21 @@ class CollisionRange(C.Structure):
     _fields_ = [("first", C.c_uint32), ("count", C.c_uint32), ("restitution", C.c_float), ("friction", C.c_float)]
 
 
+class Bvh(C.Structure):
+    _fields_ = [("num_nodes", C.c_uint32), ("num_entities", C.c_uint32), ("entities", C.POINTER(C.c_uint32)),
+                ("nodes", C.POINTER(C.c_int32)), ("hulls", C.POINTER(C.c_float))]
+
+
+class TetCollider(C.Structure):
+    _fields_ = [("shape", C.c_int), ("invert", C.c_int), ("params", C.c_float * 4),
+                ("first_particle", C.c_uint32), ("num_vertices", C.c_uint32), ("num_tets", C.c_uint32), ("tets", C.POINTER(C.c_uint32)),
+                ("initial_x", C.c_float * 3), ("initial_R", C.c_float * 9), ("restitution", C.c_float), ("friction", C.c_float),
+                ("test_mesh", C.c_int), ("body_index", C.c_uint32), ("points", Bvh), ("tets_bvh", Bvh), ("tets_rest", Bvh)]
+
+
+TET_CONTACT_FLOATS = 30
+
+
 class PlanInfo(C.Structure):
     _fields_ = [("built", C.c_int), ("active", C.c_int), ("num_segments", C.c_uint32), ("num_tiles", C.c_uint32),
                 ("num_colours", C.c_uint32), ("max_local", C.c_uint32), ("slots_per_sweep", C.c_uint64),
@@ -102,6 +117,10 @@ SIGNATURES = [
     ("pbdx_solver_set_contact_params", C.c_int, vp, f32, f32, u32),
     ("pbdx_solver_get_num_contacts", C.c_int, vp, C.POINTER(u32)),
     ("pbdx_debug_stream", C.c_int, C.c_int, C.c_uint64, C.c_int),
+    ("pbdx_solver_set_tet_colliders", C.c_int, vp, u32, C.POINTER(TetCollider), f32),
+    ("pbdx_solver_set_rest_positions", C.c_int, vp, u32, pf),
+    ("pbdx_solver_get_tet_contacts", C.c_int, vp, u32, C.POINTER(u32), pf),
+    ("pbdx_debug_tet_contacts", C.c_int, u32, pf, pf, u32, C.POINTER(TetCollider), f32, u32, C.POINTER(u32), pf),
     ("pbdx_model_plan_check", C.c_int, vp, u32, u32, u32, C.POINTER(PlanInfo)),
     ("pbdx_model_create", C.c_int, C.POINTER(vp)), ("pbdx_model_destroy", None, vp),
     ("pbdx_model_cleanup", C.c_int, vp), ("pbdx_model_reset", C.c_int, vp),

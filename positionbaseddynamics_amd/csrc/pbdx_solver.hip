@@ -34,6 +34,7 @@
 #include "pbdx_access.h"
 #include "pbdx_plan.h"
 #include "pbdx_contact.h"
+#include "pbdx_tetcontact.h"
 #include <algorithm>
 #include <string.h>
 
@@ -788,6 +789,82 @@ __global__ __launch_bounds__(256) void contact_kernel(ContactArgs a)
 	}
 }
 
+// ---- contacts between deformable solids (pbdx_tetcontact.h) ---------------------------------------------------------------
+// Per step, after the substeps: refresh the bounding spheres of every collider's point and tet hierarchy (KDTree::update: every
+// node from its entities, sums in list order -- one thread per node), the colliders' boxes, then the detection.  The detection walks
+// the ordered pairs of colliders and the dual hierarchy traversal of each pair in ONE thread: the order in which the reference's
+// single-threaded traversal reaches the leaf pairs IS the order of its contact list, and that list is solved sequentially
+// (Gauss-Seidel) inside the iteration loop of the next step -- the order is part of the result.
+constexpr uint32_t kMaxTetContacts = 1u << 16;
+enum { kTcCount = 0, kTcOverflow = 1, kTcStack = 2, kTcWords = 4 };
+__global__ __launch_bounds__(256) void tet_hull_kernel(const TetColliderView *views, uint32_t collider, const P4 *pos, int which)
+{
+	const TetColliderView &v = views[collider];
+	const uint32_t node = blockIdx.x * blockDim.x + threadIdx.x;
+	if (which == 0) { if (node < v.points.num_nodes) hull_points(v.points, node, pos + v.first); }
+	else if (node < v.tet_bvh.num_nodes) hull_tets(v.tet_bvh, node, pos + v.first, v.tets, v.tolerance);
+}
+// CollisionDetection::updateAABB: min / max over the model's particles (order-independent)
+__global__ __launch_bounds__(256) void tet_aabb_kernel(const TetColliderView *views, const P4 *pos, float *aabb)
+{
+	__shared__ float lo[3][256], hi[3][256];
+	const TetColliderView &v = views[blockIdx.x];
+	float mn[3], mx[3];
+	const P4 p0 = pos[v.first];
+	mn[0] = mx[0] = p0.x; mn[1] = mx[1] = p0.y; mn[2] = mx[2] = p0.z;
+	for (uint32_t i = threadIdx.x; i < v.num_vertices; i += blockDim.x)
+	{
+		const P4 p = pos[v.first + i];
+		const float q[3] = { p.x, p.y, p.z };
+		for (int k = 0; k < 3; k++) { if (mn[k] > q[k]) mn[k] = q[k]; if (mx[k] < q[k]) mx[k] = q[k]; }
+	}
+	for (int k = 0; k < 3; k++) { lo[k][threadIdx.x] = mn[k]; hi[k][threadIdx.x] = mx[k]; }
+	__syncthreads();
+	for (uint32_t stride = 128; stride > 0; stride >>= 1)
+	{
+		if (threadIdx.x < stride)
+			for (int k = 0; k < 3; k++)
+			{
+				if (lo[k][threadIdx.x] > lo[k][threadIdx.x + stride]) lo[k][threadIdx.x] = lo[k][threadIdx.x + stride];
+				if (hi[k][threadIdx.x] < hi[k][threadIdx.x + stride]) hi[k][threadIdx.x] = hi[k][threadIdx.x + stride];
+			}
+		__syncthreads();
+	}
+	if (threadIdx.x < 3) { aabb[6 * blockIdx.x + threadIdx.x] = lo[threadIdx.x][0]; aabb[6 * blockIdx.x + 3 + threadIdx.x] = hi[threadIdx.x][0]; }
+}
+__global__ void tet_detect_kernel(const TetColliderView *views, uint32_t n, const P4 *pos, const P4 *rest, const float *aabb, TetContact *contacts, uint32_t *counters)
+{
+	if (blockIdx.x || threadIdx.x) return;
+	uint32_t found = 0;
+	bool ok = true;
+	for (uint32_t i = 0; i < n; i++)
+		for (uint32_t k = 0; k < n; k++)
+		{
+			if (i == k || !views[i].test_mesh || !aabb_intersect(aabb + 6 * i, aabb + 6 * k)) continue;
+			ok = tet_pair_contacts(views[i], views[k], pos, rest, [&](const TetContact &c) {
+				if (found < kMaxTetContacts) contacts[found] = c;
+				found++;
+			}) && ok;
+		}
+	counters[kTcCount] = found < kMaxTetContacts ? found : kMaxTetContacts;
+	if (found > kMaxTetContacts) counters[kTcOverflow] = 1u;
+	if (!ok) counters[kTcStack] = 1u;
+}
+// TimeStepController.cpp:288-291: after the colour groups of an iteration, the contact list sequentially
+struct TetPosAccess
+{
+	float4 *pos;
+	__device__ __forceinline__ P4 get(uint32_t i) const { const float4 v = pos[i]; P4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+	__device__ __forceinline__ void add(uint32_t i, V3 c) { float4 v = pos[i]; v.x += c.x; v.y += c.y; v.z += c.z; pos[i] = v; }
+};
+__global__ void tet_contact_solve_kernel(float4 *pos, const TetContact *contacts, const uint32_t *counters)
+{
+	if (blockIdx.x || threadIdx.x) return;
+	TetPosAccess acc = { pos };
+	const uint32_t n = counters[kTcCount];
+	for (uint32_t i = 0; i < n; i++) tet_contact_position_solve(contacts[i], acc);
+}
+
 // ---- counter calibration kernels (pbdx_debug_stream): known byte counts in this engine's own access
 // widths, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be turned into bytes (MI355X_MICROARCH.md, HBM)
 __global__ __launch_bounds__(256) void calib_read_b32(const float *__restrict__ src, float *__restrict__ sink, size_t n)
@@ -929,6 +1006,35 @@ struct pbdx_solver
 	uint32_t max_iterations_v = 5;
 	uint64_t contact_version = 0;
 
+	// contacts between deformable solids (pbdx_tetcontact.h)
+	struct DevBvh { uint32_t *lst = nullptr; int32_t *nodes = nullptr; P4 *hulls = nullptr; uint32_t num_nodes = 0; };
+	struct DevTetCollider { uint32_t *tets = nullptr; DevBvh points, tet_bvh, tet_bvh0; uint32_t max_nodes = 0; };
+	std::vector<DevTetCollider> tet_dev;
+	std::vector<TetColliderView> tet_views;       // host copy of the device views
+	TetColliderView *d_tet_views = nullptr;
+	float *d_tet_aabb = nullptr;
+	TetContact *d_tet_contacts = nullptr;
+	uint32_t *d_tet_counters = nullptr;
+	float4 *d_rest = nullptr;                      // ParticleData::m_x0 (needed by the contacts between solids only)
+	bool rest_set = false;
+	bool tet_active() const { return !tet_views.empty(); }
+	void free_tet_colliders()
+	{
+		for (DevTetCollider &d : tet_dev)
+		{
+			if (d.tets) (void)hipFree(d.tets);
+			for (DevBvh *b : { &d.points, &d.tet_bvh, &d.tet_bvh0 })
+			{
+				if (b->lst) (void)hipFree(b->lst);
+				if (b->nodes) (void)hipFree(b->nodes);
+				if (b->hulls) (void)hipFree(b->hulls);
+			}
+		}
+		tet_dev.clear(); tet_views.clear();
+		if (d_tet_views) { (void)hipFree(d_tet_views); d_tet_views = nullptr; }
+		if (d_tet_aabb) { (void)hipFree(d_tet_aabb); d_tet_aabb = nullptr; }
+	}
+
 	// fused plan
 	FusedPlan plan;
 	std::vector<DeviceSegment> dsegs;
@@ -1006,13 +1112,16 @@ struct pbdx_solver
 			if (*p) { (void)hipFree(*p); *p = nullptr; }
 		if (d_stage) { (void)hipFree(d_stage); d_stage = nullptr; }
 		for (float4 *&p : d_snap) if (p) { (void)hipFree(p); p = nullptr; }
+		if (d_rest) { (void)hipFree(d_rest); d_rest = nullptr; }
+		rest_set = false;
 		n = 0;
 	}
 	// the position buffers change roles: d_pos[0] is always the state by NAME (everything enqueued later sees the new roles;
 	// kernels already enqueued carry their own pointer values)
 	void swap_state() { std::swap(d_pos[0], d_pos[1]); phys ^= 1; }
 	bool fused_active() const { return fuse && plan_ok && !dsegs.empty() && (fuse == 1 || fuse_choice); }
-	bool persistent_active() const { return persistent && persist_ok && persist_choice && fused_active(); }
+	// (contacts between solids are solved between the iterations of a substep: the sweeps of a substep cannot be one launch then)
+	bool persistent_active() const { return persistent && persist_ok && persist_choice && fused_active() && !tet_active(); }
 	void unpin_all()
 	{
 		for (const Pin &pn : pins) (void)hipHostUnregister(const_cast<void *>(pn.p));
@@ -1462,7 +1571,7 @@ inline uint32_t sweep_flips(const pbdx_solver *s, uint32_t iterations)
 
 // `iterations` Gauss-Seidel sweeps over the schedule.  Fused: reads buffer `src`, ends in buffer
 // src ^ sweep_flips().  Per-colour: in place on buffer 0 (src must be 0).
-int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, ProfCursor *pc)
+int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, ProfCursor *pc, bool with_tet_contacts = false)
 {
 	if (s->persistent_active() && iterations)
 	{
@@ -1471,9 +1580,19 @@ int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, Pr
 		if (r) return r;
 		return pc ? prof_end(pc) : PBDX_OK;
 	}
+	// contacts between solids: TimeStepController.cpp:288-291, after the colour groups of EVERY iteration, on the buffer that holds
+	// the iteration's result
+	auto tet_solve = [&](int buf) -> int
+	{
+		if (!with_tet_contacts || !s->tet_active()) return PBDX_OK;
+		hipLaunchKernelGGL(tet_contact_solve_kernel, dim3(1), dim3(64), 0, s->stream, s->d_pos[buf], (const TetContact *)s->d_tet_contacts, (const uint32_t *)s->d_tet_counters);
+		HIPCHECK(hipGetLastError());
+		return PBDX_OK;
+	};
 	if (s->fused_active())
 	{
 		for (uint32_t it = 0; it < iterations; it++)
+		{
 			for (size_t si = 0; si < s->dsegs.size(); si++)
 			{
 				if (pc) { int r = prof_begin(pc, -2 - (int)si, (uint32_t)s->dsegs[si].constraints); if (r) return r; }
@@ -1482,10 +1601,14 @@ int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, Pr
 				if (pc) { r = prof_end(pc); if (r) return r; }
 				src ^= 1;
 			}
+			int r = tet_solve(src);
+			if (r) return r;
+		}
 	}
 	else
 	{
 		for (uint32_t it = 0; it < iterations; it++)
+		{
 			for (uint32_t bi : s->order)
 			{
 				const Batch &b = s->batches[bi];
@@ -1494,6 +1617,9 @@ int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, Pr
 				if (r) return r;
 				if (pc) { r = prof_end(pc); if (r) return r; }
 			}
+			int r = tet_solve(0);
+			if (r) return r;
+		}
 	}
 	return PBDX_OK;
 }
@@ -1583,7 +1709,7 @@ int enqueue_substep_tail(pbdx_solver *s, float hs, float inv_h, uint32_t iters, 
 	const uint32_t nb = (s->n + bs - 1) / bs;
 	const int start = (int)sweep_flips(s, iters);
 	uint32_t *ctl = ctl_of(s, pc);
-	int r = projection_sweeps(s, hs, iters, start, pc);
+	int r = projection_sweeps(s, hs, iters, start, pc, true);
 	if (r) return r;
 	if (s->n)
 	{
@@ -1631,8 +1757,33 @@ int enqueue_substep(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int v
 
 // collision detection + velocity constraint projection of the contacts, once per step after the
 // substeps (TimeStepController.cpp:216-223)
+// DistanceFieldCollisionDetection::collisionDetection for the solid-solid pairs: bounding spheres, boxes, detection (pbdx_tetcontact.h).
+// The new contact list is used by the position solves of the NEXT step.
+int enqueue_tet_detection(pbdx_solver *s)
+{
+	if (!s->tet_active() || !s->n) return PBDX_OK;
+	const P4 *pos = reinterpret_cast<const P4 *>(s->d_pos[0]);
+	for (size_t c = 0; c < s->tet_views.size(); c++)
+	{
+		const TetColliderView &v = s->tet_views[c];
+		if (v.points.num_nodes)
+			hipLaunchKernelGGL(tet_hull_kernel, dim3((v.points.num_nodes + 255) / 256), dim3(256), 0, s->stream, (const TetColliderView *)s->d_tet_views, (uint32_t)c, pos, 0);
+		if (v.tet_bvh.num_nodes)
+			hipLaunchKernelGGL(tet_hull_kernel, dim3((v.tet_bvh.num_nodes + 255) / 256), dim3(256), 0, s->stream, (const TetColliderView *)s->d_tet_views, (uint32_t)c, pos, 1);
+	}
+	hipLaunchKernelGGL(tet_aabb_kernel, dim3((uint32_t)s->tet_views.size()), dim3(256), 0, s->stream, (const TetColliderView *)s->d_tet_views, pos, s->d_tet_aabb);
+	hipLaunchKernelGGL(tet_detect_kernel, dim3(1), dim3(64), 0, s->stream, (const TetColliderView *)s->d_tet_views, (uint32_t)s->tet_views.size(), pos,
+		reinterpret_cast<const P4 *>(s->d_rest), (const float *)s->d_tet_aabb, s->d_tet_contacts, s->d_tet_counters);
+	HIPCHECK(hipGetLastError());
+	return PBDX_OK;
+}
+
 int enqueue_contacts(pbdx_solver *s)
 {
+	{
+		int rt = enqueue_tet_detection(s);
+		if (rt) return rt;
+	}
 	if (s->colliders.empty() || s->ranges.empty() || !s->n) return PBDX_OK;
 	HIPCHECK(hipMemsetAsync(s->d_contact_counters, 0, sizeof(unsigned int), s->stream));      // [0] contacts of this step; [1] (overflow) is reset per call
 	for (const pbdx_collision_range &r : s->ranges)
@@ -1737,6 +1888,13 @@ int set_particles_impl(pbdx_solver *s, uint32_t n, const T *x, const T *v, const
 	HIPCHECK(hipMemcpyAsync(st_w, inv_mass, b1, hipMemcpyHostToDevice, s->stream));
 	const dim3 grid((n + 255) / 256), block(256);
 	hipLaunchKernelGGL(pack_kernel<T>, grid, block, 0, s->stream, (const T *)st_x, (const T *)st_w, s->d_pos[0], n);
+	if (!s->rest_set)
+	{
+		// rest positions (ParticleData::m_x0) default to the first uploaded positions; pbdx_solver_set_rest_positions overrides
+		if (!s->d_rest) HIPCHECK(hipMalloc(&s->d_rest, (size_t)n * sizeof(float4)));
+		hipLaunchKernelGGL(pack_kernel<T>, grid, block, 0, s->stream, (const T *)st_x, (const T *)st_w, s->d_rest, n);
+		s->rest_set = true;
+	}
 	if (v) hipLaunchKernelGGL(pack_kernel<T>, grid, block, 0, s->stream, (const T *)st_v, (const T *)st_m, s->d_vel, n);
 	else hipLaunchKernelGGL(pack_zero_kernel<T>, grid, block, 0, s->stream, (const T *)st_m, s->d_vel, n);
 	hipLaunchKernelGGL(pack_kernel<T>, grid, block, 0, s->stream, (const T *)(old_x ? st_o : st_x), (const T *)nullptr, s->d_old, n);
@@ -1823,6 +1981,9 @@ void pbdx_solver_destroy(pbdx_solver *s)
 	s->drop_graph();
 	s->free_batches();
 	s->free_particles();
+	s->free_tet_colliders();
+	if (s->d_tet_contacts) (void)hipFree(s->d_tet_contacts);
+	if (s->d_tet_counters) (void)hipFree(s->d_tet_counters);
 	s->unpin_all();
 	if (s->d_colliders) (void)hipFree(s->d_colliders);
 	if (s->d_contact_counters) (void)hipFree(s->d_contact_counters);
@@ -2225,6 +2386,17 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	float ms = 0.0f;
 	HIPCHECK(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
 	s->stats.total_ms = ms;
+	if (s->tet_active())
+	{
+		uint32_t c[kTcWords] = { 0, 0, 0, 0 };
+		HIPCHECK(hipMemcpy(c, s->d_tet_counters, sizeof(c), hipMemcpyDeviceToHost));
+		if (c[kTcOverflow] || c[kTcStack])
+		{
+			(void)hipMemset(s->d_tet_counters, 0, kTcWords * sizeof(uint32_t));
+			set_error(c[kTcOverflow] ? "more than %u contacts between solids in one step" : "bounding-sphere-hierarchy traversal deeper than the engine's stack (%u)", c[kTcOverflow] ? kMaxTetContacts : 128u);
+			return PBDX_ERR_UNSUPPORTED;
+		}
+	}
 	if (s->d_contact_counters && !s->colliders.empty())
 	{
 		// the reference has no per-particle contact limit: exceeding the engine's is an error, not a silent divergence
@@ -2330,6 +2502,123 @@ int pbdx_solver_set_contact_params(pbdx_solver *s, float tolerance, float contac
 {
 	if (!s) return PBDX_ERR_INVALID;
 	s->contact_tolerance = tolerance; s->contact_stiffness = contact_stiffness; s->max_iterations_v = max_iterations_v;
+	return PBDX_OK;
+}
+
+int pbdx_solver_set_rest_positions(pbdx_solver *s, uint32_t n, const float *x0)
+{
+	if (!s || !x0 || n != s->n || !n) { set_error("set_rest_positions: particle count mismatch (upload the particles first)"); return PBDX_ERR_INVALID; }
+	HIPCHECK(hipSetDevice(s->device));
+	{ int rs = ensure_stage(s, sizeof(float)); if (rs) return rs; }
+	if (!s->d_rest) HIPCHECK(hipMalloc(&s->d_rest, (size_t)n * sizeof(float4)));
+	HIPCHECK(hipMemcpyAsync(s->d_stage, x0, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+	hipLaunchKernelGGL(pack_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s->stream, (const float *)s->d_stage, (const float *)nullptr, s->d_rest, n);
+	HIPCHECK(hipGetLastError());
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	s->rest_set = true;
+	return PBDX_OK;
+}
+
+int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_collider *colliders, float tolerance)
+{
+	if (!s || (n && !colliders)) { set_error("set_tet_colliders: bad arguments"); return PBDX_ERR_INVALID; }
+	for (uint32_t i = 0; i < n; i++)
+	{
+		const pbdx_tet_collider &c = colliders[i];
+		if (c.shape < PBDX_SHAPE_BOX || c.shape > PBDX_SHAPE_HOLLOW_BOX) { set_error("set_tet_colliders: unknown shape %d", c.shape); return PBDX_ERR_UNSUPPORTED; }
+		if (c.friction != 0.0f)
+		{
+			set_error("set_tet_colliders: friction of a deformable-deformable contact must be 0 -- the reference's friction impulse for these contacts reads an uninitialised multiplier (Constraints.h:553)");
+			return PBDX_ERR_UNSUPPORTED;
+		}
+		if ((uint64_t)c.first_particle + c.num_vertices > s->n || !c.num_vertices) { set_error("set_tet_colliders: collider %u exceeds the %u uploaded particles", i, s->n); return PBDX_ERR_INVALID; }
+		if (!c.tets || !c.num_tets) { set_error("set_tet_colliders: collider %u has no tets", i); return PBDX_ERR_INVALID; }
+		for (const pbdx_bvh *b : { &c.points, &c.tets_bvh, &c.tets_rest })
+			if (!b->num_nodes || !b->entities || !b->nodes) { set_error("set_tet_colliders: collider %u lacks a bounding-sphere hierarchy", i); return PBDX_ERR_INVALID; }
+		if (!c.tets_rest.hulls) { set_error("set_tet_colliders: the rest-pose hierarchy of collider %u needs its spheres", i); return PBDX_ERR_INVALID; }
+		// structure checks: children and entity ranges in range (the device code trusts them)
+		const pbdx_bvh *bs[3] = { &c.points, &c.tets_bvh, &c.tets_rest };
+		const uint32_t ents[3] = { c.num_vertices, c.num_tets, c.num_tets };
+		for (int q = 0; q < 3; q++)
+		{
+			if (bs[q]->num_entities != ents[q]) { set_error("set_tet_colliders: hierarchy %d of collider %u has %u entities, expected %u", q, i, bs[q]->num_entities, ents[q]); return PBDX_ERR_INVALID; }
+			for (uint32_t e = 0; e < ents[q]; e++) if (bs[q]->entities[e] >= ents[q]) { set_error("set_tet_colliders: entity out of range"); return PBDX_ERR_INVALID; }
+			for (uint32_t nd = 0; nd < bs[q]->num_nodes; nd++)
+			{
+				const int32_t *k = bs[q]->nodes + 4 * nd;
+				const bool leaf = k[0] < 0 && k[1] < 0;
+				if ((!leaf && (k[0] < 0 || k[1] < 0 || (uint32_t)k[0] >= bs[q]->num_nodes || (uint32_t)k[1] >= bs[q]->num_nodes)) || k[2] < 0 || k[3] <= 0 ||
+					(uint64_t)k[2] + (uint64_t)k[3] > ents[q])
+				{ set_error("set_tet_colliders: node %u of hierarchy %d of collider %u is malformed", nd, q, i); return PBDX_ERR_INVALID; }
+			}
+		}
+		for (uint32_t t = 0; t < 4 * c.num_tets; t++) if (c.tets[t] >= c.num_vertices) { set_error("set_tet_colliders: tet vertex out of range"); return PBDX_ERR_INVALID; }
+	}
+	HIPCHECK(hipSetDevice(s->device));
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	s->free_tet_colliders();
+	s->drop_graph();
+	if (!n) return PBDX_OK;
+	auto up = [](auto **dst, const auto *src, size_t count) -> hipError_t
+	{
+		hipError_t e = hipMalloc(dst, count * sizeof(**dst));
+		if (e == hipSuccess) e = hipMemcpy(*dst, src, count * sizeof(**dst), hipMemcpyHostToDevice);
+		return e;
+	};
+	s->tet_dev.resize(n);
+	s->tet_views.resize(n);
+	for (uint32_t i = 0; i < n; i++)
+	{
+		const pbdx_tet_collider &c = colliders[i];
+		pbdx_solver::DevTetCollider &d = s->tet_dev[i];
+		TetColliderView &v = s->tet_views[i];
+		memset(&v, 0, sizeof(v));
+		v.sdf.shape = c.shape; v.sdf.invert = c.invert; memcpy(v.sdf.params, c.params, sizeof(c.params));
+		v.first = c.first_particle; v.num_vertices = c.num_vertices; v.num_tets = c.num_tets;
+		memcpy(v.X0, c.initial_x, sizeof(v.X0)); memcpy(v.R0, c.initial_R, sizeof(v.R0));
+		v.tolerance = tolerance; v.test_mesh = c.test_mesh; v.body_index = c.body_index;
+		HIPCHECK(up(&d.tets, c.tets, (size_t)4 * c.num_tets));
+		v.tets = d.tets;
+		const pbdx_bvh *src[3] = { &c.points, &c.tets_bvh, &c.tets_rest };
+		pbdx_solver::DevBvh *dst[3] = { &d.points, &d.tet_bvh, &d.tet_bvh0 };
+		BvhView *view[3] = { &v.points, &v.tet_bvh, &v.tet_bvh0 };
+		for (int q = 0; q < 3; q++)
+		{
+			HIPCHECK(up(&dst[q]->lst, src[q]->entities, src[q]->num_entities));
+			HIPCHECK(up(&dst[q]->nodes, src[q]->nodes, (size_t)4 * src[q]->num_nodes));
+			HIPCHECK(hipMalloc(&dst[q]->hulls, (size_t)src[q]->num_nodes * sizeof(P4)));
+			if (q == 2) HIPCHECK(hipMemcpy(dst[q]->hulls, src[q]->hulls, (size_t)src[q]->num_nodes * sizeof(P4), hipMemcpyHostToDevice));
+			else HIPCHECK(hipMemset(dst[q]->hulls, 0, (size_t)src[q]->num_nodes * sizeof(P4)));
+			dst[q]->num_nodes = src[q]->num_nodes;
+			*view[q] = BvhView{ dst[q]->lst, dst[q]->nodes, dst[q]->hulls, dst[q]->num_nodes };
+		}
+	}
+	HIPCHECK(hipMalloc(&s->d_tet_views, (size_t)n * sizeof(TetColliderView)));
+	HIPCHECK(hipMemcpy(s->d_tet_views, s->tet_views.data(), (size_t)n * sizeof(TetColliderView), hipMemcpyHostToDevice));
+	HIPCHECK(hipMalloc(&s->d_tet_aabb, (size_t)6 * n * sizeof(float)));
+	if (!s->d_tet_contacts) HIPCHECK(hipMalloc(&s->d_tet_contacts, (size_t)kMaxTetContacts * sizeof(TetContact)));
+	if (!s->d_tet_counters) HIPCHECK(hipMalloc(&s->d_tet_counters, kTcWords * sizeof(uint32_t)));
+	HIPCHECK(hipMemset(s->d_tet_counters, 0, kTcWords * sizeof(uint32_t)));      // no contacts before the first detection
+	return PBDX_OK;
+}
+
+int pbdx_solver_get_tet_contacts(pbdx_solver *s, uint32_t capacity, uint32_t *count, float *out)
+{
+	if (!s || !count) return PBDX_ERR_INVALID;
+	*count = 0;
+	if (!s->tet_active() || !s->d_tet_counters) return PBDX_OK;
+	HIPCHECK(hipSetDevice(s->device));
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	uint32_t c[kTcWords];
+	HIPCHECK(hipMemcpy(c, s->d_tet_counters, sizeof(c), hipMemcpyDeviceToHost));
+	*count = c[kTcCount];
+	const uint32_t m = std::min(capacity, c[kTcCount]);
+	if (m && out)
+	{
+		std::vector<TetContact> tmp(m);
+		HIPCHECK(hipMemcpy(tmp.data(), s->d_tet_contacts, (size_t)m * sizeof(TetContact), hipMemcpyDeviceToHost));
+		for (uint32_t i = 0; i < m; i++) contact_to_floats(tmp[i], out + (size_t)i * PBDX_TET_CONTACT_FLOATS);
+	}
 	return PBDX_OK;
 }
 

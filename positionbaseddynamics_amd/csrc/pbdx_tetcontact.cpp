@@ -1,0 +1,91 @@
+// pbdx_tetcontact.cpp -- host-side evaluation of the particle-tet contact detection (pbdx_debug_tet_contacts): the SAME code the
+// device runs (pbdx_tetcontact.h is host + device), so that the detection can be pinned against the reference without a GPU.
+#include "pbdx_internal.h"
+#include "pbdx_tetcontact.h"
+#include <string.h>
+#include <vector>
+
+using namespace pbdx;
+
+namespace pbdx {
+
+// host mirror of one collider: owns the (recomputed) hull arrays
+struct HostTetCollider
+{
+	TetColliderView view;
+	std::vector<P4> h_points, h_tets, h_tets0;
+};
+
+bool make_host_view(const pbdx_tet_collider &c, float tolerance, HostTetCollider &out)
+{
+	if (!c.tets || (c.points.num_nodes && (!c.points.entities || !c.points.nodes)) || (c.tets_bvh.num_nodes && (!c.tets_bvh.entities || !c.tets_bvh.nodes)) ||
+		(c.tets_rest.num_nodes && (!c.tets_rest.entities || !c.tets_rest.nodes || !c.tets_rest.hulls)))
+		return false;
+	TetColliderView &v = out.view;
+	memset(&v, 0, sizeof(v));
+	v.sdf.shape = c.shape; v.sdf.invert = c.invert;
+	memcpy(v.sdf.params, c.params, sizeof(c.params));
+	v.first = c.first_particle; v.num_vertices = c.num_vertices; v.num_tets = c.num_tets; v.tets = c.tets;
+	memcpy(v.X0, c.initial_x, sizeof(v.X0)); memcpy(v.R0, c.initial_R, sizeof(v.R0));
+	v.tolerance = tolerance; v.test_mesh = c.test_mesh; v.body_index = c.body_index;
+	out.h_points.assign(c.points.num_nodes, P4{ 0, 0, 0, 0 });
+	out.h_tets.assign(c.tets_bvh.num_nodes, P4{ 0, 0, 0, 0 });
+	out.h_tets0.resize(c.tets_rest.num_nodes);
+	for (uint32_t i = 0; i < c.tets_rest.num_nodes; i++) out.h_tets0[i] = P4{ c.tets_rest.hulls[4 * i], c.tets_rest.hulls[4 * i + 1], c.tets_rest.hulls[4 * i + 2], c.tets_rest.hulls[4 * i + 3] };
+	v.points = BvhView{ c.points.entities, c.points.nodes, out.h_points.data(), c.points.num_nodes };
+	v.tet_bvh = BvhView{ c.tets_bvh.entities, c.tets_bvh.nodes, out.h_tets.data(), c.tets_bvh.num_nodes };
+	v.tet_bvh0 = BvhView{ c.tets_rest.entities, c.tets_rest.nodes, out.h_tets0.data(), c.tets_rest.num_nodes };
+	return true;
+}
+
+void contact_to_floats(const TetContact &c, float *o)
+{
+	o[0] = (float)c.particle; o[1] = (float)c.solid; o[2] = (float)c.tet;
+	for (int k = 0; k < 3; k++) { o[3 + k] = c.bary[k]; o[6 + k] = c.normal[k]; }
+	o[9] = c.nKn_inv;
+	for (int v = 0; v < 4; v++) for (int k = 0; k < 3; k++) o[10 + 3 * v + k] = c.x[v][k];
+	for (int v = 0; v < 4; v++) { o[22 + v] = c.w[v]; o[26 + v] = (float)c.vert[v]; }
+}
+
+} // namespace pbdx
+
+extern "C" int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float *rest4, uint32_t n, const pbdx_tet_collider *colliders,
+	float tolerance, uint32_t capacity, uint32_t *count, float *out)
+{
+	if (!pos4 || !rest4 || (n && !colliders) || !count) { set_error("debug_tet_contacts: null argument"); return PBDX_ERR_INVALID; }
+	const P4 *pos = reinterpret_cast<const P4 *>(pos4), *x0 = reinterpret_cast<const P4 *>(rest4);
+	std::vector<HostTetCollider> cs(n);
+	std::vector<float> aabb((size_t)6 * n);
+	for (uint32_t i = 0; i < n; i++)
+	{
+		if (!make_host_view(colliders[i], tolerance, cs[i])) { set_error("debug_tet_contacts: collider %u has a null array", i); return PBDX_ERR_INVALID; }
+		const TetColliderView &v = cs[i].view;
+		if ((uint64_t)v.first + v.num_vertices > n_particles) { set_error("debug_tet_contacts: collider %u exceeds the particles", i); return PBDX_ERR_INVALID; }
+		// KDTree::update of the point and tet hierarchies, CollisionDetection::updateAABB
+		for (uint32_t nd = 0; nd < v.points.num_nodes; nd++) hull_points(v.points, nd, pos + v.first);
+		for (uint32_t nd = 0; nd < v.tet_bvh.num_nodes; nd++) hull_tets(v.tet_bvh, nd, pos + v.first, v.tets, tolerance);
+		float *bb = &aabb[6 * i];
+		for (int k = 0; k < 3; k++) bb[k] = bb[3 + k] = (&pos[v.first].x)[k];
+		for (uint32_t p = v.first + 1; p < v.first + v.num_vertices; p++)
+			for (int k = 0; k < 3; k++)
+			{
+				const float q = (&pos[p].x)[k];
+				if (bb[k] > q) bb[k] = q;
+				if (bb[3 + k] < q) bb[3 + k] = q;
+			}
+	}
+	uint32_t found = 0;
+	bool ok = true;
+	for (uint32_t i = 0; i < n; i++)
+		for (uint32_t k = 0; k < n; k++)
+		{
+			if (i == k || !cs[i].view.test_mesh || !aabb_intersect(&aabb[6 * i], &aabb[6 * k])) continue;
+			ok = tet_pair_contacts(cs[i].view, cs[k].view, pos, x0, [&](const TetContact &c) {
+				if (found < capacity && out) contact_to_floats(c, out + (size_t)found * PBDX_TET_CONTACT_FLOATS);
+				found++;
+			}) && ok;
+		}
+	*count = found;
+	if (!ok) { set_error("debug_tet_contacts: traversal stack overflow"); return PBDX_ERR_INVALID; }
+	return PBDX_OK;
+}

@@ -97,7 +97,7 @@ TimeStepControllerHIP::TimeStepControllerHIP(int device) :
 	TimeStepController(), m_solver(nullptr), m_device(device), m_scheduleValid(false),
 	m_numConstraints(0), m_numParticles(0), m_gpuSteps(0), m_fallbackSteps(0), m_failedSteps(0), m_paramRefreshes(0), m_scheduleBuilds(0), m_uploads(0),
 	m_allowFallback(false), m_deviceAhead(false), m_hostDirty(false), m_imageValid(false), m_paramsDirty(false), m_paramHash(0),
-	m_supportedFor(nullptr), m_supportedConstraints(0), m_supportedBodies(0), m_supportedObjects(0), m_supported(false), m_accelValid(false)
+	m_supportedFor(nullptr), m_supportedConstraints(0), m_supportedBodies(0), m_supportedObjects(0), m_supported(false), m_accelValid(false), m_tetSignature(0)
 {
 	m_accelGravity[0] = m_accelGravity[1] = m_accelGravity[2] = 0;
 	for (int k = 0; k < 5; k++) m_hostHash[k] = 0;
@@ -142,6 +142,53 @@ void TimeStepControllerHIP::reset()
 	m_deviceAhead = false;
 	m_hostDirty = true;
 	m_accelValid = false;
+	// SimulationModel::reset -> resetContacts: the contact list of the last detection goes with it
+	if (m_solver && m_tetSignature) { pbdx_solver_set_tet_colliders(m_solver, 0, NULL, 0.0f); m_tetSignature = 0; }
+}
+
+// analytic distance fields the engine evaluates (pbdx_contact.h); parameters as the reference's collision objects store them
+static bool analyticShape(CollisionDetection::CollisionObject *co, int *shape, float *params)
+{
+	typedef DistanceFieldCollisionDetection D;
+	const int t = co->getTypeId();
+	int sh; float p[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	if (t == D::DistanceFieldCollisionBox::TYPE_ID) { sh = PBDX_SHAPE_BOX; for (int k = 0; k < 3; k++) p[k] = (float)((D::DistanceFieldCollisionBox*)co)->m_box[k]; }
+	else if (t == D::DistanceFieldCollisionSphere::TYPE_ID) { sh = PBDX_SHAPE_SPHERE; p[0] = (float)((D::DistanceFieldCollisionSphere*)co)->m_radius; }
+	else if (t == D::DistanceFieldCollisionTorus::TYPE_ID) { sh = PBDX_SHAPE_TORUS; p[0] = (float)((D::DistanceFieldCollisionTorus*)co)->m_radii[0]; p[1] = (float)((D::DistanceFieldCollisionTorus*)co)->m_radii[1]; }
+	else if (t == D::DistanceFieldCollisionCylinder::TYPE_ID) { sh = PBDX_SHAPE_CYLINDER; p[0] = (float)((D::DistanceFieldCollisionCylinder*)co)->m_dim[0]; p[1] = (float)((D::DistanceFieldCollisionCylinder*)co)->m_dim[1]; }
+	else if (t == D::DistanceFieldCollisionHollowSphere::TYPE_ID) { sh = PBDX_SHAPE_HOLLOW_SPHERE; p[0] = (float)((D::DistanceFieldCollisionHollowSphere*)co)->m_radius; p[1] = (float)((D::DistanceFieldCollisionHollowSphere*)co)->m_thickness; }
+	else if (t == D::DistanceFieldCollisionHollowBox::TYPE_ID) { sh = PBDX_SHAPE_HOLLOW_BOX; for (int k = 0; k < 3; k++) p[k] = (float)((D::DistanceFieldCollisionHollowBox*)co)->m_box[k]; p[3] = (float)((D::DistanceFieldCollisionHollowBox*)co)->m_thickness; }
+	else return false;
+	if (shape) *shape = sh;
+	if (params) for (int k = 0; k < 4; k++) params[k] = p[k];
+	return true;
+}
+
+// structure of one of the reference's bounding-sphere hierarchies (kdTree.h: entity list, nodes, spheres), which the REFERENCE
+// built when the collision object was registered.  The node count has no accessor: nodes are numbered in creation order, so it is
+// the largest index reachable from the root + 1.
+struct HierarchyCopy { std::vector<uint32_t> lst; std::vector<int32_t> nodes; std::vector<float> hulls; };
+template <class BVH> static void copyHierarchy(const BVH &bvh, unsigned int numEntities, HierarchyCopy &out, pbdx_bvh &rec)
+{
+	std::vector<unsigned int> stack(1, 0u);
+	unsigned int maxIdx = 0;
+	while (!stack.empty())
+	{
+		const unsigned int n = stack.back(); stack.pop_back();
+		if (n > maxIdx) maxIdx = n;
+		if (!bvh.node(n).is_leaf()) { stack.push_back((unsigned int)bvh.node(n).children[0]); stack.push_back((unsigned int)bvh.node(n).children[1]); }
+	}
+	const unsigned int nNodes = maxIdx + 1;
+	out.lst.resize(numEntities); out.nodes.resize((size_t)4 * nNodes); out.hulls.resize((size_t)4 * nNodes);
+	for (unsigned int i = 0; i < numEntities; i++) out.lst[i] = bvh.entity(i);
+	for (unsigned int i = 0; i < nNodes; i++)
+	{
+		out.nodes[4 * i] = bvh.node(i).children[0]; out.nodes[4 * i + 1] = bvh.node(i).children[1];
+		out.nodes[4 * i + 2] = (int32_t)bvh.node(i).begin; out.nodes[4 * i + 3] = (int32_t)bvh.node(i).n;
+		for (int k = 0; k < 3; k++) out.hulls[4 * i + k] = (float)bvh.hull(i).x()[k];
+		out.hulls[4 * i + 3] = (float)bvh.hull(i).r();
+	}
+	rec.num_nodes = nNodes; rec.num_entities = numEntities; rec.entities = out.lst.data(); rec.nodes = out.nodes.data(); rec.hulls = out.hulls.data();
 }
 
 // The scan over all constraints (one virtual call each) is repeated only when the model's make-up changed.
@@ -173,14 +220,27 @@ bool TimeStepControllerHIP::supported(SimulationModel &model)
 					t != D::DistanceFieldCollisionCylinder::TYPE_ID && t != D::DistanceFieldCollisionHollowSphere::TYPE_ID && t != D::DistanceFieldCollisionHollowBox::TYPE_ID)
 					return false;                             // e.g. cubic SDF (Discregrid) colliders
 			}
+			else if (co->m_bodyType == CollisionDetection::CollisionObject::TetModelCollisionObjectType)
+			{
+				if (t != D::DistanceFieldCollisionObjectWithoutGeometry::TYPE_ID && !analyticShape(co, NULL, NULL)) return false;      // e.g. cubic SDF (Discregrid)
+			}
 			else if (t != D::DistanceFieldCollisionObjectWithoutGeometry::TYPE_ID)
-				return false;                                 // deformable vs deformable contacts (ParticleTetContactConstraint)
+				return false;
 		}
-		// more than one tet model registered => solid-solid contacts are possible: not handled
-		unsigned int tetObjects = 0;
+		// more than one tet model registered => every ordered pair of them is tested for deformable-deformable contacts
+		// (ParticleTetContactConstraint, DistanceFieldCollisionDetection.cpp:160-177).  The engine runs them when every tet object
+		// carries an analytic distance field (the reference walks the second object's tet hierarchy, which exists only then) and the
+		// friction of every pair is zero (the reference's friction impulse for these contacts reads an unset multiplier).
+		unsigned int tetObjects = 0, tetWithout = 0;
+		bool friction = false;
 		for (CollisionDetection::CollisionObject *co : m_collisionDetection->getCollisionObjects())
-			if (co->m_bodyType == CollisionDetection::CollisionObject::TetModelCollisionObjectType) tetObjects++;
-		if (tetObjects > 1) return false;
+			if (co->m_bodyType == CollisionDetection::CollisionObject::TetModelCollisionObjectType)
+			{
+				tetObjects++;
+				if (co->getTypeId() == D::DistanceFieldCollisionObjectWithoutGeometry::TYPE_ID) tetWithout++;
+				if (model.getTetModels()[co->m_bodyIndex]->getFrictionCoeff() != 0.0) friction = true;
+			}
+		if (tetObjects > 1 && (tetWithout != 0 || friction)) return false;
 	}
 	for (Constraint *c : model.getConstraints())
 		if (engineType(c) < 0) return false;                // e.g. GenericConstraints, joints, rods
@@ -209,12 +269,7 @@ bool TimeStepControllerHIP::uploadColliders(SimulationModel &model)
 				memset(&c, 0, sizeof(c));
 				D::DistanceFieldCollisionObject *dco = (D::DistanceFieldCollisionObject*)co;
 				c.invert = dco->m_invertSDF < 0 ? 1 : 0;
-				if (t == D::DistanceFieldCollisionBox::TYPE_ID) { c.shape = PBDX_SHAPE_BOX; for (int k = 0; k < 3; k++) c.params[k] = (float)((D::DistanceFieldCollisionBox*)co)->m_box[k]; }
-				else if (t == D::DistanceFieldCollisionSphere::TYPE_ID) { c.shape = PBDX_SHAPE_SPHERE; c.params[0] = (float)((D::DistanceFieldCollisionSphere*)co)->m_radius; }
-				else if (t == D::DistanceFieldCollisionTorus::TYPE_ID) { c.shape = PBDX_SHAPE_TORUS; c.params[0] = (float)((D::DistanceFieldCollisionTorus*)co)->m_radii[0]; c.params[1] = (float)((D::DistanceFieldCollisionTorus*)co)->m_radii[1]; }
-				else if (t == D::DistanceFieldCollisionCylinder::TYPE_ID) { c.shape = PBDX_SHAPE_CYLINDER; c.params[0] = (float)((D::DistanceFieldCollisionCylinder*)co)->m_dim[0]; c.params[1] = (float)((D::DistanceFieldCollisionCylinder*)co)->m_dim[1]; }
-				else if (t == D::DistanceFieldCollisionHollowSphere::TYPE_ID) { c.shape = PBDX_SHAPE_HOLLOW_SPHERE; c.params[0] = (float)((D::DistanceFieldCollisionHollowSphere*)co)->m_radius; c.params[1] = (float)((D::DistanceFieldCollisionHollowSphere*)co)->m_thickness; }
-				else { c.shape = PBDX_SHAPE_HOLLOW_BOX; for (int k = 0; k < 3; k++) c.params[k] = (float)((D::DistanceFieldCollisionHollowBox*)co)->m_box[k]; c.params[3] = (float)((D::DistanceFieldCollisionHollowBox*)co)->m_thickness; }
+				analyticShape(co, &c.shape, c.params);
 				RigidBody *rb = model.getRigidBodies()[co->m_bodyIndex];
 				const Matrix3r &R = rb->getTransformationR();
 				for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) c.R[3 * r + k] = (float)R(r, k);
@@ -252,7 +307,68 @@ bool TimeStepControllerHIP::uploadColliders(SimulationModel &model)
 	}
 	if (pbdx_solver_set_colliders(m_solver, (uint32_t)cols.size(), cols.data()) != PBDX_OK) return false;
 	if (pbdx_solver_set_collision_ranges(m_solver, (uint32_t)ranges.size(), ranges.data()) != PBDX_OK) return false;
+	if (!uploadTetColliders(model, tolerance)) return false;
 	return pbdx_solver_set_contact_params(m_solver, tolerance, (float)model.getContactStiffnessParticleRigidBody(), m_maxIterationsV) == PBDX_OK;
+}
+
+// Deformable vs deformable contacts: the tet-model collision objects with their distance field in the rest frame and the three
+// hierarchies the reference built for them (DistanceFieldCollisionDetection.cpp:485-520 addCollisionObject + initTetBVH).  Uploaded
+// once per set of objects: the engine keeps the contact list of the last detection next to them (it is what the NEXT step's
+// position solves read), so a re-upload is also what empties that list (reset()).
+bool TimeStepControllerHIP::uploadTetColliders(SimulationModel &model, float tolerance)
+{
+	typedef DistanceFieldCollisionDetection D;
+	std::vector<D::DistanceFieldCollisionObject*> objs;
+	if (m_collisionDetection != NULL)
+		for (CollisionDetection::CollisionObject *co : m_collisionDetection->getCollisionObjects())
+			if (co->m_bodyType == CollisionDetection::CollisionObject::TetModelCollisionObjectType && analyticShape(co, NULL, NULL))
+				objs.push_back((D::DistanceFieldCollisionObject*)co);
+	if (objs.size() < 2) objs.clear();                       // a single solid has nobody to collide with (no self collisions, :43)
+	uint64_t sig = 0;
+	if (!objs.empty())
+	{
+		const unsigned int n = model.getParticles().size();
+		sig = fnv(fnv(fnv(1469598103934665603ull, objs.data(), objs.size() * sizeof(objs[0])), &tolerance, sizeof(tolerance)), &n, sizeof(n));
+		if (!sig) sig = 1;
+	}
+	if (sig == m_tetSignature) return true;
+	m_tetSignature = 0;
+	if (objs.empty()) return pbdx_solver_set_tet_colliders(m_solver, 0, NULL, tolerance) == PBDX_OK;
+	ParticleData &pd = model.getParticles();
+	const unsigned int n = pd.size();
+#ifdef USE_DOUBLE
+	std::vector<float> x0((size_t)3 * n);
+	for (unsigned int i = 0; i < n; i++) for (int k = 0; k < 3; k++) x0[3 * i + k] = (float)pd.getPosition0(i)[k];
+	if (pbdx_solver_set_rest_positions(m_solver, n, x0.data()) != PBDX_OK) return false;
+#else
+	if (pbdx_solver_set_rest_positions(m_solver, n, &pd.getPosition0(0)[0]) != PBDX_OK) return false;
+#endif
+	std::vector<pbdx_tet_collider> recs(objs.size());
+	std::vector<HierarchyCopy> copies(3 * objs.size());
+	std::vector<std::vector<uint32_t> > tets(objs.size());
+	for (size_t q = 0; q < objs.size(); q++)
+	{
+		D::DistanceFieldCollisionObject *co = objs[q];
+		TetModel *tm = model.getTetModels()[co->m_bodyIndex];
+		const Utilities::IndexedTetMesh &mesh = tm->getParticleMesh();
+		pbdx_tet_collider &c = recs[q];
+		memset(&c, 0, sizeof(c));
+		analyticShape(co, &c.shape, c.params);
+		c.invert = co->m_invertSDF < 0 ? 1 : 0;
+		c.first_particle = tm->getIndexOffset(); c.num_vertices = mesh.numVertices(); c.num_tets = mesh.numTets();
+		tets[q].assign(mesh.getTets().begin(), mesh.getTets().end());
+		c.tets = tets[q].data();
+		for (int k = 0; k < 3; k++) c.initial_x[k] = (float)tm->getInitialX()[k];
+		for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) c.initial_R[3 * r + k] = (float)tm->getInitialR()(r, k);
+		c.restitution = (float)tm->getRestitutionCoeff(); c.friction = (float)tm->getFrictionCoeff();
+		c.test_mesh = co->m_testMesh ? 1 : 0; c.body_index = co->m_bodyIndex;
+		copyHierarchy(co->m_bvh, c.num_vertices, copies[3 * q], c.points);
+		copyHierarchy(co->m_bvhTets, c.num_tets, copies[3 * q + 1], c.tets_bvh);
+		copyHierarchy(co->m_bvhTets0, c.num_tets, copies[3 * q + 2], c.tets_rest);
+	}
+	if (pbdx_solver_set_tet_colliders(m_solver, (uint32_t)recs.size(), recs.data(), tolerance) != PBDX_OK) return false;
+	m_tetSignature = sig;
+	return true;
 }
 
 // ParticleData's arrays go to the engine as they are: std::vector<Vector3r> is a packed Real[3] array

@@ -24,7 +24,8 @@
 // Scope: models whose constraints are all particle constraints known to the engine.  Rigid bodies are
 // accepted when they are all static (mass 0) colliders of a DistanceFieldCollisionDetection with analytic
 // distance fields (box, sphere, torus, cylinder, hollow sphere / box): the particle vs rigid body contacts
-// are then detected and solved on the GPU as well.  No dynamic rigid bodies, joints, orientations.  There is NO silent CPU path: a step the
+// are then detected and solved on the GPU as well; so are the contacts between tet models that carry such a distance field
+// (ParticleTetContactConstraint; friction 0 only).  No dynamic rigid bodies, joints, orientations.  There is NO silent CPU path: a step the
 // engine cannot run (no HIP device, HIP error, unsupported model) logs an error, leaves the
 // model untouched and is counted in numFailedSteps().  A host application that prefers the
 // reference's own CPU TimeStepController for such models opts in explicitly with
@@ -89,6 +90,7 @@ namespace PBD
 		bool buildSchedule(SimulationModel &model, bool paramsOnly);
 		bool uploadParticles(SimulationModel &model);
 		bool uploadColliders(SimulationModel &model);
+		bool uploadTetColliders(SimulationModel &model, float tolerance);
 		bool downloadParticles(SimulationModel &model);
 		bool prepare(SimulationModel &model, bool forceUpload);
 		bool runSteps(SimulationModel &model, unsigned int numSteps);
@@ -115,6 +117,7 @@ namespace PBD
 		// what `supported` was last evaluated for
 		const void *m_supportedFor; size_t m_supportedConstraints, m_supportedBodies, m_supportedObjects; bool m_supported;
 		bool m_accelValid; Real m_accelGravity[3];
+		uint64_t m_tetSignature;       // which set of deformable colliders the engine holds (0 = none)
 		std::vector<float> m_invMass32;
 		std::vector<double> m_invMass64;
 	};

@@ -1,0 +1,143 @@
+"""Contacts between deformable solids (ParticleTetContactConstraint): a tet model that carries an analytic
+distance field in its rest frame collides with the particles of another tet model.
+
+CPU part: the engine's detection code (pbdx_tetcontact.h, the same source the device kernels compile) evaluated on the host
+reproduces the reference's contact list bit for bit -- every field of every contact, in the reference's order -- over a run in
+which the upper bar lands on the lower one.  GPU part: the reference scene stepped through the plug-in equals the reference's CPU
+TimeStepController bitwise, and the device's contact list equals the reference's.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from positionbaseddynamics_amd import _ffi
+from tests import tetcontact_util as tcu
+from tests import util
+
+PLUGIN = os.path.join(util.ROOT, "positionbaseddynamics_amd", "plugin", "_build", "libpbd_timestep_hip_f32.so")
+
+
+def _ref():
+    from oracle import refdrv
+    if not refdrv.available("f32"):
+        pytest.skip("oracle/_ref (the reference compiled in place) is not built")
+    return refdrv.Ref("f32")
+
+
+def test_engine_detection_on_host_equals_reference_contact_list():
+    ref = _ref()
+    objs = tcu.two_bar_scene(ref)
+    ref.set_params(1, 5, 0)
+    cols = tcu.TetColliders(ref, objs, (0, 1), 0.01)
+    total = 0
+    for step in range(110):
+        ref.step(1)
+        want = tcu.oracle_contacts_as_engine_records(ref)
+        got = tcu.host_contacts(ref, cols)
+        assert len(got) == len(want), "step %d: %d contacts, reference %d" % (step, len(got), len(want))
+        if len(want):
+            assert util.bitwise_equal(got[:, :26], want), "step %d" % step
+            # vertex ids of the contact's tet: global particle indices of tets[tet] of the solid
+            info = ref.tet_model_info(1)
+            solid = got[:, 1].astype(int)
+            for row in got[solid == 1][:8]:
+                t = int(row[2])
+                assert np.array_equal(row[26:30].astype(int), info["offset"] + np.asarray(info["tets"]).reshape(-1, 4)[t])
+        total += len(want)
+    ref.reset_all()
+    assert total > 300, "the scene is supposed to produce contacts (got %d)" % total
+
+
+def test_set_tet_colliders_validates_before_touching_the_device():
+    """Argument checks come first, so they are testable without a GPU: friction and malformed hierarchies are refused."""
+    ref = _ref()
+    objs = tcu.two_bar_scene(ref)
+    cols = tcu.TetColliders(ref, objs, (0, 1), 0.01, friction=0.1)
+    ref.reset_all()
+    h = C.c_void_p()
+    if _ffi.lib.pbdx_solver_create(C.byref(h), 0) != 0:
+        pytest.skip("no HIP device: the solver cannot be created, and the checks live behind it")
+    try:
+        assert _ffi.lib.pbdx_solver_set_tet_colliders(h, cols.n, cols.arr, 0.01) != 0
+        assert b"friction" in _ffi.lib.pbdx_last_error()
+    finally:
+        _ffi.lib.pbdx_solver_destroy(h)
+
+
+def _plugin_handles(ref):
+    lib = C.CDLL(PLUGIN)
+    lib.pbdx_timestep_hip_solver.argtypes = [C.c_void_p]
+    lib.pbdx_timestep_hip_solver.restype = C.c_void_p
+    for name in ("gpu_steps", "failed_steps", "fallback_steps"):
+        f = getattr(lib, "pbdx_timestep_hip_" + name)
+        f.argtypes = [C.c_void_p]
+        f.restype = C.c_uint
+    ts = C.c_void_p(ref.lib.refdrv_get_timestep())
+    return lib, ts
+
+
+def _device_contacts(lib, ts, capacity=8192):
+    out = np.zeros((capacity, _ffi.TET_CONTACT_FLOATS), dtype=np.float32)
+    n = C.c_uint32()
+    _ffi.check(_ffi.lib.pbdx_solver_get_tet_contacts(C.c_void_p(lib.pbdx_timestep_hip_solver(ts)), capacity, C.byref(n), out.ctypes.data_as(_ffi.pf)), "get_tet_contacts")
+    return out[:n.value]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solid_method,sub_steps", [(6, 1), (3, 1), (6, 2)])
+def test_plugin_two_colliding_bars_bit_exact(solid_method, sub_steps):
+    if not os.path.exists(PLUGIN):
+        pytest.skip("plug-in not built")
+    ref = _ref()
+    steps = 100
+    checkpoints = (60, 80, 100)
+    tcu.two_bar_scene(ref, solid_method=solid_method)
+    ref.set_params(sub_steps, 5, 0)
+    cpu = {}
+    seen = 0
+    for s in range(1, steps + 1):
+        ref.step(1)
+        seen += ref.num_particle_solid_contacts()
+        if s in checkpoints:
+            cpu[s] = (ref.positions().copy(), ref.get_array(2).copy(), tcu.oracle_contacts_as_engine_records(ref))
+    assert seen > 200, "the bars never touched (%d contacts)" % seen
+    tcu.two_bar_scene(ref, solid_method=solid_method)
+    assert ref.install_timestep_plugin(PLUGIN) == 0
+    ref.lib.refdrv_attach_collision_detection()
+    ref.set_params(sub_steps, 5, 0)
+    lib, ts = _plugin_handles(ref)
+    done = 0
+    for s in checkpoints:
+        ref.step(s - done)
+        done = s
+        assert lib.pbdx_timestep_hip_failed_steps(ts) == 0 and lib.pbdx_timestep_hip_fallback_steps(ts) == 0
+        x, v = ref.positions().copy(), ref.get_array(2).copy()
+        assert util.bitwise_equal(x, cpu[s][0]), "step %d: max err %.3e" % (s, util.max_err(x, cpu[s][0]))
+        assert util.bitwise_equal(v, cpu[s][1]), "step %d (velocities)" % s
+        got = _device_contacts(lib, ts)
+        assert len(got) == len(cpu[s][2]), "step %d: %d contacts on the device, reference %d" % (s, len(got), len(cpu[s][2]))
+        if len(got):
+            assert util.bitwise_equal(got[:, :26], cpu[s][2]), "step %d: contact records" % s
+    assert lib.pbdx_timestep_hip_gpu_steps(ts) == steps
+    ref.reset_all()
+
+
+@pytest.mark.gpu
+def test_plugin_refuses_friction_between_deformables():
+    """The reference's friction impulse for these contacts reads a multiplier nothing has written (Constraints.h:553,
+    SimulationModel.cpp:557): there is no defined result to match, so the model is refused, loudly."""
+    if not os.path.exists(PLUGIN):
+        pytest.skip("plug-in not built")
+    ref = _ref()
+    tcu.two_bar_scene(ref, friction=0.1)
+    assert ref.install_timestep_plugin(PLUGIN) == 0
+    ref.lib.refdrv_attach_collision_detection()
+    ref.set_params(1, 5, 0)
+    x0 = ref.positions().copy()
+    ref.step(2)
+    lib, ts = _plugin_handles(ref)
+    assert lib.pbdx_timestep_hip_failed_steps(ts) == 2 and lib.pbdx_timestep_hip_gpu_steps(ts) == 0
+    assert np.array_equal(ref.positions(), x0)
+    ref.reset_all()

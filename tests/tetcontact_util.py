@@ -1,0 +1,104 @@
+"""Helpers of the particle-tet contact tests: the two-bar collision scene on the oracle and the conversion of the oracle's
+collision objects (box distance fields on tet models + the bounding-sphere hierarchies the REFERENCE constructed) into the
+engine's pbdx_tet_collider records."""
+import ctypes as C
+
+import numpy as np
+
+from positionbaseddynamics_amd import _ffi
+
+DIMS = (8, 3, 3)
+SCALE = (2.0, 0.5, 0.5)
+T_LOWER = (0.0, 0.0, 0.0)
+T_UPPER = (0.3, 0.62, 0.05)
+
+
+def two_bar_scene(ref, solid_method=6, tolerance=0.01, friction=0.0, dims=DIMS, t_upper=T_UPPER):
+    """Lower bar clamped at both ends, upper bar falling onto it; both tet models carry a box distance field in their rest frame
+    and test their particles against the other solid (DistanceFieldCollisionDetection.cpp:160-177)."""
+    ref.reset_all()
+    ref.set_num_threads(1)
+    ref.set_time_step_size(0.005)
+    ref.set_gravity((0, -9.81, 0))
+    ref.add_regular_tet_model(*dims, T_LOWER, None, SCALE)
+    ref.add_regular_tet_model(*dims, t_upper, None, SCALE)
+    w, h, d = dims
+    for j in range(h):
+        for k in range(d):
+            ref.set_mass(j * d + k, 0.0)
+            ref.set_mass(((w - 1) * h + j) * d + k, 0.0)
+    for tm in (0, 1):
+        ref.add_solid_constraints(tm, solid_method, 1e5 if solid_method in (3, 6) else 1.0, 0.3, 1e5 if solid_method == 6 else 1.0, False, False)
+    ref.set_collision_tolerance(tolerance)
+    ref.set_tet_model_initial_transform(0, T_LOWER)
+    ref.set_tet_model_initial_transform(1, t_upper)
+    objs = [ref.add_tet_collision_box(tm, SCALE, True, 0.6, friction) for tm in (0, 1)]
+    ref.attach_collision_detection()
+    return objs
+
+
+class TetColliders:
+    """pbdx_tet_collider array built from the oracle's collision objects; keeps the numpy arrays alive."""
+
+    def __init__(self, ref, objs, tet_models, tolerance, friction=0.0):
+        self.keep = []
+        self.n = len(objs)
+        self.arr = (_ffi.TetCollider * self.n)()
+        self.tolerance = tolerance
+        n_per = []
+        for q, (co, tm) in enumerate(zip(objs, tet_models)):
+            info = ref.tet_model_info(tm)
+            c = self.arr[q]
+            c.shape, c.invert = 0, 0
+            box = np.asarray(info["box"], dtype=np.float32)
+            for k in range(3):
+                c.params[k] = np.float32(0.5) * box[k]           # m_box = 0.5 * box (DistanceFieldCollisionDetection.cpp:502)
+            c.first_particle, c.num_vertices, c.num_tets = info["offset"], info["num_vertices"], info["num_tets"]
+            tets = np.ascontiguousarray(info["tets"], dtype=np.uint32)
+            self.keep.append(tets)
+            c.tets = tets.ctypes.data_as(C.POINTER(C.c_uint32))
+            for k in range(3):
+                c.initial_x[k] = info["initial_x"][k]
+            for k in range(9):
+                c.initial_R[k] = info["initial_R"][k]
+            c.restitution, c.friction, c.test_mesh, c.body_index = 0.6, friction, 1, tm
+            for which, field in ((0, "points"), (1, "tets_bvh"), (2, "tets_rest")):
+                b = ref.bvh(co, which)
+                lst = np.ascontiguousarray(b["lst"], dtype=np.uint32)
+                nodes = np.ascontiguousarray(b["nodes"], dtype=np.int32)
+                hulls = np.ascontiguousarray(b["hulls"], dtype=np.float32)
+                self.keep += [lst, nodes, hulls]
+                f = getattr(c, field)
+                f.num_nodes, f.num_entities = len(nodes), len(lst)
+                f.entities = lst.ctypes.data_as(C.POINTER(C.c_uint32))
+                f.nodes = nodes.ctypes.data_as(C.POINTER(C.c_int32))
+                f.hulls = hulls.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def host_contacts(ref, colliders, capacity=4096):
+    """pbdx_debug_tet_contacts on the oracle's current state: the engine's detection code evaluated on the host."""
+    x = ref.positions().astype(np.float32)
+    x0 = ref.get_array(1).astype(np.float32)
+    w = ref.get_array(7).astype(np.float32)
+    pos4 = np.ascontiguousarray(np.concatenate([x, w[:, None]], axis=1), dtype=np.float32)
+    rest4 = np.ascontiguousarray(np.concatenate([x0, w[:, None]], axis=1), dtype=np.float32)
+    out = np.zeros((capacity, _ffi.TET_CONTACT_FLOATS), dtype=np.float32)
+    count = C.c_uint32(0)
+    _ffi.check(_ffi.lib.pbdx_debug_tet_contacts(len(x), pos4.ctypes.data_as(_ffi.pf), rest4.ctypes.data_as(_ffi.pf), colliders.n, colliders.arr,
+                                                float(colliders.tolerance), capacity, C.byref(count), out.ctypes.data_as(_ffi.pf)), "debug_tet_contacts")
+    return out[:count.value]
+
+
+def oracle_contacts_as_engine_records(ref):
+    """The oracle's ParticleTetContactConstraints in the column layout of the engine's 30-float record (vertex ids left out)."""
+    c = ref.particle_solid_contacts()
+    if not len(c):
+        return np.zeros((0, 26), dtype=np.float32)
+    out = np.zeros((len(c), 26), dtype=np.float32)
+    out[:, 0:3] = c[:, 0:3]
+    out[:, 3:6] = c[:, 3:6]
+    out[:, 6:9] = c[:, 6:9]          # constraintInfo.col(0) = normal
+    out[:, 9] = c[:, 6 + 6]          # constraintInfo(0, 2): column-major -> index 6
+    out[:, 10:22] = c[:, 16:28]
+    out[:, 22:26] = c[:, 28:32]
+    return out
