@@ -256,6 +256,9 @@ int pbdx_solver_set_rest_positions(pbdx_solver *s, uint32_t n, const float *x0);
  * m_x[4][3], m_invMasses[4], tet vertex particle ids[4] (indices as floats).  *count = number of contacts (may exceed capacity). */
 #define PBDX_TET_CONTACT_FLOATS 30
 int pbdx_solver_get_tet_contacts(pbdx_solver *s, uint32_t capacity, uint32_t *count, float *out);
+/* Developer aid: the bounding spheres (centre, radius) of hierarchy `which` (0 points, 1 tets, 2 tets at rest) of a collider as the last
+ * detection left them; *count = number of nodes. */
+int pbdx_debug_tet_hulls(pbdx_solver *s, uint32_t collider, int which, uint32_t capacity, uint32_t *count, float *out);
 /* The same detection evaluated on the HOST by the same code (pbdx_tetcontact.h is host + device): developer / test aid, no GPU
  * needed.  pos4 / rest4: n x (x, y, z, invMass) records. */
 int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float *rest4, uint32_t n, const pbdx_tet_collider *colliders,
@@ -293,8 +296,10 @@ enum {
 	                                * particle state it saved at the start of the call, repeats the call with one launch per segment and stops
 	                                * using the schedule (pbdx_persistent_info::timeouts) -- the caller sees the result of an undisturbed run. */
 	PBDX_OPT_PERSISTENT_TIMEOUT_MS = 13, /* bound of a tile-to-tile wait inside the persistent launch in milliseconds, 1 .. 10000 (default 250) */
-	PBDX_OPT_PERSISTENT_WGS_PER_CU = 14  /* tiles (workgroups) the persistent launch keeps resident per CU, 1 .. 4 (default 1): with k > 1 the LDS is split k ways
+	PBDX_OPT_PERSISTENT_WGS_PER_CU = 14, /* tiles (workgroups) the persistent launch keeps resident per CU, 1 .. 4 (default 1): with k > 1 the LDS is split k ways
 	                                * (smaller tiles, more halo) and one tile's fill / hand-off overlaps another tile's colour sweep on the same CU */
+	PBDX_OPT_TET_CONTACTS_SERIAL = 15    /* developer cross-check: 1 = detect and solve the contacts between deformable solids in ONE thread, in the reference's own
+	                                      * control flow (default 0: the parallel, order-preserving form of pbdx_tetcontact_dev.h; both give the same bits) */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
 

@@ -738,6 +738,7 @@ class Solver:
     OPT_PERSISTENT = 12
     OPT_PERSISTENT_TIMEOUT_MS = 13
     OPT_PERSISTENT_WGS_PER_CU = 14
+    OPT_TET_CONTACTS_SERIAL = 15
     OPT_USE_GRAPH = 1
     OPT_BLOCK_SIZE = 2
     OPT_XCD_REMAP = 3

@@ -34,7 +34,7 @@
 #include "pbdx_access.h"
 #include "pbdx_plan.h"
 #include "pbdx_contact.h"
-#include "pbdx_tetcontact.h"
+#include "pbdx_tetcontact_dev.h"
 #include <algorithm>
 #include <string.h>
 
@@ -789,14 +789,10 @@ __global__ __launch_bounds__(256) void contact_kernel(ContactArgs a)
 	}
 }
 
-// ---- contacts between deformable solids (pbdx_tetcontact.h) ---------------------------------------------------------------
-// Per step, after the substeps: refresh the bounding spheres of every collider's point and tet hierarchy (KDTree::update: every
-// node from its entities, sums in list order -- one thread per node), the colliders' boxes, then the detection.  The detection walks
-// the ordered pairs of colliders and the dual hierarchy traversal of each pair in ONE thread: the order in which the reference's
-// single-threaded traversal reaches the leaf pairs IS the order of its contact list, and that list is solved sequentially
-// (Gauss-Seidel) inside the iteration loop of the next step -- the order is part of the result.
-constexpr uint32_t kMaxTetContacts = 1u << 16;
-enum { kTcCount = 0, kTcOverflow = 1, kTcStack = 2, kTcWords = 4 };
+// ---- contacts between deformable solids (pbdx_tetcontact.h, pbdx_tetcontact_dev.h) -------------------------------------------
+// Per step, after the substeps: refresh the bounding spheres of every collider's point and tet hierarchy, the colliders' boxes, then
+// the detection.  Its parallel form is in pbdx_tetcontact_dev.h; the two kernels below are the reference's control flow in ONE thread
+// (PBDX_OPT_TET_CONTACTS_SERIAL), kept as the in-engine cross-check of the parallel form: both must produce the same list and state.
 __global__ __launch_bounds__(256) void tet_hull_kernel(const TetColliderView *views, uint32_t collider, const P4 *pos, int which)
 {
 	const TetColliderView &v = views[collider];
@@ -851,12 +847,6 @@ __global__ void tet_detect_kernel(const TetColliderView *views, uint32_t n, cons
 	if (!ok) counters[kTcStack] = 1u;
 }
 // TimeStepController.cpp:288-291: after the colour groups of an iteration, the contact list sequentially
-struct TetPosAccess
-{
-	float4 *pos;
-	__device__ __forceinline__ P4 get(uint32_t i) const { const float4 v = pos[i]; P4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
-	__device__ __forceinline__ void add(uint32_t i, V3 c) { float4 v = pos[i]; v.x += c.x; v.y += c.y; v.z += c.z; pos[i] = v; }
-};
 __global__ void tet_contact_solve_kernel(float4 *pos, const TetContact *contacts, const uint32_t *counters)
 {
 	if (blockIdx.x || threadIdx.x) return;
@@ -1015,6 +1005,9 @@ struct pbdx_solver
 	float *d_tet_aabb = nullptr;
 	TetContact *d_tet_contacts = nullptr;
 	uint32_t *d_tet_counters = nullptr;
+	TetWork tet_work = {};
+	void *tet_work_alloc[12] = {};
+	int tet_serial = 0;                            // PBDX_OPT_TET_CONTACTS_SERIAL
 	float4 *d_rest = nullptr;                      // ParticleData::m_x0 (needed by the contacts between solids only)
 	bool rest_set = false;
 	bool tet_active() const { return !tet_views.empty(); }
@@ -1033,6 +1026,8 @@ struct pbdx_solver
 		tet_dev.clear(); tet_views.clear();
 		if (d_tet_views) { (void)hipFree(d_tet_views); d_tet_views = nullptr; }
 		if (d_tet_aabb) { (void)hipFree(d_tet_aabb); d_tet_aabb = nullptr; }
+		for (void *&p : tet_work_alloc) if (p) { (void)hipFree(p); p = nullptr; }
+		tet_work = TetWork{};
 	}
 
 	// fused plan
@@ -1585,7 +1580,10 @@ int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, Pr
 	auto tet_solve = [&](int buf) -> int
 	{
 		if (!with_tet_contacts || !s->tet_active()) return PBDX_OK;
-		hipLaunchKernelGGL(tet_contact_solve_kernel, dim3(1), dim3(64), 0, s->stream, s->d_pos[buf], (const TetContact *)s->d_tet_contacts, (const uint32_t *)s->d_tet_counters);
+		if (s->tet_serial)
+			hipLaunchKernelGGL(tet_contact_solve_kernel, dim3(1), dim3(64), 0, s->stream, s->d_pos[buf], (const TetContact *)s->d_tet_contacts, (const uint32_t *)s->d_tet_counters);
+		else
+			hipLaunchKernelGGL(tet_contact_solve_levels_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_pos[buf], (const TetContact *)s->d_tet_contacts, s->tet_work);
 		HIPCHECK(hipGetLastError());
 		return PBDX_OK;
 	};
@@ -1763,17 +1761,33 @@ int enqueue_tet_detection(pbdx_solver *s)
 {
 	if (!s->tet_active() || !s->n) return PBDX_OK;
 	const P4 *pos = reinterpret_cast<const P4 *>(s->d_pos[0]);
-	for (size_t c = 0; c < s->tet_views.size(); c++)
+	const P4 *rest = reinterpret_cast<const P4 *>(s->d_rest);
+	const TetColliderView *views = s->d_tet_views;
+	const uint32_t nc = (uint32_t)s->tet_views.size();
+	if (s->tet_serial)
 	{
-		const TetColliderView &v = s->tet_views[c];
-		if (v.points.num_nodes)
-			hipLaunchKernelGGL(tet_hull_kernel, dim3((v.points.num_nodes + 255) / 256), dim3(256), 0, s->stream, (const TetColliderView *)s->d_tet_views, (uint32_t)c, pos, 0);
-		if (v.tet_bvh.num_nodes)
-			hipLaunchKernelGGL(tet_hull_kernel, dim3((v.tet_bvh.num_nodes + 255) / 256), dim3(256), 0, s->stream, (const TetColliderView *)s->d_tet_views, (uint32_t)c, pos, 1);
+		for (uint32_t c = 0; c < nc; c++)
+		{
+			const TetColliderView &v = s->tet_views[c];
+			hipLaunchKernelGGL(tet_hull_kernel, dim3((v.points.num_nodes + 255) / 256), dim3(256), 0, s->stream, views, c, pos, 0);
+			hipLaunchKernelGGL(tet_hull_kernel, dim3((v.tet_bvh.num_nodes + 255) / 256), dim3(256), 0, s->stream, views, c, pos, 1);
+		}
+		hipLaunchKernelGGL(tet_aabb_kernel, dim3(nc), dim3(256), 0, s->stream, views, pos, s->d_tet_aabb);
+		hipLaunchKernelGGL(tet_detect_kernel, dim3(1), dim3(64), 0, s->stream, views, nc, pos, rest, (const float *)s->d_tet_aabb, s->d_tet_contacts, s->d_tet_counters);
 	}
-	hipLaunchKernelGGL(tet_aabb_kernel, dim3((uint32_t)s->tet_views.size()), dim3(256), 0, s->stream, (const TetColliderView *)s->d_tet_views, pos, s->d_tet_aabb);
-	hipLaunchKernelGGL(tet_detect_kernel, dim3(1), dim3(64), 0, s->stream, (const TetColliderView *)s->d_tet_views, (uint32_t)s->tet_views.size(), pos,
-		reinterpret_cast<const P4 *>(s->d_rest), (const float *)s->d_tet_aabb, s->d_tet_contacts, s->d_tet_counters);
+	else
+	{
+		uint32_t max_nodes = 1;
+		for (const TetColliderView &v : s->tet_views) max_nodes = std::max(max_nodes, std::max(v.points.num_nodes, v.tet_bvh.num_nodes));
+		hipLaunchKernelGGL(tet_hull_wave_kernel, dim3((max_nodes + 3) / 4, 2 * nc), dim3(256), 0, s->stream, views, pos);
+		hipLaunchKernelGGL(tet_aabb_kernel, dim3(nc), dim3(256), 0, s->stream, views, pos, s->d_tet_aabb);
+		hipLaunchKernelGGL(tet_traverse_kernel, dim3(1), dim3(1024), 0, s->stream, views, nc, (const float *)s->d_tet_aabb, s->tet_work);
+		const uint32_t grid = (uint32_t)std::max(1, s->prop.multiProcessorCount) * 8u;
+		hipLaunchKernelGGL(tet_candidates_kernel<false>, dim3(grid), dim3(256), 0, s->stream, views, pos, rest, s->tet_work, s->d_tet_contacts);
+		hipLaunchKernelGGL(tet_chunk_scan_kernel, dim3(1), dim3(1024), 0, s->stream, s->tet_work);
+		hipLaunchKernelGGL(tet_candidates_kernel<true>, dim3(grid), dim3(256), 0, s->stream, views, pos, rest, s->tet_work, s->d_tet_contacts);
+		hipLaunchKernelGGL(tet_levels_kernel, dim3(1), dim3(1024), 0, s->stream, (const TetContact *)s->d_tet_contacts, s->tet_work);
+	}
 	HIPCHECK(hipGetLastError());
 	return PBDX_OK;
 }
@@ -1853,6 +1867,7 @@ int set_particles_impl(pbdx_solver *s, uint32_t n, const T *x, const T *v, const
 	{
 		HIPCHECK(hipStreamSynchronize(s->stream));
 		s->free_particles();
+		s->free_tet_colliders();   // they refer to particle ranges of the old image as well
 		s->drop_graph();
 		s->free_batches();         // a schedule refers to particle indices of the old image: it must be re-added
 		s->schedule_version++;
@@ -2215,6 +2230,8 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 	case PBDX_OPT_PERSISTENT_WGS_PER_CU:
 		if (value < 1 || value > 4) { set_error("persistent workgroups per CU must be 1 .. 4"); return PBDX_ERR_INVALID; }
 		s->persist_wgs_per_cu = (uint32_t)value; replan = true; break;
+	case PBDX_OPT_TET_CONTACTS_SERIAL:
+		s->tet_serial = value ? 1 : 0; break;
 	case PBDX_OPT_PERSISTENT_TIMEOUT_MS:
 		if (value < 1 || value > 10000) { set_error("persistent timeout must be 1 .. 10000 ms"); return PBDX_ERR_INVALID; }
 		s->persist_timeout_ms = (uint32_t)value; break;
@@ -2393,7 +2410,8 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		if (c[kTcOverflow] || c[kTcStack])
 		{
 			(void)hipMemset(s->d_tet_counters, 0, kTcWords * sizeof(uint32_t));
-			set_error(c[kTcOverflow] ? "more than %u contacts between solids in one step" : "bounding-sphere-hierarchy traversal deeper than the engine's stack (%u)", c[kTcOverflow] ? kMaxTetContacts : 128u);
+			set_error(c[kTcOverflow] ? "more than %u contacts between solids in one step (or more than 4096 dependent contacts at one particle)" :
+				"the traversal of the bounding-sphere hierarchies exceeded the engine's capacity (%u node pairs / 2^21 candidate chunks; serial form: stack of 128)", c[kTcOverflow] ? kMaxTetContacts : s->tet_work.front_cap);
 			return PBDX_ERR_UNSUPPORTED;
 		}
 	}
@@ -2521,7 +2539,7 @@ int pbdx_solver_set_rest_positions(pbdx_solver *s, uint32_t n, const float *x0)
 
 int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_collider *colliders, float tolerance)
 {
-	if (!s || (n && !colliders)) { set_error("set_tet_colliders: bad arguments"); return PBDX_ERR_INVALID; }
+	if (!s || (n && !colliders) || n > 256) { set_error("set_tet_colliders: bad arguments (at most 256 colliders)"); return PBDX_ERR_INVALID; }
 	for (uint32_t i = 0; i < n; i++)
 	{
 		const pbdx_tet_collider &c = colliders[i];
@@ -2599,6 +2617,31 @@ int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 	if (!s->d_tet_contacts) HIPCHECK(hipMalloc(&s->d_tet_contacts, (size_t)kMaxTetContacts * sizeof(TetContact)));
 	if (!s->d_tet_counters) HIPCHECK(hipMalloc(&s->d_tet_counters, kTcWords * sizeof(uint32_t)));
 	HIPCHECK(hipMemset(s->d_tet_counters, 0, kTcWords * sizeof(uint32_t)));      // no contacts before the first detection
+	{
+		// scratch of the parallel detection / levelling (pbdx_tetcontact_dev.h); capacities are checked on the device and reported
+		TetWork &w = s->tet_work;
+		w.front_cap = std::max<uint32_t>(1u << 20, n * n);
+		w.chunk_cap = 1u << 21;
+		const size_t bytes[12] = { (size_t)3 * w.front_cap * 4, (size_t)3 * w.front_cap * 4, (size_t)2 * n * n * 4, ((size_t)w.front_cap + 1) * 4, (size_t)w.chunk_cap * 4,
+			(size_t)w.chunk_cap * 8, (size_t)w.chunk_cap * 4, (size_t)kMaxTetContacts * 4, ((size_t)kMaxTetLevels + 1) * 4, (size_t)kMaxTetContacts * 4, (size_t)s->n * 4, 0 };
+		for (int q = 0; q < 11; q++) HIPCHECK(hipMalloc(&s->tet_work_alloc[q], bytes[q]));
+		w.front[0] = (uint32_t *)s->tet_work_alloc[0]; w.front[1] = (uint32_t *)s->tet_work_alloc[1]; w.pair_ik = (uint32_t *)s->tet_work_alloc[2];
+		w.chunk_off = (uint32_t *)s->tet_work_alloc[3]; w.chunk_pair = (uint32_t *)s->tet_work_alloc[4]; w.chunk_mask = (unsigned long long *)s->tet_work_alloc[5];
+		w.chunk_base = (uint32_t *)s->tet_work_alloc[6]; w.order = (uint32_t *)s->tet_work_alloc[7]; w.level_start = (uint32_t *)s->tet_work_alloc[8];
+		w.level_of = (uint32_t *)s->tet_work_alloc[9]; w.owner = (uint32_t *)s->tet_work_alloc[10];
+		w.counters = s->d_tet_counters;
+	}
+	return PBDX_OK;
+}
+
+int pbdx_debug_tet_hulls(pbdx_solver *s, uint32_t collider, int which, uint32_t capacity, uint32_t *count, float *out)
+{
+	if (!s || !count || collider >= s->tet_dev.size() || which < 0 || which > 2) return PBDX_ERR_INVALID;
+	HIPCHECK(hipSetDevice(s->device));
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	const pbdx_solver::DevBvh &b = which == 0 ? s->tet_dev[collider].points : which == 1 ? s->tet_dev[collider].tet_bvh : s->tet_dev[collider].tet_bvh0;
+	*count = b.num_nodes;
+	if (out && capacity) HIPCHECK(hipMemcpy(out, b.hulls, (size_t)std::min(capacity, b.num_nodes) * sizeof(P4), hipMemcpyDeviceToHost));
 	return PBDX_OK;
 }
 

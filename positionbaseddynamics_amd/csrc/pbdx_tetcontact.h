@@ -81,7 +81,8 @@ PBDX_HD void hull_points(const BvhView &b, uint32_t node, const P4 *pos /* of th
 	P4 h; h.x = x.x; h.y = x.y; h.z = x.z; h.w = sqrtf(radius2);
 	b.hulls[node] = h;
 }
-// TetMeshBSH::compute_hull_approx
+// TetMeshBSH::compute_hull_approx.  Its radius is `sqrt(radius2) + m_tolerance` with the C library's sqrt(double): the sum is formed in
+// double and rounded to Real once (BoundingSphereHierarchy.cpp:105) -- one ulp away from the float sum for about a third of the nodes.
 PBDX_HD void hull_tets(const BvhView &b, uint32_t node, const P4 *pos, const uint32_t *tets, float tolerance)
 {
 	const uint32_t beg = (uint32_t)b.nodes[4 * node + 2], n = (uint32_t)b.nodes[4 * node + 3];
@@ -102,7 +103,7 @@ PBDX_HD void hull_tets(const BvhView &b, uint32_t node, const P4 *pos, const uin
 			radius2 = (radius2 < d) ? d : radius2;
 		}
 	}
-	P4 h; h.x = x.x; h.y = x.y; h.z = x.z; h.w = sqrtf(radius2) + tolerance;
+	P4 h; h.x = x.x; h.y = x.y; h.z = x.z; h.w = (float)(sqrt((double)radius2) + (double)tolerance);
 	b.hulls[node] = h;
 }
 // BoundingSphere::overlaps: double rr = m_r + other.m_r (Real sum, promoted); squaredNorm (Real) < rr * rr (double)

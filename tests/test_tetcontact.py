@@ -85,15 +85,30 @@ def _device_contacts(lib, ts, capacity=8192):
     return out[:n.value]
 
 
+def _device_hulls(lib, ts, collider, which):
+    out = np.zeros((1 << 16, 4), dtype=np.float32)
+    n = C.c_uint32()
+    _ffi.check(_ffi.lib.pbdx_debug_tet_hulls(C.c_void_p(lib.pbdx_timestep_hip_solver(ts)), collider, which, len(out), C.byref(n), out.ctypes.data_as(_ffi.pf)), "debug_tet_hulls")
+    return out[:n.value]
+
+
+# (solid method, substeps, bar dimensions, serial cross-check form of the engine)
+CASES = [(6, 1, tcu.DIMS, 0), (6, 1, tcu.DIMS, 1), (2, 1, tcu.DIMS, 0), (5, 1, tcu.DIMS, 0), (6, 2, tcu.DIMS, 0), (6, 1, (24, 6, 6), 0), (6, 1, (24, 6, 6), 1)]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("solid_method,sub_steps", [(6, 1), (3, 1), (6, 2)])
-def test_plugin_two_colliding_bars_bit_exact(solid_method, sub_steps):
+@pytest.mark.parametrize("solid_method,sub_steps,dims,serial", CASES)
+def test_plugin_two_colliding_bars_bit_exact(solid_method, sub_steps, dims, serial):
+    """Positions, velocities, the contact list (every field, the reference's order) and the bounding spheres of the hierarchies
+    after 60 / 80 / 100 steps of two bars colliding, engine (parallel form, and the one-thread cross-check form) vs the reference."""
     if not os.path.exists(PLUGIN):
         pytest.skip("plug-in not built")
     ref = _ref()
     steps = 100
     checkpoints = (60, 80, 100)
-    tcu.two_bar_scene(ref, solid_method=solid_method)
+    big = dims != tcu.DIMS
+    t_upper = (0.3, 0.5 * (1.0 + 1.0 / 5.0) + 0.02, 0.05) if big else tcu.T_UPPER
+    objs = tcu.two_bar_scene(ref, solid_method=solid_method, dims=dims, t_upper=t_upper)
     ref.set_params(sub_steps, 5, 0)
     cpu = {}
     seen = 0
@@ -101,26 +116,32 @@ def test_plugin_two_colliding_bars_bit_exact(solid_method, sub_steps):
         ref.step(1)
         seen += ref.num_particle_solid_contacts()
         if s in checkpoints:
-            cpu[s] = (ref.positions().copy(), ref.get_array(2).copy(), tcu.oracle_contacts_as_engine_records(ref))
-    assert seen > 200, "the bars never touched (%d contacts)" % seen
-    tcu.two_bar_scene(ref, solid_method=solid_method)
+            cpu[s] = (ref.positions().copy(), ref.get_array(2).copy(), tcu.oracle_contacts_as_engine_records(ref),
+                      [[ref.bvh(co, which)["hulls"].astype(np.float32) for which in (0, 1)] for co in objs])
+    assert seen > 100, "the bars never touched (%d contacts)" % seen
+    tcu.two_bar_scene(ref, solid_method=solid_method, dims=dims, t_upper=t_upper)
     assert ref.install_timestep_plugin(PLUGIN) == 0
     ref.lib.refdrv_attach_collision_detection()
     ref.set_params(sub_steps, 5, 0)
     lib, ts = _plugin_handles(ref)
+    _ffi.check(_ffi.lib.pbdx_solver_set_option(C.c_void_p(lib.pbdx_timestep_hip_solver(ts)), 15, serial), "set_option")
     done = 0
     for s in checkpoints:
         ref.step(s - done)
         done = s
         assert lib.pbdx_timestep_hip_failed_steps(ts) == 0 and lib.pbdx_timestep_hip_fallback_steps(ts) == 0
         x, v = ref.positions().copy(), ref.get_array(2).copy()
-        assert util.bitwise_equal(x, cpu[s][0]), "step %d: max err %.3e" % (s, util.max_err(x, cpu[s][0]))
-        assert util.bitwise_equal(v, cpu[s][1]), "step %d (velocities)" % s
+        for q in (0, 1):
+            for which in (0, 1):
+                assert util.bitwise_equal(_device_hulls(lib, ts, q, which), cpu[s][3][q][which]), "step %d: spheres of hierarchy %d of solid %d" % (s, which, q)
         got = _device_contacts(lib, ts)
         assert len(got) == len(cpu[s][2]), "step %d: %d contacts on the device, reference %d" % (s, len(got), len(cpu[s][2]))
         if len(got):
             assert util.bitwise_equal(got[:, :26], cpu[s][2]), "step %d: contact records" % s
+        assert util.bitwise_equal(x, cpu[s][0]), "step %d: max err %.3e" % (s, util.max_err(x, cpu[s][0]))
+        assert util.bitwise_equal(v, cpu[s][1]), "step %d (velocities)" % s
     assert lib.pbdx_timestep_hip_gpu_steps(ts) == steps
+    print("\n[tet contacts] dims %s method %d substeps %d serial %d: %d contacts over %d steps, %d at the last" % (dims, solid_method, sub_steps, serial, seen, steps, len(cpu[steps][2])))
     ref.reset_all()
 
 
