@@ -259,6 +259,9 @@ int pbdx_solver_get_tet_contacts(pbdx_solver *s, uint32_t capacity, uint32_t *co
 /* Developer aid: the bounding spheres (centre, radius) of hierarchy `which` (0 points, 1 tets, 2 tets at rest) of a collider as the last
  * detection left them; *count = number of nodes. */
 int pbdx_debug_tet_hulls(pbdx_solver *s, uint32_t collider, int which, uint32_t capacity, uint32_t *count, float *out);
+/* Developer aid: counters of the last detection: contacts, (flags: 1, 2), overlapping leaf pairs, 64-candidate chunks, dependency levels of the
+ * solve, generations and node pairs of the traversal's recursion tree. */
+int pbdx_debug_tet_counters(pbdx_solver *s, uint32_t out[8]);
 /* The same detection evaluated on the HOST by the same code (pbdx_tetcontact.h is host + device): developer / test aid, no GPU
  * needed.  pos4 / rest4: n x (x, y, z, invMass) records. */
 int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float *rest4, uint32_t n, const pbdx_tet_collider *colliders,

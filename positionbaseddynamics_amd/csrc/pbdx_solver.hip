@@ -35,6 +35,7 @@
 #include "pbdx_plan.h"
 #include "pbdx_contact.h"
 #include "pbdx_tetcontact_dev.h"
+#include <chrono>
 #include <algorithm>
 #include <string.h>
 
@@ -997,7 +998,7 @@ struct pbdx_solver
 	uint64_t contact_version = 0;
 
 	// contacts between deformable solids (pbdx_tetcontact.h)
-	struct DevBvh { uint32_t *lst = nullptr; int32_t *nodes = nullptr; P4 *hulls = nullptr; uint32_t num_nodes = 0; };
+	struct DevBvh { uint32_t *lst = nullptr; int32_t *nodes = nullptr; P4 *hulls = nullptr; uint32_t num_nodes = 0; uint32_t *flat = nullptr; P4 *gathered = nullptr; };
 	struct DevTetCollider { uint32_t *tets = nullptr; DevBvh points, tet_bvh, tet_bvh0; uint32_t max_nodes = 0; };
 	std::vector<DevTetCollider> tet_dev;
 	std::vector<TetColliderView> tet_views;       // host copy of the device views
@@ -1006,8 +1007,21 @@ struct pbdx_solver
 	TetContact *d_tet_contacts = nullptr;
 	uint32_t *d_tet_counters = nullptr;
 	TetWork tet_work = {};
-	void *tet_work_alloc[12] = {};
+	void *tet_work_alloc[16] = {};
 	int tet_serial = 0;                            // PBDX_OPT_TET_CONTACTS_SERIAL
+	// developer aid (PBDX_TET_PROFILE=1, hipGraph off): wall time per kernel of the contact path, printed when the solver is destroyed
+	bool tet_profile = getenv("PBDX_TET_PROFILE") != nullptr;
+	double tet_ms[8] = {}; uint64_t tet_launches[8] = {};
+	template <class F> void tet_timed(int slot, F &&launch)
+	{
+		if (!tet_profile || use_graph) { launch(); return; }
+		(void)hipStreamSynchronize(stream);
+		const auto t0 = std::chrono::steady_clock::now();
+		launch();
+		(void)hipStreamSynchronize(stream);
+		tet_ms[slot] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		tet_launches[slot]++;
+	}
 	float4 *d_rest = nullptr;                      // ParticleData::m_x0 (needed by the contacts between solids only)
 	bool rest_set = false;
 	bool tet_active() const { return !tet_views.empty(); }
@@ -1021,6 +1035,8 @@ struct pbdx_solver
 				if (b->lst) (void)hipFree(b->lst);
 				if (b->nodes) (void)hipFree(b->nodes);
 				if (b->hulls) (void)hipFree(b->hulls);
+				if (b->flat) (void)hipFree(b->flat);
+				if (b->gathered) (void)hipFree(b->gathered);
 			}
 		}
 		tet_dev.clear(); tet_views.clear();
@@ -1583,7 +1599,7 @@ int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, Pr
 		if (s->tet_serial)
 			hipLaunchKernelGGL(tet_contact_solve_kernel, dim3(1), dim3(64), 0, s->stream, s->d_pos[buf], (const TetContact *)s->d_tet_contacts, (const uint32_t *)s->d_tet_counters);
 		else
-			hipLaunchKernelGGL(tet_contact_solve_levels_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_pos[buf], (const TetContact *)s->d_tet_contacts, s->tet_work);
+			s->tet_timed(7, [&] { hipLaunchKernelGGL(tet_contact_solve_levels_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_pos[buf], (const TetContact *)s->d_tet_contacts, s->tet_work); });
 		HIPCHECK(hipGetLastError());
 		return PBDX_OK;
 	};
@@ -1777,16 +1793,27 @@ int enqueue_tet_detection(pbdx_solver *s)
 	}
 	else
 	{
-		uint32_t max_nodes = 1;
-		for (const TetColliderView &v : s->tet_views) max_nodes = std::max(max_nodes, std::max(v.points.num_nodes, v.tet_bvh.num_nodes));
-		hipLaunchKernelGGL(tet_hull_wave_kernel, dim3((max_nodes + 3) / 4, 2 * nc), dim3(256), 0, s->stream, views, pos);
-		hipLaunchKernelGGL(tet_aabb_kernel, dim3(nc), dim3(256), 0, s->stream, views, pos, s->d_tet_aabb);
-		hipLaunchKernelGGL(tet_traverse_kernel, dim3(1), dim3(1024), 0, s->stream, views, nc, (const float *)s->d_tet_aabb, s->tet_work);
+		uint32_t max_nodes = 1, max_elems = 1;
+		for (const TetColliderView &v : s->tet_views)
+		{
+			max_nodes = std::max(max_nodes, std::max(v.points.num_nodes, v.tet_bvh.num_nodes));
+			max_elems = std::max(max_elems, std::max(v.num_vertices, 4u * v.num_tets));
+		}
+		s->tet_timed(0, [&] {
+			hipLaunchKernelGGL(tet_gather_kernel, dim3((max_elems + 255) / 256, 2 * nc), dim3(256), 0, s->stream, views, pos);
+			hipLaunchKernelGGL(tet_hull_kernel2, dim3(max_nodes, 2 * nc), dim3(256), 0, s->stream, views);
+		});
+		s->tet_timed(1, [&] { hipLaunchKernelGGL(tet_aabb_kernel, dim3(nc), dim3(256), 0, s->stream, views, pos, s->d_tet_aabb); });
+		s->tet_timed(2, [&] {
+			// one workgroup per CU, all resident at once (they meet at barriers); the launch's scratch words start at zero
+			(void)hipMemsetAsync(s->tet_work.trav, 0, kTrWords * sizeof(uint32_t), s->stream);
+			hipLaunchKernelGGL(tet_traverse_kernel, dim3((uint32_t)std::max(1, s->prop.multiProcessorCount)), dim3(256), 0, s->stream, views, nc, (const float *)s->d_tet_aabb, s->tet_work);
+		});
 		const uint32_t grid = (uint32_t)std::max(1, s->prop.multiProcessorCount) * 8u;
-		hipLaunchKernelGGL(tet_candidates_kernel<false>, dim3(grid), dim3(256), 0, s->stream, views, pos, rest, s->tet_work, s->d_tet_contacts);
-		hipLaunchKernelGGL(tet_chunk_scan_kernel, dim3(1), dim3(1024), 0, s->stream, s->tet_work);
-		hipLaunchKernelGGL(tet_candidates_kernel<true>, dim3(grid), dim3(256), 0, s->stream, views, pos, rest, s->tet_work, s->d_tet_contacts);
-		hipLaunchKernelGGL(tet_levels_kernel, dim3(1), dim3(1024), 0, s->stream, (const TetContact *)s->d_tet_contacts, s->tet_work);
+		s->tet_timed(3, [&] { hipLaunchKernelGGL(tet_candidates_kernel<false>, dim3(grid), dim3(256), 0, s->stream, views, pos, rest, s->tet_work, s->d_tet_contacts); });
+		s->tet_timed(4, [&] { hipLaunchKernelGGL(tet_chunk_scan_kernel, dim3(1), dim3(1024), 0, s->stream, s->tet_work); });
+		s->tet_timed(5, [&] { hipLaunchKernelGGL(tet_candidates_kernel<true>, dim3(grid), dim3(256), 0, s->stream, views, pos, rest, s->tet_work, s->d_tet_contacts); });
+		s->tet_timed(6, [&] { hipLaunchKernelGGL(tet_levels_kernel, dim3(1), dim3(1024), 0, s->stream, (const TetContact *)s->d_tet_contacts, s->tet_work); });
 	}
 	HIPCHECK(hipGetLastError());
 	return PBDX_OK;
@@ -1995,6 +2022,12 @@ void pbdx_solver_destroy(pbdx_solver *s)
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
 	s->drop_graph();
 	s->free_batches();
+	if (s->tet_profile && s->tet_launches[0])
+	{
+		static const char *names[8] = { "spheres", "boxes", "traverse", "candidates (ballot)", "chunk scan", "candidates (write)", "levels", "solve (per iteration)" };
+		for (int q = 0; q < 8; q++)
+			fprintf(stderr, "[pbdx tet profile] %-22s %8llu launches  %10.3f ms total  %8.4f ms each\n", names[q], (unsigned long long)s->tet_launches[q], s->tet_ms[q], s->tet_launches[q] ? s->tet_ms[q] / s->tet_launches[q] : 0.0);
+	}
 	s->free_particles();
 	s->free_tet_colliders();
 	if (s->d_tet_contacts) (void)hipFree(s->d_tet_contacts);
@@ -2411,7 +2444,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		{
 			(void)hipMemset(s->d_tet_counters, 0, kTcWords * sizeof(uint32_t));
 			set_error(c[kTcOverflow] ? "more than %u contacts between solids in one step (or more than 4096 dependent contacts at one particle)" :
-				"the traversal of the bounding-sphere hierarchies exceeded the engine's capacity (%u node pairs / 2^21 candidate chunks; serial form: stack of 128)", c[kTcOverflow] ? kMaxTetContacts : s->tet_work.front_cap);
+				"the traversal of the bounding-sphere hierarchies exceeded the engine's capacity (%u overlapping leaf pairs, 2^22 node pairs, 2^21 candidate chunks, 256 levels; serial form: stack of 128)", c[kTcOverflow] ? kMaxTetContacts : s->tet_work.front_cap);
 			return PBDX_ERR_UNSUPPORTED;
 		}
 	}
@@ -2608,7 +2641,18 @@ int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 			if (q == 2) HIPCHECK(hipMemcpy(dst[q]->hulls, src[q]->hulls, (size_t)src[q]->num_nodes * sizeof(P4), hipMemcpyHostToDevice));
 			else HIPCHECK(hipMemset(dst[q]->hulls, 0, (size_t)src[q]->num_nodes * sizeof(P4)));
 			dst[q]->num_nodes = src[q]->num_nodes;
-			*view[q] = BvhView{ dst[q]->lst, dst[q]->nodes, dst[q]->hulls, dst[q]->num_nodes };
+			*view[q] = BvhView{ dst[q]->lst, dst[q]->nodes, dst[q]->hulls, dst[q]->num_nodes, nullptr, nullptr, 0 };
+			if (q < 2)
+			{
+				// the entities' vertices in list order (static), and room for their positions (gathered every step)
+				const uint32_t per = q == 0 ? 1u : 4u;
+				std::vector<uint32_t> flat((size_t)per * src[q]->num_entities);
+				for (uint32_t e = 0; e < src[q]->num_entities; e++)
+					for (uint32_t k = 0; k < per; k++) flat[(size_t)per * e + k] = q == 0 ? src[q]->entities[e] : c.tets[4 * src[q]->entities[e] + k];
+				HIPCHECK(up(&dst[q]->flat, flat.data(), flat.size()));
+				HIPCHECK(hipMalloc(&dst[q]->gathered, flat.size() * sizeof(P4)));
+				view[q]->flat = dst[q]->flat; view[q]->gathered = dst[q]->gathered; view[q]->per_entity = per;
+			}
 		}
 	}
 	HIPCHECK(hipMalloc(&s->d_tet_views, (size_t)n * sizeof(TetColliderView)));
@@ -2622,15 +2666,31 @@ int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 		TetWork &w = s->tet_work;
 		w.front_cap = std::max<uint32_t>(1u << 20, n * n);
 		w.chunk_cap = 1u << 21;
-		const size_t bytes[12] = { (size_t)3 * w.front_cap * 4, (size_t)3 * w.front_cap * 4, (size_t)2 * n * n * 4, ((size_t)w.front_cap + 1) * 4, (size_t)w.chunk_cap * 4,
-			(size_t)w.chunk_cap * 8, (size_t)w.chunk_cap * 4, (size_t)kMaxTetContacts * 4, ((size_t)kMaxTetLevels + 1) * 4, (size_t)kMaxTetContacts * 4, (size_t)s->n * 4, 0 };
-		for (int q = 0; q < 11; q++) HIPCHECK(hipMalloc(&s->tet_work_alloc[q], bytes[q]));
-		w.front[0] = (uint32_t *)s->tet_work_alloc[0]; w.front[1] = (uint32_t *)s->tet_work_alloc[1]; w.pair_ik = (uint32_t *)s->tet_work_alloc[2];
+		w.node_cap = 1u << 22;
+		HIPCHECK(hipMalloc(&s->tet_work_alloc[15], kTrWords * sizeof(uint32_t)));
+		w.trav = (uint32_t *)s->tet_work_alloc[15];
+		const size_t bytes[15] = { (size_t)3 * w.front_cap * 4, 0, (size_t)2 * n * n * 4, ((size_t)w.front_cap + 1) * 4, (size_t)w.chunk_cap * 4,
+			(size_t)w.chunk_cap * 8, (size_t)w.chunk_cap * 4, (size_t)kMaxTetContacts * 4, ((size_t)kMaxTetLevels + 1) * 4, (size_t)kMaxTetContacts * 4, (size_t)s->n * 4,
+			(size_t)w.node_cap * 16, (size_t)w.node_cap * 8, (size_t)w.node_cap * 4, (size_t)w.node_cap * 8 };
+		for (int q = 0; q < 15; q++) if (bytes[q]) HIPCHECK(hipMalloc(&s->tet_work_alloc[q], bytes[q]));
+		w.front[0] = (uint32_t *)s->tet_work_alloc[0]; w.front[1] = nullptr; w.pair_ik = (uint32_t *)s->tet_work_alloc[2];
 		w.chunk_off = (uint32_t *)s->tet_work_alloc[3]; w.chunk_pair = (uint32_t *)s->tet_work_alloc[4]; w.chunk_mask = (unsigned long long *)s->tet_work_alloc[5];
 		w.chunk_base = (uint32_t *)s->tet_work_alloc[6]; w.order = (uint32_t *)s->tet_work_alloc[7]; w.level_start = (uint32_t *)s->tet_work_alloc[8];
 		w.level_of = (uint32_t *)s->tet_work_alloc[9]; w.owner = (uint32_t *)s->tet_work_alloc[10];
+		w.node_rec = (unsigned long long *)s->tet_work_alloc[11]; w.node_cnt = (unsigned long long *)s->tet_work_alloc[12]; w.node_child = (uint32_t *)s->tet_work_alloc[13]; w.node_off = (unsigned long long *)s->tet_work_alloc[14];
 		w.counters = s->d_tet_counters;
 	}
+	return PBDX_OK;
+}
+
+int pbdx_debug_tet_counters(pbdx_solver *s, uint32_t out[8])
+{
+	if (!s || !out) return PBDX_ERR_INVALID;
+	memset(out, 0, 8 * sizeof(uint32_t));
+	if (!s->d_tet_counters) return PBDX_OK;
+	HIPCHECK(hipSetDevice(s->device));
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	HIPCHECK(hipMemcpy(out, s->d_tet_counters, kTcWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
 	return PBDX_OK;
 }
 

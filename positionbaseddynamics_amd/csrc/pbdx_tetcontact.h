@@ -35,6 +35,11 @@ struct BvhView
 	const int32_t *nodes;         // 4 per node: child0, child1 (-1 = none), begin, n
 	P4 *hulls;                    // per node: centre, radius
 	uint32_t num_nodes;
+	// device form only (pbdx_tetcontact_dev.h): the entities' vertices in list order -- 1 per point, 4 per tet -- as model-local particle
+	// indices (static) and as positions (gathered every step), so that a node's sums run over a contiguous range
+	const uint32_t *flat;
+	P4 *gathered;
+	uint32_t per_entity;
 };
 
 struct TetColliderView

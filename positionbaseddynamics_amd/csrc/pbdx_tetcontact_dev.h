@@ -6,21 +6,25 @@
 //   * that list is solved one contact after the other inside every iteration of the next step (Gauss-Seidel): the order is part of
 //     the result.
 // Neither needs one thread:
-//   detection  The recursion tree of BVHTest::traverse is expanded breadth-wise, every generation as an ORDERED list in which a node
-//              pair is replaced in place by its (up to) two children, children[0] first -- an order-preserving expansion of a tree
-//              leaves its leaves in depth-first order, which is the reference's visiting order.  A generation is one pass of a
-//              workgroup-wide exclusive scan (tet_traverse_kernel).  The candidates of a leaf pair (points x tets, row-major as the
-//              reference's two loops) are then evaluated by the whole GPU, 64 candidates per wavefront; a ballot per wavefront, a scan
-//              over the ballots' populations and a second evaluation of the (few) hits put the contacts where the reference's
-//              push_back would have (tet_candidates_kernel<false>, tet_chunk_scan_kernel, tet_candidates_kernel<true>).
+//   detection  The recursion tree of BVHTest::traverse is built generation by generation (tet_traverse_kernel): every node pair of a
+//              generation is tested in parallel and appends its two children (children[0] first) to the next generation.  The order
+//              in which the reference's depth-first recursion reaches the overlapping leaf pairs is the left-to-right order of the
+//              leaves of that tree: a bottom-up pass counts the leaf pairs below every node, a top-down pass turns the counts into
+//              every leaf pair's position (children[0]'s subtree before children[1]'s) -- no thread ever walks the tree in order.
+//              The candidates of a leaf pair (points x tets, row-major as the reference's two loops) are then evaluated by the whole
+//              GPU, 64 candidates per wavefront; a ballot per wavefront, a scan over the ballots' populations and a second
+//              evaluation of the (few) hits put the contacts where the reference's push_back would have
+//              (tet_candidates_kernel<false>, tet_chunk_scan_kernel, tet_candidates_kernel<true>).
 //   solve      Two contacts commute bit for bit unless they share a particle (the solve writes the contact's particle and the four
 //              vertices of its tet, and reads nothing else that changes).  The list is levelled once per detection: a contact's
 //              level is one more than the highest level among EARLIER contacts it shares a particle with (tet_levels_kernel: rounds
 //              of "who is the first unscheduled contact at each particle").  Every level is a set of contacts on disjoint particles;
 //              the levels run in order, each in parallel (tet_contact_solve_levels_kernel).
-//   spheres    KDTree::update recomputes every node's sphere from ITS OWN entity range: the centre is a float sum in list order (a
-//              dependent chain; one wavefront per node fetches 64 entities at a time, the chain reads them from registers), the
-//              radius a maximum (order-free, lane-parallel).
+//   spheres    KDTree::update recomputes every node's sphere from ITS OWN entity range: the centre is a float sum in list order -- a
+//              dependent chain of n additions per component, 327680 for the root of an 81920-tet hierarchy, and the critical path
+//              of the whole detection.  The vertices are gathered into list order first (tet_gather_kernel), so a node reads a
+//              contiguous range; a workgroup per node, one wavefront per component's chain (tet_hull_kernel2).  The radius is a
+//              maximum (order-free, parallel).
 #ifndef PBDX_TETCONTACT_DEV_H
 #define PBDX_TETCONTACT_DEV_H
 
@@ -32,12 +36,21 @@ namespace pbdx {
 constexpr uint32_t kMaxTetContacts = 1u << 16;
 constexpr uint32_t kMaxTetLevels = 4096;
 constexpr uint32_t kTcFinal = 0x80000000u;
-enum { kTcCount = 0, kTcOverflow = 1, kTcStack = 2, kTcLeafPairs = 3, kTcChunks = 4, kTcLevels = 5, kTcGenerations = 6, kTcWords = 8 };
+enum { kTcCount = 0, kTcOverflow = 1, kTcStack = 2, kTcLeafPairs = 3, kTcChunks = 4, kTcLevels = 5, kTcGenerations = 6, kTcTreeNodes = 7, kTcWords = 8 };
 
 struct TetWork                    // device scratch of the detection; *_cap are capacities in elements
 {
-	uint32_t *front[2];           // 3 words per node pair: collider pair | kTcFinal, node of the point hierarchy, node of the tet hierarchy
+	uint32_t *front[2];           // [0]: the overlapping leaf pairs in the reference's visiting order, 3 words each: collider pair | kTcFinal, node
+	                              // of the point hierarchy, node of the tet hierarchy ([1] unused)
 	uint32_t front_cap;
+	// recursion tree of the traversal, generation after generation.  Written and read by different workgroups (= CUs, XCDs) of ONE launch:
+	// every access is a relaxed agent-scope atomic (an sc1 load / store: served past the CU's L1, written through), 8 bytes at most
+	unsigned long long *node_rec; // 2 per node: collider pair | node of the point hierarchy << 32, node of the tet hierarchy
+	unsigned long long *node_cnt; // overlapping leaf pairs | candidate chunks << 32 in the node's subtree
+	uint32_t *node_child;         // index of children[0]'s node (children[1]'s follows), 0xffffffff: none
+	unsigned long long *node_off; // position of the subtree's first leaf pair | first chunk << 32
+	uint32_t node_cap;
+	uint32_t *trav;               // kTrWords words of the traversal launch: barrier, flags, size of every generation (zeroed before the launch)
 	uint32_t *pair_ik;            // 2 words per ordered collider pair (i, k) whose boxes intersect
 	uint32_t *chunk_off;          // per leaf pair: its first 64-candidate chunk (front_cap + 1 entries)
 	uint32_t *chunk_pair;         // per chunk: its leaf pair
@@ -89,190 +102,349 @@ __device__ __forceinline__ float wave_max(float v)
 	for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(v, d); v = (v < o) ? o : v; }
 	return v;
 }
-// PointCloudBSH::compute_hull_approx (hull_points of pbdx_tetcontact.h, same operations in the same order)
-__device__ inline void hull_points_wave(const BvhView &b, uint32_t node, const P4 *pos)
+// grid: (ceil(max elements / 256), 2 * colliders)
+__global__ __launch_bounds__(256) void tet_gather_kernel(const TetColliderView *views, const P4 *pos)
 {
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t beg = (uint32_t)b.nodes[4 * node + 2], n = (uint32_t)b.nodes[4 * node + 3];
-	V3 x = mk(0.0f, 0.0f, 0.0f);
-	for (uint32_t c0 = 0; c0 < n; c0 += 64)
+	const TetColliderView &v = views[blockIdx.y >> 1];
+	const BvhView &b = (blockIdx.y & 1u) ? v.tet_bvh : v.points;
+	const uint32_t total = (blockIdx.y & 1u) ? 4u * v.num_tets : v.num_vertices;
+	const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+	if (e < total) b.gathered[e] = pos[v.first + b.flat[e]];
+}
+// PointCloudBSH / TetMeshBSH::compute_hull_approx (hull_points / hull_tets of pbdx_tetcontact.h: same operations in the same order).
+// The running sum is three dependent chains (x, y, z) of n additions each; nothing but the latency of a dependent v_add_f32 can bound a
+// chain, so each chain gets a wavefront (= a SIMD) of its own and nothing else to issue: a workgroup of four wavefronts per node stages
+// 256 vertices at a time in LDS as three component arrays (coalesced load, prefetched one stage ahead, double-buffered: one barrier per
+// stage), wavefront c < 3 then runs component c's chain over the stage, four values per (broadcast) LDS read, the reads of the next 32
+// values issued before the additions of the current 32.  Padding a stage with +0 is exact: a running sum that starts at +0 is never -0.
+// (Measured on the 81920-tet root, 327680 vertices per component: one wavefront for all three chains, operands by v_readlane 7.7 ms,
+// by v_add_f32_dpp wave_shr:1 3.2 ms, by LDS broadcast 5.3 ms; this form: see DESIGN.md.)
+__device__ __forceinline__ void chain_32(float &acc, const float4 (&v)[8])
+{
+#pragma unroll
+	for (int q = 0; q < 8; q++) { acc += v[q].x; acc += v[q].y; acc += v[q].z; acc += v[q].w; }
+}
+// grid: (max over colliders of nodes, 2 * colliders)
+__global__ __launch_bounds__(256) void tet_hull_kernel2(const TetColliderView *views)
+{
+	__shared__ __attribute__((aligned(16))) float comp[2][3][256];
+	__shared__ float s_sum[3];
+	__shared__ float s_max[4];
+	const TetColliderView &v = views[blockIdx.y >> 1];
+	const bool tets = (blockIdx.y & 1u) != 0;
+	const BvhView &b = tets ? v.tet_bvh : v.points;
+	const uint32_t node = blockIdx.x;
+	if (node >= b.num_nodes) return;
+	const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+	const uint32_t n = (uint32_t)b.nodes[4 * node + 3];
+	const uint32_t m = n * b.per_entity;
+	const float4 *g = reinterpret_cast<const float4 *>(b.gathered) + (size_t)(uint32_t)b.nodes[4 * node + 2] * b.per_entity;
+	const uint32_t stages = (m + 255u) / 256u;
+	auto fetch = [&](uint32_t st) { float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f); const uint32_t e = st * 256u + tid; if (e < m) p = g[e]; return p; };
+	float4 cur = fetch(0);
+	float acc = 0.0f;
+	for (uint32_t st = 0; st < stages; st++)
 	{
-		P4 p; p.x = p.y = p.z = p.w = 0.0f;
-		if (c0 + lane < n) p = pos[b.lst[beg + c0 + lane]];
-		const uint32_t m = (n - c0 < 64u) ? n - c0 : 64u;
-		for (uint32_t j = 0; j < m; j++) x = x + mk(lane_value(p.x, j), lane_value(p.y, j), lane_value(p.z, j));
+		const uint32_t buf = st & 1u;
+		comp[buf][0][tid] = cur.x; comp[buf][1][tid] = cur.y; comp[buf][2][tid] = cur.z;
+		cur = fetch(st + 1u);
+		__syncthreads();
+		if (wave < 3u)
+		{
+			const uint32_t left = m - st * 256u;
+			const uint32_t batches = left >= 256u ? 8u : (left + 31u) / 32u;          // of 32 values
+			const float4 *src = reinterpret_cast<const float4 *>(comp[buf][wave]);
+			float4 va[8], vb[8];
+#pragma unroll
+			for (int q = 0; q < 8; q++) va[q] = src[q];
+			for (uint32_t k = 0; k < batches; k += 2)
+			{
+				if (k + 1u < batches)
+				{
+#pragma unroll
+					for (int q = 0; q < 8; q++) vb[q] = src[8 * (k + 1u) + q];
+				}
+				chain_32(acc, va);
+				if (k + 1u < batches)
+				{
+					if (k + 2u < batches)
+					{
+#pragma unroll
+						for (int q = 0; q < 8; q++) va[q] = src[8 * (k + 2u) + q];
+					}
+					chain_32(acc, vb);
+				}
+			}
+		}
 	}
-	x = x / (float)n;
+	if (wave < 3u && lane == 0) s_sum[wave] = acc;
+	__syncthreads();
+	V3 x = mk(s_sum[0], s_sum[1], s_sum[2]);
+	x = tets ? x / (4.0f * (float)n) : x / (float)n;
 	float radius2 = 0.0f;
-	for (uint32_t i = lane; i < n; i += 64)
+	for (uint32_t e = tid; e < m; e += 256)
 	{
-		const float d = sqn(x - p3(pos[b.lst[beg + i]]));
+		const float4 q = g[e];
+		const float d = sqn(x - mk(q.x, q.y, q.z));
 		radius2 = (radius2 < d) ? d : radius2;
 	}
 	radius2 = wave_max(radius2);
-	if (lane == 0) { P4 h; h.x = x.x; h.y = x.y; h.z = x.z; h.w = sqrtf(radius2); b.hulls[node] = h; }
-}
-// TetMeshBSH::compute_hull_approx (hull_tets)
-__device__ inline void hull_tets_wave(const BvhView &b, uint32_t node, const P4 *pos, const uint32_t *tets, float tolerance)
-{
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t beg = (uint32_t)b.nodes[4 * node + 2], n = (uint32_t)b.nodes[4 * node + 3];
-	V3 x = mk(0.0f, 0.0f, 0.0f);
-	for (uint32_t c0 = 0; c0 < n; c0 += 64)
-	{
-		P4 q[4];
-		for (int k = 0; k < 4; k++) q[k].x = q[k].y = q[k].z = q[k].w = 0.0f;
-		if (c0 + lane < n)
-		{
-			const uint32_t t = b.lst[beg + c0 + lane];
-			for (int k = 0; k < 4; k++) q[k] = pos[tets[4 * t + k]];
-		}
-		const uint32_t m = (n - c0 < 64u) ? n - c0 : 64u;
-		for (uint32_t j = 0; j < m; j++)
-			for (int k = 0; k < 4; k++) x = x + mk(lane_value(q[k].x, j), lane_value(q[k].y, j), lane_value(q[k].z, j));
-	}
-	x = x / (4.0f * (float)n);
-	float radius2 = 0.0f;
-	for (uint32_t i = lane; i < n; i += 64)
-	{
-		const uint32_t t = b.lst[beg + i];
-		for (int k = 0; k < 4; k++)
-		{
-			const float d = sqn(x - p3(pos[tets[4 * t + k]]));
-			radius2 = (radius2 < d) ? d : radius2;
-		}
-	}
-	radius2 = wave_max(radius2);
-	if (lane == 0) { P4 h; h.x = x.x; h.y = x.y; h.z = x.z; h.w = (float)(sqrt((double)radius2) + (double)tolerance); b.hulls[node] = h; }
-}
-// grid: (max over colliders of ceil(nodes / 4), 2 * colliders); 4 wavefronts per workgroup
-__global__ __launch_bounds__(256) void tet_hull_wave_kernel(const TetColliderView *views, const P4 *pos)
-{
-	const TetColliderView &v = views[blockIdx.y >> 1];
-	const uint32_t node = blockIdx.x * 4u + (threadIdx.x >> 6);
-	if (blockIdx.y & 1u) { if (node < v.tet_bvh.num_nodes) hull_tets_wave(v.tet_bvh, node, pos + v.first, v.tets, v.tolerance); }
-	else if (node < v.points.num_nodes) hull_points_wave(v.points, node, pos + v.first);
-}
-
-// ---- traversal: ordered breadth-wise expansion of BVHTest::traverse's recursion tree ------------------------------------------------
-__global__ __launch_bounds__(1024) void tet_traverse_kernel(const TetColliderView *views, uint32_t n, const float *aabb, TetWork w)
-{
-	__shared__ uint32_t lds[65];
-	const uint32_t tid = threadIdx.x;
-	if (tid == 0) { w.counters[kTcCount] = 0; w.counters[kTcLeafPairs] = 0; w.counters[kTcChunks] = 0; w.counters[kTcLevels] = 0; }
-	// generation 0: the ordered collider pairs (i, k), i outer (DistanceFieldCollisionDetection.cpp:33-46), at the roots
-	uint32_t count = 0;
-	for (uint32_t c0 = 0; c0 < n * n; c0 += 1024)
-	{
-		const uint32_t e = c0 + tid;
-		uint32_t ok = 0, i = 0, k = 0;
-		if (e < n * n)
-		{
-			i = e / n; k = e % n;
-			ok = (i != k && views[i].test_mesh && views[i].points.num_nodes && views[k].tet_bvh.num_nodes && aabb_intersect(aabb + 6 * i, aabb + 6 * k)) ? 1u : 0u;
-		}
-		uint32_t total;
-		const uint32_t at = count + block_exclusive_scan(ok, lds, total);
-		if (ok && at < w.front_cap)
-		{
-			w.pair_ik[2 * at] = i; w.pair_ik[2 * at + 1] = k;
-			w.front[0][3 * at] = at; w.front[0][3 * at + 1] = 0; w.front[0][3 * at + 2] = 0;
-		}
-		count += total;
-	}
-	bool overflow = count > w.front_cap;
-	uint32_t cur = 0, generation = 0;
-	int any = overflow ? 0 : (count != 0);
-	while (any && !overflow)
-	{
-		__syncthreads();
-		const uint32_t *src = w.front[cur];
-		uint32_t *dst = w.front[cur ^ 1u];
-		uint32_t next = 0;
-		int pending = 0;
-		for (uint32_t c0 = 0; c0 < count; c0 += 1024)
-		{
-			const uint32_t e = c0 + tid;
-			uint32_t k = 0, o[6];
-			if (e < count)
-			{
-				const uint32_t p = src[3 * e], a = src[3 * e + 1], b = src[3 * e + 2];
-				if (p & kTcFinal) { k = 1; o[0] = p; o[1] = a; o[2] = b; }
-				else
-				{
-					const BvhView &b1 = views[w.pair_ik[2 * p]].points, &b2 = views[w.pair_ik[2 * p + 1]].tet_bvh;
-					const P4 bs1 = b1.hulls[a], bs2 = b2.hulls[b];
-					if (spheres_overlap(bs1, bs2))
-					{
-						const int32_t a0 = b1.nodes[4 * a], a1 = b1.nodes[4 * a + 1], d0 = b2.nodes[4 * b], d1 = b2.nodes[4 * b + 1];
-						const bool leaf1 = a0 < 0 && a1 < 0, leaf2 = d0 < 0 && d1 < 0;
-						if (leaf1 && leaf2) { k = 1; o[0] = p | kTcFinal; o[1] = a; o[2] = b; }
-						else
-						{
-							// descend the smaller sphere's hierarchy first unless it is at a leaf; children[0] before children[1]
-							const bool descend1 = (bs1.w < bs2.w) ? !leaf1 : leaf2;
-							k = 2; pending = 1;
-							o[0] = p; o[3] = p;
-							if (descend1) { o[1] = (uint32_t)a0; o[2] = b; o[4] = (uint32_t)a1; o[5] = b; }
-							else { o[1] = a; o[2] = (uint32_t)d0; o[4] = a; o[5] = (uint32_t)d1; }
-						}
-					}
-				}
-			}
-			uint32_t total;
-			const uint32_t at = next + block_exclusive_scan(k, lds, total);
-			if (k >= 1 && at < w.front_cap) { dst[3 * at] = o[0]; dst[3 * at + 1] = o[1]; dst[3 * at + 2] = o[2]; }
-			if (k == 2 && at + 1 < w.front_cap) { dst[3 * at + 3] = o[3]; dst[3 * at + 4] = o[4]; dst[3 * at + 5] = o[5]; }
-			next += total;
-		}
-		any = __syncthreads_or(pending);
-		count = next; cur ^= 1u;
-		overflow = count > w.front_cap;
-		if (++generation >= 512u) { overflow = overflow || any; break; }
-	}
+	if (lane == 0) s_max[wave] = radius2;
 	__syncthreads();
-	if (overflow)
-	{
-		if (tid == 0) w.counters[kTcStack] = 1u;
-		return;
-	}
-	// the generation that is left holds the overlapping leaf pairs in the reference's visiting order; if it ended up in front[1], copy
-	// it over so that the following kernels read front[0]
-	if (cur == 1u)
-	{
-		for (uint32_t e = tid; e < 3 * count; e += 1024) w.front[0][e] = w.front[1][e];
-		__syncthreads();
-	}
-	// 64-candidate chunks per leaf pair
-	uint32_t chunks = 0;
-	bool chunk_overflow = false;
-	for (uint32_t c0 = 0; c0 < count; c0 += 1024)
-	{
-		const uint32_t e = c0 + tid;
-		uint32_t q = 0;
-		if (e < count)
-		{
-			const uint32_t p = w.front[0][3 * e] & ~kTcFinal;
-			const BvhView &b1 = views[w.pair_ik[2 * p]].points, &b2 = views[w.pair_ik[2 * p + 1]].tet_bvh;
-			const uint32_t n1 = (uint32_t)b1.nodes[4 * w.front[0][3 * e + 1] + 3], n2 = (uint32_t)b2.nodes[4 * w.front[0][3 * e + 2] + 3];
-			q = (n1 * n2 + 63u) / 64u;
-		}
-		uint32_t total;
-		const uint32_t at = chunks + block_exclusive_scan(q, lds, total);
-		if (e < count)
-		{
-			w.chunk_off[e] = at;
-			for (uint32_t j = 0; j < q; j++) if (at + j < w.chunk_cap) w.chunk_pair[at + j] = e;
-		}
-		chunks += total;
-		if (chunks > w.chunk_cap) chunk_overflow = true;
-	}
 	if (tid == 0)
 	{
-		w.chunk_off[count] = chunks;
-		w.counters[kTcGenerations] = generation;
-		if (chunk_overflow) w.counters[kTcStack] = 1u;
-		else { w.counters[kTcLeafPairs] = count; w.counters[kTcChunks] = chunks; }
+		for (int q = 1; q < 4; q++) radius2 = (radius2 < s_max[q]) ? s_max[q] : radius2;
+		P4 h; h.x = x.x; h.y = x.y; h.z = x.z;
+		h.w = tets ? (float)(sqrt((double)radius2) + (double)v.tolerance) : sqrtf(radius2);
+		b.hulls[node] = h;
+	}
+}
+
+// ---- traversal: BVHTest::traverse's recursion tree, generation by generation ----------------------------------------------------------
+// One launch of `gridDim.x` co-resident workgroups (at most one per CU is asked for; the launch is alone on its stream) that meet at a
+// barrier between generations.  trav: zeroed before the launch.
+constexpr uint32_t kTcMaxGenerations = 256;
+constexpr uint32_t kTcNone = 0xffffffffu;
+enum { kTrArrive = 0, kTrBad = 1, kTrLeaves = 2, kTrChunks = 3, kTrCount = 4, kTrWords = kTrCount + kTcMaxGenerations + 2 };
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long pack2(uint32_t lo, uint32_t hi) { return (unsigned long long)lo | ((unsigned long long)hi << 32); }
+// all workgroups of the launch: every thread's (written-through) stores have completed, then one arrival per workgroup; returns false if
+// the wait was abandoned (a workgroup never arrived within ~50 ms)
+__device__ inline bool grid_barrier(uint32_t *trav, uint32_t &target)
+{
+	__shared__ uint32_t s_ok;
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+	__syncthreads();
+	target += gridDim.x;
+	if (threadIdx.x == 0)
+	{
+		uint32_t ok = 1u;
+		__hip_atomic_fetch_add(&trav[kTrArrive], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint64_t t0 = wall_clock64();
+		while (ld_agent(&trav[kTrArrive]) < target)
+		{
+			__builtin_amdgcn_s_sleep(1);
+			if (wall_clock64() - t0 > 5000000ull) { ok = 0u; st_agent(&trav[kTrBad], 2u); break; }
+		}
+		s_ok = ok;
+	}
+	__syncthreads();
+	return s_ok != 0u;
+}
+
+__global__ __launch_bounds__(256) void tet_traverse_kernel(const TetColliderView *views, uint32_t n, const float *aabb, TetWork w)
+{
+	__shared__ uint32_t lds[65];
+	__shared__ uint32_t gstart[kTcMaxGenerations + 2];
+	struct PairPtr { const P4 *h1, *h2; const int32_t *n1, *n2; };
+	constexpr uint32_t kCached = 64;
+	__shared__ PairPtr s_pair[kCached];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t gtid = blockIdx.x * 256u + tid, gthreads = gridDim.x * 256u;
+	uint32_t *trav = w.trav;
+	uint32_t target = 0;
+	if (blockIdx.x == 0)
+	{
+		if (tid == 0) { w.counters[kTcCount] = 0; w.counters[kTcLeafPairs] = 0; w.counters[kTcChunks] = 0; w.counters[kTcLevels] = 0; }
+		// generation 0: the ordered collider pairs (i, k), i outer (DistanceFieldCollisionDetection.cpp:33-46), at the roots
+		uint32_t roots = 0;
+		for (uint32_t c0 = 0; c0 < n * n; c0 += 256)
+		{
+			const uint32_t e = c0 + tid;
+			uint32_t ok = 0, i = 0, k = 0;
+			if (e < n * n)
+			{
+				i = e / n; k = e % n;
+				ok = (i != k && views[i].test_mesh && views[i].points.num_nodes && views[k].tet_bvh.num_nodes && aabb_intersect(aabb + 6 * i, aabb + 6 * k)) ? 1u : 0u;
+			}
+			uint32_t total;
+			const uint32_t at = roots + block_exclusive_scan(ok, lds, total);
+			if (ok && at < w.node_cap)
+			{
+				st_agent(&w.pair_ik[2 * at], i); st_agent(&w.pair_ik[2 * at + 1], k);
+				st_agent(&w.node_rec[2 * at], pack2(at, 0u)); st_agent(&w.node_rec[2 * at + 1], 0ull);
+			}
+			roots += total;
+		}
+		if (tid == 0)
+		{
+			if (roots > w.node_cap) { st_agent(&trav[kTrBad], 1u); roots = 0; }
+			st_agent(&trav[kTrCount], roots);
+		}
+	}
+	if (!grid_barrier(trav, target)) return;
+	const uint32_t roots = ld_agent(&trav[kTrCount]);
+	if (tid < kCached && tid < roots)
+	{
+		const BvhView &b1 = views[ld_agent(&w.pair_ik[2 * tid])].points, &b2 = views[ld_agent(&w.pair_ik[2 * tid + 1])].tet_bvh;
+		s_pair[tid] = PairPtr{ b1.hulls, b2.hulls, b1.nodes, b2.nodes };
+	}
+	if (tid == 0) gstart[0] = 0;
+	__syncthreads();
+	// expansion
+	uint32_t generations = 0, base = 0;
+	while (true)
+	{
+		const uint32_t cnt_g = ld_agent(&trav[kTrCount + generations]);
+		if (tid == 0) gstart[generations + 1] = base + cnt_g;
+		if (cnt_g == 0 || ld_agent(&trav[kTrBad]) || generations >= kTcMaxGenerations) break;
+		const uint32_t ge = base + cnt_g;
+		constexpr int kUnroll = 2;
+		for (uint32_t i0 = base + gtid; i0 - lane < ge; i0 += gthreads * kUnroll)      // wave-uniform trip count
+		{
+			uint32_t rp[kUnroll], ra[kUnroll], rb[kUnroll]; P4 bs1[kUnroll], bs2[kUnroll]; int4 nd1[kUnroll], nd2[kUnroll]; bool live[kUnroll];
+#pragma unroll
+			for (int u = 0; u < kUnroll; u++)
+			{
+				const uint32_t idx = i0 + (uint32_t)u * gthreads;
+				live[u] = idx < ge;
+				if (live[u])
+				{
+					const unsigned long long r0 = ld_agent(&w.node_rec[2 * idx]), r1 = ld_agent(&w.node_rec[2 * idx + 1]);
+					rp[u] = (uint32_t)r0; ra[u] = (uint32_t)(r0 >> 32); rb[u] = (uint32_t)r1;
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < kUnroll; u++)
+			{
+				if (!live[u]) continue;
+				PairPtr pp;
+				if (rp[u] < kCached) pp = s_pair[rp[u]];
+				else
+				{
+					const BvhView &b1 = views[ld_agent(&w.pair_ik[2 * rp[u]])].points, &b2 = views[ld_agent(&w.pair_ik[2 * rp[u] + 1])].tet_bvh;
+					pp = PairPtr{ b1.hulls, b2.hulls, b1.nodes, b2.nodes };
+				}
+				bs1[u] = pp.h1[ra[u]]; bs2[u] = pp.h2[rb[u]];
+				nd1[u] = *reinterpret_cast<const int4 *>(pp.n1 + 4 * ra[u]); nd2[u] = *reinterpret_cast<const int4 *>(pp.n2 + 4 * rb[u]);
+			}
+#pragma unroll
+			for (int u = 0; u < kUnroll; u++)
+			{
+				const uint32_t idx = i0 + (uint32_t)u * gthreads;
+				unsigned long long cnt = 0ull;
+				bool expand = false, leaf1 = false, leaf2 = false;
+				if (live[u] && spheres_overlap(bs1[u], bs2[u]))
+				{
+					leaf1 = nd1[u].x < 0 && nd1[u].y < 0; leaf2 = nd2[u].x < 0 && nd2[u].y < 0;
+					if (leaf1 && leaf2) cnt = pack2(1u, ((uint32_t)nd1[u].w * (uint32_t)nd2[u].w + 63u) / 64u);
+					else expand = true;
+				}
+				// two slots of the next generation per expanding node pair: one atomic per wavefront
+				const unsigned long long m = __ballot(expand);
+				uint32_t child = kTcNone;
+				if (m)
+				{
+					const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+					uint32_t first = 0;
+					if (lane == leader) first = __hip_atomic_fetch_add(&trav[kTrCount + generations + 1], 2u * (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					first = __shfl(first, (int)leader);
+					if (expand)
+					{
+						const uint32_t c = ge + first + 2u * (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+						if (c + 1u < w.node_cap)
+						{
+							// descend the smaller sphere's hierarchy first unless it is at a leaf; children[0] before children[1]
+							const bool descend1 = (bs1[u].w < bs2[u].w) ? !leaf1 : leaf2;
+							child = c;
+							if (descend1)
+							{
+								st_agent(&w.node_rec[2 * c], pack2(rp[u], (uint32_t)nd1[u].x)); st_agent(&w.node_rec[2 * c + 1], (unsigned long long)rb[u]);
+								st_agent(&w.node_rec[2 * c + 2], pack2(rp[u], (uint32_t)nd1[u].y)); st_agent(&w.node_rec[2 * c + 3], (unsigned long long)rb[u]);
+							}
+							else
+							{
+								st_agent(&w.node_rec[2 * c], pack2(rp[u], ra[u])); st_agent(&w.node_rec[2 * c + 1], (unsigned long long)(uint32_t)nd2[u].x);
+								st_agent(&w.node_rec[2 * c + 2], pack2(rp[u], ra[u])); st_agent(&w.node_rec[2 * c + 3], (unsigned long long)(uint32_t)nd2[u].y);
+							}
+						}
+						else st_agent(&trav[kTrBad], 1u);
+					}
+				}
+				if (live[u]) { st_agent(&w.node_cnt[idx], cnt); st_agent(&w.node_child[idx], child); }
+			}
+		}
+		if (!grid_barrier(trav, target)) return;
+		base = ge;
+		generations++;
+	}
+	__syncthreads();
+	const uint32_t bad = ld_agent(&trav[kTrBad]);
+	if (bad || (generations >= kTcMaxGenerations && gstart[generations + 1] != gstart[generations]))
+	{
+		if (gtid == 0) w.counters[kTcStack] = 1u;
+		return;
+	}
+	// bottom-up: leaf pairs and candidate chunks below every node (the two halves never carry into each other: both are bounded by capacities)
+	for (uint32_t g = generations; g-- > 0;)
+	{
+		for (uint32_t idx = gstart[g] + gtid; idx < gstart[g + 1]; idx += gthreads)
+		{
+			const uint32_t child = ld_agent(&w.node_child[idx]);
+			if (child != kTcNone) st_agent(&w.node_cnt[idx], ld_agent(&w.node_cnt[child]) + ld_agent(&w.node_cnt[child + 1]));
+		}
+		if (!grid_barrier(trav, target)) return;
+	}
+	// top-down: where every subtree's leaf pairs / chunks start
+	if (blockIdx.x == 0)
+	{
+		uint32_t leaves = 0, chunks = 0;
+		for (uint32_t c0 = 0; c0 < roots; c0 += 256)
+		{
+			const uint32_t r = c0 + tid;
+			const unsigned long long cnt = r < roots ? ld_agent(&w.node_cnt[r]) : 0ull;
+			uint32_t t0, t1;
+			const uint32_t o0 = leaves + block_exclusive_scan((uint32_t)cnt, lds, t0);
+			const uint32_t o1 = chunks + block_exclusive_scan((uint32_t)(cnt >> 32), lds, t1);
+			if (r < roots) st_agent(&w.node_off[r], pack2(o0, o1));
+			leaves += t0; chunks += t1;
+		}
+		if (tid == 0) { st_agent(&trav[kTrLeaves], leaves); st_agent(&trav[kTrChunks], chunks); }
+	}
+	if (!grid_barrier(trav, target)) return;
+	const uint32_t leaves = ld_agent(&trav[kTrLeaves]), chunks = ld_agent(&trav[kTrChunks]);
+	if (leaves > w.front_cap || chunks > w.chunk_cap)
+	{
+		if (gtid == 0) w.counters[kTcStack] = 1u;
+		return;
+	}
+	for (uint32_t g = 0; g < generations; g++)
+	{
+		for (uint32_t idx = gstart[g] + gtid; idx < gstart[g + 1]; idx += gthreads)
+		{
+			const uint32_t child = ld_agent(&w.node_child[idx]);
+			const unsigned long long off = ld_agent(&w.node_off[idx]);
+			if (child != kTcNone)
+			{
+				st_agent(&w.node_off[child], off);
+				st_agent(&w.node_off[child + 1], off + ld_agent(&w.node_cnt[child]));
+			}
+			else
+			{
+				const unsigned long long cnt = ld_agent(&w.node_cnt[idx]);
+				if ((uint32_t)cnt == 1u)
+				{
+					const unsigned long long r0 = ld_agent(&w.node_rec[2 * idx]), r1 = ld_agent(&w.node_rec[2 * idx + 1]);
+					const uint32_t at = (uint32_t)off, chunk0 = (uint32_t)(off >> 32), nchunks = (uint32_t)(cnt >> 32);
+					w.front[0][3 * at] = (uint32_t)r0 | kTcFinal; w.front[0][3 * at + 1] = (uint32_t)(r0 >> 32); w.front[0][3 * at + 2] = (uint32_t)r1;
+					w.chunk_off[at] = chunk0;
+					for (uint32_t j = 0; j < nchunks; j++) w.chunk_pair[chunk0 + j] = at;
+				}
+			}
+		}
+		if (g + 1 < generations && !grid_barrier(trav, target)) return;
+	}
+	if (gtid == 0)
+	{
+		w.chunk_off[leaves] = chunks;
+		w.counters[kTcGenerations] = generations;
+		w.counters[kTcLeafPairs] = leaves;
+		w.counters[kTcChunks] = chunks;
+		w.counters[kTcTreeNodes] = gstart[generations];
 	}
 }
 

@@ -146,6 +146,54 @@ def test_plugin_two_colliding_bars_bit_exact(solid_method, sub_steps, dims, seri
 
 
 @pytest.mark.gpu
+def test_plugin_tet_contacts_medium_scene_timing_and_parity():
+    """Two 64x16x16 bars (18785 particles, 81920 tets each): state resident on the device for the whole run, bitwise against the
+    reference at the end; prints ms/step of the engine and of the reference (1 thread and 16 threads)."""
+    import time
+    if not os.path.exists(PLUGIN):
+        pytest.skip("plug-in not built")
+    ref = _ref()
+    dims = tuple(int(v) for v in os.environ.get("PBDX_TET_BENCH_DIMS", "64,16,16").split(","))
+    steps = int(os.environ.get("PBDX_TET_BENCH_STEPS", "40"))
+    t_upper = (0.3, 0.5 * (1.0 + 1.0 / (dims[1] - 1)) + 0.02, 0.05)
+    cpu_ms = {}
+    for threads in (16, 1):
+        tcu.two_bar_scene(ref, dims=dims, t_upper=t_upper)
+        ref.set_num_threads(threads)
+        ref.set_params(1, 5, 0)
+        t0 = time.perf_counter()
+        seen = 0
+        for _ in range(steps):
+            ref.step(1)
+            seen += ref.num_particle_solid_contacts()
+        cpu_ms[threads] = (time.perf_counter() - t0) * 1e3 / steps
+    x_cpu, v_cpu, c_cpu = ref.positions().copy(), ref.get_array(2).copy(), tcu.oracle_contacts_as_engine_records(ref)
+    assert seen > 1000
+    tcu.two_bar_scene(ref, dims=dims, t_upper=t_upper)
+    assert ref.install_timestep_plugin(PLUGIN) == 0
+    ref.lib.refdrv_attach_collision_detection()
+    ref.set_params(1, 5, 0)
+    lib, ts = _plugin_handles(ref)
+    lib.pbdx_timestep_hip_step_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    lib.pbdx_timestep_hip_sync_to_host.argtypes = [C.c_void_p, C.c_void_p]
+    model = ref.model_ptr()
+    assert lib.pbdx_timestep_hip_step_resident(ts, model, 1) == 0          # set-up (schedule, plan, upload) + step 1
+    t0 = time.perf_counter()
+    assert lib.pbdx_timestep_hip_step_resident(ts, model, steps - 1) == 0
+    assert lib.pbdx_timestep_hip_sync_to_host(ts, model) == 0
+    gpu_ms = (time.perf_counter() - t0) * 1e3 / (steps - 1)
+    x, v = ref.positions().copy(), ref.get_array(2).copy()
+    got = _device_contacts(lib, ts, 1 << 16)
+    n_particles = len(x)
+    ref.reset_all()
+    print("\n[tet contacts timing] two %dx%dx%d bars, %d particles, %d steps, %d contacts in total (%d at the end): engine %.3f ms/step resident; "
+          "reference %.1f ms/step (1 thread), %.1f ms/step (16 threads)" % (dims + (n_particles, steps, seen, len(c_cpu), gpu_ms, cpu_ms[1], cpu_ms[16])))
+    assert len(got) == len(c_cpu) and util.bitwise_equal(got[:, :26], c_cpu)
+    assert util.bitwise_equal(x, x_cpu), "max err %.3e" % util.max_err(x, x_cpu)
+    assert util.bitwise_equal(v, v_cpu)
+
+
+@pytest.mark.gpu
 def test_plugin_refuses_friction_between_deformables():
     """The reference's friction impulse for these contacts reads a multiplier nothing has written (Constraints.h:553,
     SimulationModel.cpp:557): there is no defined result to match, so the model is refused, loudly."""
