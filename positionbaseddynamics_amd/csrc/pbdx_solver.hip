@@ -1006,6 +1006,8 @@ struct pbdx_solver
 	float *d_tet_aabb = nullptr;
 	TetContact *d_tet_contacts = nullptr;
 	uint32_t *d_tet_counters = nullptr;
+	uint32_t *d_tet_big = nullptr; uint32_t tet_big_count = 0;   // nodes with long chains (tet_hull_kernel2)
+	uint32_t *d_tet_big_slices = nullptr, *d_tet_big_r2 = nullptr; uint32_t tet_big_slices = 0;
 	TetWork tet_work = {};
 	void *tet_work_alloc[16] = {};
 	int tet_serial = 0;                            // PBDX_OPT_TET_CONTACTS_SERIAL
@@ -1043,6 +1045,8 @@ struct pbdx_solver
 		if (d_tet_views) { (void)hipFree(d_tet_views); d_tet_views = nullptr; }
 		if (d_tet_aabb) { (void)hipFree(d_tet_aabb); d_tet_aabb = nullptr; }
 		for (void *&p : tet_work_alloc) if (p) { (void)hipFree(p); p = nullptr; }
+		for (uint32_t **p : { &d_tet_big, &d_tet_big_slices, &d_tet_big_r2 }) if (*p) { (void)hipFree(*p); *p = nullptr; }
+		tet_big_count = 0; tet_big_slices = 0;
 		tet_work = TetWork{};
 	}
 
@@ -1064,6 +1068,8 @@ struct pbdx_solver
 	bool graph_valid[2] = { false, false };
 
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	hipStream_t stream_side = nullptr;                 // forked from / joined to `stream` (also under capture): the short nodes' spheres next to the long chains
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	std::vector<hipEvent_t> prof_events;
 	pbdx_step_stats stats = {};
 	double type_ms[PBDX_NUM_CONSTRAINT_TYPES] = {};
@@ -1801,9 +1807,21 @@ int enqueue_tet_detection(pbdx_solver *s)
 		}
 		s->tet_timed(0, [&] {
 			hipLaunchKernelGGL(tet_gather_kernel, dim3((max_elems + 255) / 256, 2 * nc), dim3(256), 0, s->stream, views, pos);
-			hipLaunchKernelGGL(tet_hull_kernel2, dim3(max_nodes, 2 * nc), dim3(256), 0, s->stream, views);
+			// the few long chains (one CU each, ~1 ms for 330k vertices) and the tens of thousands of short ones do not depend on each other
+			const bool fork = s->tet_big_count != 0;
+			hipStream_t side = fork ? s->stream_side : s->stream;
+			if (fork) { (void)hipEventRecord(s->ev_fork, s->stream); (void)hipStreamWaitEvent(side, s->ev_fork, 0); }
+			hipLaunchKernelGGL(tet_hull_kernel2, dim3(max_nodes, 2 * nc), dim3(256), 0, side, views, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+			hipLaunchKernelGGL(tet_aabb_kernel, dim3(nc), dim3(256), 0, side, views, pos, s->d_tet_aabb);
+			if (fork)
+			{
+				(void)hipEventRecord(s->ev_join, side);
+				hipLaunchKernelGGL(tet_hull_kernel2, dim3(s->tet_big_count), dim3(256), kTcBigNodeLds, s->stream, views, (const uint32_t *)s->d_tet_big, s->d_tet_big_r2);
+				hipLaunchKernelGGL(tet_big_radius_kernel, dim3(s->tet_big_slices), dim3(256), 0, s->stream, views, (const uint32_t *)s->d_tet_big, (const uint32_t *)s->d_tet_big_slices, s->d_tet_big_r2);
+				hipLaunchKernelGGL(tet_big_finish_kernel, dim3((s->tet_big_count + 255) / 256), dim3(256), 0, s->stream, views, (const uint32_t *)s->d_tet_big, s->tet_big_count, (const uint32_t *)s->d_tet_big_r2);
+				(void)hipStreamWaitEvent(s->stream, s->ev_join, 0);
+			}
 		});
-		s->tet_timed(1, [&] { hipLaunchKernelGGL(tet_aabb_kernel, dim3(nc), dim3(256), 0, s->stream, views, pos, s->d_tet_aabb); });
 		s->tet_timed(2, [&] {
 			// one workgroup per CU, all resident at once (they meet at barriers); the launch's scratch words start at zero
 			(void)hipMemsetAsync(s->tet_work.trav, 0, kTrWords * sizeof(uint32_t), s->stream);
@@ -1999,6 +2017,9 @@ int pbdx_solver_create(pbdx_solver **out, int device)
 	hipError_t e = hipSetDevice(device);
 	if (e == hipSuccess) e = hipGetDeviceProperties(&s->prop, device);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream_side, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreate(&s->ev_start);
 	if (e == hipSuccess) e = hipEventCreate(&s->ev_stop);
 	if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s->h_error), 4 * sizeof(uint32_t), hipHostMallocMapped);
@@ -2038,6 +2059,9 @@ void pbdx_solver_destroy(pbdx_solver *s)
 	for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
 	if (s->ev_start) (void)hipEventDestroy(s->ev_start);
 	if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
+	if (s->stream_side) (void)hipStreamDestroy(s->stream_side);
+	if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+	if (s->ev_join) (void)hipEventDestroy(s->ev_join);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
 	if (s->h_error) (void)hipHostFree(s->h_error);
 	if (s->d_ctl) (void)hipFree(s->d_ctl);
@@ -2654,6 +2678,37 @@ int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 				view[q]->flat = dst[q]->flat; view[q]->gathered = dst[q]->gathered; view[q]->per_entity = per;
 			}
 		}
+	}
+	{
+		// the nodes whose chains are long, longest first
+		struct Big { uint32_t m, which, node; };
+		std::vector<Big> big;
+		for (uint32_t i = 0; i < n; i++)
+			for (int q = 0; q < 2; q++)
+			{
+				const pbdx_bvh &b = q ? colliders[i].tets_bvh : colliders[i].points;
+				for (uint32_t nd = 0; nd < b.num_nodes; nd++)
+				{
+					const uint32_t m = (uint32_t)b.nodes[4 * nd + 3] * (q ? 4u : 1u);
+					if (m >= kTcBigNode) big.push_back(Big{ m, 2 * i + (uint32_t)q, nd });
+				}
+			}
+		std::sort(big.begin(), big.end(), [](const Big &a, const Big &b) { return a.m > b.m; });
+		std::vector<uint32_t> flat, slices;
+		for (size_t bi = 0; bi < big.size(); bi++)
+		{
+			flat.push_back(big[bi].which); flat.push_back(big[bi].node);
+			for (uint32_t sl = 0; sl * kTcRadiusSlice < big[bi].m; sl++) { slices.push_back((uint32_t)bi); slices.push_back(sl); }
+		}
+		s->tet_big_count = (uint32_t)big.size();
+		s->tet_big_slices = (uint32_t)(slices.size() / 2);
+		if (!flat.empty())
+		{
+			HIPCHECK(up(&s->d_tet_big, flat.data(), flat.size()));
+			HIPCHECK(up(&s->d_tet_big_slices, slices.data(), slices.size()));
+			HIPCHECK(hipMalloc(&s->d_tet_big_r2, big.size() * sizeof(uint32_t)));
+		}
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(tet_hull_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTcBigNodeLds);
 	}
 	HIPCHECK(hipMalloc(&s->d_tet_views, (size_t)n * sizeof(TetColliderView)));
 	HIPCHECK(hipMemcpy(s->d_tet_views, s->tet_views.data(), (size_t)n * sizeof(TetColliderView), hipMemcpyHostToDevice));

@@ -119,61 +119,108 @@ __global__ __launch_bounds__(256) void tet_gather_kernel(const TetColliderView *
 // values issued before the additions of the current 32.  Padding a stage with +0 is exact: a running sum that starts at +0 is never -0.
 // (Measured on the 81920-tet root, 327680 vertices per component: one wavefront for all three chains, operands by v_readlane 7.7 ms,
 // by v_add_f32_dpp wave_shr:1 3.2 ms, by LDS broadcast 5.3 ms; this form: see DESIGN.md.)
-__device__ __forceinline__ void chain_32(float &acc, const float4 (&v)[8])
+// The LDS reads of a chain are issued by hand (the compiler waits for ALL outstanding LDS reads before the first addition of a batch,
+// which leaves the chain idle for the LDS round trip 8 times per stage): ds_read_b128 by inline asm, which the compiler's wait-count
+// insertion does not see, and the waits as asm statements that "rewrite" the batch's registers, so that no addition can be moved
+// above its wait and the registers stay reserved while the data is in flight.  LDS returns in order: with the next batch's 8 reads
+// issued behind it, a batch has arrived when at most 8 reads are outstanding.
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int OFF> __device__ __forceinline__ void lds_read16(f4v &d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int BATCH> __device__ __forceinline__ void lds_read_batch(f4v (&v)[8], uint32_t addr)
+{
+	lds_read16<128 * BATCH + 0>(v[0], addr); lds_read16<128 * BATCH + 16>(v[1], addr); lds_read16<128 * BATCH + 32>(v[2], addr); lds_read16<128 * BATCH + 48>(v[3], addr);
+	lds_read16<128 * BATCH + 64>(v[4], addr); lds_read16<128 * BATCH + 80>(v[5], addr); lds_read16<128 * BATCH + 96>(v[6], addr); lds_read16<128 * BATCH + 112>(v[7], addr);
+}
+__device__ __forceinline__ void lds_wait_8_outstanding(f4v (&v)[8])
+{
+	asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+__device__ __forceinline__ void lds_wait_all(f4v (&v)[8])
+{
+	asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+__device__ __forceinline__ void chain_32(float &acc, const f4v (&v)[8])
 {
 #pragma unroll
 	for (int q = 0; q < 8; q++) { acc += v[q].x; acc += v[q].y; acc += v[q].z; acc += v[q].w; }
 }
-// grid: (max over colliders of nodes, 2 * colliders)
-__global__ __launch_bounds__(256) void tet_hull_kernel2(const TetColliderView *views)
+// `batches` x 32 values at LDS address `addr` (1 .. 8; the waits are explicit, so the early exits cost nothing)
+__device__ __forceinline__ void chain_stage(float &acc, uint32_t addr, uint32_t batches)
+{
+	if (batches < 8u)
+	{
+		f4v a[8];
+		lds_read_batch<0>(a, addr); lds_wait_all(a); chain_32(acc, a);
+		if (batches < 2u) return;
+		lds_read_batch<1>(a, addr); lds_wait_all(a); chain_32(acc, a);
+		if (batches < 3u) return;
+		lds_read_batch<2>(a, addr); lds_wait_all(a); chain_32(acc, a);
+		if (batches < 4u) return;
+		lds_read_batch<3>(a, addr); lds_wait_all(a); chain_32(acc, a);
+		if (batches < 5u) return;
+		lds_read_batch<4>(a, addr); lds_wait_all(a); chain_32(acc, a);
+		if (batches < 6u) return;
+		lds_read_batch<5>(a, addr); lds_wait_all(a); chain_32(acc, a);
+		if (batches < 7u) return;
+		lds_read_batch<6>(a, addr); lds_wait_all(a); chain_32(acc, a);
+		return;
+	}
+	f4v a[8], b[8];
+	lds_read_batch<0>(a, addr);
+	lds_read_batch<1>(b, addr); lds_wait_8_outstanding(a); chain_32(acc, a);
+	lds_read_batch<2>(a, addr); lds_wait_8_outstanding(b); chain_32(acc, b);
+	lds_read_batch<3>(b, addr); lds_wait_8_outstanding(a); chain_32(acc, a);
+	lds_read_batch<4>(a, addr); lds_wait_8_outstanding(b); chain_32(acc, b);
+	lds_read_batch<5>(b, addr); lds_wait_8_outstanding(a); chain_32(acc, a);
+	lds_read_batch<6>(a, addr); lds_wait_8_outstanding(b); chain_32(acc, b);
+	lds_read_batch<7>(b, addr); lds_wait_8_outstanding(a); chain_32(acc, a);
+	lds_wait_all(b); chain_32(acc, b);
+}
+// The long chains are the critical path, and a chain that shares its SIMD with other wavefronts' chains runs at a fraction of its speed:
+// the nodes with at least kTcBigNode vertices (a static list: `big`, 2 words each: collider * 2 + hierarchy, node) go first, in a launch
+// that asks for so much LDS that a CU takes one workgroup; everything else follows in a second launch (big == nullptr;
+// grid: (max over colliders of nodes, 2 * colliders)).
+constexpr uint32_t kTcBigNode = 8192;
+constexpr uint32_t kTcBigNodeLds = 96 * 1024;
+__global__ __launch_bounds__(256) void tet_hull_kernel2(const TetColliderView *views, const uint32_t *big, uint32_t *big_r2)
 {
 	__shared__ __attribute__((aligned(16))) float comp[2][3][256];
 	__shared__ float s_sum[3];
 	__shared__ float s_max[4];
-	const TetColliderView &v = views[blockIdx.y >> 1];
-	const bool tets = (blockIdx.y & 1u) != 0;
+	const uint32_t which = big ? big[2 * blockIdx.x] : blockIdx.y;
+	const uint32_t node = big ? big[2 * blockIdx.x + 1] : blockIdx.x;
+	const TetColliderView &v = views[which >> 1];
+	const bool tets = (which & 1u) != 0;
 	const BvhView &b = tets ? v.tet_bvh : v.points;
-	const uint32_t node = blockIdx.x;
 	if (node >= b.num_nodes) return;
 	const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
 	const uint32_t n = (uint32_t)b.nodes[4 * node + 3];
 	const uint32_t m = n * b.per_entity;
+	if (!big && m >= kTcBigNode) return;
 	const float4 *g = reinterpret_cast<const float4 *>(b.gathered) + (size_t)(uint32_t)b.nodes[4 * node + 2] * b.per_entity;
 	const uint32_t stages = (m + 255u) / 256u;
 	auto fetch = [&](uint32_t st) { float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f); const uint32_t e = st * 256u + tid; if (e < m) p = g[e]; return p; };
-	float4 cur = fetch(0);
+	constexpr int kAhead = 6;          // stages in flight: a stage's chain is ~0.5 us, a load from HBM comes back in ~1-2 us
+	float4 cur[kAhead];
+#pragma unroll
+	for (int d = 0; d < kAhead; d++) cur[d] = fetch((uint32_t)d);
 	float acc = 0.0f;
-	for (uint32_t st = 0; st < stages; st++)
+	for (uint32_t st0 = 0; st0 < stages; st0 += kAhead)
 	{
-		const uint32_t buf = st & 1u;
-		comp[buf][0][tid] = cur.x; comp[buf][1][tid] = cur.y; comp[buf][2][tid] = cur.z;
-		cur = fetch(st + 1u);
-		__syncthreads();
-		if (wave < 3u)
+#pragma unroll
+		for (int d = 0; d < kAhead; d++)
 		{
-			const uint32_t left = m - st * 256u;
-			const uint32_t batches = left >= 256u ? 8u : (left + 31u) / 32u;          // of 32 values
-			const float4 *src = reinterpret_cast<const float4 *>(comp[buf][wave]);
-			float4 va[8], vb[8];
-#pragma unroll
-			for (int q = 0; q < 8; q++) va[q] = src[q];
-			for (uint32_t k = 0; k < batches; k += 2)
+			const uint32_t st = st0 + (uint32_t)d;
+			if (st >= stages) break;
+			const uint32_t buf = st & 1u;
+			comp[buf][0][tid] = cur[d].x; comp[buf][1][tid] = cur[d].y; comp[buf][2][tid] = cur[d].z;
+			cur[d] = fetch(st + kAhead);
+			__syncthreads();
+			if (wave < 3u)
 			{
-				if (k + 1u < batches)
-				{
-#pragma unroll
-					for (int q = 0; q < 8; q++) vb[q] = src[8 * (k + 1u) + q];
-				}
-				chain_32(acc, va);
-				if (k + 1u < batches)
-				{
-					if (k + 2u < batches)
-					{
-#pragma unroll
-						for (int q = 0; q < 8; q++) va[q] = src[8 * (k + 2u) + q];
-					}
-					chain_32(acc, vb);
-				}
+				// the stage, padded with +0 to a multiple of 32 values
+				const uint32_t left = m - st * 256u;
+				chain_stage(acc, (uint32_t)(uintptr_t)&comp[buf][wave][0], left >= 256u ? 8u : (left + 31u) / 32u);
 			}
 		}
 	}
@@ -181,6 +228,12 @@ __global__ __launch_bounds__(256) void tet_hull_kernel2(const TetColliderView *v
 	__syncthreads();
 	V3 x = mk(s_sum[0], s_sum[1], s_sum[2]);
 	x = tets ? x / (4.0f * (float)n) : x / (float)n;
+	if (big)
+	{
+		// the radius of a long node is a maximum over megabytes: not for four wavefronts (tet_big_radius_kernel)
+		if (tid == 0) { P4 h; h.x = x.x; h.y = x.y; h.z = x.z; h.w = 0.0f; b.hulls[node] = h; big_r2[blockIdx.x] = 0u; }
+		return;
+	}
 	float radius2 = 0.0f;
 	for (uint32_t e = tid; e < m; e += 256)
 	{
@@ -198,6 +251,47 @@ __global__ __launch_bounds__(256) void tet_hull_kernel2(const TetColliderView *v
 		h.w = tets ? (float)(sqrt((double)radius2) + (double)v.tolerance) : sqrtf(radius2);
 		b.hulls[node] = h;
 	}
+}
+
+// radius of the long nodes.  slices: 2 words per workgroup (index into `big`, slice of kTcRadiusSlice vertices); squared distances are
+// non-negative floats, whose order is the order of their bit patterns
+constexpr uint32_t kTcRadiusSlice = 4096;
+__global__ __launch_bounds__(256) void tet_big_radius_kernel(const TetColliderView *views, const uint32_t *big, const uint32_t *slices, uint32_t *big_r2)
+{
+	__shared__ float s_max[4];
+	const uint32_t bi = slices[2 * blockIdx.x], slice = slices[2 * blockIdx.x + 1];
+	const uint32_t which = big[2 * bi], node = big[2 * bi + 1];
+	const TetColliderView &v = views[which >> 1];
+	const BvhView &b = (which & 1u) ? v.tet_bvh : v.points;
+	const uint32_t m = (uint32_t)b.nodes[4 * node + 3] * b.per_entity;
+	const float4 *g = reinterpret_cast<const float4 *>(b.gathered) + (size_t)(uint32_t)b.nodes[4 * node + 2] * b.per_entity;
+	const V3 x = p3(b.hulls[node]);
+	float radius2 = 0.0f;
+	const uint32_t end = (slice + 1u) * kTcRadiusSlice < m ? (slice + 1u) * kTcRadiusSlice : m;
+	for (uint32_t e = slice * kTcRadiusSlice + threadIdx.x; e < end; e += 256)
+	{
+		const float4 q = g[e];
+		const float d = sqn(x - mk(q.x, q.y, q.z));
+		radius2 = (radius2 < d) ? d : radius2;
+	}
+	radius2 = wave_max(radius2);
+	if ((threadIdx.x & 63u) == 0) s_max[threadIdx.x >> 6] = radius2;
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		for (int q = 1; q < 4; q++) radius2 = (radius2 < s_max[q]) ? s_max[q] : radius2;
+		atomicMax(&big_r2[bi], __float_as_uint(radius2));
+	}
+}
+__global__ __launch_bounds__(256) void tet_big_finish_kernel(const TetColliderView *views, const uint32_t *big, uint32_t count, const uint32_t *big_r2)
+{
+	const uint32_t bi = blockIdx.x * 256u + threadIdx.x;
+	if (bi >= count) return;
+	const uint32_t which = big[2 * bi], node = big[2 * bi + 1];
+	const TetColliderView &v = views[which >> 1];
+	const BvhView &b = (which & 1u) ? v.tet_bvh : v.points;
+	const float radius2 = __uint_as_float(big_r2[bi]);
+	b.hulls[node].w = (which & 1u) ? (float)(sqrt((double)radius2) + (double)v.tolerance) : sqrtf(radius2);
 }
 
 // ---- traversal: BVHTest::traverse's recursion tree, generation by generation ----------------------------------------------------------
