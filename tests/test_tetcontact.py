@@ -50,6 +50,26 @@ def test_engine_detection_on_host_equals_reference_contact_list():
     assert total > 300, "the scene is supposed to produce contacts (got %d)" % total
 
 
+def test_engine_detection_on_host_three_solids_pair_order():
+    """Three stacked bars: four ordered pairs of solids produce contacts in the same step; the list is pair-major, i outer."""
+    ref = _ref()
+    objs = tcu.stacked_bars_scene(ref, 3)
+    ref.set_params(1, 5, 0)
+    cols = tcu.TetColliders(ref, objs, (0, 1, 2), 0.01)
+    total, solids_seen = 0, set()
+    for step in range(90):
+        ref.step(1)
+        want = tcu.oracle_contacts_as_engine_records(ref)
+        got = tcu.host_contacts(ref, cols)
+        assert len(got) == len(want), "step %d: %d contacts, reference %d" % (step, len(got), len(want))
+        if len(want):
+            assert util.bitwise_equal(got[:, :26], want), "step %d" % step
+            solids_seen.update(int(v) for v in want[:, 1])
+        total += len(want)
+    ref.reset_all()
+    assert total > 500 and solids_seen == {0, 1, 2}
+
+
 def test_set_tet_colliders_validates_before_touching_the_device():
     """Argument checks come first, so they are testable without a GPU: friction and malformed hierarchies are refused."""
     ref = _ref()
@@ -142,6 +162,39 @@ def test_plugin_two_colliding_bars_bit_exact(solid_method, sub_steps, dims, seri
         assert util.bitwise_equal(v, cpu[s][1]), "step %d (velocities)" % s
     assert lib.pbdx_timestep_hip_gpu_steps(ts) == steps
     print("\n[tet contacts] dims %s method %d substeps %d serial %d: %d contacts over %d steps, %d at the last" % (dims, solid_method, sub_steps, serial, seen, steps, len(cpu[steps][2])))
+    ref.reset_all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("serial", [0, 1])
+def test_plugin_three_stacked_solids_bit_exact(serial):
+    """Several colliding pairs of solids share one traversal: contact order across pairs, levels across pairs."""
+    if not os.path.exists(PLUGIN):
+        pytest.skip("plug-in not built")
+    ref = _ref()
+    steps, checkpoints = 90, (50, 70, 90)
+    tcu.stacked_bars_scene(ref, 3)
+    ref.set_params(1, 5, 0)
+    cpu = {}
+    for s in range(1, steps + 1):
+        ref.step(1)
+        if s in checkpoints:
+            cpu[s] = (ref.positions().copy(), ref.get_array(2).copy(), tcu.oracle_contacts_as_engine_records(ref))
+    assert len(cpu[steps][2]) > 0 and len(set(cpu[steps][2][:, 1])) >= 2
+    tcu.stacked_bars_scene(ref, 3)
+    assert ref.install_timestep_plugin(PLUGIN) == 0
+    ref.lib.refdrv_attach_collision_detection()
+    ref.set_params(1, 5, 0)
+    lib, ts = _plugin_handles(ref)
+    _ffi.check(_ffi.lib.pbdx_solver_set_option(C.c_void_p(lib.pbdx_timestep_hip_solver(ts)), 15, serial), "set_option")
+    done = 0
+    for s in checkpoints:
+        ref.step(s - done)
+        done = s
+        assert lib.pbdx_timestep_hip_failed_steps(ts) == 0
+        got = _device_contacts(lib, ts)
+        assert len(got) == len(cpu[s][2]) and (not len(got) or util.bitwise_equal(got[:, :26], cpu[s][2])), "step %d: contact list" % s
+        assert util.bitwise_equal(ref.positions(), cpu[s][0]) and util.bitwise_equal(ref.get_array(2), cpu[s][1]), "step %d" % s
     ref.reset_all()
 
 

@@ -37,6 +37,31 @@ def two_bar_scene(ref, solid_method=6, tolerance=0.01, friction=0.0, dims=DIMS, 
     return objs
 
 
+def stacked_bars_scene(ref, n_bars=3, solid_method=6, tolerance=0.01, dims=DIMS):
+    """n bars stacked with gaps, the lowest clamped at both ends: every ordered pair (i, k) of solids whose boxes meet is tested,
+    i outer (DistanceFieldCollisionDetection.cpp:33-46) -- the contact list interleaves several pairs."""
+    ref.reset_all()
+    ref.set_num_threads(1)
+    ref.set_time_step_size(0.005)
+    ref.set_gravity((0, -9.81, 0))
+    offsets = [(0.3 * (q % 2), 0.62 * q, 0.05 * (q % 2)) for q in range(n_bars)]
+    for t in offsets:
+        ref.add_regular_tet_model(*dims, t, None, SCALE)
+    w, h, d = dims
+    for j in range(h):
+        for k in range(d):
+            ref.set_mass(j * d + k, 0.0)
+            ref.set_mass(((w - 1) * h + j) * d + k, 0.0)
+    for tm in range(n_bars):
+        ref.add_solid_constraints(tm, solid_method, 1e5 if solid_method in (3, 6) else 1.0, 0.3, 1e5 if solid_method == 6 else 1.0, False, False)
+    ref.set_collision_tolerance(tolerance)
+    for tm, t in enumerate(offsets):
+        ref.set_tet_model_initial_transform(tm, t)
+    objs = [ref.add_tet_collision_box(tm, SCALE, True, 0.6, 0.0) for tm in range(n_bars)]
+    ref.attach_collision_detection()
+    return objs
+
+
 class TetColliders:
     """pbdx_tet_collider array built from the oracle's collision objects; keeps the numpy arrays alive."""
 
