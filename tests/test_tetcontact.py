@@ -199,6 +199,46 @@ def test_plugin_three_stacked_solids_bit_exact(serial):
 
 
 @pytest.mark.gpu
+def test_c_abi_without_the_plugin_two_bars_bit_exact():
+    """The same scene through the package's own model mirror and the raw solver calls (pbdx_solver_set_rest_positions /
+    set_tet_colliders / get_tet_contacts): what a host application that is not the reference would do -- it brings its own
+    bounding-sphere hierarchies (here: the ones the oracle built for the identical rest shape)."""
+    import positionbaseddynamics_amd as pbd
+    ref = _ref()
+    objs = tcu.two_bar_scene(ref)
+    ref.set_params(1, 5, 0)
+    cols = tcu.TetColliders(ref, objs, (0, 1), 0.01)
+    x0 = ref.get_array(1).astype(np.float32)
+    steps = 80
+    ref.step(steps)
+    x_cpu, v_cpu, c_cpu = ref.positions().copy(), ref.get_array(2).copy(), tcu.oracle_contacts_as_engine_records(ref)
+    ref.reset_all()
+    assert len(c_cpu) > 0
+    w, h, d = tcu.DIMS
+    ops = [("tet", w, h, d, tcu.T_LOWER, None, tcu.SCALE), ("tet", w, h, d, tcu.T_UPPER, None, tcu.SCALE)]
+    for j in range(h):
+        for k in range(d):
+            ops += [("mass", j * d + k, 0.0), ("mass", ((w - 1) * h + j) * d + k, 0.0)]
+    ops += [("solid", tm, 6, 1e5, 0.3, 1e5, False, False) for tm in (0, 1)]
+    model = util.build_mine(ops)
+    ts = pbd.TimeStepController()
+    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 5)
+    pbd.TimeManager.getCurrent().setTimeStepSize(0.005)
+    ts.syncFromHost(model)                       # particles on the device: the colliders refer to their ranges
+    sol = ts.solver()
+    sol.set_rest_positions(x0)
+    sol.set_tet_colliders(cols.arr, cols.n, 0.01)
+    ts.stepResident(model, steps)
+    ts.syncToHost(model)
+    got = sol.tet_contacts()
+    x, v = model.getParticles().positions(), model.getParticles().velocities()
+    assert len(got) == len(c_cpu) and util.bitwise_equal(got[:, :26], c_cpu)
+    assert util.bitwise_equal(x, x_cpu), "max err %.3e" % util.max_err(x, x_cpu)
+    assert util.bitwise_equal(v, v_cpu)
+
+
+@pytest.mark.gpu
 def test_plugin_tet_contacts_medium_scene_timing_and_parity():
     """Two 64x16x16 bars (18785 particles, 81920 tets each): state resident on the device for the whole run, bitwise against the
     reference at the end; prints ms/step of the engine and of the reference (1 thread and 16 threads)."""
