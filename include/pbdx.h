@@ -262,6 +262,9 @@ int pbdx_debug_tet_hulls(pbdx_solver *s, uint32_t collider, int which, uint32_t 
 /* Developer aid: counters of the last detection: contacts, (flags: 1, 2), overlapping leaf pairs, 64-candidate chunks, dependency levels of the
  * solve, generations and node pairs of the traversal's recursion tree. */
 int pbdx_debug_tet_counters(pbdx_solver *s, uint32_t out[8]);
+/* Developer aid: capacities of the detection's scratch (node pairs, overlapping leaf pairs, contacts) and how often it was enlarged: the scratch
+ * grows on demand -- an overflow is detected after the detection that caused it, the buffer is made four times as large and the detection repeated. */
+int pbdx_debug_tet_capacity(pbdx_solver *s, uint32_t out[4]);
 /* The same detection evaluated on the HOST by the same code (pbdx_tetcontact.h is host + device): developer / test aid, no GPU
  * needed.  pos4 / rest4: n x (x, y, z, invMass) records. */
 int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float *rest4, uint32_t n, const pbdx_tet_collider *colliders,

@@ -121,6 +121,7 @@ SIGNATURES = [
     ("pbdx_solver_set_rest_positions", C.c_int, vp, u32, pf),
     ("pbdx_solver_get_tet_contacts", C.c_int, vp, u32, C.POINTER(u32), pf),
     ("pbdx_debug_tet_counters", C.c_int, vp, C.POINTER(u32)),
+    ("pbdx_debug_tet_capacity", C.c_int, vp, C.POINTER(u32)),
     ("pbdx_debug_tet_hulls", C.c_int, vp, u32, C.c_int, u32, C.POINTER(u32), pf),
     ("pbdx_debug_tet_contacts", C.c_int, u32, pf, pf, u32, C.POINTER(TetCollider), f32, u32, C.POINTER(u32), pf),
     ("pbdx_model_plan_check", C.c_int, vp, u32, u32, u32, C.POINTER(PlanInfo)),

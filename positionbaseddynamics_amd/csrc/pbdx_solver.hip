@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256) void tet_aabb_kernel(const TetColliderView *vi
 	}
 	if (threadIdx.x < 3) { aabb[6 * blockIdx.x + threadIdx.x] = lo[threadIdx.x][0]; aabb[6 * blockIdx.x + 3 + threadIdx.x] = hi[threadIdx.x][0]; }
 }
-__global__ void tet_detect_kernel(const TetColliderView *views, uint32_t n, const P4 *pos, const P4 *rest, const float *aabb, TetContact *contacts, uint32_t *counters)
+__global__ void tet_detect_kernel(const TetColliderView *views, uint32_t n, const P4 *pos, const P4 *rest, const float *aabb, TetContact *contacts, uint32_t *counters, uint32_t max_contacts)
 {
 	if (blockIdx.x || threadIdx.x) return;
 	uint32_t found = 0;
@@ -839,12 +839,12 @@ __global__ void tet_detect_kernel(const TetColliderView *views, uint32_t n, cons
 		{
 			if (i == k || !views[i].test_mesh || !aabb_intersect(aabb + 6 * i, aabb + 6 * k)) continue;
 			ok = tet_pair_contacts(views[i], views[k], pos, rest, [&](const TetContact &c) {
-				if (found < kMaxTetContacts) contacts[found] = c;
+				if (found < max_contacts) contacts[found] = c;
 				found++;
 			}) && ok;
 		}
-	counters[kTcCount] = found < kMaxTetContacts ? found : kMaxTetContacts;
-	if (found > kMaxTetContacts) counters[kTcOverflow] = 1u;
+	counters[kTcCount] = found < max_contacts ? found : max_contacts;
+	if (found > max_contacts) counters[kTcOverflow] = 1u;
 	if (!ok) counters[kTcStack] = 1u;
 }
 // TimeStepController.cpp:288-291: after the colour groups of an iteration, the contact list sequentially
@@ -1011,6 +1011,8 @@ struct pbdx_solver
 	TetWork tet_work = {};
 	void *tet_work_alloc[16] = {};
 	int tet_serial = 0;                            // PBDX_OPT_TET_CONTACTS_SERIAL
+	uint32_t tet_grown = 0;                        // times the detection's scratch was enlarged
+	uint32_t tet_num_colliders = 0;
 	// developer aid (PBDX_TET_PROFILE=1, hipGraph off): wall time per kernel of the contact path, printed when the solver is destroyed
 	bool tet_profile = getenv("PBDX_TET_PROFILE") != nullptr;
 	double tet_ms[8] = {}; uint64_t tet_launches[8] = {};
@@ -1779,7 +1781,46 @@ int enqueue_substep(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int v
 // substeps (TimeStepController.cpp:216-223)
 // DistanceFieldCollisionDetection::collisionDetection for the solid-solid pairs: bounding spheres, boxes, detection (pbdx_tetcontact.h).
 // The new contact list is used by the position solves of the NEXT step.
-int enqueue_tet_detection(pbdx_solver *s)
+// (re)allocates the scratch of the detection; the contact list is preserved across a growth of anything else
+int alloc_tet_work(pbdx_solver *s, uint64_t nodes, uint32_t contacts)
+{
+	TetWork &w = s->tet_work;
+	const uint32_t n = s->tet_num_colliders;
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	s->drop_graph();               // the captured substep carries the solve's launch with the old buffers
+	if (contacts != w.max_contacts || !s->d_tet_contacts)
+	{
+		TetContact *fresh = nullptr;
+		HIPCHECK(hipMalloc(&fresh, (size_t)contacts * sizeof(TetContact)));
+		if (s->d_tet_contacts)
+		{
+			HIPCHECK(hipMemcpy(fresh, s->d_tet_contacts, (size_t)std::min(contacts, w.max_contacts) * sizeof(TetContact), hipMemcpyDeviceToDevice));
+			(void)hipFree(s->d_tet_contacts);
+		}
+		s->d_tet_contacts = fresh;
+	}
+	for (void *&p : s->tet_work_alloc) if (p) { (void)hipFree(p); p = nullptr; }
+	w.max_contacts = contacts;
+	w.node_cap = (uint32_t)nodes;
+	w.front_cap = (uint32_t)std::max<uint64_t>(nodes / 4, (uint64_t)n * n);
+	w.chunk_cap = (uint32_t)(nodes / 2);
+	HIPCHECK(hipMalloc(&s->tet_work_alloc[15], kTrWords * sizeof(uint32_t)));
+	w.trav = (uint32_t *)s->tet_work_alloc[15];
+	const size_t bytes[15] = { (size_t)3 * w.front_cap * 4, 0, (size_t)2 * n * n * 4, ((size_t)w.front_cap + 1) * 4, (size_t)w.chunk_cap * 4,
+		(size_t)w.chunk_cap * 8, (size_t)w.chunk_cap * 4, (size_t)contacts * 4, ((size_t)kMaxTetLevels + 1) * 4, (size_t)contacts * 4, (size_t)s->n * 4,
+		(size_t)w.node_cap * 16, (size_t)w.node_cap * 8, (size_t)w.node_cap * 4, (size_t)w.node_cap * 8 };
+	for (int q = 0; q < 15; q++) if (bytes[q]) HIPCHECK(hipMalloc(&s->tet_work_alloc[q], bytes[q]));
+	w.front[0] = (uint32_t *)s->tet_work_alloc[0]; w.front[1] = nullptr; w.pair_ik = (uint32_t *)s->tet_work_alloc[2];
+	w.chunk_off = (uint32_t *)s->tet_work_alloc[3]; w.chunk_pair = (uint32_t *)s->tet_work_alloc[4]; w.chunk_mask = (unsigned long long *)s->tet_work_alloc[5];
+	w.chunk_base = (uint32_t *)s->tet_work_alloc[6]; w.order = (uint32_t *)s->tet_work_alloc[7]; w.level_start = (uint32_t *)s->tet_work_alloc[8];
+	w.level_of = (uint32_t *)s->tet_work_alloc[9]; w.owner = (uint32_t *)s->tet_work_alloc[10];
+	w.node_rec = (unsigned long long *)s->tet_work_alloc[11]; w.node_cnt = (unsigned long long *)s->tet_work_alloc[12]; w.node_child = (uint32_t *)s->tet_work_alloc[13]; w.node_off = (unsigned long long *)s->tet_work_alloc[14];
+	w.counters = s->d_tet_counters;
+	return PBDX_OK;
+}
+
+
+int launch_tet_detection(pbdx_solver *s)
 {
 	if (!s->tet_active() || !s->n) return PBDX_OK;
 	const P4 *pos = reinterpret_cast<const P4 *>(s->d_pos[0]);
@@ -1795,7 +1836,7 @@ int enqueue_tet_detection(pbdx_solver *s)
 			hipLaunchKernelGGL(tet_hull_kernel, dim3((v.tet_bvh.num_nodes + 255) / 256), dim3(256), 0, s->stream, views, c, pos, 1);
 		}
 		hipLaunchKernelGGL(tet_aabb_kernel, dim3(nc), dim3(256), 0, s->stream, views, pos, s->d_tet_aabb);
-		hipLaunchKernelGGL(tet_detect_kernel, dim3(1), dim3(64), 0, s->stream, views, nc, pos, rest, (const float *)s->d_tet_aabb, s->d_tet_contacts, s->d_tet_counters);
+		hipLaunchKernelGGL(tet_detect_kernel, dim3(1), dim3(64), 0, s->stream, views, nc, pos, rest, (const float *)s->d_tet_aabb, s->d_tet_contacts, s->d_tet_counters, s->tet_work.max_contacts);
 	}
 	else
 	{
@@ -1834,6 +1875,35 @@ int enqueue_tet_detection(pbdx_solver *s)
 		s->tet_timed(6, [&] { hipLaunchKernelGGL(tet_levels_kernel, dim3(1), dim3(1024), 0, s->stream, (const TetContact *)s->d_tet_contacts, s->tet_work); });
 	}
 	HIPCHECK(hipGetLastError());
+	return PBDX_OK;
+}
+
+// The detection's scratch (node pairs of the traversal, overlapping leaf pairs, candidate chunks, the contact list) has capacities; the
+// reference's vectors have none.  The kernels check every capacity and flag an overflow instead of writing; the flags are read back
+// after EVERY detection (one small synchronisation per step, for scenes with deformable colliders only), the exhausted buffer is made
+// four times as large and the detection -- which only reads the particle state -- is repeated.  What cannot be grown away (an abandoned
+// barrier, more than 256 generations / 4096 levels, the address space of 32-bit indices) stays flagged and is reported by the step.
+int enqueue_tet_detection(pbdx_solver *s)
+{
+	if (!s->tet_active() || !s->n) return PBDX_OK;
+	for (int attempt = 0; attempt < 8; attempt++)
+	{
+		int r = launch_tet_detection(s);
+		if (r) return r;
+		uint32_t c[kTcWords];
+		HIPCHECK(hipMemcpyAsync(c, s->d_tet_counters, sizeof(c), hipMemcpyDeviceToHost, s->stream));
+		HIPCHECK(hipStreamSynchronize(s->stream));
+		const bool more_nodes = c[kTcStack] == 1u || c[kTcStack] == 4u || (s->tet_serial && c[kTcStack]);
+		const bool more_contacts = c[kTcOverflow] == 1u;
+		if (!more_nodes && !more_contacts) return PBDX_OK;
+		const uint64_t nodes = more_nodes ? (uint64_t)s->tet_work.node_cap * 4u : s->tet_work.node_cap;
+		const uint64_t contacts = more_contacts ? (uint64_t)s->tet_work.max_contacts * 4u : s->tet_work.max_contacts;
+		if (nodes > (1ull << 29) || contacts > (1ull << 24) || (s->tet_serial && more_nodes)) return PBDX_OK;      // reported by the step
+		s->tet_grown++;
+		r = alloc_tet_work(s, nodes, (uint32_t)contacts);
+		if (r) return r;
+		HIPCHECK(hipMemsetAsync(s->d_tet_counters, 0, kTcWords * sizeof(uint32_t), s->stream));
+	}
 	return PBDX_OK;
 }
 
@@ -2467,8 +2537,12 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		if (c[kTcOverflow] || c[kTcStack])
 		{
 			(void)hipMemset(s->d_tet_counters, 0, kTcWords * sizeof(uint32_t));
-			set_error(c[kTcOverflow] ? "more than %u contacts between solids in one step (or more than 4096 dependent contacts at one particle)" :
-				"the traversal of the bounding-sphere hierarchies exceeded the engine's capacity (%u overlapping leaf pairs, 2^22 node pairs, 2^21 candidate chunks, 256 levels; serial form: stack of 128)", c[kTcOverflow] ? kMaxTetContacts : s->tet_work.front_cap);
+			if (getenv("PBDX_TET_PROFILE"))
+				fprintf(stderr, "[pbdx tet] detection failed: flag %u (1 node pairs, 2 barrier abandoned, 3 generations, 4 leaf pairs / chunks); generations %u, node pairs %u of %u, leaf pairs %u of %u, chunks %u of %u\n",
+					c[kTcStack], c[kTcGenerations], c[kTcTreeNodes], s->tet_work.node_cap, c[kTcLeafPairs], s->tet_work.front_cap, c[kTcChunks], s->tet_work.chunk_cap);
+			set_error(c[kTcOverflow] ? "contacts between solids: more than %u contacts in one step, or more than 4096 dependent contacts at one particle" :
+				"contacts between solids: the traversal of the bounding-sphere hierarchies could not be completed (more than %u node pairs, more than 256 levels of the recursion, or a workgroup that never arrived at a barrier; serial form: stack of 128)",
+				c[kTcOverflow] ? s->tet_work.max_contacts : s->tet_work.node_cap);
 			return PBDX_ERR_UNSUPPORTED;
 		}
 	}
@@ -2713,28 +2787,33 @@ int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 	HIPCHECK(hipMalloc(&s->d_tet_views, (size_t)n * sizeof(TetColliderView)));
 	HIPCHECK(hipMemcpy(s->d_tet_views, s->tet_views.data(), (size_t)n * sizeof(TetColliderView), hipMemcpyHostToDevice));
 	HIPCHECK(hipMalloc(&s->d_tet_aabb, (size_t)6 * n * sizeof(float)));
-	if (!s->d_tet_contacts) HIPCHECK(hipMalloc(&s->d_tet_contacts, (size_t)kMaxTetContacts * sizeof(TetContact)));
 	if (!s->d_tet_counters) HIPCHECK(hipMalloc(&s->d_tet_counters, kTcWords * sizeof(uint32_t)));
 	HIPCHECK(hipMemset(s->d_tet_counters, 0, kTcWords * sizeof(uint32_t)));      // no contacts before the first detection
 	{
-		// scratch of the parallel detection / levelling (pbdx_tetcontact_dev.h); capacities are checked on the device and reported
-		TetWork &w = s->tet_work;
-		w.front_cap = std::max<uint32_t>(1u << 20, n * n);
-		w.chunk_cap = 1u << 21;
-		w.node_cap = 1u << 22;
-		HIPCHECK(hipMalloc(&s->tet_work_alloc[15], kTrWords * sizeof(uint32_t)));
-		w.trav = (uint32_t *)s->tet_work_alloc[15];
-		const size_t bytes[15] = { (size_t)3 * w.front_cap * 4, 0, (size_t)2 * n * n * 4, ((size_t)w.front_cap + 1) * 4, (size_t)w.chunk_cap * 4,
-			(size_t)w.chunk_cap * 8, (size_t)w.chunk_cap * 4, (size_t)kMaxTetContacts * 4, ((size_t)kMaxTetLevels + 1) * 4, (size_t)kMaxTetContacts * 4, (size_t)s->n * 4,
-			(size_t)w.node_cap * 16, (size_t)w.node_cap * 8, (size_t)w.node_cap * 4, (size_t)w.node_cap * 8 };
-		for (int q = 0; q < 15; q++) if (bytes[q]) HIPCHECK(hipMalloc(&s->tet_work_alloc[q], bytes[q]));
-		w.front[0] = (uint32_t *)s->tet_work_alloc[0]; w.front[1] = nullptr; w.pair_ik = (uint32_t *)s->tet_work_alloc[2];
-		w.chunk_off = (uint32_t *)s->tet_work_alloc[3]; w.chunk_pair = (uint32_t *)s->tet_work_alloc[4]; w.chunk_mask = (unsigned long long *)s->tet_work_alloc[5];
-		w.chunk_base = (uint32_t *)s->tet_work_alloc[6]; w.order = (uint32_t *)s->tet_work_alloc[7]; w.level_start = (uint32_t *)s->tet_work_alloc[8];
-		w.level_of = (uint32_t *)s->tet_work_alloc[9]; w.owner = (uint32_t *)s->tet_work_alloc[10];
-		w.node_rec = (unsigned long long *)s->tet_work_alloc[11]; w.node_cnt = (unsigned long long *)s->tet_work_alloc[12]; w.node_child = (uint32_t *)s->tet_work_alloc[13]; w.node_off = (unsigned long long *)s->tet_work_alloc[14];
-		w.counters = s->d_tet_counters;
+		// sized by the scene to begin with: the 2 x 81920-tet scene of the tests walks 0.71 M node pairs for 14 k overlapping leaf pairs
+		// (4.3 per tet) -- and 50 M when the bars are pushed far into each other: the scratch grows on demand (enqueue_tet_detection)
+		uint64_t total_tets = 0;
+		for (uint32_t i = 0; i < n; i++) total_tets += colliders[i].num_tets;
+		s->tet_num_colliders = n;
+		// (PBDX_TET_SCRATCH="nodes,contacts": developer aid, lets a test start from capacities that must grow)
+		uint64_t nodes0 = std::min<uint64_t>((1ull << 22) + 32ull * total_tets, 1ull << 27);
+		uint32_t contacts0 = kTetContactsAtFirst;
+		if (const char *e = getenv("PBDX_TET_SCRATCH"))
+		{
+			unsigned long long a = 0; unsigned b = 0;
+			if (sscanf(e, "%llu,%u", &a, &b) == 2 && a >= 64 && b >= 1) { nodes0 = a; contacts0 = b; }
+		}
+		s->tet_grown = 0;
+		int r = alloc_tet_work(s, nodes0, contacts0);
+		if (r) return r;
 	}
+	return PBDX_OK;
+}
+
+int pbdx_debug_tet_capacity(pbdx_solver *s, uint32_t out[4])
+{
+	if (!s || !out) return PBDX_ERR_INVALID;
+	out[0] = s->tet_work.node_cap; out[1] = s->tet_work.front_cap; out[2] = s->tet_work.max_contacts; out[3] = s->tet_grown;
 	return PBDX_OK;
 }
 

@@ -33,7 +33,7 @@
 
 namespace pbdx {
 
-constexpr uint32_t kMaxTetContacts = 1u << 16;
+constexpr uint32_t kTetContactsAtFirst = 1u << 16;      // capacities grow on demand (grow_tet_work in pbdx_solver.hip)
 constexpr uint32_t kMaxTetLevels = 4096;
 constexpr uint32_t kTcFinal = 0x80000000u;
 enum { kTcCount = 0, kTcOverflow = 1, kTcStack = 2, kTcLeafPairs = 3, kTcChunks = 4, kTcLevels = 5, kTcGenerations = 6, kTcTreeNodes = 7, kTcWords = 8 };
@@ -57,6 +57,7 @@ struct TetWork                    // device scratch of the detection; *_cap are 
 	unsigned long long *chunk_mask; // per chunk: which of its candidates are contacts
 	uint32_t *chunk_base;         // per chunk: number of its contacts, then (scanned) the index of its first contact
 	uint32_t chunk_cap;
+	uint32_t max_contacts;        // capacity of the contact list, `order` and `level_of`
 	uint32_t *order;              // contact indices grouped by level
 	uint32_t *level_start;        // kMaxTetLevels + 1
 	uint32_t *level_of;           // per contact
@@ -470,7 +471,8 @@ __global__ __launch_bounds__(256) void tet_traverse_kernel(const TetColliderView
 	const uint32_t bad = ld_agent(&trav[kTrBad]);
 	if (bad || (generations >= kTcMaxGenerations && gstart[generations + 1] != gstart[generations]))
 	{
-		if (gtid == 0) w.counters[kTcStack] = 1u;
+		// kTcStack: 1 node pairs, 2 a barrier was abandoned, 3 generations, 4 leaf pairs / chunks
+		if (gtid == 0) { w.counters[kTcStack] = bad ? bad : 3u; w.counters[kTcGenerations] = generations; w.counters[kTcTreeNodes] = gstart[generations + 1]; }
 		return;
 	}
 	// bottom-up: leaf pairs and candidate chunks below every node (the two halves never carry into each other: both are bounded by capacities)
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(256) void tet_traverse_kernel(const TetColliderView
 	const uint32_t leaves = ld_agent(&trav[kTrLeaves]), chunks = ld_agent(&trav[kTrChunks]);
 	if (leaves > w.front_cap || chunks > w.chunk_cap)
 	{
-		if (gtid == 0) w.counters[kTcStack] = 1u;
+		if (gtid == 0) { w.counters[kTcStack] = 4u; w.counters[kTcGenerations] = generations; w.counters[kTcTreeNodes] = gstart[generations]; w.counters[kTcLeafPairs] = leaves; w.counters[kTcChunks] = chunks; }
 		return;
 	}
 	for (uint32_t g = 0; g < generations; g++)
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256) void tet_candidates_kernel(const TetColliderVi
 		else if (hit)
 		{
 			const uint32_t at = w.chunk_base[q] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-			if (at < kMaxTetContacts) contacts[at] = c;
+			if (at < w.max_contacts) contacts[at] = c;
 		}
 	}
 }
@@ -597,8 +599,8 @@ __global__ __launch_bounds__(1024) void tet_chunk_scan_kernel(TetWork w)
 	}
 	if (threadIdx.x == 0)
 	{
-		w.counters[kTcCount] = base < kMaxTetContacts ? base : kMaxTetContacts;
-		if (base > kMaxTetContacts) w.counters[kTcOverflow] = 1u;
+		w.counters[kTcCount] = base < w.max_contacts ? base : w.max_contacts;
+		if (base > w.max_contacts) w.counters[kTcOverflow] = 1u;          // 1: the list is full, 2: more than kMaxTetLevels levels
 	}
 }
 
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(1024) void tet_levels_kernel(const TetContact *cont
 	{
 		w.level_start[level] = done;
 		w.counters[kTcLevels] = level;
-		if (done < n) w.counters[kTcOverflow] = 1u;
+		if (done < n) w.counters[kTcOverflow] = 2u;
 	}
 }
 

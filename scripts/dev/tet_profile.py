@@ -19,7 +19,16 @@ lib.pbdx_timestep_hip_step_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_uint
 model = ref.model_ptr()
 assert lib.pbdx_timestep_hip_step_resident(ts, model, 1) == 0
 t0 = time.perf_counter()
-assert lib.pbdx_timestep_hip_step_resident(ts, model, steps - 1) == 0
+if os.environ.get("PBDX_TET_STEPWISE"):
+    c = (C.c_uint32 * 8)()
+    for k in range(steps - 1):
+        rc = lib.pbdx_timestep_hip_step_resident(ts, model, 1)
+        _ffi.check(_ffi.lib.pbdx_debug_tet_counters(sol, c), "counters")
+        print("step %d rc %d: contacts %d flags %d %d leaf pairs %d chunks %d levels %d generations %d tree nodes %d" % (k + 2, rc, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]))
+        if rc:
+            break
+else:
+    assert lib.pbdx_timestep_hip_step_resident(ts, model, steps - 1) == 0
 print("ms/step (profiling syncs included): %.3f" % ((time.perf_counter() - t0) * 1e3 / (steps - 1)))
 c = (C.c_uint32 * 8)()
 _ffi.check(_ffi.lib.pbdx_debug_tet_counters(sol, c), "counters")

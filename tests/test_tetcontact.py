@@ -199,6 +199,39 @@ def test_plugin_three_stacked_solids_bit_exact(serial):
 
 
 @pytest.mark.gpu
+def test_detection_scratch_grows_on_demand(monkeypatch):
+    """The reference's vectors have no capacity; the engine's buffers start small here (64 node pairs, 4 contacts) and must grow,
+    in the middle of a run, without a trace in the result."""
+    if not os.path.exists(PLUGIN):
+        pytest.skip("plug-in not built")
+    monkeypatch.setenv("PBDX_TET_SCRATCH", "64,4")
+    ref = _ref()
+    steps = 70
+    tcu.two_bar_scene(ref)
+    ref.set_params(1, 5, 0)
+    ref.step(steps)
+    x_cpu, v_cpu, c_cpu = ref.positions().copy(), ref.get_array(2).copy(), tcu.oracle_contacts_as_engine_records(ref)
+    tcu.two_bar_scene(ref)
+    assert ref.install_timestep_plugin(PLUGIN) == 0
+    ref.lib.refdrv_attach_collision_detection()
+    ref.set_params(1, 5, 0)
+    lib, ts = _plugin_handles(ref)
+    lib.pbdx_timestep_hip_step_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    lib.pbdx_timestep_hip_sync_to_host.argtypes = [C.c_void_p, C.c_void_p]
+    model = ref.model_ptr()
+    assert lib.pbdx_timestep_hip_step_resident(ts, model, steps) == 0        # ONE call: the growth happens between its steps
+    assert lib.pbdx_timestep_hip_sync_to_host(ts, model) == 0
+    cap = (C.c_uint32 * 4)()
+    _ffi.check(_ffi.lib.pbdx_debug_tet_capacity(C.c_void_p(lib.pbdx_timestep_hip_solver(ts)), cap), "capacity")
+    got = _device_contacts(lib, ts)
+    x, v = ref.positions().copy(), ref.get_array(2).copy()
+    ref.reset_all()
+    assert cap[3] >= 2 and cap[0] > 64 and cap[2] > 4, list(cap)
+    assert len(got) == len(c_cpu) and (not len(got) or util.bitwise_equal(got[:, :26], c_cpu))
+    assert util.bitwise_equal(x, x_cpu) and util.bitwise_equal(v, v_cpu)
+
+
+@pytest.mark.gpu
 def test_c_abi_without_the_plugin_two_bars_bit_exact():
     """The same scene through the package's own model mirror and the raw solver calls (pbdx_solver_set_rest_positions /
     set_tet_colliders / get_tet_contacts): what a host application that is not the reference would do -- it brings its own
