@@ -1807,10 +1807,10 @@ int alloc_tet_work(pbdx_solver *s, uint64_t nodes, uint32_t contacts)
 	HIPCHECK(hipMalloc(&s->tet_work_alloc[15], kTrWords * sizeof(uint32_t)));
 	w.trav = (uint32_t *)s->tet_work_alloc[15];
 	const size_t bytes[15] = { (size_t)3 * w.front_cap * 4, 0, (size_t)2 * n * n * 4, ((size_t)w.front_cap + 1) * 4, (size_t)w.chunk_cap * 4,
-		(size_t)w.chunk_cap * 8, (size_t)w.chunk_cap * 4, (size_t)contacts * 4, ((size_t)kMaxTetLevels + 1) * 4, (size_t)contacts * 4, (size_t)s->n * 4,
+		(size_t)w.chunk_cap * 8, (size_t)w.chunk_cap * 4, (size_t)contacts * 4, ((size_t)contacts + 1) * 4, (size_t)contacts * 4, (size_t)s->n * 4,
 		(size_t)w.node_cap * 16, (size_t)w.node_cap * 8, (size_t)w.node_cap * 4, (size_t)w.node_cap * 8 };
 	for (int q = 0; q < 15; q++) if (bytes[q]) HIPCHECK(hipMalloc(&s->tet_work_alloc[q], bytes[q]));
-	w.front[0] = (uint32_t *)s->tet_work_alloc[0]; w.front[1] = nullptr; w.pair_ik = (uint32_t *)s->tet_work_alloc[2];
+	w.leaf_pairs = (uint32_t *)s->tet_work_alloc[0]; w.pair_ik = (uint32_t *)s->tet_work_alloc[2];
 	w.chunk_off = (uint32_t *)s->tet_work_alloc[3]; w.chunk_pair = (uint32_t *)s->tet_work_alloc[4]; w.chunk_mask = (unsigned long long *)s->tet_work_alloc[5];
 	w.chunk_base = (uint32_t *)s->tet_work_alloc[6]; w.order = (uint32_t *)s->tet_work_alloc[7]; w.level_start = (uint32_t *)s->tet_work_alloc[8];
 	w.level_of = (uint32_t *)s->tet_work_alloc[9]; w.owner = (uint32_t *)s->tet_work_alloc[10];
@@ -1882,7 +1882,7 @@ int launch_tet_detection(pbdx_solver *s)
 // reference's vectors have none.  The kernels check every capacity and flag an overflow instead of writing; the flags are read back
 // after EVERY detection (one small synchronisation per step, for scenes with deformable colliders only), the exhausted buffer is made
 // four times as large and the detection -- which only reads the particle state -- is repeated.  What cannot be grown away (an abandoned
-// barrier, more than 256 generations / 4096 levels, the address space of 32-bit indices) stays flagged and is reported by the step.
+// barrier, more than 256 generations of the recursion, the address space of 32-bit indices) stays flagged and is reported by the step.
 int enqueue_tet_detection(pbdx_solver *s)
 {
 	if (!s->tet_active() || !s->n) return PBDX_OK;
@@ -2115,7 +2115,7 @@ void pbdx_solver_destroy(pbdx_solver *s)
 	s->free_batches();
 	if (s->tet_profile && s->tet_launches[0])
 	{
-		static const char *names[8] = { "spheres", "boxes", "traverse", "candidates (ballot)", "chunk scan", "candidates (write)", "levels", "solve (per iteration)" };
+		static const char *names[8] = { "spheres + boxes", "-", "traverse", "candidates (ballot)", "chunk scan", "candidates (write)", "levels", "solve (per iteration)" };
 		for (int q = 0; q < 8; q++)
 			fprintf(stderr, "[pbdx tet profile] %-22s %8llu launches  %10.3f ms total  %8.4f ms each\n", names[q], (unsigned long long)s->tet_launches[q], s->tet_ms[q], s->tet_launches[q] ? s->tet_ms[q] / s->tet_launches[q] : 0.0);
 	}
@@ -2540,7 +2540,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 			if (getenv("PBDX_TET_PROFILE"))
 				fprintf(stderr, "[pbdx tet] detection failed: flag %u (1 node pairs, 2 barrier abandoned, 3 generations, 4 leaf pairs / chunks); generations %u, node pairs %u of %u, leaf pairs %u of %u, chunks %u of %u\n",
 					c[kTcStack], c[kTcGenerations], c[kTcTreeNodes], s->tet_work.node_cap, c[kTcLeafPairs], s->tet_work.front_cap, c[kTcChunks], s->tet_work.chunk_cap);
-			set_error(c[kTcOverflow] ? "contacts between solids: more than %u contacts in one step, or more than 4096 dependent contacts at one particle" :
+			set_error(c[kTcOverflow] ? "contacts between solids: more than %u contacts in one step" :
 				"contacts between solids: the traversal of the bounding-sphere hierarchies could not be completed (more than %u node pairs, more than 256 levels of the recursion, or a workgroup that never arrived at a barrier; serial form: stack of 128)",
 				c[kTcOverflow] ? s->tet_work.max_contacts : s->tet_work.node_cap);
 			return PBDX_ERR_UNSUPPORTED;

@@ -34,14 +34,12 @@
 namespace pbdx {
 
 constexpr uint32_t kTetContactsAtFirst = 1u << 16;      // capacities grow on demand (grow_tet_work in pbdx_solver.hip)
-constexpr uint32_t kMaxTetLevels = 4096;
-constexpr uint32_t kTcFinal = 0x80000000u;
 enum { kTcCount = 0, kTcOverflow = 1, kTcStack = 2, kTcLeafPairs = 3, kTcChunks = 4, kTcLevels = 5, kTcGenerations = 6, kTcTreeNodes = 7, kTcWords = 8 };
 
 struct TetWork                    // device scratch of the detection; *_cap are capacities in elements
 {
-	uint32_t *front[2];           // [0]: the overlapping leaf pairs in the reference's visiting order, 3 words each: collider pair | kTcFinal, node
-	                              // of the point hierarchy, node of the tet hierarchy ([1] unused)
+	uint32_t *leaf_pairs;         // the overlapping leaf pairs in the reference's visiting order, 3 words each: collider pair, node of the
+	                              // point hierarchy, node of the tet hierarchy
 	uint32_t front_cap;
 	// recursion tree of the traversal, generation after generation.  Written and read by different workgroups (= CUs, XCDs) of ONE launch:
 	// every access is a relaxed agent-scope atomic (an sc1 load / store: served past the CU's L1, written through), 8 bytes at most
@@ -59,7 +57,7 @@ struct TetWork                    // device scratch of the detection; *_cap are 
 	uint32_t chunk_cap;
 	uint32_t max_contacts;        // capacity of the contact list, `order` and `level_of`
 	uint32_t *order;              // contact indices grouped by level
-	uint32_t *level_start;        // kMaxTetLevels + 1
+	uint32_t *level_start;        // max_contacts + 1 (a level holds at least one contact)
 	uint32_t *level_of;           // per contact
 	uint32_t *owner;              // per particle: first unscheduled contact that touches it (written and read at the L2: the minima are atomics)
 	uint32_t *counters;           // kTcWords
@@ -526,7 +524,7 @@ __global__ __launch_bounds__(256) void tet_traverse_kernel(const TetColliderView
 				{
 					const unsigned long long r0 = ld_agent(&w.node_rec[2 * idx]), r1 = ld_agent(&w.node_rec[2 * idx + 1]);
 					const uint32_t at = (uint32_t)off, chunk0 = (uint32_t)(off >> 32), nchunks = (uint32_t)(cnt >> 32);
-					w.front[0][3 * at] = (uint32_t)r0 | kTcFinal; w.front[0][3 * at + 1] = (uint32_t)(r0 >> 32); w.front[0][3 * at + 2] = (uint32_t)r1;
+					w.leaf_pairs[3 * at] = (uint32_t)r0; w.leaf_pairs[3 * at + 1] = (uint32_t)(r0 >> 32); w.leaf_pairs[3 * at + 2] = (uint32_t)r1;
 					w.chunk_off[at] = chunk0;
 					for (uint32_t j = 0; j < nchunks; j++) w.chunk_pair[chunk0 + j] = at;
 				}
@@ -561,7 +559,7 @@ __global__ __launch_bounds__(256) void tet_candidates_kernel(const TetColliderVi
 			if (!mask) continue;
 		}
 		const uint32_t e = w.chunk_pair[q];
-		const uint32_t p = w.front[0][3 * e] & ~kTcFinal, a = w.front[0][3 * e + 1], b = w.front[0][3 * e + 2];
+		const uint32_t p = w.leaf_pairs[3 * e], a = w.leaf_pairs[3 * e + 1], b = w.leaf_pairs[3 * e + 2];
 		const TetColliderView &co1 = views[w.pair_ik[2 * p]], &co2 = views[w.pair_ik[2 * p + 1]];
 		const uint32_t beg1 = (uint32_t)co1.points.nodes[4 * a + 2], n1 = (uint32_t)co1.points.nodes[4 * a + 3];
 		const uint32_t beg2 = (uint32_t)co2.tet_bvh.nodes[4 * b + 2], n2 = (uint32_t)co2.tet_bvh.nodes[4 * b + 3];
@@ -600,7 +598,7 @@ __global__ __launch_bounds__(1024) void tet_chunk_scan_kernel(TetWork w)
 	if (threadIdx.x == 0)
 	{
 		w.counters[kTcCount] = base < w.max_contacts ? base : w.max_contacts;
-		if (base > w.max_contacts) w.counters[kTcOverflow] = 1u;          // 1: the list is full, 2: more than kMaxTetLevels levels
+		if (base > w.max_contacts) w.counters[kTcOverflow] = 1u;          // the list is full
 	}
 }
 
@@ -612,7 +610,7 @@ __global__ __launch_bounds__(1024) void tet_levels_kernel(const TetContact *cont
 	const uint32_t tid = threadIdx.x;
 	for (uint32_t c = tid; c < n; c += 1024) w.level_of[c] = 0xffffffffu;
 	uint32_t done = 0, level = 0;
-	while (done < n && level < kMaxTetLevels)
+	while (done < n && level < w.max_contacts)
 	{
 		__syncthreads();
 		for (uint32_t c = tid; c < n; c += 1024)
@@ -657,7 +655,7 @@ __global__ __launch_bounds__(1024) void tet_levels_kernel(const TetContact *cont
 	{
 		w.level_start[level] = done;
 		w.counters[kTcLevels] = level;
-		if (done < n) w.counters[kTcOverflow] = 2u;
+		if (done < n) w.counters[kTcOverflow] = 2u;                 // cannot happen: every round schedules the first unscheduled contact
 	}
 }
 
