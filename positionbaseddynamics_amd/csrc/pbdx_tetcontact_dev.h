@@ -33,7 +33,7 @@
 
 namespace pbdx {
 
-constexpr uint32_t kTetContactsAtFirst = 1u << 16;      // capacities grow on demand (grow_tet_work in pbdx_solver.hip)
+constexpr uint32_t kTetContactsAtFirst = 1u << 16;      // capacities grow on demand (enqueue_tet_detection / alloc_tet_work in pbdx_solver.hip)
 enum { kTcCount = 0, kTcOverflow = 1, kTcStack = 2, kTcLeafPairs = 3, kTcChunks = 4, kTcLevels = 5, kTcGenerations = 6, kTcTreeNodes = 7, kTcWords = 8 };
 
 struct TetWork                    // device scratch of the detection; *_cap are capacities in elements
@@ -113,11 +113,11 @@ __global__ __launch_bounds__(256) void tet_gather_kernel(const TetColliderView *
 // PointCloudBSH / TetMeshBSH::compute_hull_approx (hull_points / hull_tets of pbdx_tetcontact.h: same operations in the same order).
 // The running sum is three dependent chains (x, y, z) of n additions each; nothing but the latency of a dependent v_add_f32 can bound a
 // chain, so each chain gets a wavefront (= a SIMD) of its own and nothing else to issue: a workgroup of four wavefronts per node stages
-// 256 vertices at a time in LDS as three component arrays (coalesced load, prefetched one stage ahead, double-buffered: one barrier per
+// 256 vertices at a time in LDS as three component arrays (coalesced load, prefetched six stages ahead, double-buffered: one barrier per
 // stage), wavefront c < 3 then runs component c's chain over the stage, four values per (broadcast) LDS read, the reads of the next 32
 // values issued before the additions of the current 32.  Padding a stage with +0 is exact: a running sum that starts at +0 is never -0.
 // (Measured on the 81920-tet root, 327680 vertices per component: one wavefront for all three chains, operands by v_readlane 7.7 ms,
-// by v_add_f32_dpp wave_shr:1 3.2 ms, by LDS broadcast 5.3 ms; this form: see DESIGN.md.)
+// by v_add_f32_dpp wave_shr:1 3.2 ms, by LDS broadcast 5.3 ms; this form 1.0 ms, a chain in registers alone 0.58 ms: scripts/microbench/chain.hip.)
 // The LDS reads of a chain are issued by hand (the compiler waits for ALL outstanding LDS reads before the first addition of a batch,
 // which leaves the chain idle for the LDS round trip 8 times per stage): ds_read_b128 by inline asm, which the compiler's wait-count
 // insertion does not see, and the waits as asm statements that "rewrite" the batch's registers, so that no addition can be moved
