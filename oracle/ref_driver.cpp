@@ -566,6 +566,51 @@ int refdrv_add_tet_collision_box(unsigned tetModel, const double *box, int testM
 		mesh.getTets().data(), mesh.numTets(), cd().getTolerance());
 	return (int)index;
 }
+// the same with any of the analytic shapes (0 box, 1 sphere, 2 torus, 3 cylinder, 4 hollow sphere, 5 hollow box; p as in refdrv_add_static_collider)
+int refdrv_add_tet_collision_shape(unsigned tetModel, int shape, const double *p, int testMesh, int invertSDF, double restitution, double friction)
+{
+	SimulationModel *m = model();
+	if (tetModel >= m->getTetModels().size()) return -1;
+	TetModel *tm = m->getTetModels()[tetModel];
+	tm->setRestitutionCoeff((Real)restitution);
+	tm->setFrictionCoeff((Real)friction);
+	ParticleData &pd = m->getParticles();
+	const unsigned int offset = tm->getIndexOffset();
+	const Utilities::IndexedTetMesh &mesh = tm->getParticleMesh();
+	const Vector3r *verts = &pd.getPosition(offset);
+	const unsigned int nv = mesh.numVertices();
+	const unsigned int T = CollisionDetection::CollisionObject::TetModelCollisionObjectType;
+	switch (shape)
+	{
+	case 0: cd().addCollisionBox(tetModel, T, verts, nv, Vector3r((Real)p[0], (Real)p[1], (Real)p[2]), testMesh != 0, invertSDF != 0); break;
+	case 1: cd().addCollisionSphere(tetModel, T, verts, nv, (Real)p[0], testMesh != 0, invertSDF != 0); break;
+	case 2: cd().addCollisionTorus(tetModel, T, verts, nv, Vector2r((Real)p[0], (Real)p[1]), testMesh != 0, invertSDF != 0); break;
+	case 3: cd().addCollisionCylinder(tetModel, T, verts, nv, Vector2r((Real)p[0], (Real)p[1]), testMesh != 0, invertSDF != 0); break;
+	case 4: cd().addCollisionHollowSphere(tetModel, T, verts, nv, (Real)p[0], (Real)p[1], testMesh != 0, invertSDF != 0); break;
+	case 5: cd().addCollisionHollowBox(tetModel, T, verts, nv, Vector3r((Real)p[0], (Real)p[1], (Real)p[2]), (Real)p[3], testMesh != 0, invertSDF != 0); break;
+	default: return -1;
+	}
+	const unsigned int index = (unsigned int)cd().getCollisionObjects().size() - 1;
+	((DistanceFieldCollisionDetection::DistanceFieldCollisionObject*)cd().getCollisionObjects()[index])->initTetBVH(verts, nv, mesh.getTets().data(), mesh.numTets(), cd().getTolerance());
+	return (int)index;
+}
+// what a collision object stores about its distance field: shape id as above (-1: none / unknown), invertSDF, the members the field is evaluated from
+int refdrv_get_collision_object_shape(unsigned co, int *invert, double *p)
+{
+	typedef DistanceFieldCollisionDetection D;
+	if (co >= cd().getCollisionObjects().size()) return -1;
+	CollisionDetection::CollisionObject *o = cd().getCollisionObjects()[co];
+	const int t = o->getTypeId();
+	for (int k = 0; k < 4; k++) p[k] = 0.0;
+	*invert = ((D::DistanceFieldCollisionObject*)o)->m_invertSDF < 0 ? 1 : 0;
+	if (t == D::DistanceFieldCollisionBox::TYPE_ID) { for (int k = 0; k < 3; k++) p[k] = (double)((D::DistanceFieldCollisionBox*)o)->m_box[k]; return 0; }
+	if (t == D::DistanceFieldCollisionSphere::TYPE_ID) { p[0] = (double)((D::DistanceFieldCollisionSphere*)o)->m_radius; return 1; }
+	if (t == D::DistanceFieldCollisionTorus::TYPE_ID) { p[0] = (double)((D::DistanceFieldCollisionTorus*)o)->m_radii[0]; p[1] = (double)((D::DistanceFieldCollisionTorus*)o)->m_radii[1]; return 2; }
+	if (t == D::DistanceFieldCollisionCylinder::TYPE_ID) { p[0] = (double)((D::DistanceFieldCollisionCylinder*)o)->m_dim[0]; p[1] = (double)((D::DistanceFieldCollisionCylinder*)o)->m_dim[1]; return 3; }
+	if (t == D::DistanceFieldCollisionHollowSphere::TYPE_ID) { p[0] = (double)((D::DistanceFieldCollisionHollowSphere*)o)->m_radius; p[1] = (double)((D::DistanceFieldCollisionHollowSphere*)o)->m_thickness; return 4; }
+	if (t == D::DistanceFieldCollisionHollowBox::TYPE_ID) { for (int k = 0; k < 3; k++) p[k] = (double)((D::DistanceFieldCollisionHollowBox*)o)->m_box[k]; p[3] = (double)((D::DistanceFieldCollisionHollowBox*)o)->m_thickness; return 5; }
+	return -1;
+}
 void refdrv_set_tet_model_initial_transform(unsigned tetModel, const double *x, const double *R /*row-major*/)
 {
 	TetModel *tm = model()->getTetModels()[tetModel];

@@ -336,6 +336,22 @@ class Ref:
         self._tet_boxes[int(tet_model)] = b.copy()
         return self.lib.refdrv_add_tet_collision_box(int(tet_model), _dp(b), int(bool(test_mesh)), float(restitution), float(friction))
 
+    def add_tet_collision_shape(self, tet_model, shape, params, test_mesh=True, invert=False, restitution=0.6, friction=0.0):
+        """shape: 0 box (full side lengths), 1 sphere (radius), 2 torus (radii), 3 cylinder (radius, height), 4 hollow sphere (radius,
+        thickness), 5 hollow box (full side lengths, thickness) -- the arguments of DistanceFieldCollisionDetection::addCollision*."""
+        self.lib.refdrv_add_tet_collision_shape.argtypes = [_u, _i, _pd, _i, _i, _d, _d]
+        p = np.zeros(4, dtype=np.float64)
+        p[:len(params)] = params
+        return self.lib.refdrv_add_tet_collision_shape(int(tet_model), int(shape), _dp(p), int(bool(test_mesh)), int(bool(invert)), float(restitution), float(friction))
+
+    def collision_object_shape(self, co):
+        """(shape id, invert, params[4]) as the collision object STORES them (half extents for boxes, ...): what a binding hands to the engine"""
+        self.lib.refdrv_get_collision_object_shape.argtypes = [_u, C.POINTER(C.c_int), _pd]
+        inv = C.c_int(0)
+        p = np.zeros(4, dtype=np.float64)
+        shape = self.lib.refdrv_get_collision_object_shape(int(co), C.byref(inv), _dp(p))
+        return shape, inv.value, p
+
     def set_tet_model_initial_transform(self, tet_model, x, R=None):
         self.lib.refdrv_set_tet_model_initial_transform.argtypes = [_u, _pd, _pd]
         xx = np.ascontiguousarray(x, dtype=np.float64)

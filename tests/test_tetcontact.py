@@ -70,6 +70,37 @@ def test_engine_detection_on_host_three_solids_pair_order():
     assert total > 500 and solids_seen == {0, 1, 2}
 
 
+SHAPE_CASES = {
+    "sphere": [(1, (0.6,), False)] * 2,
+    "hollow_box": [(5, (2.0, 0.5, 0.5, 0.1), False)] * 2,
+    "hollow_sphere": [(4, (0.7, 0.3), False)] * 2,
+    "cylinder": [(3, (0.8, 0.5), False)] * 2,
+    "torus": [(2, (0.6, 0.25), False)] * 2,
+    "inverted_sphere": [(1, (0.2,), True)] * 2,
+    "box_and_sphere": [(0, (2.0, 0.5, 0.5), False), (1, (0.6,), False)],
+}
+
+
+@pytest.mark.parametrize("case", sorted(SHAPE_CASES))
+def test_engine_detection_on_host_other_distance_fields(case):
+    """Every analytic distance field of the reference in a tet model's rest frame (and the inverted form)."""
+    ref = _ref()
+    objs = tcu.two_bar_scene_shapes(ref, SHAPE_CASES[case])
+    ref.set_params(1, 5, 0)
+    cols = tcu.TetColliders(ref, objs, (0, 1), 0.01)
+    total = 0
+    for step in range(100):
+        ref.step(1)
+        want = tcu.oracle_contacts_as_engine_records(ref)
+        got = tcu.host_contacts(ref, cols)
+        assert len(got) == len(want), "step %d: %d contacts, reference %d" % (step, len(got), len(want))
+        if len(want):
+            assert util.bitwise_equal(got[:, :26], want), "step %d" % step
+        total += len(want)
+    ref.reset_all()
+    assert total > 10
+
+
 def test_set_tet_colliders_validates_before_touching_the_device():
     """Argument checks come first, so they are testable without a GPU: friction and malformed hierarchies are refused."""
     ref = _ref()
@@ -163,6 +194,32 @@ def test_plugin_two_colliding_bars_bit_exact(solid_method, sub_steps, dims, seri
     assert lib.pbdx_timestep_hip_gpu_steps(ts) == steps
     print("\n[tet contacts] dims %s method %d substeps %d serial %d: %d contacts over %d steps, %d at the last" % (dims, solid_method, sub_steps, serial, seen, steps, len(cpu[steps][2])))
     ref.reset_all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["hollow_box", "cylinder", "inverted_sphere", "box_and_sphere"])
+def test_plugin_other_distance_fields_bit_exact(case):
+    if not os.path.exists(PLUGIN):
+        pytest.skip("plug-in not built")
+    ref = _ref()
+    steps = 100
+    tcu.two_bar_scene_shapes(ref, SHAPE_CASES[case])
+    ref.set_params(1, 5, 0)
+    ref.step(steps)
+    x_cpu, v_cpu, c_cpu = ref.positions().copy(), ref.get_array(2).copy(), tcu.oracle_contacts_as_engine_records(ref)
+    tcu.two_bar_scene_shapes(ref, SHAPE_CASES[case])
+    assert ref.install_timestep_plugin(PLUGIN) == 0
+    ref.lib.refdrv_attach_collision_detection()
+    ref.set_params(1, 5, 0)
+    lib, ts = _plugin_handles(ref)
+    ref.step(steps)
+    assert lib.pbdx_timestep_hip_failed_steps(ts) == 0 and lib.pbdx_timestep_hip_gpu_steps(ts) == steps
+    got = _device_contacts(lib, ts)
+    x, v = ref.positions().copy(), ref.get_array(2).copy()
+    ref.reset_all()
+    assert len(got) == len(c_cpu) and (not len(got) or util.bitwise_equal(got[:, :26], c_cpu))
+    assert util.bitwise_equal(x, x_cpu), "max err %.3e" % util.max_err(x, x_cpu)
+    assert util.bitwise_equal(v, v_cpu)
 
 
 @pytest.mark.gpu

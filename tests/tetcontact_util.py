@@ -62,6 +62,31 @@ def stacked_bars_scene(ref, n_bars=3, solid_method=6, tolerance=0.01, dims=DIMS)
     return objs
 
 
+def two_bar_scene_shapes(ref, shapes, solid_method=6, tolerance=0.01, dims=DIMS, t_upper=T_UPPER):
+    """two_bar_scene with other analytic distance fields in the bars' rest frames: shapes = [(shape id, params, invert)] * 2.  The field
+    need not look like the mesh: a contact is "a particle of the other solid, inside one of my tets, at a point of my rest shape where
+    my field is negative"."""
+    ref.reset_all()
+    ref.set_num_threads(1)
+    ref.set_time_step_size(0.005)
+    ref.set_gravity((0, -9.81, 0))
+    ref.add_regular_tet_model(*dims, T_LOWER, None, SCALE)
+    ref.add_regular_tet_model(*dims, t_upper, None, SCALE)
+    w, h, d = dims
+    for j in range(h):
+        for k in range(d):
+            ref.set_mass(j * d + k, 0.0)
+            ref.set_mass(((w - 1) * h + j) * d + k, 0.0)
+    for tm in (0, 1):
+        ref.add_solid_constraints(tm, solid_method, 1e5 if solid_method in (3, 6) else 1.0, 0.3, 1e5 if solid_method == 6 else 1.0, False, False)
+    ref.set_collision_tolerance(tolerance)
+    ref.set_tet_model_initial_transform(0, T_LOWER)
+    ref.set_tet_model_initial_transform(1, t_upper)
+    objs = [ref.add_tet_collision_shape(tm, sh[0], sh[1], True, sh[2], 0.6, 0.0) for tm, sh in zip((0, 1), shapes)]
+    ref.attach_collision_detection()
+    return objs
+
+
 class TetColliders:
     """pbdx_tet_collider array built from the oracle's collision objects; keeps the numpy arrays alive."""
 
@@ -74,10 +99,11 @@ class TetColliders:
         for q, (co, tm) in enumerate(zip(objs, tet_models)):
             info = ref.tet_model_info(tm)
             c = self.arr[q]
-            c.shape, c.invert = 0, 0
-            box = np.asarray(info["box"], dtype=np.float32)
-            for k in range(3):
-                c.params[k] = np.float32(0.5) * box[k]           # m_box = 0.5 * box (DistanceFieldCollisionDetection.cpp:502)
+            shape, invert, params = ref.collision_object_shape(co)     # as stored: m_box = 0.5 * box (DistanceFieldCollisionDetection.cpp:502), ...
+            assert shape >= 0
+            c.shape, c.invert = shape, invert
+            for k in range(4):
+                c.params[k] = params[k]
             c.first_particle, c.num_vertices, c.num_tets = info["offset"], info["num_vertices"], info["num_tets"]
             tets = np.ascontiguousarray(info["tets"], dtype=np.uint32)
             self.keep.append(tets)
