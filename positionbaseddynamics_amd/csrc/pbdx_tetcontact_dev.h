@@ -603,11 +603,63 @@ __global__ __launch_bounds__(1024) void tet_chunk_scan_kernel(TetWork w)
 }
 
 // ---- levels: order-preserving decomposition of the sequential solve into sets of contacts on disjoint particles ----------------------
+// Up to kTcSmallList contacts (one per thread) the rounds run out of LDS: the particles get slots of a hash table, the "first unscheduled
+// contact at each particle" is an LDS atomic instead of a round trip to the L2 per round (20 rounds: 0.18 ms -> see DESIGN.md).
+constexpr uint32_t kTcSmallList = 1024;
+constexpr uint32_t kTcHashSlots = 8192;           // >= 5 * kTcSmallList / 0.63
 __global__ __launch_bounds__(1024) void tet_levels_kernel(const TetContact *contacts, TetWork w)
 {
 	__shared__ uint32_t lds[65];
+	__shared__ uint32_t h_key[kTcHashSlots], h_owner[kTcHashSlots];
 	const uint32_t n = w.counters[kTcCount];
 	const uint32_t tid = threadIdx.x;
+	if (n <= kTcSmallList)
+	{
+		for (uint32_t q = tid; q < kTcHashSlots; q += 1024) h_key[q] = 0xffffffffu;
+		__syncthreads();
+		uint32_t slot[5];
+		const bool mine = tid < n;
+		if (mine)
+		{
+			const TetContact &k = contacts[tid];
+			const uint32_t ids[5] = { k.particle, k.vert[0], k.vert[1], k.vert[2], k.vert[3] };
+			for (int j = 0; j < 5; j++)
+			{
+				uint32_t h = (ids[j] * 2654435761u) >> 19;          // 13 bits
+				while (true)
+				{
+					const uint32_t old = atomicCAS(&h_key[h], 0xffffffffu, ids[j]);
+					if (old == 0xffffffffu || old == ids[j]) break;
+					h = (h + 1u) & (kTcHashSlots - 1u);
+				}
+				slot[j] = h;
+			}
+		}
+		bool scheduled = !mine;
+		uint32_t done = 0, level = 0;
+		while (done < n)
+		{
+			__syncthreads();
+			if (!scheduled) for (int j = 0; j < 5; j++) h_owner[slot[j]] = 0xffffffffu;
+			__syncthreads();
+			if (!scheduled) for (int j = 0; j < 5; j++) atomicMin(&h_owner[slot[j]], tid);
+			__syncthreads();
+			uint32_t ready = 0;
+			if (!scheduled)
+			{
+				ready = 1u;
+				for (int j = 0; j < 5; j++) if (h_owner[slot[j]] != tid) ready = 0u;
+			}
+			uint32_t total;
+			const uint32_t at = done + block_exclusive_scan(ready, lds, total);
+			if (ready) { w.order[at] = tid; w.level_of[tid] = level; scheduled = true; }
+			if (tid == 0) w.level_start[level] = done;
+			done += total;
+			level++;
+		}
+		if (tid == 0) { w.level_start[level] = done; w.counters[kTcLevels] = level; }
+		return;
+	}
 	for (uint32_t c = tid; c < n; c += 1024) w.level_of[c] = 0xffffffffu;
 	uint32_t done = 0, level = 0;
 	while (done < n && level < w.max_contacts)
@@ -668,8 +720,24 @@ struct TetPosAccess
 };
 __global__ __launch_bounds__(1024) void tet_contact_solve_levels_kernel(float4 *pos, const TetContact *contacts, TetWork w)
 {
+	__shared__ uint32_t s_start[kTcSmallList + 2];
 	TetPosAccess acc = { pos };
 	const uint32_t levels = w.counters[kTcLevels];
+	const uint32_t n = w.counters[kTcCount];
+	if (n <= kTcSmallList)
+	{
+		// one contact per thread, fetched before the first level: a level then costs one round trip for the particle's position
+		for (uint32_t l = threadIdx.x; l <= levels; l += 1024) s_start[l] = w.level_start[l];
+		TetContact mine;
+		if (threadIdx.x < n) mine = contacts[w.order[threadIdx.x]];
+		__syncthreads();
+		for (uint32_t l = 0; l < levels; l++)
+		{
+			if (threadIdx.x >= s_start[l] && threadIdx.x < s_start[l + 1]) tet_contact_position_solve(mine, acc);
+			__syncthreads();
+		}
+		return;
+	}
 	for (uint32_t l = 0; l < levels; l++)
 	{
 		const uint32_t end = w.level_start[l + 1];
