@@ -998,7 +998,7 @@ struct pbdx_solver
 	uint64_t contact_version = 0;
 
 	// contacts between deformable solids (pbdx_tetcontact.h)
-	struct DevBvh { uint32_t *lst = nullptr; int32_t *nodes = nullptr; P4 *hulls = nullptr; uint32_t num_nodes = 0; uint32_t *flat = nullptr; P4 *gathered = nullptr; };
+	struct DevBvh { uint32_t *lst = nullptr; int32_t *nodes = nullptr; P4 *hulls = nullptr; uint32_t num_nodes = 0; uint32_t *flat = nullptr; P4 *gathered = nullptr; float *soa = nullptr; };
 	struct DevTetCollider { uint32_t *tets = nullptr; DevBvh points, tet_bvh, tet_bvh0; uint32_t max_nodes = 0; };
 	std::vector<DevTetCollider> tet_dev;
 	std::vector<TetColliderView> tet_views;       // host copy of the device views
@@ -1041,6 +1041,7 @@ struct pbdx_solver
 				if (b->hulls) (void)hipFree(b->hulls);
 				if (b->flat) (void)hipFree(b->flat);
 				if (b->gathered) (void)hipFree(b->gathered);
+				if (b->soa) (void)hipFree(b->soa);
 			}
 		}
 		tet_dev.clear(); tet_views.clear();
@@ -1852,12 +1853,12 @@ int launch_tet_detection(pbdx_solver *s)
 			const bool fork = s->tet_big_count != 0;
 			hipStream_t side = fork ? s->stream_side : s->stream;
 			if (fork) { (void)hipEventRecord(s->ev_fork, s->stream); (void)hipStreamWaitEvent(side, s->ev_fork, 0); }
-			hipLaunchKernelGGL(tet_hull_kernel2, dim3(max_nodes, 2 * nc), dim3(256), 0, side, views, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+			hipLaunchKernelGGL(tet_hull_kernel2, dim3(max_nodes, 2 * nc), dim3(192), 0, side, views, (const uint32_t *)nullptr, (uint32_t *)nullptr);
 			hipLaunchKernelGGL(tet_aabb_kernel, dim3(nc), dim3(256), 0, side, views, pos, s->d_tet_aabb);
 			if (fork)
 			{
 				(void)hipEventRecord(s->ev_join, side);
-				hipLaunchKernelGGL(tet_hull_kernel2, dim3(s->tet_big_count), dim3(256), kTcBigNodeLds, s->stream, views, (const uint32_t *)s->d_tet_big, s->d_tet_big_r2);
+				hipLaunchKernelGGL(tet_hull_kernel2, dim3(s->tet_big_count), dim3(192), kTcBigNodeLds, s->stream, views, (const uint32_t *)s->d_tet_big, s->d_tet_big_r2);
 				hipLaunchKernelGGL(tet_big_radius_kernel, dim3(s->tet_big_slices), dim3(256), 0, s->stream, views, (const uint32_t *)s->d_tet_big, (const uint32_t *)s->d_tet_big_slices, s->d_tet_big_r2);
 				hipLaunchKernelGGL(tet_big_finish_kernel, dim3((s->tet_big_count + 255) / 256), dim3(256), 0, s->stream, views, (const uint32_t *)s->d_tet_big, s->tet_big_count, (const uint32_t *)s->d_tet_big_r2);
 				(void)hipStreamWaitEvent(s->stream, s->ev_join, 0);
@@ -2739,7 +2740,7 @@ int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 			if (q == 2) HIPCHECK(hipMemcpy(dst[q]->hulls, src[q]->hulls, (size_t)src[q]->num_nodes * sizeof(P4), hipMemcpyHostToDevice));
 			else HIPCHECK(hipMemset(dst[q]->hulls, 0, (size_t)src[q]->num_nodes * sizeof(P4)));
 			dst[q]->num_nodes = src[q]->num_nodes;
-			*view[q] = BvhView{ dst[q]->lst, dst[q]->nodes, dst[q]->hulls, dst[q]->num_nodes, nullptr, nullptr, 0 };
+			*view[q] = BvhView{ dst[q]->lst, dst[q]->nodes, dst[q]->hulls, dst[q]->num_nodes, nullptr, nullptr, nullptr, 0, 0 };
 			if (q < 2)
 			{
 				// the entities' vertices in list order (static), and room for their positions (gathered every step)
@@ -2749,7 +2750,8 @@ int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 					for (uint32_t k = 0; k < per; k++) flat[(size_t)per * e + k] = q == 0 ? src[q]->entities[e] : c.tets[4 * src[q]->entities[e] + k];
 				HIPCHECK(up(&dst[q]->flat, flat.data(), flat.size()));
 				HIPCHECK(hipMalloc(&dst[q]->gathered, flat.size() * sizeof(P4)));
-				view[q]->flat = dst[q]->flat; view[q]->gathered = dst[q]->gathered; view[q]->per_entity = per;
+				HIPCHECK(hipMalloc(&dst[q]->soa, 3 * flat.size() * sizeof(float)));
+				view[q]->flat = dst[q]->flat; view[q]->gathered = dst[q]->gathered; view[q]->soa = dst[q]->soa; view[q]->per_entity = per; view[q]->num_elements = (uint32_t)flat.size();
 			}
 		}
 	}

@@ -39,7 +39,8 @@ struct BvhView
 	// indices (static) and as positions (gathered every step), so that a node's sums run over a contiguous range
 	const uint32_t *flat;
 	P4 *gathered;
-	uint32_t per_entity;
+	float *soa;                   // the same positions as three component arrays of num_elements floats each (x, y, z)
+	uint32_t per_entity, num_elements;
 };
 
 struct TetColliderView

@@ -23,8 +23,8 @@
 //   spheres    KDTree::update recomputes every node's sphere from ITS OWN entity range: the centre is a float sum in list order -- a
 //              dependent chain of n additions per component, 327680 for the root of an 81920-tet hierarchy, and the critical path
 //              of the whole detection.  The vertices are gathered into list order first (tet_gather_kernel), so a node reads a
-//              contiguous range; a workgroup per node, one wavefront per component's chain (tet_hull_kernel2).  The radius is a
-//              maximum (order-free, parallel).
+//              contiguous range; one wavefront per node and component, whose lanes hold the values in their own registers and take
+//              turns at the running sum (tet_hull_kernel2).  The radius is a maximum (order-free, parallel).
 #ifndef PBDX_TETCONTACT_DEV_H
 #define PBDX_TETCONTACT_DEV_H
 
@@ -108,84 +108,65 @@ __global__ __launch_bounds__(256) void tet_gather_kernel(const TetColliderView *
 	const BvhView &b = (blockIdx.y & 1u) ? v.tet_bvh : v.points;
 	const uint32_t total = (blockIdx.y & 1u) ? 4u * v.num_tets : v.num_vertices;
 	const uint32_t e = blockIdx.x * 256u + threadIdx.x;
-	if (e < total) b.gathered[e] = pos[v.first + b.flat[e]];
+	if (e < total)
+	{
+		const P4 p = pos[v.first + b.flat[e]];
+		b.gathered[e] = p;
+		b.soa[e] = p.x; b.soa[(size_t)total + e] = p.y; b.soa[2 * (size_t)total + e] = p.z;
+	}
 }
 // PointCloudBSH / TetMeshBSH::compute_hull_approx (hull_points / hull_tets of pbdx_tetcontact.h: same operations in the same order).
 // The running sum is three dependent chains (x, y, z) of n additions each; nothing but the latency of a dependent v_add_f32 can bound a
-// chain, so each chain gets a wavefront (= a SIMD) of its own and nothing else to issue: a workgroup of four wavefronts per node stages
-// 256 vertices at a time in LDS as three component arrays (coalesced load, prefetched six stages ahead, double-buffered: one barrier per
-// stage), wavefront c < 3 then runs component c's chain over the stage, four values per (broadcast) LDS read, the reads of the next 32
-// values issued before the additions of the current 32.  Padding a stage with +0 is exact: a running sum that starts at +0 is never -0.
-// (Measured on the 81920-tet root, 327680 vertices per component: one wavefront for all three chains, operands by v_readlane 7.7 ms,
-// by v_add_f32_dpp wave_shr:1 3.2 ms, by LDS broadcast 5.3 ms; this form 1.0 ms, a chain in registers alone 0.58 ms: scripts/microbench/chain.hip.)
-// The LDS reads of a chain are issued by hand (the compiler waits for ALL outstanding LDS reads before the first addition of a batch,
-// which leaves the chain idle for the LDS round trip 8 times per stage): ds_read_b128 by inline asm, which the compiler's wait-count
-// insertion does not see, and the waits as asm statements that "rewrite" the batch's registers, so that no addition can be moved
-// above its wait and the registers stay reserved while the data is in flight.  LDS returns in order: with the next batch's 8 reads
-// issued behind it, a batch has arrived when at most 8 reads are outstanding.
-typedef float f4v __attribute__((ext_vector_type(4)));
-template <int OFF> __device__ __forceinline__ void lds_read16(f4v &d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
-template <int BATCH> __device__ __forceinline__ void lds_read_batch(f4v (&v)[8], uint32_t addr)
+// chain (1.75 ns on this GPU), so each chain gets a wavefront (= a SIMD) of its own -- and no instruction besides the additions:
+// every LANE loads B consecutive values of its chain into its own registers (64 B values per chunk, one load instruction per 64 values),
+// and the running sum visits the lanes in turn: all lanes execute `acc += v[0..B)`, then acc moves one lane up (v_mov_b32_dpp
+// wave_ror:1).  After turn t lane t + 1 holds the sum through lane t's values and adds its own in the next turn; what the other lanes
+// compute meanwhile is never looked at.  After 64 turns lane 0 holds the sum through the chunk and starts the next one.
+// A partial last chunk is padded with +0, which is exact: a running sum that starts at +0 is never -0.
+// (Measured on the 81920-tet root, 327680 values per component: operands by v_readlane 7.7 ms, by v_add_f32_dpp wave_shr:1 through the
+// lanes -- a DPP add issues at under half rate -- 3.2 ms, by LDS broadcast read 5.3 / 1.0 ms (compiler- / hand-placed waits, staged by
+// the fourth wavefront), this form: scripts/microbench/chain.hip variant G)
+template <int B> __device__ __forceinline__ float chain_turns(float acc, const float (&v)[32])
 {
-	lds_read16<128 * BATCH + 0>(v[0], addr); lds_read16<128 * BATCH + 16>(v[1], addr); lds_read16<128 * BATCH + 32>(v[2], addr); lds_read16<128 * BATCH + 48>(v[3], addr);
-	lds_read16<128 * BATCH + 64>(v[4], addr); lds_read16<128 * BATCH + 80>(v[5], addr); lds_read16<128 * BATCH + 96>(v[6], addr); lds_read16<128 * BATCH + 112>(v[7], addr);
+	for (int t = 0; t < 64; t++)
+	{
+#pragma unroll
+		for (int k = 0; k < B; k++) acc += v[k];
+		acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x13C /* wave_ror:1 */, 0xf, 0xf, false));
+	}
+	return acc;
 }
-__device__ __forceinline__ void lds_wait_8_outstanding(f4v (&v)[8])
-{
-	asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-}
-__device__ __forceinline__ void lds_wait_all(f4v (&v)[8])
-{
-	asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-}
-__device__ __forceinline__ void chain_32(float &acc, const f4v (&v)[8])
+template <int B> __device__ __forceinline__ void chain_fetch(float (&v)[32], const float *g, uint32_t first, uint32_t m)
 {
 #pragma unroll
-	for (int q = 0; q < 8; q++) { acc += v[q].x; acc += v[q].y; acc += v[q].z; acc += v[q].w; }
+	for (int k = 0; k < B; k++) { const uint32_t e = first + (uint32_t)k; v[k] = e < m ? g[e] : 0.0f; }
 }
-// `batches` x 32 values at LDS address `addr` (1 .. 8; the waits are explicit, so the early exits cost nothing)
-__device__ __forceinline__ void chain_stage(float &acc, uint32_t addr, uint32_t batches)
+// the sum of g[0 .. m) in index order, in every lane
+template <int B> __device__ __forceinline__ float chain_sum(const float *g, uint32_t m)
 {
-	if (batches < 8u)
+	const uint32_t lane = threadIdx.x & 63u;
+	float v[32], nx[32];
+	chain_fetch<B>(v, g, lane * B, m);
+	float acc = 0.0f;
+	for (uint32_t c0 = 0; c0 < m; c0 += 64u * B)
 	{
-		f4v a[8];
-		lds_read_batch<0>(a, addr); lds_wait_all(a); chain_32(acc, a);
-		if (batches < 2u) return;
-		lds_read_batch<1>(a, addr); lds_wait_all(a); chain_32(acc, a);
-		if (batches < 3u) return;
-		lds_read_batch<2>(a, addr); lds_wait_all(a); chain_32(acc, a);
-		if (batches < 4u) return;
-		lds_read_batch<3>(a, addr); lds_wait_all(a); chain_32(acc, a);
-		if (batches < 5u) return;
-		lds_read_batch<4>(a, addr); lds_wait_all(a); chain_32(acc, a);
-		if (batches < 6u) return;
-		lds_read_batch<5>(a, addr); lds_wait_all(a); chain_32(acc, a);
-		if (batches < 7u) return;
-		lds_read_batch<6>(a, addr); lds_wait_all(a); chain_32(acc, a);
-		return;
+		chain_fetch<B>(nx, g, c0 + 64u * B + lane * B, m);
+		acc = chain_turns<B>(acc, v);
+#pragma unroll
+		for (int k = 0; k < B; k++) v[k] = nx[k];
 	}
-	f4v a[8], b[8];
-	lds_read_batch<0>(a, addr);
-	lds_read_batch<1>(b, addr); lds_wait_8_outstanding(a); chain_32(acc, a);
-	lds_read_batch<2>(a, addr); lds_wait_8_outstanding(b); chain_32(acc, b);
-	lds_read_batch<3>(b, addr); lds_wait_8_outstanding(a); chain_32(acc, a);
-	lds_read_batch<4>(a, addr); lds_wait_8_outstanding(b); chain_32(acc, b);
-	lds_read_batch<5>(b, addr); lds_wait_8_outstanding(a); chain_32(acc, a);
-	lds_read_batch<6>(a, addr); lds_wait_8_outstanding(b); chain_32(acc, b);
-	lds_read_batch<7>(b, addr); lds_wait_8_outstanding(a); chain_32(acc, a);
-	lds_wait_all(b); chain_32(acc, b);
+	return lane_value(acc, 0);
 }
 // The long chains are the critical path, and a chain that shares its SIMD with other wavefronts' chains runs at a fraction of its speed:
 // the nodes with at least kTcBigNode vertices (a static list: `big`, 2 words each: collider * 2 + hierarchy, node) go first, in a launch
 // that asks for so much LDS that a CU takes one workgroup; everything else follows in a second launch (big == nullptr;
-// grid: (max over colliders of nodes, 2 * colliders)).
+// grid: (max over colliders of nodes, 2 * colliders)).  Workgroup = 3 wavefronts = the 3 components.
 constexpr uint32_t kTcBigNode = 8192;
 constexpr uint32_t kTcBigNodeLds = 96 * 1024;
-__global__ __launch_bounds__(256) void tet_hull_kernel2(const TetColliderView *views, const uint32_t *big, uint32_t *big_r2)
+__global__ __launch_bounds__(192) void tet_hull_kernel2(const TetColliderView *views, const uint32_t *big, uint32_t *big_r2)
 {
-	__shared__ __attribute__((aligned(16))) float comp[2][3][256];
 	__shared__ float s_sum[3];
-	__shared__ float s_max[4];
+	__shared__ float s_max[3];
 	const uint32_t which = big ? big[2 * blockIdx.x] : blockIdx.y;
 	const uint32_t node = big ? big[2 * blockIdx.x + 1] : blockIdx.x;
 	const TetColliderView &v = views[which >> 1];
@@ -196,45 +177,22 @@ __global__ __launch_bounds__(256) void tet_hull_kernel2(const TetColliderView *v
 	const uint32_t n = (uint32_t)b.nodes[4 * node + 3];
 	const uint32_t m = n * b.per_entity;
 	if (!big && m >= kTcBigNode) return;
-	const float4 *g = reinterpret_cast<const float4 *>(b.gathered) + (size_t)(uint32_t)b.nodes[4 * node + 2] * b.per_entity;
-	const uint32_t stages = (m + 255u) / 256u;
-	auto fetch = [&](uint32_t st) { float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f); const uint32_t e = st * 256u + tid; if (e < m) p = g[e]; return p; };
-	constexpr int kAhead = 6;          // stages in flight: a stage's chain is ~0.5 us, a load from HBM comes back in ~1-2 us
-	float4 cur[kAhead];
-#pragma unroll
-	for (int d = 0; d < kAhead; d++) cur[d] = fetch((uint32_t)d);
-	float acc = 0.0f;
-	for (uint32_t st0 = 0; st0 < stages; st0 += kAhead)
-	{
-#pragma unroll
-		for (int d = 0; d < kAhead; d++)
-		{
-			const uint32_t st = st0 + (uint32_t)d;
-			if (st >= stages) break;
-			const uint32_t buf = st & 1u;
-			comp[buf][0][tid] = cur[d].x; comp[buf][1][tid] = cur[d].y; comp[buf][2][tid] = cur[d].z;
-			cur[d] = fetch(st + kAhead);
-			__syncthreads();
-			if (wave < 3u)
-			{
-				// the stage, padded with +0 to a multiple of 32 values
-				const uint32_t left = m - st * 256u;
-				chain_stage(acc, (uint32_t)(uintptr_t)&comp[buf][wave][0], left >= 256u ? 8u : (left + 31u) / 32u);
-			}
-		}
-	}
-	if (wave < 3u && lane == 0) s_sum[wave] = acc;
+	const size_t first = (size_t)(uint32_t)b.nodes[4 * node + 2] * b.per_entity;
+	const float *gc = b.soa + (size_t)wave * b.num_elements + first;
+	const float sum = m <= 64u ? chain_sum<1>(gc, m) : m <= 256u ? chain_sum<4>(gc, m) : chain_sum<32>(gc, m);
+	if (lane == 0) s_sum[wave] = sum;
 	__syncthreads();
 	V3 x = mk(s_sum[0], s_sum[1], s_sum[2]);
 	x = tets ? x / (4.0f * (float)n) : x / (float)n;
 	if (big)
 	{
-		// the radius of a long node is a maximum over megabytes: not for four wavefronts (tet_big_radius_kernel)
+		// the radius of a long node is a maximum over megabytes: not for three wavefronts (tet_big_radius_kernel)
 		if (tid == 0) { P4 h; h.x = x.x; h.y = x.y; h.z = x.z; h.w = 0.0f; b.hulls[node] = h; big_r2[blockIdx.x] = 0u; }
 		return;
 	}
+	const float4 *g = reinterpret_cast<const float4 *>(b.gathered) + first;
 	float radius2 = 0.0f;
-	for (uint32_t e = tid; e < m; e += 256)
+	for (uint32_t e = tid; e < m; e += 192)
 	{
 		const float4 q = g[e];
 		const float d = sqn(x - mk(q.x, q.y, q.z));
@@ -245,7 +203,7 @@ __global__ __launch_bounds__(256) void tet_hull_kernel2(const TetColliderView *v
 	__syncthreads();
 	if (tid == 0)
 	{
-		for (int q = 1; q < 4; q++) radius2 = (radius2 < s_max[q]) ? s_max[q] : radius2;
+		for (int q = 1; q < 3; q++) radius2 = (radius2 < s_max[q]) ? s_max[q] : radius2;
 		P4 h; h.x = x.x; h.y = x.y; h.z = x.z;
 		h.w = tets ? (float)(sqrt((double)radius2) + (double)v.tolerance) : sqrtf(radius2);
 		b.hulls[node] = h;

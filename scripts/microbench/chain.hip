@@ -1,6 +1,8 @@
 // Developer microbenchmark: what bounds ONE sequential float sum of N values on a CU?  (the centre of the root's bounding sphere,
 // pbdx_tetcontact_dev.h).  Variants: A registers only; B LDS reads, compiler-placed waits; C LDS reads by hand, counted waits;
-// D = C on one lane; E = C + a workgroup barrier and restaging per 256 values; F = E + global loads (the kernel's pattern).
+// D = C on one lane; E = C + a workgroup barrier and restaging per 256 values; F = E + global loads;
+// G every lane holds 32 consecutive values in its own registers, the running sum visits the lanes in turn (64 turns of 32 additions,
+// v_mov_b32_dpp wave_ror:1 between turns): no operand instruction per value at all (the kernel's form).
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -o chain chain.hip && ./chain
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -26,7 +28,17 @@ __device__ __forceinline__ void stage_hand(float &acc, uint32_t addr)
 	rb<5>(b, addr); w8(a); c32(acc, a); rb<6>(a, addr); w8(b); c32(acc, b);
 	rb<7>(b, addr); w8(a); c32(acc, a); w0(b); c32(acc, b);
 }
-// mode 0: A, 1: B, 2: C, 3: D, 4: E, 5: F
+__device__ __forceinline__ float turn_chunk(float acc, const float (&v)[32])
+{
+	for (int t = 0; t < 64; t++)
+	{
+#pragma unroll
+		for (int k = 0; k < 32; k++) acc += v[k];
+		acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x13C, 0xf, 0xf, false));
+	}
+	return acc;
+}
+// mode 0: A, 1: B, 2: C, 3: D, 4: E, 5: F, 6: G
 __global__ __launch_bounds__(256) void k(const float4 *g, float *out, int stages, int mode)
 {
 	__shared__ __attribute__((aligned(16))) float comp[2][3][256];
@@ -51,6 +63,21 @@ __global__ __launch_bounds__(256) void k(const float4 *g, float *out, int stages
 	}
 	else if (mode == 2) { if (wave < 3) for (int st = 0; st < stages; st++) stage_hand(acc, (uint32_t)(uintptr_t)&comp[st & 1][wave][0]); }
 	else if (mode == 3) { if (wave < 3 && lane == 0) for (int st = 0; st < stages; st++) stage_hand(acc, (uint32_t)(uintptr_t)&comp[st & 1][wave][0]); }
+	else if (mode == 6)
+	{
+		if (wave < 3)
+		{
+			const float *gc = (const float *)g + (size_t)wave * stages * 256;      // component arrays
+			float v[32], nx[32];
+			for (int k = 0; k < 32; k++) v[k] = gc[lane * 32 + k];
+			for (int c = 0; c < stages / 8; c++)                                   // 2048 values per chunk
+			{
+				for (int k = 0; k < 32; k++) nx[k] = gc[(size_t)(c + 1) * 2048 + lane * 32 + k];
+				acc = turn_chunk(acc, v);
+				for (int k = 0; k < 32; k++) v[k] = nx[k];
+			}
+		}
+	}
 	else
 	{
 		for (int st0 = 0; st0 < stages; st0 += 6)
@@ -72,10 +99,10 @@ int main()
 	const int stages = 1280;      // 327680 values per chain
 	float4 *g; float *out;
 	hipMalloc(&g, (size_t)(stages + 8) * 256 * sizeof(float4)); hipMemset(g, 0, (size_t)(stages + 8) * 256 * sizeof(float4)); hipMalloc(&out, 4096);
-	const char *names[6] = { "A registers only", "B LDS, compiler waits", "C LDS by hand, counted waits", "D = C on one lane", "E = C + barrier + restage", "F = E + global loads" };
+	const char *names[7] = { "A registers only", "B LDS, compiler waits", "C LDS by hand, counted waits", "D = C on one lane", "E = C + barrier + restage", "F = E + global loads", "G lanes in turn, own registers" };
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
 	for (int blocks : { 1, 256 })
-		for (int mode = 0; mode < 6; mode++)
+		for (int mode = 0; mode < 7; mode++)
 		{
 			hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, g, out, 16, mode);
 			hipEventRecord(e0);
