@@ -1012,6 +1012,7 @@ struct pbdx_solver
 	void *tet_work_alloc[16] = {};
 	int tet_serial = 0;                            // PBDX_OPT_TET_CONTACTS_SERIAL
 	uint32_t tet_grown = 0;                        // times the detection's scratch was enlarged
+	bool tet_plain_chains = getenv("PBDX_TET_PLAIN_CHAINS") != nullptr;   // developer aid: long sphere sums by the plain chain instead of run by run
 	uint32_t tet_num_colliders = 0;
 	// developer aid (PBDX_TET_PROFILE=1, hipGraph off): wall time per kernel of the contact path, printed when the solver is destroyed
 	bool tet_profile = getenv("PBDX_TET_PROFILE") != nullptr;
@@ -1858,7 +1859,10 @@ int launch_tet_detection(pbdx_solver *s)
 			if (fork)
 			{
 				(void)hipEventRecord(s->ev_join, side);
-				hipLaunchKernelGGL(tet_hull_kernel2, dim3(s->tet_big_count), dim3(192), kTcBigNodeLds, s->stream, views, (const uint32_t *)s->d_tet_big, s->d_tet_big_r2);
+				if (s->tet_plain_chains)
+					hipLaunchKernelGGL(tet_hull_kernel2, dim3(s->tet_big_count), dim3(192), kTcBigNodeLds, s->stream, views, (const uint32_t *)s->d_tet_big, s->d_tet_big_r2);
+				else
+					hipLaunchKernelGGL(tet_big_sum_kernel, dim3(3 * s->tet_big_count), dim3(1024), 0, s->stream, views, (const uint32_t *)s->d_tet_big, s->d_tet_big_r2);
 				hipLaunchKernelGGL(tet_big_radius_kernel, dim3(s->tet_big_slices), dim3(256), 0, s->stream, views, (const uint32_t *)s->d_tet_big, (const uint32_t *)s->d_tet_big_slices, s->d_tet_big_r2);
 				hipLaunchKernelGGL(tet_big_finish_kernel, dim3((s->tet_big_count + 255) / 256), dim3(256), 0, s->stream, views, (const uint32_t *)s->d_tet_big, s->tet_big_count, (const uint32_t *)s->d_tet_big_r2);
 				(void)hipStreamWaitEvent(s->stream, s->ev_join, 0);
@@ -2809,6 +2813,22 @@ int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 		int r = alloc_tet_work(s, nodes0, contacts0);
 		if (r) return r;
 	}
+	return PBDX_OK;
+}
+
+int pbdx_debug_chain_sum(pbdx_solver *s, const float *x, uint32_t n, float *out)
+{
+	if (!s || !out || (n && !x)) return PBDX_ERR_INVALID;
+	HIPCHECK(hipSetDevice(s->device));
+	float *d = nullptr, *r = nullptr;
+	HIPCHECK(hipMalloc(&d, (size_t)std::max<uint32_t>(n, 1u) * sizeof(float)));
+	HIPCHECK(hipMalloc(&r, sizeof(float)));
+	if (n) HIPCHECK(hipMemcpy(d, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(chain_sum_debug_kernel, dim3(1), dim3(1024), 0, s->stream, (const float *)d, n, r);
+	HIPCHECK(hipGetLastError());
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	HIPCHECK(hipMemcpy(out, r, sizeof(float), hipMemcpyDeviceToHost));
+	(void)hipFree(d); (void)hipFree(r);
 	return PBDX_OK;
 }
 

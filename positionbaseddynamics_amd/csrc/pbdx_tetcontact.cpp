@@ -2,6 +2,7 @@
 // device runs (pbdx_tetcontact.h is host + device), so that the detection can be pinned against the reference without a GPU.
 #include "pbdx_internal.h"
 #include "pbdx_tetcontact.h"
+#include "pbdx_chainsum.h"
 #include <string.h>
 #include <vector>
 
@@ -87,5 +88,16 @@ extern "C" int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, 
 		}
 	*count = found;
 	if (!ok) { set_error("debug_tet_contacts: traversal stack overflow"); return PBDX_ERR_INVALID; }
+	return PBDX_OK;
+}
+
+// the sequential float sum two ways on the host (tests/test_chainsum.py): the plain loop and the run-by-run evaluation of pbdx_chainsum.h
+extern "C" int pbdx_debug_chain_sum_host(const float *x, uint64_t n, uint32_t threads, uint32_t per_thread, float *blocked, float *plain, uint64_t *single_additions)
+{
+	if (!x || !blocked || !plain || !threads || !per_thread) return PBDX_ERR_INVALID;
+	volatile float s = 0.0f;                        // volatile: every partial sum is rounded to float, whatever the host compiler would like
+	for (uint64_t i = 0; i < n; i++) s = s + x[i];
+	*plain = s;
+	*blocked = pbdx::cs_sum_blocked_host(x, n, threads, per_thread, single_additions);
 	return PBDX_OK;
 }
