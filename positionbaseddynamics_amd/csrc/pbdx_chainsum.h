@@ -3,7 +3,7 @@
 //
 // Why: the centre of a bounding sphere is such a sum over the node's vertices in list order (BoundingSphereHierarchy.cpp:34-51,72-98);
 // the root of a hierarchy sums everything, and a dependent v_add_f32 costs 1.75 ns on this GPU whatever else the GPU does
-// (pbdx_tetcontact_dev.h): for two bars of 655 k tets the root's chain is 5.8 ms of an 8.9 ms step.
+// (pbdx_tetcontact_dev.h): for two bars of 610 k tets the root's chain is 5.4 ms of an 8.9 ms step.
 //
 // How: while the running sum stays in one binade [2^e, 2^(e+1)) it lives on the grid u = 2^(e-23): s = S u with an integer
 // 2^23 <= S < 2^24, and adding x moves it by an integer: with x / u = X + f (X = floor, 0 <= f < 1)
@@ -156,6 +156,45 @@ inline float cs_sum_blocked_host(const float *x, uint64_t n, uint32_t threads, u
 		pos += stop + 1;
 	}
 	if (single_additions) *single_additions = singles;
+	return s;
+}
+
+// the device kernel's POLICY (windows, fall-back bursts) replayed on the host, with counts: stats[0] window attempts, [1] values gained by
+// them, [2] bursts, [3] values summed the plain way
+inline float cs_sum_policy_host(const float *x, uint64_t n, uint32_t window_max, uint32_t poor_below, uint32_t burst0, uint64_t stats[4])
+{
+	float s = 0.0f;
+	uint64_t pos = 0; uint32_t poor = 0; bool plain_next = true;
+	stats[0] = stats[1] = stats[2] = stats[3] = 0;
+	while (pos < n)
+	{
+		CsFrame fr; uint32_t S = 0;
+		const bool framed = cs_frame_of(s, fr, S);
+		if (plain_next || !framed)
+		{
+			const uint64_t want = (uint64_t)burst0 << (poor < 4u ? poor : 4u);
+			const uint64_t len = n - pos < want ? n - pos : want;
+			for (uint64_t i = 0; i < len; i++) { volatile float t = s + x[pos + i]; s = t; }
+			pos += len; plain_next = false; stats[2]++; stats[3] += len;
+			continue;
+		}
+		const uint64_t window = n - pos < window_max ? n - pos : window_max;
+		uint64_t i = 0; bool inside = false, stopped = false;
+		for (; i < window; i++)
+		{
+			bool ok;
+			const uint32_t S1 = cs_apply(S, cs_classify(x[pos + i], fr), ok);
+			if (!ok) { stopped = true; break; }
+			S = S1;
+			if (S1 == 0x1000000u) { stopped = true; inside = true; break; }
+		}
+		stats[0]++;
+		s = cs_value(fr, S);
+		if (!stopped) { pos += window; stats[1] += window; poor = 0; continue; }
+		if (!inside) { volatile float t = s + x[pos + i]; s = t; }
+		pos += i + 1; stats[1] += i + 1;
+		if (i + 1 < poor_below) { plain_next = true; poor++; } else poor = 0;
+	}
 	return s;
 }
 

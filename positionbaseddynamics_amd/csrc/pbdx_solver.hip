@@ -1012,7 +1012,9 @@ struct pbdx_solver
 	void *tet_work_alloc[16] = {};
 	int tet_serial = 0;                            // PBDX_OPT_TET_CONTACTS_SERIAL
 	uint32_t tet_grown = 0;                        // times the detection's scratch was enlarged
-	bool tet_plain_chains = getenv("PBDX_TET_PLAIN_CHAINS") != nullptr;   // developer aid: long sphere sums by the plain chain instead of run by run
+	// developer switch: the long sphere sums run by run (pbdx_chainsum.h) instead of by the plain chain.  Exact either way; on the test
+	// scenes the plain chain is the faster one, so it is the default
+	bool tet_run_sums = getenv("PBDX_TET_RUN_SUMS") != nullptr;
 	uint32_t tet_num_colliders = 0;
 	// developer aid (PBDX_TET_PROFILE=1, hipGraph off): wall time per kernel of the contact path, printed when the solver is destroyed
 	bool tet_profile = getenv("PBDX_TET_PROFILE") != nullptr;
@@ -1859,7 +1861,7 @@ int launch_tet_detection(pbdx_solver *s)
 			if (fork)
 			{
 				(void)hipEventRecord(s->ev_join, side);
-				if (s->tet_plain_chains)
+				if (!s->tet_run_sums)
 					hipLaunchKernelGGL(tet_hull_kernel2, dim3(s->tet_big_count), dim3(192), kTcBigNodeLds, s->stream, views, (const uint32_t *)s->d_tet_big, s->d_tet_big_r2);
 				else
 					hipLaunchKernelGGL(tet_big_sum_kernel, dim3(3 * s->tet_big_count), dim3(1024), 0, s->stream, views, (const uint32_t *)s->d_tet_big, s->d_tet_big_r2);
@@ -2796,7 +2798,7 @@ int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 	if (!s->d_tet_counters) HIPCHECK(hipMalloc(&s->d_tet_counters, kTcWords * sizeof(uint32_t)));
 	HIPCHECK(hipMemset(s->d_tet_counters, 0, kTcWords * sizeof(uint32_t)));      // no contacts before the first detection
 	{
-		// sized by the scene to begin with: the 2 x 81920-tet scene of the tests walks 0.71 M node pairs for 14 k overlapping leaf pairs
+		// sized by the scene to begin with: the 2 x 70875-tet scene of the tests walks 0.71 M node pairs for 14 k overlapping leaf pairs
 		// (4.3 per tet) -- and 50 M when the bars are pushed far into each other: the scratch grows on demand (enqueue_tet_detection)
 		uint64_t total_tets = 0;
 		for (uint32_t i = 0; i < n; i++) total_tets += colliders[i].num_tets;

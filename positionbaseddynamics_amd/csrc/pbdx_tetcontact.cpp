@@ -101,3 +101,9 @@ extern "C" int pbdx_debug_chain_sum_host(const float *x, uint64_t n, uint32_t th
 	*blocked = pbdx::cs_sum_blocked_host(x, n, threads, per_thread, single_additions);
 	return PBDX_OK;
 }
+extern "C" int pbdx_debug_chain_sum_policy_host(const float *x, uint64_t n, uint32_t window_max, uint32_t poor_below, uint32_t burst0, float *out, uint64_t stats[4])
+{
+	if (!x || !out || !stats || !window_max || !burst0) return PBDX_ERR_INVALID;
+	*out = pbdx::cs_sum_policy_host(x, n, window_max, poor_below, burst0, stats);
+	return PBDX_OK;
+}

@@ -21,7 +21,7 @@
 //              of "who is the first unscheduled contact at each particle").  Every level is a set of contacts on disjoint particles;
 //              the levels run in order, each in parallel (tet_contact_solve_levels_kernel).
 //   spheres    KDTree::update recomputes every node's sphere from ITS OWN entity range: the centre is a float sum in list order -- a
-//              dependent chain of n additions per component, 327680 for the root of an 81920-tet hierarchy, and the critical path
+//              dependent chain of n additions per component, 283500 for the root of a 70875-tet hierarchy, and the critical path
 //              of the whole detection.  The vertices are gathered into list order first (tet_gather_kernel), so a node reads a
 //              contiguous range; one wavefront per node and component, whose lanes hold the values in their own registers and take
 //              turns at the running sum (tet_hull_kernel2).  The radius is a maximum (order-free, parallel).
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void tet_gather_kernel(const TetColliderView *
 // wave_ror:1).  After turn t lane t + 1 holds the sum through lane t's values and adds its own in the next turn; what the other lanes
 // compute meanwhile is never looked at.  After 64 turns lane 0 holds the sum through the chunk and starts the next one.
 // A partial last chunk is padded with +0, which is exact: a running sum that starts at +0 is never -0.
-// (Measured on the 81920-tet root, 327680 values per component: operands by v_readlane 7.7 ms, by v_add_f32_dpp wave_shr:1 through the
+// (Measured on the 70875-tet root, 283500 values per component: operands by v_readlane 7.7 ms, by v_add_f32_dpp wave_shr:1 through the
 // lanes -- a DPP add issues at under half rate -- 3.2 ms, by LDS broadcast read 5.3 / 1.0 ms (compiler- / hand-placed waits, staged by
 // the fourth wavefront), this form: scripts/microbench/chain.hip variant G)
 template <int B> __device__ __forceinline__ float chain_turns(float acc, const float (&v)[32])
@@ -172,14 +172,18 @@ __device__ __forceinline__ float chain_sum_from(float start, const float *g, uin
 	return lane_value(acc, 0);
 }
 
-// ---- long sums: run by run (pbdx_chainsum.h) -----------------------------------------------------------------------------------------
+// ---- long sums: run by run (pbdx_chainsum.h) -- an EXPERIMENT, off by default (PBDX_TET_RUN_SUMS) ------------------------------------
 // One workgroup of 1024 threads per sum.  A window of 16384 values is staged in LDS (coalesced load, padded so that a thread's 16
 // consecutive values are conflict-free), every thread turns its 16 values into a function of the state's parity, a workgroup-wide scan
 // composes the functions, every thread replays its values from its true starting state and reports the first value at which the sum
-// leaves the binade.  No violation: the window is done (0.2 ns per value instead of 2.2).  A violation at value i: the state before
-// i is exact, one real addition, next window from i + 1.  If that gained fewer than 2048 values the next 2048, 4096, ... are summed
-// the plain way by one wavefront (chain_sum_from) before runs are tried again: a sum that hovers around zero costs at most twice the
-// plain chain, a sum of one sign a tenth of it.
+// leaves the binade.  No violation: the window is done.  A violation at value i: the state before i is exact, one real addition, next
+// window from i + 1.  If that gained fewer than 2048 values the next 2048, 4096, ... are summed the plain way by one wavefront
+// (chain_sum_from) before runs are tried again.
+// Exact (tests/test_chainsum.py: bit-identical to the plain loop on adversarial data, host and device) -- and not faster here: a window
+// costs ~15 us on one CU (0.9 ns per value: ~90 instructions per value against one dependent addition), every change of binade costs a
+// window, and a component about which the solid is symmetric hovers around zero (the lower bar's z: 40 windows + 207 k of 283 k values
+// in plain bursts).  Spheres of the two 71 k-tet bars: 1.51 ms this way, 0.83 ms by the plain chains; two 610 k-tet bars: 6.5 vs 6.7 ms.
+// What would pay is a window spread over all CUs for the few million-value sums of large scenes.
 constexpr uint32_t kCsThreads = 1024, kCsPerThread = 16, kCsWindow = kCsThreads * kCsPerThread;
 struct CsShared
 {

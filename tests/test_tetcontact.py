@@ -330,7 +330,7 @@ def test_c_abi_without_the_plugin_two_bars_bit_exact():
 
 @pytest.mark.gpu
 def test_plugin_tet_contacts_medium_scene_timing_and_parity():
-    """Two 64x16x16 bars (18785 particles, 81920 tets each): state resident on the device for the whole run, bitwise against the
+    """Two 64x16x16 bars (16384 particles, 70875 tets each): state resident on the device for the whole run, bitwise against the
     reference at the end; prints ms/step of the engine and of the reference (1 thread and 16 threads)."""
     import time
     if not os.path.exists(PLUGIN):
