@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void tet_big_finish_kernel(const TetColliderVi
 }
 
 // ---- traversal: BVHTest::traverse's recursion tree, generation by generation ----------------------------------------------------------
-// One launch of `gridDim.x` co-resident workgroups (at most one per CU is asked for; the launch is alone on its stream) that meet at a
+// One launch of `gridDim.x` co-resident workgroups (a quarter of the CUs is asked for; the launch is alone on its stream) that meet at a
 // barrier between generations.  trav: zeroed before the launch.
 constexpr uint32_t kTcMaxGenerations = 256;
 constexpr uint32_t kTcNone = 0xffffffffu;
