@@ -54,5 +54,43 @@ def main():
         print("scene", name, "done")
 
 
+def tet_contact_golden():
+    """Two colliding bars with box distance fields (tests/tetcontact_util.two_bar_scene): the hierarchies the reference built, and the
+    reference's state and contact list after 71 / 76 steps -- everything a parity test of the engine's detection and of the
+    contact solve needs without the reference at hand."""
+    from tests import tetcontact_util as tcu
+    ref = refdrv.Ref("f32")
+    objs = tcu.two_bar_scene(ref)
+    ref.set_params(1, 5, 0)
+    out = {"x0": ref.get_array(1).astype(np.float32), "w": ref.get_array(7).astype(np.float32), "tolerance": np.float32(0.01), "steps": np.array([71, 76])}
+    for q, co in enumerate(objs):
+        info = ref.tet_model_info(q)
+        shape, invert, params = ref.collision_object_shape(co)
+        out["c%d_meta" % q] = np.array([shape, invert, info["offset"], info["num_vertices"], info["num_tets"], q], dtype=np.int64)
+        out["c%d_params" % q] = np.asarray(params, dtype=np.float32)
+        out["c%d_tets" % q] = np.asarray(info["tets"], dtype=np.uint32)
+        out["c%d_initial_x" % q] = np.asarray(info["initial_x"], dtype=np.float32)
+        out["c%d_initial_R" % q] = np.asarray(info["initial_R"], dtype=np.float32)
+        for which, name in ((0, "points"), (1, "tets"), (2, "rest")):
+            b = ref.bvh(co, which)
+            out["c%d_%s_lst" % (q, name)] = np.asarray(b["lst"], dtype=np.uint32)
+            out["c%d_%s_nodes" % (q, name)] = np.asarray(b["nodes"], dtype=np.int32)
+            out["c%d_%s_hulls" % (q, name)] = np.asarray(b["hulls"], dtype=np.float32)
+    done = 0
+    for steps in (71, 76):
+        ref.step(steps - done)
+        done = steps
+        out["x_%d" % steps] = ref.positions().astype(np.float32)
+        out["v_%d" % steps] = ref.get_array(2).astype(np.float32)
+        out["contacts_%d" % steps] = tcu.oracle_contacts_as_engine_records(ref)
+    ref.reset_all()
+    np.savez_compressed(os.path.join(OUT, "tetcontact_two_bars.npz"), **out)
+    print("tet contact scene done:", len(out["contacts_71"]), len(out["contacts_76"]), "contacts")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "tetcontact":
+        tet_contact_golden()
+    else:
+        main()
+        tet_contact_golden()

@@ -70,6 +70,76 @@ def test_engine_detection_on_host_three_solids_pair_order():
     assert total > 500 and solids_seen == {0, 1, 2}
 
 
+GOLDEN = os.path.join(util.ROOT, "tests", "golden", "tetcontact_two_bars.npz")
+
+
+def _two_bar_ops():
+    w, h, d = tcu.DIMS
+    ops = [("tet", w, h, d, tcu.T_LOWER, None, tcu.SCALE), ("tet", w, h, d, tcu.T_UPPER, None, tcu.SCALE)]
+    for j in range(h):
+        for k in range(d):
+            ops += [("mass", j * d + k, 0.0), ("mass", ((w - 1) * h + j) * d + k, 0.0)]
+    return ops + [("solid", tm, 6, 1e5, 0.3, 1e5, False, False) for tm in (0, 1)]
+
+
+def test_golden_fixture_engine_detection_on_host():
+    """Committed outputs of the reference (tests/golden/make_golden.py): its hierarchies, its state after 71 / 76 steps and its
+    contact lists there.  The engine's detection on that state reproduces those lists -- no reference needed at test time."""
+    g = np.load(GOLDEN)
+    cols = tcu.GoldenTetColliders(g)
+    for steps in g["steps"]:
+        got = tcu.host_contacts_of_state(g["x_%d" % steps], g["x0"], g["w"], cols)
+        want = g["contacts_%d" % steps]
+        assert len(want) > 10 and len(got) == len(want) and util.bitwise_equal(got[:, :26], want), "step %d" % steps
+
+
+def test_golden_fixture_still_matches_the_reference():
+    """... and the fixture is what the reference computes today"""
+    ref = _ref()
+    g = np.load(GOLDEN)
+    objs = tcu.two_bar_scene(ref)
+    ref.set_params(1, 5, 0)
+    assert util.bitwise_equal(ref.get_array(1).astype(np.float32), g["x0"])
+    done = 0
+    for steps in g["steps"]:
+        ref.step(int(steps) - done)
+        done = int(steps)
+        assert util.bitwise_equal(ref.positions().astype(np.float32), g["x_%d" % steps])
+        assert util.bitwise_equal(tcu.oracle_contacts_as_engine_records(ref), g["contacts_%d" % steps])
+    for q, co in enumerate(objs):
+        assert np.array_equal(np.asarray(ref.bvh(co, 1)["lst"], dtype=np.uint32), g["c%d_tets_lst" % q])
+    ref.reset_all()
+
+
+@pytest.mark.gpu
+def test_golden_fixture_c_abi_run_on_the_gpu():
+    """the whole run -- model mirror, raw solver calls, the golden hierarchies -- against the golden states: parity of the deformable
+    contacts on a box that has neither the reference nor oracle/_ref"""
+    import positionbaseddynamics_amd as pbd
+    g = np.load(GOLDEN)
+    cols = tcu.GoldenTetColliders(g)
+    model = util.build_mine(_two_bar_ops())
+    assert util.bitwise_equal(model.getParticles().positions(), g["x0"])
+    ts = pbd.TimeStepController()
+    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 5)
+    pbd.TimeManager.getCurrent().setTimeStepSize(0.005)
+    ts.syncFromHost(model)
+    sol = ts.solver()
+    sol.set_rest_positions(g["x0"])
+    sol.set_tet_colliders(cols.arr, cols.n, float(g["tolerance"]))
+    done = 0
+    for steps in g["steps"]:
+        ts.stepResident(model, int(steps) - done)
+        done = int(steps)
+        ts.syncToHost(model)
+        got = sol.tet_contacts()
+        want = g["contacts_%d" % steps]
+        assert len(got) == len(want) and util.bitwise_equal(got[:, :26], want), "step %d: contact list" % steps
+        assert util.bitwise_equal(model.getParticles().positions(), g["x_%d" % steps]), "step %d" % steps
+        assert util.bitwise_equal(model.getParticles().velocities(), g["v_%d" % steps])
+
+
 SHAPE_CASES = {
     "sphere": [(1, (0.6,), False)] * 2,
     "hollow_box": [(5, (2.0, 0.5, 0.5, 0.1), False)] * 2,
@@ -304,13 +374,7 @@ def test_c_abi_without_the_plugin_two_bars_bit_exact():
     x_cpu, v_cpu, c_cpu = ref.positions().copy(), ref.get_array(2).copy(), tcu.oracle_contacts_as_engine_records(ref)
     ref.reset_all()
     assert len(c_cpu) > 0
-    w, h, d = tcu.DIMS
-    ops = [("tet", w, h, d, tcu.T_LOWER, None, tcu.SCALE), ("tet", w, h, d, tcu.T_UPPER, None, tcu.SCALE)]
-    for j in range(h):
-        for k in range(d):
-            ops += [("mass", j * d + k, 0.0), ("mass", ((w - 1) * h + j) * d + k, 0.0)]
-    ops += [("solid", tm, 6, 1e5, 0.3, 1e5, False, False) for tm in (0, 1)]
-    model = util.build_mine(ops)
+    model = util.build_mine(_two_bar_ops())
     ts = pbd.TimeStepController()
     ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
     ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 5)

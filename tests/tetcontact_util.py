@@ -126,6 +126,52 @@ class TetColliders:
                 f.hulls = hulls.ctypes.data_as(C.POINTER(C.c_float))
 
 
+class GoldenTetColliders:
+    """the same records from tests/golden/tetcontact_two_bars.npz (made by tests/golden/make_golden.py from the reference)"""
+
+    def __init__(self, g):
+        self.keep = []
+        self.n = 2
+        self.arr = (_ffi.TetCollider * self.n)()
+        self.tolerance = float(g["tolerance"])
+        for q in range(self.n):
+            shape, invert, offset, nv, nt, body = (int(v) for v in g["c%d_meta" % q])
+            c = self.arr[q]
+            c.shape, c.invert = shape, invert
+            for k in range(4):
+                c.params[k] = g["c%d_params" % q][k]
+            c.first_particle, c.num_vertices, c.num_tets = offset, nv, nt
+            tets = np.ascontiguousarray(g["c%d_tets" % q], dtype=np.uint32)
+            self.keep.append(tets)
+            c.tets = tets.ctypes.data_as(C.POINTER(C.c_uint32))
+            for k in range(3):
+                c.initial_x[k] = g["c%d_initial_x" % q][k]
+            for k in range(9):
+                c.initial_R[k] = g["c%d_initial_R" % q].reshape(-1)[k]
+            c.restitution, c.friction, c.test_mesh, c.body_index = 0.6, 0.0, 1, body
+            for name, field in (("points", "points"), ("tets", "tets_bvh"), ("rest", "tets_rest")):
+                lst = np.ascontiguousarray(g["c%d_%s_lst" % (q, name)], dtype=np.uint32)
+                nodes = np.ascontiguousarray(g["c%d_%s_nodes" % (q, name)], dtype=np.int32)
+                hulls = np.ascontiguousarray(g["c%d_%s_hulls" % (q, name)], dtype=np.float32)
+                self.keep += [lst, nodes, hulls]
+                f = getattr(c, field)
+                f.num_nodes, f.num_entities = len(nodes), len(lst)
+                f.entities = lst.ctypes.data_as(C.POINTER(C.c_uint32))
+                f.nodes = nodes.ctypes.data_as(C.POINTER(C.c_int32))
+                f.hulls = hulls.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def host_contacts_of_state(x, x0, w, colliders, capacity=4096):
+    """pbdx_debug_tet_contacts on a given state"""
+    pos4 = np.ascontiguousarray(np.concatenate([x, w[:, None]], axis=1), dtype=np.float32)
+    rest4 = np.ascontiguousarray(np.concatenate([x0, w[:, None]], axis=1), dtype=np.float32)
+    out = np.zeros((capacity, _ffi.TET_CONTACT_FLOATS), dtype=np.float32)
+    count = C.c_uint32(0)
+    _ffi.check(_ffi.lib.pbdx_debug_tet_contacts(len(x), pos4.ctypes.data_as(_ffi.pf), rest4.ctypes.data_as(_ffi.pf), colliders.n, colliders.arr,
+                                                float(colliders.tolerance), capacity, C.byref(count), out.ctypes.data_as(_ffi.pf)), "debug_tet_contacts")
+    return out[:count.value]
+
+
 def host_contacts(ref, colliders, capacity=4096):
     """pbdx_debug_tet_contacts on the oracle's current state: the engine's detection code evaluated on the host."""
     x = ref.positions().astype(np.float32)
