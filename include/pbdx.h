@@ -256,6 +256,9 @@ int pbdx_solver_set_rest_positions(pbdx_solver *s, uint32_t n, const float *x0);
  * m_x[4][3], m_invMasses[4], tet vertex particle ids[4] (indices as floats).  *count = number of contacts (may exceed capacity). */
 #define PBDX_TET_CONTACT_FLOATS 30
 int pbdx_solver_get_tet_contacts(pbdx_solver *s, uint32_t capacity, uint32_t *count, float *out);
+/* Developer aid: the position solve of contact records (as returned by pbdx_solver_get_tet_contacts) applied on the host to pos4 (n x (x, y, z, invMass),
+ * in place) in the given order (order == NULL: list order): the sequential loop of TimeStepController.cpp:288-291 with the engine's arithmetic. */
+int pbdx_debug_tet_solve_host(uint32_t n_particles, float *pos4, uint32_t n_contacts, const float *records, const uint32_t *order);
 /* Developer aid: the bounding spheres (centre, radius) of hierarchy `which` (0 points, 1 tets, 2 tets at rest) of a collider as the last
  * detection left them; *count = number of nodes. */
 int pbdx_debug_tet_hulls(pbdx_solver *s, uint32_t collider, int which, uint32_t capacity, uint32_t *count, float *out);

@@ -107,3 +107,30 @@ extern "C" int pbdx_debug_chain_sum_policy_host(const float *x, uint64_t n, uint
 	*out = pbdx::cs_sum_policy_host(x, n, window_max, poor_below, burst0, stats);
 	return PBDX_OK;
 }
+
+// solve_ParticleTetContactConstraint applied to pos4 (n x (x, y, z, invMass), updated in place) for the contacts records[order[0]],
+// records[order[1]], ... (30-float records as pbdx_solver_get_tet_contacts returns them; order == NULL: 0, 1, 2, ...): the host side of the
+// claim that the contact list may be solved level by level (tests/test_tetcontact.py)
+extern "C" int pbdx_debug_tet_solve_host(uint32_t n_particles, float *pos4, uint32_t n_contacts, const float *records, const uint32_t *order)
+{
+	if ((n_particles && !pos4) || (n_contacts && !records)) return PBDX_ERR_INVALID;
+	struct Access
+	{
+		pbdx::P4 *p;
+		pbdx::P4 get(uint32_t i) const { return p[i]; }
+		void add(uint32_t i, pbdx::V3 c) { p[i].x += c.x; p[i].y += c.y; p[i].z += c.z; }
+	} acc = { reinterpret_cast<pbdx::P4 *>(pos4) };
+	for (uint32_t q = 0; q < n_contacts; q++)
+	{
+		const float *o = records + (size_t)(order ? order[q] : q) * PBDX_TET_CONTACT_FLOATS;
+		pbdx::TetContact c;
+		c.particle = (uint32_t)o[0]; c.solid = (uint32_t)o[1]; c.tet = (uint32_t)o[2];
+		for (int k = 0; k < 3; k++) { c.bary[k] = o[3 + k]; c.normal[k] = o[6 + k]; }
+		c.nKn_inv = o[9];
+		for (int v = 0; v < 4; v++) for (int k = 0; k < 3; k++) c.x[v][k] = o[10 + 3 * v + k];
+		for (int v = 0; v < 4; v++) { c.w[v] = o[22 + v]; c.vert[v] = (uint32_t)o[26 + v]; }
+		if (c.particle >= n_particles || c.vert[0] >= n_particles || c.vert[1] >= n_particles || c.vert[2] >= n_particles || c.vert[3] >= n_particles) return PBDX_ERR_INVALID;
+		pbdx::tet_contact_position_solve(c, acc);
+	}
+	return PBDX_OK;
+}

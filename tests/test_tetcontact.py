@@ -93,6 +93,59 @@ def test_golden_fixture_engine_detection_on_host():
         assert len(want) > 10 and len(got) == len(want) and util.bitwise_equal(got[:, :26], want), "step %d" % steps
 
 
+def _levels(records):
+    """the engine's levelling rule (pbdx_tetcontact_dev.h): a contact's level is one more than the highest level among EARLIER contacts
+    that share one of its five particles"""
+    last = {}
+    level = np.zeros(len(records), dtype=np.int64)
+    for c, r in enumerate(records):
+        ids = [int(r[0])] + [int(v) for v in r[26:30]]
+        level[c] = 1 + max([last.get(i, -1) for i in ids])
+        for i in ids:
+            last[i] = level[c]
+    return level
+
+
+def test_level_by_level_solve_equals_the_sequential_loop_on_the_host():
+    """The reference solves its contact list one contact after the other.  Contacts that share no particle commute bit for bit, so any
+    order that keeps the list order among contacts sharing a particle gives the same bits: checked here with the engine's own solve
+    arithmetic on the host, on real contact lists (several lists: the levels interleave differently), for the level order, for the
+    level order with every level reversed, and -- as a control -- that a random permutation does NOT."""
+    ref = _ref()
+    objs = tcu.stacked_bars_scene(ref, 3)
+    ref.set_params(1, 5, 0)
+    cols = tcu.TetColliders(ref, objs, (0, 1, 2), 0.01)
+    rng = np.random.default_rng(5)
+    checked, differing_controls = 0, 0
+    for step in range(90):
+        ref.step(1)
+        rec = np.ascontiguousarray(tcu.host_contacts(ref, cols), dtype=np.float32)
+        if len(rec) < 12:
+            continue
+        level = _levels(rec)
+        assert level.max() >= 1, "some contacts must share a particle for the test to mean anything"
+        x = ref.positions().astype(np.float32)
+        w = ref.get_array(7).astype(np.float32)
+        start = np.ascontiguousarray(np.concatenate([x, w[:, None]], axis=1), dtype=np.float32)
+
+        def solve(order):
+            p = start.copy()
+            o = None if order is None else np.ascontiguousarray(order, dtype=np.uint32)
+            _ffi.check(_ffi.lib.pbdx_debug_tet_solve_host(len(p), p.ctypes.data_as(_ffi.pf), len(rec), rec.ctypes.data_as(_ffi.pf),
+                                                          None if o is None else o.ctypes.data_as(C.POINTER(C.c_uint32))), "tet_solve_host")
+            return p
+        sequential = solve(None)
+        by_level = np.argsort(level, kind="stable")
+        assert util.bitwise_equal(solve(by_level), sequential), "step %d" % step
+        reversed_within = np.concatenate([np.flatnonzero(level == l)[::-1] for l in range(level.max() + 1)])
+        assert util.bitwise_equal(solve(reversed_within), sequential), "step %d (levels reversed inside)" % step
+        if not util.bitwise_equal(solve(rng.permutation(len(rec))), sequential):
+            differing_controls += 1
+        checked += 1
+    ref.reset_all()
+    assert checked >= 20 and differing_controls >= 1, (checked, differing_controls)
+
+
 def test_golden_fixture_still_matches_the_reference():
     """... and the fixture is what the reference computes today"""
     ref = _ref()
