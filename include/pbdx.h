@@ -249,7 +249,8 @@ typedef struct pbdx_tet_collider
 	pbdx_bvh points, tets_bvh, tets_rest; /* m_bvh, m_bvhTets, m_bvhTets0 */
 } pbdx_tet_collider;
 /* tolerance = CollisionDetection::m_tolerance.  Needs rest positions: pbdx_solver_set_rest_positions (default: the positions of
- * the first pbdx_solver_set_particles call). */
+ * the first pbdx_solver_set_particles call).  Replaces the previous set and empties the contact list (n = 0: no deformable colliders); after a
+ * failed call (invalid records, friction != 0, out of memory) NO deformable colliders are set.  The detection's scratch buffers grow on demand. */
 int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_collider *colliders, float tolerance);
 int pbdx_solver_set_rest_positions(pbdx_solver *s, uint32_t n, const float *x0);   /* ParticleData::m_x0, packed xyz */
 /* The contact list of the last detection, 30 floats per contact: particle, solid, tet, bary[3], normal[3], 1/(J M^-1 J^T),

@@ -1786,7 +1786,15 @@ int enqueue_substep(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int v
 // DistanceFieldCollisionDetection::collisionDetection for the solid-solid pairs: bounding spheres, boxes, detection (pbdx_tetcontact.h).
 // The new contact list is used by the position solves of the NEXT step.
 // (re)allocates the scratch of the detection; the contact list is preserved across a growth of anything else
+int alloc_tet_work_impl(pbdx_solver *s, uint64_t nodes, uint32_t contacts);
+// a failed (re)allocation leaves nothing half-built behind: the colliders are dropped, the step that needed them reports the error
 int alloc_tet_work(pbdx_solver *s, uint64_t nodes, uint32_t contacts)
+{
+	const int r = alloc_tet_work_impl(s, nodes, contacts);
+	if (r) s->free_tet_colliders();
+	return r;
+}
+int alloc_tet_work_impl(pbdx_solver *s, uint64_t nodes, uint32_t contacts)
 {
 	TetWork &w = s->tet_work;
 	const uint32_t n = s->tet_num_colliders;
@@ -2681,7 +2689,14 @@ int pbdx_solver_set_rest_positions(pbdx_solver *s, uint32_t n, const float *x0)
 	return PBDX_OK;
 }
 
+static int set_tet_colliders_impl(pbdx_solver *s, uint32_t n, const pbdx_tet_collider *colliders, float tolerance);
 int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_collider *colliders, float tolerance)
+{
+	const int r = set_tet_colliders_impl(s, n, colliders, tolerance);
+	if (r && s) s->free_tet_colliders();          // nothing half-uploaded stays active
+	return r;
+}
+static int set_tet_colliders_impl(pbdx_solver *s, uint32_t n, const pbdx_tet_collider *colliders, float tolerance)
 {
 	if (!s || (n && !colliders) || n > 256) { set_error("set_tet_colliders: bad arguments (at most 256 colliders)"); return PBDX_ERR_INVALID; }
 	for (uint32_t i = 0; i < n; i++)
