@@ -19,9 +19,12 @@ WORLD_SIZE / MASTER_* from the environment) or, when WORLD_SIZE is not set, by t
                               the 512 instances sharded contiguously over the ranks       (strong scaling)
 value = projections of all ranks / max-over-ranks time.
 
-Prints ONE JSON line on rank 0.  The line carries `roofline` and `cpu_baseline` (N = 1 only), the
-parity of the timed engine against the reference on the headline scene (`config.parity_vs_reference`)
-and the other BASELINE workloads that fit one GPU as `extra_workloads`.
+Output (rank 0).  The LAST stdout line is the compact headline record (< 4 KB: the driver keeps an 8 KB tail):
+metric / value / ms_per_step, `config` (workload, counts, per-rank times, `parity_vs_reference` summary), `roofline`,
+`cpu_baseline` (N = 1 only).  Before it, one compact line per extra workload ({"extra": ...}: configs[2] variants,
+the configs[3] block, the configs[4]-shaped contact scene).  The full record (segment tables, counter raw values, notes,
+engine descriptions) goes to `bench_detail.json` next to this script (and to $PBDX_BENCH_DETAIL if set).
+`--dry-line [full.json]` prints the compact lines for a stored full record without a GPU (tests/test_bench_line.py).
 """
 import argparse
 import json
@@ -62,9 +65,10 @@ def workload_spec(w, ens):
             begin, end = ens.shard(w["instances"] * ens.world)     # weak scaling: `instances` per GPU
         k = end - begin
         # one prototype + SimulationModel.addInstances: built, coloured and planned once, replicated
-        ops = scenes.cloth_spec(w["size"], w["size"], 4, 3, instances=k, instance_offset=(0.0, 0.0, 12.0), instanced=True)
-        desc = "configs[3]: %d independent %dx%d cloth instances on this GPU (%s; XPBD distance + XPBD isometric bending), %d iterations, 1 substep, h=0.005" % (
-            k, w["size"], w["size"], ("strong scaling: %d instances over %d GPUs" % (w["total_instances"], ens.world)) if w["scaling"] == "strong" else "weak scaling", w["iters"])
+        # this rank's instances are the GLOBAL instances begin .. end-1 of the job (their own translations), not 0 .. k-1
+        ops = scenes.cloth_spec(w["size"], w["size"], 4, 3, instances=k, instance_offset=(0.0, 0.0, 12.0), instanced=True, first_instance=begin)
+        desc = "configs[3]: %d independent %dx%d cloth instances on this GPU (global instances %d..%d; %s; XPBD distance + XPBD isometric bending), %d iterations, 1 substep, h=0.005" % (
+            k, w["size"], w["size"], begin, end - 1, ("strong scaling: %d instances over %d GPUs" % (w["total_instances"], ens.world)) if w["scaling"] == "strong" else "weak scaling", w["iters"])
         return ops, desc, [0, w["size"] - 1]
     ops = scenes.cloth_spec(w["size"], w["size"], 4, 3)
     desc = "configs[1]: single %dx%d cloth sheet per GPU (XPBD distance k=1e5 + XPBD isometric bending k=100), %d iterations, 1 substep, h=0.005" % (
@@ -89,7 +93,7 @@ def child_flags(w, fused_active, persist_active, opts):
 # ---------------------------------------------------------------------------------------------------
 # rocprofv3 child passes (counters and traces are never combined; the profiled run is never the timed one)
 # ---------------------------------------------------------------------------------------------------
-def _rocprof_child(extra_args, child_args, prefix, timeout_s=300):
+def _rocprof_child(extra_args, child_args, prefix, timeout_s=300, child_steps=None):
     import shutil
     import tempfile
     exe = shutil.which("rocprofv3")
@@ -97,7 +101,8 @@ def _rocprof_child(extra_args, child_args, prefix, timeout_s=300):
         return None
     outdir = tempfile.mkdtemp(prefix=prefix, dir="/tmp")
     cmd = [exe] + extra_args + ["--output-format", "csv", "-d", outdir, "-o", "out", "--",
-                                sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args
+                                sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args + (
+                                    ["--child-steps", str(child_steps)] if child_steps else [])
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
@@ -130,11 +135,13 @@ def _pmc_pass(counter, child_args):
 def rocprof_kernel_durations(child_args, kernel_substring):
     """Cross-check of the event-measured launch durations: a `rocprofv3 --kernel-trace` child pass (no counters) of a
     short run of the same configuration with the schedule FORCED (no autotune launches in the trace): every dispatch
-    of the dominant kernel in it is one of the timed kind.  Returns dict(mean_us, min_us, max_us, dispatches)."""
+    of the dominant kernel in it is one of the timed kind; the child replays the hipGraph like the timed loop does
+    (10 untimed + 30 steps), and the MEDIAN is the figure to compare with ms_per_step (the first dispatches of a process
+    run on cold clocks and caches).  Returns dict(median_us, mean_us, min_us, max_us, dispatches)."""
     import csv
     import glob
     import shutil
-    outdir = _rocprof_child(["--kernel-trace"], child_args, "pbdx_trace_")
+    outdir = _rocprof_child(["--kernel-trace"], child_args, "pbdx_trace_", child_steps=30)
     if outdir is None:
         return None
     durs = []
@@ -146,7 +153,8 @@ def rocprof_kernel_durations(child_args, kernel_substring):
     shutil.rmtree(outdir, ignore_errors=True)
     if not durs:
         return None
-    return {"mean_us": sum(durs) / len(durs) / 1e3, "min_us": min(durs) / 1e3, "max_us": max(durs) / 1e3, "dispatches": len(durs)}
+    durs.sort()
+    return {"median_us": durs[len(durs) // 2] / 1e3, "mean_us": sum(durs) / len(durs) / 1e3, "min_us": durs[0] / 1e3, "max_us": durs[-1] / 1e3, "dispatches": len(durs)}
 
 
 def collect_traffic(child_args, kernel_substring):
@@ -278,15 +286,20 @@ def run_workload(w, opts, ens, steps, warmup, with_roofline, with_traffic, with_
         sol.set_collision_ranges([])
 
     if with_roofline and ens.rank == 0:
-        res["roofline"] = roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles)
+        res["roofline"] = roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles, stats)
         if with_traffic and res["roofline"] is not None and ens.world == 1:
             add_profiled_passes(res["roofline"], w, opts, plan, persist)
     return res
 
 
-def roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles):
-    """Dominant kernel of the workload: duration measured live with HIP events on the engine's own stream (eager
-    launches, one event pair around every projection launch), bytes as SURVEY 8d defines them."""
+def roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles, timed_stats=None):
+    """Dominant kernel of the workload, bytes as SURVEY 8d defines them, duration measured live with HIP events on the
+    engine's own stream.  Where ONE launch is the whole substep (persistent schedule with integration and velocity update
+    folded in) the duration is taken in the SAME mode as the timed loop: the device-event time of the timed region (graph
+    replay, `steps` launches back to back) / `steps` -- an upper bound of the kernel's own duration (it includes the gaps
+    between graph launches), so that kernel time <= ms_per_step by construction; the eager event-pair figure (one pair
+    around a single launch on an otherwise idle GPU: slower, cold clocks and caches) is kept as `eager_launch_us`.
+    Other schedules: one event pair around every projection launch (eager)."""
     iters = w["iters"]
     sol.set_profiling(True)
     psteps = max(2, min(5, steps))
@@ -296,21 +309,26 @@ def roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles):
     pinfo = sol.persistent_info()
     if plan["active"] and pinfo["active"] and pinfo["profiled_launches"]:
         # one launch per substep runs all `iters` sweeps: algorithmic bytes of a launch = iters x bytes of a sweep
-        dur_s = 1e-3 * pinfo["profiled_ms"] / pinfo["profiled_launches"]
+        eager_s = 1e-3 * pinfo["profiled_ms"] / pinfo["profiled_launches"]
+        dur_s, mode = eager_s, "eager launch, HIP event pair around it"
         bytes_per_launch = pinfo["algorithmic_bytes_per_sweep"] * iters
         folded = bool(pinfo["last_folded"])
+        if folded and timed_stats and timed_stats["total_ms"] > 0 and timed_stats["kernel_launches"] == steps:
+            dur_s = 1e-3 * timed_stats["total_ms"] / steps
+            mode = "timed region: HIP events around the %d graph-replayed launches of the timed loop / %d" % (steps, steps)
         if folded:      # the launch also integrates and updates the velocities (140 B per particle)
             bytes_per_launch += n_particles * 140
         segs = [sol.segment_info(i) for i in range(plan["num_segments"])]
         streamed = sum(si["stream_bytes"] for si in segs) * iters
         compulsory = plan["compulsory_stream_bytes_per_sweep"] * iters + n_particles * 140
         achieved = bytes_per_launch / dur_s / 1e9
-        return {"bound": "hbm", "kernel": "persistent_kernel (colour-fused LDS tiles, all %d sweeps x %d segments of a substep in one launch%s)" % (
-                    iters, plan["num_segments"], ", integration and velocity update included" if folded else ""),
+        return {"bound": "hbm", "kernel": "persistent_kernel: %d sweeps x %d segments%s in ONE launch (colour-fused LDS tiles)" % (
+                    iters, plan["num_segments"], " + integrate + velocity update" if folded else ""),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "streamed_bytes_per_launch": streamed,
-                "compulsory_bytes_per_launch": compulsory, "avg_launch_us": dur_s * 1e6,
-                "launches_measured": pinfo["profiled_launches"], "grid": pinfo["grid"], "block": pinfo["block"], "lds_bytes": pinfo["lds_bytes"], "folded": folded,
+                "compulsory_bytes_per_launch": compulsory, "avg_launch_us": dur_s * 1e6, "timing_mode": mode,
+                "eager_launch_us": eager_s * 1e6,
+                "launches_measured": steps if dur_s != eager_s else pinfo["profiled_launches"], "grid": pinfo["grid"], "block": pinfo["block"], "lds_bytes": pinfo["lds_bytes"], "folded": folded,
                 "segments": [{"segment": i, "colours": [si["colour_begin"], si["colour_end"]], "tiles": si["num_tiles"], "constraints": si["constraints"], "slots": si["slots"],
                               "algorithmic_bytes_per_pass": si["algorithmic_bytes"], "streamed_bytes_per_pass": si["stream_bytes"]} for i, si in enumerate(segs)],
                 "note": "frac = SURVEY 8d ALGORITHMIC bytes (every endpoint position read and written once per projection, 32-bit indices, no cache credit) / "
@@ -378,6 +396,7 @@ def add_profiled_passes(r, w, opts, plan, persist):
         r["traffic_detail"] = {k: tr[k] for k in ("fetch_bytes", "write_bytes", "launches", "raw")}
     kd = rocprof_kernel_durations(child, kname)
     if kd is not None:
+        r["rocprofv3_median_kernel_us"] = kd["median_us"]
         r["rocprofv3_mean_kernel_us"] = kd["mean_us"]
         r["rocprofv3_min_kernel_us"] = kd["min_us"]
         r["rocprofv3_max_kernel_us"] = kd["max_us"]
@@ -494,6 +513,157 @@ def cpu_baseline(size, iters, opts, hip_device, parity_steps=3, timed_steps=3):
     return rec, parity
 
 
+def shard_vs_reference(w, ens, opts, steps):
+    """--check-shards (checker leg, small sizes): THIS rank's instances stepped by the reference itself (oracle/_ref f32) and by a
+    fresh engine, compared bit for bit.  Ranks hold different instances, so this -- not a comparison of the ranks' checksums with each
+    other -- is what says that a shard simulated the instances it was given."""
+    from oracle import refdrv
+    from oracle.scene_ref import apply_ref
+    import positionbaseddynamics_amd as pbd
+    from positionbaseddynamics_amd import scenes
+    ops, _, _ = workload_spec(w, ens)
+    ref = refdrv.Ref("f32")
+    apply_ref(ref, ops)
+    ref.set_time_step_size(0.005)
+    ref.set_gravity(scenes.GRAVITY)
+    ref.set_params(1, w["iters"], 0)
+    ref.set_num_threads(1)
+    ref.step(steps)
+    xr = ref.positions().astype(np.float32)
+    ref.reset_all()
+    model = scenes.build_model(ops)
+    pbd.TimeManager.getCurrent().setTimeStepSize(0.005)
+    ts = pbd.TimeStepController(device=ens.hip_device)
+    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, w["iters"])
+    ts.stepResident(model, steps)
+    ts.syncToHost(model)
+    xg = model.getParticles().positions()
+    return bool(np.array_equal(xg.view(np.uint32), xr.view(np.uint32)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# output: full record -> bench_detail.json, compact lines -> stdout (the headline LAST, < 4 KB)
+# ---------------------------------------------------------------------------------------------------
+MAX_LINE = 4096
+
+
+def _r(x, sig=6):
+    """Floats to `sig` significant digits (the compact lines carry measurements, not bit patterns)."""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def compact_roofline(r):
+    if not r:
+        return None
+    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "traffic_over_compulsory", "algorithmic_bytes_per_launch",
+                    "compulsory_bytes_per_launch", "avg_launch_us", "eager_launch_us", "rocprofv3_median_kernel_us", "rocprofv3_mean_kernel_us",
+                    "rocprofv3_dispatches", "launches_measured"))
+    out["kernel"] = str(r.get("kernel", ""))[:110]
+    if r.get("timing_mode"):
+        out["timing_mode"] = r["timing_mode"].split(":")[0]
+    return out
+
+
+def compact_headline(full, detail_path=None):
+    """The driver-facing line: every key the bench contract names, summaries instead of tables."""
+    c = full["config"]
+    cfg = _pick(c, ("workload", "particles", "constraints", "colour_groups", "projections_per_substep", "rccl_ranks", "dist_backend", "oversubscribed",
+                    "per_rank_ms_per_step", "state_ok", "replicas_bit_identical", "shards_distinct", "replica_checksums", "shard_parity", "instances_of_rank0",
+                    "device_event_ms_per_substep", "pcie_inclusive_ms_per_step"))
+    cfg["workload"] = str(cfg.get("workload", ""))[:200]
+    cfg["parallelism"] = "ensemble x%d, no data-path collective" % c.get("rccl_ranks", 1)
+    pv = c.get("parity_vs_reference")
+    if pv:
+        cfg["parity_vs_reference"] = _pick(pv, ("bit_identical", "steps", "compared_values", "max_abs"))
+        cfg["parity_vs_reference"]["schedule"] = pv.get("engine_schedule")
+    per = c.get("persistent") or {}
+    cfg["schedule"] = {"fused": bool((c.get("plan") or {}).get("active")), "persistent": bool(per.get("active")), "folded": bool(per.get("last_folded")),
+                       "refusals": per.get("refusals"), "timeouts": per.get("timeouts")}
+    if detail_path:
+        cfg["detail"] = detail_path
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_substep", "higher_is_better", "scaling", "vs_baseline",
+                       "dtype", "data"))
+    out["config"] = cfg
+    if full.get("roofline"):
+        out["roofline"] = compact_roofline(full["roofline"])
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ms_per_substep", "single_thread", "variant", "host_logical_cpus"))
+        out["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+    ex = full.get("extra_workloads") or []
+    if ex:
+        out["extras"] = [{"w": e.get("tag", "?"), "ms": _r(e.get("ms_per_substep"), 4), "ok": e.get("state_ok", False) and e.get("bit_identical", True)} for e in ex]
+    out = _r(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= MAX_LINE:            # never let a long list cost the record: drop the optional parts, longest first
+        for k in ("extras",):
+            out.pop(k, None)
+        for k in ("replica_checksums", "schedule", "instances_of_rank0"):
+            out["config"].pop(k, None)
+        line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= MAX_LINE:
+        raise RuntimeError("bench.py: headline line is %d bytes (limit %d)" % (len(line), MAX_LINE))
+    return line
+
+
+def compact_extra(e):
+    """One line per extra workload (printed BEFORE the headline)."""
+    out = _pick(e, ("tag", "workload", "particles", "constraints", "colour_groups", "steps", "ms_per_substep", "ms_per_step", "projections_per_s", "state_ok",
+                    "host_scene_build_s", "bit_identical", "compared_values", "parity_steps", "contacts_last_step", "contacts_max", "sub_steps", "iterations",
+                    "reference_ms_per_step", "error"))
+    if "workload" in out:
+        out["workload"] = str(out["workload"])[:220]
+    if e.get("roofline"):
+        out["roofline"] = compact_roofline(e["roofline"])
+    per = e.get("persistent") or {}
+    if per:
+        out["schedule"] = {"fused": bool((e.get("plan") or {}).get("active")), "persistent": bool(per.get("active"))}
+    line = json.dumps({"extra": _r(out)}, separators=(",", ":"))
+    return line if len(line) < MAX_LINE else json.dumps({"extra": _r(_pick(out, ("tag", "ms_per_substep", "state_ok")))}, separators=(",", ":"))
+
+
+def emit(full, write_detail=True):
+    """Full record to the side file, compact lines to stdout, headline last."""
+    detail_path = None
+    if write_detail:
+        for path in [os.environ.get("PBDX_BENCH_DETAIL"), os.path.join(ROOT, "bench_detail.json")]:
+            if not path:
+                continue
+            try:
+                with open(path, "w") as fh:
+                    json.dump(full, fh)
+                detail_path = detail_path or os.path.relpath(path, ROOT)
+            except OSError:
+                pass
+    for e in full.get("extra_workloads") or []:
+        print(compact_extra(e), flush=True)
+    print(compact_headline(full, detail_path), flush=True)
+
+
+def dry_line(path):
+    """No GPU: the compact lines of a stored full record, stretched to the worst case the driver will see (8 ranks)."""
+    with open(path) as fh:
+        full = json.load(fh)
+    c = full["config"]
+    c["rccl_ranks"] = 8
+    c["per_rank_ms_per_step"] = [(c.get("per_rank_ms_per_step") or [1.0])[0] * (1 + 1e-3 * i) for i in range(8)]
+    c["replica_checksums"] = [(c.get("replica_checksums") or ["0" * 16])[0]] * 8
+    for i, e in enumerate(full.get("extra_workloads") or []):
+        e.setdefault("tag", "extra%d" % i)
+    emit(full, write_detail=False)
+
+
 # ---------------------------------------------------------------------------------------------------
 # N ranks from one command
 # ---------------------------------------------------------------------------------------------------
@@ -513,7 +683,7 @@ def spawn_ranks(n, argv):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0 = procs[0].communicate()[0].decode()
     rcs = [p.wait() for p in procs]
-    for line in out0.splitlines():      # the ONE JSON line goes to stdout; library chatter of the rank (gloo / RCCL banners) to stderr
+    for line in out0.splitlines():      # the JSON lines go to stdout (headline last); library chatter of the rank (gloo / RCCL banners) to stderr
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     if any(rcs):
@@ -550,9 +720,15 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than GPUs (ranks share devices; smoke test of the N>1 path, not a measurement)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--child-steps", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--dry-line", nargs="?", const=os.path.join(ROOT, "profiles", "r02_bench.json"), default=None,
+                    help="no GPU: print the compact lines for a stored FULL record (default profiles/r02_bench.json)")
+    ap.add_argument("--check-shards", action="store_true", help="c4: every rank also steps ITS instances with the reference (oracle/_ref f32) and compares bits (small sizes only)")
     ap.add_argument("--rank-selftest", action="store_true", help="launcher self-test: the ranks rendezvous, exchange their rank numbers and exit (no GPU work, no metric)")
     args = ap.parse_args()
 
+    if args.dry_line:
+        return dry_line(args.dry_line)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
         return spawn_ranks(args.gpus, sys.argv[1:])
 
@@ -588,7 +764,7 @@ def main():
         for mode in range(4):
             _ffi.check(_ffi.lib.pbdx_debug_stream(ens.hip_device, CALIB_BYTES, mode), "pbdx_debug_stream")
         args.no_roofline = args.no_cpu_baseline = args.no_extras = True
-        args.steps, args.warmup = 2, 1
+        args.steps, args.warmup = (args.child_steps, 10) if args.child_steps else (2, 1)
 
     w = {"workload": args.workload, "size": args.size, "instances": args.instances, "bars": args.bars, "solid_method": args.solid_method,
          "iters": args.iters, "scaling": args.scaling, "total_instances": args.total_instances}
@@ -603,7 +779,14 @@ def main():
     # cross-GPU parity: ranks that simulate the same scene (c2, c3: replicas; c4: identical instance blocks when the blocks
     # have equal size) must hold the same bits -- one tiny all-reduce of per-rank checksums
     sums = ens.gather_checksums([res["checksum"]], world)
-    replicas_identical = len(set(sums)) == 1
+    # c2 / c3: every rank holds the same scene (replicas must agree bit for bit); c4: ranks hold DIFFERENT instances
+    # (global instances begin .. end-1 with their own translations), so equal checksums would be a sharding bug
+    replicas_identical = (len(set(sums)) == 1) if args.workload != "c4" else None
+    shards_distinct = (len(set(sums)) == world) if args.workload == "c4" else None
+    shard_parity = None
+    if args.check_shards and args.workload == "c4":
+        ok_ranks = ens.sum_count(1 if shard_vs_reference(w, ens, opts, 3) else 0)
+        shard_parity = {"ranks_checked": world, "ranks_bit_identical_to_reference": ok_ranks, "steps": 3}
     all_ok = ens.sum_count(1 if res["state_ok"] else 0) == world
 
     value = total_constraints * args.iters * args.steps / t_max
@@ -623,7 +806,9 @@ def main():
                    "parallelism": "ensemble x%d (independent instances per GPU, no cross-GPU constraints, no data-path collective)" % world,
                    "rccl_ranks": world, "dist_backend": ens.backend, "oversubscribed": bool(args.oversubscribe and world > ndev),
                    "per_rank_ms_per_step": per_rank_ms, "replica_checksums": ["%016x" % c for c in sums],
-                   "state_ok": all_ok, "replicas_bit_identical": replicas_identical, "state_checksum": "%016x" % sums[0],
+                   "state_ok": all_ok, "replicas_bit_identical": replicas_identical, "shards_distinct": shards_distinct, "shard_parity": shard_parity,
+                   "instances_of_rank0": list(ens.shard(args.total_instances if args.scaling == "strong" else args.instances * world)) if args.workload == "c4" else None,
+                   "state_checksum": "%016x" % sums[0],
                    "device_event_ms_per_substep": stats["total_ms"] / max(args.steps, 1),
                    "algorithmic_GB_per_substep": stats["algorithmic_bytes"] / max(args.steps, 1) / 1e9,
                    "whole_substep_algorithmic_GBs": stats["algorithmic_bytes"] / max(stats["total_ms"], 1e-9) / 1e6,
@@ -644,23 +829,23 @@ def main():
         # the other BASELINE workloads that fit one GPU, witnessed in the same line (shorter runs; same engine, defaults)
         extras = []
         base = {"size": 200, "instances": 64, "bars": False, "solid_method": 2, "iters": args.iters, "scaling": "weak", "total_instances": 512}
-        for ew, want_traffic in (({**base, "workload": "c3", "solid_method": 2}, True), ({**base, "workload": "c3", "solid_method": 4}, False),
-                                 ({**base, "workload": "c3", "solid_method": 6}, False), ({**base, "workload": "c4"}, True)):
+        for tag, ew, want_traffic in (("c3_fem_tets", {**base, "workload": "c3", "solid_method": 2}, True), ("c3_strain_tets", {**base, "workload": "c3", "solid_method": 4}, False),
+                                      ("c3_xpbd_distance_volume", {**base, "workload": "c3", "solid_method": 6}, False), ("c4_block_64x200x200", {**base, "workload": "c4"}, True)):
             try:
                 r = run_workload(ew, {}, ens, max(10, min(args.steps, 30)), 5, with_roofline=not args.no_roofline, with_traffic=want_traffic and not args.no_traffic)
             except Exception as e:  # an extra must never cost the headline line
-                extras.append({"workload": ew["workload"], "error": repr(e)})
+                extras.append({"tag": tag, "workload": ew["workload"], "error": repr(e)})
                 continue
             nsteps = max(10, min(args.steps, 30))
             ms = 1e3 * r["t_local"] / nsteps
-            extras.append({"workload": r["desc"], "particles": r["n_particles"], "constraints": r["n_constraints"], "colour_groups": r["n_groups"],
+            extras.append({"tag": tag, "workload": r["desc"], "particles": r["n_particles"], "constraints": r["n_constraints"], "colour_groups": r["n_groups"],
                            "steps": nsteps, "ms_per_substep": ms, "projections_per_s": r["n_constraints"] * ew["iters"] * nsteps / r["t_local"],
                            "state_ok": r["state_ok"], "host_scene_build_s": r["t_build"], "plan": r["plan"], "persistent": r["persistent"],
                            "engine": r["engine"], "roofline": r.get("roofline")})
         out["extra_workloads"] = extras
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out, write_detail=not args.pmc_child)
     ens.close()
 
 

@@ -257,32 +257,6 @@ int pbdx_solver_set_rest_positions(pbdx_solver *s, uint32_t n, const float *x0);
  * m_x[4][3], m_invMasses[4], tet vertex particle ids[4] (indices as floats).  *count = number of contacts (may exceed capacity). */
 #define PBDX_TET_CONTACT_FLOATS 30
 int pbdx_solver_get_tet_contacts(pbdx_solver *s, uint32_t capacity, uint32_t *count, float *out);
-/* Developer aid: the position solve of contact records (as returned by pbdx_solver_get_tet_contacts) applied on the host to pos4 (n x (x, y, z, invMass),
- * in place) in the given order (order == NULL: list order): the sequential loop of TimeStepController.cpp:288-291 with the engine's arithmetic. */
-int pbdx_debug_tet_solve_host(uint32_t n_particles, float *pos4, uint32_t n_contacts, const float *records, const uint32_t *order);
-/* Developer aid: the bounding spheres (centre, radius) of hierarchy `which` (0 points, 1 tets, 2 tets at rest) of a collider as the last
- * detection left them; *count = number of nodes. */
-int pbdx_debug_tet_hulls(pbdx_solver *s, uint32_t collider, int which, uint32_t capacity, uint32_t *count, float *out);
-/* Developer aid: counters of the last detection: contacts, (flags: 1, 2), overlapping leaf pairs, 64-candidate chunks, dependency levels of the
- * solve, generations and node pairs of the traversal's recursion tree. */
-int pbdx_debug_tet_counters(pbdx_solver *s, uint32_t out[8]);
-/* Developer aid: capacities of the detection's scratch (node pairs, overlapping leaf pairs, contacts) and how often it was enlarged: the scratch
- * grows on demand -- an overflow is detected after the detection that caused it, the buffer is made four times as large and the detection repeated. */
-int pbdx_debug_tet_capacity(pbdx_solver *s, uint32_t out[4]);
-/* Developer aid: a sequential float sum (s <- s + x[i], every step rounded) evaluated on the host by the plain loop (*plain) and by the
- * run-by-run procedure the device uses for the long bounding-sphere sums (pbdx_chainsum.h; blocks of per_thread elements, `threads` blocks per
- * window): the two must agree bit for bit.  *single_additions: how many elements fell back to a real addition. */
-int pbdx_debug_chain_sum_host(const float *x, uint64_t n, uint32_t threads, uint32_t per_thread, float *blocked, float *plain, uint64_t *single_additions);
-/* The same on the device (one workgroup, the kernel code of the long bounding-sphere sums): *out must equal the plain loop bit for bit. */
-int pbdx_debug_chain_sum(pbdx_solver *s, const float *x, uint32_t n, float *out);
-/* Developer aid: the device kernel's policy (windows of at most window_max values; an attempt that gains fewer than poor_below values is followed by
- * burst0 << min(consecutive poor attempts, 4) plainly summed values) replayed on the host; stats: attempts, values gained by them, bursts, values in bursts. */
-int pbdx_debug_chain_sum_policy_host(const float *x, uint64_t n, uint32_t window_max, uint32_t poor_below, uint32_t burst0, float *out, uint64_t stats[4]);
-/* The same detection evaluated on the HOST by the same code (pbdx_tetcontact.h is host + device): developer / test aid, no GPU
- * needed.  pos4 / rest4: n x (x, y, z, invMass) records. */
-int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float *rest4, uint32_t n, const pbdx_tet_collider *colliders,
-	float tolerance, uint32_t capacity, uint32_t *count, float *out);
-
 /* XPBD multipliers of batch `batch_index` (order of add_batch calls). */
 int pbdx_solver_get_lambdas(pbdx_solver *s, uint32_t batch_index, uint32_t count, float *out);
 
@@ -380,12 +354,6 @@ int pbdx_solver_set_profiling(pbdx_solver *s, int profile_kernels);
  * that type's launches (event before the launch -> event before the next launch), number of
  * launches, number of projections. */
 int pbdx_solver_get_type_stats(pbdx_solver *s, int type, double *ms, uint64_t *launches, uint64_t *projections);
-/* Counter calibration (developer aid for rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): one streaming
- * kernel over `nbytes` of HBM in one of the engine's access widths.  mode 0: 4-byte reads
- * (kernel calib_read_b32), 1: 16-byte reads (calib_read_b128), 2: 4-byte writes, 3: 16-byte writes, 4: the buffer read EIGHT times in
- * one launch with 16-byte loads (calib_reread_b128: with a buffer between the L2 and the Infinity-Cache size this tells whether a
- * counter sees Infinity-Cache hits). */
-int pbdx_debug_stream(int device, uint64_t nbytes, int mode);
 /* SURVEY 8d algorithmic bytes per projection of a type. */
 uint32_t pbdx_type_algorithmic_bytes(int type);
 /* Device / engine description for logs (device name, CU count, schedule size). */

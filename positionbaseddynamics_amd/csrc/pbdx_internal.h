@@ -3,6 +3,7 @@
 #define PBDX_INTERNAL_H
 
 #include "../../include/pbdx.h"
+#include "../../include/pbdx_debug.h"
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>

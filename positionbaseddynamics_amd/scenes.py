@@ -20,10 +20,21 @@ def rot_x_half_pi():
 
 
 def cloth_spec(n_cols, n_rows, cloth_method, bending_method, cloth_k=None, bending_k=None,
-               width=10.0, height=10.0, T=(0, 1, 0), pin=True, instances=1, instance_offset=(0, 0, 0), instanced=False):
+               width=10.0, height=10.0, T=(0, 1, 0), pin=True, instances=1, instance_offset=(0, 0, 0), instanced=False, first_instance=0):
     """Demos/ClothDemo/main.cpp:132-162 generalised to n_cols x n_rows and K instances.  instanced=True: the K - 1 copies
     are one ("instances", offsets) operation (SimulationModel.addInstances: built, coloured and stored once) instead of
-    K - 1 more rounds of builder calls; both describe the same model."""
+    K - 1 more rounds of builder calls; both describe the same model.
+    first_instance = g0: the K instances are the GLOBAL instances g0 .. g0+K-1 of a larger ensemble (instance g sits at
+    T + g * instance_offset, float arithmetic): what a rank of a sharded job builds (bench.py --workload c4)."""
+    if first_instance:
+        f = np.float32
+        Tg = [tuple(f(T[i]) + f(g) * f(instance_offset[i]) for i in range(3)) for g in range(first_instance, first_instance + instances)]
+        # the shard is built as instance g0 + copies at k * instance_offset: that must land every copy exactly where the
+        # whole job's builder calls put instance g0 + k (true for offsets / translations exactly representable in float)
+        for k in range(instances):
+            if any(f(Tg[0][i]) + f(k) * f(instance_offset[i]) != Tg[k][i] for i in range(3)):
+                raise ValueError("cloth_spec: instance %d of a shard starting at %d would not sit where the unsharded ensemble puts it" % (k, first_instance))
+        return cloth_spec(n_cols, n_rows, cloth_method, bending_method, cloth_k, bending_k, width, height, Tg[0], pin, instances, instance_offset, instanced)
     if instanced and instances > 1:
         ops = cloth_spec(n_cols, n_rows, cloth_method, bending_method, cloth_k, bending_k, width, height, T, pin)
         offs = [tuple(np.float32(k) * np.float32(instance_offset[i]) for i in range(3)) for k in range(1, instances)]

@@ -20,11 +20,6 @@ def _has_gpu():
         return False
 
 
-def pytest_collection_modifyitems(config, items):
-    # a -m gpu run on a box without a GPU must fail loudly rather than silently skip
-    pass
-
-
 @pytest.fixture(scope="session")
 def have_gpu():
     return _has_gpu()

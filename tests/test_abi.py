@@ -10,12 +10,21 @@ import pytest
 from tests import util
 
 HEADER = os.path.join(util.ROOT, "include", "pbdx.h")
+DEBUG_HEADER = os.path.join(util.ROOT, "include", "pbdx_debug.h")
 
 
-def declared_symbols():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(pbdx_[a-z0-9_]+)\s*\(", text)))
+def declared_symbols(headers=(HEADER, DEBUG_HEADER)):
+    syms = set()
+    for h in headers:
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        syms |= set(re.findall(r"\b(pbdx_[a-z0-9_]+)\s*\(", text))
+    return sorted(syms)
+
+
+def test_debug_entry_points_are_not_part_of_the_boundary():
+    """include/pbdx.h is what a reference-side binding sees; developer aids live in include/pbdx_debug.h."""
+    assert not [s for s in declared_symbols((HEADER,)) if s.startswith("pbdx_debug_")]
+    assert all(s.startswith("pbdx_debug_") for s in declared_symbols((DEBUG_HEADER,)))
 
 
 def test_header_declares_the_expected_surface():
@@ -30,7 +39,7 @@ def test_library_exports_every_declared_symbol():
     import positionbaseddynamics_amd._ffi as ffi
     lib = ctypes.CDLL(ffi.LIB_PATH)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
-    assert not missing, "declared in include/pbdx.h but not exported: %s" % missing
+    assert not missing, "declared in include/*.h but not exported: %s" % missing
     bound = {s[0] for s in ffi.SIGNATURES}
     unbound = [s for s in declared_symbols() if s not in bound]
     assert not unbound, "declared but not bound in _ffi.py: %s" % unbound
