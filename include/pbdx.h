@@ -132,6 +132,49 @@ int pbdx_solver_set_positions(pbdx_solver *s, uint32_t n, const float *x);
 int pbdx_solver_get_particles(pbdx_solver *s, uint32_t n,
 	float *x, float *v, float *old_x, float *last_x);
 
+/* ---- Dirty tracking of a host mirror ------------------------------------------------------------
+ * A host application that cannot be instrumented (the reference's ParticleData hands out plain references) is tracked by
+ * FULL-COVERAGE block hashes of its arrays: one 64-bit hash per PBDX_HASH_BLOCK consecutive elements, the XOR over the
+ * block's 32-bit words of pbdx_hash_word(word, index of the word in the array) -- order-free, so the host evaluates it with
+ * as many threads as it likes and the device with one workgroup per block.  A single changed word always changes its
+ * block's hash.  pbdx_solver_get_particles_hashed downloads like pbdx_solver_get_particles and ALSO returns the block hashes
+ * of exactly the bytes it delivered (computed on the device's staging copy: the host does not read 48 MB again to know what
+ * it has); hash arrays hold pbdx_hash_num_blocks(n) values, any of them may be NULL. */
+#define PBDX_HASH_BLOCK 1024u
+#if defined(__HIPCC__)
+#define PBDX_HOST_DEVICE __host__ __device__
+#else
+#define PBDX_HOST_DEVICE
+#endif
+PBDX_HOST_DEVICE static inline uint64_t pbdx_hash_word(uint32_t word, uint32_t index)
+{
+	uint64_t m = (uint64_t)(word ^ (index * 0x9E3779B9u)) * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
+	return m ^ (m >> 31);
+}
+static inline uint32_t pbdx_hash_num_blocks(uint32_t n) { return (n + PBDX_HASH_BLOCK - 1u) / PBDX_HASH_BLOCK; }
+/* hash of block `block` of an array of n elements of elem_words 32-bit words each (host side) */
+static inline uint64_t pbdx_hash_block(const void *base, uint32_t n, uint32_t elem_words, uint32_t block)
+{
+	const uint32_t *w = (const uint32_t *)base;
+	const uint64_t first = (uint64_t)block * PBDX_HASH_BLOCK * elem_words;
+	uint64_t last = first + (uint64_t)PBDX_HASH_BLOCK * elem_words;
+	const uint64_t total = (uint64_t)n * elem_words;
+	uint64_t h = 0, i;
+	if (last > total) last = total;
+	for (i = first; i < last; i++) h ^= pbdx_hash_word(w[i], (uint32_t)i);
+	return h;
+}
+int pbdx_solver_get_particles_hashed(pbdx_solver *s, uint32_t n, float *x, float *v, float *old_x, float *last_x,
+	uint64_t *hash_x, uint64_t *hash_v, uint64_t *hash_old, uint64_t *hash_last);
+int pbdx_solver_get_particles_hashed_f64(pbdx_solver *s, uint32_t n, double *x, double *v, double *old_x, double *last_x,
+	uint64_t *hash_x, uint64_t *hash_v, uint64_t *hash_old, uint64_t *hash_last);
+/* Partial upload: element ranges (num_ranges pairs first, count) of ONE of the caller's arrays replace the device's values;
+ * everything else on the device stays.  `base` is the start of the WHOLE array (element 0), as for pbdx_solver_set_particles.
+ * The particle count must be the uploaded one (a first upload is pbdx_solver_set_particles). */
+enum { PBDX_ARRAY_X = 0, PBDX_ARRAY_V = 1, PBDX_ARRAY_OLD_X = 2, PBDX_ARRAY_LAST_X = 3, PBDX_ARRAY_MASS = 4, PBDX_ARRAY_INV_MASS = 5 };
+int pbdx_solver_update_particle_ranges(pbdx_solver *s, int array, const float *base, uint32_t num_ranges, const uint32_t *ranges);
+int pbdx_solver_update_particle_ranges_f64(pbdx_solver *s, int array, const double *base, uint32_t num_ranges, const uint32_t *ranges);
+
 /* Constraint schedule = the reference's colour groups
  * (SimulationModel::getConstraintGroups(), SimulationModel.cpp:1033-1094).
  * begin -> add_batch* -> end.  `group` is the colour index: groups execute in

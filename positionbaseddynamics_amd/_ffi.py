@@ -117,6 +117,11 @@ SIGNATURES = [
     ("pbdx_solver_set_contact_params", C.c_int, vp, f32, f32, u32),
     ("pbdx_solver_get_num_contacts", C.c_int, vp, C.POINTER(u32)),
     ("pbdx_debug_stream", C.c_int, C.c_int, C.c_uint64, C.c_int),
+    ("pbdx_solver_get_particles_hashed", C.c_int, vp, u32, pf, pf, pf, pf, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)),
+    ("pbdx_solver_get_particles_hashed_f64", C.c_int, vp, u32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)),
+    ("pbdx_solver_update_particle_ranges", C.c_int, vp, C.c_int, pf, u32, pu),
+    ("pbdx_solver_update_particle_ranges_f64", C.c_int, vp, C.c_int, C.POINTER(C.c_double), u32, pu),
     ("pbdx_solver_set_tet_colliders", C.c_int, vp, u32, C.POINTER(TetCollider), f32),
     ("pbdx_solver_set_rest_positions", C.c_int, vp, u32, pf),
     ("pbdx_solver_get_tet_contacts", C.c_int, vp, u32, C.POINTER(u32), pf),

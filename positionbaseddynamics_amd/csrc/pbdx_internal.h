@@ -24,6 +24,8 @@ struct TypeInfo
 	bool xpbd;                    // owns a lambda stream
 };
 const TypeInfo *type_info(int type);
+// structural checks of deformable colliders (pbdx_tetcontact.cpp): ranges, hierarchies are trees of depth <= 62, friction 0, indices < 2^24
+int validate_tet_colliders(uint32_t n, const pbdx_tet_collider *colliders, uint32_t n_particles);
 
 // ---- host model (pbdx_model.cpp) -------------------------------------------
 struct HostConstraint

@@ -749,6 +749,40 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float4 *__restrict__ 
 	const float4 v = src[i];
 	xyz[3 * (size_t)i] = (T)v.x; xyz[3 * (size_t)i + 1] = (T)v.y; xyz[3 * (size_t)i + 2] = (T)v.z;
 }
+// partial upload (pbdx_solver_update_particle_ranges): elements [first, first + count) of one staged array
+template <class T>
+__global__ __launch_bounds__(256) void update_xyz_kernel(const T *__restrict__ xyz, float4 *__restrict__ dst, uint32_t first, uint32_t count)
+{
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= count) return;
+	const size_t i = (size_t)first + k;
+	float4 v = dst[i];
+	v.x = (float)xyz[3 * i]; v.y = (float)xyz[3 * i + 1]; v.z = (float)xyz[3 * i + 2];
+	dst[i] = v;
+}
+template <class T>
+__global__ __launch_bounds__(256) void update_w_kernel(const T *__restrict__ w, float4 *__restrict__ dst, uint32_t first, uint32_t count)
+{
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= count) return;
+	const size_t i = (size_t)first + k;
+	dst[i].w = (float)w[i];
+}
+// block hashes of a staged host array (include/pbdx.h: pbdx_hash_word / pbdx_hash_block): one workgroup per block of
+// PBDX_HASH_BLOCK elements, XOR over the block's 32-bit words
+__global__ __launch_bounds__(256) void hash_blocks_kernel(const uint32_t *__restrict__ words, uint64_t total_words, uint32_t words_per_block, uint64_t *__restrict__ out)
+{
+	__shared__ uint64_t part[4];
+	const uint64_t first = (uint64_t)blockIdx.x * words_per_block;
+	uint64_t last = first + words_per_block;
+	if (last > total_words) last = total_words;
+	uint64_t h = 0;
+	for (uint64_t i = first + threadIdx.x; i < last; i += 256) h ^= pbdx_hash_word(words[i], (uint32_t)i);
+	for (int o = 32; o > 0; o >>= 1) h ^= __shfl_xor(h, o, 64);
+	if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = h;
+	__syncthreads();
+	if (threadIdx.x == 0) out[blockIdx.x] = part[0] ^ part[1] ^ part[2] ^ part[3];
+}
 __global__ __launch_bounds__(256) void set_xyz_kernel(const float *__restrict__ xyz, float4 *__restrict__ dst, uint32_t n)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -943,6 +977,7 @@ struct pbdx_solver
 	uint32_t n = 0;
 	float4 *d_pos[2] = { nullptr, nullptr };
 	float4 *d_vel = nullptr, *d_old = nullptr, *d_last = nullptr;
+	uint64_t *d_hash = nullptr; uint32_t hash_blocks = 0;   // block hashes of the staged arrays (pbdx_solver_get_particles_hashed)
 	float *d_stage = nullptr;            // 4 x 3n + 2n values: device staging of the caller's packed arrays (floats; doubles once a double host called)
 	size_t stage_elem = sizeof(float);
 	std::vector<float> h_x;              // positions at upload time (tile partition only)
@@ -1134,6 +1169,7 @@ struct pbdx_solver
 		for (float4 **p : { &d_pos[0], &d_pos[1], &d_vel, &d_old, &d_last })
 			if (*p) { (void)hipFree(*p); *p = nullptr; }
 		if (d_stage) { (void)hipFree(d_stage); d_stage = nullptr; }
+		if (d_hash) { (void)hipFree(d_hash); d_hash = nullptr; hash_blocks = 0; }
 		for (float4 *&p : d_snap) if (p) { (void)hipFree(p); p = nullptr; }
 		if (d_rest) { (void)hipFree(d_rest); d_rest = nullptr; }
 		rest_set = false;
@@ -2079,6 +2115,74 @@ int get_particles_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, T *last
 	return PBDX_OK;
 }
 
+template <class T>
+int get_particles_hashed_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, T *last_x, uint64_t *hx, uint64_t *hv, uint64_t *ho, uint64_t *hl)
+{
+	if (!s || n != s->n) { set_error("get_particles: particle count mismatch (%u vs %u)", n, s ? s->n : 0); return PBDX_ERR_INVALID; }
+	if (!n) return PBDX_OK;
+	HIPCHECK(hipSetDevice(s->device));
+	{ int rs = ensure_stage(s, sizeof(T)); if (rs) return rs; }
+	const uint32_t nb = pbdx_hash_num_blocks(n);
+	if (s->hash_blocks < nb)
+	{
+		HIPCHECK(hipStreamSynchronize(s->stream));
+		if (s->d_hash) { (void)hipFree(s->d_hash); s->d_hash = nullptr; }
+		HIPCHECK(hipMalloc(&s->d_hash, (size_t)4 * nb * sizeof(uint64_t)));
+		s->hash_blocks = nb;
+	}
+	struct { T *dst; const float4 *src; uint64_t *h; } jobs[4] = { { x, s->d_pos[0], hx }, { v, s->d_vel, hv }, { old_x, s->d_old, ho }, { last_x, s->d_last, hl } };
+	const size_t b3 = (size_t)3 * n * sizeof(T);
+	const uint32_t elem_words = 3 * (uint32_t)(sizeof(T) / 4);
+	int k = 0;
+	for (auto &j : jobs)
+	{
+		const int q = k++;
+		T *st = reinterpret_cast<T *>(s->d_stage) + (size_t)3 * n * q;
+		if (!j.dst && !j.h) continue;
+		if (j.dst) s->pin(j.dst, b3);
+		hipLaunchKernelGGL(unpack_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s->stream, j.src, st, n);
+		if (j.h)
+			hipLaunchKernelGGL(hash_blocks_kernel, dim3(nb), dim3(256), 0, s->stream, reinterpret_cast<const uint32_t *>(st), (uint64_t)n * elem_words,
+				PBDX_HASH_BLOCK * elem_words, s->d_hash + (size_t)q * nb);
+		HIPCHECK(hipGetLastError());
+		if (j.dst) HIPCHECK(hipMemcpyAsync(j.dst, st, b3, hipMemcpyDeviceToHost, s->stream));
+		if (j.h) HIPCHECK(hipMemcpyAsync(j.h, s->d_hash + (size_t)q * nb, (size_t)nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+	}
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	return PBDX_OK;
+}
+
+template <class T>
+int update_ranges_impl(pbdx_solver *s, int array, const T *base, uint32_t num_ranges, const uint32_t *ranges)
+{
+	if (!s || !base || (num_ranges && !ranges) || array < PBDX_ARRAY_X || array > PBDX_ARRAY_INV_MASS) { set_error("update_particle_ranges: bad arguments"); return PBDX_ERR_INVALID; }
+	if (!s->n || !s->d_pos[0]) { set_error("update_particle_ranges: no particle image yet (pbdx_solver_set_particles first)"); return PBDX_ERR_INVALID; }
+	for (uint32_t r = 0; r < num_ranges; r++)
+		if (ranges[2 * r] > s->n || ranges[2 * r + 1] > s->n - ranges[2 * r]) { set_error("update_particle_ranges: range %u (%u, %u) outside the %u particles", r, ranges[2 * r], ranges[2 * r + 1], s->n); return PBDX_ERR_INVALID; }
+	if (!num_ranges) return PBDX_OK;
+	HIPCHECK(hipSetDevice(s->device));
+	{ int rs = ensure_stage(s, sizeof(T)); if (rs) return rs; }
+	const uint32_t n = s->n;
+	const bool vec = array <= PBDX_ARRAY_LAST_X;
+	// the staging slot of the array (layout of set_particles_impl)
+	T *st = reinterpret_cast<T *>(s->d_stage) + (vec ? (size_t)3 * n * array : (size_t)12 * n + (size_t)n * (array - PBDX_ARRAY_MASS));
+	const size_t per = vec ? 3 : 1;
+	s->pin(base, per * n * sizeof(T));
+	float4 *dst = array == PBDX_ARRAY_X ? s->d_pos[0] : array == PBDX_ARRAY_V ? s->d_vel : array == PBDX_ARRAY_OLD_X ? s->d_old : array == PBDX_ARRAY_LAST_X ? s->d_last :
+		array == PBDX_ARRAY_MASS ? s->d_vel : s->d_pos[0];
+	for (uint32_t r = 0; r < num_ranges; r++)
+	{
+		const uint32_t first = ranges[2 * r], count = ranges[2 * r + 1];
+		if (!count) continue;
+		HIPCHECK(hipMemcpyAsync(st + per * first, base + per * first, per * count * sizeof(T), hipMemcpyHostToDevice, s->stream));
+		if (vec) hipLaunchKernelGGL(update_xyz_kernel<T>, dim3((count + 255) / 256), dim3(256), 0, s->stream, (const T *)st, dst, first, count);
+		else hipLaunchKernelGGL(update_w_kernel<T>, dim3((count + 255) / 256), dim3(256), 0, s->stream, (const T *)st, dst, first, count);
+	}
+	HIPCHECK(hipGetLastError());
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	return PBDX_OK;
+}
+
 
 } // namespace
 
@@ -2189,6 +2293,25 @@ int pbdx_solver_get_particles(pbdx_solver *s, uint32_t n, float *x, float *v, fl
 int pbdx_solver_get_particles_f64(pbdx_solver *s, uint32_t n, double *x, double *v, double *old_x, double *last_x)
 {
 	return get_particles_impl<double>(s, n, x, v, old_x, last_x);
+}
+
+int pbdx_solver_get_particles_hashed(pbdx_solver *s, uint32_t n, float *x, float *v, float *old_x, float *last_x,
+	uint64_t *hash_x, uint64_t *hash_v, uint64_t *hash_old, uint64_t *hash_last)
+{
+	return get_particles_hashed_impl<float>(s, n, x, v, old_x, last_x, hash_x, hash_v, hash_old, hash_last);
+}
+int pbdx_solver_get_particles_hashed_f64(pbdx_solver *s, uint32_t n, double *x, double *v, double *old_x, double *last_x,
+	uint64_t *hash_x, uint64_t *hash_v, uint64_t *hash_old, uint64_t *hash_last)
+{
+	return get_particles_hashed_impl<double>(s, n, x, v, old_x, last_x, hash_x, hash_v, hash_old, hash_last);
+}
+int pbdx_solver_update_particle_ranges(pbdx_solver *s, int array, const float *base, uint32_t num_ranges, const uint32_t *ranges)
+{
+	return update_ranges_impl<float>(s, array, base, num_ranges, ranges);
+}
+int pbdx_solver_update_particle_ranges_f64(pbdx_solver *s, int array, const double *base, uint32_t num_ranges, const uint32_t *ranges)
+{
+	return update_ranges_impl<double>(s, array, base, num_ranges, ranges);
 }
 
 int pbdx_solver_begin_schedule(pbdx_solver *s)
@@ -2699,38 +2822,7 @@ int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 static int set_tet_colliders_impl(pbdx_solver *s, uint32_t n, const pbdx_tet_collider *colliders, float tolerance)
 {
 	if (!s || (n && !colliders) || n > 256) { set_error("set_tet_colliders: bad arguments (at most 256 colliders)"); return PBDX_ERR_INVALID; }
-	for (uint32_t i = 0; i < n; i++)
-	{
-		const pbdx_tet_collider &c = colliders[i];
-		if (c.shape < PBDX_SHAPE_BOX || c.shape > PBDX_SHAPE_HOLLOW_BOX) { set_error("set_tet_colliders: unknown shape %d", c.shape); return PBDX_ERR_UNSUPPORTED; }
-		if (c.friction != 0.0f)
-		{
-			set_error("set_tet_colliders: friction of a deformable-deformable contact must be 0 -- the reference's friction impulse for these contacts reads an uninitialised multiplier (Constraints.h:553)");
-			return PBDX_ERR_UNSUPPORTED;
-		}
-		if ((uint64_t)c.first_particle + c.num_vertices > s->n || !c.num_vertices) { set_error("set_tet_colliders: collider %u exceeds the %u uploaded particles", i, s->n); return PBDX_ERR_INVALID; }
-		if (!c.tets || !c.num_tets) { set_error("set_tet_colliders: collider %u has no tets", i); return PBDX_ERR_INVALID; }
-		for (const pbdx_bvh *b : { &c.points, &c.tets_bvh, &c.tets_rest })
-			if (!b->num_nodes || !b->entities || !b->nodes) { set_error("set_tet_colliders: collider %u lacks a bounding-sphere hierarchy", i); return PBDX_ERR_INVALID; }
-		if (!c.tets_rest.hulls) { set_error("set_tet_colliders: the rest-pose hierarchy of collider %u needs its spheres", i); return PBDX_ERR_INVALID; }
-		// structure checks: children and entity ranges in range (the device code trusts them)
-		const pbdx_bvh *bs[3] = { &c.points, &c.tets_bvh, &c.tets_rest };
-		const uint32_t ents[3] = { c.num_vertices, c.num_tets, c.num_tets };
-		for (int q = 0; q < 3; q++)
-		{
-			if (bs[q]->num_entities != ents[q]) { set_error("set_tet_colliders: hierarchy %d of collider %u has %u entities, expected %u", q, i, bs[q]->num_entities, ents[q]); return PBDX_ERR_INVALID; }
-			for (uint32_t e = 0; e < ents[q]; e++) if (bs[q]->entities[e] >= ents[q]) { set_error("set_tet_colliders: entity out of range"); return PBDX_ERR_INVALID; }
-			for (uint32_t nd = 0; nd < bs[q]->num_nodes; nd++)
-			{
-				const int32_t *k = bs[q]->nodes + 4 * nd;
-				const bool leaf = k[0] < 0 && k[1] < 0;
-				if ((!leaf && (k[0] < 0 || k[1] < 0 || (uint32_t)k[0] >= bs[q]->num_nodes || (uint32_t)k[1] >= bs[q]->num_nodes)) || k[2] < 0 || k[3] <= 0 ||
-					(uint64_t)k[2] + (uint64_t)k[3] > ents[q])
-				{ set_error("set_tet_colliders: node %u of hierarchy %d of collider %u is malformed", nd, q, i); return PBDX_ERR_INVALID; }
-			}
-		}
-		for (uint32_t t = 0; t < 4 * c.num_tets; t++) if (c.tets[t] >= c.num_vertices) { set_error("set_tet_colliders: tet vertex out of range"); return PBDX_ERR_INVALID; }
-	}
+	{ const int rv = validate_tet_colliders(n, colliders, s->n); if (rv) return rv; }
 	HIPCHECK(hipSetDevice(s->device));
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	s->free_tet_colliders();

@@ -48,12 +48,73 @@ void contact_to_floats(const TetContact &c, float *o)
 	for (int v = 0; v < 4; v++) { o[22 + v] = c.w[v]; o[26 + v] = (float)c.vert[v]; }
 }
 
+
+// Everything the device (and the host evaluation of the same header code) trusts about a set of deformable colliders; shared by
+// pbdx_solver_set_tet_colliders and pbdx_debug_tet_contacts.
+int validate_tet_colliders(uint32_t n, const pbdx_tet_collider *colliders, uint32_t n_particles)
+{
+	for (uint32_t i = 0; i < n; i++)
+	{
+		const pbdx_tet_collider &c = colliders[i];
+		if (c.shape < PBDX_SHAPE_BOX || c.shape > PBDX_SHAPE_HOLLOW_BOX) { set_error("set_tet_colliders: unknown shape %d", c.shape); return PBDX_ERR_UNSUPPORTED; }
+		if (c.friction != 0.0f)
+		{
+			set_error("set_tet_colliders: friction of a deformable-deformable contact must be 0 -- the reference's friction impulse for these contacts reads an uninitialised multiplier (Constraints.h:553)");
+			return PBDX_ERR_UNSUPPORTED;
+		}
+		if ((uint64_t)c.first_particle + c.num_vertices > n_particles || !c.num_vertices) { set_error("set_tet_colliders: collider %u exceeds the %u uploaded particles", i, n_particles); return PBDX_ERR_INVALID; }
+		if (!c.tets || !c.num_tets) { set_error("set_tet_colliders: collider %u has no tets", i); return PBDX_ERR_INVALID; }
+		for (const pbdx_bvh *b : { &c.points, &c.tets_bvh, &c.tets_rest })
+			if (!b->num_nodes || !b->entities || !b->nodes) { set_error("set_tet_colliders: collider %u lacks a bounding-sphere hierarchy", i); return PBDX_ERR_INVALID; }
+		if (!c.tets_rest.hulls) { set_error("set_tet_colliders: the rest-pose hierarchy of collider %u needs its spheres", i); return PBDX_ERR_INVALID; }
+		// structure checks: children and entity ranges in range (the device code trusts them)
+		const pbdx_bvh *bs[3] = { &c.points, &c.tets_bvh, &c.tets_rest };
+		const uint32_t ents[3] = { c.num_vertices, c.num_tets, c.num_tets };
+		for (int q = 0; q < 3; q++)
+		{
+			if (bs[q]->num_entities != ents[q]) { set_error("set_tet_colliders: hierarchy %d of collider %u has %u entities, expected %u", q, i, bs[q]->num_entities, ents[q]); return PBDX_ERR_INVALID; }
+			for (uint32_t e = 0; e < ents[q]; e++) if (bs[q]->entities[e] >= ents[q]) { set_error("set_tet_colliders: entity out of range"); return PBDX_ERR_INVALID; }
+			for (uint32_t nd = 0; nd < bs[q]->num_nodes; nd++)
+			{
+				const int32_t *k = bs[q]->nodes + 4 * nd;
+				const bool leaf = k[0] < 0 && k[1] < 0;
+				if ((!leaf && (k[0] < 0 || k[1] < 0 || (uint32_t)k[0] >= bs[q]->num_nodes || (uint32_t)k[1] >= bs[q]->num_nodes)) || k[2] < 0 || k[3] <= 0 ||
+					(uint64_t)k[2] + (uint64_t)k[3] > ents[q])
+				{ set_error("set_tet_colliders: node %u of hierarchy %d of collider %u is malformed", nd, q, i); return PBDX_ERR_INVALID; }
+			}
+		}
+		// ... and each hierarchy is a TREE rooted at node 0 (every node reached at most once: no cycles, no shared subtrees) of depth <= 62:
+		// the device walks it with fixed stacks (find_ref_tet_at: 64 entries = depth + 2; the pair traversal: generations) and never checks again
+		for (int q = 0; q < 3; q++)
+		{
+			std::vector<uint8_t> seen(bs[q]->num_nodes, 0);
+			std::vector<std::pair<uint32_t, uint32_t> > stack(1, std::make_pair(0u, 0u));
+			while (!stack.empty())
+			{
+				const uint32_t nd = stack.back().first, depth = stack.back().second;
+				stack.pop_back();
+				if (seen[nd]) { set_error("set_tet_colliders: hierarchy %d of collider %u is not a tree (node %u is reached twice)", q, i, nd); return PBDX_ERR_INVALID; }
+				seen[nd] = 1;
+				if (depth > 62) { set_error("set_tet_colliders: hierarchy %d of collider %u is deeper than 62 levels", q, i); return PBDX_ERR_INVALID; }
+				const int32_t *k = bs[q]->nodes + 4 * nd;
+				if (k[0] >= 0 || k[1] >= 0) { stack.push_back(std::make_pair((uint32_t)k[0], depth + 1)); stack.push_back(std::make_pair((uint32_t)k[1], depth + 1)); }
+			}
+		}
+		for (uint32_t t = 0; t < 4 * c.num_tets; t++) if (c.tets[t] >= c.num_vertices) { set_error("set_tet_colliders: tet vertex out of range"); return PBDX_ERR_INVALID; }
+		// the 30-float contact records (pbdx_solver_get_tet_contacts) carry particle / tet indices as floats: exact up to 2^24
+		if ((uint64_t)c.first_particle + c.num_vertices > (1u << 24) || c.num_tets > (1u << 24))
+		{ set_error("set_tet_colliders: collider %u reaches particle / tet indices above 2^24 (the contact records store indices as floats)", i); return PBDX_ERR_UNSUPPORTED; }
+	}
+	return PBDX_OK;
+}
+
 } // namespace pbdx
 
 extern "C" int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float *rest4, uint32_t n, const pbdx_tet_collider *colliders,
 	float tolerance, uint32_t capacity, uint32_t *count, float *out)
 {
 	if (!pos4 || !rest4 || (n && !colliders) || !count) { set_error("debug_tet_contacts: null argument"); return PBDX_ERR_INVALID; }
+	{ const int rv = validate_tet_colliders(n, colliders, n_particles); if (rv) return rv; }
 	const P4 *pos = reinterpret_cast<const P4 *>(pos4), *x0 = reinterpret_cast<const P4 *>(rest4);
 	std::vector<HostTetCollider> cs(n);
 	std::vector<float> aabb((size_t)6 * n);

@@ -164,7 +164,7 @@ PBDX_HD bool find_ref_tet_at(const TetColliderView &c, const P4 *x0 /* rest posi
 				any = true;
 			}
 		}
-		else if (sphere_contains(b.hulls[node], X) && sp + 2 <= 64)
+		else if (sphere_contains(b.hulls[node], X))     // (sp + 2 <= 64 always: pbdx_solver_set_tet_colliders admits only trees of depth <= 62, and a depth-first walk holds at most depth + 2 entries)
 		{
 			stack[sp++] = (uint32_t)c1;          // children[0] is visited first
 			stack[sp++] = (uint32_t)c0;

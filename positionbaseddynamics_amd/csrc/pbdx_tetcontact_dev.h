@@ -427,7 +427,7 @@ __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long lo
 __device__ __forceinline__ unsigned long long pack2(uint32_t lo, uint32_t hi) { return (unsigned long long)lo | ((unsigned long long)hi << 32); }
 // all workgroups of the launch: every thread's (written-through) stores have completed, then one arrival per workgroup; returns false if
 // the wait was abandoned (a workgroup never arrived within ~50 ms)
-__device__ inline bool grid_barrier(uint32_t *trav, uint32_t &target)
+__device__ inline bool grid_barrier(uint32_t *trav, uint32_t &target, uint32_t *counters)
 {
 	__shared__ uint32_t s_ok;
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -441,7 +441,9 @@ __device__ inline bool grid_barrier(uint32_t *trav, uint32_t &target)
 		while (ld_agent(&trav[kTrArrive]) < target)
 		{
 			__builtin_amdgcn_s_sleep(1);
-			if (wall_clock64() - t0 > 5000000ull) { ok = 0u; st_agent(&trav[kTrBad], 2u); break; }
+			// abandoned: the flag the HOST reads back after every detection (kTcStack = 2) is raised by whoever gives up, so that the
+			// step reports the failure whichever workgroup was late (the later kernels then see an empty list, but the step fails)
+			if (wall_clock64() - t0 > 5000000ull) { ok = 0u; st_agent(&trav[kTrBad], 2u); st_agent(&counters[kTcStack], 2u); break; }
 		}
 		s_ok = ok;
 	}
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(256) void tet_traverse_kernel(const TetColliderView
 			st_agent(&trav[kTrCount], roots);
 		}
 	}
-	if (!grid_barrier(trav, target)) return;
+	if (!grid_barrier(trav, target, w.counters)) return;
 	const uint32_t roots = ld_agent(&trav[kTrCount]);
 	if (tid < kCached && tid < roots)
 	{
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(256) void tet_traverse_kernel(const TetColliderView
 				if (live[u]) { st_agent(&w.node_cnt[idx], cnt); st_agent(&w.node_child[idx], child); }
 			}
 		}
-		if (!grid_barrier(trav, target)) return;
+		if (!grid_barrier(trav, target, w.counters)) return;
 		base = ge;
 		generations++;
 	}
@@ -601,7 +603,7 @@ __global__ __launch_bounds__(256) void tet_traverse_kernel(const TetColliderView
 			const uint32_t child = ld_agent(&w.node_child[idx]);
 			if (child != kTcNone) st_agent(&w.node_cnt[idx], ld_agent(&w.node_cnt[child]) + ld_agent(&w.node_cnt[child + 1]));
 		}
-		if (!grid_barrier(trav, target)) return;
+		if (!grid_barrier(trav, target, w.counters)) return;
 	}
 	// top-down: where every subtree's leaf pairs / chunks start
 	if (blockIdx.x == 0)
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(256) void tet_traverse_kernel(const TetColliderView
 		}
 		if (tid == 0) { st_agent(&trav[kTrLeaves], leaves); st_agent(&trav[kTrChunks], chunks); }
 	}
-	if (!grid_barrier(trav, target)) return;
+	if (!grid_barrier(trav, target, w.counters)) return;
 	const uint32_t leaves = ld_agent(&trav[kTrLeaves]), chunks = ld_agent(&trav[kTrChunks]);
 	if (leaves > w.front_cap || chunks > w.chunk_cap)
 	{
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(256) void tet_traverse_kernel(const TetColliderView
 				}
 			}
 		}
-		if (g + 1 < generations && !grid_barrier(trav, target)) return;
+		if (g + 1 < generations && !grid_barrier(trav, target, w.counters)) return;
 	}
 	if (gtid == 0)
 	{

@@ -8,6 +8,7 @@
 #include "Utils/Timing.h"
 #include <stdio.h>
 #include <string.h>
+#include <omp.h>
 
 using namespace PBD;
 
@@ -80,16 +81,37 @@ namespace
 		for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
 		return h;
 	}
-	// hash of a strided sample (at most ~4096 elements of `elem` bytes, first and last always included) of a packed array
-	inline uint64_t sampleHash(const void *base, size_t count, size_t elem)
+	// full-coverage block hashes of a packed host array (include/pbdx.h: pbdx_hash_block): every word of the array is hashed,
+	// PBDX_HASH_BLOCK elements per 64-bit hash.  The pass is bandwidth-bound (one read of the array) and runs on a handful of
+	// threads when the array is large -- the host application is an OpenMP program anyway (TimeStepController.cpp:270-286);
+	// the thread count is stated explicitly because hosts commonly run the solver loops with omp_set_num_threads(1).
+	void hashBlocks(const void *base, uint32_t n, uint32_t elemWords, std::vector<uint64_t> &out)
 	{
-		uint64_t h = 1469598103934665603ull ^ (uint64_t)count;
-		if (!count) return h;
-		const size_t stride = count > 4096 ? count / 4096 : 1;
-		const unsigned char *b = (const unsigned char *)base;
-		for (size_t i = 0; i < count; i += stride) h = fnv(h, b + i * elem, elem);
-		return fnv(h, b + (count - 1) * elem, elem);
+		const int nb = (int)pbdx_hash_num_blocks(n);
+		out.resize((size_t)nb);
+		int threads = (size_t)n * elemWords * 4 >= ((size_t)1 << 20) ? omp_get_num_procs() : 1;
+		if (threads > 16) threads = 16;
+		#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+		for (int b = 0; b < nb; b++) out[(size_t)b] = pbdx_hash_block(base, n, elemWords, (uint32_t)b);
 	}
+	// element ranges (first, count pairs; adjacent blocks merged) covered by the blocks whose hash differs
+	void changedRanges(const std::vector<uint64_t> &was, const std::vector<uint64_t> &now, uint32_t n, std::vector<uint32_t> &ranges)
+	{
+		ranges.clear();
+		const size_t nb = now.size();
+		if (was.size() != nb) { if (n) { ranges.push_back(0); ranges.push_back(n); } return; }
+		for (size_t b = 0; b < nb; b++)
+		{
+			if (was[b] == now[b]) continue;
+			const uint32_t first = (uint32_t)(b * PBDX_HASH_BLOCK);
+			const uint32_t count = n - first < PBDX_HASH_BLOCK ? n - first : PBDX_HASH_BLOCK;
+			if (!ranges.empty() && ranges[ranges.size() - 2] + ranges.back() == first) ranges.back() += count;
+			else { ranges.push_back(first); ranges.push_back(count); }
+		}
+		// many scattered edits: one range over everything costs less than hundreds of small copies
+		if (ranges.size() > 2 * 256) { ranges.clear(); ranges.push_back(0); ranges.push_back(n); }
+	}
+	const uint32_t kVecWords = 3 * (uint32_t)(sizeof(Real) / 4), kScalarWords = (uint32_t)(sizeof(Real) / 4);
 	static_assert(sizeof(Vector3r) == 3 * sizeof(Real), "ParticleData's std::vector<Vector3r> must be a packed Real[3] array (Common/Common.h:31, Eigen::DontAlign)");
 }
 
@@ -100,7 +122,7 @@ TimeStepControllerHIP::TimeStepControllerHIP(int device) :
 	m_supportedFor(nullptr), m_supportedConstraints(0), m_supportedBodies(0), m_supportedObjects(0), m_supported(false), m_accelValid(false), m_tetSignature(0)
 {
 	m_accelGravity[0] = m_accelGravity[1] = m_accelGravity[2] = 0;
-	for (int k = 0; k < 5; k++) m_hostHash[k] = 0;
+	m_fullParameterScan = false; m_partialUploads = 0;
 	if (pbdx_solver_create(&m_solver, device) != PBDX_OK)
 	{
 		LOG_ERR << "TimeStepControllerHIP: " << pbdx_last_error() << " -- every step() will fail (no CPU path)";
@@ -198,7 +220,22 @@ bool TimeStepControllerHIP::supported(SimulationModel &model)
 	const size_t nObjects = m_collisionDetection != NULL ? m_collisionDetection->getCollisionObjects().size() : 0;
 	if (m_supportedFor == (const void *)&model && m_supportedConstraints == model.getConstraints().size() &&
 		m_supportedBodies == model.getRigidBodies().size() && m_supportedObjects == nObjects && model.m_groupsInitialized && m_scheduleValid)
+	{
+		// coefficients are host-mutable between steps: the friction rule for deformable-deformable contacts is checked every step
+		// (O(number of tet collision objects))
+		if (m_supported && m_collisionDetection != NULL)
+		{
+			unsigned int tetObjects = 0; bool friction = false;
+			for (CollisionDetection::CollisionObject *co : m_collisionDetection->getCollisionObjects())
+				if (co->m_bodyType == CollisionDetection::CollisionObject::TetModelCollisionObjectType)
+				{
+					tetObjects++;
+					if (model.getTetModels()[co->m_bodyIndex]->getFrictionCoeff() != 0.0) friction = true;
+				}
+			if (tetObjects > 1 && friction) return false;
+		}
 		return m_supported;
+	}
 	m_supportedFor = (const void *)&model; m_supportedConstraints = model.getConstraints().size();
 	m_supportedBodies = model.getRigidBodies().size(); m_supportedObjects = nObjects;
 	m_supported = false;
@@ -329,6 +366,20 @@ bool TimeStepControllerHIP::uploadTetColliders(SimulationModel &model, float tol
 	{
 		const unsigned int n = model.getParticles().size();
 		sig = fnv(fnv(fnv(1469598103934665603ull, objs.data(), objs.size() * sizeof(objs[0])), &tolerance, sizeof(tolerance)), &n, sizeof(n));
+		// everything the engine's copy of a collider was made from and the host can change at run time: distance field, flags,
+		// coefficients, the model's rest frame, the extent of the three hierarchies (a fresh initTetBVH)
+		for (D::DistanceFieldCollisionObject *co : objs)
+		{
+			TetModel *tm = model.getTetModels()[co->m_bodyIndex];
+			int shape = 0; float params[4];
+			analyticShape(co, &shape, params);
+			const int flags[3] = { shape, co->m_invertSDF < 0 ? 1 : 0, co->m_testMesh ? 1 : 0 };
+			const Real coeff[2] = { tm->getFrictionCoeff(), tm->getRestitutionCoeff() };
+			const unsigned int extent[8] = { co->m_bodyIndex, tm->getIndexOffset(), tm->getParticleMesh().numVertices(), tm->getParticleMesh().numTets(),
+				co->m_bvh.node(0).n, co->m_bvhTets.node(0).n, co->m_bvhTets0.node(0).n, (unsigned int)co->m_bvh.node(0).children[0] };
+			sig = fnv(fnv(fnv(fnv(sig, flags, sizeof(flags)), params, sizeof(params)), coeff, sizeof(coeff)), extent, sizeof(extent));
+			sig = fnv(fnv(sig, &tm->getInitialX()[0], 3 * sizeof(Real)), tm->getInitialR().data(), 9 * sizeof(Real));
+		}
 		if (!sig) sig = 1;
 	}
 	if (sig == m_tetSignature) return true;
@@ -379,35 +430,65 @@ bool TimeStepControllerHIP::uploadParticles(SimulationModel &model)
 {
 	ParticleData &pd = model.getParticles();
 	const unsigned int n = pd.size();
-	if (n != m_numParticles) { m_scheduleValid = false; m_accelValid = false; m_invMass32.clear(); m_invMass64.clear(); }      // the engine drops its schedule with the old particle image
+	if (n != m_numParticles) { m_scheduleValid = false; }      // the engine drops its schedule with the old particle image
 	m_numParticles = n;
 	m_uploads++;
+	m_accelValid = false;
+	// a full upload always gathers the inverse masses afresh (one linear pass, negligible next to the transfer): the host is
+	// authoritative and ParticleData::setMass may have pinned / released any particle since the last upload
+	m_invMass.resize(n);
+	for (unsigned int i = 0; i < n; i++) m_invMass[i] = pd.getInvMass(i);
 	int r;
 #ifdef USE_DOUBLE
-	if (m_invMass64.size() != n || m_hostDirty || (n && sampleHash(&pd.getMass(0), n, sizeof(Real)) != m_hostHash[4]))
-	{
-		m_invMass64.resize(n);
-		for (unsigned int i = 0; i < n; i++) m_invMass64[i] = pd.getInvMass(i);
-		m_accelValid = false;
-	}
 	r = n ? pbdx_solver_set_particles_f64(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0],
-		&pd.getMass(0), m_invMass64.data()) : PBDX_OK;
+		&pd.getMass(0), m_invMass.data()) : PBDX_OK;
 #else
-	// (gathered again only when the masses changed: sampled hash, or markHostDirty())
-	if (m_invMass32.size() != n || m_hostDirty || (n && sampleHash(&pd.getMass(0), n, sizeof(Real)) != m_hostHash[4]))
-	{
-		m_invMass32.resize(n);
-		for (unsigned int i = 0; i < n; i++) m_invMass32[i] = pd.getInvMass(i);
-		m_accelValid = false;
-	}
 	r = n ? pbdx_solver_set_particles(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0],
-		&pd.getMass(0), m_invMass32.data()) : PBDX_OK;
+		&pd.getMass(0), m_invMass.data()) : PBDX_OK;
 #endif
 	if (r != PBDX_OK) return false;
 	m_imageValid = true;
 	m_deviceAhead = false;
 	m_hostDirty = false;
-	hashHostState(model, m_hostHash);
+	hashHostState(model, m_blockHash);
+	return true;
+}
+
+// Host is current (nothing newer on the device): only the blocks the host wrote since the last upload / download go to the
+// device.  Changed masses re-derive the inverse masses of their blocks (ParticleData::setMass, ParticleData.h:239-246).
+bool TimeStepControllerHIP::uploadChanges(SimulationModel &model, std::vector<uint64_t> now[5])
+{
+	ParticleData &pd = model.getParticles();
+	const unsigned int n = pd.size();
+	const Real *base[5] = { &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0], &pd.getMass(0) };
+	std::vector<uint32_t> ranges;
+	bool any = false;
+	for (int k = 0; k < 5; k++)
+	{
+		changedRanges(m_blockHash[k], now[k], n, ranges);
+		if (ranges.empty()) continue;
+		any = true;
+		const uint32_t nr = (uint32_t)(ranges.size() / 2);
+#ifdef USE_DOUBLE
+		if (pbdx_solver_update_particle_ranges_f64(m_solver, k, base[k], nr, ranges.data()) != PBDX_OK) return false;
+#else
+		if (pbdx_solver_update_particle_ranges(m_solver, k, base[k], nr, ranges.data()) != PBDX_OK) return false;
+#endif
+		if (k == 4)
+		{
+			if (m_invMass.size() != n) { m_invMass.resize(n); ranges.assign(1, 0u); ranges.push_back(n); }
+			for (size_t r = 0; r + 1 < ranges.size(); r += 2)
+				for (uint32_t i = ranges[r]; i < ranges[r] + ranges[r + 1]; i++) m_invMass[i] = pd.getInvMass(i);
+#ifdef USE_DOUBLE
+			if (pbdx_solver_update_particle_ranges_f64(m_solver, PBDX_ARRAY_INV_MASS, m_invMass.data(), (uint32_t)(ranges.size() / 2), ranges.data()) != PBDX_OK) return false;
+#else
+			if (pbdx_solver_update_particle_ranges(m_solver, PBDX_ARRAY_INV_MASS, m_invMass.data(), (uint32_t)(ranges.size() / 2), ranges.data()) != PBDX_OK) return false;
+#endif
+			m_accelValid = false;
+		}
+		m_blockHash[k].swap(now[k]);
+	}
+	if (any) m_partialUploads++;
 	return true;
 }
 
@@ -416,40 +497,50 @@ bool TimeStepControllerHIP::downloadParticles(SimulationModel &model)
 	ParticleData &pd = model.getParticles();
 	const unsigned int n = pd.size();
 	if (!n) return true;
+	// the device returns the block hashes of exactly the bytes it delivers: the host does not have to read its arrays again
+	// to know what they hold now
+	const size_t nb = pbdx_hash_num_blocks(n);
+	for (int k = 0; k < 4; k++) m_blockHash[k].resize(nb);
 #ifdef USE_DOUBLE
-	if (pbdx_solver_get_particles_f64(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0]) != PBDX_OK)
-		return false;
+	if (pbdx_solver_get_particles_hashed_f64(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0],
+		m_blockHash[0].data(), m_blockHash[1].data(), m_blockHash[2].data(), m_blockHash[3].data()) != PBDX_OK)
 #else
-	if (pbdx_solver_get_particles(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0]) != PBDX_OK)
-		return false;
+	if (pbdx_solver_get_particles_hashed(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0],
+		m_blockHash[0].data(), m_blockHash[1].data(), m_blockHash[2].data(), m_blockHash[3].data()) != PBDX_OK)
 #endif
+	{
+		for (int k = 0; k < 4; k++) m_blockHash[k].clear();      // unknown host contents: the next prepare() uploads everything
+		return false;
+	}
 	m_deviceAhead = false;
 	m_hostDirty = false;
-	hashHostState(model, m_hostHash);
 	return true;
 }
 
-// sampled hashes of the host arrays: x, v, oldX, lastX, masses (dirty tracking of a host the plug-in cannot instrument)
-void TimeStepControllerHIP::hashHostState(SimulationModel &model, uint64_t out[5]) const
+// full-coverage block hashes of the host arrays: x, v, oldX, lastX, masses (dirty tracking of a host the plug-in cannot instrument)
+void TimeStepControllerHIP::hashHostState(SimulationModel &model, std::vector<uint64_t> out[5]) const
 {
 	ParticleData &pd = model.getParticles();
-	const size_t n = pd.size();
-	if (!n) { for (int k = 0; k < 5; k++) out[k] = 0; return; }
-	out[0] = sampleHash(&pd.getPosition(0)[0], n, sizeof(Vector3r));
-	out[1] = sampleHash(&pd.getVelocity(0)[0], n, sizeof(Vector3r));
-	out[2] = sampleHash(&pd.getOldPosition(0)[0], n, sizeof(Vector3r));
-	out[3] = sampleHash(&pd.getLastPosition(0)[0], n, sizeof(Vector3r));
-	out[4] = sampleHash(&pd.getMass(0), n, sizeof(Real));
+	const uint32_t n = pd.size();
+	if (!n) { for (int k = 0; k < 5; k++) out[k].clear(); return; }
+	hashBlocks(&pd.getPosition(0)[0], n, kVecWords, out[0]);
+	hashBlocks(&pd.getVelocity(0)[0], n, kVecWords, out[1]);
+	hashBlocks(&pd.getOldPosition(0)[0], n, kVecWords, out[2]);
+	hashBlocks(&pd.getLastPosition(0)[0], n, kVecWords, out[3]);
+	hashBlocks(&pd.getMass(0), n, kScalarWords, out[4]);
 }
 
-// hash over a sample of the constraints' parameter records (what pushParams would hand to the engine)
+// hash over the constraints' parameter records (what pushParams would hand to the engine): a strided sample of ~4096 records by
+// default -- a walk over all of a 6 M-constraint model's heap objects costs tens of milliseconds, more than the step -- which
+// sees every bulk edit (SimulationModel::setClothStiffness & co write ALL constraints of a kind); an edit of a single constraint
+// needs refreshParameters() (documented in the header), or setFullParameterScan(true) for hosts that prefer exactness to speed.
 uint64_t TimeStepControllerHIP::hashParameters(SimulationModel &model) const
 {
 	SimulationModel::ConstraintVector &constraints = model.getConstraints();
 	const size_t nc = constraints.size();
 	uint64_t h = 1469598103934665603ull ^ (uint64_t)nc;
 	if (!nc) return h;
-	const size_t stride = nc > 4096 ? nc / 4096 : 1;
+	const size_t stride = (nc > 4096 && !m_fullParameterScan) ? nc / 4096 : 1;
 	std::vector<float> rec;
 	for (size_t i = 0; i < nc; i += stride)
 	{
@@ -505,24 +596,32 @@ bool TimeStepControllerHIP::buildSchedule(SimulationModel &model, bool paramsOnl
 	return true;
 }
 
-// Bring the device image up to date: particles (when the host is newer, or on demand), schedule (topology change),
-// parameters (run-time edits), colliders.  If the device is ahead of the host and the host changed only some arrays, the
-// unchanged ones are first pulled from the device (a partial host write must not roll the rest back).
+// Bring the device image up to date: particles (what the host wrote), schedule (topology change), parameters (run-time
+// edits), colliders.  Host writes are found by FULL-COVERAGE block hashes of the five arrays (every word is looked at):
+//  * host current (the last thing that happened was an upload or a download): only the changed blocks are uploaded -- usually
+//    none, so a round-trip step() no longer re-sends 56 MB the device already has;
+//  * device ahead (stepResident without syncToHost): the host arrays are STALE as a whole, so a change is read at array
+//    granularity -- an array the host wrote replaces the device's, the others are first pulled from the device (a partial
+//    host write must not roll the rest back).  Element edits of a stale array make no sense: syncToHost() first.
 bool TimeStepControllerHIP::prepare(SimulationModel &model, bool forceUpload)
 {
-	bool upload = forceUpload || !m_imageValid || model.getParticles().size() != m_numParticles;
+	bool upload = forceUpload || m_hostDirty || !m_imageValid || model.getParticles().size() != m_numParticles || m_blockHash[4].empty();
 	if (!upload)
 	{
-		uint64_t h[5];
-		hashHostState(model, h);
-		bool changed[5];
-		bool any = m_hostDirty;
-		for (int k = 0; k < 5; k++) { changed[k] = h[k] != m_hostHash[k]; any = any || changed[k]; }
-		if (any)
+		std::vector<uint64_t> now[5];
+		hashHostState(model, now);
+		if (!m_deviceAhead)
 		{
-			if (m_deviceAhead && !m_hostDirty)
+			if (!uploadChanges(model, now)) return false;
+		}
+		else
+		{
+			bool changed[5];
+			bool any = false;
+			for (int k = 0; k < 5; k++) { changed[k] = now[k] != m_blockHash[k]; any = any || changed[k]; }
+			if (any)
 			{
-				// pull what the host did not touch (markHostDirty() = "everything on the host is newer": nothing is pulled)
+				// pull what the host did not touch
 				ParticleData &pd = model.getParticles();
 				const unsigned int n = pd.size();
 #ifdef USE_DOUBLE
@@ -532,8 +631,8 @@ bool TimeStepControllerHIP::prepare(SimulationModel &model, bool forceUpload)
 				if (pbdx_solver_get_particles(m_solver, n, changed[0] ? NULL : &pd.getPosition(0)[0], changed[1] ? NULL : &pd.getVelocity(0)[0],
 					changed[2] ? NULL : &pd.getOldPosition(0)[0], changed[3] ? NULL : &pd.getLastPosition(0)[0]) != PBDX_OK) return false;
 #endif
+				upload = true;
 			}
-			upload = true;
 		}
 	}
 	if (upload && !uploadParticles(model)) return false;
@@ -588,9 +687,11 @@ void TimeStepControllerHIP::step(SimulationModel &model)
 		return;
 	}
 	START_TIMING("simulation step");
-	// TimeStep::step contract: the host ParticleData is authoritative on entry and up to date on exit.  (If the device
-	// is ahead -- a stepResident without syncToHost -- prepare() merges instead of overwriting.)
-	bool ok = prepare(model, /*forceUpload=*/!m_deviceAhead);
+	// TimeStep::step contract: the host ParticleData is authoritative on entry and up to date on exit.  prepare() looks at
+	// every word of the host arrays (block hashes) and uploads what differs from what the device delivered last time -- after
+	// the plug-in's own download that is nothing, unless the host wrote in between.  (If the device is ahead -- a stepResident
+	// without syncToHost -- prepare() merges at array granularity instead.)
+	bool ok = prepare(model, /*forceUpload=*/false);
 	if (ok)
 	{
 		refreshAccelerations(model);                        // host-visible side effect of TimeStepController.cpp:84
@@ -667,4 +768,7 @@ extern "C" int pbdx_timestep_hip_step_resident(PBD::TimeStep *ts, PBD::Simulatio
 extern "C" int pbdx_timestep_hip_sync_to_host(PBD::TimeStep *ts, PBD::SimulationModel *model) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->syncToHost(*model) ? 0 : 1; }
 extern "C" int pbdx_timestep_hip_sync_from_host(PBD::TimeStep *ts, PBD::SimulationModel *model) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->syncFromHost(*model) ? 0 : 1; }
 extern "C" void pbdx_timestep_hip_mark_host_dirty(PBD::TimeStep *ts) { static_cast<PBD::TimeStepControllerHIP*>(ts)->markHostDirty(); }
+extern "C" unsigned int pbdx_timestep_hip_partial_uploads(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numPartialUploads(); }
+extern "C" void pbdx_timestep_hip_refresh_parameters(PBD::TimeStep *ts) { static_cast<PBD::TimeStepControllerHIP*>(ts)->refreshParameters(); }
+extern "C" void pbdx_timestep_hip_set_full_parameter_scan(PBD::TimeStep *ts, int on) { static_cast<PBD::TimeStepControllerHIP*>(ts)->setFullParameterScan(on != 0); }
 extern "C" void *pbdx_timestep_hip_solver(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->solver(); }

@@ -18,8 +18,15 @@
 //                             ParticleData.h:91-100) are handed to the engine as they are -- no per-element
 //                             conversion loops; a double host is converted on the device.
 //   stepResident(model, n)    SURVEY 8f rank 1: n steps with the state resident in HBM; nothing is downloaded until
-//                             syncToHost(model).  Host writes to ParticleData in between are picked up by a sampled
-//                             hash of the arrays (or explicitly: markHostDirty()).
+//                             syncToHost(model).  Contract: after stepResident the host arrays are STALE until syncToHost.
+//                             Host writes are found by full-coverage block hashes of the arrays (every word is hashed,
+//                             PBDX_HASH_BLOCK elements per hash; no sampling): after a syncToHost / step() the changed
+//                             blocks are uploaded; while the host is stale a written ARRAY replaces the device's as a whole
+//                             (the others are kept) -- to edit single particles, syncToHost first.
+// Masses: ParticleData::setMass between steps (pinning, mouse attach) is found the same way; the inverse masses of the changed
+// blocks are re-derived.  Constraint parameters: bulk edits (setClothStiffness ...) are found by a sampled hash, an edit of a
+// single constraint needs refreshParameters() (or setFullParameterScan(true)): a walk over all heap constraints per step
+// would cost more than the step.
 //
 // Scope: models whose constraints are all particle constraints known to the engine.  Rigid bodies are
 // accepted when they are all static (mass 0) colliders of a DistanceFieldCollisionDetection with analytic
@@ -59,8 +66,9 @@ namespace PBD
 		bool syncToHost(SimulationModel &model);
 		/** ParticleData -> device, unconditionally (the host is authoritative) */
 		bool syncFromHost(SimulationModel &model);
-		/** tell the plug-in that ParticleData was written on the host since the last sync (the sampled hash can miss a
-		 * single-particle edit in a large model) */
+		/** "everything on the host is newer": the next step uploads all arrays without looking.  Not needed for correctness --
+		 * host writes are found by full-coverage block hashes (every word of x, v, oldX, lastX, masses is looked at before every
+		 * step) -- only to override the device-ahead merge rule below. */
 		void markHostDirty() { m_hostDirty = true; m_accelValid = false; }
 		/** page-lock ParticleData's arrays for the transfers of step() (default on) */
 		void setPinHostArrays(bool b) { if (m_solver) pbdx_solver_set_option(m_solver, PBDX_OPT_PIN_HOST, b ? 1 : 0); }
@@ -81,6 +89,10 @@ namespace PBD
 		unsigned int numParameterRefreshes() const { return m_paramRefreshes; }
 		unsigned int numScheduleBuilds() const { return m_scheduleBuilds; }
 		unsigned int numUploads() const { return m_uploads; }
+		/** uploads of only the blocks the host wrote (host current, full-coverage block hashes) */
+		unsigned int numPartialUploads() const { return m_partialUploads; }
+		/** hash ALL parameter records every step instead of a sample (exact, costs a walk over every constraint object) */
+		void setFullParameterScan(bool b) { m_fullParameterScan = b; }
 		/** Opt in to running unsupported models / failed steps on the reference's CPU path (default off). */
 		void setAllowReferenceFallback(bool b) { m_allowFallback = b; }
 		pbdx_solver *solver() { return m_solver; }
@@ -94,8 +106,9 @@ namespace PBD
 		bool downloadParticles(SimulationModel &model);
 		bool prepare(SimulationModel &model, bool forceUpload);
 		bool runSteps(SimulationModel &model, unsigned int numSteps);
+		bool uploadChanges(SimulationModel &model, std::vector<uint64_t> now[5]);
 		uint64_t hashParameters(SimulationModel &model) const;
-		void hashHostState(SimulationModel &model, uint64_t out[5]) const;
+		void hashHostState(SimulationModel &model, std::vector<uint64_t> out[5]) const;
 		void refuse(SimulationModel &model, const char *why);
 		void refreshAccelerations(SimulationModel &model);
 
@@ -110,7 +123,9 @@ namespace PBD
 		bool m_deviceAhead;            // device state newer than ParticleData
 		bool m_hostDirty;              // markHostDirty()
 		bool m_imageValid;             // particles were uploaded at least once for the current model
-		uint64_t m_hostHash[5];        // sampled hashes of x, v, oldX, lastX, masses as of the last upload / download
+		std::vector<uint64_t> m_blockHash[5]; // full-coverage block hashes (include/pbdx.h) of x, v, oldX, lastX, masses as of the last upload / download
+		unsigned int m_partialUploads;
+		bool m_fullParameterScan;
 		// parameters
 		bool m_paramsDirty;
 		uint64_t m_paramHash;
@@ -118,8 +133,7 @@ namespace PBD
 		const void *m_supportedFor; size_t m_supportedConstraints, m_supportedBodies, m_supportedObjects; bool m_supported;
 		bool m_accelValid; Real m_accelGravity[3];
 		uint64_t m_tetSignature;       // which set of deformable colliders the engine holds (0 = none)
-		std::vector<float> m_invMass32;
-		std::vector<double> m_invMass64;
+		std::vector<Real> m_invMass;
 	};
 }
 

@@ -120,6 +120,8 @@ PYBIND11_MODULE(pypbd, m)
 		.def("deviceAhead", &TimeStepControllerHIP::deviceAhead)
 		.def("invalidate", &TimeStepControllerHIP::invalidate)
 		.def("refreshParameters", &TimeStepControllerHIP::refreshParameters)
+		.def("setFullParameterScan", &TimeStepControllerHIP::setFullParameterScan)
+		.def("numPartialUploads", &TimeStepControllerHIP::numPartialUploads)
 		.def("setAllowReferenceFallback", &TimeStepControllerHIP::setAllowReferenceFallback)
 		.def("numGpuSteps", &TimeStepControllerHIP::numGpuSteps)
 		.def("numFallbackSteps", &TimeStepControllerHIP::numFallbackSteps)

@@ -17,7 +17,8 @@ def declared_symbols(headers=(HEADER, DEBUG_HEADER)):
     syms = set()
     for h in headers:
         text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
-        syms |= set(re.findall(r"\b(pbdx_[a-z0-9_]+)\s*\(", text))
+        inline = set(re.findall(r"static\s+inline\s+[a-z0-9_]+\s+(pbdx_[a-z0-9_]+)\s*\(", text))     # header-only helpers: no symbol
+        syms |= set(re.findall(r"\b(pbdx_[a-z0-9_]+)\s*\(", text)) - inline
     return sorted(syms)
 
 

@@ -343,3 +343,195 @@ def test_reference_python_example_through_compiled_pypbd_on_the_gpu():
         assert g["gpu_steps"] == 16 and g["failed"] == 0 and g["moved"] and c["moved"]
         print("compiled pypbd, model %s: bitwise %s, max abs %.3e" % (key, res[key + "_bitwise"], res[key + "_maxabs"]))
         assert res[key + "_bitwise"], res[key + "_maxabs"]
+
+
+# ---------------------------------------------------------------------------
+# dirty tracking at a size where a sampled hash would miss single-element edits: the plug-in looks at
+# EVERY word of the host arrays (block hashes, include/pbdx.h) before every step
+# ---------------------------------------------------------------------------
+def _np_block_hashes(a):
+    """pbdx_hash_block (include/pbdx.h) restated in numpy for a packed array."""
+    w = np.ascontiguousarray(a).view(np.uint32).reshape(-1)
+    elem_words = w.size // len(a)
+    i = np.arange(w.size, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        k = ((i * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        m = (w ^ k).astype(np.uint64) * np.uint64(0xD1B54A32D192ED03) + np.uint64(0x632BE59BD9B4E019)
+    m ^= m >> np.uint64(31)
+    per = 1024 * elem_words
+    nb = (w.size + per - 1) // per
+    return np.array([np.bitwise_xor.reduce(m[b * per:(b + 1) * per]) for b in range(nb)], dtype=np.uint64)
+
+
+@pytest.mark.gpu
+def test_device_block_hashes_equal_the_host_definition():
+    """pbdx_solver_get_particles_hashed: the hashes the device returns are the host definition applied to the delivered bytes
+    (float and double hosts; a particle count that is not a multiple of the block size), and pbdx_solver_update_particle_ranges
+    replaces exactly the given ranges."""
+    import positionbaseddynamics_amd as pbd
+    from positionbaseddynamics_amd import _ffi
+    n = 5 * 1024 + 137
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((n, 3)).astype(np.float32)
+    v = rng.standard_normal((n, 3)).astype(np.float32)
+    mass = np.ones(n, dtype=np.float32)
+    sol = pbd.Solver()
+    sol.set_particles(x, mass, v=v)
+    pu64 = C.POINTER(C.c_uint64)
+    nb = (n + 1023) // 1024
+    for dt, fn, cptr in ((np.float32, _ffi.lib.pbdx_solver_get_particles_hashed, _ffi.pf), (np.float64, _ffi.lib.pbdx_solver_get_particles_hashed_f64, C.POINTER(C.c_double))):
+        out = [np.zeros((n, 3), dtype=dt) for _ in range(4)]
+        hs = [np.zeros(nb, dtype=np.uint64) for _ in range(4)]
+        _ffi.check(fn(sol._h, n, *[o.ctypes.data_as(cptr) for o in out], *[h.ctypes.data_as(pu64) for h in hs]), "get_particles_hashed")
+        assert np.array_equal(out[0], x.astype(dt)) and np.array_equal(out[1], v.astype(dt))
+        for o, h in zip(out, hs):
+            assert np.array_equal(h, _np_block_hashes(o))
+    # partial upload: two ranges of x, one of v; everything else stays
+    x2 = x.copy(); x2[10:20] += 1.0; x2[4000:4100] -= 2.0; x2[3000] = 99.0          # 3000 is NOT in a range: must not arrive
+    ranges = np.array([10, 10, 4000, 100], dtype=np.uint32)
+    _ffi.check(_ffi.lib.pbdx_solver_update_particle_ranges(sol._h, 0, x2.ctypes.data_as(_ffi.pf), 2, ranges.ctypes.data_as(_ffi.pu)), "update_ranges")
+    want = x.copy(); want[10:20] = x2[10:20]; want[4000:4100] = x2[4000:4100]
+    got = sol.get_particles()
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], v)
+    bad = np.array([n - 5, 10], dtype=np.uint32)
+    assert _ffi.lib.pbdx_solver_update_particle_ranges(sol._h, 0, x2.ctypes.data_as(_ffi.pf), 1, bad.ctypes.data_as(_ffi.pu)) != 0
+
+
+def _extra(path):
+    lib = C.CDLL(path)
+    lib.pbdx_timestep_hip_partial_uploads.argtypes = [C.c_void_p]; lib.pbdx_timestep_hip_partial_uploads.restype = C.c_uint
+    lib.pbdx_timestep_hip_refresh_parameters.argtypes = [C.c_void_p]; lib.pbdx_timestep_hip_refresh_parameters.restype = None
+    lib.pbdx_timestep_hip_set_full_parameter_scan.argtypes = [C.c_void_p, C.c_int]; lib.pbdx_timestep_hip_set_full_parameter_scan.restype = None
+    return lib
+
+
+BIG = (320, 320)      # 102 400 particles, 611 522 constraints: a 4 096-element sample would see 1 particle in 25
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["f32", "f64"])
+def test_plugin_sees_one_pinned_particle_in_a_large_model(variant):
+    """ParticleData::setMass(i, 0) on ONE particle between step() calls (pinning / mouse attach, ParticleData.h:239-246): the
+    reference reads pd.getInvMass(i) fresh in every step; so must the device image.  102 400 particles, the pinned particle
+    sits in the middle of a hash block.  Bitwise vs the CPU TimeStepController making the same edit (float host; fp32
+    envelope for the double host)."""
+    refdrv, path = _plugin(variant)
+    ops = util.cloth_spec(BIG[0], BIG[1], 4, 3)
+    victim = 160 * 320 + 171
+
+    def run(gpu):
+        ref = refdrv.Ref(variant)
+        _setup(ref, ops, 1, 5)
+        ref.set_num_threads(8)
+        if gpu:
+            assert ref.install_timestep_plugin(path) == 0
+        ref.set_params(1, 5, 0)
+        ref.step(3)
+        ref.set_mass(victim, 0.0)
+        ref.step(3)
+        x_pinned = ref.positions()[victim].copy()
+        ref.step(2)
+        assert np.array_equal(ref.positions()[victim], x_pinned), "the pinned particle moved"
+        ref.set_mass(victim, 1.0)              # ... and released again
+        ref.step(2)
+        out = (ref.positions().copy(), ref.get_array(2).copy())
+        if gpu:
+            lib, cnt = _counters(path)
+            ts = ref.timestep_ptr()
+            assert cnt["gpu_steps"](ts) == 10 and cnt["failed_steps"](ts) == 0
+            # one full upload (the first step); the two mass edits went up as changed blocks, and no step re-sent what the device
+            # itself had delivered
+            assert cnt["uploads"](ts) == 1 and _extra(path).pbdx_timestep_hip_partial_uploads(ts) == 2
+        ref.reset_all()
+        return out
+
+    (xc, vc), (xg, vg) = run(False), run(True)
+    if variant == "f32":
+        assert util.bitwise_equal(xg, xc), "max err %.3e" % util.max_err(xg, xc)
+        assert util.bitwise_equal(vg, vc)
+    else:
+        assert util.max_err(xg, xc) <= 2e-4
+
+
+@pytest.mark.gpu
+def test_plugin_sees_one_moved_particle_between_resident_steps():
+    """Resident mode contract (TimeStepControllerHIP.h): host arrays are stale until syncToHost; after it, host writes are
+    found by full-coverage block hashes and only the changed blocks are uploaded.  ONE particle of 102 400 is moved (and given
+    a velocity) between resident steps; bitwise vs the CPU TimeStepController making the same edit."""
+    refdrv, path = _plugin("f32")
+    ops = util.cloth_spec(BIG[0], BIG[1], 4, 3)
+    victim = 200 * 320 + 57
+
+    def edit(ref):
+        x = ref.positions().copy(); x[victim] += np.array([0.0, 0.05, 0.02], dtype=x.dtype); ref.set_array(0, x)
+        v = ref.get_array(2).copy(); v[victim, 1] = 1.5; ref.set_array(2, v)
+
+    def run(gpu):
+        ref = refdrv.Ref("f32")
+        _setup(ref, ops, 1, 5)
+        ref.set_num_threads(8)
+        ref.set_params(1, 5, 0)
+        if gpu:
+            assert ref.install_timestep_plugin(path) == 0
+            ref.set_params(1, 5, 0)
+            lib, cnt = _counters(path)
+            ts, model = ref.timestep_ptr(), ref.model_ptr()
+            assert cnt["step_resident"](ts, model, 4) == 0
+            assert cnt["sync_to_host"](ts, model) == 0
+            edit(ref)
+            assert cnt["step_resident"](ts, model, 3) == 0
+            assert cnt["uploads"](ts) == 1 and _extra(path).pbdx_timestep_hip_partial_uploads(ts) == 1
+            assert cnt["step_resident"](ts, model, 2) == 0
+            assert cnt["uploads"](ts) == 1 and _extra(path).pbdx_timestep_hip_partial_uploads(ts) == 1
+            assert cnt["sync_to_host"](ts, model) == 0
+            assert cnt["failed_steps"](ts) == 0
+        else:
+            ref.step(4)
+            edit(ref)
+            ref.step(5)
+        out = [ref.get_array(k).copy() for k in (0, 2, 4, 5)]
+        ref.reset_all()
+        return out
+
+    a, b = run(False), run(True)
+    for k in range(4):
+        assert util.bitwise_equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["refreshParameters", "fullParameterScan"])
+def test_plugin_sees_one_edited_constraint_in_a_large_model(how):
+    """`constraint.stiffness = ...` on ONE of 611 522 constraints (pyPBD/ConstraintsModule.cpp:62-116).  The documented contract:
+    the default sampled parameter hash sees bulk edits only; a single-constraint edit is announced with refreshParameters(), or
+    the host switches the full scan on.  Either way: parameter streams refreshed, no replanning, bitwise vs the CPU path."""
+    refdrv, path = _plugin("f32")
+    ops = util.cloth_spec(BIG[0], BIG[1], 4, 3)
+    victim = 123457
+
+    def run(gpu):
+        ref = refdrv.Ref("f32")
+        _setup(ref, ops, 1, 5)
+        ref.set_num_threads(8)
+        if gpu:
+            assert ref.install_timestep_plugin(path) == 0
+        ref.set_params(1, 5, 0)
+        if gpu and how == "fullParameterScan":
+            _extra(path).pbdx_timestep_hip_set_full_parameter_scan(ref.timestep_ptr(), 1)
+        ref.step(3)
+        ref.set_constraint_stiffness(victim, 3.0)
+        if gpu and how == "refreshParameters":
+            _extra(path).pbdx_timestep_hip_refresh_parameters(ref.timestep_ptr())
+        ref.step(4)
+        out = (ref.positions().copy(), ref.get_array(2).copy())
+        if gpu:
+            lib, cnt = _counters(path)
+            ts = ref.timestep_ptr()
+            assert cnt["gpu_steps"](ts) == 7 and cnt["failed_steps"](ts) == 0
+            assert cnt["schedule_builds"](ts) == 1 and cnt["param_refreshes"](ts) == 1
+        ref.reset_all()
+        return out
+
+    (xc, vc), (xg, vg) = run(False), run(True)
+    assert not np.array_equal(xc, util.oracle_positions(ops, 7, 1, 5, "f32")), "the edit changes nothing: the test would prove nothing"
+    assert util.bitwise_equal(xg, xc), "max err %.3e" % util.max_err(xg, xc)
+    assert util.bitwise_equal(vg, vc)

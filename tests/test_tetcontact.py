@@ -93,6 +93,46 @@ def test_golden_fixture_engine_detection_on_host():
         assert len(want) > 10 and len(got) == len(want) and util.bitwise_equal(got[:, :26], want), "step %d" % steps
 
 
+def test_malformed_hierarchies_are_refused_before_anything_walks_them():
+    """the device walks the hierarchies with fixed stacks and trusts them.  A hierarchy that is not a tree (a child
+    pointing back to the root: a cycle; two parents sharing a child) or a collider with friction is refused by the shared
+    validator (pbdx_solver_set_tet_colliders and the host evaluation go through the same function); no GPU needed."""
+    g = np.load(GOLDEN)
+    x, x0, w = g["x_%d" % g["steps"][0]], g["x0"], g["w"]
+
+    def fails(mutate, needle):
+        cols = tcu.GoldenTetColliders(g)
+        mutate(cols)
+        pos4 = np.ascontiguousarray(np.concatenate([x, w[:, None]], axis=1), dtype=np.float32)
+        rest4 = np.ascontiguousarray(np.concatenate([x0, w[:, None]], axis=1), dtype=np.float32)
+        count = C.c_uint32(0)
+        rc = _ffi.lib.pbdx_debug_tet_contacts(len(x), pos4.ctypes.data_as(_ffi.pf), rest4.ctypes.data_as(_ffi.pf), cols.n, cols.arr, float(cols.tolerance), 0,
+                                              C.byref(count), None)
+        assert rc != 0 and needle in _ffi.lib.pbdx_last_error(), _ffi.lib.pbdx_last_error()
+
+    def nodes_of(cols, q, field):
+        f = getattr(cols.arr[q], field)
+        return np.ctypeslib.as_array(f.nodes, shape=(f.num_nodes * 4,))
+
+    def cycle(cols):
+        nd = nodes_of(cols, 1, "tets_rest")
+        inner = [i for i in range(1, len(nd) // 4) if nd[4 * i] >= 0][0]
+        nd[4 * inner] = 0                                   # an inner node's first child is the root again
+
+    def shared(cols):
+        nd = nodes_of(cols, 0, "points")
+        nd[1] = nd[0]                                       # both children of the root are the same node
+
+    def friction(cols):
+        cols.arr[0].friction = 0.25
+
+    fails(cycle, b"not a tree")
+    fails(shared, b"not a tree")
+    fails(friction, b"friction")
+    # and the untouched fixture passes
+    assert len(tcu.host_contacts_of_state(x, x0, w, tcu.GoldenTetColliders(g))) > 10
+
+
 def _levels(records):
     """the engine's levelling rule (pbdx_tetcontact_dev.h): a contact's level is one more than the highest level among EARLIER contacts
     that share one of its five particles"""
