@@ -450,7 +450,20 @@ def test_plugin_sees_one_pinned_particle_in_a_large_model(variant):
         assert util.bitwise_equal(xg, xc), "max err %.3e" % util.max_err(xg, xc)
         assert util.bitwise_equal(vg, vc)
     else:
-        assert util.max_err(xg, xc) <= 2e-4
+        # pinning and releasing a particle of a stiff falling sheet is a violent event: float and double runs drift apart
+        # quickly.  The bar for a double host is the envelope: the fp32 engine is no further from the double CPU
+        # path than 3x what the reference's OWN float build is
+        refdrv32, _ = _plugin("f32")
+        ref = refdrv32.Ref("f32")
+        _setup(ref, ops, 1, 5)
+        ref.set_num_threads(8)
+        ref.set_params(1, 5, 0)
+        ref.step(3); ref.set_mass(victim, 0.0); ref.step(5); ref.set_mass(victim, 1.0); ref.step(2)
+        x32 = ref.positions().copy()
+        ref.reset_all()
+        e_gpu, e_f32 = util.max_err(xg, xc), util.max_err(x32, xc)
+        print("double host, one particle pinned / released: |gpu - f64| = %.3e, |f32 reference - f64| = %.3e" % (e_gpu, e_f32))
+        assert e_gpu <= 3.0 * e_f32 + 1e-6
 
 
 @pytest.mark.gpu
