@@ -218,6 +218,25 @@ void compute_type_view(int type, const std::vector<ParamSpan> &spans, TypeView &
 			if ((kCompactScalars[type] >> k) & 1u) memcpy(&v.u[k], &first[k], 4);
 }
 
+// Tile count when the caller does not fix the tile size.  One workgroup (= one tile) runs per CU at a time.
+//  * large scenes: a whole number of "waves" of num_cus tiles, tiles as large as the LDS allows (fewer waves, less halo
+//    redundancy): measured on the 64 x 200x200 ensemble, 512 tiles of 5 000 particles beat 768 x 3 333 by 10 % and 625 x 4 100 by
+//    18 %.  About half of the LDS is needed for the halo of a 12-15 colour segment, hence at most ~5 200 owned particles.
+//  * small scenes (fewer than 512 particles per CU): a colour step of a tile is one projection chain of a lone wave whatever its
+//    slot count, so what a smaller tile saves is pass-boundary work (LDS fill, write-back, hand-off all scale with the particles
+//    a tile stages) while the extra halo slots ride along for free -- as long as every tile still has a CU of its own.  Measured
+//    (profiles/r03b_c3_tile_sweep.log, r03c_small_scene_tile_sweep.log): the 100 k-tet bar (23 331 particles) 46 tiles x 507:
+//    0.712 ms, 183 x 128: 0.640, 234 x 100: 0.636, 257 x 91 (> 256 CUs): 1.20; 100x100 cloth 20 x 512: 0.358, 63 x 160: 0.324;
+//    200x200 cloth 79 x 512: 0.376, 250 x 160: 0.343, 400 x 100: 0.63.  => ~128 particles per tile, never more tiles than CUs.
+uint64_t default_tile_count(uint64_t n, uint32_t num_cus, uint32_t max_local)
+{
+	const uint64_t cus = std::max(1u, num_cus);
+	const uint64_t t_max = std::max(512u, std::min(5200u, max_local / 2 + max_local / 50));
+	if (n <= cus * 512u)
+		return std::max<uint64_t>(1, std::min<uint64_t>(cus, (n + 127) / 128));
+	return cus * ((n + cus * t_max - 1) / (cus * t_max));
+}
+
 bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &batches,
 	const PlanOptions &opt, FusedPlan &plan, std::string &why)
 {
@@ -280,19 +299,11 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	}
 
 	// ---- tiles ---------------------------------------------------------------------------------
-	// One workgroup (= one tile) runs per CU at a time, so the tile count should be a whole number of "waves"
-	// of num_cus tiles, with tiles as large as the LDS allows (fewer waves, less halo redundancy): measured on
-	// the 64 x 200x200 ensemble, 512 tiles of 5 000 particles beat 768 x 3 333 by 10 % and 625 x 4 100 by 18 %.
-	// About half of the LDS is needed for the halo of a 12-15 colour segment, hence at most ~5 200 owned particles.
+	// (tile count: default_tile_count above)
 	uint32_t T = opt.tile_particles, k;
 	if (T == 0)
 	{
-		const uint32_t cus = std::max(1u, opt.num_cus);
-		const uint32_t t_max = std::max(512u, std::min(5200u, opt.max_local / 2 + opt.max_local / 50));
-		if ((uint64_t)n <= (uint64_t)cus * 512u)
-			k = (n + 511) / 512;                                      // small scene: 512-particle tiles, fewer than one wave
-		else
-			k = cus * (uint32_t)(((uint64_t)n + (uint64_t)cus * t_max - 1) / ((uint64_t)cus * t_max));
+		k = (uint32_t)default_tile_count(n, opt.num_cus, opt.max_local);
 	}
 	else
 	{
@@ -326,7 +337,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	// ---- segment boundaries: dynamic programme over a sample of tiles ---------------------------
 	// (developer aid: PBDX_PLAN_SLOT_SCALE / PBDX_PLAN_FIXED_NS / PBDX_PLAN_LAUNCH_NS rescale the time model to explore other
 	// segmentations on the GPU; never set in production)
-	// Small scenes (512-particle tiles, fewer tiles than CUs): a colour step of a tile holds fewer slots than the workgroup has
+	// Small scenes (fewer than 512 particles per CU; ~128-particle tiles, at most one per CU): a colour step of a tile holds fewer slots than the workgroup has
 	// lanes, so its duration is one projection chain of a lone wave whatever the slot count (step traces of the 100 k-tet bar:
 	// 1.00 us for every step of 100-250 FEM slots; lone-wave VALU issue interval 4.5 cycles, scripts/microbench/valu_single.hip)
 	// and redundant halo slots are nearly free: the per-slot cost is discounted, which makes segments longer (fewer tile-to-tile
@@ -672,10 +683,7 @@ bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const st
 	{
 		// tile count of the whole as the planner would choose it (whole waves of num_cus tiles at the largest tile the LDS
 		// allows), divided among the instances
-		const uint32_t cus = std::max(1u, opt.num_cus);
-		const uint32_t t_max = std::max(512u, std::min(5200u, opt.max_local / 2 + opt.max_local / 50));
-		const uint64_t n = (uint64_t)n_proto * K;
-		const uint64_t k_all = n <= (uint64_t)cus * 512u ? (n + 511) / 512 : (uint64_t)cus * ((n + (uint64_t)cus * t_max - 1) / ((uint64_t)cus * t_max));
+		const uint64_t k_all = default_tile_count((uint64_t)n_proto * K, opt.num_cus, opt.max_local);
 		const uint32_t k_proto = (uint32_t)std::max<uint64_t>(1, (k_all + K / 2) / K);
 		po.tile_particles = std::min<uint32_t>(opt.max_local, (n_proto + k_proto - 1) / k_proto);
 	}
