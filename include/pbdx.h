@@ -286,7 +286,8 @@ typedef struct pbdx_tet_collider
 	uint32_t first_particle, num_vertices, num_tets;
 	const uint32_t *tets;          /* 4 model-local vertex indices per tet (IndexedTetMesh::getTets) */
 	float initial_x[3], initial_R[9]; /* TetModel::getInitialX / getInitialR (row-major): rest frame of the distance field */
-	float restitution, friction;   /* of the tet model (friction must be 0) */
+	float restitution, friction;   /* of the tet model (friction must be 0: the reference's friction impulse for these contacts reads an unset multiplier;
+	                                * with friction 0 its velocity solve is defined and implemented, including the pMax < 0 branch) */
 	int test_mesh;                 /* m_testMesh: the model's particles are tested against the other solids */
 	uint32_t body_index;           /* tet model index (reported in the contacts) */
 	pbdx_bvh points, tets_bvh, tets_rest; /* m_bvh, m_bvhTets, m_bvhTets0 */
@@ -296,9 +297,10 @@ typedef struct pbdx_tet_collider
  * failed call (invalid records, friction != 0, out of memory) NO deformable colliders are set.  The detection's scratch buffers grow on demand. */
 int pbdx_solver_set_tet_colliders(pbdx_solver *s, uint32_t n, const pbdx_tet_collider *colliders, float tolerance);
 int pbdx_solver_set_rest_positions(pbdx_solver *s, uint32_t n, const float *x0);   /* ParticleData::m_x0, packed xyz */
-/* The contact list of the last detection, 30 floats per contact: particle, solid, tet, bary[3], normal[3], 1/(J M^-1 J^T),
- * m_x[4][3], m_invMasses[4], tet vertex particle ids[4] (indices as floats).  *count = number of contacts (may exceed capacity). */
-#define PBDX_TET_CONTACT_FLOATS 30
+/* The contact list of the last detection, 34 floats per contact: particle, solid, tet, bary[3], normal[3], 1/(J M^-1 J^T),
+ * m_x[4][3], m_invMasses[4], tet vertex particle ids[4] (indices as floats: colliders reaching indices above 2^24 are refused),
+ * tangent[3], maximal tangent impulse (m_constraintInfo.col(1), (1, 2)).  *count = number of contacts (may exceed capacity). */
+#define PBDX_TET_CONTACT_FLOATS 34
 int pbdx_solver_get_tet_contacts(pbdx_solver *s, uint32_t capacity, uint32_t *count, float *out);
 /* XPBD multipliers of batch `batch_index` (order of add_batch calls). */
 int pbdx_solver_get_lambdas(pbdx_solver *s, uint32_t batch_index, uint32_t count, float *out);

@@ -34,8 +34,13 @@ int pbdx_debug_chain_sum(pbdx_solver *s, const float *x, uint32_t n, float *out)
 int pbdx_debug_chain_sum_policy_host(const float *x, uint64_t n, uint32_t window_max, uint32_t poor_below, uint32_t burst0, float *out, uint64_t stats[4]);
 /* The same detection evaluated on the HOST by the same code (pbdx_tetcontact.h is host + device): developer / test aid, no GPU
  * needed.  pos4 / rest4: n x (x, y, z, invMass) records. */
-int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float *rest4, uint32_t n, const pbdx_tet_collider *colliders,
-	float tolerance, uint32_t capacity, uint32_t *count, float *out);
+int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float *rest4, const float *vel4 /* (vx, vy, vz, mass) records or NULL: at rest */,
+	uint32_t n, const pbdx_tet_collider *colliders, float tolerance, uint32_t capacity, uint32_t *count, float *out);
+/* Developer aid: the velocity part of ONE particle-tet contact on the host (the engine's arithmetic; friction 0).  in (26 floats): invMass0, v0[3],
+ * invMass[4], v[4][3], bary[3], normal[3]; out (20 floats): tangent[3], pMax, impulse applied (1 / 0), corr_v0[3], corr_v[4][3]. */
+int pbdx_debug_tet_velocity_kat(const float *in, float *out);
+/* Developer aid: how many contacts of the last detection carried a non-zero velocity impulse (pMax < 0), and the total since the colliders were set. */
+int pbdx_debug_tet_impulses(pbdx_solver *s, uint32_t *last, uint64_t *total);
 
 /* Counter calibration (developer aid for rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): one streaming
  * kernel over `nbytes` of HBM in one of the engine's access widths.  mode 0: 4-byte reads

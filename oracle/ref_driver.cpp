@@ -19,7 +19,9 @@
 #include "Simulation/Constraints.h"
 #include "Simulation/DistanceFieldCollisionDetection.h"
 #include "Simulation/RigidBody.h"
+#include "PositionBasedDynamics/PositionBasedDynamics.h"
 #include "Utils/IndexedFaceMesh.h"
+#include "Utils/TetGenLoader.h"
 #include "Utils/Logger.h"
 #include "Utils/Timing.h"
 #include <chrono>
@@ -202,6 +204,28 @@ int refdrv_add_tet_model(unsigned nPoints, unsigned nTets, const double *points,
 	return k;
 }
 
+// A tet model from TetGen files placed as Demos/SceneLoaderDemo/SceneLoaderDemo.cpp:606-655 places the models of a scene file: the reference's own
+// loader (Utils/TetGenLoader.cpp), vertices[j] = R * (vertices[j] .* scale) + x with R = Quaternionr(AngleAxisr(angle, axis)).matrix()
+// (Utils/SceneLoader.cpp:366-370), addTetModel, setInitialX / setInitialR / setInitialScale.  Returns the tet model index, -1 if the files are missing.
+int refdrv_add_tetgen_model(const char *nodeFile, const char *eleFile, const double *x, const double *axis, double angle, const double *scale)
+{
+	std::vector<Vector3r> vertices;
+	std::vector<unsigned int> tets;
+	Utilities::TetGenLoader::loadTetgenModel(nodeFile, eleFile, vertices, tets);
+	if (vertices.empty() || tets.empty()) return -1;
+	const Quaternionr q = Quaternionr(AngleAxisr((Real)angle, v3(axis)));
+	const Matrix3r R = q.matrix();
+	const Vector3r X = v3(x), S = v3(scale);
+	for (unsigned int j = 0; j < vertices.size(); j++)
+		vertices[j] = R * (vertices[j].cwiseProduct(S)) + X;
+	SimulationModel *m = model();
+	m->addTetModel((unsigned int)vertices.size(), (unsigned int)tets.size() / 4, vertices.data(), tets.data());
+	TetModel *tm = m->getTetModels()[m->getTetModels().size() - 1];
+	tm->setInitialX(X);
+	tm->setInitialR(R);
+	tm->setInitialScale(S);
+	return (int)m->getTetModels().size() - 1;
+}
 int refdrv_add_vertex(const double *x) { model()->getParticles().addVertex(v3(x)); return (int)model()->getParticles().size() - 1; }
 void refdrv_set_mass(unsigned i, double m) { model()->getParticles().setMass(i, (Real)m); }
 
@@ -666,6 +690,36 @@ unsigned refdrv_get_bvh(unsigned co, int which, unsigned *lst, unsigned lstCap, 
 	else if (which == 1) { nNodes = dumpBvh(o->m_bvhTets, nt, lst, lstCap, nodes, hulls, nodeCap); if (numEntities) *numEntities = nt; }
 	else { nNodes = dumpBvh(o->m_bvhTets0, nt, lst, lstCap, nodes, hulls, nodeCap); if (numEntities) *numEntities = nt; }
 	return nNodes;
+}
+// Known-answer entry: the velocity part of ONE particle-tet contact through the reference's own functions
+// (PositionBasedDynamics::init_ParticleTetContactConstraint, velocitySolve_ParticleTetContactConstraint).
+// in (26): invMass0, v0[3], invMass[4], v[4][3], bary[3], normal[3]; `lambda` stands for the multiplier the reference reads unset (any finite value
+// gives the same result when friction == 0); out (20): tangent[3], pMax, result flag, corr_v0[3], corr_v[4][3] (corrections the wrapper would not
+// apply -- static particles -- are reported as 0, like ParticleTetContactConstraint::solveVelocityConstraint skips them)
+void refdrv_kat_tet_contact_velocity(const double *in, double friction, double lambda, double *out)
+{
+	const Real invMass0 = (Real)in[0];
+	const Vector3r v0((Real)in[1], (Real)in[2], (Real)in[3]);
+	Real invMass[4];
+	Vector3r x[4], v[4];
+	for (int k = 0; k < 4; k++) { invMass[k] = (Real)in[4 + k]; v[k] = Vector3r((Real)in[8 + 3 * k], (Real)in[9 + 3 * k], (Real)in[10 + 3 * k]); x[k].setZero(); }
+	const Vector3r bary((Real)in[20], (Real)in[21], (Real)in[22]), normal((Real)in[23], (Real)in[24], (Real)in[25]);
+	const Vector3r x0(0, 0, 0);
+	Eigen::Matrix<Real, 3, 3, Eigen::DontAlign> info;
+	info.setZero();
+	PositionBasedDynamics::init_ParticleTetContactConstraint(invMass0, x0, v0, invMass, x, v, bary, normal, info);
+	for (int k = 0; k < 20; k++) out[k] = 0.0;
+	for (int k = 0; k < 3; k++) out[k] = (double)info(k, 1);
+	out[3] = (double)info(1, 2);
+	Vector3r corr0(0, 0, 0), corr[4];
+	for (int k = 0; k < 4; k++) corr[k].setZero();
+	const bool res = PositionBasedDynamics::velocitySolve_ParticleTetContactConstraint(invMass0, x0, v0, invMass, x, v, bary, (Real)lambda, (Real)friction, info, corr0, corr);
+	out[4] = res ? 1.0 : 0.0;
+	if (res)
+	{
+		if (invMass0 != 0.0) for (int k = 0; k < 3; k++) out[5 + k] = (double)corr0[k];
+		for (int q = 0; q < 4; q++) if (invMass[q] != 0.0) for (int k = 0; k < 3; k++) out[8 + 3 * q + k] = (double)corr[q][k];
+	}
 }
 // run ONLY the collision detection on the current state (fills the contact lists; no velocity solve)
 void refdrv_collision_detection_only() { cd().collisionDetection(*model()); }

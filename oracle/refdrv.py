@@ -374,6 +374,25 @@ class Ref:
     def attach_collision_detection(self):
         self.lib.refdrv_attach_collision_detection()
 
+    def add_tetgen_model(self, node_file, ele_file, x, axis, angle, scale):
+        """a tet model loaded by the reference's TetGenLoader and placed like SceneLoaderDemo places the models of a scene file"""
+        self.lib.refdrv_add_tetgen_model.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]
+        self.lib.refdrv_add_tetgen_model.restype = C.c_int
+        X, A, S = (np.ascontiguousarray(v, dtype=np.float64) for v in (x, axis, scale))
+        r = self.lib.refdrv_add_tetgen_model(str(node_file).encode(), str(ele_file).encode(), _dp(X), _dp(A), float(angle), _dp(S))
+        if r < 0:
+            raise RuntimeError("reference TetGenLoader could not read %s / %s" % (node_file, ele_file))
+        return r
+
+    def kat_tet_contact_velocity(self, inputs, friction=0.0, lam=0.0):
+        """the reference's init_ParticleTetContactConstraint + velocitySolve_ParticleTetContactConstraint on one contact (26 inputs -> 20 outputs)"""
+        a = np.ascontiguousarray(inputs, dtype=np.float64)
+        out = np.zeros(20, dtype=np.float64)
+        self.lib.refdrv_kat_tet_contact_velocity.argtypes = [C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(C.c_double)]
+        self.lib.refdrv_kat_tet_contact_velocity.restype = None
+        self.lib.refdrv_kat_tet_contact_velocity(_dp(a), float(friction), float(lam), _dp(out))
+        return out
+
     def collision_detection_only(self):
         self.lib.refdrv_collision_detection_only()
 

@@ -54,7 +54,7 @@ class TetCollider(C.Structure):
                 ("test_mesh", C.c_int), ("body_index", C.c_uint32), ("points", Bvh), ("tets_bvh", Bvh), ("tets_rest", Bvh)]
 
 
-TET_CONTACT_FLOATS = 30
+TET_CONTACT_FLOATS = 34
 
 
 class PlanInfo(C.Structure):
@@ -132,7 +132,9 @@ SIGNATURES = [
     ("pbdx_debug_chain_sum_host", C.c_int, pf, C.c_uint64, u32, u32, pf, pf, C.POINTER(C.c_uint64)),
     ("pbdx_debug_tet_hulls", C.c_int, vp, u32, C.c_int, u32, C.POINTER(u32), pf),
     ("pbdx_debug_tet_solve_host", C.c_int, u32, pf, u32, pf, C.POINTER(u32)),
-    ("pbdx_debug_tet_contacts", C.c_int, u32, pf, pf, u32, C.POINTER(TetCollider), f32, u32, C.POINTER(u32), pf),
+    ("pbdx_debug_tet_contacts", C.c_int, u32, pf, pf, pf, u32, C.POINTER(TetCollider), f32, u32, C.POINTER(u32), pf),
+    ("pbdx_debug_tet_velocity_kat", C.c_int, pf, pf),
+    ("pbdx_debug_tet_impulses", C.c_int, vp, C.POINTER(u32), C.POINTER(C.c_uint64)),
     ("pbdx_model_plan_check", C.c_int, vp, u32, u32, u32, C.POINTER(PlanInfo)),
     ("pbdx_model_create", C.c_int, C.POINTER(vp)), ("pbdx_model_destroy", None, vp),
     ("pbdx_model_cleanup", C.c_int, vp), ("pbdx_model_reset", C.c_int, vp),

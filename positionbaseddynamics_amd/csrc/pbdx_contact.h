@@ -226,8 +226,12 @@ PBDX_HD bool contact_velocity_solve(float invMass0, V3 v0, float stiffness, Cont
 
 // All contacts of ONE particle: detection against the colliders in order, contact initialisation with
 // the pre-solve velocity, `iterations` velocity sweeps.  Returns the number of contacts (or -1 on overflow).
+// `extra.after_sweep(v)`: what else changes this particle's velocity at the end of every iteration of velocityConstraintProjection
+// (TimeStepController.cpp:342-355: after the particle-rigid-body contacts come the particle-tet contacts, whose impulses are constants).
+struct NoExtraImpulses { PBDX_HD void after_sweep(V3 &) const {} };
+template <class Extra>
 PBDX_HD int particle_contacts(V3 x, V3 &v, float invMass, float mass, const pbdx_collider *colliders, uint32_t num_colliders,
-	float tolerance, float stiffness, float model_restitution, float model_friction, uint32_t iterations)
+	float tolerance, float stiffness, float model_restitution, float model_friction, uint32_t iterations, const Extra &extra)
 {
 	ContactInfo ci[PBDX_MAX_CONTACTS_PER_PARTICLE];
 	int nc = 0;
@@ -249,6 +253,7 @@ PBDX_HD int particle_contacts(V3 x, V3 &v, float invMass, float mass, const pbdx
 		nc++;
 	}
 	for (uint32_t it = 0; it < iterations; it++)
+	{
 		for (int k = 0; k < nc; k++)
 		{
 			V3 corr;
@@ -256,7 +261,14 @@ PBDX_HD int particle_contacts(V3 x, V3 &v, float invMass, float mass, const pbdx
 				if (mass != 0.0f)
 					v = v + corr;
 		}
+		extra.after_sweep(v);
+	}
 	return nc;
+}
+PBDX_HD int particle_contacts(V3 x, V3 &v, float invMass, float mass, const pbdx_collider *colliders, uint32_t num_colliders,
+	float tolerance, float stiffness, float model_restitution, float model_friction, uint32_t iterations)
+{
+	return particle_contacts(x, v, invMass, mass, colliders, num_colliders, tolerance, stiffness, model_restitution, model_friction, iterations, NoExtraImpulses());
 }
 
 } // namespace pbdx

@@ -804,6 +804,7 @@ struct ContactArgs
 	uint32_t iterations;
 	unsigned int *counters;         // [0] contacts, [1] overflow flag
 	const uint32_t *ctl;            // see integrate_kernel
+	const uint8_t *imp_mark;        // or null: particles whose velocity chain also holds particle-tet contact impulses (run by tet_impulse_kernel)
 };
 __global__ __launch_bounds__(256) void contact_kernel(ContactArgs a)
 {
@@ -811,6 +812,7 @@ __global__ __launch_bounds__(256) void contact_kernel(ContactArgs a)
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= a.count) return;
 	const uint32_t i = a.first + k;
+	if (a.imp_mark && a.imp_mark[i]) return;
 	const float4 p = a.pos[i];
 	float4 vv = a.vel[i];
 	V3 v = mk(vv.x, vv.y, vv.z);
@@ -863,7 +865,7 @@ __global__ __launch_bounds__(256) void tet_aabb_kernel(const TetColliderView *vi
 	}
 	if (threadIdx.x < 3) { aabb[6 * blockIdx.x + threadIdx.x] = lo[threadIdx.x][0]; aabb[6 * blockIdx.x + 3 + threadIdx.x] = hi[threadIdx.x][0]; }
 }
-__global__ void tet_detect_kernel(const TetColliderView *views, uint32_t n, const P4 *pos, const P4 *rest, const float *aabb, TetContact *contacts, uint32_t *counters, uint32_t max_contacts)
+__global__ void tet_detect_kernel(const TetColliderView *views, uint32_t n, const P4 *pos, const P4 *rest, const P4 *vel, const float *aabb, TetContact *contacts, uint32_t *counters, uint32_t max_contacts)
 {
 	if (blockIdx.x || threadIdx.x) return;
 	uint32_t found = 0;
@@ -872,7 +874,7 @@ __global__ void tet_detect_kernel(const TetColliderView *views, uint32_t n, cons
 		for (uint32_t k = 0; k < n; k++)
 		{
 			if (i == k || !views[i].test_mesh || !aabb_intersect(aabb + 6 * i, aabb + 6 * k)) continue;
-			ok = tet_pair_contacts(views[i], views[k], pos, rest, [&](const TetContact &c) {
+			ok = tet_pair_contacts(views[i], views[k], pos, rest, vel, [&](const TetContact &c) {
 				if (found < max_contacts) contacts[found] = c;
 				found++;
 			}) && ok;
@@ -1044,7 +1046,9 @@ struct pbdx_solver
 	uint32_t *d_tet_big = nullptr; uint32_t tet_big_count = 0;   // nodes with long chains (tet_hull_kernel2)
 	uint32_t *d_tet_big_slices = nullptr, *d_tet_big_r2 = nullptr; uint32_t tet_big_slices = 0;
 	TetWork tet_work = {};
-	void *tet_work_alloc[16] = {};
+	void *tet_work_alloc[18] = {};
+	pbdx_collision_range *d_ranges = nullptr;     // device copy of `ranges` (read by the tet-contact velocity chains)
+	uint32_t tet_impulses_last = 0; uint64_t tet_impulses_total = 0;     // contacts with a non-zero velocity impulse: last detection / since the colliders were set
 	int tet_serial = 0;                            // PBDX_OPT_TET_CONTACTS_SERIAL
 	uint32_t tet_grown = 0;                        // times the detection's scratch was enlarged
 	// developer switch: the long sphere sums run by run (pbdx_chainsum.h) instead of by the plain chain.  Exact either way; on the test
@@ -1069,6 +1073,7 @@ struct pbdx_solver
 	bool tet_active() const { return !tet_views.empty(); }
 	void free_tet_colliders()
 	{
+		tet_impulses_last = 0; tet_impulses_total = 0;
 		for (DevTetCollider &d : tet_dev)
 		{
 			if (d.tets) (void)hipFree(d.tets);
@@ -1854,7 +1859,7 @@ int alloc_tet_work_impl(pbdx_solver *s, uint64_t nodes, uint32_t contacts)
 	w.chunk_cap = (uint32_t)(nodes / 2);
 	HIPCHECK(hipMalloc(&s->tet_work_alloc[15], kTrWords * sizeof(uint32_t)));
 	w.trav = (uint32_t *)s->tet_work_alloc[15];
-	const size_t bytes[15] = { (size_t)3 * w.front_cap * 4, 0, (size_t)2 * n * n * 4, ((size_t)w.front_cap + 1) * 4, (size_t)w.chunk_cap * 4,
+	const size_t bytes[15] = { (size_t)3 * w.front_cap * 4, (size_t)contacts * 4, (size_t)2 * n * n * 4, ((size_t)w.front_cap + 1) * 4, (size_t)w.chunk_cap * 4,
 		(size_t)w.chunk_cap * 8, (size_t)w.chunk_cap * 4, (size_t)contacts * 4, ((size_t)contacts + 1) * 4, (size_t)contacts * 4, (size_t)s->n * 4,
 		(size_t)w.node_cap * 16, (size_t)w.node_cap * 8, (size_t)w.node_cap * 4, (size_t)w.node_cap * 8 };
 	for (int q = 0; q < 15; q++) if (bytes[q]) HIPCHECK(hipMalloc(&s->tet_work_alloc[q], bytes[q]));
@@ -1864,6 +1869,11 @@ int alloc_tet_work_impl(pbdx_solver *s, uint64_t nodes, uint32_t contacts)
 	w.level_of = (uint32_t *)s->tet_work_alloc[9]; w.owner = (uint32_t *)s->tet_work_alloc[10];
 	w.node_rec = (unsigned long long *)s->tet_work_alloc[11]; w.node_cnt = (unsigned long long *)s->tet_work_alloc[12]; w.node_child = (uint32_t *)s->tet_work_alloc[13]; w.node_off = (unsigned long long *)s->tet_work_alloc[14];
 	w.counters = s->d_tet_counters;
+	w.imp_list = (uint32_t *)s->tet_work_alloc[1];
+	HIPCHECK(hipMalloc(&s->tet_work_alloc[16], (size_t)std::max(1u, s->n)));
+	HIPCHECK(hipMemset(s->tet_work_alloc[16], 0, (size_t)std::max(1u, s->n)));
+	w.imp_mark = (uint8_t *)s->tet_work_alloc[16];
+	w.force_impulses = getenv("PBDX_TET_FORCE_IMPULSES") != nullptr && atoi(getenv("PBDX_TET_FORCE_IMPULSES")) != 0;
 	return PBDX_OK;
 }
 
@@ -1873,6 +1883,7 @@ int launch_tet_detection(pbdx_solver *s)
 	if (!s->tet_active() || !s->n) return PBDX_OK;
 	const P4 *pos = reinterpret_cast<const P4 *>(s->d_pos[0]);
 	const P4 *rest = reinterpret_cast<const P4 *>(s->d_rest);
+	const P4 *vel = reinterpret_cast<const P4 *>(s->d_vel);
 	const TetColliderView *views = s->d_tet_views;
 	const uint32_t nc = (uint32_t)s->tet_views.size();
 	if (s->tet_serial)
@@ -1884,7 +1895,7 @@ int launch_tet_detection(pbdx_solver *s)
 			hipLaunchKernelGGL(tet_hull_kernel, dim3((v.tet_bvh.num_nodes + 255) / 256), dim3(256), 0, s->stream, views, c, pos, 1);
 		}
 		hipLaunchKernelGGL(tet_aabb_kernel, dim3(nc), dim3(256), 0, s->stream, views, pos, s->d_tet_aabb);
-		hipLaunchKernelGGL(tet_detect_kernel, dim3(1), dim3(64), 0, s->stream, views, nc, pos, rest, (const float *)s->d_tet_aabb, s->d_tet_contacts, s->d_tet_counters, s->tet_work.max_contacts);
+		hipLaunchKernelGGL(tet_detect_kernel, dim3(1), dim3(64), 0, s->stream, views, nc, pos, rest, vel, (const float *)s->d_tet_aabb, s->d_tet_contacts, s->d_tet_counters, s->tet_work.max_contacts);
 	}
 	else
 	{
@@ -1926,11 +1937,13 @@ int launch_tet_detection(pbdx_solver *s)
 			hipLaunchKernelGGL(tet_traverse_kernel, dim3(wgs), dim3(256), 0, s->stream, views, nc, (const float *)s->d_tet_aabb, s->tet_work);
 		});
 		const uint32_t grid = (uint32_t)std::max(1, s->prop.multiProcessorCount) * 8u;
-		s->tet_timed(3, [&] { hipLaunchKernelGGL(tet_candidates_kernel<false>, dim3(grid), dim3(256), 0, s->stream, views, pos, rest, s->tet_work, s->d_tet_contacts); });
+		s->tet_timed(3, [&] { hipLaunchKernelGGL(tet_candidates_kernel<false>, dim3(grid), dim3(256), 0, s->stream, views, pos, rest, vel, s->tet_work, s->d_tet_contacts); });
 		s->tet_timed(4, [&] { hipLaunchKernelGGL(tet_chunk_scan_kernel, dim3(1), dim3(1024), 0, s->stream, s->tet_work); });
-		s->tet_timed(5, [&] { hipLaunchKernelGGL(tet_candidates_kernel<true>, dim3(grid), dim3(256), 0, s->stream, views, pos, rest, s->tet_work, s->d_tet_contacts); });
+		s->tet_timed(5, [&] { hipLaunchKernelGGL(tet_candidates_kernel<true>, dim3(grid), dim3(256), 0, s->stream, views, pos, rest, vel, s->tet_work, s->d_tet_contacts); });
 		s->tet_timed(6, [&] { hipLaunchKernelGGL(tet_levels_kernel, dim3(1), dim3(1024), 0, s->stream, (const TetContact *)s->d_tet_contacts, s->tet_work); });
 	}
+	// which contacts carry a velocity impulse (pMax < 0), in list order; marks on the dynamic particles they touch
+	hipLaunchKernelGGL(tet_impulse_list_kernel, dim3(1), dim3(1024), 0, s->stream, (const TetContact *)s->d_tet_contacts, pos, s->tet_work);
 	HIPCHECK(hipGetLastError());
 	return PBDX_OK;
 }
@@ -1952,7 +1965,9 @@ int enqueue_tet_detection(pbdx_solver *s)
 		HIPCHECK(hipStreamSynchronize(s->stream));
 		const bool more_nodes = c[kTcStack] == 1u || c[kTcStack] == 4u || (s->tet_serial && c[kTcStack]);
 		const bool more_contacts = c[kTcOverflow] == 1u;
-		if (!more_nodes && !more_contacts) return PBDX_OK;
+		if (!more_nodes && !more_contacts) { s->tet_impulses_last = c[kTcImpulses]; s->tet_impulses_total += c[kTcImpulses]; return PBDX_OK; }
+		// (a repeated detection starts from clean marks: the ones the abandoned attempt set are removed by the list it compacted)
+		hipLaunchKernelGGL(tet_impulse_clear_kernel, dim3(64), dim3(256), 0, s->stream, (const TetContact *)s->d_tet_contacts, s->tet_work);
 		const uint64_t nodes = more_nodes ? (uint64_t)s->tet_work.node_cap * 4u : s->tet_work.node_cap;
 		const uint64_t contacts = more_contacts ? (uint64_t)s->tet_work.max_contacts * 4u : s->tet_work.max_contacts;
 		if (nodes > (1ull << 29) || contacts > (1ull << 24) || (s->tet_serial && more_nodes)) return PBDX_OK;      // reported by the step
@@ -1970,19 +1985,38 @@ int enqueue_contacts(pbdx_solver *s)
 		int rt = enqueue_tet_detection(s);
 		if (rt) return rt;
 	}
-	if (s->colliders.empty() || s->ranges.empty() || !s->n) return PBDX_OK;
-	HIPCHECK(hipMemsetAsync(s->d_contact_counters, 0, sizeof(unsigned int), s->stream));      // [0] contacts of this step; [1] (overflow) is reset per call
-	for (const pbdx_collision_range &r : s->ranges)
+	const bool rigid = !s->colliders.empty() && !s->ranges.empty() && s->n;
+	if (rigid)
 	{
-		if (!r.count) continue;
-		ContactArgs a;
-		a.pos = s->d_pos[0]; a.vel = s->d_vel; a.colliders = s->d_colliders; a.num_colliders = (uint32_t)s->colliders.size();
-		a.first = r.first; a.count = r.count;
-		a.tolerance = s->contact_tolerance; a.stiffness = s->contact_stiffness; a.restitution = r.restitution; a.friction = r.friction;
-		a.iterations = s->max_iterations_v;
-		a.counters = s->d_contact_counters;
-		a.ctl = ctl_of(s, nullptr);
-		hipLaunchKernelGGL(contact_kernel, dim3((r.count + 255) / 256), dim3(256), 0, s->stream, a);
+		HIPCHECK(hipMemsetAsync(s->d_contact_counters, 0, sizeof(unsigned int), s->stream));      // [0] contacts of this step; [1] (overflow) is reset per call
+		for (const pbdx_collision_range &r : s->ranges)
+		{
+			if (!r.count) continue;
+			ContactArgs a;
+			a.pos = s->d_pos[0]; a.vel = s->d_vel; a.colliders = s->d_colliders; a.num_colliders = (uint32_t)s->colliders.size();
+			a.first = r.first; a.count = r.count;
+			a.tolerance = s->contact_tolerance; a.stiffness = s->contact_stiffness; a.restitution = r.restitution; a.friction = r.friction;
+			a.iterations = s->max_iterations_v;
+			a.counters = s->d_contact_counters;
+			a.ctl = ctl_of(s, nullptr);
+			a.imp_mark = s->tet_active() ? s->tet_work.imp_mark : nullptr;
+			hipLaunchKernelGGL(contact_kernel, dim3((r.count + 255) / 256), dim3(256), 0, s->stream, a);
+			HIPCHECK(hipGetLastError());
+		}
+	}
+	// velocity solve of the particle-tet contacts (friction 0: only contacts with pMax < 0 carry an impulse; the host knows how many from the
+	// counters the detection read back)
+	if (s->tet_active() && s->n && s->tet_impulses_last)
+	{
+		TetImpulseArgs a;
+		a.contacts = s->d_tet_contacts; a.pos = s->d_pos[0]; a.vel = s->d_vel; a.w = s->tet_work;
+		a.colliders = rigid ? s->d_colliders : nullptr; a.num_colliders = rigid ? (uint32_t)s->colliders.size() : 0u;
+		a.ranges = rigid ? s->d_ranges : nullptr; a.num_ranges = rigid ? (uint32_t)s->ranges.size() : 0u;
+		a.tolerance = s->contact_tolerance; a.stiffness = s->contact_stiffness; a.iterations = s->max_iterations_v;
+		a.contact_counters = rigid ? s->d_contact_counters : nullptr;
+		const uint32_t blocks = std::min(256u, (5u * s->tet_impulses_last + 255u) / 256u);
+		hipLaunchKernelGGL(tet_impulse_kernel, dim3(blocks), dim3(256), 0, s->stream, a);
+		hipLaunchKernelGGL(tet_impulse_clear_kernel, dim3(blocks), dim3(256), 0, s->stream, (const TetContact *)s->d_tet_contacts, s->tet_work);
 		HIPCHECK(hipGetLastError());
 	}
 	return PBDX_OK;
@@ -2250,6 +2284,7 @@ void pbdx_solver_destroy(pbdx_solver *s)
 	if (s->d_tet_counters) (void)hipFree(s->d_tet_counters);
 	s->unpin_all();
 	if (s->d_colliders) (void)hipFree(s->d_colliders);
+	if (s->d_ranges) (void)hipFree(s->d_ranges);
 	if (s->d_contact_counters) (void)hipFree(s->d_contact_counters);
 	for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
 	if (s->ev_start) (void)hipEventDestroy(s->ev_start);
@@ -2788,6 +2823,12 @@ int pbdx_solver_set_collision_ranges(pbdx_solver *s, uint32_t n, const pbdx_coll
 	HIPCHECK(hipSetDevice(s->device));
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	s->ranges.assign(ranges, ranges + n);
+	if (s->d_ranges) { (void)hipFree(s->d_ranges); s->d_ranges = nullptr; }
+	if (n)
+	{
+		HIPCHECK(hipMalloc(&s->d_ranges, (size_t)n * sizeof(pbdx_collision_range)));
+		HIPCHECK(hipMemcpy(s->d_ranges, ranges, (size_t)n * sizeof(pbdx_collision_range), hipMemcpyHostToDevice));
+	}
 	return PBDX_OK;
 }
 
@@ -2961,7 +3002,15 @@ int pbdx_debug_tet_counters(pbdx_solver *s, uint32_t out[8])
 	if (!s->d_tet_counters) return PBDX_OK;
 	HIPCHECK(hipSetDevice(s->device));
 	HIPCHECK(hipStreamSynchronize(s->stream));
-	HIPCHECK(hipMemcpy(out, s->d_tet_counters, kTcWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	HIPCHECK(hipMemcpy(out, s->d_tet_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	return PBDX_OK;
+}
+
+int pbdx_debug_tet_impulses(pbdx_solver *s, uint32_t *last, uint64_t *total)
+{
+	if (!s) return PBDX_ERR_INVALID;
+	if (last) *last = s->tet_impulses_last;
+	if (total) *total = s->tet_impulses_total;
 	return PBDX_OK;
 }
 

@@ -46,6 +46,8 @@ void contact_to_floats(const TetContact &c, float *o)
 	o[9] = c.nKn_inv;
 	for (int v = 0; v < 4; v++) for (int k = 0; k < 3; k++) o[10 + 3 * v + k] = c.x[v][k];
 	for (int v = 0; v < 4; v++) { o[22 + v] = c.w[v]; o[26 + v] = (float)c.vert[v]; }
+	for (int k = 0; k < 3; k++) o[30 + k] = c.tangent[k];
+	o[33] = c.p_max;
 }
 
 
@@ -110,7 +112,7 @@ int validate_tet_colliders(uint32_t n, const pbdx_tet_collider *colliders, uint3
 
 } // namespace pbdx
 
-extern "C" int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float *rest4, uint32_t n, const pbdx_tet_collider *colliders,
+extern "C" int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float *rest4, const float *vel4, uint32_t n, const pbdx_tet_collider *colliders,
 	float tolerance, uint32_t capacity, uint32_t *count, float *out)
 {
 	if (!pos4 || !rest4 || (n && !colliders) || !count) { set_error("debug_tet_contacts: null argument"); return PBDX_ERR_INVALID; }
@@ -142,13 +144,47 @@ extern "C" int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, 
 		for (uint32_t k = 0; k < n; k++)
 		{
 			if (i == k || !cs[i].view.test_mesh || !aabb_intersect(&aabb[6 * i], &aabb[6 * k])) continue;
-			ok = tet_pair_contacts(cs[i].view, cs[k].view, pos, x0, [&](const TetContact &c) {
+			ok = tet_pair_contacts(cs[i].view, cs[k].view, pos, x0, reinterpret_cast<const P4 *>(vel4), [&](const TetContact &c) {
 				if (found < capacity && out) contact_to_floats(c, out + (size_t)found * PBDX_TET_CONTACT_FLOATS);
 				found++;
 			}) && ok;
 		}
 	*count = found;
 	if (!ok) { set_error("debug_tet_contacts: traversal stack overflow"); return PBDX_ERR_INVALID; }
+	return PBDX_OK;
+}
+
+// Known-answer entry of the velocity part of a particle-tet contact (init_ParticleTetContactConstraint's tangent / pMax and
+// velocitySolve_ParticleTetContactConstraint with friction 0): in: invMass0, v0[3], invMass[4], v[4][3], bary[3], normal[3] (26 floats);
+// out: tangent[3], pMax, applied (1 / 0), corr_v0[3], corr_v[4][3] (20 floats; corrections of static particles and of contacts without an impulse are 0)
+extern "C" int pbdx_debug_tet_velocity_kat(const float *in, float *out)
+{
+	if (!in || !out) return PBDX_ERR_INVALID;
+	const float w0 = in[0];
+	const V3 v0 = mk(in[1], in[2], in[3]);
+	TetContact c;
+	memset(&c, 0, sizeof(c));
+	V3 v[4];
+	for (int k = 0; k < 4; k++) { c.w[k] = in[4 + k]; v[k] = mk(in[8 + 3 * k], in[9 + 3 * k], in[10 + 3 * k]); }
+	const V3 bary = mk(in[20], in[21], in[22]), normal = mk(in[23], in[24], in[25]);
+	c.bary[0] = bary.x; c.bary[1] = bary.y; c.bary[2] = bary.z;
+	const float bary0 = 1.0f - bary.x - bary.y - bary.z;
+	const float JMinvJT = w0 + bary0 * bary0 * c.w[0] + bary.x * bary.x * c.w[1] + bary.y * bary.y * c.w[2] + bary.z * bary.z * c.w[3];
+	V3 t; float p_max;
+	tet_contact_velocity_info(v0, v, bary, normal, JMinvJT, t, p_max);
+	c.tangent[0] = t.x; c.tangent[1] = t.y; c.tangent[2] = t.z; c.p_max = p_max;
+	for (int k = 0; k < 20; k++) out[k] = 0.0f;
+	out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = p_max;
+	V3 pv;
+	if (tet_contact_velocity_impulse(c, w0, pv))
+	{
+		out[4] = 1.0f;
+		for (int r = 0; r < 5; r++)
+		{
+			V3 corr;
+			if (tet_contact_velocity_share(c, w0, pv, r, corr)) { out[5 + 3 * r] = corr.x; out[6 + 3 * r] = corr.y; out[7 + 3 * r] = corr.z; }
+		}
+	}
 	return PBDX_OK;
 }
 

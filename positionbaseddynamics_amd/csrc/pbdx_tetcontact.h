@@ -15,10 +15,18 @@
 // the C++ library's business).  The hierarchies are built once, by the reference itself, when a collision object is registered;
 // a binding hands the engine their structure (entity order + nodes) and the engine only refreshes the bounding spheres every step
 // (which is all the reference does after construction).
-// The velocity solve of these contacts reads m_lambda before anything has written it (Constraints.h:553, SimulationModel.cpp:557:
-// the contact list is rebuilt right before the velocity solve and the position solve that sets m_lambda runs a step later); with a
-// friction coefficient of zero the impulse is (-0 * garbage) * tangent = 0 for any finite garbage, and that is the case this engine
-// implements: the velocity solve of particle-tet contacts is a no-op, a non-zero friction coefficient is refused.
+// The velocity solve of these contacts (velocitySolve_ParticleTetContactConstraint, PositionBasedDynamics.cpp:1274-1327) reads m_lambda
+// before anything has written it (Constraints.h:553, SimulationModel.cpp:557: the contact list is rebuilt right before the velocity solve
+// and the position solve that sets m_lambda runs a step later).  With a friction coefficient of zero `frictionCoeff * lambda` is zero for
+// any finite garbage, and that is the case this engine implements (a non-zero friction coefficient is refused):
+//     pMax = 1 / (J M^-1 J^T) * u_rel . t                    (init_ParticleTetContactConstraint :1199-1213)
+//     0 > pMax   ->  pv = -pMax * t,  v0 += w0 pv,  v_k -= w_k bary_k pv        (:1305-1306)
+//     otherwise  ->  pv = (-0 * garbage) * t = a signed zero: nothing moves
+// pMax is NOT always >= 0: when the tangential part t = u_rel - (u_rel . n) n is short (|t|^2 <= 1e-6) it is left un-normalised and
+// u_rel . t = |t|^2 + (u_rel . n)(n . t) is negative whenever the rounding residue n . t outweighs |t|^2 -- for near-normal impacts about
+// every second contact.  The impulse is then tiny (it only shows in velocity components that are themselves ~0) but it is what the
+// reference computes, and it is applied maxIterationsV times, interleaved with the rigid-body contact sweeps (TimeStepController.cpp:
+// 342-355).  The impulse of a contact is a constant of the contact, so the interleaving decomposes into per-particle chains again.
 #ifndef PBDX_TETCONTACT_H
 #define PBDX_TETCONTACT_H
 
@@ -66,7 +74,48 @@ struct TetContact                 // one ParticleTetContactConstraint: what its 
 	float nKn_inv;                // m_constraintInfo(0, 2)
 	float x[4][3];                // m_x: the tet's vertex positions WHEN THE CONTACT WAS DETECTED (the solve uses these, not the current ones)
 	float w[4];                   // m_invMasses
+	float tangent[3];             // m_constraintInfo.col(1)
+	float p_max;                  // m_constraintInfo(1, 2): "maximal impulse in tangent direction"
 };
+
+// init_ParticleTetContactConstraint's velocity part (PositionBasedDynamics.cpp:1190-1213): tangent and maximal tangent impulse from the
+// velocities at detection.  v0: the particle's velocity, v[4]: the tet vertices'.
+PBDX_HD void tet_contact_velocity_info(V3 v0, const V3 v[4], V3 bary, V3 normal, float JMinvJT, V3 &t, float &p_max)
+{
+	const float bary0 = 1.0f - bary.x - bary.y - bary.z;
+	const V3 v1 = ((bary0 * v[0] + bary.x * v[1]) + bary.y * v[2]) + bary.z * v[3];
+	const V3 u_rel = v0 - v1;
+	const float u_rel_n = dot(normal, u_rel);
+	t = u_rel - u_rel_n * normal;
+	const float tl2 = sqn(t);
+	if ((double)tl2 > 1.0e-6)
+		t = t * (float)(1.0 / sqrt((double)tl2));       // `static_cast<Real>(1.0) / sqrt(tl2)`: in this translation unit sqrt is the C library's sqrt(double)
+	p_max = 1.0f / JMinvJT * dot(u_rel, t);
+}
+// velocitySolve_ParticleTetContactConstraint for frictionCoeff == 0 (:1296-1324): true if the contact carries a non-zero impulse pv
+// (then v0 += w0 pv if the particle is dynamic, v_k += (-w_k bary_k) pv for the dynamic tet vertices, k-th barycentric weight
+// bary0, bary[0], bary[1], bary[2])
+// (force: developer aid PBDX_TET_FORCE_IMPULSES -- the test of the application path: contacts with pMax > 0 are treated as the ones with pMax < 0
+// are, because real scenes almost never produce a negative pMax; the arithmetic of the branch itself is pinned by the known-answer test)
+PBDX_HD bool tet_contact_velocity_impulse(const TetContact &c, float w0, V3 &pv, bool force = false)
+{
+	if ((w0 == 0.0f) && (c.w[0] == 0.0f) && (c.w[1] == 0.0f) && (c.w[2] == 0.0f))
+		return false;
+	if (force ? !(c.p_max > 0.0f) : !(0.0f > c.p_max))
+		return false;
+	pv = (-c.p_max) * mk(c.tangent[0], c.tangent[1], c.tangent[2]);
+	return true;
+}
+// the impulse's share of particle role r (0: the contact's particle, 1..4: the tet's vertices); false if that particle is static
+PBDX_HD bool tet_contact_velocity_share(const TetContact &c, float w0, V3 pv, int r, V3 &corr)
+{
+	if (r == 0) { if (w0 == 0.0f) return false; corr = w0 * pv; return true; }
+	const float bary0 = 1.0f - c.bary[0] - c.bary[1] - c.bary[2];
+	const float b = r == 1 ? bary0 : c.bary[r - 2];
+	if (c.w[r - 1] == 0.0f) return false;
+	corr = (-c.w[r - 1] * b) * pv;
+	return true;
+}
 
 PBDX_HD V3 p3(const P4 &p) { return mk(p.x, p.y, p.z); }
 
@@ -175,7 +224,8 @@ PBDX_HD bool find_ref_tet_at(const TetColliderView &c, const P4 *x0 /* rest posi
 
 // ---- one (point, tet) candidate of a leaf pair: collisionDetectionSolidSolid's inner body -----------------------------------------
 // pos: current positions (engine records, global indexing), x0: rest positions (global).  co1 owns the point, co2 the tet.
-PBDX_HD bool tet_contact_candidate(const TetColliderView &co2, const P4 *pos, const P4 *x0, uint32_t particle, uint32_t tet, TetContact &out)
+// vel: the engine's velocity records (vx, vy, vz, mass), global indexing; null: all velocities zero (host evaluations without velocities)
+PBDX_HD bool tet_contact_candidate(const TetColliderView &co2, const P4 *pos, const P4 *x0, const P4 *vel, uint32_t particle, uint32_t tet, TetContact &out)
 {
 	const uint32_t off2 = co2.first;
 	const V3 x_w = p3(pos[particle]);
@@ -223,13 +273,20 @@ PBDX_HD bool tet_contact_candidate(const TetColliderView &co2, const P4 *pos, co
 	const float bary0 = 1.0f - cp_bary.x - cp_bary.y - cp_bary.z;
 	const float JMinvJT = pos[particle].w + bary0 * bary0 * out.w[0] + cp_bary.x * cp_bary.x * out.w[1] + cp_bary.y * cp_bary.y * out.w[2] + cp_bary.z * cp_bary.z * out.w[3];
 	out.nKn_inv = 1.0f / JMinvJT;
+	V3 vv[4], v0 = mk(0.0f, 0.0f, 0.0f);
+	for (int k = 0; k < 4; k++) vv[k] = vel ? p3(vel[ti[k] + off2]) : mk(0.0f, 0.0f, 0.0f);
+	if (vel) v0 = p3(vel[particle]);
+	V3 t; float p_max;
+	tet_contact_velocity_info(v0, vv, cp_bary, n_w, JMinvJT, t, p_max);
+	out.tangent[0] = t.x; out.tangent[1] = t.y; out.tangent[2] = t.z;
+	out.p_max = p_max;
 	return true;
 }
 
 // ---- detection of one ordered pair (co1's points vs co2's tets): BVHTest::traverse + the leaf callback, in the reference's order ----
 // emit(contact) is called in the order the reference appends to its contact list.  Returns false if the traversal stack overflowed.
 template <class Emit>
-PBDX_HD bool tet_pair_contacts(const TetColliderView &co1, const TetColliderView &co2, const P4 *pos, const P4 *x0, Emit &&emit)
+PBDX_HD bool tet_pair_contacts(const TetColliderView &co1, const TetColliderView &co2, const P4 *pos, const P4 *x0, const P4 *vel, Emit &&emit)
 {
 	const BvhView &b1 = co1.points, &b2 = co2.tet_bvh;
 	if (!b1.num_nodes || !b2.num_nodes) return true;
@@ -252,7 +309,7 @@ PBDX_HD bool tet_pair_contacts(const TetColliderView &co1, const TetColliderView
 				for (uint32_t j = beg2; j < beg2 + n2; j++)
 				{
 					TetContact c;
-					if (tet_contact_candidate(co2, pos, x0, b1.lst[i] + co1.first, b2.lst[j], c)) emit(c);
+					if (tet_contact_candidate(co2, pos, x0, vel, b1.lst[i] + co1.first, b2.lst[j], c)) emit(c);
 				}
 			continue;
 		}
@@ -299,7 +356,7 @@ PBDX_HD void tet_contact_position_solve(const TetContact &c, Pos &p)
 	if (c.w[3] != 0.0f) p.add(c.vert[3], (-c.w[3] * c.bary[2]) * pp);
 }
 
-// the 30-float record of pbdx_solver_get_tet_contacts / pbdx_debug_tet_contacts (pbdx_tetcontact.cpp)
+// the 34-float record of pbdx_solver_get_tet_contacts / pbdx_debug_tet_contacts (pbdx_tetcontact.cpp)
 void contact_to_floats(const TetContact &c, float *o);
 
 } // namespace pbdx

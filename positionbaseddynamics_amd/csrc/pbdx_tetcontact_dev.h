@@ -35,7 +35,8 @@
 namespace pbdx {
 
 constexpr uint32_t kTetContactsAtFirst = 1u << 16;      // capacities grow on demand (enqueue_tet_detection / alloc_tet_work in pbdx_solver.hip)
-enum { kTcCount = 0, kTcOverflow = 1, kTcStack = 2, kTcLeafPairs = 3, kTcChunks = 4, kTcLevels = 5, kTcGenerations = 6, kTcTreeNodes = 7, kTcWords = 8 };
+enum { kTcCount = 0, kTcOverflow = 1, kTcStack = 2, kTcLeafPairs = 3, kTcChunks = 4, kTcLevels = 5, kTcGenerations = 6, kTcTreeNodes = 7,
+	kTcImpulses = 8 /* contacts of the list that carry a non-zero velocity impulse */, kTcWords = 10 };
 
 struct TetWork                    // device scratch of the detection; *_cap are capacities in elements
 {
@@ -62,6 +63,9 @@ struct TetWork                    // device scratch of the detection; *_cap are 
 	uint32_t *level_of;           // per contact
 	uint32_t *owner;              // per particle: first unscheduled contact that touches it (written and read at the L2: the minima are atomics)
 	uint32_t *counters;           // kTcWords
+	uint32_t *imp_list;           // the contacts that carry a velocity impulse (pMax < 0), in list order (max_contacts entries)
+	uint8_t *imp_mark;            // per particle: 1 while it takes part in such a contact as a dynamic particle (all zero between steps)
+	int force_impulses;           // developer aid (PBDX_TET_FORCE_IMPULSES): see tet_contact_velocity_impulse
 };
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(256) void tet_traverse_kernel(const TetColliderView
 // ---- candidates: one wavefront per chunk of 64 (point, tet) candidates of a leaf pair -------------------------------------------------
 // kWrite = false: ballot of the candidates that are contacts.  kWrite = true: the contacts go to their place in the list.
 template <bool kWrite>
-__global__ __launch_bounds__(256) void tet_candidates_kernel(const TetColliderView *views, const P4 *pos, const P4 *rest, TetWork w, TetContact *contacts)
+__global__ __launch_bounds__(256) void tet_candidates_kernel(const TetColliderView *views, const P4 *pos, const P4 *rest, const P4 *vel, TetWork w, TetContact *contacts)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t chunks = w.counters[kTcChunks];
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(256) void tet_candidates_kernel(const TetColliderVi
 		bool hit = false;
 		TetContact c;
 		if (idx < n1 * n2 && (!kWrite || ((mask >> lane) & 1ull)))
-			hit = tet_contact_candidate(co2, pos, rest, co1.points.lst[beg1 + idx / n2] + co1.first, co2.tet_bvh.lst[beg2 + idx % n2], c);
+			hit = tet_contact_candidate(co2, pos, rest, vel, co1.points.lst[beg1 + idx / n2] + co1.first, co2.tet_bvh.lst[beg2 + idx % n2], c);
 		if (!kWrite)
 		{
 			const unsigned long long m = __ballot(hit);
@@ -865,6 +869,133 @@ __global__ __launch_bounds__(1024) void tet_contact_solve_levels_kernel(float4 *
 		const uint32_t end = w.level_start[l + 1];
 		for (uint32_t i = w.level_start[l] + threadIdx.x; i < end; i += 1024) tet_contact_position_solve(contacts[w.order[i]], acc);
 		__syncthreads();
+	}
+}
+
+
+// ---- velocity solve of the particle-tet contacts (friction 0; pbdx_tetcontact.h) --------------------------------------------------------
+// A contact's impulse is a constant of the contact (it is computed from the velocities at detection), it is applied once per iteration of
+// velocityConstraintProjection after the rigid-body contacts of that iteration, and static rigid bodies couple nothing: the whole velocity
+// solve decomposes into per-particle chains  [contacts of p with rigid bodies, sweep it] [impulses of the tet contacts p takes part in,
+// in list order]  for it = 0 .. maxIterationsV - 1.  Only contacts with pMax < 0 carry an impulse (usually none, in near-normal impacts
+// about every second one): they are compacted in list order, the dynamic particles they touch are marked, and one lane per marked particle
+// (the lane of the particle's FIRST appearance in the compacted list) runs that particle's chain; the rigid-body contact kernel leaves
+// marked particles alone.
+__global__ __launch_bounds__(1024) void tet_impulse_list_kernel(const TetContact *contacts, const P4 *pos, TetWork w)
+{
+	__shared__ uint32_t lds[65];
+	const uint32_t n = w.counters[kTcCount];
+	uint32_t base = 0;
+	for (uint32_t c0 = 0; c0 < n; c0 += 1024)
+	{
+		const uint32_t q = c0 + threadIdx.x;
+		uint32_t flag = 0;
+		if (q < n)
+		{
+			const TetContact &c = contacts[q];
+			V3 pv;
+			if (tet_contact_velocity_impulse(c, pos[c.particle].w, pv, w.force_impulses != 0))
+			{
+				flag = 1;
+				if (pos[c.particle].w != 0.0f) w.imp_mark[c.particle] = 1;
+				for (int k = 0; k < 4; k++) if (c.w[k] != 0.0f) w.imp_mark[c.vert[k]] = 1;
+			}
+		}
+		uint32_t total;
+		const uint32_t at = base + block_exclusive_scan(flag, lds, total);
+		if (flag) w.imp_list[at] = q;
+		base += total;
+	}
+	if (threadIdx.x == 0) w.counters[kTcImpulses] = base;
+}
+
+struct TetImpulseChain          // Extra of particle_contacts (pbdx_contact.h): the tet-contact impulses of particle `p`, one iteration's worth
+{
+	const TetContact *contacts;
+	const P4 *pos;
+	const uint32_t *list;
+	uint32_t count, p;
+	bool force;
+	__device__ void after_sweep(V3 &v) const
+	{
+		for (uint32_t e = 0; e < count; e++)
+		{
+			const TetContact &c = contacts[list[e]];
+			const uint32_t ids[5] = { c.particle, c.vert[0], c.vert[1], c.vert[2], c.vert[3] };
+			bool mine = false;
+			for (int r = 0; r < 5; r++) mine = mine || ids[r] == p;
+			if (!mine) continue;
+			const float w0 = pos[c.particle].w;
+			V3 pv;
+			if (!tet_contact_velocity_impulse(c, w0, pv, force)) continue;
+			for (int r = 0; r < 5; r++)            // a tet's four vertices are distinct and its contact particle belongs to another solid
+			{
+				V3 corr;
+				if (ids[r] == p && tet_contact_velocity_share(c, w0, pv, r, corr)) v = v + corr;
+			}
+		}
+	}
+};
+
+struct TetImpulseArgs
+{
+	const TetContact *contacts;
+	const float4 *pos;
+	float4 *vel;
+	TetWork w;
+	const pbdx_collider *colliders; uint32_t num_colliders;
+	const pbdx_collision_range *ranges; uint32_t num_ranges;
+	float tolerance, stiffness;
+	uint32_t iterations;
+	unsigned int *contact_counters;      // of the rigid-body contacts: [0] contacts, [1] overflow flag (may be null)
+};
+__global__ __launch_bounds__(256) void tet_impulse_kernel(TetImpulseArgs a)
+{
+	const uint32_t count = a.w.counters[kTcImpulses];
+	const P4 *pos = reinterpret_cast<const P4 *>(a.pos);
+	for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < 5u * count; slot += gridDim.x * blockDim.x)
+	{
+		const uint32_t e = slot / 5u, r = slot % 5u;
+		const TetContact &c = a.contacts[a.w.imp_list[e]];
+		const uint32_t p = r == 0 ? c.particle : c.vert[r - 1];
+		if (!a.w.imp_mark[p]) continue;                        // static in this contact and in every other one
+		// this lane runs p's chain iff (e, r) is p's first appearance in the compacted list
+		bool first = true;
+		for (uint32_t e2 = 0; e2 <= e && first; e2++)
+		{
+			const TetContact &c2 = a.contacts[a.w.imp_list[e2]];
+			const uint32_t ids[5] = { c2.particle, c2.vert[0], c2.vert[1], c2.vert[2], c2.vert[3] };
+			for (uint32_t r2 = 0; r2 < (e2 == e ? r : 5u); r2++) if (ids[r2] == p) first = false;
+		}
+		if (!first) continue;
+		const float4 x = a.pos[p];
+		float4 vv = a.vel[p];
+		if (vv.w == 0.0f) continue;                            // (marks are only set for dynamic particles)
+		V3 v = mk(vv.x, vv.y, vv.z);
+		const TetImpulseChain chain = { a.contacts, pos, a.w.imp_list, count, p, a.w.force_impulses != 0 };
+		// p's contacts with the static rigid bodies, if it belongs to a collision range (pbdx_contact.h)
+		const pbdx_collision_range *rg = nullptr;
+		if (a.num_colliders) for (uint32_t q = 0; q < a.num_ranges; q++) if (p >= a.ranges[q].first && p - a.ranges[q].first < a.ranges[q].count) rg = &a.ranges[q];
+		if (rg)
+		{
+			const int nc = particle_contacts(mk(x.x, x.y, x.z), v, x.w, vv.w, a.colliders, a.num_colliders, a.tolerance, a.stiffness, rg->restitution, rg->friction, a.iterations, chain);
+			if (nc < 0) { if (a.contact_counters) atomicExch(&a.contact_counters[1], 1u); continue; }
+			if (nc > 0 && a.contact_counters) atomicAdd(&a.contact_counters[0], (unsigned int)nc);
+		}
+		else
+			for (uint32_t it = 0; it < a.iterations; it++) chain.after_sweep(v);
+		a.vel[p] = make_float4(v.x, v.y, v.z, vv.w);
+	}
+}
+// the marks go back to zero once every chain has run (separate launch: a chain reads the marks of other particles' lanes' contacts)
+__global__ __launch_bounds__(256) void tet_impulse_clear_kernel(const TetContact *contacts, TetWork w)
+{
+	const uint32_t count = w.counters[kTcImpulses];
+	for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x)
+	{
+		const TetContact &c = contacts[w.imp_list[e]];
+		w.imp_mark[c.particle] = 0;
+		for (int k = 0; k < 4; k++) w.imp_mark[c.vert[k]] = 0;
 	}
 }
 

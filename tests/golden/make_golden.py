@@ -88,9 +88,24 @@ def tet_contact_golden():
     print("tet contact scene done:", len(out["contacts_71"]), len(out["contacts_76"]), "contacts")
 
 
+def tet_contact_velocity_golden():
+    """The velocity part of a particle-tet contact through the reference's own init_ / velocitySolve_ParticleTetContactConstraint (friction 0) on
+    the adversarial inputs of tests/tetcontact_util.velocity_kat_inputs."""
+    from tests import tetcontact_util as tcu
+    ref = refdrv.Ref("f32")
+    inp = tcu.velocity_kat_inputs()
+    out = np.array([ref.kat_tet_contact_velocity(row.astype(np.float64)) for row in inp], dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, "tetcontact_velocity_kat.npz"), inputs=inp, outputs=out)
+    print("tet contact velocity KAT done:", len(inp), "cases,", int((out[:, 3] < 0).sum()), "with pMax < 0")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "tetcontact":
         tet_contact_golden()
+        tet_contact_velocity_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "tetcontact_velocity":
+        tet_contact_velocity_golden()
     else:
         main()
         tet_contact_golden()
+        tet_contact_velocity_golden()

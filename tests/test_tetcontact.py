@@ -106,7 +106,7 @@ def test_malformed_hierarchies_are_refused_before_anything_walks_them():
         pos4 = np.ascontiguousarray(np.concatenate([x, w[:, None]], axis=1), dtype=np.float32)
         rest4 = np.ascontiguousarray(np.concatenate([x0, w[:, None]], axis=1), dtype=np.float32)
         count = C.c_uint32(0)
-        rc = _ffi.lib.pbdx_debug_tet_contacts(len(x), pos4.ctypes.data_as(_ffi.pf), rest4.ctypes.data_as(_ffi.pf), cols.n, cols.arr, float(cols.tolerance), 0,
+        rc = _ffi.lib.pbdx_debug_tet_contacts(len(x), pos4.ctypes.data_as(_ffi.pf), rest4.ctypes.data_as(_ffi.pf), None, cols.n, cols.arr, float(cols.tolerance), 0,
                                               C.byref(count), None)
         assert rc != 0 and needle in _ffi.lib.pbdx_last_error(), _ffi.lib.pbdx_last_error()
 
@@ -131,6 +131,52 @@ def test_malformed_hierarchies_are_refused_before_anything_walks_them():
     fails(friction, b"friction")
     # and the untouched fixture passes
     assert len(tcu.host_contacts_of_state(x, x0, w, tcu.GoldenTetColliders(g))) > 10
+
+
+def test_contact_velocity_arithmetic_vs_golden_and_live_reference():
+    """velocitySolve_ParticleTetContactConstraint for friction 0 INCLUDING its `0 > pMax` branch (PositionBasedDynamics.cpp:1199-1213, 1296-1324;
+    VERDICT r2 weak 1c): the engine's arithmetic (host evaluation of the device header) against the committed outputs of the reference's own
+    functions on adversarial inputs -- near-normal relative velocities, un-normalised tangents, negative maximal tangent impulses -- and, where the
+    reference is built, against the live reference."""
+    g = np.load(os.path.join(util.ROOT, "tests", "golden", "tetcontact_velocity_kat.npz"))
+    inp, want = g["inputs"], g["outputs"]
+    assert (want[:, 3] < 0).sum() > 500 and (want[:, 3] > 0).sum() > 500          # both branches are there
+    got = tcu.engine_velocity_kat(inp)
+    assert tcu.velocity_kat_equal(got, want)
+    # the impulse is applied exactly when pMax < 0 (and not everything is static), and it is never zero then
+    applied = got[:, 4] == 1
+    not_static = ~((inp[:, 0] == 0) & (inp[:, 4] == 0) & (inp[:, 5] == 0) & (inp[:, 6] == 0))
+    assert np.array_equal(applied, (want[:, 3] < 0) & not_static)
+    from oracle import refdrv
+    if refdrv.available("f32"):
+        ref = refdrv.Ref("f32")
+        fresh = tcu.velocity_kat_inputs(600, seed=99)
+        live = np.array([ref.kat_tet_contact_velocity(r.astype(np.float64)) for r in fresh], dtype=np.float32)
+        assert tcu.velocity_kat_equal(tcu.engine_velocity_kat(fresh), live)
+        # the golden file is what the live reference says
+        again = np.array([ref.kat_tet_contact_velocity(r.astype(np.float64)) for r in inp[:400]], dtype=np.float32)
+        assert np.array_equal(again.view(np.uint32), want[:400].view(np.uint32))
+
+
+def test_engine_contact_velocity_columns_equal_reference():
+    """tangent and maximal tangent impulse of every contact (constraintInfo.col(1), (1, 2)) as the detection computes them from the velocities
+    at detection: the engine's host evaluation against the reference's contact list on the same state, 110 steps of the two-bar scene."""
+    ref = _ref()
+    objs = tcu.two_bar_scene(ref)
+    ref.set_params(1, 5, 0)
+    cols = tcu.TetColliders(ref, objs, (0, 1), 0.01)
+    total = 0
+    for step in range(110):
+        ref.step(1)
+        ref.collision_detection_only()          # the contact list of the state the host arrays hold now (the step's own list predates its velocity solve)
+        want, wv = tcu.oracle_contacts_as_engine_records(ref), tcu.oracle_contact_velocity_columns(ref)
+        got = tcu.host_contacts(ref, cols)
+        assert len(got) == len(want)
+        if len(want):
+            assert util.bitwise_equal(got[:, :26], want) and util.bitwise_equal(got[:, 30:34], wv), "step %d" % step
+        total += len(want)
+    ref.reset_all()
+    assert total > 300
 
 
 def _levels(records):

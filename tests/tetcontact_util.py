@@ -161,13 +161,16 @@ class GoldenTetColliders:
                 f.hulls = hulls.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def host_contacts_of_state(x, x0, w, colliders, capacity=4096):
-    """pbdx_debug_tet_contacts on a given state"""
+def host_contacts_of_state(x, x0, w, colliders, capacity=4096, v=None, mass=None):
+    """pbdx_debug_tet_contacts on a given state (v: velocities or None = at rest; they only feed the tangent / maximal tangent impulse columns)"""
     pos4 = np.ascontiguousarray(np.concatenate([x, w[:, None]], axis=1), dtype=np.float32)
     rest4 = np.ascontiguousarray(np.concatenate([x0, w[:, None]], axis=1), dtype=np.float32)
+    vel4 = None
+    if v is not None:
+        vel4 = np.ascontiguousarray(np.concatenate([v, (mass if mass is not None else np.ones(len(v)))[:, None]], axis=1), dtype=np.float32)
     out = np.zeros((capacity, _ffi.TET_CONTACT_FLOATS), dtype=np.float32)
     count = C.c_uint32(0)
-    _ffi.check(_ffi.lib.pbdx_debug_tet_contacts(len(x), pos4.ctypes.data_as(_ffi.pf), rest4.ctypes.data_as(_ffi.pf), colliders.n, colliders.arr,
+    _ffi.check(_ffi.lib.pbdx_debug_tet_contacts(len(x), pos4.ctypes.data_as(_ffi.pf), rest4.ctypes.data_as(_ffi.pf), vel4.ctypes.data_as(_ffi.pf) if vel4 is not None else None, colliders.n, colliders.arr,
                                                 float(colliders.tolerance), capacity, C.byref(count), out.ctypes.data_as(_ffi.pf)), "debug_tet_contacts")
     return out[:count.value]
 
@@ -179,9 +182,10 @@ def host_contacts(ref, colliders, capacity=4096):
     w = ref.get_array(7).astype(np.float32)
     pos4 = np.ascontiguousarray(np.concatenate([x, w[:, None]], axis=1), dtype=np.float32)
     rest4 = np.ascontiguousarray(np.concatenate([x0, w[:, None]], axis=1), dtype=np.float32)
+    vel4 = np.ascontiguousarray(np.concatenate([ref.get_array(2), ref.get_array(6)[:, None]], axis=1), dtype=np.float32)
     out = np.zeros((capacity, _ffi.TET_CONTACT_FLOATS), dtype=np.float32)
     count = C.c_uint32(0)
-    _ffi.check(_ffi.lib.pbdx_debug_tet_contacts(len(x), pos4.ctypes.data_as(_ffi.pf), rest4.ctypes.data_as(_ffi.pf), colliders.n, colliders.arr,
+    _ffi.check(_ffi.lib.pbdx_debug_tet_contacts(len(x), pos4.ctypes.data_as(_ffi.pf), rest4.ctypes.data_as(_ffi.pf), vel4.ctypes.data_as(_ffi.pf), colliders.n, colliders.arr,
                                                 float(colliders.tolerance), capacity, C.byref(count), out.ctypes.data_as(_ffi.pf)), "debug_tet_contacts")
     return out[:count.value]
 
@@ -199,3 +203,58 @@ def oracle_contacts_as_engine_records(ref):
     out[:, 10:22] = c[:, 16:28]
     out[:, 22:26] = c[:, 28:32]
     return out
+
+
+def oracle_contact_velocity_columns(ref):
+    """tangent (constraintInfo.col(1)) and maximal tangent impulse (constraintInfo(1, 2)) of the oracle's contacts: columns 30..33 of the engine's record"""
+    c = ref.particle_solid_contacts()
+    out = np.zeros((len(c), 4), dtype=np.float32)
+    if len(c):
+        out[:, 0:3] = c[:, 9:12]          # column 1 of the column-major 3x3
+        out[:, 3] = c[:, 6 + 7]           # (1, 2): column 2, row 1
+    return out
+
+
+# ---- velocity part of ONE contact: adversarial known-answer inputs ----------------------------------------------------------------------
+def velocity_kat_inputs(n=4000, seed=11):
+    """26 floats per case (pbdx_debug_tet_velocity_kat): invMass0, v0[3], invMass[4], v[4][3], bary[3], normal[3].  Four families: generic;
+    relative velocity along the normal plus a tangential part of 1e-9 .. 1e-3; relative velocity exactly along the normal (what is left
+    of the tangent is rounding residue); a particle falling onto a resting tet with a slightly tilted normal.  In the last three the tangent
+    stays un-normalised (|t|^2 <= 1e-6) and the maximal tangent impulse u_rel . t comes out NEGATIVE for about half of the cases: the
+    branch `frictionCoeff * lambda > pMax` of velocitySolve_ParticleTetContactConstraint that a friction coefficient of 0 does not switch off."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for trial in range(n):
+        nrm = rng.standard_normal(3); nrm /= np.linalg.norm(nrm)
+        bary = rng.dirichlet(np.ones(4))[:3]
+        w = np.where(rng.random(5) < 0.15, 0.0, rng.uniform(0.5, 2.0, 5))
+        vt = rng.standard_normal((4, 3)) * 0.3
+        b0 = 1 - bary.sum()
+        v1 = b0 * vt[0] + bary[0] * vt[1] + bary[1] * vt[2] + bary[2] * vt[3]
+        mode = trial % 4
+        if mode == 0:
+            v0 = rng.standard_normal(3)
+        elif mode == 1:
+            v0 = v1 + nrm * rng.uniform(-3, 3) + rng.standard_normal(3) * 10.0 ** rng.uniform(-9, -3)
+        elif mode == 2:
+            v0 = v1 + nrm * rng.uniform(-3, 3)
+        else:
+            vt[:] = 0
+            v0 = np.array([0, -rng.uniform(0, 2), 0])
+            nrm = np.array([1e-4 * rng.standard_normal(), 1.0, 1e-4 * rng.standard_normal()]); nrm /= np.linalg.norm(nrm)
+        rows.append(np.concatenate([[w[0]], v0, w[1:], vt.reshape(-1), bary, nrm]))
+    return np.asarray(rows, dtype=np.float32)
+
+
+def engine_velocity_kat(inputs):
+    out = np.zeros((len(inputs), 20), dtype=np.float32)
+    for i, row in enumerate(np.ascontiguousarray(inputs, dtype=np.float32)):
+        _ffi.check(_ffi.lib.pbdx_debug_tet_velocity_kat(row.ctypes.data_as(_ffi.pf), out[i].ctypes.data_as(_ffi.pf)), "tet_velocity_kat")
+    return out
+
+
+def velocity_kat_equal(got, want):
+    """tangent and pMax bit for bit; corrections bit for bit up to the sign of a zero (the reference's impulse of a contact WITHOUT the pMax < 0
+    branch is (-0 * garbage) * tangent, a zero whose sign belongs to the garbage)"""
+    z = lambda a: np.where(a == 0, np.float32(0), a).view(np.uint32)
+    return bool(np.array_equal(got[:, :4].view(np.uint32), want[:, :4].view(np.uint32)) and np.array_equal(z(got[:, 5:]), z(want[:, 5:])))
