@@ -513,6 +513,91 @@ def cpu_baseline(size, iters, opts, hip_device, parity_steps=3, timed_steps=3):
     return rec, parity
 
 
+def run_c5(ens, sub_steps, with_reference=True):
+    """BASELINE configs[4] in the shape that can be pinned (positionbaseddynamics_amd/scenes.py: armadillo_collision_scene): three armadillo_4k FEM
+    solids + static floor, floor contacts and deformable-deformable contacts, maxIterations 1, maxIterationsV 5, h = 0.01.  Timed: 260 steps
+    resident in one call.  Parity: a second run, step by step, against the reference's committed results after 120 and 260 steps (positions,
+    velocities, contact lists: bit for bit).  CPU beside it: the reference itself on the same scene (oracle/_ref, 1 thread), 60 steps."""
+    import torch
+    import positionbaseddynamics_amd as pbd
+    from positionbaseddynamics_amd import scenes
+    ops, g = scenes.armadillo_collision_scene()
+
+    def fresh():
+        model = scenes.build_model(ops)
+        pbd.TimeManager.getCurrent().setTimeStepSize(float(g["time_step"]))
+        ts = pbd.TimeStepController(device=ens.hip_device)
+        ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, sub_steps)
+        ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, int(g["iterations"]))
+        ts.syncFromHost(model)
+        sol = ts.solver()
+        cols = scenes.install_armadillo_colliders(sol, g)
+        return model, ts, sol, cols
+
+    model, ts, sol, cols = fresh()
+    ts.stepResident(model, 2)                   # plan, schedule measurement
+    model, ts, sol, cols = fresh()
+    ts.stepResident(model, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ts.stepResident(model, 259)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / 259
+    engine = sol.describe()
+    n_particles, n_constraints = model.getParticles().size(), model.numConstraints()
+    # parity pass
+    model, ts, sol, cols = fresh()
+    same, compared, done, floor, tet_max = True, 0, 0, 0, 0
+    for steps in g["steps"]:
+        for _ in range(int(steps) - done):
+            ts.stepResident(model, 1)
+            floor += sol.num_contacts()
+        done = int(steps)
+        ts.syncToHost(model)
+        got, want = sol.tet_contacts(), g["contacts_sub%d_%d" % (sub_steps, steps)]
+        tet_max = max(tet_max, len(got))
+        x, v = model.getParticles().positions(), model.getParticles().velocities()
+        same = same and len(got) == len(want) and (not len(want) or np.array_equal(got[:, :26].view(np.uint32), want.view(np.uint32)))
+        same = same and np.array_equal(x.view(np.uint32), g["x_sub%d_%d" % (sub_steps, steps)].view(np.uint32)) and np.array_equal(v.view(np.uint32), g["v_sub%d_%d" % (sub_steps, steps)].view(np.uint32))
+        compared += x.size + v.size + got[:, :26].size
+    totals = g["contact_totals_sub%d" % sub_steps]
+    out = {"tag": "c5_armadillo_%dsub" % sub_steps,
+           "workload": "configs[4] (pinnable shape): 3 x armadillo_4k FEM tet solids (analytic box SDF stand-in, friction 0) + static floor, floor AND deformable-deformable contacts, "
+                       "%d substeps, maxIterations 1, maxIterationsV 5, h=0.01" % sub_steps,
+           "particles": n_particles, "constraints": n_constraints, "steps": 260, "sub_steps": sub_steps, "iterations": 1, "ms_per_step": ms, "ms_per_substep": ms / sub_steps,
+           "state_ok": bool(np.all(np.isfinite(model.getParticles().positions()))), "bit_identical": bool(same and floor == int(totals[1])), "compared_values": int(compared), "parity_steps": 260,
+           "contacts_deformable_total": int(totals[0]), "contacts_floor_total": int(floor), "contacts_max": int(tet_max), "engine": engine}
+    if with_reference:
+        try:
+            from oracle import refdrv
+            if refdrv.available("f32"):
+                ref = refdrv.Ref("f32")
+                ref.reset_all(); ref.set_num_threads(1); ref.set_time_step_size(0.01); ref.set_gravity(scenes.GRAVITY)
+                for q in range(3):
+                    _, _, offset, nv, nt, _ = (int(v) for v in g["c%d_meta" % q])
+                    ref.add_tet_model(g["x0"][offset:offset + nv].astype(np.float64), g["c%d_tets" % q].reshape(-1, 4))
+                    ref.set_tet_model_initial_transform(q, g["c%d_initial_x" % q].astype(np.float64), g["c%d_initial_R" % q].astype(np.float64).reshape(3, 3))
+                for q in range(3):
+                    ref.add_solid_constraints(q, 2, 1.0, 0.2, 1.0, False, False)
+                ref.set_collision_tolerance(0.0)
+                ref.add_static_collider("box", (0, 0, 0), (1, 0, 0, 0), (100, 1, 100), (100, 1, 100), 0.6, 0.0)
+                for q in range(3):
+                    ref.add_tet_collision_shape(q, 0, [float(v) for v in g["box"]], True, False, float(g["c%d_restitution" % q]), 0.0)
+                ref.attach_collision_detection()
+                ref.set_params(sub_steps, 1, 0); ref.set_max_iterations_v(5)
+                ref.step(60)
+                t1 = time.perf_counter()
+                ref.step(60)
+                out["reference_ms_per_step"] = 1e3 * (time.perf_counter() - t1) / 60
+                # the live reference also reproduces the fixture (steps 120)
+                out["reference_reproduces_fixture"] = bool(np.array_equal(ref.positions().astype(np.float32).view(np.uint32), g["x_sub%d_120" % sub_steps].view(np.uint32)))
+                ref.reset_all()
+        except Exception as e:  # pragma: no cover
+            out["reference_error"] = repr(e)
+    del cols
+    return out
+
+
 def shard_vs_reference(w, ens, opts, steps):
     """--check-shards (checker leg, small sizes): THIS rank's instances stepped by the reference itself (oracle/_ref f32) and by a
     fresh engine, compared bit for bit.  Ranks hold different instances, so this -- not a comparison of the ranks' checksums with each
@@ -603,7 +688,7 @@ def compact_headline(full, detail_path=None):
         out["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
     ex = full.get("extra_workloads") or []
     if ex:
-        out["extras"] = [{"w": e.get("tag", "?"), "ms": _r(e.get("ms_per_substep"), 4), "ok": e.get("state_ok", False) and e.get("bit_identical", True)} for e in ex]
+        out["extras"] = [{"w": e.get("tag", "?"), "ms": _r(e.get("ms_per_step", e.get("ms_per_substep")), 4), "ok": bool(e.get("state_ok", False) and e.get("bit_identical", True))} for e in ex]
     out = _r(out)
     line = json.dumps(out, separators=(",", ":"))
     if len(line) >= MAX_LINE:            # never let a long list cost the record: drop the optional parts, longest first
@@ -620,8 +705,8 @@ def compact_headline(full, detail_path=None):
 def compact_extra(e):
     """One line per extra workload (printed BEFORE the headline)."""
     out = _pick(e, ("tag", "workload", "particles", "constraints", "colour_groups", "steps", "ms_per_substep", "ms_per_step", "projections_per_s", "state_ok",
-                    "host_scene_build_s", "bit_identical", "compared_values", "parity_steps", "contacts_last_step", "contacts_max", "sub_steps", "iterations",
-                    "reference_ms_per_step", "error"))
+                    "host_scene_build_s", "bit_identical", "compared_values", "parity_steps", "contacts_deformable_total", "contacts_floor_total", "contacts_max", "sub_steps", "iterations",
+                    "reference_ms_per_step", "reference_reproduces_fixture", "error"))
     if "workload" in out:
         out["workload"] = str(out["workload"])[:220]
     if e.get("roofline"):
@@ -695,7 +780,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2", help="c5: only the configs[4]-shaped contact scene lines (8 and 5 substeps), no headline")
     ap.add_argument("--size", type=int, default=None, help="cloth is size x size particles (default 1000; 200 for c4)")
     ap.add_argument("--instances", type=int, default=64, help="c4 (weak scaling): cloth instances per GPU; c3 --bars: bars per GPU")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="c4: fixed instances per GPU (weak) or --total-instances sharded over the GPUs (strong)")
@@ -759,6 +844,11 @@ def main():
     if world == 1:
         torch.cuda.set_device(0)
 
+    if args.workload == "c5":
+        for sub in (8, 5):
+            print(compact_extra(run_c5(ens, sub)), flush=True)
+        ens.close()
+        return
     if args.pmc_child:
         from positionbaseddynamics_amd import _ffi
         for mode in range(4):
@@ -842,6 +932,11 @@ def main():
                            "steps": nsteps, "ms_per_substep": ms, "projections_per_s": r["n_constraints"] * ew["iters"] * nsteps / r["t_local"],
                            "state_ok": r["state_ok"], "host_scene_build_s": r["t_build"], "plan": r["plan"], "persistent": r["persistent"],
                            "engine": r["engine"], "roofline": r.get("roofline")})
+        for sub in (8, 5):
+            try:
+                extras.append(run_c5(ens, sub))
+            except Exception as e:
+                extras.append({"tag": "c5_armadillo_%dsub" % sub, "error": repr(e)})
         out["extra_workloads"] = extras
 
     if rank == 0:

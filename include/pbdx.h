@@ -336,8 +336,10 @@ enum {
 	PBDX_OPT_PERSISTENT_TIMEOUT_MS = 13, /* bound of a tile-to-tile wait inside the persistent launch in milliseconds, 1 .. 10000 (default 250) */
 	PBDX_OPT_PERSISTENT_WGS_PER_CU = 14, /* tiles (workgroups) the persistent launch keeps resident per CU, 1 .. 4 (default 1): with k > 1 the LDS is split k ways
 	                                * (smaller tiles, more halo) and one tile's fill / hand-off overlaps another tile's colour sweep on the same CU */
-	PBDX_OPT_TET_CONTACTS_SERIAL = 15    /* developer cross-check: 1 = detect and solve the contacts between deformable solids in ONE thread, in the reference's own
+	PBDX_OPT_TET_CONTACTS_SERIAL = 15,   /* developer cross-check: 1 = detect and solve the contacts between deformable solids in ONE thread, in the reference's own
 	                                      * control flow (default 0: the parallel, order-preserving form of pbdx_tetcontact_dev.h; both give the same bits) */
+	PBDX_OPT_TET_FORCE_IMPULSES = 16     /* developer aid (test of the velocity-impulse application path of particle-tet contacts): 1 = contacts with pMax > 0
+	                                      * are given the impulse the reference gives contacts with pMax < 0 -- NOT the reference's result; default 0 */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
 

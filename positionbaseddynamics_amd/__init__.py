@@ -695,7 +695,7 @@ class Solver:
         check(lib.pbdx_solver_set_tet_colliders(self._h, int(count), records, float(tolerance)), "set_tet_colliders")
 
     def tet_contacts(self, capacity=1 << 16):
-        """Contact list of the last detection between deformable solids: (count, 30) float records (include/pbdx.h)."""
+        """Contact list of the last detection between deformable solids: (count, 34) float records (include/pbdx.h)."""
         out = np.zeros((capacity, _ffi.TET_CONTACT_FLOATS), dtype=np.float32)
         n = C.c_uint32()
         check(lib.pbdx_solver_get_tet_contacts(self._h, capacity, C.byref(n), out.ctypes.data_as(_ffi.pf)), "get_tet_contacts")
@@ -705,6 +705,12 @@ class Solver:
         n = C.c_uint32()
         check(lib.pbdx_solver_get_num_contacts(self._h, C.byref(n)), "get_num_contacts")
         return n.value
+
+    def tet_impulses(self):
+        """(contacts of the last detection that carried a velocity impulse, total since the colliders were set)"""
+        last, total = C.c_uint32(), C.c_uint64()
+        check(lib.pbdx_debug_tet_impulses(self._h, C.byref(last), C.byref(total)), "tet_impulses")
+        return last.value, total.value
 
     def plan_info(self):
         """The colour-fused tile schedule planned for the current constraint schedule."""
@@ -739,6 +745,7 @@ class Solver:
     OPT_PERSISTENT_TIMEOUT_MS = 13
     OPT_PERSISTENT_WGS_PER_CU = 14
     OPT_TET_CONTACTS_SERIAL = 15
+    OPT_TET_FORCE_IMPULSES = 16
     OPT_USE_GRAPH = 1
     OPT_BLOCK_SIZE = 2
     OPT_XCD_REMAP = 3

@@ -1048,6 +1048,7 @@ struct pbdx_solver
 	TetWork tet_work = {};
 	void *tet_work_alloc[18] = {};
 	pbdx_collision_range *d_ranges = nullptr;     // device copy of `ranges` (read by the tet-contact velocity chains)
+	int tet_force_impulses = 0;          // PBDX_OPT_TET_FORCE_IMPULSES
 	uint32_t tet_impulses_last = 0; uint64_t tet_impulses_total = 0;     // contacts with a non-zero velocity impulse: last detection / since the colliders were set
 	int tet_serial = 0;                            // PBDX_OPT_TET_CONTACTS_SERIAL
 	uint32_t tet_grown = 0;                        // times the detection's scratch was enlarged
@@ -1873,7 +1874,7 @@ int alloc_tet_work_impl(pbdx_solver *s, uint64_t nodes, uint32_t contacts)
 	HIPCHECK(hipMalloc(&s->tet_work_alloc[16], (size_t)std::max(1u, s->n)));
 	HIPCHECK(hipMemset(s->tet_work_alloc[16], 0, (size_t)std::max(1u, s->n)));
 	w.imp_mark = (uint8_t *)s->tet_work_alloc[16];
-	w.force_impulses = getenv("PBDX_TET_FORCE_IMPULSES") != nullptr && atoi(getenv("PBDX_TET_FORCE_IMPULSES")) != 0;
+	w.force_impulses = s->tet_force_impulses;
 	return PBDX_OK;
 }
 
@@ -2538,6 +2539,8 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 		s->persist_wgs_per_cu = (uint32_t)value; replan = true; break;
 	case PBDX_OPT_TET_CONTACTS_SERIAL:
 		s->tet_serial = value ? 1 : 0; break;
+	case PBDX_OPT_TET_FORCE_IMPULSES:
+		s->tet_force_impulses = value ? 1 : 0; s->tet_work.force_impulses = s->tet_force_impulses; break;
 	case PBDX_OPT_PERSISTENT_TIMEOUT_MS:
 		if (value < 1 || value > 10000) { set_error("persistent timeout must be 1 .. 10000 ms"); return PBDX_ERR_INVALID; }
 		s->persist_timeout_ms = (uint32_t)value; break;

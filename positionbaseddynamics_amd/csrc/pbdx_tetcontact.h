@@ -95,7 +95,7 @@ PBDX_HD void tet_contact_velocity_info(V3 v0, const V3 v[4], V3 bary, V3 normal,
 // velocitySolve_ParticleTetContactConstraint for frictionCoeff == 0 (:1296-1324): true if the contact carries a non-zero impulse pv
 // (then v0 += w0 pv if the particle is dynamic, v_k += (-w_k bary_k) pv for the dynamic tet vertices, k-th barycentric weight
 // bary0, bary[0], bary[1], bary[2])
-// (force: developer aid PBDX_TET_FORCE_IMPULSES -- the test of the application path: contacts with pMax > 0 are treated as the ones with pMax < 0
+// (force: developer aid PBDX_OPT_TET_FORCE_IMPULSES -- the test of the application path: contacts with pMax > 0 are treated as the ones with pMax < 0
 // are, because real scenes almost never produce a negative pMax; the arithmetic of the branch itself is pinned by the known-answer test)
 PBDX_HD bool tet_contact_velocity_impulse(const TetContact &c, float w0, V3 &pv, bool force = false)
 {

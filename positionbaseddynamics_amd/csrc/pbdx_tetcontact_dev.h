@@ -65,7 +65,7 @@ struct TetWork                    // device scratch of the detection; *_cap are 
 	uint32_t *counters;           // kTcWords
 	uint32_t *imp_list;           // the contacts that carry a velocity impulse (pMax < 0), in list order (max_contacts entries)
 	uint8_t *imp_mark;            // per particle: 1 while it takes part in such a contact as a dynamic particle (all zero between steps)
-	int force_impulses;           // developer aid (PBDX_TET_FORCE_IMPULSES): see tet_contact_velocity_impulse
+	int force_impulses;           // developer aid (PBDX_OPT_TET_FORCE_IMPULSES): see tet_contact_velocity_impulse
 };
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)

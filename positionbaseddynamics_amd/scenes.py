@@ -5,6 +5,8 @@ A scene is a list of operations (the reference's own builder calls, Demos/ClothD
 Demos/BarDemo/main.cpp:116-166, with their arguments), so that the same list can drive this package's
 SimulationModel mirror (`build_model`) and -- in the tests and in bench.py's cpu_baseline leg -- the reference
 itself.  All scenes are deterministic (no RNG except the seeded irregular meshes)."""
+import os
+
 import numpy as np
 
 GRAVITY = (0.0, -9.81, 0.0)
@@ -117,11 +119,9 @@ def delaunay_solid_spec(n_points=400, seed=5, solid_method=2):
 
 
 def config5_like_spec(n_points=220):
-    """BASELINE configs[4] (data/scenes/ArmadilloCollisionScene.json) in the form this container can pin:
-    three irregular tet solids (FEM tets, method 2, Poisson 0.2) stacked above a static floor.  The armadillo
-    surface / its Discregrid SDF (tet-tet contacts) are not in the tree, so the solids only collide with the
-    floor; they are submitted as ONE tet model with three components (a second tet collision object would make
-    the reference traverse tet-tet pairs, which need that SDF)."""
+    """A small stand-in for BASELINE configs[4] with floor contacts only: three irregular tet solids (FEM tets, method 2, Poisson 0.2) stacked above
+    a static floor, submitted as ONE tet model with three components (so that no tet-tet pairs exist).  The scene file's own shape -- three
+    armadillo_4k tet models, floor contacts AND contacts between the solids -- is `armadillo_collision_scene` below."""
     from scipy.spatial import Delaunay
     all_pts, all_tets = [], []
     offset = 0
@@ -135,6 +135,82 @@ def config5_like_spec(n_points=220):
         all_tets.append(tets[vol > 2e-4].astype(np.uint32) + np.uint32(offset))
         offset += n_points
     return [("tetmesh", np.concatenate(all_pts), np.concatenate(all_tets)), ("solid", 0, 2, 1.0, 0.2, 1.0, False, False)]
+
+
+# ---- BASELINE configs[4]: data/scenes/ArmadilloCollisionScene.json in the shape that can be pinned -----------------------------------------
+ARMADILLO_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "armadillo_collision_scene.npz")
+
+
+def armadillo_collision_scene():
+    """(ops, fixture).  The scene file's three armadillo_4k tet models (1180 vertices, 3717 tets each; scale 2; translations (0,10,0), (0,4,0),
+    (0,18,0); rotations 1.57 about y, 0.1 and 0.5 about z) as the reference's own TetGenLoader + SceneLoaderDemo placement produce them, FEM tets
+    (tetModelSimulationMethod 2, stiffness 1, Poisson ratio 0.2), above the static floor box (100 x 1 x 100, restitution 0.6, friction 0):
+    maxIterations 1, maxIterationsV 5, time step 0.01, contact tolerance 0, contact stiffness 100; subSteps 5 in the file, 8 in BASELINE.json.
+    Two forced deviations: the solids carry an analytic box (3 x 4 x 2.6) in their rest frame instead of the cubic SDF of armadillo.obj (Discregrid
+    and that surface mesh are not in the reference tree), and their friction coefficient is 0 instead of 0.3 (the reference's friction impulse between
+    deformables reads a multiplier nothing has written).  The fixture (tests/golden/make_golden.py armadillo) holds the placed meshes, the
+    bounding-sphere hierarchies the reference built, the collision objects as the reference stores them, and the reference's results."""
+    g = np.load(ARMADILLO_FIXTURE)
+    ops = []
+    for q in range(3):
+        _, _, offset, nv, nt, _ = (int(v) for v in g["c%d_meta" % q])
+        ops.append(("tetmesh", g["x0"][offset:offset + nv], g["c%d_tets" % q].reshape(-1, 4)))
+    method, k, nu, kv = g["solid"]
+    for q in range(3):
+        ops.append(("solid", q, int(method), float(k), float(nu), float(kv), False, False))
+    return ops, g
+
+
+class FixtureTetColliders:
+    """pbdx_tet_collider records from a fixture's arrays (keys c<q>_meta / _params / _tets / _initial_x / _initial_R / _<hierarchy>_{lst,nodes,hulls});
+    keeps the arrays alive."""
+
+    def __init__(self, g, n):
+        import ctypes as C
+        from . import _ffi
+        self.keep = []
+        self.n = n
+        self.arr = (_ffi.TetCollider * n)()
+        self.tolerance = float(g["tolerance"])
+        for q in range(n):
+            shape, invert, offset, nv, nt, body = (int(v) for v in g["c%d_meta" % q])
+            c = self.arr[q]
+            c.shape, c.invert = shape, invert
+            for k in range(4):
+                c.params[k] = g["c%d_params" % q][k]
+            c.first_particle, c.num_vertices, c.num_tets = offset, nv, nt
+            tets = np.ascontiguousarray(g["c%d_tets" % q], dtype=np.uint32)
+            self.keep.append(tets)
+            c.tets = tets.ctypes.data_as(C.POINTER(C.c_uint32))
+            for k in range(3):
+                c.initial_x[k] = g["c%d_initial_x" % q][k]
+            for k in range(9):
+                c.initial_R[k] = g["c%d_initial_R" % q].reshape(-1)[k]
+            c.restitution = float(g["c%d_restitution" % q]) if ("c%d_restitution" % q) in g else 0.6
+            c.friction, c.test_mesh, c.body_index = 0.0, 1, body
+            for name, field in (("points", "points"), ("tets", "tets_bvh"), ("rest", "tets_rest")):
+                lst = np.ascontiguousarray(g["c%d_%s_lst" % (q, name)], dtype=np.uint32)
+                nodes = np.ascontiguousarray(g["c%d_%s_nodes" % (q, name)], dtype=np.int32)
+                hulls = np.ascontiguousarray(g["c%d_%s_hulls" % (q, name)], dtype=np.float32)
+                self.keep += [lst, nodes, hulls]
+                f = getattr(c, field)
+                f.num_nodes, f.num_entities = len(nodes), len(lst)
+                f.entities = lst.ctypes.data_as(C.POINTER(C.c_uint32))
+                f.nodes = nodes.ctypes.data_as(C.POINTER(C.c_int32))
+                f.hulls = hulls.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def install_armadillo_colliders(sol, g):
+    """floor (static rigid body with an analytic box), the three solids' collision ranges, contact parameters, rest positions and the deformable
+    colliders of the armadillo scene on a Solver whose particles are uploaded.  Returns the collider records (keep them alive while they are in use)."""
+    sol.set_colliders([dict(shape=int(g["rb_shape"]), invert=bool(g["rb_invert"]), params=list(g["rb_params"]), com=g["rb_com"], R=g["rb_R"], v1=g["rb_v1"], v2=g["rb_v2"],
+                            restitution=float(g["rb_restitution"]), friction=float(g["rb_friction"]), body_index=int(g["rb_body_index"]))])
+    sol.set_collision_ranges([(int(r[0]), int(r[1]), float(r[2]), float(r[3])) for r in g["ranges"]])
+    sol.set_contact_params(float(g["tolerance"]), float(g["contact_stiffness"]), int(g["max_iterations_v"]))
+    sol.set_rest_positions(g["x0"])
+    cols = FixtureTetColliders(g, 3)
+    sol.set_tet_colliders(cols.arr, cols.n, cols.tolerance)
+    return cols
 
 
 def kitchen_sink_spec():

@@ -596,3 +596,131 @@ def test_plugin_refuses_friction_between_deformables():
     assert lib.pbdx_timestep_hip_failed_steps(ts) == 2 and lib.pbdx_timestep_hip_gpu_steps(ts) == 0
     assert np.array_equal(ref.positions(), x0)
     ref.reset_all()
+
+
+@pytest.mark.gpu
+def test_velocity_impulses_of_tet_contacts_are_applied_in_list_order_five_times():
+    """The APPLICATION path of the particle-tet velocity impulses on the device (compaction of the contacts that carry one, marks, one lane per
+    particle's first appearance, maxIterationsV repetitions).  Real scenes hardly ever produce pMax < 0 (the arithmetic of that branch is pinned by
+    the known-answer test), so the developer option PBDX_OPT_TET_FORCE_IMPULSES makes the contacts with pMax > 0 carry the impulse instead: two
+    engines run the two-bar scene identically for 75 steps, then one step plain / forced.  Positions and contact lists must stay identical, and the
+    forced velocities must equal the plain ones plus the sequential re-enactment of the reference's loop (TimeStepController.cpp:342-355) in numpy."""
+    import positionbaseddynamics_amd as pbd
+    g = np.load(GOLDEN)
+    f = np.float32
+
+    def engine():
+        cols = tcu.GoldenTetColliders(g)
+        model = util.build_mine(_two_bar_ops())
+        ts = pbd.TimeStepController()
+        ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+        ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 5)
+        pbd.TimeManager.getCurrent().setTimeStepSize(0.005)
+        ts.syncFromHost(model)
+        sol = ts.solver()
+        sol.set_rest_positions(g["x0"])
+        sol.set_tet_colliders(cols.arr, cols.n, float(g["tolerance"]))
+        ts.stepResident(model, 75)
+        return model, ts, sol, cols
+
+    ma, tsa, sa, ka = engine()
+    mb, tsb, sb, kb = engine()
+    sb.set_option(pbd.Solver.OPT_TET_FORCE_IMPULSES, 1)
+    for ts, m in ((tsa, ma), (tsb, mb)):
+        ts.stepResident(m, 1)
+        ts.syncToHost(m)
+    ca, cb = sa.tet_contacts(), sb.tet_contacts()
+    assert len(ca) > 5 and util.bitwise_equal(ca, cb)
+    assert util.bitwise_equal(ma.getParticles().positions(), mb.getParticles().positions())
+    assert sa.tet_impulses()[0] == 0 and sb.tet_impulses()[0] == int((cb[:, 33] > 0).sum()) > 3
+    v = ma.getParticles().velocities().astype(np.float32).copy()
+    w = g["w"].astype(np.float32)
+    for it in range(5):
+        for c in cb:
+            p, verts = int(c[0]), [int(q) for q in c[26:30]]
+            bary = c[3:6].astype(np.float32)
+            wk = c[22:26].astype(np.float32)
+            if w[p] == 0 and wk[0] == 0 and wk[1] == 0 and wk[2] == 0:
+                continue
+            if not (c[33] > 0):
+                continue
+            pv = (-f(c[33])) * c[30:33].astype(np.float32)
+            if w[p] != 0:
+                v[p] = v[p] + w[p] * pv
+            b = [f(f(f(f(1.0) - bary[0]) - bary[1]) - bary[2]), bary[0], bary[1], bary[2]]
+            for k in range(4):
+                if wk[k] != 0:
+                    v[verts[k]] = v[verts[k]] + f(-wk[k] * b[k]) * pv
+    vb = mb.getParticles().velocities()
+    assert not util.bitwise_equal(vb, ma.getParticles().velocities()), "the forced impulses changed nothing: the test proves nothing"
+    assert util.bitwise_equal(vb, v), "max err %.3e" % util.max_err(vb, v)
+
+
+# ---- BASELINE configs[4] in the shape that can be pinned: three armadillo_4k tet models + floor (positionbaseddynamics_amd/scenes.py) ------------
+def _armadillo_models(g):
+    out = []
+    for q in range(3):
+        _, _, offset, nv, nt, _ = (int(v) for v in g["c%d_meta" % q])
+        out.append((g["x0"][offset:offset + nv].astype(np.float64), g["c%d_tets" % q].reshape(-1, 4), g["c%d_initial_x" % q].astype(np.float64),
+                    g["c%d_initial_R" % q].astype(np.float64).reshape(3, 3)))
+    return out
+
+
+def test_armadillo_fixture_is_what_the_reference_produces():
+    """The package's armadillo scene fixture against the live reference: (a) where the reference tree is present, its own TetGenLoader + placement
+    give the fixture's rest positions bit for bit; (b) the reference fed with the fixture's meshes (what a box without /root/reference does) builds
+    the fixture's bounding-sphere hierarchies and reproduces the fixture's state after 120 steps at 8 substeps."""
+    from positionbaseddynamics_amd import scenes
+    ops, g = scenes.armadillo_collision_scene()
+    ref = _ref()
+    if os.path.exists("/root/reference/data/models/armadillo_4k.node"):
+        tcu.armadillo_scene(ref, 8)
+        assert util.bitwise_equal(ref.get_array(1), g["x0"])
+    objs = tcu.armadillo_scene(ref, 8, models=_armadillo_models(g))
+    assert util.bitwise_equal(ref.get_array(1), g["x0"]) and ref.num_constraints() == 11151
+    for q, co in enumerate(objs):
+        for which, name in ((0, "points"), (1, "tets"), (2, "rest")):
+            b = ref.bvh(co, which)
+            assert np.array_equal(np.asarray(b["lst"], dtype=np.uint32), g["c%d_%s_lst" % (q, name)])
+            assert np.array_equal(np.asarray(b["nodes"], dtype=np.int32), g["c%d_%s_nodes" % (q, name)])
+    ref.step(120)
+    assert util.bitwise_equal(ref.positions(), g["x_sub8_120"]) and util.bitwise_equal(ref.get_array(2), g["v_sub8_120"])
+    want = g["contacts_sub8_120"]
+    got = tcu.oracle_contacts_as_engine_records(ref)
+    assert len(got) == len(want) and (not len(want) or util.bitwise_equal(got, want))
+    ref.reset_all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sub_steps", [8, 5])
+def test_armadillo_collision_scene_bit_exact(sub_steps):
+    """configs[4]'s shape on the GPU through the raw solver calls: three armadillo_4k FEM solids falling onto the static floor and onto each other --
+    floor contacts AND deformable-deformable contacts in the same steps, 8 substeps (BASELINE.json) and 5 (the scene file), maxIterations 1,
+    maxIterationsV 5 -- against the reference's committed results after 120 and 260 steps (positions, velocities, contact lists; 585 / 346
+    deformable and 5 756 / 6 484 floor contacts on the way)."""
+    import positionbaseddynamics_amd as pbd
+    from positionbaseddynamics_amd import scenes
+    ops, g = scenes.armadillo_collision_scene()
+    model = scenes.build_model(ops)
+    ts = pbd.TimeStepController()
+    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, sub_steps)
+    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, int(g["iterations"]))
+    pbd.TimeManager.getCurrent().setTimeStepSize(float(g["time_step"]))
+    ts.syncFromHost(model)
+    sol = ts.solver()
+    cols = scenes.install_armadillo_colliders(sol, g)
+    done, floor_contacts = 0, 0
+    for steps in g["steps"]:
+        for _ in range(int(steps) - done):
+            ts.stepResident(model, 1)
+            floor_contacts += sol.num_contacts()
+        done = int(steps)
+        ts.syncToHost(model)
+        got, want = sol.tet_contacts(), g["contacts_sub%d_%d" % (sub_steps, steps)]
+        assert len(got) == len(want) and (not len(want) or util.bitwise_equal(got[:, :26], want)), "step %d: contact list" % steps
+        x, v = model.getParticles().positions(), model.getParticles().velocities()
+        assert util.bitwise_equal(x, g["x_sub%d_%d" % (sub_steps, steps)]), "step %d: max err %.3e" % (steps, util.max_err(x, g["x_sub%d_%d" % (sub_steps, steps)]))
+        assert util.bitwise_equal(v, g["v_sub%d_%d" % (sub_steps, steps)]), "step %d" % steps
+    assert floor_contacts == int(g["contact_totals_sub%d" % sub_steps][1])
+    print("armadillo scene, %d substeps: 260 steps bit-identical; %d floor contacts; schedule %s" % (sub_steps, floor_contacts, sol.describe()))
+    del cols

@@ -258,3 +258,37 @@ def velocity_kat_equal(got, want):
     branch is (-0 * garbage) * tangent, a zero whose sign belongs to the garbage)"""
     z = lambda a: np.where(a == 0, np.float32(0), a).view(np.uint32)
     return bool(np.array_equal(got[:, :4].view(np.uint32), want[:, :4].view(np.uint32)) and np.array_equal(z(got[:, 5:]), z(want[:, 5:])))
+
+
+# ---- BASELINE configs[4] in the shape that can be pinned (data/scenes/ArmadilloCollisionScene.json) ---------------------------------------
+ARMADILLO_PLACEMENT = [((0, 10, 0), (0, 1, 0), 1.57, 0.1), ((0, 4, 0), (0, 0, 1), 0.1, 0.0), ((0, 18, 0), (0, 0, 1), 0.5, 0.0)]   # translation, axis, angle, restitution
+ARMADILLO_BOX = (3.0, 4.0, 2.6)      # analytic stand-in (full side lengths, rest frame) for the scene's Discregrid SDF of armadillo.obj (neither is in the tree)
+
+
+def armadillo_scene(ref, sub_steps, models=None):
+    """The scene file's three armadillo_4k tet models (scale 2, its translations / rotations, FEM tets with stiffness 1 and Poisson ratio 0.2,
+    maxIterations 1, maxIterationsV 5, time step 0.01, contact tolerance 0, contact stiffness 100) above its static floor box (100 x 1 x 100,
+    restitution 0.6, friction 0), on the reference.  Deviations, all forced: the tet models carry an analytic box in their rest frame instead of
+    the cubic SDF of armadillo.obj (Discregrid and the surface mesh are not in the tree), their friction coefficient is 0 instead of 0.3 (the
+    reference's friction impulse between deformables reads an unset multiplier).  models: (vertices, tets) per model to feed addTetModel with
+    (a box without /root/reference: the fixture holds what the reference's own TetGenLoader + placement produced); None: load the files."""
+    ref.reset_all()
+    ref.set_num_threads(1)
+    ref.set_time_step_size(0.01)
+    ref.set_gravity((0, -9.81, 0))
+    base = "/root/reference/data/models/armadillo_4k"
+    for q, (x, axis, angle, _) in enumerate(ARMADILLO_PLACEMENT):
+        if models is None:
+            ref.add_tetgen_model(base + ".node", base + ".ele", x, axis, angle, (2, 2, 2))
+        else:
+            ref.add_tet_model(models[q][0], models[q][1])
+            ref.set_tet_model_initial_transform(q, models[q][2], models[q][3])
+    for tm in range(3):
+        ref.add_solid_constraints(tm, 2, 1.0, 0.2, 1.0, False, False)
+    ref.set_collision_tolerance(0.0)
+    ref.add_static_collider("box", (0, 0, 0), (1, 0, 0, 0), (100, 1, 100), (100, 1, 100), 0.6, 0.0)
+    objs = [ref.add_tet_collision_shape(tm, 0, ARMADILLO_BOX, True, False, ARMADILLO_PLACEMENT[tm][3], 0.0) for tm in range(3)]
+    ref.attach_collision_detection()
+    ref.set_params(sub_steps, 1, 0)
+    ref.set_max_iterations_v(5)
+    return objs
