@@ -1337,6 +1337,10 @@ int ensure_plan(pbdx_solver *s)
 			uint32_t widest = 0;
 			for (const FusedStep &st : seg.steps) widest = std::max(widest, st.count);
 			block = widest > 512 ? 1024 : widest > 256 ? 512 : 256;
+			// small scenes (fewer than 512 particles per CU: every colour step is latency-bound, pbdx_plan.cpp): 8 wavefronts meet at the colour
+			// barriers sooner than 16 and a step wider than 512 slots simply takes a second chunk -- measured 3 - 14 % faster than 1 024 threads
+			// (profiles/r03b_c3_tile_sweep.log, r03c_small_scene_tile_sweep.log: bar XPBD distance + volume 0.84 -> 0.74 ms, 100x100 / 200x200 cloth -5 %)
+			if (block > 512 && (uint64_t)s->n <= (uint64_t)std::max(1, s->prop.multiProcessorCount) * 512u) block = 512;
 		}
 		if ((seg.type_mask & ~kMaskLight) && block > 512) block = 512;   // heavy types need > 128 VGPRs
 		if (block == 768) block = 512;
