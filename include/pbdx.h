@@ -28,6 +28,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -135,7 +136,7 @@ int pbdx_solver_get_particles(pbdx_solver *s, uint32_t n,
 /* ---- Dirty tracking of a host mirror ------------------------------------------------------------
  * A host application that cannot be instrumented (the reference's ParticleData hands out plain references) is tracked by
  * FULL-COVERAGE block hashes of its arrays: one 64-bit hash per PBDX_HASH_BLOCK consecutive elements, the XOR over the
- * block's 32-bit words of pbdx_hash_word(word, index of the word in the array) -- order-free, so the host evaluates it with
+ * block's 64-bit words of pbdx_hash_word(word, index of the word in the array) -- order-free, so the host evaluates it with
  * as many threads as it likes and the device with one workgroup per block.  A single changed word always changes its
  * block's hash.  pbdx_solver_get_particles_hashed downloads like pbdx_solver_get_particles and ALSO returns the block hashes
  * of exactly the bytes it delivered (computed on the device's staging copy: the host does not read 48 MB again to know what
@@ -146,22 +147,48 @@ int pbdx_solver_get_particles(pbdx_solver *s, uint32_t n,
 #else
 #define PBDX_HOST_DEVICE
 #endif
-PBDX_HOST_DEVICE static inline uint64_t pbdx_hash_word(uint32_t word, uint32_t index)
+PBDX_HOST_DEVICE static inline uint64_t pbdx_hash_word(uint64_t word, uint32_t index)
 {
-	uint64_t m = (uint64_t)(word ^ (index * 0x9E3779B9u)) * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
-	return m ^ (m >> 31);
+	uint64_t m = (word ^ ((uint64_t)index * 0x9E3779B97F4A7C15ull)) * 0xD1B54A32D192ED03ull;
+	return m ^ (m >> 29);
 }
 static inline uint32_t pbdx_hash_num_blocks(uint32_t n) { return (n + PBDX_HASH_BLOCK - 1u) / PBDX_HASH_BLOCK; }
-/* hash of block `block` of an array of n elements of elem_words 32-bit words each (host side) */
-static inline uint64_t pbdx_hash_block(const void *base, uint32_t n, uint32_t elem_words, uint32_t block)
+/* hash of block `block` of an array of n elements of elem_bytes bytes each (a multiple of 4; host side).  The array is read as 64-bit words
+ * (a block of 1024 elements is a whole number of them); an odd 32-bit word at the very end of the array counts as a 64-bit word with a zero
+ * upper half. */
+static inline uint64_t pbdx_hash_block(const void *base, uint32_t n, uint32_t elem_bytes, uint32_t block)
 {
-	const uint32_t *w = (const uint32_t *)base;
-	const uint64_t first = (uint64_t)block * PBDX_HASH_BLOCK * elem_words;
-	uint64_t last = first + (uint64_t)PBDX_HASH_BLOCK * elem_words;
-	const uint64_t total = (uint64_t)n * elem_words;
-	uint64_t h = 0, i;
+	const unsigned char *b = (const unsigned char *)base;
+	const uint64_t total = (uint64_t)n * elem_bytes;
+	const uint64_t first = (uint64_t)block * PBDX_HASH_BLOCK * elem_bytes;
+	uint64_t last = first + (uint64_t)PBDX_HASH_BLOCK * elem_bytes, h = 0, o;
 	if (last > total) last = total;
-	for (i = first; i < last; i++) h ^= pbdx_hash_word(w[i], (uint32_t)i);
+	/* (index * constant advances by the constant from word to word: one multiplication per word is left; four independent accumulators) */
+	{
+		const uint64_t K = 0x9E3779B97F4A7C15ull, M = 0xD1B54A32D192ED03ull;
+		uint64_t k = (uint64_t)(uint32_t)(first >> 3) * K, h1 = 0, h2 = 0, h3 = 0;
+		for (o = first; o + 32 <= last; o += 32)
+		{
+			uint64_t w[4], m0, m1, m2, m3;
+			memcpy(w, b + o, 32);
+			m0 = (w[0] ^ k) * M; m1 = (w[1] ^ (k + K)) * M; m2 = (w[2] ^ (k + 2 * K)) * M; m3 = (w[3] ^ (k + 3 * K)) * M;
+			h ^= m0 ^ (m0 >> 29); h1 ^= m1 ^ (m1 >> 29); h2 ^= m2 ^ (m2 >> 29); h3 ^= m3 ^ (m3 >> 29);
+			k += 4 * K;
+		}
+		h ^= h1 ^ h2 ^ h3;
+	}
+	for (; o + 8 <= last; o += 8)
+	{
+		uint64_t w;
+		memcpy(&w, b + o, 8);
+		h ^= pbdx_hash_word(w, (uint32_t)(o >> 3));
+	}
+	if (o < last)
+	{
+		uint32_t t;
+		memcpy(&t, b + o, 4);
+		h ^= pbdx_hash_word((uint64_t)t, (uint32_t)(o >> 3));
+	}
 	return h;
 }
 int pbdx_solver_get_particles_hashed(pbdx_solver *s, uint32_t n, float *x, float *v, float *old_x, float *last_x,

@@ -770,14 +770,19 @@ __global__ __launch_bounds__(256) void update_w_kernel(const T *__restrict__ w, 
 }
 // block hashes of a staged host array (include/pbdx.h: pbdx_hash_word / pbdx_hash_block): one workgroup per block of
 // PBDX_HASH_BLOCK elements, XOR over the block's 32-bit words
-__global__ __launch_bounds__(256) void hash_blocks_kernel(const uint32_t *__restrict__ words, uint64_t total_words, uint32_t words_per_block, uint64_t *__restrict__ out)
+__global__ __launch_bounds__(256) void hash_blocks_kernel(const uint32_t *__restrict__ words32, uint64_t total_bytes, uint32_t bytes_per_block, uint64_t *__restrict__ out)
 {
 	__shared__ uint64_t part[4];
-	const uint64_t first = (uint64_t)blockIdx.x * words_per_block;
-	uint64_t last = first + words_per_block;
-	if (last > total_words) last = total_words;
+	const uint64_t first = (uint64_t)blockIdx.x * bytes_per_block;
+	uint64_t last = first + bytes_per_block;
+	if (last > total_bytes) last = total_bytes;
+	const uint64_t *words = reinterpret_cast<const uint64_t *>(words32);
 	uint64_t h = 0;
-	for (uint64_t i = first + threadIdx.x; i < last; i += 256) h ^= pbdx_hash_word(words[i], (uint32_t)i);
+	for (uint64_t o = first + 8ull * threadIdx.x; o < last; o += 8ull * 256)
+	{
+		const uint64_t w = o + 8 <= last ? words[o >> 3] : (uint64_t)words32[o >> 2];      // an odd 32-bit word at the very end of the array
+		h ^= pbdx_hash_word(w, (uint32_t)(o >> 3));
+	}
 	for (int o = 32; o > 0; o >>= 1) h ^= __shfl_xor(h, o, 64);
 	if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = h;
 	__syncthreads();
@@ -2181,8 +2186,8 @@ int get_particles_hashed_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, 
 		if (j.dst) s->pin(j.dst, b3);
 		hipLaunchKernelGGL(unpack_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s->stream, j.src, st, n);
 		if (j.h)
-			hipLaunchKernelGGL(hash_blocks_kernel, dim3(nb), dim3(256), 0, s->stream, reinterpret_cast<const uint32_t *>(st), (uint64_t)n * elem_words,
-				PBDX_HASH_BLOCK * elem_words, s->d_hash + (size_t)q * nb);
+			hipLaunchKernelGGL(hash_blocks_kernel, dim3(nb), dim3(256), 0, s->stream, reinterpret_cast<const uint32_t *>(st), (uint64_t)n * elem_words * 4u,
+				PBDX_HASH_BLOCK * elem_words * 4u, s->d_hash + (size_t)q * nb);
 		HIPCHECK(hipGetLastError());
 		if (j.dst) HIPCHECK(hipMemcpyAsync(j.dst, st, b3, hipMemcpyDeviceToHost, s->stream));
 		if (j.h) HIPCHECK(hipMemcpyAsync(j.h, s->d_hash + (size_t)q * nb, (size_t)nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));

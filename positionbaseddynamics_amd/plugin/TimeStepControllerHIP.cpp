@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <omp.h>
+#include <chrono>
 
 using namespace PBD;
 
@@ -83,16 +84,33 @@ namespace
 	}
 	// full-coverage block hashes of a packed host array (include/pbdx.h: pbdx_hash_block): every word of the array is hashed,
 	// PBDX_HASH_BLOCK elements per 64-bit hash.  The pass is bandwidth-bound (one read of the array) and runs on a handful of
-	// threads when the array is large -- the host application is an OpenMP program anyway (TimeStepController.cpp:270-286);
+	// threads when the arrays are large -- the host application is an OpenMP program anyway (TimeStepController.cpp:270-286);
 	// the thread count is stated explicitly because hosts commonly run the solver loops with omp_set_num_threads(1).
-	void hashBlocks(const void *base, uint32_t n, uint32_t elemWords, std::vector<uint64_t> &out)
+	struct HashJob { const void *base; uint32_t n, elemBytes; std::vector<uint64_t> *out; };
+	void hashBlocks(HashJob *jobs, int numJobs)
 	{
-		const int nb = (int)pbdx_hash_num_blocks(n);
-		out.resize((size_t)nb);
-		int threads = (size_t)n * elemWords * 4 >= ((size_t)1 << 20) ? omp_get_num_procs() : 1;
-		if (threads > 16) threads = 16;
+		size_t bytes = 0;
+		int total = 0;
+		int first[8];
+		for (int j = 0; j < numJobs; j++)
+		{
+			first[j] = total;
+			const int nb = (int)pbdx_hash_num_blocks(jobs[j].n);
+			jobs[j].out->resize((size_t)nb);
+			total += nb;
+			bytes += (size_t)jobs[j].n * jobs[j].elemBytes;
+		}
+		first[numJobs] = total;
+		int threads = bytes >= ((size_t)1 << 20) ? omp_get_num_procs() : 1;
+		if (threads > 32) threads = 32;
+		// ONE parallel region over the blocks of all arrays
 		#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
-		for (int b = 0; b < nb; b++) out[(size_t)b] = pbdx_hash_block(base, n, elemWords, (uint32_t)b);
+		for (int q = 0; q < total; q++)
+		{
+			int j = 0;
+			while (q >= first[j + 1]) j++;
+			(*jobs[j].out)[(size_t)(q - first[j])] = pbdx_hash_block(jobs[j].base, jobs[j].n, jobs[j].elemBytes, (uint32_t)(q - first[j]));
+		}
 	}
 	// element ranges (first, count pairs; adjacent blocks merged) covered by the blocks whose hash differs
 	void changedRanges(const std::vector<uint64_t> &was, const std::vector<uint64_t> &now, uint32_t n, std::vector<uint32_t> &ranges)
@@ -111,7 +129,8 @@ namespace
 		// many scattered edits: one range over everything costs less than hundreds of small copies
 		if (ranges.size() > 2 * 256) { ranges.clear(); ranges.push_back(0); ranges.push_back(n); }
 	}
-	const uint32_t kVecWords = 3 * (uint32_t)(sizeof(Real) / 4), kScalarWords = (uint32_t)(sizeof(Real) / 4);
+	inline double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+	struct Lap { double *acc, t0; Lap(double *a) : acc(a), t0(nowMs()) {} ~Lap() { *acc += nowMs() - t0; } };
 	static_assert(sizeof(Vector3r) == 3 * sizeof(Real), "ParticleData's std::vector<Vector3r> must be a packed Real[3] array (Common/Common.h:31, Eigen::DontAlign)");
 }
 
@@ -123,6 +142,7 @@ TimeStepControllerHIP::TimeStepControllerHIP(int device) :
 {
 	m_accelGravity[0] = m_accelGravity[1] = m_accelGravity[2] = 0;
 	m_fullParameterScan = false; m_partialUploads = 0;
+	for (int k = 0; k < 6; k++) m_ms[k] = 0.0;
 	if (pbdx_solver_create(&m_solver, device) != PBDX_OK)
 	{
 		LOG_ERR << "TimeStepControllerHIP: " << pbdx_last_error() << " -- every step() will fail (no CPU path)";
@@ -523,11 +543,10 @@ void TimeStepControllerHIP::hashHostState(SimulationModel &model, std::vector<ui
 	ParticleData &pd = model.getParticles();
 	const uint32_t n = pd.size();
 	if (!n) { for (int k = 0; k < 5; k++) out[k].clear(); return; }
-	hashBlocks(&pd.getPosition(0)[0], n, kVecWords, out[0]);
-	hashBlocks(&pd.getVelocity(0)[0], n, kVecWords, out[1]);
-	hashBlocks(&pd.getOldPosition(0)[0], n, kVecWords, out[2]);
-	hashBlocks(&pd.getLastPosition(0)[0], n, kVecWords, out[3]);
-	hashBlocks(&pd.getMass(0), n, kScalarWords, out[4]);
+	HashJob jobs[5] = { { &pd.getPosition(0)[0], n, (uint32_t)sizeof(Vector3r), &out[0] }, { &pd.getVelocity(0)[0], n, (uint32_t)sizeof(Vector3r), &out[1] },
+		{ &pd.getOldPosition(0)[0], n, (uint32_t)sizeof(Vector3r), &out[2] }, { &pd.getLastPosition(0)[0], n, (uint32_t)sizeof(Vector3r), &out[3] },
+		{ &pd.getMass(0), n, (uint32_t)sizeof(Real), &out[4] } };
+	hashBlocks(jobs, 5);
 }
 
 // hash over the constraints' parameter records (what pushParams would hand to the engine): a strided sample of ~4096 records by
@@ -609,7 +628,7 @@ bool TimeStepControllerHIP::prepare(SimulationModel &model, bool forceUpload)
 	if (!upload)
 	{
 		std::vector<uint64_t> now[5];
-		hashHostState(model, now);
+		{ Lap lap(&m_ms[0]); hashHostState(model, now); }
 		if (!m_deviceAhead)
 		{
 			if (!uploadChanges(model, now)) return false;
@@ -635,16 +654,19 @@ bool TimeStepControllerHIP::prepare(SimulationModel &model, bool forceUpload)
 			}
 		}
 	}
-	if (upload && !uploadParticles(model)) return false;
+	if (upload) { Lap lap(&m_ms[1]); if (!uploadParticles(model)) return false; }
 	// topology change: groups re-initialised (every add* clears m_groupsInitialized), counts changed
 	if (!m_scheduleValid || !model.m_groupsInitialized || m_numConstraints != model.getConstraints().size())
 	{
 		if (!buildSchedule(model, false)) return false;
 	}
-	else if (m_paramsDirty || hashParameters(model) != m_paramHash)
+	else
 	{
-		if (!buildSchedule(model, true)) return false;      // parameter streams only: no replanning, no re-measurement
+		bool changed;
+		{ Lap lap(&m_ms[2]); changed = m_paramsDirty || hashParameters(model) != m_paramHash; }
+		if (changed && !buildSchedule(model, true)) return false;      // parameter streams only: no replanning, no re-measurement
 	}
+	Lap lap(&m_ms[3]);
 	return uploadColliders(model);                          // cheap; poses / coefficients are host-mutable between steps
 }
 
@@ -695,6 +717,7 @@ void TimeStepControllerHIP::step(SimulationModel &model)
 	if (ok)
 	{
 		refreshAccelerations(model);                        // host-visible side effect of TimeStepController.cpp:84
+		Lap lap(&m_ms[4]);
 		ok = runSteps(model, 1);
 	}
 	if (ok)
@@ -702,6 +725,7 @@ void TimeStepControllerHIP::step(SimulationModel &model)
 		// TimeStepController.cpp:216-223: the reference rebuilds the contact lists every step; the device keeps
 		// its contacts to itself, so the host lists are emptied (counts: pbdx_solver_get_num_contacts)
 		if (m_collisionDetection != NULL) model.resetContacts();
+		Lap lap(&m_ms[5]);
 		ok = downloadParticles(model);
 	}
 	if (!ok)
@@ -771,4 +795,5 @@ extern "C" void pbdx_timestep_hip_mark_host_dirty(PBD::TimeStep *ts) { static_ca
 extern "C" unsigned int pbdx_timestep_hip_partial_uploads(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numPartialUploads(); }
 extern "C" void pbdx_timestep_hip_refresh_parameters(PBD::TimeStep *ts) { static_cast<PBD::TimeStepControllerHIP*>(ts)->refreshParameters(); }
 extern "C" void pbdx_timestep_hip_set_full_parameter_scan(PBD::TimeStep *ts, int on) { static_cast<PBD::TimeStepControllerHIP*>(ts)->setFullParameterScan(on != 0); }
+extern "C" void pbdx_timestep_hip_timing(PBD::TimeStep *ts, double out[6], int reset) { static_cast<PBD::TimeStepControllerHIP*>(ts)->timing(out, reset != 0); }
 extern "C" void *pbdx_timestep_hip_solver(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->solver(); }

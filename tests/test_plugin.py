@@ -249,9 +249,14 @@ def test_plugin_full_size_c2_reference_model():
     ts, model = ref.timestep_ptr(), ref.model_ptr()
     assert cnt["gpu_steps"](ts) == 2 and cnt["failed_steps"](ts) == 0
     assert util.bitwise_equal(ref.positions(), x_cpu) and util.bitwise_equal(ref.get_array(2), v_cpu)
+    lib.pbdx_timestep_hip_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+    lap = (C.c_double * 6)()
+    lib.pbdx_timestep_hip_timing(ts, lap, 1)
     t0 = time.perf_counter()
     ref.step(10)
     t_round = (time.perf_counter() - t0) / 10
+    lib.pbdx_timestep_hip_timing(ts, lap, 1)
+    print("plug-in round trip at 1000x1000, ms per step: host-array hashes %.3f, uploads %.3f, parameter check %.3f, colliders %.3f, engine step %.3f, download %.3f" % tuple(v / 10 for v in lap))
     assert cnt["step_resident"](ts, model, 5) == 0
     t0 = time.perf_counter()
     assert cnt["step_resident"](ts, model, 50) == 0
@@ -351,15 +356,17 @@ def test_reference_python_example_through_compiled_pypbd_on_the_gpu():
 # ---------------------------------------------------------------------------
 def _np_block_hashes(a):
     """pbdx_hash_block (include/pbdx.h) restated in numpy for a packed array."""
-    w = np.ascontiguousarray(a).view(np.uint32).reshape(-1)
-    elem_words = w.size // len(a)
+    raw = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    elem_bytes = raw.size // len(a)
+    if raw.size % 8:
+        raw = np.concatenate([raw, np.zeros(4, dtype=np.uint8)])          # an odd 32-bit word at the end counts as a 64-bit word with a zero upper half
+    w = raw.view(np.uint64)
     i = np.arange(w.size, dtype=np.uint64)
     with np.errstate(over="ignore"):
-        k = ((i * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        m = (w ^ k).astype(np.uint64) * np.uint64(0xD1B54A32D192ED03) + np.uint64(0x632BE59BD9B4E019)
-    m ^= m >> np.uint64(31)
-    per = 1024 * elem_words
-    nb = (w.size + per - 1) // per
+        m = (w ^ (i * np.uint64(0x9E3779B97F4A7C15))) * np.uint64(0xD1B54A32D192ED03)
+    m ^= m >> np.uint64(29)
+    per = 1024 * elem_bytes // 8
+    nb = (len(a) + 1023) // 1024
     return np.array([np.bitwise_xor.reduce(m[b * per:(b + 1) * per]) for b in range(nb)], dtype=np.uint64)
 
 
