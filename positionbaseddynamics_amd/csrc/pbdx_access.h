@@ -107,6 +107,8 @@ template <int TYPE, bool COMPACT, bool COHERENT = false> struct TileAccess
 		// plane * 256 is a compile-time constant: folded into the instruction's immediate offset
 		return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.par, (int)(v_par + plane * 256u), (int)par_soff, 0));
 	}
+	// raw dword of the chunk's parameter block at a per-lane byte offset (quad-lane records, pbdx_quad.h: every lane fetches its own planes)
+	__device__ __forceinline__ uint32_t par_raw(uint32_t voff) const { return __builtin_amdgcn_raw_buffer_load_b32(str.par, (int)voff, (int)par_soff, 0); }
 	__device__ __forceinline__ bool sym() const { return COMPACT; }
 	__device__ __forceinline__ float lam_load(uint32_t i) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.lam, (int)(i * 4u), (int)lam_soff, COHERENT ? 16 : 0)); }
 	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), str.lam, (int)(i * 4u), (int)lam_soff, 0); }

@@ -73,6 +73,13 @@ constexpr uint32_t kCompactScalars[13] = {
 };
 constexpr int kParamCount[13] = { 2, 2, 2, 17, 17, 10, 9, 2, 2, 12, 12, 13, 24 };
 
+// Types whose projection is spread over the four lanes of a quad in the fused tile kernels (pbdx_quad.h): a workgroup-wide chunk of such a
+// step holds BLOCK / 4 slots.  PBDX_QUAD_LANES = 0 builds the one-lane-per-constraint form for A/B measurements.
+#ifndef PBDX_QUAD_LANES
+#define PBDX_QUAD_LANES 1
+#endif
+constexpr bool is_quad_type(int type) { return PBDX_QUAD_LANES != 0 && (type == 9 || type == 10); }      // FEM_TET, FEM_TET_XPBD
+
 constexpr bool is_bending_type(int type) { return type == 3 || type == 4; }
 // Q(r,c) is parameter 1 + c*4 + r; the strictly lower triangle (r > c) is mirrored, not streamed
 constexpr bool is_mirrored_q(int type, bool compact, int k)

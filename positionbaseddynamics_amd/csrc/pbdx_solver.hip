@@ -32,11 +32,13 @@
 #include <hip/hip_runtime.h>
 #include "pbdx_internal.h"
 #include "pbdx_access.h"
+#include "pbdx_quad.h"
 #include "pbdx_plan.h"
 #include "pbdx_contact.h"
 #include "pbdx_tetcontact_dev.h"
 #include <chrono>
 #include <algorithm>
+#include <type_traits>
 #include <string.h>
 
 using namespace pbdx;
@@ -273,21 +275,26 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 {
 	constexpr int D = Depth<TYPE>::value;
 	typedef TileAccess<TYPE, COMPACT, COHERENT> Acc;
+	// quad-lane types (pbdx_quad.h): four lanes share a slot, a chunk holds BLOCK / 4 slots
+	constexpr bool QUAD = is_quad_type(TYPE);
+	typedef typename std::conditional<QUAD, RecQ<TYPE, COMPACT>, Rec<TYPE, COMPACT>>::type RecT;
 	// per-lane constants of the run
-	const uint32_t lane_slot = threadIdx.x;
-	const uint32_t v_par = (threadIdx.x >> 6) * (uint32_t)(num_planes(TYPE, COMPACT) * 256) + (threadIdx.x & 63u) * 4u;
+	const uint32_t lane_slot = QUAD ? threadIdx.x >> 2 : threadIdx.x;
+	const uint32_t v_par = (lane_slot >> 6) * (uint32_t)(num_planes(TYPE, COMPACT) * 256) + (lane_slot & 63u) * 4u;
+	const QuadLane ql = quad_lane(v_par);
 	// end of the run (first chunk of another type): precomputed on the host
 	const uint32_t run_end = c0 + chunk_run_left(rfl(lchunks[c0].x));
 
 	uint32_t c_ld = c0, c_ex = c0;
 	// the ring lives in named records (not an array): keeps every record in registers
-	Rec<TYPE, COMPACT> r0, r1, r2, r3;
-	auto fetch = [&](Rec<TYPE, COMPACT> &dst)
+	RecT r0, r1, r2, r3;
+	auto fetch = [&](RecT &dst)
 	{
 		// beyond the run the last chunk is fetched again (harmless): the fetch itself stays unconditional
 		const ChunkS ch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
 		const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, a.views[TYPE] };
-		load_rec<TYPE, COMPACT>(acc, lane_slot, dst);
+		if constexpr (QUAD) load_rec_quad<TYPE, COMPACT>(acc, ql, lane_slot, dst);
+		else load_rec<TYPE, COMPACT>(acc, lane_slot, dst);
 		c_ld++;
 	};
 	fetch(r0); fetch(r1);
@@ -298,14 +305,17 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 	// the descriptor of the chunk to project next is read BEFORE the colour barrier of the previous one,
 	// so that the first thing after a barrier is the LDS gather of the already prefetched record
 	ChunkS ch_next = load_chunk(lchunks, c0);
-	auto sub = [&](Rec<TYPE, COMPACT> &cur)
+	auto sub = [&](RecT &cur)
 	{
 		if (c_ex < run_end)
 		{
 			const ChunkS ch = ch_next;
 			const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, a.views[TYPE] };
 			if (lane_slot < chunk_valid(ch.info))
-				exec_rec<TYPE, COMPACT>(acc, cur, lane_slot, a.dt, a.first_iter);
+			{
+				if constexpr (QUAD) exec_rec_quad<TYPE, COMPACT>(acc, ql, cur, lane_slot, a.dt, a.first_iter);
+				else exec_rec<TYPE, COMPACT>(acc, cur, lane_slot, a.dt, a.first_iter);
+			}
 			c_ex++;
 			ch_next = load_chunk(lchunks, c_ex < run_end ? c_ex : run_end - 1);
 			if (chunk_last_of_step(ch.info))
@@ -647,6 +657,10 @@ constexpr uint32_t kMaskClothXpbd = (1u << PBDX_DISTANCE_XPBD) | (1u << PBDX_ISO
 constexpr uint32_t kMaskLight = (1u << PBDX_DISTANCE) | (1u << PBDX_DISTANCE_XPBD) | (1u << PBDX_ISOMETRIC_BENDING) |
 	(1u << PBDX_ISOMETRIC_BENDING_XPBD) | (1u << PBDX_VOLUME) | (1u << PBDX_VOLUME_XPBD) | (1u << PBDX_DIHEDRAL);
 constexpr uint32_t kMaskAll = (1u << PBDX_NUM_CONSTRAINT_TYPES) - 1u;
+// the solid workloads get kernels of their own: the everything-kernel carries the register demand of its heaviest type (shape matching, strain
+// tets: 256 VGPRs and spills) into every run
+constexpr uint32_t kMaskFemTet = kMaskLight | (1u << PBDX_FEM_TET) | (1u << PBDX_FEM_TET_XPBD);
+constexpr uint32_t kMaskStrainTet = kMaskLight | (1u << PBDX_STRAIN_TET);
 
 fused_fn pick_fused_kernel(uint32_t mask, int block)
 {
@@ -655,6 +669,10 @@ fused_fn pick_fused_kernel(uint32_t mask, int block)
 	if ((mask & ~kMaskLight) == 0)
 		return block == 1024 ? fused_kernel<kMaskLight, 1024> : block == 512 ? fused_kernel<kMaskLight, 512> : fused_kernel<kMaskLight, 256>;
 	// heavy types (FEM / strain / shape matching) need > 128 VGPRs: at most 512 threads per workgroup
+	if ((mask & ~kMaskFemTet) == 0)
+		return block >= 512 ? fused_kernel<kMaskFemTet, 512> : fused_kernel<kMaskFemTet, 256>;
+	if ((mask & ~kMaskStrainTet) == 0)
+		return block >= 512 ? fused_kernel<kMaskStrainTet, 512> : fused_kernel<kMaskStrainTet, 256>;
 	return block >= 512 ? fused_kernel<kMaskAll, 512> : fused_kernel<kMaskAll, 256>;
 }
 
@@ -664,6 +682,10 @@ persist_fn pick_persistent_kernel(uint32_t mask, int block)
 		return block == 1024 ? persistent_kernel<kMaskClothXpbd, 1024> : block == 512 ? persistent_kernel<kMaskClothXpbd, 512> : persistent_kernel<kMaskClothXpbd, 256>;
 	if ((mask & ~kMaskLight) == 0)
 		return block == 1024 ? persistent_kernel<kMaskLight, 1024> : block == 512 ? persistent_kernel<kMaskLight, 512> : persistent_kernel<kMaskLight, 256>;
+	if ((mask & ~kMaskFemTet) == 0)
+		return block >= 512 ? persistent_kernel<kMaskFemTet, 512> : persistent_kernel<kMaskFemTet, 256>;
+	if ((mask & ~kMaskStrainTet) == 0)
+		return block >= 512 ? persistent_kernel<kMaskStrainTet, 512> : persistent_kernel<kMaskStrainTet, 256>;
 	return block >= 512 ? persistent_kernel<kMaskAll, 512> : persistent_kernel<kMaskAll, 256>;
 }
 
@@ -1340,7 +1362,7 @@ int ensure_plan(pbdx_solver *s)
 		if (block != 256 && block != 512 && block != 1024)
 		{
 			uint32_t widest = 0;
-			for (const FusedStep &st : seg.steps) widest = std::max(widest, st.count);
+			for (const FusedStep &st : seg.steps) widest = std::max(widest, st.count * (is_quad_type((int)st.type) ? 4u : 1u));      // in lanes
 			block = widest > 512 ? 1024 : widest > 256 ? 512 : 256;
 			// small scenes (fewer than 512 particles per CU: every colour step is latency-bound, pbdx_plan.cpp): 8 wavefronts meet at the colour
 			// barriers sooner than 16 and a step wider than 512 slots simply takes a second chunk -- measured 3 - 14 % faster than 1 024 threads
@@ -1380,11 +1402,13 @@ int ensure_plan(pbdx_solver *s)
 				const TypeInfo *ti = type_info((int)st.type);
 				const uint32_t nplanes = (uint32_t)num_planes((int)st.type, s->plan.views[st.type].compact != 0);
 				const uint32_t slot_idx_bytes = ti->num_bodies == 2 ? 4u : 8u;
-				const uint32_t nchunks = (st.count + (uint32_t)block - 1) / (uint32_t)block;
+				// slots per workgroup-wide chunk: one per lane, or one per QUAD of lanes (pbdx_quad.h; a multiple of 64: the parameter planes are wave-tiled)
+				const uint32_t cap = is_quad_type((int)st.type) ? (uint32_t)block / 4u : (uint32_t)block;
+				const uint32_t nchunks = (st.count + cap - 1) / cap;
 				for (uint32_t k = 0; k < nchunks; k++)
 				{
-					const uint32_t first = k * (uint32_t)block;
-					const uint32_t valid = std::min<uint32_t>((uint32_t)block, st.count - first);
+					const uint32_t first = k * cap;
+					const uint32_t valid = std::min<uint32_t>(cap, st.count - first);
 					const bool last = (k + 1 == nchunks);
 					FusedChunk c;
 					c.info = st.type | ((last && st.barrier) ? 0x40u : 0u) | (last ? 0x80u : 0u) | (valid << 8);
