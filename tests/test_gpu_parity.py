@@ -789,3 +789,23 @@ def test_more_contacts_per_particle_than_the_engine_keeps_is_an_error(pbd):
     with pytest.raises(pbd.PbdxError) as e:
         run(9)
     assert e.value.code == 4 and "simultaneous contacts" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_quad_lane_build_is_bit_identical(pbd):
+    """The opt-in build with the FEM tet projections spread over the four lanes of a quad (pbdx_quad.h: columns of F / strain / stress per lane, DPP
+    quad_perm exchanges, reductions replayed in the reference's order; `north_star`: "DPP reductions for per-constraint 3x3 math"): the FEM known-answer
+    tests, the inversion branch, every scene against the float reference, the fused-vs-per-colour cross-check and the full-size 100 k-tet bar, all
+    bit for bit, in a process that loads _lib/libpbdx_quad.so instead of the product library."""
+    import subprocess
+    import sys
+    lib = os.path.join(util.ROOT, "positionbaseddynamics_amd", "_lib", "libpbdx_quad.so")
+    if not os.path.exists(lib):
+        pytest.skip("libpbdx_quad.so not built")
+    sel = "known_answer_projection or fem_tet_inversion_branch or scene_parity_vs_float_reference or fused_tiles_equal_per_colour_schedule or full_size_c3"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(util.ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k", sel],
+                       env=dict(os.environ, PBDX_LIB=lib), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    tail = p.stdout[-1500:]
+    assert p.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
+    print("quad-lane build: " + tail.strip().splitlines()[-1])
