@@ -394,7 +394,8 @@ typedef struct pbdx_segment_info {
 int pbdx_solver_get_segment_info(pbdx_solver *s, uint32_t segment, pbdx_segment_info *out);
 /* The one-launch form of the fused schedule (PBDX_OPT_PERSISTENT). */
 typedef struct pbdx_persistent_info {
-	int eligible, active;          /* the plan can run as one launch per substep / that is the schedule in use */
+	int eligible, active;          /* the plan can run as one launch per substep / the schedule in use: 1 = one launch per substep, 2 = one launch per ITERATION
+	                                * (scenes with contacts between deformable solids: the contact list is solved between the iterations) */
 	uint32_t grid, block, lds_bytes; /* launch geometry */
 	uint32_t refusals;             /* launches that found their workgroups not co-resident (the engine then fell back for good) */
 	uint32_t timeouts;             /* calls in which a tile-to-tile wait expired (state restored, call repeated with one launch per segment) */

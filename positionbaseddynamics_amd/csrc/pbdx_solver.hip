@@ -548,6 +548,8 @@ struct PersistArgs
 	uint32_t *ctl;                                // kCtl* words (device)
 	uint32_t *error;                              // page-locked host words: [0] a dependency wait timed out, [1] launch refused, [2] at which substep
 	uint32_t num_segs, passes, num_tiles;
+	uint32_t first_iter_passes;                   // passes [0, first_iter_passes) belong to iteration 0 of a substep (multipliers := 0 unread): num_segs for a launch
+	                                              // that starts a substep's sweeps, 0 for a later iteration launched on its own (contacts between the iterations)
 	uint32_t expect;                              // arrivals that mean "everybody is here" (gridDim.x; one more in the self-test)
 	unsigned long long spin_limit;                // bound of a dependency wait in wall-clock ticks (PBDX_OPT_PERSISTENT_TIMEOUT_MS)
 	int mute_tile0;                               // self-test of the timeout path: tile 0 never publishes its first pass
@@ -602,7 +604,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 	for (uint32_t pass = 0; pass < a.passes; pass++)
 	{
 		const SegArgs &sg = a.seg[sgi];
-		const RunArgs ra = { a.dt, pass < a.num_segs ? 1 : 0, a.views };
+		const RunArgs ra = { a.dt, pass < a.first_iter_passes ? 1 : 0, a.views };
 		const float4 *pos_in = a.pos[(a.start + pass) & 1u];
 		float4 *pos_out = a.pos[(a.start + pass + 1u) & 1u];
 		for (uint32_t tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x)
@@ -1214,6 +1216,9 @@ struct pbdx_solver
 	bool fused_active() const { return fuse && plan_ok && !dsegs.empty() && (fuse == 1 || fuse_choice); }
 	// (contacts between solids are solved between the iterations of a substep: the sweeps of a substep cannot be one launch then)
 	bool persistent_active() const { return persistent && persist_ok && persist_choice && fused_active() && !tet_active(); }
+	// contacts between deformable solids are solved BETWEEN the iterations (TimeStepController.cpp:288-291): the one-launch schedule then runs one
+	// launch per ITERATION (all segments of a sweep; tile-to-tile hand-offs instead of kernel boundaries), the contact solve in between
+	bool persistent_iter_active() const { return persistent && persist_ok && persist_choice && fused_active() && tet_active(); }
 	void unpin_all()
 	{
 		for (const Pin &pn : pins) (void)hipHostUnregister(const_cast<void *>(pn.p));
@@ -1551,7 +1556,7 @@ SegArgs seg_args(const DeviceSegment &d)
 }
 
 // (A') all `iterations` sweeps as one launch; with `fold` also the integration before and the velocity update after them
-int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations, const FoldArgs *fold = nullptr)
+int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations, const FoldArgs *fold = nullptr, bool first_iteration = true)
 {
 	PersistArgs a;
 	memset(&a, 0, sizeof(a));
@@ -1568,6 +1573,7 @@ int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations, co
 	a.error = s->d_error;
 	a.num_segs = (uint32_t)s->dsegs.size();
 	a.passes = iterations * a.num_segs;
+	a.first_iter_passes = first_iteration ? a.num_segs : 0u;
 	a.num_tiles = s->plan.num_tiles;
 	a.expect = s->persist_grid + (s->persistent == 3 ? 1u : 0u);     // 3 = self-test: the handshake cannot complete
 	a.spin_limit = (unsigned long long)s->persist_timeout_ms * kTicksPerMs;
@@ -1690,6 +1696,20 @@ int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, Pr
 		HIPCHECK(hipGetLastError());
 		return PBDX_OK;
 	};
+	if (s->persistent_iter_active() && with_tet_contacts)
+	{
+		for (uint32_t it = 0; it < iterations; it++)
+		{
+			if (pc) { int r = prof_begin(pc, -1, 0); if (r) return r; }
+			int r = launch_persistent(s, src, dt, 1, nullptr, it == 0);
+			if (r) return r;
+			if (pc) { r = prof_end(pc); if (r) return r; }
+			src ^= (int)(s->dsegs.size() & 1u);
+			r = tet_solve(src);
+			if (r) return r;
+		}
+		return PBDX_OK;
+	}
 	if (s->fused_active())
 	{
 		for (uint32_t it = 0; it < iterations; it++)
@@ -1801,7 +1821,7 @@ int autotune_schedule(pbdx_solver *s)
 
 // the control block is handed to the particle kernels only while the persistent schedule runs (captured graphs are
 // rebuilt when that changes: GraphKey::persist)
-inline uint32_t *ctl_of(pbdx_solver *s, ProfCursor *) { return s->persistent_active() ? s->d_ctl : nullptr; }
+inline uint32_t *ctl_of(pbdx_solver *s, ProfCursor *) { return (s->persistent_active() || s->persistent_iter_active()) ? s->d_ctl : nullptr; }
 
 // second half of a substep: the sweeps and the velocity update
 int enqueue_substep_tail(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int vel, ProfCursor *pc)
@@ -2617,7 +2637,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	const uint64_t launches_per_sweep = s->fused_active() ? s->dsegs.size() : s->order.size();
 	s->stats = pbdx_step_stats();
 	s->stats.projections = proj_per_sweep * max_iterations * substeps_total;
-	s->stats.kernel_launches = (s->persistent_active() ? 1 : launches_per_sweep * max_iterations + 2) * substeps_total;
+	s->stats.kernel_launches = (s->persistent_active() ? 1 : s->persistent_iter_active() ? 2 * max_iterations + 2 : launches_per_sweep * max_iterations + 2) * substeps_total;
 	s->stats.algorithmic_bytes = (bytes_per_sweep * max_iterations + (uint64_t)s->n * 140) * substeps_total;
 	memset(s->type_ms, 0, sizeof(s->type_ms));
 	memset(s->type_launches, 0, sizeof(s->type_launches));
@@ -2633,24 +2653,58 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	}
 	if (s->d_contact_counters && !s->colliders.empty())
 		HIPCHECK(hipMemsetAsync(s->d_contact_counters, 0, 2 * sizeof(unsigned int), s->stream));     // [1] = overflow flag, sticky for the whole call
+	// One launch per ITERATION (scenes with contacts between deformable solids, persistent_iter_active): a launch can be refused (residency) or a
+	// tile can time out at any iteration of any substep, after earlier iterations and contact solves of the same step have changed the state.  The
+	// state is therefore saved per STEP -- the contact list is not written before the detection at the end of the step, and that detection
+	// synchronises with the host anyway -- and a failed step is restored, the schedule switched off and the step repeated with one launch per segment.
+	auto step_begin = [&]() -> int
+	{
+		if (!s->persistent_iter_active()) return PBDX_OK;
+		HIPCHECK(hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream));
+		return snapshot_state(s, false);
+	};
+	auto step_end = [&]() -> int          // before the step's contact detection
+	{
+		if (!s->persistent_iter_active()) return PBDX_OK;
+		HIPCHECK(hipStreamSynchronize(s->stream));
+		if (!s->h_error[0] && !s->h_error[1]) return PBDX_OK;
+		if (s->h_error[1]) s->persist_refusals++; else s->persist_timeouts++;
+		s->h_error[0] = s->h_error[1] = s->h_error[2] = 0u;
+		s->persist_ok = false;                   // persistent_iter_active() is false from here on
+		s->drop_graph();
+		float4 *dst[4] = { s->d_pos[0], s->d_vel, s->d_old, s->d_last };
+		for (int q = 0; q < 4; q++)
+		{
+			if (!s->d_snap[q]) { set_error("one-launch-per-iteration schedule: a launch failed and no snapshot exists"); return PBDX_ERR_HIP; }
+			HIPCHECK(hipMemcpyAsync(dst[q], s->d_snap[q], (size_t)s->n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+		}
+		HIPCHECK(hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream));
+		for (uint32_t q = 0; q < sub_steps; q++)
+		{
+			int r = enqueue_substep(s, hs, inv_h, max_iterations, vel, gravity, nullptr);
+			if (r) return r;
+		}
+		return PBDX_OK;
+	};
 	if (s->profile)
 	{
 		HIPCHECK(hipEventRecord(s->ev_start, s->stream));
 		for (uint64_t k = 0; k < substeps_total; k++)
 		{
+			if (k % sub_steps == 0) { int rb = step_begin(); if (rb) return rb; }
 			ProfCursor pc; pc.s = s;
 			int r = enqueue_substep(s, hs, inv_h, max_iterations, vel, gravity, &pc);
 			if (r) return r;
 			if (s->last_flips) s->swap_state();
 			r = collect_profile(s, &pc);
 			if (r) return r;
-			if ((k + 1) % sub_steps == 0) { r = enqueue_contacts(s); if (r) return r; }
+			if ((k + 1) % sub_steps == 0) { r = step_end(); if (!r) r = enqueue_contacts(s); if (r) return r; }
 		}
 		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
 	}
 	else if (s->use_graph)
 	{
-		pbdx_solver::GraphKey k = { hs, max_iterations, vel, { gravity[0], gravity[1], gravity[2] }, s->schedule_version, s->block_size, s->xcd_remap, s->n, s->fused_active() ? 1 : 0, s->persistent_active() ? 1 : 0 };
+		pbdx_solver::GraphKey k = { hs, max_iterations, vel, { gravity[0], gravity[1], gravity[2] }, s->schedule_version, s->block_size, s->xcd_remap, s->n, s->fused_active() ? 1 : 0, s->persistent_active() ? 1 : (s->persistent_iter_active() ? 2 : 0) };
 		if (memcmp(&k, &s->key, sizeof(k)) != 0) { s->drop_graph(); s->key = k; }
 		bool flips = false;
 		auto capture = [&]() -> int
@@ -2676,10 +2730,11 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		HIPCHECK(hipEventRecord(s->ev_start, s->stream));
 		for (uint64_t k2 = 0; k2 < substeps_total; k2++)
 		{
+			if (k2 % sub_steps == 0) { int rb = step_begin(); if (rb) return rb; }
 			if (!s->graph_valid[s->phys]) { int r = capture(); if (r) return r; }
 			HIPCHECK(hipGraphLaunch(s->graph_exec[s->phys], s->stream));
 			if (flips) s->swap_state();
-			if ((k2 + 1) % sub_steps == 0) { int r = enqueue_contacts(s); if (r) return r; }
+			if ((k2 + 1) % sub_steps == 0) { int r = step_end(); if (!r) r = enqueue_contacts(s); if (r) return r; }
 		}
 		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
 	}
@@ -2688,10 +2743,11 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		HIPCHECK(hipEventRecord(s->ev_start, s->stream));
 		for (uint64_t k = 0; k < substeps_total; k++)
 		{
+			if (k % sub_steps == 0) { int rb = step_begin(); if (rb) return rb; }
 			int r = enqueue_substep(s, hs, inv_h, max_iterations, vel, gravity, nullptr);
 			if (r) return r;
 			if (s->last_flips) s->swap_state();
-			if ((k + 1) % sub_steps == 0) { r = enqueue_contacts(s); if (r) return r; }
+			if ((k + 1) % sub_steps == 0) { r = step_end(); if (!r) r = enqueue_contacts(s); if (r) return r; }
 		}
 		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
 	}
@@ -3203,7 +3259,7 @@ int pbdx_solver_get_persistent_info(pbdx_solver *s, pbdx_persistent_info *out)
 	if (!s || !out) return PBDX_ERR_INVALID;
 	memset(out, 0, sizeof(*out));
 	out->eligible = s->persist_ok ? 1 : 0;
-	out->active = s->persistent_active() ? 1 : 0;
+	out->active = s->persistent_active() ? 1 : (s->persistent_iter_active() ? 2 : 0);      // 2: one launch per ITERATION (contacts between deformable solids are solved between the iterations)
 	out->grid = s->persist_grid; out->block = (uint32_t)s->persist_block; out->lds_bytes = s->persist_lds;
 	out->refusals = s->persist_refusals;
 	out->timeouts = s->persist_timeouts;
@@ -3269,7 +3325,7 @@ int pbdx_solver_describe(pbdx_solver *s, char *buf, size_t n)
 			uint32_t ml = 0;
 			for (const FusedSegment &seg : s->plan.segs) ml = std::max(ml, seg.max_local);
 			int w2 = snprintf(buf + w, n - w, " schedule=%s segments=%zu tiles=%u redundancy=%.3f max_tile_particles=%u plan_s=%.2f%s",
-				s->persistent_active() ? "fused-persistent" : "fused", s->plan.segs.size(), s->plan.num_tiles, s->plan.redundancy, ml, s->plan.build_seconds,
+				s->persistent_active() ? "fused-persistent" : (s->persistent_iter_active() ? "fused-persistent-per-iteration" : "fused"), s->plan.segs.size(), s->plan.num_tiles, s->plan.redundancy, ml, s->plan.build_seconds,
 				s->plan_instanced ? " (one instance planned, replicated)" : "");
 			if (s->persist_refusals && w2 > 0 && (size_t)(w + w2) < n)
 				w2 += snprintf(buf + w + w2, n - w - w2, " persistent_refusals=%u", s->persist_refusals);

@@ -724,3 +724,48 @@ def test_armadillo_collision_scene_bit_exact(sub_steps):
     assert floor_contacts == int(g["contact_totals_sub%d" % sub_steps][1])
     print("armadillo scene, %d substeps: 260 steps bit-identical; %d floor contacts; schedule %s" % (sub_steps, floor_contacts, sol.describe()))
     del cols
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["forced", "refused", "timed_out", "per_segment"])
+def test_one_launch_per_iteration_schedule_with_contacts_between_the_iterations(mode):
+    """With contacts between deformable solids the contact list is solved after EVERY iteration (TimeStepController.cpp:288-291), so the one-launch
+    schedule runs one persistent launch per iteration (all segments of a sweep, tile-to-tile hand-offs instead of kernel boundaries).  Bit-identical to
+    the golden run of the reference; a refused launch (self-test: the residency handshake cannot complete) and a timed-out tile (self-test: tile 0
+    never publishes its first pass) are recovered PER STEP -- state restored, schedule switched off, step repeated with one launch per segment."""
+    import positionbaseddynamics_amd as pbd
+    g = np.load(GOLDEN)
+    cols = tcu.GoldenTetColliders(g)
+    model = util.build_mine(_two_bar_ops())
+    ts = pbd.TimeStepController()
+    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 5)
+    pbd.TimeManager.getCurrent().setTimeStepSize(0.005)
+    ts.syncFromHost(model)
+    sol = ts.solver()
+    S = pbd.Solver
+    sol.set_option(S.OPT_FUSE, 1)
+    sol.set_option(S.OPT_PERSISTENT, {"forced": 2, "refused": 3, "timed_out": 4, "per_segment": 0}[mode])
+    if mode == "timed_out":
+        sol.set_option(S.OPT_PERSISTENT_TIMEOUT_MS, 5)
+    sol.set_rest_positions(g["x0"])
+    sol.set_tet_colliders(cols.arr, cols.n, float(g["tolerance"]))
+    done = 0
+    for steps in g["steps"]:
+        ts.stepResident(model, int(steps) - done)
+        done = int(steps)
+        ts.syncToHost(model)
+        got, want = sol.tet_contacts(), g["contacts_%d" % steps]
+        assert len(got) == len(want) and util.bitwise_equal(got[:, :26], want), "step %d: contact list" % steps
+        assert util.bitwise_equal(model.getParticles().positions(), g["x_%d" % steps]), "step %d" % steps
+        assert util.bitwise_equal(model.getParticles().velocities(), g["v_%d" % steps])
+    pi = sol.persistent_info()
+    print("schedule with contacts (%s): %s; refusals %d, time-outs %d" % (mode, sol.describe().split("schedule=")[1].split()[0], pi["refusals"], pi["timeouts"]))
+    if mode == "forced":
+        assert pi["active"] == 2 and pi["refusals"] == 0 and pi["timeouts"] == 0
+    elif mode == "refused":
+        assert pi["active"] == 0 and pi["refusals"] == 1
+    elif mode == "timed_out":
+        assert pi["active"] == 0 and pi["timeouts"] == 1
+    else:
+        assert pi["active"] == 0
