@@ -7,6 +7,7 @@
 #include "Utils/Logger.h"
 #include "Utils/Timing.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <omp.h>
 #include <chrono>
@@ -103,6 +104,7 @@ namespace
 		first[numJobs] = total;
 		int threads = bytes >= ((size_t)1 << 20) ? omp_get_num_procs() : 1;
 		if (threads > 32) threads = 32;
+		if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) threads = v; }      // developer aid
 		// ONE parallel region over the blocks of all arrays
 		#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
 		for (int q = 0; q < total; q++)
@@ -143,6 +145,7 @@ TimeStepControllerHIP::TimeStepControllerHIP(int device) :
 	m_accelGravity[0] = m_accelGravity[1] = m_accelGravity[2] = 0;
 	m_fullParameterScan = false; m_partialUploads = 0;
 	for (int k = 0; k < 6; k++) m_ms[k] = 0.0;
+	m_deviceMs = 0.0;
 	if (pbdx_solver_create(&m_solver, device) != PBDX_OK)
 	{
 		LOG_ERR << "TimeStepControllerHIP: " << pbdx_last_error() << " -- every step() will fail (no CPU path)";
@@ -693,6 +696,7 @@ bool TimeStepControllerHIP::runSteps(SimulationModel &model, unsigned int numSte
 	const bool ok = pbdx_solver_step(m_solver, (float)h, m_subSteps, m_maxIterations, m_velocityUpdateMethod, g, numSteps) == PBDX_OK;
 	STOP_TIMING_AVG;
 	if (!ok) return false;
+	{ pbdx_step_stats st; if (pbdx_solver_get_stats(m_solver, &st) == PBDX_OK) m_deviceMs += st.total_ms; }
 	m_iterations = m_maxIterations;
 	m_iterationsV = m_maxIterationsV;
 	m_deviceAhead = true;
@@ -795,5 +799,5 @@ extern "C" void pbdx_timestep_hip_mark_host_dirty(PBD::TimeStep *ts) { static_ca
 extern "C" unsigned int pbdx_timestep_hip_partial_uploads(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numPartialUploads(); }
 extern "C" void pbdx_timestep_hip_refresh_parameters(PBD::TimeStep *ts) { static_cast<PBD::TimeStepControllerHIP*>(ts)->refreshParameters(); }
 extern "C" void pbdx_timestep_hip_set_full_parameter_scan(PBD::TimeStep *ts, int on) { static_cast<PBD::TimeStepControllerHIP*>(ts)->setFullParameterScan(on != 0); }
-extern "C" void pbdx_timestep_hip_timing(PBD::TimeStep *ts, double out[6], int reset) { static_cast<PBD::TimeStepControllerHIP*>(ts)->timing(out, reset != 0); }
+extern "C" void pbdx_timestep_hip_timing(PBD::TimeStep *ts, double out[7], int reset) { static_cast<PBD::TimeStepControllerHIP*>(ts)->timing(out, reset != 0); }
 extern "C" void *pbdx_timestep_hip_solver(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->solver(); }

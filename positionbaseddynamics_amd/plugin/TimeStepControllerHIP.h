@@ -95,8 +95,8 @@ namespace PBD
 		void setFullParameterScan(bool b) { m_fullParameterScan = b; }
 		/** Opt in to running unsupported models / failed steps on the reference's CPU path (default off). */
 		void setAllowReferenceFallback(bool b) { m_allowFallback = b; }
-		/** accumulated host milliseconds of step(): [0] block hashes of the host arrays, [1] full uploads, [2] parameter check, [3] collider refresh, [4] engine step, [5] download */
-		void timing(double out[6], bool reset) { for (int k = 0; k < 6; k++) { out[k] = m_ms[k]; if (reset) m_ms[k] = 0.0; } }
+		/** accumulated host milliseconds of step(): [0] block hashes of the host arrays, [1] full uploads, [2] parameter check, [3] collider refresh, [4] engine step (host wall clock), [5] download, [6] the engine steps' device-event time */
+		void timing(double out[7], bool reset) { for (int k = 0; k < 6; k++) { out[k] = m_ms[k]; if (reset) m_ms[k] = 0.0; } out[6] = m_deviceMs; if (reset) m_deviceMs = 0.0; }
 		pbdx_solver *solver() { return m_solver; }
 
 	protected:
@@ -127,6 +127,7 @@ namespace PBD
 		bool m_imageValid;             // particles were uploaded at least once for the current model
 		std::vector<uint64_t> m_blockHash[5]; // full-coverage block hashes (include/pbdx.h) of x, v, oldX, lastX, masses as of the last upload / download
 		unsigned int m_partialUploads;
+		double m_deviceMs;             // device-event time of the engine's steps (pbdx_step_stats.total_ms), to tell GPU time from host-side waiting
 		double m_ms[6];                // host milliseconds spent in: hashing the host arrays, full uploads, the parameter check, the collider refresh, the engine's step, the download
 		bool m_fullParameterScan;
 		// parameters

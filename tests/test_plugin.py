@@ -250,13 +250,14 @@ def test_plugin_full_size_c2_reference_model():
     assert cnt["gpu_steps"](ts) == 2 and cnt["failed_steps"](ts) == 0
     assert util.bitwise_equal(ref.positions(), x_cpu) and util.bitwise_equal(ref.get_array(2), v_cpu)
     lib.pbdx_timestep_hip_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
-    lap = (C.c_double * 6)()
+    lap = (C.c_double * 7)()
     lib.pbdx_timestep_hip_timing(ts, lap, 1)
     t0 = time.perf_counter()
     ref.step(10)
     t_round = (time.perf_counter() - t0) / 10
     lib.pbdx_timestep_hip_timing(ts, lap, 1)
-    print("plug-in round trip at 1000x1000, ms per step: host-array hashes %.3f, uploads %.3f, parameter check %.3f, colliders %.3f, engine step %.3f, download %.3f" % tuple(v / 10 for v in lap))
+    print("plug-in round trip at 1000x1000, ms per step: host-array hashes %.3f, uploads %.3f, parameter check %.3f, colliders %.3f, engine step %.3f (device events %.3f), download %.3f" % (
+        lap[0] / 10, lap[1] / 10, lap[2] / 10, lap[3] / 10, lap[4] / 10, lap[6] / 10, lap[5] / 10))
     assert cnt["step_resident"](ts, model, 5) == 0
     t0 = time.perf_counter()
     assert cnt["step_resident"](ts, model, 50) == 0
