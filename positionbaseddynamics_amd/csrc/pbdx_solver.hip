@@ -1077,6 +1077,7 @@ struct pbdx_solver
 	TetWork tet_work = {};
 	void *tet_work_alloc[18] = {};
 	pbdx_collision_range *d_ranges = nullptr;     // device copy of `ranges` (read by the tet-contact velocity chains)
+	bool measuring_iter_form = false;    // autotune_schedule: time the one-launch-per-iteration form of the sweeps
 	int tet_force_impulses = 0;          // PBDX_OPT_TET_FORCE_IMPULSES
 	uint32_t tet_impulses_last = 0; uint64_t tet_impulses_total = 0;     // contacts with a non-zero velocity impulse: last detection / since the colliders were set
 	int tet_serial = 0;                            // PBDX_OPT_TET_CONTACTS_SERIAL
@@ -1696,7 +1697,7 @@ int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, Pr
 		HIPCHECK(hipGetLastError());
 		return PBDX_OK;
 	};
-	if (s->persistent_iter_active() && with_tet_contacts)
+	if (s->persistent_iter_active() && (with_tet_contacts || s->measuring_iter_form))
 	{
 		for (uint32_t it = 0; it < iterations; it++)
 		{
@@ -1786,7 +1787,9 @@ int autotune_schedule(pbdx_solver *s)
 			if (hipMemcpyAsync(scratch[0], keep[0], (size_t)s->n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream) != hipSuccess) { r = PBDX_ERR_HIP; break; }
 			if (cand == 2 && hipMemsetAsync(s->d_ctl, 0, kCtlWords * sizeof(uint32_t), s->stream) != hipSuccess) { r = PBDX_ERR_HIP; break; }
 			(void)hipEventRecord(s->ev_start, s->stream);
+			s->measuring_iter_form = cand == 2 && s->tet_active();      // with contacts between the iterations the one-launch form is one launch per ITERATION
 			r = projection_sweeps(s, dt, round == 0 ? 2u : sweeps, 0, nullptr);
+			s->measuring_iter_form = false;
 			(void)hipEventRecord(s->ev_stop, s->stream);
 			if (hipStreamSynchronize(s->stream) != hipSuccess) r = PBDX_ERR_HIP;
 			float t = 0.0f;
@@ -1812,7 +1815,9 @@ int autotune_schedule(pbdx_solver *s)
 	// The short run on scratch positions understates the one-launch form (measured 1-3 % ahead here where whole
 	// substeps are 5-8 % faster: its launch-time costs are spread over 12 sweeps, not over a substep loop), so it
 	// is only rejected where it is clearly behind.
-	if (ms[2] > 0.0f && ms[2] < 1.02f * ms[1]) s->persist_choice = true;
+	// (one launch per ITERATION, scenes with contacts between deformable solids: nothing is amortised over a substep there -- every launch pays its
+	// residency handshake and the reset of the pass counters, about what the kernel boundaries it replaces cost; it has to win the measurement clearly)
+	if (ms[2] > 0.0f && ms[2] < (s->tet_active() ? 0.97f : 1.02f) * ms[1]) s->persist_choice = true;
 	const float fused_best = s->persist_choice ? ms[2] : ms[1];
 	if (ms[0] > 0.0f && ms[0] < fused_best) { s->fuse_choice = 0; s->persist_choice = false; }
 	if (s->persistent >= 2 && s->fuse_choice) s->persist_choice = true;
