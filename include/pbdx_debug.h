@@ -23,15 +23,6 @@ int pbdx_debug_tet_counters(pbdx_solver *s, uint32_t out[8]);
 /* Developer aid: capacities of the detection's scratch (node pairs, overlapping leaf pairs, contacts) and how often it was enlarged: the scratch
  * grows on demand -- an overflow is detected after the detection that caused it, the buffer is made four times as large and the detection repeated. */
 int pbdx_debug_tet_capacity(pbdx_solver *s, uint32_t out[4]);
-/* Developer aid: a sequential float sum (s <- s + x[i], every step rounded) evaluated on the host by the plain loop (*plain) and by the
- * run-by-run procedure the device uses for the long bounding-sphere sums (pbdx_chainsum.h; blocks of per_thread elements, `threads` blocks per
- * window): the two must agree bit for bit.  *single_additions: how many elements fell back to a real addition. */
-int pbdx_debug_chain_sum_host(const float *x, uint64_t n, uint32_t threads, uint32_t per_thread, float *blocked, float *plain, uint64_t *single_additions);
-/* The same on the device (one workgroup, the kernel code of the long bounding-sphere sums): *out must equal the plain loop bit for bit. */
-int pbdx_debug_chain_sum(pbdx_solver *s, const float *x, uint32_t n, float *out);
-/* Developer aid: the device kernel's policy (windows of at most window_max values; an attempt that gains fewer than poor_below values is followed by
- * burst0 << min(consecutive poor attempts, 4) plainly summed values) replayed on the host; stats: attempts, values gained by them, bursts, values in bursts. */
-int pbdx_debug_chain_sum_policy_host(const float *x, uint64_t n, uint32_t window_max, uint32_t poor_below, uint32_t burst0, float *out, uint64_t stats[4]);
 /* The same detection evaluated on the HOST by the same code (pbdx_tetcontact.h is host + device): developer / test aid, no GPU
  * needed.  pos4 / rest4: n x (x, y, z, invMass) records. */
 int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float *rest4, const float *vel4 /* (vx, vy, vz, mass) records or NULL: at rest */,

@@ -127,9 +127,6 @@ SIGNATURES = [
     ("pbdx_solver_get_tet_contacts", C.c_int, vp, u32, C.POINTER(u32), pf),
     ("pbdx_debug_tet_counters", C.c_int, vp, C.POINTER(u32)),
     ("pbdx_debug_tet_capacity", C.c_int, vp, C.POINTER(u32)),
-    ("pbdx_debug_chain_sum", C.c_int, vp, pf, u32, pf),
-    ("pbdx_debug_chain_sum_policy_host", C.c_int, pf, C.c_uint64, u32, u32, u32, pf, C.POINTER(C.c_uint64)),
-    ("pbdx_debug_chain_sum_host", C.c_int, pf, C.c_uint64, u32, u32, pf, pf, C.POINTER(C.c_uint64)),
     ("pbdx_debug_tet_hulls", C.c_int, vp, u32, C.c_int, u32, C.POINTER(u32), pf),
     ("pbdx_debug_tet_solve_host", C.c_int, u32, pf, u32, pf, C.POINTER(u32)),
     ("pbdx_debug_tet_contacts", C.c_int, u32, pf, pf, pf, u32, C.POINTER(TetCollider), f32, u32, C.POINTER(u32), pf),

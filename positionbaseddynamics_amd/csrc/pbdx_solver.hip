@@ -1082,9 +1082,6 @@ struct pbdx_solver
 	uint32_t tet_impulses_last = 0; uint64_t tet_impulses_total = 0;     // contacts with a non-zero velocity impulse: last detection / since the colliders were set
 	int tet_serial = 0;                            // PBDX_OPT_TET_CONTACTS_SERIAL
 	uint32_t tet_grown = 0;                        // times the detection's scratch was enlarged
-	// developer switch: the long sphere sums run by run (pbdx_chainsum.h) instead of by the plain chain.  Exact either way; on the test
-	// scenes the plain chain is the faster one, so it is the default
-	bool tet_run_sums = getenv("PBDX_TET_RUN_SUMS") != nullptr;
 	uint32_t tet_num_colliders = 0;
 	// developer aid (PBDX_TET_PROFILE=1, hipGraph off): wall time per kernel of the contact path, printed when the solver is destroyed
 	bool tet_profile = getenv("PBDX_TET_PROFILE") != nullptr;
@@ -1975,10 +1972,7 @@ int launch_tet_detection(pbdx_solver *s)
 			if (fork)
 			{
 				(void)hipEventRecord(s->ev_join, side);
-				if (!s->tet_run_sums)
-					hipLaunchKernelGGL(tet_hull_kernel2, dim3(s->tet_big_count), dim3(192), kTcBigNodeLds, s->stream, views, (const uint32_t *)s->d_tet_big, s->d_tet_big_r2);
-				else
-					hipLaunchKernelGGL(tet_big_sum_kernel, dim3(3 * s->tet_big_count), dim3(1024), 0, s->stream, views, (const uint32_t *)s->d_tet_big, s->d_tet_big_r2);
+				hipLaunchKernelGGL(tet_hull_kernel2, dim3(s->tet_big_count), dim3(192), kTcBigNodeLds, s->stream, views, (const uint32_t *)s->d_tet_big, s->d_tet_big_r2);
 				hipLaunchKernelGGL(tet_big_radius_kernel, dim3(s->tet_big_slices), dim3(256), 0, s->stream, views, (const uint32_t *)s->d_tet_big, (const uint32_t *)s->d_tet_big_slices, s->d_tet_big_r2);
 				hipLaunchKernelGGL(tet_big_finish_kernel, dim3((s->tet_big_count + 255) / 256), dim3(256), 0, s->stream, views, (const uint32_t *)s->d_tet_big, s->tet_big_count, (const uint32_t *)s->d_tet_big_r2);
 				(void)hipStreamWaitEvent(s->stream, s->ev_join, 0);
@@ -3066,22 +3060,6 @@ static int set_tet_colliders_impl(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 		int r = alloc_tet_work(s, nodes0, contacts0);
 		if (r) return r;
 	}
-	return PBDX_OK;
-}
-
-int pbdx_debug_chain_sum(pbdx_solver *s, const float *x, uint32_t n, float *out)
-{
-	if (!s || !out || (n && !x)) return PBDX_ERR_INVALID;
-	HIPCHECK(hipSetDevice(s->device));
-	float *d = nullptr, *r = nullptr;
-	HIPCHECK(hipMalloc(&d, (size_t)std::max<uint32_t>(n, 1u) * sizeof(float)));
-	HIPCHECK(hipMalloc(&r, sizeof(float)));
-	if (n) HIPCHECK(hipMemcpy(d, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-	hipLaunchKernelGGL(chain_sum_debug_kernel, dim3(1), dim3(1024), 0, s->stream, (const float *)d, n, r);
-	HIPCHECK(hipGetLastError());
-	HIPCHECK(hipStreamSynchronize(s->stream));
-	HIPCHECK(hipMemcpy(out, r, sizeof(float), hipMemcpyDeviceToHost));
-	(void)hipFree(d); (void)hipFree(r);
 	return PBDX_OK;
 }
 

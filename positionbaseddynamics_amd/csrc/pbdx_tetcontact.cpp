@@ -2,7 +2,6 @@
 // device runs (pbdx_tetcontact.h is host + device), so that the detection can be pinned against the reference without a GPU.
 #include "pbdx_internal.h"
 #include "pbdx_tetcontact.h"
-#include "pbdx_chainsum.h"
 #include <string.h>
 #include <vector>
 
@@ -185,23 +184,6 @@ extern "C" int pbdx_debug_tet_velocity_kat(const float *in, float *out)
 			if (tet_contact_velocity_share(c, w0, pv, r, corr)) { out[5 + 3 * r] = corr.x; out[6 + 3 * r] = corr.y; out[7 + 3 * r] = corr.z; }
 		}
 	}
-	return PBDX_OK;
-}
-
-// the sequential float sum two ways on the host (tests/test_chainsum.py): the plain loop and the run-by-run evaluation of pbdx_chainsum.h
-extern "C" int pbdx_debug_chain_sum_host(const float *x, uint64_t n, uint32_t threads, uint32_t per_thread, float *blocked, float *plain, uint64_t *single_additions)
-{
-	if (!x || !blocked || !plain || !threads || !per_thread) return PBDX_ERR_INVALID;
-	volatile float s = 0.0f;                        // volatile: every partial sum is rounded to float, whatever the host compiler would like
-	for (uint64_t i = 0; i < n; i++) s = s + x[i];
-	*plain = s;
-	*blocked = pbdx::cs_sum_blocked_host(x, n, threads, per_thread, single_additions);
-	return PBDX_OK;
-}
-extern "C" int pbdx_debug_chain_sum_policy_host(const float *x, uint64_t n, uint32_t window_max, uint32_t poor_below, uint32_t burst0, float *out, uint64_t stats[4])
-{
-	if (!x || !out || !stats || !window_max || !burst0) return PBDX_ERR_INVALID;
-	*out = pbdx::cs_sum_policy_host(x, n, window_max, poor_below, burst0, stats);
 	return PBDX_OK;
 }
 

@@ -29,7 +29,6 @@
 #define PBDX_TETCONTACT_DEV_H
 
 #include "pbdx_tetcontact.h"
-#include "pbdx_chainsum.h"
 #include <hip/hip_runtime.h>
 
 namespace pbdx {
@@ -162,7 +161,7 @@ template <int B> __device__ __forceinline__ float chain_sum(const float *g, uint
 	}
 	return lane_value(acc, 0);
 }
-// the same, continuing from `start` (wavefront-uniform): used for the stretches of a long sum that do not form runs (below)
+// the same, continuing from `start` (wavefront-uniform)
 __device__ __forceinline__ float chain_sum_from(float start, const float *g, uint32_t m)
 {
 	const uint32_t lane = threadIdx.x & 63u;
@@ -174,124 +173,6 @@ __device__ __forceinline__ float chain_sum_from(float start, const float *g, uin
 		acc = chain_turns<32>(acc, v);
 	}
 	return lane_value(acc, 0);
-}
-
-// ---- long sums: run by run (pbdx_chainsum.h) -- an EXPERIMENT, off by default (PBDX_TET_RUN_SUMS) ------------------------------------
-// One workgroup of 1024 threads per sum.  A window of 16384 values is staged in LDS (coalesced load, padded so that a thread's 16
-// consecutive values are conflict-free), every thread turns its 16 values into a function of the state's parity, a workgroup-wide scan
-// composes the functions, every thread replays its values from its true starting state and reports the first value at which the sum
-// leaves the binade.  No violation: the window is done.  A violation at value i: the state before i is exact, one real addition, next
-// window from i + 1.  If that gained fewer than 2048 values the next 2048, 4096, ... are summed the plain way by one wavefront
-// (chain_sum_from) before runs are tried again.
-// Exact (tests/test_chainsum.py: bit-identical to the plain loop on adversarial data, host and device) -- and not faster here: a window
-// costs ~15 us on one CU (0.9 ns per value: ~90 instructions per value against one dependent addition), every change of binade costs a
-// window, and a component about which the solid is symmetric hovers around zero (the lower bar's z: 40 windows + 207 k of 283 k values
-// in plain bursts).  Spheres of the two 71 k-tet bars: 1.51 ms this way, 0.83 ms by the plain chains; two 610 k-tet bars: 6.5 vs 6.7 ms.
-// What would pay is a window spread over all CUs for the few million-value sums of large scenes.
-constexpr uint32_t kCsThreads = 1024, kCsPerThread = 16, kCsWindow = kCsThreads * kCsPerThread;
-struct CsShared
-{
-	float vals[kCsWindow + kCsWindow / 16];
-	uint32_t wave_a0[16], wave_a1[16];
-	uint32_t stop;                                      // min over threads of (index << 1 | 1 if the run ends AFTER the value)
-	uint32_t stop_state;
-	float seq;
-};
-__device__ __forceinline__ CsFun cs_shfl_up(const CsFun &f, int d)
-{
-	CsFun r; r.a[0] = __shfl_up(f.a[0], d); r.a[1] = __shfl_up(f.a[1], d); return r;
-}
-__device__ inline float chain_sum_runs(const float *g, uint32_t m, CsShared &sh)
-{
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	float s = 0.0f;
-	uint32_t pos = 0, poor = 0;
-	bool plain_next = true;                             // the first values of any sum cross a binade each
-	while (pos < m)
-	{
-		CsFrame fr; uint32_t S0 = 0;
-		const bool framed = cs_frame_of(s, fr, S0);
-		if (plain_next || !framed)
-		{
-			const uint32_t want = 2048u << (poor < 4u ? poor : 4u);
-			const uint32_t len = m - pos < want ? m - pos : want;
-			if (wave == 0) { const float r = chain_sum_from(s, g + pos, len); if (lane == 0) sh.seq = r; }
-			__syncthreads();
-			s = sh.seq;
-			__syncthreads();
-			pos += len;
-			plain_next = false;
-			continue;
-		}
-		const uint32_t window = m - pos < kCsWindow ? m - pos : kCsWindow;
-		for (uint32_t i = tid; i < window; i += kCsThreads) sh.vals[i + (i >> 4)] = g[pos + i];
-		if (tid == 0) sh.stop = 0xffffffffu;
-		__syncthreads();
-		// every thread's values as a function of the parity of the state
-		CsElem q[kCsPerThread];
-		CsFun f = cs_identity();
-		const uint32_t first = tid * kCsPerThread;
-#pragma unroll
-		for (uint32_t k = 0; k < kCsPerThread; k++)
-		{
-			const uint32_t i = first + k;
-			if (i < window) { q[k] = cs_classify(sh.vals[i + (i >> 4)], fr); cs_push(f, q[k]); }
-			else { q[k].X = 0u; q[k].cls = kCsDown; }
-		}
-		// exclusive scan of the functions over the workgroup
-		CsFun inc = f;
-		for (int d = 1; d < 64; d <<= 1)
-		{
-			const CsFun prev = cs_shfl_up(inc, d);
-			if (lane >= (uint32_t)d) inc = cs_then(prev, inc);
-		}
-		if (lane == 63u) { sh.wave_a0[wave] = inc.a[0]; sh.wave_a1[wave] = inc.a[1]; }
-		__syncthreads();
-		CsFun before = cs_identity();                       // all earlier wavefronts
-		for (uint32_t w2 = 0; w2 < wave; w2++) { CsFun t; t.a[0] = sh.wave_a0[w2]; t.a[1] = sh.wave_a1[w2]; before = cs_then(before, t); }
-		CsFun excl = cs_shfl_up(inc, 1);
-		if (lane == 0) excl = cs_identity();
-		const CsFun prefix = cs_then(before, excl);
-		// replay from the true state
-		uint32_t S = S0 + prefix.a[S0 & 1u];
-		uint32_t my_stop = 0xffffffffu, my_state = 0;
-#pragma unroll
-		for (uint32_t k = 0; k < kCsPerThread; k++)
-		{
-			const uint32_t i = first + k;
-			if (i < window && my_stop == 0xffffffffu)
-			{
-				bool ok;
-				const uint32_t S1 = cs_apply(S, q[k], ok);
-				if (!ok) { my_stop = i << 1; my_state = S; }
-				else if (S1 == 0x1000000u) { my_stop = (i << 1) | 1u; my_state = S1; }
-				else S = S1;
-			}
-		}
-		if (my_stop != 0xffffffffu) atomicMin(&sh.stop, my_stop);
-		__syncthreads();
-		const uint32_t stop = sh.stop;
-		if (stop == 0xffffffffu)
-		{
-			if (tid == (window - 1u) / kCsPerThread) sh.stop_state = S;      // the thread that holds the window's last value
-			__syncthreads();
-			s = cs_value(fr, sh.stop_state);
-			pos += window;
-			poor = 0;
-		}
-		else
-		{
-			if (my_stop == stop) sh.stop_state = my_state;
-			__syncthreads();
-			const uint32_t i = stop >> 1;
-			s = cs_value(fr, sh.stop_state);
-			if (!(stop & 1u)) s = s + sh.vals[i + (i >> 4)];              // the one real addition
-			pos += i + 1u;
-			if (i + 1u < 2048u) { plain_next = true; poor++; } else poor = 0;
-		}
-		__syncthreads();                                    // sh.vals / sh.stop are rewritten by the next window
-	}
-	return s;
 }
 
 // The long chains are the critical path, and a chain that shares its SIMD with other wavefronts' chains runs at a fraction of its speed:
@@ -345,35 +226,6 @@ __global__ __launch_bounds__(192) void tet_hull_kernel2(const TetColliderView *v
 		h.w = tets ? (float)(sqrt((double)radius2) + (double)v.tolerance) : sqrtf(radius2);
 		b.hulls[node] = h;
 	}
-}
-
-// centre of the long nodes: one workgroup per (node, component); grid = 3 * number of long nodes
-__global__ __launch_bounds__(1024) void tet_big_sum_kernel(const TetColliderView *views, const uint32_t *big, uint32_t *big_r2)
-{
-	__shared__ CsShared sh;
-	const uint32_t bi = blockIdx.x / 3u, comp = blockIdx.x % 3u;
-	const uint32_t which = big[2 * bi], node = big[2 * bi + 1];
-	const TetColliderView &v = views[which >> 1];
-	const bool tets = (which & 1u) != 0;
-	const BvhView &b = tets ? v.tet_bvh : v.points;
-	const uint32_t n = (uint32_t)b.nodes[4 * node + 3];
-	const uint32_t m = n * b.per_entity;
-	const float *gc = b.soa + (size_t)comp * b.num_elements + (size_t)(uint32_t)b.nodes[4 * node + 2] * b.per_entity;
-	const float sum = chain_sum_runs(gc, m, sh);
-	if (threadIdx.x == 0)
-	{
-		const float c = tets ? sum / (4.0f * (float)n) : sum / (float)n;
-		float *h = reinterpret_cast<float *>(&b.hulls[node]);
-		h[comp] = c;
-		if (comp == 0) { h[3] = 0.0f; big_r2[bi] = 0u; }
-	}
-}
-// developer aid (pbdx_debug_chain_sum): the same procedure on any data
-__global__ __launch_bounds__(1024) void chain_sum_debug_kernel(const float *g, uint32_t m, float *out)
-{
-	__shared__ CsShared sh;
-	const float sum = chain_sum_runs(g, m, sh);
-	if (threadIdx.x == 0) out[0] = sum;
 }
 
 // radius of the long nodes.  slices: 2 words per workgroup (index into `big`, slice of kTcRadiusSlice vertices); squared distances are
