@@ -401,6 +401,33 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	for (uint32_t c = ncol; c > 0; c = prev[c]) todo.push_back({ prev[c], c });
 	std::reverse(todo.begin(), todo.end());
 
+	// ---- interior / boundary split of every tile's owned particles ------------------------------
+	// A particle is BOUNDARY if some other tile stages it (its closure reaches it) in some segment.  The owned particles of a tile are
+	// ordered interior first, boundary last (each part by particle id): in the persistent schedule, where a tile's owned particles stay in
+	// LDS from pass to pass, only the boundary part has to reach memory between passes (FusedTile::wb_begin).  Costs one more closure per
+	// (segment, tile); the order is the same for all segments.
+	std::vector<uint32_t> wb_begin(k, 0);
+	{
+		std::vector<uint8_t> boundary(n, 0);
+		for (size_t si = 0; si < todo.size(); si++)
+		{
+			const uint32_t c0 = todo[si].first, c1 = todo[si].second;
+			parallel_for(k, threads, [&](uint32_t t, uint32_t th) {
+				Scratch &s = scratch[th];
+				closure(g, s, perm.data() + tile_begin[t], tile_begin[t + 1] - tile_begin[t], c0, c1, [](uint32_t) {});
+				for (uint32_t h : s.halo) boundary[h] = 1;       // (benign race: every writer stores 1)
+			});
+		}
+		for (uint32_t t = 0; t < k; t++)
+		{
+			uint32_t *first = perm.data() + tile_begin[t], *last = perm.data() + tile_begin[t + 1];
+			uint32_t *mid = std::stable_partition(first, last, [&](uint32_t p) { return boundary[p] == 0; });      // both parts stay sorted by id
+			const uint32_t n_owned = (uint32_t)(last - first);
+			// the persistent fill re-reads the owned particles from index (n_owned & ~63) on (LDS-DMA granularity): they count as boundary
+			wb_begin[t] = std::min((uint32_t)(mid - first), n_owned & ~63u);
+		}
+	}
+
 	// ---- full build ----------------------------------------------------------------------------
 	uint64_t slots_total = 0;
 	for (size_t si = 0; si < todo.size(); si++)
@@ -509,6 +536,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 			ft.step_begin = (uint32_t)seg.steps.size();
 			ft.n_local = (uint32_t)o.gid.size();
 			ft.n_owned = o.n_owned;
+			ft.wb_begin = wb_begin[t];
 			ft.gid_off = (uint32_t)seg.gid.size();
 			ft.slots = o.slots;
 			const uint32_t idx_base = (uint32_t)seg.idx.size(), par_base = (uint32_t)seg.params.size();
@@ -825,7 +853,7 @@ void build_persistent_deps(const FusedPlan &plan, PersistentDeps &out)
 	}
 }
 
-bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, uint32_t passes, std::string &why)
+bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, uint32_t passes, std::string &why, bool keep_owned)
 {
 	const size_t nseg = plan.segs.size();
 	const uint32_t k = plan.num_tiles, n = plan.num_particles;
@@ -878,7 +906,9 @@ bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, ui
 			if (!filled[t])
 			{
 				const std::vector<int32_t> &in = ver[p & 1u];
-				for (uint32_t i = 0; i < ft.n_local; i++)
+				// keep_owned (one workgroup per tile): after its first pass a tile stages only what it does not hold already -- its halo and,
+				// for the LDS-DMA granularity, its last (n_owned mod 64) owned particles
+				for (uint32_t i = (keep_owned && p > 0) ? (ft.n_owned & ~63u) : 0u; i < ft.n_local; i++)
 				{
 					const uint32_t g = seg.gid[ft.gid_off + i];
 					if (in[g] != (int32_t)p - 1)
@@ -895,7 +925,8 @@ bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, ui
 			else
 			{
 				std::vector<int32_t> &outv = ver[(p + 1) & 1u];
-				for (uint32_t i = 0; i < ft.n_owned; i++) outv[seg.gid[ft.gid_off + i]] = (int32_t)p;
+				// ... and a pass that is not the last one writes back only its boundary particles (FusedTile::wb_begin)
+				for (uint32_t i = (keep_owned && p + 1 < passes) ? ft.wb_begin : 0u; i < ft.n_owned; i++) outv[seg.gid[ft.gid_off + i]] = (int32_t)p;
 				filled[t] = 0;
 				done[t] = p + 1;
 			}

@@ -131,14 +131,17 @@ struct FusedStep      // one (colour, type) run of a tile; 32 bytes, read with s
 	uint32_t cid_off;     // host only: into slot_cid
 };
 
-struct FusedTile      // 32 bytes
+struct FusedTile      // 36 bytes
 {
 	uint32_t step_begin, step_end;
-	uint32_t n_local;     // particles staged in LDS (owned first)
+	uint32_t n_local;     // particles staged in LDS (owned first; among the owned ones the INTERIOR first: see wb_begin)
 	uint32_t n_owned;
 	uint32_t gid_off;     // into the segment's global-id stream
 	uint32_t slots;       // constraints executed by this tile in this segment
 	uint32_t chunk_begin, chunk_end;   // filled by the engine once the workgroup size is chosen (FusedChunk list)
+	uint32_t wb_begin;    // owned particles [0, wb_begin) are INTERIOR: no other tile stages them in any segment, and this tile's own fill does not
+	                      // re-read them while its owned particles stay in LDS (persistent schedule) -- a pass that is not the last one of its launch
+	                      // writes back only [wb_begin, n_owned).  The same value in every segment (the owned order is shared by all segments).
 };
 
 // One workgroup-wide pass over (part of) a step: lanes [0, valid) project slot k*BLOCK + lane of the step.
@@ -231,7 +234,7 @@ void build_persistent_deps(const FusedPlan &plan, PersistentDeps &out);
 // one tile held back for as long as the lists allow, pseudo-random) subject only to the lists.  Every FILL must
 // find, for every particle it reads, the version written by pass p-1 (or the initial state for pass 0).
 // `passes` = iterations x segments to simulate.
-bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, uint32_t passes, std::string &why);
+bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, uint32_t passes, std::string &why, bool keep_owned = false);
 
 } // namespace pbdx
 

@@ -443,8 +443,11 @@ __device__ __forceinline__ void velocity_write_back(const FoldArgs &f, const uin
 // workgroup, same owned set in every segment): only the halo is staged.  `wait`: see TileFill.
 template <uint32_t MASK, int BLOCK, bool COHERENT, class Wait>
 __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &ra, const float4 *pos_in, float4 *pos_out, uint32_t tile_index,
-	unsigned long long *trace, uint4 *lchunks, float4 *lpos, bool keep_owned, const Wait &wait, const FoldArgs *fold = nullptr, uint32_t fold_phase = 0)
+	unsigned long long *trace, uint4 *lchunks, float4 *lpos, bool keep_owned, const Wait &wait, const FoldArgs *fold = nullptr, uint32_t fold_phase = 0,
+	bool boundary_only = false)
 {
+	// boundary_only (persistent schedule, one workgroup per tile, not the last pass of the launch): the owned particles stay in LDS for the next
+	// pass, so only the ones another tile stages -- [wb_begin, n_owned): the planner orders the interior first -- have to reach memory
 	// fold_phase (persistent schedule only): bit 0 = this pass integrates while it stages, bit 1 = it updates the velocities
 	const FusedTile t = sg.tiles[tile_index];
 	if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
@@ -493,7 +496,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	{
 		constexpr uint32_t kWbBatch = 4;
 		const uint32_t last = t.n_owned - 1u;
-		for (uint32_t base = threadIdx.x; base < t.n_owned; base += kWbBatch * BLOCK)
+		for (uint32_t base = (boundary_only ? t.wb_begin : 0u) + threadIdx.x; base < t.n_owned; base += kWbBatch * BLOCK)
 		{
 			uint32_t g[kWbBatch];
 #pragma unroll
@@ -534,6 +537,9 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 // Residency: gridDim <= number of CUs and one workgroup per CU; HIP guarantees neither, so every wait is bounded
 // (PersistArgs::spin_limit) and a timeout raises `*error` instead of hanging -- the host then restores the state it
 // saved at the start of the call and repeats the call with schedule (A).
+#ifndef PBDX_FULL_WRITE_BACK
+#define PBDX_FULL_WRITE_BACK 0       // 1: every pass writes back all owned particles (A/B builds)
+#endif
 constexpr uint32_t kMaxPersistSegs = 8;
 constexpr unsigned long long kTicksPerMs = 100000ull;           // the wall clock runs at 100 MHz
 constexpr unsigned long long kArriveLimitTicks = 100000ull;     // 1 ms: all workgroups of a launch must have started by then
@@ -633,7 +639,9 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 			unsigned long long *trace = (a.trace[sgi] && pass + a.num_segs >= a.passes) ? a.trace[sgi] + (size_t)tile * kTraceStride : nullptr;
 			// one tile per workgroup: its owned particles stay in LDS from pass to pass
 			const uint32_t fold_phase = a.folded ? ((pass == 0 ? 1u : 0u) | (pass + 1u == a.passes ? 2u : 0u)) : 0u;
-			process_tile<MASK, BLOCK, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && gridDim.x == a.num_tiles, wait, &a.fold, fold_phase);
+			const bool resident = gridDim.x == a.num_tiles;
+			process_tile<MASK, BLOCK, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && resident, wait, &a.fold, fold_phase,
+				resident && pass + 1u != a.passes && !PBDX_FULL_WRITE_BACK);
 			if (s_failed)
 			{
 				// a neighbour never arrived: the state of this step is garbage.  Say so, turn every later kernel of the call

@@ -220,6 +220,21 @@ int pbdx_model_plan_check(pbdx_model *m, uint32_t tile_particles, uint32_t lds_p
 			}
 		if (removed && check_persistent_deps(plan, broken, passes, why))
 		{ set_error("plan check: the asynchronous-execution check accepted dependency lists with a missing entry"); return PBDX_ERR_INVALID; }
+		// the same with one workgroup per tile: owned particles stay in LDS, a pass that is not the last writes back only its boundary particles
+		// (FusedTile::wb_begin) -- and the check of THAT check: a tile that keeps a particle to itself which a neighbour stages must be caught
+		if (!check_persistent_deps(plan, deps, passes, why, true)) { set_error("plan check (owned particles resident): %s", why.c_str()); return PBDX_ERR_INVALID; }
+		for (uint32_t t = 0; t < plan.num_tiles; t++)
+		{
+			const FusedTile &ft0 = plan.segs[0].tiles[t];
+			const uint32_t all = ft0.n_owned & ~63u;
+			if (ft0.wb_begin >= all) continue;                     // nothing more to withhold in this tile
+			std::vector<uint32_t> keep(plan.segs.size());
+			for (size_t si = 0; si < plan.segs.size(); si++) { keep[si] = plan.segs[si].tiles[t].wb_begin; plan.segs[si].tiles[t].wb_begin = all; }
+			const bool accepted = check_persistent_deps(plan, deps, passes, why, true);
+			for (size_t si = 0; si < plan.segs.size(); si++) plan.segs[si].tiles[t].wb_begin = keep[si];
+			if (accepted && plan.num_tiles > 1) { set_error("plan check: a tile that writes back none of its boundary particles went unnoticed"); return PBDX_ERR_INVALID; }
+			break;
+		}
 	}
 	if (out)
 	{
