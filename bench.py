@@ -552,10 +552,10 @@ def run_c5(ens, sub_steps, with_reference=True):
         for _ in range(int(steps) - done):
             ts.stepResident(model, 1)
             floor += sol.num_contacts()
+            tet_max = max(tet_max, sol.num_tet_contacts())
         done = int(steps)
         ts.syncToHost(model)
         got, want = sol.tet_contacts(), g["contacts_sub%d_%d" % (sub_steps, steps)]
-        tet_max = max(tet_max, len(got))
         x, v = model.getParticles().positions(), model.getParticles().velocities()
         same = same and len(got) == len(want) and (not len(want) or np.array_equal(got[:, :26].view(np.uint32), want.view(np.uint32)))
         same = same and np.array_equal(x.view(np.uint32), g["x_sub%d_%d" % (sub_steps, steps)].view(np.uint32)) and np.array_equal(v.view(np.uint32), g["v_sub%d_%d" % (sub_steps, steps)].view(np.uint32))

@@ -706,6 +706,12 @@ class Solver:
         check(lib.pbdx_solver_get_num_contacts(self._h, C.byref(n)), "get_num_contacts")
         return n.value
 
+    def num_tet_contacts(self):
+        """number of contacts between deformable solids found by the last detection"""
+        c = (C.c_uint32 * 8)()
+        check(lib.pbdx_debug_tet_counters(self._h, c), "tet_counters")
+        return int(c[0])
+
     def tet_impulses(self):
         """(contacts of the last detection that carried a velocity impulse, total since the colliders were set)"""
         last, total = C.c_uint32(), C.c_uint64()
