@@ -660,7 +660,10 @@ def test_persistent_schedule_is_bit_identical_and_recovers_from_a_refused_launch
               ("pbd cloth, second-order velocities", util.cloth_spec(40, 40, 1, 2), 5, 1, 4, {"vel_method": 1}),
               ("kitchen sink", util.kitchen_sink_spec(), 4, 2, 4, {}),
               ("fem bar", util.bar_spec(30, 6, 6, 2), 4, 1, 5, {}),
-              ("xpbd cloth 120x120, 60-particle tiles (more tiles than CUs)", util.cloth_spec(120, 120, 4, 3), 3, 1, 4, {"opts": {S.OPT_TILE_PARTICLES: 48}})]
+              ("xpbd cloth 120x120, 60-particle tiles (more tiles than CUs)", util.cloth_spec(120, 120, 4, 3), 3, 1, 4, {"opts": {S.OPT_TILE_PARTICLES: 48}}),
+              # two tiles resident per CU: every tile still has a workgroup of its own, so owned particles stay in LDS and the passes between the
+              # first and the last write back only their boundary particles (FusedTile::wb_begin) -- as in the default one-tile-per-CU scenes above
+              ("xpbd cloth 120x120, 40-particle tiles, two resident per CU", util.cloth_spec(120, 120, 4, 3), 3, 1, 4, {"opts": {S.OPT_TILE_PARTICLES: 40, S.OPT_PERSISTENT_WGS_PER_CU: 2}})]
     # both parities of the number of passes per substep (iterations x segments) must be covered: with an odd number the
     # folded launch ends in the other position buffer and the two buffers change roles from substep to substep
     scenes += [("xpbd cloth 70x70, 5 iterations", util.cloth_spec(70, 70, 4, 3), 5, 3, 5, {}),
