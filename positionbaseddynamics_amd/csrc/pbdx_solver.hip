@@ -223,6 +223,9 @@ __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0
 // (7 x 2 serialised latencies for a 7 000-particle tile).  The loads are issued in batches instead: the chunk
 // descriptor, then kFillBatch particle ids, then their kFillBatch positions -- two exposed latencies per batch,
 // one batch for most tiles.
+#ifndef PBDX_DEFER_FILL_WAIT
+#define PBDX_DEFER_FILL_WAIT 1       // 0: the fill waits for its copies itself (A/B builds)
+#endif
 constexpr uint32_t kMaxTileChunks = 256;
 template <int BLOCK, bool COHERENT> struct TileFill
 {
@@ -263,15 +266,31 @@ template <int BLOCK, bool COHERENT> struct TileFill
 #undef PBDX_G
 #undef PBDX_D
 		if (threadIdx.x < num_chunks) lchunks[threadIdx.x] = chv;
+#if PBDX_DEFER_FILL_WAIT
+		// The positions are still in flight (HBM -> LDS copies).  Only the chunk descriptors have to be visible now: the first run of the sweep
+		// issues its record prefetches (which read the descriptors, not the positions) and THEN waits for the copies (fill_wait below), so that
+		// the first colour step of a pass does not pay the copies' latency and the prefetch ring's start-up latency one after the other.
+		__syncthreads();
+#else
 		lds_dma_wait();
 		__syncthreads();
 		if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
+#endif
 	}
 };
+// second half of a fill whose wait was deferred: all HBM -> LDS copies of this workgroup have landed
+__device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *trace)
+{
+	if (!pending) return;
+	lds_dma_wait();
+	__syncthreads();
+	if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
+	pending = false;
+}
 
 template <int TYPE, bool COMPACT, int BLOCK, bool COHERENT>
 __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStreams &str, const uint4 *lchunks, uint32_t c0,
-	float4 *lpos, unsigned long long *trace, uint32_t &step_counter)
+	float4 *lpos, unsigned long long *trace, uint32_t &step_counter, bool &fill_pending)
 {
 	constexpr int D = Depth<TYPE>::value;
 	typedef TileAccess<TYPE, COMPACT, COHERENT> Acc;
@@ -299,6 +318,7 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 	};
 	fetch(r0); fetch(r1);
 	if constexpr (D == 4) { fetch(r2); fetch(r3); }
+	fill_wait(fill_pending, trace);      // (first run of a pass: the positions land while the ring's first records are on their way)
 	// Every sub-iteration issues exactly one record fetch, whether or not a projection still happens in it
 	// (single loop exit at the bottom): the number of memory operations between a fetch and its use is then
 	// the same on every path.
@@ -337,8 +357,8 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 }
 
 #define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) { \
-		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter) \
-		                        : run_typed<T, false, BLOCK, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter); } \
+		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending) \
+		                        : run_typed<T, false, BLOCK, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending); } \
 	else { c = num_chunks; } break;
 
 // LDS: [ chunk descriptors of the tile: kMaxTileChunks x 16 B ][ positions: n_local x float4 ]
@@ -415,26 +435,44 @@ __device__ __forceinline__ void velocity_write_back(const FoldArgs &f, const uin
 	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(f.vel, 0, f.state_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(f.old, 0, f.state_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(f.last, 0, f.state_bytes, 0x00020000);
-	for (uint32_t i = threadIdx.x; i < n_owned; i += BLOCK)
+	// four particles per thread and batch: ids, then all state loads, then the arithmetic -- two exposed memory latencies per batch instead of
+	// two per particle (a tile's ~3 900 owned particles are one batch for a 1 024-thread workgroup)
+	constexpr uint32_t kBatch = 4;
+	const uint32_t last_i = n_owned - 1u;
+	for (uint32_t base = threadIdx.x; base < n_owned; base += kBatch * BLOCK)
 	{
-		const uint32_t g = gid[i];
-		const float4 p = lpos[i];
-		float4 v = load_f4_sc1(rv, g);
-		const float4 o = load_f4_sc1(ro, g);
-		store_pos<true>(pos_out, g, p);
-		if (v.w == 0.0f) continue;
-		if (!f.second_order)
+		uint32_t g[kBatch];
+		float4 v[kBatch], o[kBatch], l[kBatch];
+#pragma unroll
+		for (uint32_t k = 0; k < kBatch; k++) { const uint32_t i = base + k * BLOCK; g[k] = gid[i < last_i ? i : last_i]; }
+#pragma unroll
+		for (uint32_t k = 0; k < kBatch; k++)
 		{
-			v.x = f.inv_h * (p.x - o.x); v.y = f.inv_h * (p.y - o.y); v.z = f.inv_h * (p.z - o.z);
+			v[k] = load_f4_sc1(rv, g[k]);
+			o[k] = load_f4_sc1(ro, g[k]);
+			if (f.second_order) l[k] = load_f4_sc1(rl, g[k]);
 		}
-		else
+#pragma unroll
+		for (uint32_t k = 0; k < kBatch; k++)
 		{
-			const float4 l = load_f4_sc1(rl, g);
-			v.x = f.inv_h * (1.5f * p.x - 2.0f * o.x + 0.5f * l.x);
-			v.y = f.inv_h * (1.5f * p.y - 2.0f * o.y + 0.5f * l.y);
-			v.z = f.inv_h * (1.5f * p.z - 2.0f * o.z + 0.5f * l.z);
+			const uint32_t i = base + k * BLOCK;
+			if (i >= n_owned) continue;
+			const float4 p = lpos[i];
+			store_pos<true>(pos_out, g[k], p);
+			float4 w = v[k];
+			if (w.w == 0.0f) continue;
+			if (!f.second_order)
+			{
+				w.x = f.inv_h * (p.x - o[k].x); w.y = f.inv_h * (p.y - o[k].y); w.z = f.inv_h * (p.z - o[k].z);
+			}
+			else
+			{
+				w.x = f.inv_h * (1.5f * p.x - 2.0f * o[k].x + 0.5f * l[k].x);
+				w.y = f.inv_h * (1.5f * p.y - 2.0f * o[k].y + 0.5f * l[k].y);
+				w.z = f.inv_h * (1.5f * p.z - 2.0f * o[k].z + 0.5f * l[k].z);
+			}
+			f.vel[g[k]] = w;
 		}
-		f.vel[g] = v;
 	}
 }
 
@@ -469,6 +507,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			staged = true;
 		}
 	if (!staged) fill(wait);
+	bool fill_pending = PBDX_DEFER_FILL_WAIT != 0 && !staged;
 	// chunks are addressed relative to the tile from here on (they sit at lchunks[0 .. num_chunks))
 	uint32_t c = 0, step_counter = 0;
 	while (c < num_chunks)
@@ -484,6 +523,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 		default: c = num_chunks; break;
 		}
 	}
+	fill_wait(fill_pending, trace);          // (a tile without work in this segment, or whose first chunk has an unknown type)
 	bool written = false;
 	if constexpr (COHERENT)
 		if (fold_phase & 2u)
