@@ -223,8 +223,12 @@ __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0
 // (7 x 2 serialised latencies for a 7 000-particle tile).  The loads are issued in batches instead: the chunk
 // descriptor, then kFillBatch particle ids, then their kFillBatch positions -- two exposed latencies per batch,
 // one batch for most tiles.
+// PBDX_DEFER_FILL_WAIT = 1 (A/B builds): the fill returns once the chunk descriptors are visible and the wait for its HBM -> LDS copies moves
+// behind the first run's ring priming (fill_wait).  Bit-identical (144 GPU tests) and measured SLOWER on the 1 M cloth: the first colour step
+// of a pass drops from 3.2-3.8 to 2.2 us, but the fill itself grows from 3.5 to 4.4-5.6 us (the record fetches queue in front of the copies'
+// completion) and a barrier is added: 0.777-0.787 against 0.759-0.768 ms per substep (profiles/r03k_deferred_fill_wait_ab.log).  Off.
 #ifndef PBDX_DEFER_FILL_WAIT
-#define PBDX_DEFER_FILL_WAIT 1       // 0: the fill waits for its copies itself (A/B builds)
+#define PBDX_DEFER_FILL_WAIT 0
 #endif
 constexpr uint32_t kMaxTileChunks = 256;
 template <int BLOCK, bool COHERENT> struct TileFill
