@@ -33,7 +33,9 @@ __device__ __forceinline__ float sel3(uint32_t c, float a0, float a1, float a2) 
 // lane 3 doubles lane 0), and -- full layout only -- Young's modulus and Poisson ratio
 template <int TYPE, bool COMPACT> struct RecQ
 {
-	uint32_t w[COMPACT ? 10 : 12];
+	// FEM tets: indices (2), multiplier, rest volume, column and row of Dm^-1 (3 + 3) [+ Young's modulus, Poisson ratio]
+	// strain tets: indices (2), unused, Dm^-1 (9) [+ two stiffnesses, two flags]
+	uint32_t w[TYPE == PBDX_STRAIN_TET ? (COMPACT ? 12 : 16) : (COMPACT ? 10 : 12)];
 };
 struct QuadLane
 {
@@ -57,6 +59,13 @@ __device__ __forceinline__ void load_rec_quad(const A &a, const QuadLane &l, uin
 	const uint2 v = a.idx_raw2(slot);
 	r.w[0] = v.x; r.w[1] = v.y;
 	r.w[2] = 0u;
+	if constexpr (TYPE == PBDX_STRAIN_TET)
+	{
+		// every lane needs all of Dm^-1 (the six sub-projections use every column); parameter k = plane k in both layouts (k < 9)
+#pragma unroll
+		for (uint32_t k = 0; k < (COMPACT ? 9u : 13u); k++) r.w[3 + k] = a.par_raw(a.v_par + k * 256u);
+		return;
+	}
 	if constexpr (kHasLambda[TYPE]) r.w[2] = __builtin_bit_cast(uint32_t, a.lam_load(slot));
 	r.w[3] = a.par_raw(a.v_par);
 #pragma unroll
@@ -133,10 +142,93 @@ __device__ __forceinline__ void quad_inversion_branch(uint32_t c, V3 x1, V3 x2, 
 	sigma_c = mk(sel3(c, sigma.m[0][0], sigma.m[0][1], sigma.m[0][2]), sel3(c, sigma.m[1][0], sigma.m[1][1], sigma.m[1][2]), sel3(c, sigma.m[2][0], sigma.m[2][1], sigma.m[2][2]));
 }
 
+// ---- StrainTetConstraint (PositionBasedDynamics.cpp:713-805): lane q of the quad owns particle q -------------------------------------------
+// Each of the six sub-projections (i, j), j <= i, is: P = [x1 - x0 | x2 - x0 | x3 - x0] at the CURRENT corrections, f_i = P c_i, f_j = P c_j,
+// S = f_i . f_j, the gradients d_1..3 (one per lane 1..3), d_0 = 0 - d_1 - d_2 - d_3 (lane 0), lambda from sum_q w_q |d_q|^2, corr_q -= lambda w_q d_q.
+// Per lane: its particle's position + correction, its gradient, its correction; exchanged: x0 + corr0 (from lane 0), the three columns of P
+// (from lanes 1..3), the gradients for d_0, the four terms of the denominator.  f_i, f_j, S and the division are repeated on every lane.
+template <bool COMPACT, class A>
+__device__ __forceinline__ void exec_rec_quad_strain(const A &a, const QuadLane &l, const RecQ<PBDX_STRAIN_TET, COMPACT> &r, uint32_t slot)
+{
+	const uint32_t q = l.q;
+	const uint32_t idw = q < 2u ? r.w[0] : r.w[1];
+	const uint32_t my_id = (q & 1u) ? (idw >> 16) : (idw & 0xffffu);
+	V3 my_p; float my_w;
+	ldp(a, my_id, my_p, my_w);
+	M3 im;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int rr = 0; rr < 3; rr++) im.m[rr][c] = __builtin_bit_cast(float, r.w[3 + c * 3 + rr]);
+	float stretchStiffness, shearStiffness; bool normalizeStretch, normalizeShear;
+	if constexpr (COMPACT) { stretchStiffness = a.view.u[9]; shearStiffness = a.view.u[10]; normalizeStretch = a.view.u[11] != 0.0f; normalizeShear = a.view.u[12] != 0.0f; }
+	else
+	{
+		stretchStiffness = __builtin_bit_cast(float, r.w[12]); shearStiffness = __builtin_bit_cast(float, r.w[13]);
+		normalizeStretch = __builtin_bit_cast(float, r.w[14]) != 0.0f; normalizeShear = __builtin_bit_cast(float, r.w[15]) != 0.0f;
+	}
+	const uint32_t k = q == 0u ? 0u : q - 1u;          // lanes 1..3 own gradient d_{k+1} and column k of P (lane 0's copies are not used)
+	V3 corr = mk(0.0f, 0.0f, 0.0f);
+	V3 cc[3];
+	cc[0] = get_col(im, 0); cc[1] = get_col(im, 1); cc[2] = get_col(im, 2);
+#pragma unroll
+	for (int i = 0; i < 3; i++)
+	{
+#pragma unroll
+		for (int j = 0; j <= i; j++)
+		{
+			const V3 xq = my_p + corr;                       // (p_q + corr_q)
+			const V3 x0 = qb3<0>(xq);
+			const V3 col = xq - x0;                          // lanes 1..3: column q-1 of P
+			const V3 P0 = qb3<1>(col), P1 = qb3<2>(col), P2 = qb3<3>(col);
+			// mul(P, c): row r = P(r,0) c.x + (P(r,1) c.y + P(r,2) c.z)
+			const V3 fi = mk(P0.x * cc[i].x + (P1.x * cc[i].y + P2.x * cc[i].z), P0.y * cc[i].x + (P1.y * cc[i].y + P2.y * cc[i].z), P0.z * cc[i].x + (P1.z * cc[i].y + P2.z * cc[i].z));
+			const V3 fj = mk(P0.x * cc[j].x + (P1.x * cc[j].y + P2.x * cc[j].z), P0.y * cc[j].x + (P1.y * cc[j].y + P2.y * cc[j].z), P0.z * cc[j].x + (P1.z * cc[j].y + P2.z * cc[j].z));
+			float Sij = dot(fi, fj);
+			float wi = 0.0f, wj = 0.0f, s1 = 0.0f, s3 = 0.0f;
+			const bool ns = normalizeShear && i != j;
+			if (ns)
+			{
+				wi = norm(fi);
+				wj = norm(fj);
+				s1 = 1.0f / (wi * wj);
+				s3 = s1 * s1 * s1;
+			}
+			// this lane's gradient d_{k+1} = fj im(k,i) + fi im(k,j)
+			const float imki = sel3(k, im.m[0][i], im.m[1][i], im.m[2][i]), imkj = sel3(k, im.m[0][j], im.m[1][j], im.m[2][j]);
+			V3 d = fj * imki + fi * imkj;
+			if (ns)
+				d = s1 * d - (Sij * s3) * (((wj * wj) * fi) * imki + ((wi * wi) * fj) * imkj);
+			const V3 d1 = qb3<1>(d), d2 = qb3<2>(d), d3 = qb3<3>(d);
+			V3 d0 = mk(0.0f, 0.0f, 0.0f);
+			d0 = d0 - d1; d0 = d0 - d2; d0 = d0 - d3;
+			if (q == 0u) d = d0;
+			if (ns)
+				Sij *= s1;
+			const float t = my_w * sqn(d);
+			float lambda = qb<0>(t) + qb<1>(t) + qb<2>(t) + qb<3>(t);
+			if (fabsf(lambda) < PBDX_EPS)
+				continue;
+			if (i == j)
+			{
+				if (normalizeStretch) { const float s = sqrtf(Sij); lambda = 2.0f * s * (s - 1.0f) / lambda * stretchStiffness; }
+				else lambda = (Sij - 1.0f) / lambda * stretchStiffness;
+			}
+			else
+				lambda = Sij / lambda * shearStiffness;
+			corr = corr - (lambda * my_w) * d;
+		}
+	}
+	if (my_w != 0.0f)
+		a.st(my_id, make_float4(my_p.x + corr.x, my_p.y + corr.y, my_p.z + corr.z, my_w));
+}
+
 template <int TYPE, bool COMPACT, class A>
 __device__ __forceinline__ void exec_rec_quad(const A &a, const QuadLane &l, const RecQ<TYPE, COMPACT> &r, uint32_t slot, float dt, int first_iter)
 {
-	static_assert(TYPE == PBDX_FEM_TET || TYPE == PBDX_FEM_TET_XPBD, "quad-lane projection: FEM tets");
+	if constexpr (TYPE == PBDX_STRAIN_TET) { exec_rec_quad_strain<COMPACT>(a, l, r, slot); return; }
+	else {
+	static_assert(TYPE == PBDX_FEM_TET || TYPE == PBDX_FEM_TET_XPBD || TYPE == PBDX_STRAIN_TET, "quad-lane projection: FEM tets, strain tets");
 	const uint32_t id[4] = { r.w[0] & 0xffffu, r.w[0] >> 16, r.w[1] & 0xffffu, r.w[1] >> 16 };
 	V3 p0, p1, p2, p3; float w0, w1, w2, w3;
 	ldp(a, id[0], p0, w0); ldp(a, id[1], p1, w1); ldp(a, id[2], p2, w2); ldp(a, id[3], p3, w3);
@@ -213,6 +305,7 @@ __device__ __forceinline__ void exec_rec_quad(const A &a, const QuadLane &l, con
 		a.st(my_id, make_float4(my_p.x + corr.x, my_p.y + corr.y, my_p.z + corr.z, my_w));
 	if constexpr (kHasLambda[TYPE])
 		if (q == 0u) a.lam_store(slot, multiplier);
+	}
 }
 
 } // namespace pbdx
