@@ -73,17 +73,21 @@ constexpr uint32_t kCompactScalars[13] = {
 };
 constexpr int kParamCount[13] = { 2, 2, 2, 17, 17, 10, 9, 2, 2, 12, 12, 13, 24 };
 
-// Types whose projection is / can be spread over the four lanes of a quad in the fused tile kernels (pbdx_quad.h): a workgroup-wide chunk of
-// such a step then holds BLOCK / 4 slots.
-//  * StrainTetConstraint (PBDX_QUAD_STRAIN, default ON): six sequential sub-projections whose work is per PARTICLE (gradient, correction), so a
-//    lane per particle carries little redundant work: ~120 instructions per sub-projection and lane against ~250 for one lane per constraint.
+// Projections spread over the four lanes of a quad in the fused tile kernels (pbdx_quad.h); a workgroup-wide chunk in that form holds
+// BLOCK / 4 slots.
+//  * StrainTetConstraint, PER STEP (PBDX_QUAD_STRAIN, default ON): six sequential sub-projections whose work is per PARTICLE (gradient,
+//    correction), so a lane per particle carries little redundant work.  Measured (profiles/r03m_*, r03n_*): a colour step of a tile in quad form
+//    takes 1.68 us per chunk of BLOCK / 4 slots against ~2.8 us for the one-lane-per-constraint chain whatever its slot count (<= BLOCK): a win
+//    exactly for the steps that fit ONE quad chunk, a loss for larger ones (quad form for every step: 1.55 vs 1.16 ms on the bar).  So the
+//    engine picks per step when it expands a plan into chunks: steps with 4 * slots <= BLOCK become one chunk of pseudo-type kQuadStrainChunk,
+//    the others stay in the one-lane form; both forms are instantiated in the kernel.
 //  * FEMTetConstraint / XPBD_FEMTetConstraint (PBDX_QUAD_FEM, default OFF: an opt-in BUILD, _lib/libpbdx_quad.so, built and GPU-tested next to the
-//    product): bit-identical, but measured SLOWER on MI355X -- the 100 k-tet bar 0.878 ms vs 0.638 ms per substep, 32 bars 1.76 vs 1.01
-//    (profiles/r03e_quad_lanes_ab.log).  A lane of the quad still executes ~450 instructions (the per-slot preamble -- volumes, two divisions --
-//    the lane selects and the DPP exchanges eat what the column split saves of the ~390-instruction scalar chain) and four times as many lanes
-//    execute them, while a colour step of the bar already fills two wavefronts per tile.
+//    product; every step in quad form): bit-identical, but measured SLOWER on MI355X -- the 100 k-tet bar 0.878 ms vs 0.638 ms per substep, 32 bars
+//    1.76 vs 1.01 (profiles/r03e_quad_lanes_ab.log).  A lane of the quad still executes ~450 instructions (the per-slot preamble -- volumes, two
+//    divisions -- the lane selects and the DPP exchanges eat what the column split saves of the ~390-instruction scalar chain), so even a
+//    single quad chunk (1.6 us) loses to the scalar step (1.0 us).
 #ifndef PBDX_QUAD_LANES
-#define PBDX_QUAD_LANES 0            // 1: every type below (the opt-in build)
+#define PBDX_QUAD_LANES 0            // 1: the opt-in build (FEM tets in quad form)
 #endif
 #ifndef PBDX_QUAD_FEM
 #define PBDX_QUAD_FEM PBDX_QUAD_LANES
@@ -91,7 +95,9 @@ constexpr int kParamCount[13] = { 2, 2, 2, 17, 17, 10, 9, 2, 2, 12, 12, 13, 24 }
 #ifndef PBDX_QUAD_STRAIN
 #define PBDX_QUAD_STRAIN 1
 #endif
-constexpr bool is_quad_type(int type) { return (PBDX_QUAD_FEM != 0 && (type == 9 || type == 10)) || (PBDX_QUAD_STRAIN != 0 && type == 11); }      // FEM_TET, FEM_TET_XPBD, STRAIN_TET
+constexpr bool is_quad_type(int type) { return PBDX_QUAD_FEM != 0 && (type == 9 || type == 10); }      // every step of FEM_TET / FEM_TET_XPBD in quad form
+constexpr uint32_t kQuadStrainChunk = 13;    // chunk pseudo-type: a StrainTetConstraint step in quad form (chunk type field: 6 bits, real types 0..12)
+constexpr bool quad_strain_step(int type, uint32_t slots, uint32_t block) { return PBDX_QUAD_STRAIN != 0 && type == 11 && slots * 4u <= block; }
 
 constexpr bool is_bending_type(int type) { return type == 3 || type == 4; }
 // Q(r,c) is parameter 1 + c*4 + r; the strictly lower triangle (r > c) is mirrored, not streamed

@@ -292,14 +292,14 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 	pending = false;
 }
 
-template <int TYPE, bool COMPACT, int BLOCK, bool COHERENT>
+template <int TYPE, bool COMPACT, int BLOCK, bool COHERENT, bool QUAD_STEP = false>
 __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStreams &str, const uint4 *lchunks, uint32_t c0,
 	float4 *lpos, unsigned long long *trace, uint32_t &step_counter, bool &fill_pending)
 {
 	constexpr int D = Depth<TYPE>::value;
 	typedef TileAccess<TYPE, COMPACT, COHERENT> Acc;
 	// quad-lane types (pbdx_quad.h): four lanes share a slot, a chunk holds BLOCK / 4 slots
-	constexpr bool QUAD = is_quad_type(TYPE);
+	constexpr bool QUAD = QUAD_STEP || is_quad_type(TYPE);
 	typedef typename std::conditional<QUAD, RecQ<TYPE, COMPACT>, Rec<TYPE, COMPACT>>::type RecT;
 	// per-lane constants of the run
 	const uint32_t lane_slot = QUAD ? threadIdx.x >> 2 : threadIdx.x;
@@ -363,6 +363,11 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 #define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) { \
 		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending) \
 		                        : run_typed<T, false, BLOCK, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending); } \
+	else { c = num_chunks; } break;
+// a run of StrainTetConstraint steps in quad form (chunk pseudo-type kQuadStrainChunk)
+#define PBDX_CASE_QUAD_STRAIN case kQuadStrainChunk: if constexpr (((MASK >> PBDX_STRAIN_TET) & 1u) && PBDX_QUAD_STRAIN) { \
+		c = ra.views[PBDX_STRAIN_TET].compact ? run_typed<PBDX_STRAIN_TET, true, BLOCK, COHERENT, true>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending) \
+		                                      : run_typed<PBDX_STRAIN_TET, false, BLOCK, COHERENT, true>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending); } \
 	else { c = num_chunks; } break;
 
 // LDS: [ chunk descriptors of the tile: kMaxTileChunks x 16 B ][ positions: n_local x float4 ]
@@ -524,6 +529,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			PBDX_CASE(PBDX_VOLUME) PBDX_CASE(PBDX_VOLUME_XPBD)
 			PBDX_CASE(PBDX_FEM_TET) PBDX_CASE(PBDX_FEM_TET_XPBD) PBDX_CASE(PBDX_STRAIN_TET)
 			PBDX_CASE(PBDX_SHAPE_MATCHING)
+			PBDX_CASE_QUAD_STRAIN
 		default: c = num_chunks; break;
 		}
 	}
@@ -1458,7 +1464,8 @@ int ensure_plan(pbdx_solver *s)
 				const uint32_t nplanes = (uint32_t)num_planes((int)st.type, s->plan.views[st.type].compact != 0);
 				const uint32_t slot_idx_bytes = ti->num_bodies == 2 ? 4u : 8u;
 				// slots per workgroup-wide chunk: one per lane, or one per QUAD of lanes (pbdx_quad.h; a multiple of 64: the parameter planes are wave-tiled)
-				const uint32_t cap = is_quad_type((int)st.type) ? (uint32_t)block / 4u : (uint32_t)block;
+				const bool quad_step = quad_strain_step((int)st.type, st.count, (uint32_t)block);      // this step in quad form (one chunk)
+				const uint32_t cap = (quad_step || is_quad_type((int)st.type)) ? (uint32_t)block / 4u : (uint32_t)block;
 				const uint32_t nchunks = (st.count + cap - 1) / cap;
 				for (uint32_t k = 0; k < nchunks; k++)
 				{
@@ -1466,7 +1473,7 @@ int ensure_plan(pbdx_solver *s)
 					const uint32_t valid = std::min<uint32_t>(cap, st.count - first);
 					const bool last = (k + 1 == nchunks);
 					FusedChunk c;
-					c.info = st.type | ((last && st.barrier) ? 0x40u : 0u) | (last ? 0x80u : 0u) | (valid << 8);
+					c.info = (quad_step ? kQuadStrainChunk : st.type) | ((last && st.barrier) ? 0x40u : 0u) | (last ? 0x80u : 0u) | (valid << 8);
 					c.idx_boff = st.idx_off * 2u + first * slot_idx_bytes;
 					c.par_boff = (st.par_off + (first / 64u) * nplanes * 64u) * 4u;
 					c.lam_boff = (st.lam_off + first) * 4u;

@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 3, GPU pass m: quad-lane STRAIN tet projection (lane = particle) -- suite + A/B against one lane per constraint
+# round 3, GPU pass m/n: quad-lane STRAIN tet projection (lane = particle; n: per step, only where a step fits one quad chunk) -- suite + A/B
 set -u
-O=$PWD/gpurun_out/r03m; mkdir -p $O
+O=$PWD/gpurun_out/r03n; mkdir -p $O
 export TMPDIR=/tmp
 timeout 2000 python -m pytest tests -m gpu -q -s -x > $O/pytest.log 2>&1; echo "pytest rc=$?" > $O/rc.txt
 run() {
