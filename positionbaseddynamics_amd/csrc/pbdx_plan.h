@@ -77,7 +77,7 @@ constexpr int kParamCount[13] = { 2, 2, 2, 17, 17, 10, 9, 2, 2, 12, 12, 13, 24 }
 // BLOCK / 4 slots.
 //  * StrainTetConstraint, PER STEP (PBDX_QUAD_STRAIN, default ON): six sequential sub-projections whose work is per PARTICLE (gradient,
 //    correction), so a lane per particle carries little redundant work.  Measured (profiles/r03m_*, r03n_*): a colour step of a tile in quad form
-//    takes 1.68 us per chunk of BLOCK / 4 slots against ~2.8 us for the one-lane-per-constraint chain whatever its slot count (<= BLOCK): a win
+//    takes 1.7 us per chunk of BLOCK / 4 slots against 2.4-2.7 us for the one-lane-per-constraint chain whatever its slot count (<= BLOCK): a win
 //    exactly for the steps that fit ONE quad chunk, a loss for larger ones (quad form for every step: 1.55 vs 1.16 ms on the bar).  So the
 //    engine picks per step when it expands a plan into chunks: steps with 4 * slots <= BLOCK become one chunk of pseudo-type kQuadStrainChunk,
 //    the others stay in the one-lane form; both forms are instantiated in the kernel.
