@@ -70,14 +70,17 @@ struct TileStreams
 // COHERENT (persistent schedule): the multiplier stream is re-read by the same workgroup one iteration later
 // INSIDE one launch; the CU's vector L1 may still hold the line from before the store (no kernel boundary
 // invalidates it), so those loads go past the L1 (sc1: served by the XCD's L2, which does see the CU's own stores).
-template <int TYPE, bool COMPACT, bool COHERENT = false> struct TileAccess
+// VEC: form of the parameter stream (pbdx_plan.h param_float_index)
+template <int TYPE, bool COMPACT, bool COHERENT = false, bool VEC = false> struct TileAccess
 {
 	float4 *pos;               // LDS
 	const TileStreams &str;
 	uint32_t idx_soff;         // BYTE offsets of the current chunk inside the streams (SGPRs)
 	uint32_t par_soff;
 	uint32_t lam_soff;
-	uint32_t v_par;            // per-lane byte offset inside a chunk's parameter block: wave * nplanes * 256 + lane * 4
+	uint32_t v_par;            // per-lane byte offsets inside a chunk's parameter block (pbdx_plan.h param_float_index): the lane's dword of plane 0, or
+	                           // (VEC) its 16 bytes of segment 0
+	uint32_t v_tail;           // (VEC) ... and its np % 4 floats of the tail segment
 	const TypeView &view;
 
 	// `i` = lane's slot inside the chunk (threadIdx.x): the per-lane offsets are the same for every chunk
@@ -104,8 +107,42 @@ template <int TYPE, bool COMPACT, bool COHERENT = false> struct TileAccess
 	{
 		if (is_scalar_param(TYPE, COMPACT, k)) return view.u[k];
 		const uint32_t plane = (uint32_t)kPlanes.plane[COMPACT ? 1 : 0][TYPE][k];
-		// plane * 256 is a compile-time constant: folded into the instruction's immediate offset
-		return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.par, (int)(v_par + plane * 256u), (int)par_soff, 0));
+		// the segment / component offsets are compile-time constants: folded into the instruction's immediate offset
+		return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.par, (int)plane_voff_c(plane), (int)par_soff, 0));
+	}
+	static constexpr uint32_t kNP = (uint32_t)num_planes(TYPE, COMPACT), kFull = kNP / 4u, kTail = kNP % 4u;
+	__device__ __forceinline__ uint32_t plane_voff_c(uint32_t plane) const      // `plane` a constant
+	{
+		if constexpr (!VEC) return v_par + plane * 256u;
+		return plane < 4u * kFull ? v_par + (plane / 4u) * 1024u + (plane % 4u) * 4u : v_tail + (plane - 4u * kFull) * 4u;
+	}
+	// the same for a plane only known at run time (quad-lane FEM records: a lane fetches ITS column / row of Dm^-1)
+	__device__ __forceinline__ uint32_t plane_voff(uint32_t plane) const
+	{
+		if constexpr (!VEC) return v_par + plane * 256u;
+		return plane < 4u * kFull ? v_par + (plane >> 2) * 1024u + (plane & 3u) * 4u : v_tail + (plane - 4u * kFull) * 4u;
+	}
+	// ALL streamed planes of the lane's slot, w[plane]: one dword load per plane, or (VEC) one 16-byte load per full segment and one load of the tail's width
+	__device__ __forceinline__ void par_planes(uint32_t *w) const
+	{
+		if constexpr (!VEC)
+		{
+#pragma unroll
+			for (uint32_t pl = 0; pl < kNP; pl++) w[pl] = __builtin_amdgcn_raw_buffer_load_b32(str.par, (int)(v_par + pl * 256u), (int)par_soff, 0);
+			return;
+		}
+		typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+		typedef unsigned int v3u __attribute__((ext_vector_type(3)));
+		typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+		for (uint32_t sgm = 0; sgm < kFull; sgm++)
+		{
+			const v4u v = __builtin_amdgcn_raw_buffer_load_b128(str.par, (int)(v_par + sgm * 1024u), (int)par_soff, 0);
+			w[4 * sgm] = v.x; w[4 * sgm + 1] = v.y; w[4 * sgm + 2] = v.z; w[4 * sgm + 3] = v.w;
+		}
+		if constexpr (kTail == 1u) w[4 * kFull] = __builtin_amdgcn_raw_buffer_load_b32(str.par, (int)v_tail, (int)par_soff, 0);
+		if constexpr (kTail == 2u) { const v2u v = __builtin_amdgcn_raw_buffer_load_b64(str.par, (int)v_tail, (int)par_soff, 0); w[4 * kFull] = v.x; w[4 * kFull + 1] = v.y; }
+		if constexpr (kTail == 3u) { const v3u v = __builtin_amdgcn_raw_buffer_load_b96(str.par, (int)v_tail, (int)par_soff, 0); w[4 * kFull] = v.x; w[4 * kFull + 1] = v.y; w[4 * kFull + 2] = v.z; }
 	}
 	// raw dword of the chunk's parameter block at a per-lane byte offset (quad-lane records, pbdx_quad.h: every lane fetches its own planes)
 	__device__ __forceinline__ uint32_t par_raw(uint32_t voff) const { return __builtin_amdgcn_raw_buffer_load_b32(str.par, (int)voff, (int)par_soff, 0); }
@@ -432,10 +469,7 @@ template <int TYPE, bool COMPACT, class A> __device__ __forceinline__ void load_
 {
 	if constexpr (kTwoBodies[TYPE]) { r.w[0] = a.idx_raw1(i); r.w[1] = 0u; }
 	else { const uint2 v = a.idx_raw2(i); r.w[0] = v.x; r.w[1] = v.y; }
-#pragma unroll
-	for (int k = 0; k < kParamCount[TYPE]; k++)
-		if (param_streams(TYPE, COMPACT, k))
-			r.w[3 + kPlanes.plane[COMPACT ? 1 : 0][TYPE][k]] = __builtin_bit_cast(uint32_t, a.p(k, i));
+	a.par_planes(r.w + 3);        // (w[3 + plane]: the streamed parameters in plane order)
 	r.w[2] = 0u;
 	// unconditional load (the stream always exists; iteration 0 ignores the value): branch-free prefetch
 	if constexpr (kHasLambda[TYPE]) r.w[2] = __builtin_bit_cast(uint32_t, a.lam_load(i));

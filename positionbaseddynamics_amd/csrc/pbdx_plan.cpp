@@ -499,7 +499,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 							o.idx[st.idx_off + slot * iw + j] = (uint16_t)s.local_of[pb.idx[(size_t)i * ti->num_bodies + j]];
 						for (uint32_t p = 0; p < ti->param_stride; p++)
 							if (param_streams(pb.type, v.compact != 0, (int)p))
-								o.params[st.par_off + (size_t)(slot / 64) * (np_stream * 64) + (size_t)param_plane(pb.type, v.compact != 0, (int)p) * 64 + (slot % 64)] =
+								o.params[st.par_off + param_float_index(opt.vector_params, np_stream, (uint32_t)param_plane(pb.type, v.compact != 0, (int)p), slot)] =
 									pb.params[(size_t)i * ti->param_stride + p];
 						o.slot_cid.push_back(cid);
 					}
@@ -525,6 +525,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 		FusedSegment &seg = plan.segs.back();
 		seg.colour_begin = c0;
 		seg.colour_end = c1;
+		seg.vector_params = opt.vector_params;
 		for (size_t b = 0; b < batches.size(); b++)
 			if (batches[b].colour >= c0 && batches[b].colour < c1) { seg.constraints += batches[b].count; seg.type_mask |= 1u << batches[b].type; }
 		seg.tiles.resize(k);
@@ -566,6 +567,24 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	plan.redundancy = g.nc ? (double)slots_total / (double)g.nc : 1.0;
 	plan.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 	return true;
+}
+
+void relayout_params(FusedSegment &seg, const TypeView *views, bool vector_params)
+{
+	if (seg.vector_params == vector_params) return;
+	std::vector<float> tmp;
+	for (const FusedStep &st : seg.steps)
+	{
+		const uint32_t np = (uint32_t)num_planes((int)st.type, views[st.type].compact != 0);
+		if (!np || !st.count) continue;
+		const size_t floats = (size_t)((st.count + 63) / 64) * np * 64;
+		tmp.assign(seg.params.begin() + st.par_off, seg.params.begin() + st.par_off + floats);
+		for (uint32_t g = 0; g < (st.count + 63) / 64; g++)
+			for (uint32_t plane = 0; plane < np; plane++)
+				for (uint32_t l = 0; l < 64; l++)
+					seg.params[st.par_off + param_float_index(vector_params, np, plane, g * 64 + l)] = tmp[param_float_index(seg.vector_params, np, plane, g * 64 + l)];
+	}
+	seg.vector_params = vector_params;
 }
 
 namespace {
@@ -749,6 +768,7 @@ bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const st
 		if ((uint64_t)n_idx * K * 2 >= 0xfffffff0ull || (uint64_t)n_par * K * 4 >= 0xfffffff0ull || (uint64_t)ps.lam_count * K * 4 >= 0xfffffff0ull)
 		{ why = "a segment stream exceeds 4 GiB"; return false; }
 		seg.colour_begin = ps.colour_begin; seg.colour_end = ps.colour_end;
+		seg.vector_params = ps.vector_params;
 		seg.lam_count = ps.lam_count * K;
 		seg.max_local = ps.max_local;
 		seg.type_mask = ps.type_mask;
@@ -799,9 +819,8 @@ bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const st
 					if (np_stream)
 					{
 						const float *rec = recs + (size_t)i * ti->param_stride;
-						float *dst = dst0 + (size_t)(q / 64) * (np_stream * 64) + (q % 64);
 						for (uint32_t pk = 0; pk < ti->param_stride; pk++)
-							if (plane_of[pk] >= 0) dst[(size_t)plane_of[pk] * 64] = rec[pk];
+							if (plane_of[pk] >= 0) dst0[param_float_index(seg.vector_params, np_stream, (uint32_t)plane_of[pk], q)] = rec[pk];
 					}
 				}
 			}

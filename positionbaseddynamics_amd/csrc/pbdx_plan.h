@@ -115,6 +115,24 @@ constexpr int param_plane(int type, bool compact, int k)
 }
 constexpr int num_planes(int type, bool compact) { return param_plane(type, compact, kParamCount[type]); }
 
+// Layout of the streamed parameters of one step inside a segment's parameter stream.  The step's slots are taken in groups of 64 (one wave);
+// a group's block holds its `np` planes (streamed parameters) x 64 slots in one of two forms (FusedSegment::vector_params):
+//  * PLANES: plane p stored [64 slots], one coalesced dword load per plane;
+//  * VECTOR SEGMENTS: segment s = planes 4s .. 4s+3 stored [64 slots][4 floats], the last segment = the remaining np % 4 planes stored
+//    [64 slots][np % 4 floats]: a lane fetches four consecutive planes of its slot with ONE 16-byte load (a wave: 1 KiB contiguous).
+// Issuing a vector-memory instruction costs a wave 15-40 cycles whatever its width (scripts/microbench/vmem_issue.hip: 11 dword loads 290-585
+// counts, 3 dwordx4 loads 190-255), and a latency-bound colour step is ONE wave's instruction stream: vector segments make the 100 k-tet
+// bar 6.7 % faster (FEM 0.638 -> 0.595 ms), 16 bars 7.4 %, 100x100 / 300x300 cloth 3.5 %.  The 1 024-thread kernels of large cloth
+// scenes (16 waves per CU, throughput-bound) measure 2.5 % SLOWER with them (1 M cloth 0.769 -> 0.79 ms, 64-instance block 2.06 -> 2.12;
+// profiles/r03r_*) although their code gets smaller (114 instead of 128 VGPRs, no spill): those keep the planes.  The rule, in one place:
+constexpr bool vector_params_for_block(int block) { return block <= 512; }
+// Returns the float index of (plane, slot) relative to the step's first float.
+constexpr size_t param_float_index(bool vec, uint32_t np, uint32_t plane, uint32_t slot)
+{
+	const uint32_t nfull = np / 4u, tail = np % 4u, l = slot % 64u;
+	return (size_t)(slot / 64u) * (np * 64u) + (!vec ? plane * 64u + l : plane < 4u * nfull ? (plane / 4u) * 256u + l * 4u + plane % 4u : nfull * 256u + l * tail + (plane - 4u * nfull));
+}
+
 // plane index tables (constant-folded in the kernels once the parameter index is a constant)
 struct PlaneTable
 {
@@ -185,7 +203,10 @@ struct FusedSegment
 	uint64_t slots = 0;                 // executed (incl. redundant halo copies)
 	uint64_t constraints = 0;           // distinct constraints of the segment
 	uint64_t stream_bytes = 0;          // idx + params + 2*lambda bytes per sweep
+	bool vector_params = false;         // form of `params` (param_float_index)
 };
+// rewrites seg.params from one form into the other (a permutation inside every 64-slot block)
+void relayout_params(FusedSegment &seg, const TypeView *views, bool vector_params);
 
 struct PlanOptions
 {
@@ -197,6 +218,7 @@ struct PlanOptions
 	double launch_cost_ns = 3000.0;     // cost of one more launch (kernel boundary + tail)
 	bool owned_stay_in_lds = false;     // persistent schedule: a pass stages only the halo, and a pass boundary is a tile-to-tile hand-off
 	uint32_t threads = 0;               // 0 = auto
+	bool vector_params = false;         // form of the parameter streams (the caller predicts the workgroup size: vector_params_for_block)
 };
 
 struct FusedPlan

@@ -40,16 +40,12 @@ template <int TYPE, bool COMPACT> struct RecQ
 struct QuadLane
 {
 	uint32_t q, c;            // lane of the quad, its column
-	uint32_t v_col, v_row;    // byte offsets inside a chunk's parameter block of the column's / the row's first plane
 };
-__device__ __forceinline__ QuadLane quad_lane(uint32_t v_par)
+__device__ __forceinline__ QuadLane quad_lane()
 {
 	QuadLane l;
 	l.q = threadIdx.x & 3u;
 	l.c = l.q == 3u ? 0u : l.q;
-	// Dm^-1(r, c) is parameter 1 + 3 c + r = plane 1 + 3 c + r of both layouts (the rest volume is plane 0); a plane is 256 bytes per wave tile
-	l.v_col = v_par + (1u + 3u * l.c) * 256u;
-	l.v_row = v_par + (1u + l.c) * 256u;
 	return l;
 }
 
@@ -62,17 +58,17 @@ __device__ __forceinline__ void load_rec_quad(const A &a, const QuadLane &l, uin
 	if constexpr (TYPE == PBDX_STRAIN_TET)
 	{
 		// every lane needs all of Dm^-1 (the six sub-projections use every column); parameter k = plane k in both layouts (k < 9)
-#pragma unroll
-		for (uint32_t k = 0; k < (COMPACT ? 9u : 13u); k++) r.w[3 + k] = a.par_raw(a.v_par + k * 256u);
+		a.par_planes(r.w + 3);
 		return;
 	}
 	if constexpr (kHasLambda[TYPE]) r.w[2] = __builtin_bit_cast(uint32_t, a.lam_load(slot));
-	r.w[3] = a.par_raw(a.v_par);
+	// Dm^-1(r, c) is parameter 1 + 3 c + r = plane 1 + 3 c + r of both layouts (the rest volume is plane 0)
+	r.w[3] = a.par_raw(a.plane_voff_c(0u));
 #pragma unroll
-	for (uint32_t k = 0; k < 3; k++) r.w[4 + k] = a.par_raw(l.v_col + k * 256u);
+	for (uint32_t k = 0; k < 3; k++) r.w[4 + k] = a.par_raw(a.plane_voff(1u + 3u * l.c + k));
 #pragma unroll
-	for (uint32_t k = 0; k < 3; k++) r.w[7 + k] = a.par_raw(l.v_row + k * 768u);
-	if constexpr (!COMPACT) { r.w[10] = a.par_raw(a.v_par + 10u * 256u); r.w[11] = a.par_raw(a.v_par + 11u * 256u); }
+	for (uint32_t k = 0; k < 3; k++) r.w[7 + k] = a.par_raw(a.plane_voff(1u + l.c + 3u * k));
+	if constexpr (!COMPACT) { r.w[10] = a.par_raw(a.plane_voff_c(10u)); r.w[11] = a.par_raw(a.plane_voff_c(11u)); }
 }
 
 // Column c of the stress sigma and the energy, lane-parallel (computeGreenStrainAndPiolaStress); p14 etc. as in deformation_gradient

@@ -329,19 +329,27 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 	pending = false;
 }
 
+// developer build (-DPBDX_STEP_PROBE=1, scripts/probe_steps.py): cycle stamps inside the colour steps of the traced tile's first thread
+#ifndef PBDX_STEP_PROBE
+#define PBDX_STEP_PROBE 0
+#endif
 template <int TYPE, bool COMPACT, int BLOCK, bool COHERENT, bool QUAD_STEP = false>
 __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStreams &str, const uint4 *lchunks, uint32_t c0,
 	float4 *lpos, unsigned long long *trace, uint32_t &step_counter, bool &fill_pending)
 {
 	constexpr int D = Depth<TYPE>::value;
-	typedef TileAccess<TYPE, COMPACT, COHERENT> Acc;
+	constexpr bool VEC = vector_params_for_block(BLOCK);
+	typedef TileAccess<TYPE, COMPACT, COHERENT, VEC> Acc;
 	// quad-lane types (pbdx_quad.h): four lanes share a slot, a chunk holds BLOCK / 4 slots
 	constexpr bool QUAD = QUAD_STEP || is_quad_type(TYPE);
 	typedef typename std::conditional<QUAD, RecQ<TYPE, COMPACT>, Rec<TYPE, COMPACT>>::type RecT;
 	// per-lane constants of the run
 	const uint32_t lane_slot = QUAD ? threadIdx.x >> 2 : threadIdx.x;
-	const uint32_t v_par = (lane_slot >> 6) * (uint32_t)(num_planes(TYPE, COMPACT) * 256) + (lane_slot & 63u) * 4u;
-	const QuadLane ql = quad_lane(v_par);
+	// (parameter block of the lane's 64-slot group: pbdx_plan.h param_float_index -- full segments at 16 bytes per lane, the tail segment after them)
+	constexpr uint32_t NP = (uint32_t)num_planes(TYPE, COMPACT);
+	const uint32_t v_par = (lane_slot >> 6) * (NP * 256u) + (lane_slot & 63u) * (VEC ? 16u : 4u);
+	const uint32_t v_tail = VEC ? (lane_slot >> 6) * (NP * 256u) + (NP / 4u) * 1024u + (lane_slot & 63u) * ((NP % 4u) * 4u) : 0u;
+	const QuadLane ql = quad_lane();
 	// end of the run (first chunk of another type): precomputed on the host
 	const uint32_t run_end = c0 + chunk_run_left(rfl(lchunks[c0].x));
 
@@ -350,9 +358,12 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 	RecT r0, r1, r2, r3;
 	auto fetch = [&](RecT &dst)
 	{
-		// beyond the run the last chunk is fetched again (harmless): the fetch itself stays unconditional
+		// beyond the run the last chunk is fetched again (harmless): the fetch itself stays unconditional.  (Also for waves none of whose lanes
+		// has a slot in the chunk -- small scenes: 6 of 8 waves on the 100 k-tet bar.  Letting those skip the fetch was measured SLOWER, 0.638 ->
+		// 0.650 ms FEM, 0.745 -> 0.827 XPBD distance + volume, profiles/r03q_*: the compiler can no longer count the loads between a fetch and
+		// its use and waits for ALL outstanding loads, i.e. also for the records requested one step ago, and one step is about one memory latency.)
 		const ChunkS ch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
-		const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, a.views[TYPE] };
+		const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, v_tail, a.views[TYPE] };
 		if constexpr (QUAD) load_rec_quad<TYPE, COMPACT>(acc, ql, lane_slot, dst);
 		else load_rec<TYPE, COMPACT>(acc, lane_slot, dst);
 		c_ld++;
@@ -368,25 +379,47 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 	ChunkS ch_next = load_chunk(lchunks, c0);
 	auto sub = [&](RecT &cur)
 	{
+#if PBDX_STEP_PROBE
+		const bool probing = trace && threadIdx.x == 0 && step_counter < 8u;
+		const uint32_t pslot = 20u + 7u * step_counter;
+		unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
+		if (probing) tA = __builtin_readcyclecounter();
+#endif
 		if (c_ex < run_end)
 		{
 			const ChunkS ch = ch_next;
-			const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, a.views[TYPE] };
+			const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, v_tail, a.views[TYPE] };
 			if (lane_slot < chunk_valid(ch.info))
 			{
 				if constexpr (QUAD) exec_rec_quad<TYPE, COMPACT>(acc, ql, cur, lane_slot, a.dt, a.first_iter);
 				else exec_rec<TYPE, COMPACT>(acc, cur, lane_slot, a.dt, a.first_iter);
 			}
+#if PBDX_STEP_PROBE
+			if (probing) tB = __builtin_readcyclecounter();
+#endif
 			c_ex++;
 			ch_next = load_chunk(lchunks, c_ex < run_end ? c_ex : run_end - 1);
+#if PBDX_STEP_PROBE
+			if (probing) { asm volatile("" :: "s"(ch_next.info)); tC = __builtin_readcyclecounter(); }
+#endif
 			if (chunk_last_of_step(ch.info))
 			{
 				if (chunk_barrier(ch.info)) __syncthreads();
+#if PBDX_STEP_PROBE
+				if (probing) tD = __builtin_readcyclecounter();
+#endif
 				if (trace && threadIdx.x == 0 && step_counter + 2 < kTraceStride - 1) trace[2 + step_counter] = wall_clock64();
 				step_counter++;
 			}
 		}
 		fetch(cur);
+#if PBDX_STEP_PROBE
+		if (probing)
+		{
+			trace[pslot] = tA; trace[pslot + 1] = 0; trace[pslot + 2] = 0; trace[pslot + 3] = tB;
+			trace[pslot + 4] = tC; trace[pslot + 5] = tD; trace[pslot + 6] = __builtin_readcyclecounter();
+		}
+#endif
 	};
 	for (;;)
 	{
@@ -1454,6 +1487,15 @@ int ensure_plan(pbdx_solver *s)
 		opt.launch_cost_ns = 1500.0;
 		opt.owned_stay_in_lds = true;
 	}
+	{
+		// form of the parameter streams (pbdx_plan.h): follows the workgroup size, which is only final once the plan exists -- predicted here by
+		// the rules applied below (forced size; heavy types and small scenes run 512 threads at most), converted afterwards where the prediction missed
+		uint32_t mask = 0;
+		for (const PlanBatch &pb : pbs) mask |= 1u << pb.type;
+		const bool small_scene = (uint64_t)s->n <= (uint64_t)std::max(1, s->prop.multiProcessorCount) * 512u;
+		opt.vector_params = (s->fuse_block == 256 || s->fuse_block == 512 || s->fuse_block == 1024) ? vector_params_for_block(s->fuse_block)
+			: ((mask & ~kMaskLight) != 0 || small_scene);
+	}
 	bool planned = false;
 	if (s->inst_count > 1 && (uint64_t)s->inst_particles * s->inst_count == s->n)
 	{
@@ -1496,6 +1538,7 @@ int ensure_plan(pbdx_solver *s)
 	// per-segment device image (pushed first, so that free_plan() releases a partially built one)
 	for (size_t segi = 0; segi < s->plan.segs.size(); segi++)
 	{
+		relayout_params(s->plan.segs[segi], s->plan.views, vector_params_for_block(blocks[segi]));      // (a no-op unless the prediction above missed)
 		const FusedSegment &seg = s->plan.segs[segi];
 		s->dsegs.emplace_back();
 		DeviceSegment &d = s->dsegs.back();
@@ -2621,7 +2664,7 @@ int pbdx_solver_commit_params(pbdx_solver *s)
 				const float *rec = b.h_params.data() + (size_t)(cid - s->plan.batch_base[pos]) * ti->param_stride;
 				for (uint32_t k = 0; k < ti->param_stride; k++)
 					if (param_streams(type, compact, (int)k))
-						seg.params[st.par_off + (size_t)(q / 64) * (np_stream * 64) + (size_t)param_plane(type, compact, (int)k) * 64 + (q % 64)] = rec[k];
+						seg.params[st.par_off + param_float_index(seg.vector_params, np_stream, (uint32_t)param_plane(type, compact, (int)k), q)] = rec[k];
 			}
 		}
 		if (!seg.params.empty())

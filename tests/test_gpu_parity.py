@@ -245,6 +245,27 @@ def test_resident_equals_roundtrip_and_options_are_invariant(pbd):
         assert ts.solver().plan_info()["active"] == (0 if "per-colour" in label else 1), label
 
 
+def test_parameter_streams_converted_when_the_predicted_form_misses(pbd):
+    """The parameter streams of a plan come in two forms (pbdx_plan.h param_float_index: planes for 1 024-thread workgroups, vector segments
+    up to 512); the form is predicted before the plan exists and converted afterwards if the workgroup size turns out otherwise.  A cloth
+    with more than 512 particles per CU but tiles forced small: predicted 1 024 threads, runs with <= 512 (and, as the control, the same cloth
+    with the tiles the engine picks).  Both must reproduce the per-colour schedule bit for bit (positions, velocities, old / last positions)."""
+    S = pbd.Solver
+    for label, ops, opts in (("380x380 cloth, 150-particle tiles", util.cloth_spec(380, 380, 4, 3), {S.OPT_TILE_PARTICLES: 150}),
+                             ("380x380 cloth, default tiles", util.cloth_spec(380, 380, 4, 3), {})):
+        ma, _ = util.mine_run(ops, 2, 1, 3, options={S.OPT_FUSE: 0})
+        mb, tsb = util.mine_run(ops, 2, 1, 3, options={S.OPT_FUSE: 1, **opts})
+        sol = tsb.solver()
+        info = sol.plan_info()
+        assert info["active"] == 1
+        blocks = sorted({sol.segment_info(g)["block"] for g in range(info["num_segments"])})
+        for which in (0, 2, 4, 5):
+            assert util.bitwise_equal(ma.getParticles().array(which), mb.getParticles().array(which)), (label, which)
+        print("%s: %d tiles, workgroup sizes %s: fused == per-colour" % (label, info["num_tiles"], blocks))
+        if opts:
+            assert max(blocks) <= 512, "the small tiles were meant to give narrow steps"
+
+
 @pytest.mark.parametrize("name", list(SCENES))
 def test_fused_tiles_equal_per_colour_schedule(pbd, name):
     """Every constraint type through both device schedules: the colour-fused LDS tiles (forced to
