@@ -230,20 +230,12 @@ __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0
 #ifndef PBDX_DEFER_FILL_WAIT
 #define PBDX_DEFER_FILL_WAIT 0
 #endif
-// PBDX_FILL_AHEAD (persistent schedule, one workgroup per tile): the particle ids and the chunk descriptor of the NEXT pass's fill are requested
-// before this pass's write-back stores are issued, so that their latency hides behind the wait for those stores to reach memory (the wait every
-// pass ends with) instead of opening the next fill.  Bit-identical (144 GPU tests) and measured SLOWER: the fill shrinks (3.5 -> 2.9-3.5 us) but the
-// write-back grows by more (2.2 -> 3.5-7.4 us: the requests queue in front of the stores), 0.785-0.791 against 0.767-0.771 ms per substep on the 1 M
-// cloth, 2.037 against 2.029 ms on the c4 block (profiles/r03o_fill_ahead_ab.log).  Off; 1 builds it.
-#ifndef PBDX_FILL_AHEAD
-#define PBDX_FILL_AHEAD 0
-#endif
-struct FillAhead
-{
-	uint32_t g0, g1, g2, g3, g4, g5, g6, g7;      // first batch of particle ids of the fill
-	uint4 chv;                                      // this thread's chunk descriptor
-	uint32_t valid;                                 // (uniform)
-};
+// Tried at the pass boundaries and removed (all bit-identical, all slower; the A/B logs are in profiles/):
+//  * requesting the NEXT pass's first particle ids and chunk descriptor before this pass's write-back stores (r03o_fill_ahead_ab.log): the fill shrank
+//    (3.5 -> 2.9-3.5 us) but the write-back grew by more (2.2 -> 3.5-7.4 us: the requests queue in front of the stores), 1 M cloth 0.769 -> 0.788 ms;
+//  * requesting the prefetch ring of a pass's first run DURING the fill, behind the particle ids (r03u_ring_primed_in_fill_ab.log): the 1 024-thread cloth
+//    kernel has no registers to carry the ring across the fill (79 spilled, and a spill of a requested value waits for its load: fill 3.5 -> 12 us); on the
+//    FEM bar, where registers are free, the first step gains 0.24 us and the fill loses 0.3.
 constexpr uint32_t kMaxTileChunks = 256;
 template <int BLOCK, bool COHERENT> struct TileFill
 {
@@ -261,35 +253,13 @@ template <int BLOCK, bool COHERENT> struct TileFill
 	// the compiler waits for them once and places no wait (stricter than necessary, see lds_dma16) between the copies.
 	// `wait` runs after the first batch of ids is in flight and before any position is read: the persistent
 	// schedule waits for the neighbouring tiles there (the ids do not depend on them).
-	// the loads of the first batch, issued early (FillAhead): what operator() would request first
-	__device__ __forceinline__ void prefetch(FillAhead &out) const
-	{
-		out.chv = make_uint4(0u, 0u, 0u, 0u);
-		if (threadIdx.x < num_chunks) out.chv = src[threadIdx.x];
-		const uint32_t last = n_local - 1u, base = first + threadIdx.x;
-#define PBDX_P(k) { const uint32_t i = base + k * BLOCK; out.g##k = gid[i < last ? i : last]; }
-		PBDX_P(0) PBDX_P(1) PBDX_P(2) PBDX_P(3) PBDX_P(4) PBDX_P(5) PBDX_P(6) PBDX_P(7)
-#undef PBDX_P
-		out.valid = 1u;
-	}
-	template <class Wait> __device__ __forceinline__ void operator()(const Wait &wait, FillAhead *pre = nullptr) const
+	template <class Wait> __device__ __forceinline__ void operator()(const Wait &wait) const
 	{
 		static_assert(BLOCK >= (int)kMaxTileChunks, "one chunk descriptor per thread");
-		const bool have = pre != nullptr && pre->valid != 0u;      // (uniform) the first batch was requested during the previous pass
 		uint4 chv = make_uint4(0u, 0u, 0u, 0u);       // this thread's chunk descriptor: in flight with the ids
+		if (threadIdx.x < num_chunks) chv = src[threadIdx.x];
 		const uint32_t last = n_local - 1u;
 		uint32_t base = first + threadIdx.x;
-		if (have)
-		{
-			chv = pre->chv;
-			pre->valid = 0u;
-			const uint32_t g0 = pre->g0, g1 = pre->g1, g2 = pre->g2, g3 = pre->g3, g4 = pre->g4, g5 = pre->g5, g6 = pre->g6, g7 = pre->g7;
-			wait();
-#define PBDX_DH(k) { const uint32_t i = base + k * BLOCK; if (i < n_local) lds_dma16<COHERENT>(pos_in, g##k, lpos + (i & ~63u)); }
-			PBDX_DH(0) PBDX_DH(1) PBDX_DH(2) PBDX_DH(3) PBDX_DH(4) PBDX_DH(5) PBDX_DH(6) PBDX_DH(7)
-#undef PBDX_DH
-		}
-		else if (threadIdx.x < num_chunks) chv = src[threadIdx.x];
 #define PBDX_G(k) const uint32_t i##k = base + k * BLOCK; const uint32_t g##k = gid[i##k < last ? i##k : last];
 #define PBDX_D(k) if (i##k < n_local) lds_dma16<COHERENT>(pos_in, g##k, lpos + (i##k & ~63u));
 #define PBDX_BATCH(BETWEEN) { \
@@ -299,8 +269,7 @@ template <int BLOCK, bool COHERENT> struct TileFill
 			PBDX_D(0) PBDX_D(1) PBDX_D(2) PBDX_D(3) PBDX_D(4) PBDX_D(5) PBDX_D(6) PBDX_D(7) }
 		// first batch: executed by every thread (ids clamped, copies guarded per lane), so that wait() -- which
 		// contains a workgroup barrier -- sits at ONE point of the program for all waves
-		if (!have)
-			PBDX_BATCH(wait())
+		PBDX_BATCH(wait())
 		for (base += 8u * BLOCK; base < n_local; base += 8u * BLOCK)
 			PBDX_BATCH((void)0)
 #undef PBDX_BATCH
@@ -561,10 +530,8 @@ __device__ __forceinline__ void velocity_write_back(const FoldArgs &f, const uin
 template <uint32_t MASK, int BLOCK, bool COHERENT, class Wait>
 __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &ra, const float4 *pos_in, float4 *pos_out, uint32_t tile_index,
 	unsigned long long *trace, uint4 *lchunks, float4 *lpos, bool keep_owned, const Wait &wait, const FoldArgs *fold = nullptr, uint32_t fold_phase = 0,
-	bool boundary_only = false, FillAhead *ahead = nullptr, const SegArgs *next_seg = nullptr, bool fill_ahead = false)
+	bool boundary_only = false)
 {
-	// ahead / next_seg (persistent schedule, one workgroup per tile): `ahead` holds the first batch of this pass's fill if the previous pass requested
-	// it, and receives the next pass's (segment next_seg, same tile, owned particles resident) before this pass's write-back
 	// boundary_only (persistent schedule, one workgroup per tile, not the last pass of the launch): the owned particles stay in LDS for the next
 	// pass, so only the ones another tile stages -- [wb_begin, n_owned): the planner orders the interior first -- have to reach memory
 	// fold_phase (persistent schedule only): bit 0 = this pass integrates while it stages, bit 1 = it updates the velocities
@@ -587,7 +554,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			integrate_fill<BLOCK>(*fold, reinterpret_cast<const uint4 *>(gchunks), gid, pos_in, lchunks, lpos, num_chunks, t.n_local, t.n_owned, trace);
 			staged = true;
 		}
-	if (!staged) fill(wait, ahead);
+	if (!staged) fill(wait);
 	bool fill_pending = PBDX_DEFER_FILL_WAIT != 0 && !staged;
 	// chunks are addressed relative to the tile from here on (they sit at lchunks[0 .. num_chunks))
 	uint32_t c = 0, step_counter = 0;
@@ -613,15 +580,6 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			velocity_write_back<BLOCK>(*fold, gid, pos_out, lpos, t.n_owned);
 			written = true;
 		}
-	// (the next pass's first ids and chunk descriptor are requested now: their latency hides behind the write-back's completion)
-	if (PBDX_FILL_AHEAD != 0 && fill_ahead)
-	{
-		const FusedTile tn = next_seg->tiles[tile_index];
-		const TileFill<BLOCK, COHERENT> nf = { reinterpret_cast<const uint4 *>(next_seg->chunks + tn.chunk_begin), next_seg->gid + tn.gid_off, nullptr, lchunks, lpos,
-			tn.chunk_end - tn.chunk_begin, tn.n_local, tn.n_owned & ~63u, nullptr };
-		nf.prefetch(*ahead);
-	}
-	else if (ahead != nullptr) *ahead = FillAhead{};        // (every path defines it here: nothing of it is live across the colour steps)
 	// write-back of the owned particles, ids batched like the fill
 	if (!written)
 	{
@@ -738,8 +696,6 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 	}
 	__syncthreads();
 	if (!s_go) return;
-	FillAhead ahead;
-	ahead.valid = 0u;
 	for (uint32_t pass = 0; pass < a.passes; pass++)
 	{
 		const SegArgs &sg = a.seg[sgi];
@@ -773,9 +729,8 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 			// one tile per workgroup: its owned particles stay in LDS from pass to pass
 			const uint32_t fold_phase = a.folded ? ((pass == 0 ? 1u : 0u) | (pass + 1u == a.passes ? 2u : 0u)) : 0u;
 			const bool resident = gridDim.x == a.num_tiles;
-			const bool more = resident && pass + 1u != a.passes;       // this workgroup runs the same tile's next pass with its owned particles in LDS
 			process_tile<MASK, BLOCK, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && resident, wait, &a.fold, fold_phase,
-				more && !PBDX_FULL_WRITE_BACK, &ahead, &a.seg[sgi + 1u == a.num_segs ? 0u : sgi + 1u], more);
+				resident && pass + 1u != a.passes && !PBDX_FULL_WRITE_BACK);
 			if (s_failed)
 			{
 				// a neighbour never arrived: the state of this step is garbage.  Say so, turn every later kernel of the call
