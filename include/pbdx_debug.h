@@ -39,6 +39,13 @@ int pbdx_debug_tet_impulses(pbdx_solver *s, uint32_t *last, uint64_t *total);
  * one launch with 16-byte loads (calib_reread_b128: with a buffer between the L2 and the Infinity-Cache size this tells whether a
  * counter sees Infinity-Cache hits). */
 int pbdx_debug_stream(int device, uint64_t nbytes, int mode);
+/* Developer / test aid (host only): the two forms of a step's parameter stream (pbdx_plan.h param_float_index: planes for 1 024-thread workgroups,
+ * vector segments up to 512).  `block` holds ceil(slots / 64) * planes * 64 floats of ONE step in the form `from_vector`; it is rewritten into the
+ * other form by the planner's own conversion (relayout_params).  `type` / `compact` select the constraint type whose plane count applies;
+ * *planes_out (optional) receives that count. */
+int pbdx_debug_relayout_params(int type, int compact, uint32_t slots, int from_vector, float *block, uint32_t *planes_out);
+/* ... and the index function itself: float index of (plane, slot) relative to the step's first float. */
+uint64_t pbdx_debug_param_float_index(int vector_params, uint32_t planes, uint32_t plane, uint32_t slot);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 // pbdx_plan.cpp -- planner of the colour-fused tile schedule (see pbdx_plan.h).  Host only.
 #include "pbdx_plan.h"
 #include "pbdx_internal.h"
+#include "../../include/pbdx_debug.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -587,6 +588,32 @@ void relayout_params(FusedSegment &seg, const TypeView *views, bool vector_param
 	seg.vector_params = vector_params;
 }
 
+} // namespace pbdx (the debug entries below are C symbols)
+
+extern "C" int pbdx_debug_relayout_params(int type, int compact, uint32_t slots, int from_vector, float *block, uint32_t *planes_out)
+{
+	using namespace pbdx;
+	if (!type_info(type) || !block) return PBDX_ERR_INVALID;
+	TypeView views[16] = {};
+	views[type].compact = compact ? 1 : 0;
+	const uint32_t np = (uint32_t)num_planes(type, compact != 0);
+	if (planes_out) *planes_out = np;
+	FusedSegment seg;
+	seg.vector_params = from_vector != 0;
+	FusedStep st = {};
+	st.type = (uint32_t)type; st.count = slots; st.par_off = 0;
+	seg.steps.push_back(st);
+	seg.params.assign(block, block + (size_t)((slots + 63) / 64) * np * 64);
+	relayout_params(seg, views, from_vector == 0);
+	std::copy(seg.params.begin(), seg.params.end(), block);
+	return PBDX_OK;
+}
+extern "C" uint64_t pbdx_debug_param_float_index(int vector_params, uint32_t planes, uint32_t plane, uint32_t slot)
+{
+	return (uint64_t)pbdx::param_float_index(vector_params != 0, planes, plane, slot);
+}
+
+namespace pbdx {
 namespace {
 inline uint64_t mix(uint64_t a, uint64_t b)
 {

@@ -11,6 +11,7 @@ launch): a host simulation lets the tiles run asynchronously in adversarial orde
 advanced first, pseudo-random, one tile held back) subject only to the lists and requires every LDS fill to find
 the particle versions of the previous pass in the double-buffered positions; and it checks the checker -- with
 one list entry removed the simulation must report the stale read."""
+import numpy as np
 import pytest
 
 from tests import util
@@ -115,3 +116,62 @@ def test_instanced_plan_is_one_instance_replicated_and_exact(name, ops, tile):
     # given the same tile size (its tiles may straddle instances, so only the totals are comparable)
     plain = util.build_mine(expand_instances(ops))
     assert plain.numInstances() == 1 and plain.numConstraints() == m.numConstraints()
+
+
+def test_parameter_stream_forms_and_their_conversion():
+    """The two forms of a step's parameter stream (pbdx_plan.h param_float_index): planes (1 024-thread workgroups) and vector segments
+    (up to 512: planes 4s..4s+3 of a slot adjacent, one 16-byte load).  Both index functions are bijections onto the step's block, the
+    vector form puts a slot's planes where ONE aligned load of 4 / 3 / 2 / 1 floats finds them, and the planner's conversion
+    (relayout_params, through a developer entry point) moves every (plane, slot) value to its place in the other form and back."""
+    import ctypes as C
+    from positionbaseddynamics_amd import _ffi
+    lib = _ffi.lib
+    idx = lib.pbdx_debug_param_float_index
+    for planes in (1, 2, 3, 4, 5, 9, 10, 12, 13, 17):
+        for slots in (1, 63, 64, 65, 200):
+            groups = (slots + 63) // 64
+            total = groups * planes * 64
+            for vec in (0, 1):
+                seen = set()
+                for slot in range(groups * 64):
+                    for plane in range(planes):
+                        seen.add(idx(vec, planes, plane, slot))
+                assert seen == set(range(total)), (planes, slots, vec)
+            # vector form: the planes of a full segment are consecutive floats starting at a multiple of 4; the tail's planes are consecutive too
+            for slot in (0, 1, 63, 64 * (groups - 1) + 5):
+                for sgm in range(planes // 4):
+                    base = idx(1, planes, 4 * sgm, slot)
+                    assert base % 4 == 0 and [idx(1, planes, 4 * sgm + c, slot) for c in range(4)] == [base + c for c in range(4)]
+                tail = planes % 4
+                if tail:
+                    base = idx(1, planes, planes - tail, slot)
+                    assert [idx(1, planes, planes - tail + c, slot) for c in range(tail)] == [base + c for c in range(tail)]
+            # plane form: a plane's 64 slots are consecutive
+            assert [idx(0, planes, planes - 1, q) for q in range(64)] == list(range((planes - 1) * 64, planes * 64))
+    # the conversion, on the plane counts of real types (compact and full layouts)
+    rng = np.random.default_rng(5)
+    checked = 0
+    for ctype in range(13):
+        for compact in (0, 1):
+            for slots in (1, 64, 150):
+                np_out = C.c_uint32(0)
+                probe = np.zeros(64 * 64, dtype=np.float32)
+                assert lib.pbdx_debug_relayout_params(ctype, compact, 1, 0, probe.ctypes.data_as(C.POINTER(C.c_float)), C.byref(np_out)) == 0
+                planes = np_out.value
+                if planes == 0:
+                    continue
+                groups = (slots + 63) // 64
+                values = rng.random((planes, groups * 64)).astype(np.float32)         # value of (plane, slot)
+                block = np.zeros(groups * planes * 64, dtype=np.float32)
+                for plane in range(planes):
+                    for slot in range(groups * 64):
+                        block[idx(0, planes, plane, slot)] = values[plane, slot]
+                start = block.copy()
+                assert lib.pbdx_debug_relayout_params(ctype, compact, slots, 0, block.ctypes.data_as(C.POINTER(C.c_float)), None) == 0
+                for plane in range(planes):
+                    for slot in range(0, groups * 64, 7):
+                        assert block[idx(1, planes, plane, slot)] == values[plane, slot], (ctype, compact, slots, plane, slot)
+                assert lib.pbdx_debug_relayout_params(ctype, compact, slots, 1, block.ctypes.data_as(C.POINTER(C.c_float)), None) == 0
+                assert np.array_equal(block, start)
+                checked += 1
+    assert checked > 20
