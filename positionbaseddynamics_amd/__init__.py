@@ -34,6 +34,30 @@ def device_count():
     return lib.pbdx_device_count()
 
 
+def colour_constraints(num_bodies, body_off, bodies, device=0):
+    """pbdx_colour_constraints: the reference's greedy colouring (SimulationModel.cpp:1033-1094) on the device, on raw arrays.
+    Returns (group_of, num_groups, rounds)."""
+    body_off = np.ascontiguousarray(body_off, dtype=np.uint32)
+    bodies = np.ascontiguousarray(bodies, dtype=np.uint32)
+    nc = len(body_off) - 1
+    group_of = np.zeros(max(nc, 1), dtype=np.uint32)
+    ng, rounds = C.c_uint32(0), C.c_uint32(0)
+    check(lib.pbdx_colour_constraints(int(device), int(num_bodies), nc, _u(body_off), _u(bodies), _u(group_of), C.byref(ng), C.byref(rounds)),
+          "pbdx_colour_constraints")
+    return group_of[:nc], ng.value, rounds.value
+
+
+def colour_constraints_host(num_bodies, body_off, bodies):
+    """pbdx_colour_constraints_host: the same colouring on the host (bit masks per body).  Returns (group_of, num_groups)."""
+    body_off = np.ascontiguousarray(body_off, dtype=np.uint32)
+    bodies = np.ascontiguousarray(bodies, dtype=np.uint32)
+    nc = len(body_off) - 1
+    group_of = np.zeros(max(nc, 1), dtype=np.uint32)
+    ng = C.c_uint32(0)
+    check(lib.pbdx_colour_constraints_host(int(num_bodies), nc, _u(body_off), _u(bodies), _u(group_of), C.byref(ng)), "pbdx_colour_constraints_host")
+    return group_of[:nc], ng.value
+
+
 def _f(a):
     return a.ctypes.data_as(_ffi.pf)
 
@@ -460,8 +484,13 @@ class SimulationModel:
               "pbdx_model_plan_check")
         return {k: getattr(pi, k) for k, _ in _ffi.PlanInfo._fields_}
 
-    def initConstraintGroups(self):
-        check(lib.pbdx_model_init_constraint_groups(self._h), "initConstraintGroups")
+    def initConstraintGroups(self, device=None):
+        """SimulationModel::initConstraintGroups.  device=None: on the host; device=k: the same colouring computed on GPU k
+        (group for group identical; raises for what the device form does not take -- call again without `device` then)."""
+        if device is None:
+            check(lib.pbdx_model_init_constraint_groups(self._h), "initConstraintGroups")
+        else:
+            check(lib.pbdx_model_init_constraint_groups_device(self._h, int(device)), "initConstraintGroups(device)")
 
     def getConstraintGroups(self):
         self.initConstraintGroups()

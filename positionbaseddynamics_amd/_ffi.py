@@ -174,6 +174,9 @@ SIGNATURES = [
     ("pbdx_model_constraint_bodies", C.c_int, vp, u32, pu), ("pbdx_model_constraint_params", C.c_int, vp, u32, pf),
     ("pbdx_model_set_constraint_params", C.c_int, vp, u32, pf),
     ("pbdx_model_init_constraint_groups", C.c_int, vp), ("pbdx_model_groups_initialized", C.c_int, vp),
+    ("pbdx_model_init_constraint_groups_device", C.c_int, vp, C.c_int),
+    ("pbdx_colour_constraints", C.c_int, C.c_int, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)),
+    ("pbdx_colour_constraints_host", C.c_int, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)),
     ("pbdx_model_num_groups", u32, vp), ("pbdx_model_group_size", u32, vp, u32), ("pbdx_model_get_group", C.c_int, vp, u32, pu),
     ("pbdx_timestep_create", C.c_int, C.POINTER(vp), C.c_int), ("pbdx_timestep_destroy", None, vp),
     ("pbdx_timestep_set_param", C.c_int, vp, C.c_int, i64), ("pbdx_timestep_get_param", i64, vp, C.c_int),
