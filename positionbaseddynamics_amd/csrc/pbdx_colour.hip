@@ -162,7 +162,7 @@ extern "C" int pbdx_colour_constraints(int device, uint32_t num_bodies, uint32_t
 	if (num_groups) *num_groups = 0;
 	if (rounds) *rounds = 0;
 	if (num_constraints == 0) return PBDX_OK;
-	if (num_constraints >= (1u << 30)) { set_error("pbdx_colour_constraints: too many constraints"); return PBDX_ERR_UNSUPPORTED; }
+	if (num_constraints >= (1u << 29)) { set_error("pbdx_colour_constraints: too many constraints (the pair sort counts 4 per constraint in an int)"); return PBDX_ERR_UNSUPPORTED; }
 	for (uint32_t c = 0; c < num_constraints; c++)
 		if (body_off[c + 1] < body_off[c] || body_off[c + 1] - body_off[c] > 4u || body_off[c + 1] == body_off[c])
 		{ set_error("pbdx_colour_constraints: constraint %u has %u bodies (1..4 supported)", c, body_off[c + 1] - body_off[c]); return PBDX_ERR_UNSUPPORTED; }
