@@ -184,9 +184,162 @@ struct TileOut
 	uint32_t n_owned = 0;
 	uint32_t slots = 0;
 	uint64_t stream_bytes = 0;
+	uint32_t tab_off = 0, tab_f4 = 0;       // dictionary form: the tile's table inside `params` (float offset) and its used size (16-byte units)
 };
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// ---- dictionary form of wide, repetitive parameter records (FusedStep::dict) -------------------------
+// distinct records of `words` dwords each, compared bit for bit (open addressing)
+struct RecordTable
+{
+	uint32_t words;
+	std::vector<uint32_t> keys;
+	std::vector<uint32_t> cells;
+	explicit RecordTable(uint32_t w) : words(w), cells(1024, 0xffffffffu) {}
+	uint32_t size() const { return (uint32_t)(keys.size() / words); }
+	static uint64_t hash(const uint32_t *r, uint32_t n)
+	{
+		uint64_t h = 1469598103934665603ull;
+		for (uint32_t i = 0; i < n; i++) { h ^= r[i]; h *= 1099511628211ull; h ^= h >> 29; }
+		return h;
+	}
+	void grow()
+	{
+		std::vector<uint32_t> bigger(cells.size() * 2, 0xffffffffu);
+		for (uint32_t e = 0; e < size(); e++)
+		{
+			size_t c = hash(&keys[(size_t)e * words], words) & (bigger.size() - 1);
+			while (bigger[c] != 0xffffffffu) c = (c + 1) & (bigger.size() - 1);
+			bigger[c] = e;
+		}
+		cells.swap(bigger);
+	}
+	uint32_t find_or_add(const uint32_t *rec)
+	{
+		size_t c = hash(rec, words) & (cells.size() - 1);
+		while (cells[c] != 0xffffffffu)
+		{
+			if (!memcmp(&keys[(size_t)cells[c] * words], rec, words * 4)) return cells[c];
+			c = (c + 1) & (cells.size() - 1);
+		}
+		const uint32_t e = size();
+		cells[c] = e;
+		keys.insert(keys.end(), rec, rec + words);
+		if ((size_t)size() * 2 > cells.size()) grow();
+		return e;
+	}
+};
+// room a tile's table gets in the parameter stream (floats): the whole LDS budget of a table -- the congruent copies of an instanced plan share the
+// prototype's layout, and their records (rest geometry of a translated mesh, rounded elsewhere) differ from the prototype's in their last bits
+inline uint32_t dict_area_floats() { return kDictTableF4 * 4u; }
+
+// The dictionaries of one tile.  `steps`: the tile's steps; `candidate(si)`: may step si take the form (planning: every step of a dict_type; replicating an
+// instanced plan: the steps the prototype converted); `record(si, q, out)`: the streamed planes of slot q of step si, plane order.  On success:
+// entry_of[si][q] = the slot's offset in the table (16-byte units), `table` = the table (floats, used_f4 * 4), converted[si] = 1.  A type is converted
+// if its records fit what is left of `capacity_f4` and repeat at least four times on average; `must`: fail (return false) instead of skipping a type.
+template <class Candidate, class Record>
+bool build_tile_dictionary(const FusedStep *steps, size_t nsteps, const TypeView *views, uint32_t capacity_f4, bool must, Candidate &&candidate, Record &&record,
+	std::vector<std::vector<uint16_t>> &entry_of, std::vector<uint8_t> &converted, std::vector<float> &table, uint32_t &used_f4)
+{
+	entry_of.assign(nsteps, std::vector<uint16_t>());
+	converted.assign(nsteps, 0);
+	table.clear();
+	used_f4 = 0;
+	uint32_t rec[PBDX_MAX_PARAMS];
+	for (int type = 0; type < PBDX_NUM_CONSTRAINT_TYPES; type++)
+	{
+		const uint32_t np = (uint32_t)num_planes(type, views[type].compact != 0), ef4 = dict_entry_f4(np);
+		RecordTable rt(std::max(np, 1u));
+		std::vector<std::vector<uint32_t>> ent(nsteps);
+		uint64_t slots = 0;
+		for (size_t si = 0; si < nsteps; si++)
+		{
+			if ((int)steps[si].type != type || !candidate(si)) continue;
+			ent[si].resize(steps[si].count);
+			for (uint32_t q = 0; q < steps[si].count; q++) { record(si, q, reinterpret_cast<float *>(rec)); ent[si][q] = rt.find_or_add(rec); }
+			slots += steps[si].count;
+		}
+		if (!slots) continue;
+		const uint64_t need = (uint64_t)rt.size() * ef4;
+		if (used_f4 + need > capacity_f4 || (!must && slots < 4ull * rt.size()))
+		{
+			if (must) return false;
+			continue;
+		}
+		table.resize((size_t)(used_f4 + need) * 4, 0.0f);
+		for (uint32_t e = 0; e < rt.size(); e++) memcpy(&table[((size_t)used_f4 + (size_t)e * ef4) * 4], &rt.keys[(size_t)e * np], np * 4);
+		for (size_t si = 0; si < nsteps; si++)
+		{
+			if (ent[si].empty()) continue;
+			converted[si] = 1;
+			entry_of[si].resize(ent[si].size());
+			for (size_t q = 0; q < ent[si].size(); q++) entry_of[si][q] = (uint16_t)(used_f4 + ent[si][q] * ef4);
+		}
+		used_f4 += (uint32_t)need;
+	}
+	return true;
+}
+// floats a dictionary-form step occupies in the parameter stream: one uint16 per slot, whole 256-byte units
+inline uint32_t dict_step_floats(uint32_t count) { return round_up((count + 1u) / 2u, 64u); }
+
+// developer aid (PBDX_PLAN_VERBOSE): how much of the dictionary-eligible work took the form
+void print_dictionary_coverage(const FusedPlan &plan)
+{
+	uint64_t cand = 0, conv = 0, tabs = 0, tiles = 0;
+	uint32_t max_tab = 0;
+	for (const FusedSegment &seg : plan.segs)
+	{
+		for (const FusedStep &st : seg.steps)
+			if (dict_type((int)st.type)) { cand += st.count; if (st.dict) conv += st.count; }
+		for (const FusedTile &t : seg.tiles) { tiles++; if (t.tab_f4) tabs++; max_tab = std::max(max_tab, t.tab_f4); }
+	}
+	fprintf(stderr, "[plan] dictionary form: %llu of %llu eligible slots, %llu of %llu (tile, segment) pairs carry a table, largest %u x 16 B\n",
+		(unsigned long long)conv, (unsigned long long)cand, (unsigned long long)tabs, (unsigned long long)tiles, max_tab);
+}
+
+// planning: convert the steps of a freshly built tile (parameter stream in the `vec` form) where it pays
+// keep_streams (prototype of an instanced plan): a converted step keeps its streamed block BEHIND its index area, so that a copy whose records do not
+// fit a table can fall back to streaming them inside the same layout
+void dictionary_pass(TileOut &o, const TypeView *views, bool vec, bool keep_streams)
+{
+	std::vector<std::vector<uint16_t>> entry_of;
+	std::vector<uint8_t> converted;
+	std::vector<float> table;
+	uint32_t used_f4 = 0;
+	build_tile_dictionary(o.steps.data(), o.steps.size(), views, kDictTableF4, false,
+		[&](size_t si) { return dict_type((int)o.steps[si].type) && num_planes((int)o.steps[si].type, views[o.steps[si].type].compact != 0) >= 4; },
+		[&](size_t si, uint32_t q, float *out) {
+			const FusedStep &st = o.steps[si];
+			const uint32_t np = (uint32_t)num_planes((int)st.type, views[st.type].compact != 0);
+			for (uint32_t p = 0; p < np; p++) out[p] = o.params[st.par_off + param_float_index(vec, np, p, q)];
+		}, entry_of, converted, table, used_f4);
+	if (!used_f4) return;
+	std::vector<float> out;
+	out.reserve(o.params.size());
+	for (size_t si = 0; si < o.steps.size(); si++)
+	{
+		FusedStep &st = o.steps[si];
+		const uint32_t np = (uint32_t)num_planes((int)st.type, views[st.type].compact != 0);
+		const uint32_t old_off = st.par_off, old_floats = ((st.count + 63u) / 64u) * np * 64u;
+		st.par_off = (uint32_t)out.size();
+		if (converted[si])
+		{
+			st.dict = 1;
+			out.resize(out.size() + dict_step_floats(st.count), 0.0f);
+			memcpy(&out[st.par_off], entry_of[si].data(), (size_t)st.count * 2);
+			o.stream_bytes -= (uint64_t)st.count * (np * 4u - 2u);
+			if (keep_streams) out.insert(out.end(), o.params.begin() + old_off, o.params.begin() + old_off + old_floats);
+		}
+		else
+			out.insert(out.end(), o.params.begin() + old_off, o.params.begin() + old_off + old_floats);
+	}
+	o.tab_off = (uint32_t)out.size();
+	o.tab_f4 = used_f4;
+	out.resize(out.size() + dict_area_floats(), 0.0f);
+	memcpy(&out[o.tab_off], table.data(), table.size() * sizeof(float));
+	o.params.swap(out);
+}
 
 } // namespace
 
@@ -304,7 +457,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	uint32_t T = opt.tile_particles, k;
 	if (T == 0)
 	{
-		k = (uint32_t)default_tile_count(n, opt.num_cus, opt.max_local);
+		k = (uint32_t)default_tile_count(n, opt.num_cus, opt.sizing_local ? opt.sizing_local : opt.max_local);
 	}
 	else
 	{
@@ -482,7 +635,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 					st.count = (uint32_t)(e - a);
 					st.idx_off = (uint32_t)o.idx.size();
 					st.par_off = (uint32_t)o.params.size();
-					st.par_stride = 0;
+					st.dict = 0;
 					const uint32_t np_stream = (uint32_t)num_planes(pb.type, v.compact != 0);
 					const uint32_t groups64 = (st.count + 63) / 64;
 					st.lam_off = o.lam_count;
@@ -511,6 +664,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 					a = e;
 				}
 			}
+			if (opt.dict_params) dictionary_pass(o, plan.views, opt.vector_params, opt.dict_keep_streams);
 		});
 		if (worst.load() > opt.max_local)
 		{
@@ -539,9 +693,13 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 			ft.n_local = (uint32_t)o.gid.size();
 			ft.n_owned = o.n_owned;
 			ft.wb_begin = wb_begin[t];
+
 			ft.gid_off = (uint32_t)seg.gid.size();
 			ft.slots = o.slots;
 			const uint32_t idx_base = (uint32_t)seg.idx.size(), par_base = (uint32_t)seg.params.size();
+			ft.tab_off = o.tab_f4 ? (par_base + o.tab_off) / 4u : 0u;      // (every block of the stream is a whole number of 256-byte units)
+			ft.tab_f4 = o.tab_f4;
+			seg.max_tab_f4 = std::max(seg.max_tab_f4, o.tab_f4);
 			const uint32_t lam_base = seg.lam_count, cid_base = (uint32_t)seg.slot_cid.size();
 			// streams are addressed with 32-bit BYTE offsets (buffer descriptors)
 			if (((uint64_t)idx_base + o.idx.size()) * 2 >= 0xfffffff0ull || ((uint64_t)par_base + o.params.size()) * 4 >= 0xfffffff0ull ||
@@ -567,6 +725,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	}
 	plan.redundancy = g.nc ? (double)slots_total / (double)g.nc : 1.0;
 	plan.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+	if (getenv("PBDX_PLAN_VERBOSE")) print_dictionary_coverage(plan);
 	return true;
 }
 
@@ -577,7 +736,7 @@ void relayout_params(FusedSegment &seg, const TypeView *views, bool vector_param
 	for (const FusedStep &st : seg.steps)
 	{
 		const uint32_t np = (uint32_t)num_planes((int)st.type, views[st.type].compact != 0);
-		if (!np || !st.count) continue;
+		if (!np || !st.count || st.dict) continue;      // (a dictionary-form step holds slot -> record offsets: the same in both forms)
 		const size_t floats = (size_t)((st.count + 63) / 64) * np * 64;
 		tmp.assign(seg.params.begin() + st.par_off, seg.params.begin() + st.par_off + floats);
 		for (uint32_t g = 0; g < (st.count + 63) / 64; g++)
@@ -659,6 +818,7 @@ bool check_fused_plan(uint32_t n, const std::vector<PlanBatch> &batches, const F
 		for (const FusedTile &t : seg.tiles)
 		{
 			if (t.n_local > 65535 || t.n_owned > t.n_local) { why = "bad tile sizes"; return false; }
+			if (t.tab_f4 > kDictTableF4 || ((size_t)t.tab_off + t.tab_f4) * 4 > seg.params.size() || t.tab_f4 > seg.max_tab_f4) { why = "bad dictionary table"; return false; }
 			local.resize(t.n_local);
 			for (uint32_t i = 0; i < t.n_local; i++)
 			{
@@ -678,6 +838,28 @@ bool check_fused_plan(uint32_t n, const std::vector<PlanBatch> &batches, const F
 					const size_t b = std::upper_bound(base.begin(), base.end(), cid) - base.begin() - 1;
 					if (batches[b].type != (int)st.type) { why = "slot type mismatch"; return false; }
 					if (batches[b].colour < seg.colour_begin || batches[b].colour >= seg.colour_end) { why = "slot colour outside its segment"; return false; }
+					// the slot's streamed parameters, whatever form the step's part of the stream has (planes / vector segments / dictionary): bit for bit the
+					// constraint's own
+					{
+						const bool compact = plan.views[st.type].compact != 0;
+						const uint32_t np = (uint32_t)num_planes((int)st.type, compact);
+						const float *rec = batches[b].params + (size_t)(cid - base[b]) * ti->param_stride;
+						const float *entry = nullptr;
+						if (st.dict)
+						{
+							if (!dict_type((int)st.type) || !t.tab_f4) { why = "dictionary-form step without a table"; return false; }
+							const uint16_t e = reinterpret_cast<const uint16_t *>(&seg.params[st.par_off])[q];
+							if ((uint32_t)e + dict_entry_f4(np) > t.tab_f4) { why = "dictionary offset outside the tile's table"; return false; }
+							entry = &seg.params[((size_t)t.tab_off + e) * 4];
+						}
+						for (uint32_t pk = 0; pk < ti->param_stride; pk++)
+						{
+							if (!param_streams((int)st.type, compact, (int)pk)) continue;
+							const uint32_t plane = (uint32_t)param_plane((int)st.type, compact, (int)pk);
+							const float got = entry ? entry[plane] : seg.params[st.par_off + param_float_index(seg.vector_params, np, plane, q)];
+							if (memcmp(&got, &rec[pk], 4)) { snprintf(msg, sizeof(msg), "constraint %u: streamed parameter %u differs from the constraint's", cid, pk); why = msg; return false; }
+						}
+					}
 					uint32_t lb[4];
 					for (uint32_t j = 0; j < ti->num_bodies; j++)
 					{
@@ -753,11 +935,12 @@ bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const st
 	std::vector<PlanBatch> proto(batches);
 	for (PlanBatch &b : proto) b.count /= K;
 	PlanOptions po = opt;
+	po.dict_keep_streams = true;
 	if (!po.tile_particles)
 	{
 		// tile count of the whole as the planner would choose it (whole waves of num_cus tiles at the largest tile the LDS
 		// allows), divided among the instances
-		const uint64_t k_all = default_tile_count((uint64_t)n_proto * K, opt.num_cus, opt.max_local);
+		const uint64_t k_all = default_tile_count((uint64_t)n_proto * K, opt.num_cus, opt.sizing_local ? opt.sizing_local : opt.max_local);
 		const uint32_t k_proto = (uint32_t)std::max<uint64_t>(1, (k_all + K / 2) / K);
 		po.tile_particles = std::min<uint32_t>(opt.max_local, (n_proto + k_proto - 1) / k_proto);
 	}
@@ -789,6 +972,7 @@ bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const st
 	plan.segs.resize(pp.segs.size());
 	for (size_t si = 0; si < pp.segs.size(); si++)
 	{
+		std::atomic<uint64_t> streamed_instead(0);
 		const FusedSegment &ps = pp.segs[si];
 		FusedSegment &seg = plan.segs[si];
 		const size_t n_idx = ps.idx.size(), n_par = ps.params.size(), n_gid = ps.gid.size(), n_cid = ps.slot_cid.size(), n_steps = ps.steps.size();
@@ -812,6 +996,7 @@ bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const st
 				FusedTile ft = ps.tiles[t];
 				ft.step_begin += (uint32_t)(k * n_steps); ft.step_end += (uint32_t)(k * n_steps);
 				ft.gid_off += (uint32_t)(k * n_gid);
+				if (ft.tab_f4) ft.tab_off += (uint32_t)(k * n_par / 4);       // (its used size: below, from this instance's records)
 				seg.tiles[(size_t)k * kt + t] = ft;
 			}
 			memcpy(&seg.idx[k * n_idx], ps.idx.data(), n_idx * sizeof(uint16_t));
@@ -843,7 +1028,7 @@ bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const st
 				{
 					const uint32_t i = ps.slot_cid[cid_off0 + q] - base_p;       // position in the prototype's batch
 					cid_dst[q] = base_full + i;
-					if (np_stream)
+					if (np_stream && !st.dict)
 					{
 						const float *rec = recs + (size_t)i * ti->param_stride;
 						for (uint32_t pk = 0; pk < ti->param_stride; pk++)
@@ -851,9 +1036,63 @@ bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const st
 					}
 				}
 			}
+			// dictionary-form steps: this instance's OWN tables (its records differ from the prototype's in their last bits), in the prototype's layout
+			std::vector<std::vector<uint16_t>> entry_of;
+			std::vector<uint8_t> converted;
+			std::vector<float> table;
+			for (uint32_t t = 0; t < kt; t++)
+			{
+				const FusedTile &pt = ps.tiles[t];
+				if (!pt.tab_f4) continue;
+				const FusedStep *psteps = &ps.steps[pt.step_begin];
+				const size_t nst = pt.step_end - pt.step_begin;
+				uint32_t used_f4 = 0;
+				build_tile_dictionary(psteps, nst, plan.views, dict_area_floats() / 4u, false,
+					[&](size_t si) { return psteps[si].dict != 0; },
+					[&](size_t si, uint32_t q, float *out) {
+						const FusedStep &st = psteps[si];
+						const int type = (int)st.type;
+						const TypeInfo *ti = type_info(type);
+						const bool compact = plan.views[type].compact != 0;
+						const uint32_t cid_p = ps.slot_cid[st.cid_off + q];
+						const size_t b = (size_t)(std::upper_bound(pp.batch_base.begin(), pp.batch_base.end(), cid_p) - pp.batch_base.begin()) - 1;
+						const float *rec = batches[b].params + ((size_t)k * proto[b].count + (cid_p - pp.batch_base[b])) * ti->param_stride;
+						for (uint32_t pk = 0; pk < ti->param_stride; pk++)
+							if (param_streams(type, compact, (int)pk)) out[param_plane(type, compact, (int)pk)] = rec[pk];
+					}, entry_of, converted, table, used_f4);
+				for (size_t si = 0; si < nst; si++)
+				{
+					const FusedStep &st0 = psteps[si];
+					if (!st0.dict) continue;
+					FusedStep &mine = seg.steps[k * n_steps + pt.step_begin + si];
+					if (converted[si]) { memcpy(&seg.params[k * n_par + st0.par_off], entry_of[si].data(), (size_t)st0.count * 2); continue; }
+					// this copy's records of the type do not fit a table (or do not repeat): streamed, in the block the prototype kept behind the index area
+					const int type = (int)st0.type;
+					const TypeInfo *ti = type_info(type);
+					const bool compact = plan.views[type].compact != 0;
+					const uint32_t np = (uint32_t)num_planes(type, compact);
+					mine.dict = 0;
+					mine.par_off += dict_step_floats(st0.count);
+					float *dst0 = &seg.params[k * n_par + st0.par_off + dict_step_floats(st0.count)];
+					for (uint32_t q = 0; q < st0.count; q++)
+					{
+						const uint32_t cid_p = ps.slot_cid[st0.cid_off + q];
+						const size_t b = (size_t)(std::upper_bound(pp.batch_base.begin(), pp.batch_base.end(), cid_p) - pp.batch_base.begin()) - 1;
+						const float *rec = batches[b].params + ((size_t)k * proto[b].count + (cid_p - pp.batch_base[b])) * ti->param_stride;
+						for (uint32_t pk = 0; pk < ti->param_stride; pk++)
+							if (param_streams(type, compact, (int)pk)) dst0[param_float_index(seg.vector_params, np, (uint32_t)param_plane(type, compact, (int)pk), q)] = rec[pk];
+					}
+					streamed_instead += (uint64_t)st0.count * (np * 4u - 2u);
+				}
+				if (!table.empty()) memcpy(&seg.params[k * n_par + (size_t)pt.tab_off * 4], table.data(), table.size() * sizeof(float));
+				seg.tiles[(size_t)k * kt + t].tab_f4 = used_f4;
+			}
 		});
+		for (const FusedTile &ft : seg.tiles) seg.max_tab_f4 = std::max(seg.max_tab_f4, ft.tab_f4);
+		seg.stream_bytes += streamed_instead.load();
 	}
 	lap("replicated");
+	if (verbose) print_dictionary_coverage(plan);
 	plan.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 	return true;
 }

@@ -158,13 +158,16 @@ struct FusedStep      // one (colour, type) run of a tile; 32 bytes, read with s
 	uint32_t par_off;     // into the segment's float parameter stream; "wave-tiled" layout: slot q, plane p at
 	                      //   par_off + (q / 64) * (nplanes * 64) + p * 64 + (q % 64)
 	                      // i.e. one wave reads 256 contiguous bytes per plane and the plane offset is an immediate
-	uint32_t par_stride;  // unused (kept for layout stability)
+	uint32_t dict;        // 1: DICTIONARY form -- the step's part of the parameter stream holds one uint16 per slot, the offset (in 16-byte units) of the slot's
+	                      // record in the tile's table of DISTINCT records (FusedTile::tab_off), which the tile stages in LDS with its particles.  A regular
+	                      // mesh repeats a few hundred distinct records (the 1000x1000 cloth: 6 M constraints, < 1 000 distinct bending matrices, 100-250 per
+	                      // tile), so a bending slot streams 2 bytes instead of 40 (dict_type() says which types take the form)
 	uint32_t lam_off;     // into the segment's lambda stream (XPBD types)
 	uint32_t barrier;     // workgroup barrier after this step (last step of a colour)
 	uint32_t cid_off;     // host only: into slot_cid
 };
 
-struct FusedTile      // 36 bytes
+struct FusedTile      // 44 bytes
 {
 	uint32_t step_begin, step_end;
 	uint32_t n_local;     // particles staged in LDS (owned first; among the owned ones the INTERIOR first: see wb_begin)
@@ -172,6 +175,8 @@ struct FusedTile      // 36 bytes
 	uint32_t gid_off;     // into the segment's global-id stream
 	uint32_t slots;       // constraints executed by this tile in this segment
 	uint32_t chunk_begin, chunk_end;   // filled by the engine once the workgroup size is chosen (FusedChunk list)
+	uint32_t tab_off, tab_f4;          // the tile's table of distinct parameter records (dictionary form): offset into the segment's parameter stream and
+	                      // size, both in 16-byte units; records in plane order, padded to whole 16-byte units; 0 / 0 if the tile has none
 	uint32_t wb_begin;    // owned particles [0, wb_begin) are INTERIOR: no other tile stages them in any segment, and this tile's own fill does not
 	                      // re-read them while its owned particles stay in LDS (persistent schedule) -- a pass that is not the last one of its launch
 	                      // writes back only [wb_begin, n_owned).  The same value in every segment (the owned order is shared by all segments).
@@ -204,6 +209,7 @@ struct FusedSegment
 	uint64_t constraints = 0;           // distinct constraints of the segment
 	uint64_t stream_bytes = 0;          // idx + params + 2*lambda bytes per sweep
 	bool vector_params = false;         // form of `params` (param_float_index)
+	uint32_t max_tab_f4 = 0;            // largest table of a tile (LDS next to the particles)
 };
 // rewrites seg.params from one form into the other (a permutation inside every 64-slot block)
 void relayout_params(FusedSegment &seg, const TypeView *views, bool vector_params);
@@ -219,7 +225,17 @@ struct PlanOptions
 	bool owned_stay_in_lds = false;     // persistent schedule: a pass stages only the halo, and a pass boundary is a tile-to-tile hand-off
 	uint32_t threads = 0;               // 0 = auto
 	bool vector_params = false;         // form of the parameter streams (the caller predicts the workgroup size: vector_params_for_block)
+	bool dict_params = false;           // wide, repetitive records go into per-tile dictionaries (FusedStep::dict); the caller reserves kDictTableF4 of max_local
+	bool dict_keep_streams = false;     // (set by build_instanced_plan for its prototype: pbdx_plan.cpp dictionary_pass)
+	uint32_t sizing_local = 0;          // LDS capacity the default tile SIZE is derived from (0: max_local); the caller that reserved LDS for the tables passes
+	                                    // the unreduced capacity, so that the reservation does not change the tile count where the tiles fit anyway
 };
+// types whose records may take the dictionary form: wide (ten and more streamed planes) and, on regular meshes, highly repetitive.  (The FEM / strain
+// records of solids are as repetitive, but their scenes run latency-bound, where three more LDS reads per step cost more than the loads they replace.)
+constexpr bool dict_type(int type) { return is_bending_type(type); }
+constexpr uint32_t kDictTableF4 = 1024;                  // LDS reserved for a tile's table: 16 KiB
+constexpr uint32_t kDictChunkType = 16;                  // chunk type of a dictionary-form step = kDictChunkType + constraint type
+constexpr uint32_t dict_entry_f4(uint32_t planes) { return (planes + 3u) / 4u; }
 
 struct FusedPlan
 {

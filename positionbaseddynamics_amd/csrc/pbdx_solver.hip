@@ -302,16 +302,21 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 #ifndef PBDX_STEP_PROBE
 #define PBDX_STEP_PROBE 0
 #endif
-template <int TYPE, bool COMPACT, int BLOCK, bool COHERENT, bool QUAD_STEP = false>
+// DICT: a run of dictionary-form steps (FusedStep::dict, pbdx_plan.h): a slot streams its indices, its multiplier and ONE uint16 -- the offset of its
+// parameter record in the tile's table of distinct records, which sits in LDS behind the particles (ltab); the record is read from there when the
+// slot is projected.  Same arithmetic on the same values: bit-identical.
+struct RecD { uint32_t w[4]; };          // packed indices (2), multiplier, table offset (16-byte units)
+template <int TYPE, bool COMPACT, int BLOCK, bool COHERENT, bool QUAD_STEP = false, bool DICT = false>
 __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStreams &str, const uint4 *lchunks, uint32_t c0,
-	float4 *lpos, unsigned long long *trace, uint32_t &step_counter, bool &fill_pending)
+	float4 *lpos, unsigned long long *trace, uint32_t &step_counter, bool &fill_pending, const float4 *ltab = nullptr)
 {
+	static_assert(!(DICT && (QUAD_STEP || is_quad_type(TYPE))), "dictionary form: one lane per slot");
 	constexpr int D = Depth<TYPE>::value;
 	constexpr bool VEC = vector_params_for_block(BLOCK);
 	typedef TileAccess<TYPE, COMPACT, COHERENT, VEC> Acc;
 	// quad-lane types (pbdx_quad.h): four lanes share a slot, a chunk holds BLOCK / 4 slots
 	constexpr bool QUAD = QUAD_STEP || is_quad_type(TYPE);
-	typedef typename std::conditional<QUAD, RecQ<TYPE, COMPACT>, Rec<TYPE, COMPACT>>::type RecT;
+	typedef typename std::conditional<DICT, RecD, typename std::conditional<QUAD, RecQ<TYPE, COMPACT>, Rec<TYPE, COMPACT>>::type>::type RecT;
 	// per-lane constants of the run
 	const uint32_t lane_slot = QUAD ? threadIdx.x >> 2 : threadIdx.x;
 	// (parameter block of the lane's 64-slot group: pbdx_plan.h param_float_index -- full segments at 16 bytes per lane, the tail segment after them)
@@ -333,7 +338,15 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 		// its use and waits for ALL outstanding loads, i.e. also for the records requested one step ago, and one step is about one memory latency.)
 		const ChunkS ch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
 		const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, v_tail, a.views[TYPE] };
-		if constexpr (QUAD) load_rec_quad<TYPE, COMPACT>(acc, ql, lane_slot, dst);
+		if constexpr (DICT)
+		{
+			if constexpr (kTwoBodies[TYPE]) { dst.w[0] = acc.idx_raw1(lane_slot); dst.w[1] = 0u; }
+			else { const uint2 v = acc.idx_raw2(lane_slot); dst.w[0] = v.x; dst.w[1] = v.y; }
+			dst.w[2] = 0u;
+			if constexpr (kHasLambda[TYPE]) dst.w[2] = __builtin_bit_cast(uint32_t, acc.lam_load(lane_slot));
+			dst.w[3] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(str.par, (int)(lane_slot * 2u), (int)ch.par_boff, 0);
+		}
+		else if constexpr (QUAD) load_rec_quad<TYPE, COMPACT>(acc, ql, lane_slot, dst);
 		else load_rec<TYPE, COMPACT>(acc, lane_slot, dst);
 		c_ld++;
 	};
@@ -360,7 +373,23 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 			const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, v_tail, a.views[TYPE] };
 			if (lane_slot < chunk_valid(ch.info))
 			{
-				if constexpr (QUAD) exec_rec_quad<TYPE, COMPACT>(acc, ql, cur, lane_slot, a.dt, a.first_iter);
+				if constexpr (DICT)
+				{
+					// the slot's record: indices and multiplier as streamed, the parameter planes from the tile's table
+					Rec<TYPE, COMPACT> full;
+					full.w[0] = cur.w[0]; full.w[1] = cur.w[1]; full.w[2] = cur.w[2];
+					const float4 *e = ltab + cur.w[3];
+#pragma unroll
+					for (uint32_t q4 = 0; q4 < dict_entry_f4(NP); q4++)
+					{
+						const float4 v = e[q4];
+						const uint32_t vw[4] = { __builtin_bit_cast(uint32_t, v.x), __builtin_bit_cast(uint32_t, v.y), __builtin_bit_cast(uint32_t, v.z), __builtin_bit_cast(uint32_t, v.w) };
+#pragma unroll
+						for (uint32_t c4 = 0; c4 < 4u; c4++) if (4u * q4 + c4 < NP) full.w[3u + 4u * q4 + c4] = vw[c4];
+					}
+					exec_rec<TYPE, COMPACT>(acc, full, lane_slot, a.dt, a.first_iter);
+				}
+				else if constexpr (QUAD) exec_rec_quad<TYPE, COMPACT>(acc, ql, cur, lane_slot, a.dt, a.first_iter);
 				else exec_rec<TYPE, COMPACT>(acc, cur, lane_slot, a.dt, a.first_iter);
 			}
 #if PBDX_STEP_PROBE
@@ -402,6 +431,11 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 #define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) { \
 		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending) \
 		                        : run_typed<T, false, BLOCK, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending); } \
+	else { c = num_chunks; } break;
+// a run of dictionary-form steps of type T (chunk type kDictChunkType + T)
+#define PBDX_CASE_DICT(T) case kDictChunkType + T: if constexpr (((MASK >> T) & 1u) && dict_type(T)) { \
+		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT, false, true>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending, ltab) \
+		                        : run_typed<T, false, BLOCK, COHERENT, false, true>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending, ltab); } \
 	else { c = num_chunks; } break;
 // a run of StrainTetConstraint steps in quad form (chunk pseudo-type kQuadStrainChunk)
 #define PBDX_CASE_QUAD_STRAIN case kQuadStrainChunk: if constexpr (((MASK >> PBDX_STRAIN_TET) & 1u) && PBDX_QUAD_STRAIN) { \
@@ -545,6 +579,16 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	str.par = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sg.params), 0, sg.params_bytes, 0x00020000);
 	str.lam = __builtin_amdgcn_make_buffer_rsrc(sg.lambda, 0, sg.lambda_bytes, 0x00020000);
 	const FusedChunk *gchunks = sg.chunks + t.chunk_begin;
+	// the tile's table of distinct parameter records (dictionary-form steps): requested now, written into LDS behind the particles once the fill is through
+	constexpr uint32_t kTabPerThread = kDictTableF4 / (uint32_t)BLOCK;
+	float4 *ltab = lpos + t.n_local;
+	float4 tabv[kTabPerThread];
+	if (t.tab_f4)
+	{
+		const float4 *gtab = reinterpret_cast<const float4 *>(sg.params) + t.tab_off;
+#pragma unroll
+		for (uint32_t k = 0; k < kTabPerThread; k++) { const uint32_t i = threadIdx.x + k * BLOCK; tabv[k] = gtab[i < t.tab_f4 ? i : 0u]; }
+	}
 	const TileFill<BLOCK, COHERENT> fill = { reinterpret_cast<const uint4 *>(gchunks), gid, pos_in, lchunks, lpos, num_chunks, t.n_local,
 		keep_owned ? (t.n_owned & ~63u) : 0u, trace };
 	bool staged = false;
@@ -555,6 +599,12 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			staged = true;
 		}
 	if (!staged) fill(wait);
+	if (t.tab_f4)
+	{
+#pragma unroll
+		for (uint32_t k = 0; k < kTabPerThread; k++) { const uint32_t i = threadIdx.x + k * BLOCK; if (i < t.tab_f4) ltab[i] = tabv[k]; }
+		__syncthreads();
+	}
 	bool fill_pending = PBDX_DEFER_FILL_WAIT != 0 && !staged;
 	// chunks are addressed relative to the tile from here on (they sit at lchunks[0 .. num_chunks))
 	uint32_t c = 0, step_counter = 0;
@@ -569,6 +619,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			PBDX_CASE(PBDX_FEM_TET) PBDX_CASE(PBDX_FEM_TET_XPBD) PBDX_CASE(PBDX_STRAIN_TET)
 			PBDX_CASE(PBDX_SHAPE_MATCHING)
 			PBDX_CASE_QUAD_STRAIN
+			PBDX_CASE_DICT(PBDX_ISOMETRIC_BENDING) PBDX_CASE_DICT(PBDX_ISOMETRIC_BENDING_XPBD)
 		default: c = num_chunks; break;
 		}
 	}
@@ -1450,6 +1501,10 @@ int ensure_plan(pbdx_solver *s)
 		const bool small_scene = (uint64_t)s->n <= (uint64_t)std::max(1, s->prop.multiProcessorCount) * 512u;
 		opt.vector_params = (s->fuse_block == 256 || s->fuse_block == 512 || s->fuse_block == 1024) ? vector_params_for_block(s->fuse_block)
 			: ((mask & ~kMaskLight) != 0 || small_scene);
+		// dictionary form of the bending records (pbdx_plan.h dict_type): where the sweep is bandwidth-bound, i.e. the scenes that run 1 024 threads
+		// (PBDX_NO_DICT: developer A/B switch)
+		opt.dict_params = !opt.vector_params && !getenv("PBDX_NO_DICT") && opt.max_local > 2u * kDictTableF4;
+		if (opt.dict_params) { opt.sizing_local = opt.max_local; opt.max_local -= kDictTableF4; }
 	}
 	bool planned = false;
 	if (s->inst_count > 1 && (uint64_t)s->inst_particles * s->inst_count == s->n)
@@ -1522,9 +1577,9 @@ int ensure_plan(pbdx_solver *s)
 					const uint32_t valid = std::min<uint32_t>(cap, st.count - first);
 					const bool last = (k + 1 == nchunks);
 					FusedChunk c;
-					c.info = (quad_step ? kQuadStrainChunk : st.type) | ((last && st.barrier) ? 0x40u : 0u) | (last ? 0x80u : 0u) | (valid << 8);
+					c.info = (st.dict ? kDictChunkType + st.type : quad_step ? kQuadStrainChunk : st.type) | ((last && st.barrier) ? 0x40u : 0u) | (last ? 0x80u : 0u) | (valid << 8);
 					c.idx_boff = st.idx_off * 2u + first * slot_idx_bytes;
-					c.par_boff = (st.par_off + (first / 64u) * nplanes * 64u) * 4u;
+					c.par_boff = st.dict ? st.par_off * 4u + first * 2u : (st.par_off + (first / 64u) * nplanes * 64u) * 4u;       // (dictionary form: one uint16 per slot)
 					c.lam_boff = (st.lam_off + first) * 4u;
 					chunks.push_back(c);
 				}
@@ -1568,7 +1623,7 @@ int ensure_plan(pbdx_solver *s)
 		d.params_bytes = (uint32_t)(seg.params.size() * sizeof(float));
 		d.lambda_bytes = (uint32_t)((size_t)seg.lam_count * sizeof(float));
 		d.num_tiles = (uint32_t)seg.tiles.size();
-		d.lds_bytes = std::max(seg.max_local, 1u) * 16u + kMaxTileChunks * 16u;
+		d.lds_bytes = (std::max(seg.max_local, 1u) + seg.max_tab_f4) * 16u + kMaxTileChunks * 16u;       // (+ the largest dictionary table of a tile)
 		d.type_mask = seg.type_mask;
 		d.constraints = seg.constraints;
 		for (const PlanBatch &pb : pbs)
@@ -2599,6 +2654,8 @@ int pbdx_solver_commit_params(pbdx_solver *s)
 		if (views[t].compact != s->plan.views[t].compact) same_layout = false;
 	}
 	if (!same_layout) { s->free_plan(); return PBDX_OK; }
+	// dictionary-form steps index tables of DISTINCT records: new parameter values mean new tables -- the plan is rebuilt by the next step
+	for (const FusedSegment &seg : s->plan.segs) if (seg.max_tab_f4) { s->free_plan(); return PBDX_OK; }
 	for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++) s->plan.views[t] = views[t];
 	for (size_t si = 0; si < s->plan.segs.size(); si++)
 	{

@@ -186,6 +186,9 @@ int pbdx_model_plan_check(pbdx_model *m, uint32_t tile_particles, uint32_t lds_p
 	opt.tile_particles = tile_particles;
 	if (lds_particles) opt.max_local = lds_particles;
 	if (max_segment_colours) opt.max_segment_colours = max_segment_colours;
+	// (the dictionary form of the wide records is planned here too, so that check_fused_plan compares every slot's table entry with its constraint)
+	opt.dict_params = !getenv("PBDX_NO_DICT") && opt.max_local > 2u * kDictTableF4;
+	if (opt.dict_params) { opt.sizing_local = opt.max_local; opt.max_local -= kDictTableF4; }
 	FusedPlan plan;
 	std::string why;
 	if (m->inst_count > 1)
