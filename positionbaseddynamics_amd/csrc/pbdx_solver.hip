@@ -582,12 +582,15 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	// the tile's table of distinct parameter records (dictionary-form steps): requested now, written into LDS behind the particles once the fill is through
 	constexpr uint32_t kTabPerThread = kDictTableF4 / (uint32_t)BLOCK;
 	float4 *ltab = lpos + t.n_local;
-	float4 tabv[kTabPerThread];
+	static_assert(kTabPerThread >= 1 && kTabPerThread <= 4, "table staging: up to four 16-byte units per thread");
+	float4 tabv0 = make_float4(0.f, 0.f, 0.f, 0.f), tabv1 = tabv0, tabv2 = tabv0, tabv3 = tabv0;      // (named, not an array: registers)
 	if (t.tab_f4)
 	{
 		const float4 *gtab = reinterpret_cast<const float4 *>(sg.params) + t.tab_off;
-#pragma unroll
-		for (uint32_t k = 0; k < kTabPerThread; k++) { const uint32_t i = threadIdx.x + k * BLOCK; tabv[k] = gtab[i < t.tab_f4 ? i : 0u]; }
+		const uint32_t lastf4 = t.tab_f4 - 1u, i0 = threadIdx.x;
+		tabv0 = gtab[i0 < lastf4 ? i0 : lastf4];
+		if constexpr (kTabPerThread > 1) tabv1 = gtab[i0 + BLOCK < lastf4 ? i0 + BLOCK : lastf4];
+		if constexpr (kTabPerThread > 2) { tabv2 = gtab[i0 + 2 * BLOCK < lastf4 ? i0 + 2 * BLOCK : lastf4]; tabv3 = gtab[i0 + 3 * BLOCK < lastf4 ? i0 + 3 * BLOCK : lastf4]; }
 	}
 	const TileFill<BLOCK, COHERENT> fill = { reinterpret_cast<const uint4 *>(gchunks), gid, pos_in, lchunks, lpos, num_chunks, t.n_local,
 		keep_owned ? (t.n_owned & ~63u) : 0u, trace };
@@ -601,8 +604,10 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	if (!staged) fill(wait);
 	if (t.tab_f4)
 	{
-#pragma unroll
-		for (uint32_t k = 0; k < kTabPerThread; k++) { const uint32_t i = threadIdx.x + k * BLOCK; if (i < t.tab_f4) ltab[i] = tabv[k]; }
+		const uint32_t i0 = threadIdx.x;
+		if (i0 < t.tab_f4) ltab[i0] = tabv0;
+		if constexpr (kTabPerThread > 1) { if (i0 + BLOCK < t.tab_f4) ltab[i0 + BLOCK] = tabv1; }
+		if constexpr (kTabPerThread > 2) { if (i0 + 2 * BLOCK < t.tab_f4) ltab[i0 + 2 * BLOCK] = tabv2; if (i0 + 3 * BLOCK < t.tab_f4) ltab[i0 + 3 * BLOCK] = tabv3; }
 		__syncthreads();
 	}
 	bool fill_pending = PBDX_DEFER_FILL_WAIT != 0 && !staged;

@@ -727,6 +727,57 @@ def test_persistent_schedule_auto_mode_reports_its_measurement(pbd):
     assert info["active"] == (1 if info["autotune_persistent_ms"] < 1.02 * info["autotune_fused_ms"] else 0)
 
 
+def test_dictionary_form_of_the_bending_records(pbd):
+    """Scenes that run 1 024-thread workgroups keep a tile's DISTINCT bending records in LDS and stream one uint16 per slot
+    (pbdx_plan.h FusedStep::dict).  Same values, same arithmetic: bit-identical to the plan without the form (PBDX_NO_DICT), to the
+    per-colour schedule, and the streams shrink; a run-time edit of streamed parameters (new rest lengths AND new bending matrices, so that
+    the tables change) takes effect as in a model built with the edited values."""
+    S = pbd.Solver
+    ops = util.cloth_spec(400, 400, 4, 3)                      # 160 000 particles: more than 512 per CU
+
+    def run(nodict, edit, steps=2, fuse=1):
+        if nodict:
+            os.environ["PBDX_NO_DICT"] = "1"
+        else:
+            os.environ.pop("PBDX_NO_DICT", None)
+        try:
+            m = util.build_mine(ops)
+            pbd.TimeManager.setCurrent(pbd.TimeManager())
+            ts = pbd.TimeStepController()
+            ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+            ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 4)
+            ts.solver().set_option(S.OPT_FUSE, fuse)
+            for _ in range(steps):
+                ts.step(m)
+            if edit:
+                nc = m.numConstraints()
+                for c in list(range(0, 3000, 11)) + list(range(nc - 3000, nc, 13)):       # distance constraints first, bending constraints last
+                    p = m.constraintParams(c)
+                    if len(p) == 2:
+                        p[0] = p[0] * np.float32(1.01)       # rest length
+                    else:
+                        p[1:] = p[1:] * np.float32(0.5)      # Q
+                    m.setConstraintParams(c, p)
+                for _ in range(steps):
+                    ts.step(m)
+            info = ts.solver().plan_info() if fuse else None
+            return m, info
+        finally:
+            os.environ.pop("PBDX_NO_DICT", None)
+
+    for edit in (False, True):
+        ma, ia = run(False, edit)
+        mb, ib = run(True, edit)
+        mc, _ = run(False, edit, fuse=0)
+        assert ia["active"] == 1 and ib["active"] == 1
+        assert ia["stream_bytes_per_sweep"] < 0.6 * ib["stream_bytes_per_sweep"], (ia, ib)
+        for which in (0, 2, 4, 5):
+            assert util.bitwise_equal(ma.getParticles().array(which), mb.getParticles().array(which)), (edit, which)
+            assert util.bitwise_equal(ma.getParticles().array(which), mc.getParticles().array(which)), (edit, which)
+        print("400x400 cloth, %s: dictionary form == streamed == per-colour; streams %.1f vs %.1f MB per sweep" % (
+            "parameters edited between the steps" if edit else "as built", ia["stream_bytes_per_sweep"] / 1e6, ib["stream_bytes_per_sweep"] / 1e6))
+
+
 def test_parameter_edit_between_resident_steps_keeps_the_device_state(pbd):
     """after stepResident the device is ahead of the host mirror; a constraint-parameter edit, a setMass or a
     write of ONE host array must not roll the simulation back to the stale mirror.  Ground truth: host-authoritative stepping."""
