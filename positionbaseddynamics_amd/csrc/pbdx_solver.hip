@@ -1506,9 +1506,9 @@ int ensure_plan(pbdx_solver *s)
 		const bool small_scene = (uint64_t)s->n <= (uint64_t)std::max(1, s->prop.multiProcessorCount) * 512u;
 		opt.vector_params = (s->fuse_block == 256 || s->fuse_block == 512 || s->fuse_block == 1024) ? vector_params_for_block(s->fuse_block)
 			: ((mask & ~kMaskLight) != 0 || small_scene);
-		// dictionary form of the bending records (pbdx_plan.h dict_type): where the sweep is bandwidth-bound, i.e. the scenes that run 1 024 threads
-		// (PBDX_NO_DICT: developer A/B switch)
-		opt.dict_params = !opt.vector_params && !getenv("PBDX_NO_DICT") && opt.max_local > 2u * kDictTableF4;
+		// dictionary form of the bending records (pbdx_plan.h dict_type; PBDX_NO_DICT: developer A/B switch).  Worth most where the sweep is
+		// bandwidth-bound (1 M cloth -15 %, configs[3] block -17 %), still 4-8 % on 200x200 ... 360x360 cloths, nothing at 100x100 (profiles/r03z_*)
+		opt.dict_params = !getenv("PBDX_NO_DICT") && opt.max_local > 2u * kDictTableF4;
 		if (opt.dict_params) { opt.sizing_local = opt.max_local; opt.max_local -= kDictTableF4; }
 	}
 	bool planned = false;
