@@ -3,6 +3,7 @@
 #include "pbdx_internal.h"
 #include "../../include/pbdx_debug.h"
 #include <algorithm>
+#include <memory>
 #include <atomic>
 #include <chrono>
 #include <stdio.h>
@@ -185,7 +186,11 @@ struct TileOut
 	uint32_t slots = 0;
 	uint64_t stream_bytes = 0;
 	uint32_t tab_off = 0, tab_f4 = 0;       // dictionary form: the tile's table inside `params` (float offset) and its used size (16-byte units)
+	// while the tile is being built: the distinct records of its dictionary candidates by type, and the candidate steps (slot -> record)
+	std::unique_ptr<struct RecordTable> tables[PBDX_NUM_CONSTRAINT_TYPES];
+	std::vector<struct DeferredStep> deferred;
 };
+struct DeferredStep { size_t step = 0; std::vector<uint32_t> entry; };
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
@@ -298,47 +303,63 @@ void print_dictionary_coverage(const FusedPlan &plan)
 		(unsigned long long)conv, (unsigned long long)cand, (unsigned long long)tabs, (unsigned long long)tiles, max_tab);
 }
 
-// planning: convert the steps of a freshly built tile (parameter stream in the `vec` form) where it pays
-// keep_streams (prototype of an instanced plan): a converted step keeps its streamed block BEHIND its index area, so that a copy whose records do not
-// fit a table can fall back to streaming them inside the same layout
-void dictionary_pass(TileOut &o, const TypeView *views, bool vec, bool keep_streams)
+// planning: the tile is complete -- what its dictionary candidates become.  A type takes the form if its distinct records fit what is left of the
+// table and repeat at least four times on average; its steps then hold one uint16 per slot (keep_streams -- the prototype of an instanced plan --: and
+// the streamed block behind it, so that a copy whose records do not fit can fall back inside the same layout); otherwise they are streamed like any other.
+void dictionary_finish(TileOut &o, const TypeView *views, bool vec, bool keep_streams)
 {
-	std::vector<std::vector<uint16_t>> entry_of;
-	std::vector<uint8_t> converted;
+	if (o.deferred.empty()) return;
+	uint32_t used_f4 = 0, base_of[PBDX_NUM_CONSTRAINT_TYPES];
+	bool converted[PBDX_NUM_CONSTRAINT_TYPES] = {};
+	uint64_t slots_of[PBDX_NUM_CONSTRAINT_TYPES] = {};
+	for (const DeferredStep &d : o.deferred) slots_of[o.steps[d.step].type] += o.steps[d.step].count;
 	std::vector<float> table;
-	uint32_t used_f4 = 0;
-	build_tile_dictionary(o.steps.data(), o.steps.size(), views, kDictTableF4, false,
-		[&](size_t si) { return dict_type((int)o.steps[si].type) && num_planes((int)o.steps[si].type, views[o.steps[si].type].compact != 0) >= 4; },
-		[&](size_t si, uint32_t q, float *out) {
-			const FusedStep &st = o.steps[si];
-			const uint32_t np = (uint32_t)num_planes((int)st.type, views[st.type].compact != 0);
-			for (uint32_t p = 0; p < np; p++) out[p] = o.params[st.par_off + param_float_index(vec, np, p, q)];
-		}, entry_of, converted, table, used_f4);
-	if (!used_f4) return;
-	std::vector<float> out;
-	out.reserve(o.params.size());
-	for (size_t si = 0; si < o.steps.size(); si++)
+	for (int type = 0; type < PBDX_NUM_CONSTRAINT_TYPES; type++)
 	{
-		FusedStep &st = o.steps[si];
-		const uint32_t np = (uint32_t)num_planes((int)st.type, views[st.type].compact != 0);
-		const uint32_t old_off = st.par_off, old_floats = ((st.count + 63u) / 64u) * np * 64u;
-		st.par_off = (uint32_t)out.size();
-		if (converted[si])
+		const RecordTable *rt = o.tables[type].get();
+		if (!rt || !rt->size()) continue;
+		const uint32_t np = rt->words, ef4 = dict_entry_f4(np);
+		const uint64_t need = (uint64_t)rt->size() * ef4;
+		if (used_f4 + need > kDictTableF4 || slots_of[type] < 4ull * rt->size()) continue;
+		converted[type] = true;
+		base_of[type] = used_f4;
+		table.resize((size_t)(used_f4 + need) * 4, 0.0f);
+		for (uint32_t e = 0; e < rt->size(); e++) memcpy(&table[((size_t)used_f4 + (size_t)e * ef4) * 4], &rt->keys[(size_t)e * np], np * 4);
+		used_f4 += (uint32_t)need;
+	}
+	for (const DeferredStep &d : o.deferred)
+	{
+		FusedStep &st = o.steps[d.step];
+		const RecordTable &rt = *o.tables[st.type];
+		const uint32_t np = rt.words, groups64 = (st.count + 63) / 64;
+		st.par_off = (uint32_t)o.params.size();
+		if (converted[st.type])
 		{
 			st.dict = 1;
-			out.resize(out.size() + dict_step_floats(st.count), 0.0f);
-			memcpy(&out[st.par_off], entry_of[si].data(), (size_t)st.count * 2);
+			o.params.resize(o.params.size() + dict_step_floats(st.count), 0.0f);
+			uint16_t *ix = reinterpret_cast<uint16_t *>(&o.params[st.par_off]);
+			for (uint32_t q = 0; q < st.count; q++) ix[q] = (uint16_t)(base_of[st.type] + d.entry[q] * dict_entry_f4(np));
 			o.stream_bytes -= (uint64_t)st.count * (np * 4u - 2u);
-			if (keep_streams) out.insert(out.end(), o.params.begin() + old_off, o.params.begin() + old_off + old_floats);
+			if (!keep_streams) continue;
 		}
-		else
-			out.insert(out.end(), o.params.begin() + old_off, o.params.begin() + old_off + old_floats);
+		// streamed block (a type that did not convert; or the fallback block of an instanced prototype), from the table's records
+		const size_t off = o.params.size();
+		o.params.resize(off + (size_t)groups64 * np * 64, 0.0f);
+		for (uint32_t q = 0; q < st.count; q++)
+		{
+			const uint32_t *r = &rt.keys[(size_t)d.entry[q] * np];
+			for (uint32_t pl = 0; pl < np; pl++) memcpy(&o.params[off + param_float_index(vec, np, pl, q)], &r[pl], 4);
+		}
 	}
-	o.tab_off = (uint32_t)out.size();
-	o.tab_f4 = used_f4;
-	out.resize(out.size() + dict_area_floats(), 0.0f);
-	memcpy(&out[o.tab_off], table.data(), table.size() * sizeof(float));
-	o.params.swap(out);
+	if (used_f4)
+	{
+		o.tab_off = (uint32_t)o.params.size();
+		o.tab_f4 = used_f4;
+		o.params.resize(o.params.size() + dict_area_floats(), 0.0f);
+		memcpy(&o.params[o.tab_off], table.data(), table.size() * sizeof(float));
+	}
+	o.deferred.clear();
+	for (auto &t : o.tables) t.reset();
 }
 
 } // namespace
@@ -582,6 +603,9 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 		}
 	}
 
+	const bool verbose_build = getenv("PBDX_PLAN_VERBOSE") != nullptr;
+	auto lap_build = [&](const char *what) { if (verbose_build) fprintf(stderr, "[plan] %-24s %7.3f s since start\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
+	lap_build("segments, boundary split");
 	// ---- full build ----------------------------------------------------------------------------
 	uint64_t slots_total = 0;
 	for (size_t si = 0; si < todo.size(); si++)
@@ -643,7 +667,31 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 					st.cid_off = (uint32_t)o.slot_cid.size();
 					const uint32_t iw = ti->num_bodies == 2 ? 2 : 4;
 					o.idx.resize(o.idx.size() + round_up(st.count * iw, 8), 0);
-					o.params.resize(o.params.size() + (size_t)groups64 * np_stream * 64, 0.0f);
+					// where parameter p of slot (64 g + l) goes: par_off + g * np * 64 + pa[p] + l * pb_[p] (param_float_index, resolved once per step)
+					int plane_of[PBDX_MAX_PARAMS];
+					uint32_t pa[PBDX_MAX_PARAMS], pb_[PBDX_MAX_PARAMS];
+					for (uint32_t p = 0; p < ti->param_stride; p++)
+					{
+						plane_of[p] = param_streams(pb.type, v.compact != 0, (int)p) ? param_plane(pb.type, v.compact != 0, (int)p) : -1;
+						if (plane_of[p] < 0) continue;
+						pa[p] = (uint32_t)param_float_index(opt.vector_params, np_stream, (uint32_t)plane_of[p], 0);
+						pb_[p] = (uint32_t)param_float_index(opt.vector_params, np_stream, (uint32_t)plane_of[p], 1) - pa[p];
+					}
+					// dictionary candidates (pbdx_plan.h dict_type) are not written yet: their records go into the tile's table of distinct records, and
+					// what the step's part of the stream holds is decided when the tile is complete (dictionary_finish)
+					const bool candidate = opt.dict_params && dict_type(pb.type) && np_stream >= 4;
+					DeferredStep *def = nullptr;
+					if (candidate)
+					{
+						if (!o.tables[pb.type]) o.tables[pb.type].reset(new RecordTable(np_stream));
+						o.deferred.emplace_back();
+						def = &o.deferred.back();
+						def->step = o.steps.size();
+						def->entry.resize(st.count);
+					}
+					else
+						o.params.resize(o.params.size() + (size_t)groups64 * np_stream * 64, 0.0f);
+					uint32_t rec[PBDX_MAX_PARAMS];
 					for (size_t q = a; q < e; q++)
 					{
 						const uint32_t cid = bk[q];
@@ -651,10 +699,18 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 						const uint32_t slot = (uint32_t)(q - a);
 						for (uint32_t j = 0; j < ti->num_bodies; j++)
 							o.idx[st.idx_off + slot * iw + j] = (uint16_t)s.local_of[pb.idx[(size_t)i * ti->num_bodies + j]];
-						for (uint32_t p = 0; p < ti->param_stride; p++)
-							if (param_streams(pb.type, v.compact != 0, (int)p))
-								o.params[st.par_off + param_float_index(opt.vector_params, np_stream, (uint32_t)param_plane(pb.type, v.compact != 0, (int)p), slot)] =
-									pb.params[(size_t)i * ti->param_stride + p];
+						const float *src = pb.params + (size_t)i * ti->param_stride;
+						if (candidate)
+						{
+							for (uint32_t p = 0; p < ti->param_stride; p++) if (plane_of[p] >= 0) memcpy(&rec[plane_of[p]], &src[p], 4);
+							def->entry[slot] = o.tables[pb.type]->find_or_add(rec);
+						}
+						else
+						{
+							float *dst = &o.params[st.par_off + (size_t)(slot / 64) * np_stream * 64];
+							const uint32_t l = slot % 64;
+							for (uint32_t p = 0; p < ti->param_stride; p++) if (plane_of[p] >= 0) dst[pa[p] + l * pb_[p]] = src[p];
+						}
 						o.slot_cid.push_back(cid);
 					}
 					if (ti->xpbd) o.lam_count += round_up(st.count, 4);
@@ -664,7 +720,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 					a = e;
 				}
 			}
-			if (opt.dict_params) dictionary_pass(o, plan.views, opt.vector_params, opt.dict_keep_streams);
+			if (opt.dict_params) dictionary_finish(o, plan.views, opt.vector_params, opt.dict_keep_streams);
 		});
 		if (worst.load() > opt.max_local)
 		{
@@ -676,6 +732,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 			si--;
 			continue;
 		}
+		lap_build("tiles of a segment built");
 		plan.segs.emplace_back();
 		FusedSegment &seg = plan.segs.back();
 		seg.colour_begin = c0;
@@ -722,6 +779,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 			seg.stream_bytes += o.stream_bytes;
 		}
 		slots_total += seg.slots;
+		lap_build("segment assembled");
 	}
 	plan.redundancy = g.nc ? (double)slots_total / (double)g.nc : 1.0;
 	plan.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
