@@ -230,9 +230,13 @@ struct PlanOptions
 	uint32_t sizing_local = 0;          // LDS capacity the default tile SIZE is derived from (0: max_local); the caller that reserved LDS for the tables passes
 	                                    // the unreduced capacity, so that the reservation does not change the tile count where the tiles fit anyway
 };
-// types whose records may take the dictionary form: wide (ten and more streamed planes) and, on regular meshes, highly repetitive.  (The FEM / strain
-// records of solids are as repetitive, but their scenes run latency-bound, where three more LDS reads per step cost more than the loads they replace.)
-constexpr bool dict_type(int type) { return is_bending_type(type); }
+// types whose records may take the dictionary form: wide (ten and more streamed planes) and, on regular meshes, highly repetitive -- the bending
+// matrices, and the FEM tets' rest volume + Dm^-1 (100 k-tet bar: 92 % of the slots convert, 0.600 -> 0.581 ms; PBDX_DICT_FEM=0: A/B builds).  Not the
+// strain tets: their steps may run in quad form (pbdx_quad.h), where every lane fetches the record itself.
+#ifndef PBDX_DICT_FEM
+#define PBDX_DICT_FEM 1
+#endif
+constexpr bool dict_type(int type) { return is_bending_type(type) || (PBDX_DICT_FEM != 0 && (type == 9 || type == 10) && !is_quad_type(type)); }
 constexpr uint32_t kDictTableF4 = 1024;                  // LDS reserved for a tile's table: 16 KiB
 constexpr uint32_t kDictChunkType = 16;                  // chunk type of a dictionary-form step = kDictChunkType + constraint type
 constexpr uint32_t dict_entry_f4(uint32_t planes) { return (planes + 3u) / 4u; }

@@ -624,7 +624,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			PBDX_CASE(PBDX_FEM_TET) PBDX_CASE(PBDX_FEM_TET_XPBD) PBDX_CASE(PBDX_STRAIN_TET)
 			PBDX_CASE(PBDX_SHAPE_MATCHING)
 			PBDX_CASE_QUAD_STRAIN
-			PBDX_CASE_DICT(PBDX_ISOMETRIC_BENDING) PBDX_CASE_DICT(PBDX_ISOMETRIC_BENDING_XPBD)
+			PBDX_CASE_DICT(PBDX_ISOMETRIC_BENDING) PBDX_CASE_DICT(PBDX_ISOMETRIC_BENDING_XPBD) PBDX_CASE_DICT(PBDX_FEM_TET) PBDX_CASE_DICT(PBDX_FEM_TET_XPBD)
 		default: c = num_chunks; break;
 		}
 	}
