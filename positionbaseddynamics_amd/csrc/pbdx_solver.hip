@@ -2659,8 +2659,32 @@ int pbdx_solver_commit_params(pbdx_solver *s)
 		if (views[t].compact != s->plan.views[t].compact) same_layout = false;
 	}
 	if (!same_layout) { s->free_plan(); return PBDX_OK; }
-	// dictionary-form steps index tables of DISTINCT records: new parameter values mean new tables -- the plan is rebuilt by the next step
-	for (const FusedSegment &seg : s->plan.segs) if (seg.max_tab_f4) { s->free_plan(); return PBDX_OK; }
+	// dictionary-form steps index tables of DISTINCT records: if a record that sits in a table changed (a streamed parameter: a rest geometry entry),
+	// the tables are stale and the plan is rebuilt by the next step; scalar edits (stiffnesses of the compact layout) leave them as they are
+	for (const FusedSegment &seg : s->plan.segs)
+	{
+		if (!seg.max_tab_f4) continue;
+		for (const FusedTile &t : seg.tiles)
+			for (uint32_t si2 = t.step_begin; si2 < t.step_end; si2++)
+			{
+				const FusedStep &st = seg.steps[si2];
+				if (!st.dict) continue;
+				const int type = (int)st.type;
+				const TypeInfo *ti = type_info(type);
+				const bool compact = s->plan.views[type].compact != 0;
+				const uint16_t *entry = reinterpret_cast<const uint16_t *>(&seg.params[st.par_off]);
+				for (uint32_t q = 0; q < st.count; q++)
+				{
+					const uint32_t cid = seg.slot_cid[st.cid_off + q];
+					const size_t pos = (size_t)(std::upper_bound(s->plan.batch_base.begin(), s->plan.batch_base.end(), cid) - s->plan.batch_base.begin()) - 1;
+					const Batch &b = s->batches[s->order[pos]];
+					const float *rec = b.h_params.data() + (size_t)(cid - s->plan.batch_base[pos]) * ti->param_stride;
+					const float *have = &seg.params[((size_t)t.tab_off + entry[q]) * 4];
+					for (uint32_t k = 0; k < ti->param_stride; k++)
+						if (param_streams(type, compact, (int)k) && memcmp(&have[param_plane(type, compact, (int)k)], &rec[k], 4)) { s->free_plan(); return PBDX_OK; }
+				}
+			}
+	}
 	for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++) s->plan.views[t] = views[t];
 	for (size_t si = 0; si < s->plan.segs.size(); si++)
 	{
@@ -2671,7 +2695,7 @@ int pbdx_solver_commit_params(pbdx_solver *s)
 			const TypeInfo *ti = type_info(type);
 			const bool compact = s->plan.views[type].compact != 0;
 			const uint32_t np_stream = (uint32_t)num_planes(type, compact);
-			if (!np_stream) continue;
+			if (!np_stream || st.dict) continue;       // (dictionary form: checked above, nothing to rewrite)
 			for (uint32_t q = 0; q < st.count; q++)
 			{
 				const uint32_t cid = seg.slot_cid[st.cid_off + q];
