@@ -17,9 +17,11 @@
 //      ONE launch: a workgroup stages the dependency closure of its tile of particles in LDS
 //      (float4 per particle, up to 160 KiB), sweeps its constraints colour by colour with a
 //      workgroup barrier between colours and writes back the particles it owns.  Per slot it
-//      streams 16-bit tile-local indices, the planar parameter records and the XPBD multiplier
-//      once from HBM; positions never leave the CU during the segment.  A 27-colour cloth sweep
-//      becomes 2-4 launches instead of 29.
+//      streams 16-bit tile-local indices, the parameter record (planes, or vector segments for
+//      workgroups up to 512 threads; wide records that repeat on regular meshes -- bending matrices,
+//      FEM rest geometry -- as a 2-byte offset into the tile's table of distinct records, which sits
+//      in LDS behind the particles: pbdx_plan.h) and the XPBD multiplier once from HBM; positions
+//      never leave the CU during the segment.  A 27-colour cloth sweep becomes 2-4 launches instead of 29.
 //  (A') the same tiles and passes as ONE persistent launch per substep: a tile starts its next pass as
 //      soon as its neighbouring tiles have published theirs (persistent_kernel; default where measured
 //      faster; needs every workgroup resident, checked by a handshake before anything is modified).
