@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""pyPBD/examples/cloth_model.py of the reference through a COMPILED pypbd module, on the MI355X engine.
+"""pyPBD/examples/cloth_model.py of the reference through the reference's OWN python package, on the MI355X engine.
 
-`import pypbd as pbd` here is positionbaseddynamics_amd/plugin/_build/pypbd*.so: the reference's own classes bound
-with pybind11 under pypbd's names (a reduced pypbd -- the full one needs Discregrid, which is not in the tree) plus the ONE
-class the drop-in adds: `pbd.TimeStepControllerHIP`.  The scene-building and stepping code is the reference example's
-(pyPBD/examples/cloth_model.py:18-110; viewer removed); the three marked lines install the GPU time step exactly as the
-reference installs a custom time step (Demos/PositionBasedElasticRodsDemo/PositionBasedElasticRodsDemo.cpp:51-54).
-    python examples/cloth_model_pypbd.py [--cpu]      # --cpu: leave the reference's own TimeStepController in place
+`import pypbd as pbd` here is positionbaseddynamics_amd/plugin/_build/pypbd*.so: the reference's pyPBD/*.cpp compiled
+UNMODIFIED (plugin/Makefile; Discregrid replaced by a compile-only shim) plus the ONE class the drop-in adds,
+`pbd.TimeStepControllerHIP` (plugin/TimeStepHIPModule.cpp).  The scene-building and stepping code is the reference
+example's (pyPBD/examples/cloth_model.py:18-110; the pygame / OpenGL viewer removed); the marked lines install the GPU time
+step the way the reference installs a custom time step (Demos/PositionBasedElasticRodsDemo/PositionBasedElasticRodsDemo.cpp:51-54).
+    python examples/cloth_model_pypbd.py [--cpu]      # --cpu: the reference's own TimeStepController
 """
 import math
 import os
@@ -33,12 +33,24 @@ def rotation_matrix(angle, axis):
                      [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]])
 
 
+_keep = []
+
+
+def installTimeStep(gpu):
+    sim = pbd.Simulation.getCurrent()
+    cd = sim.getTimeStep().getCollisionDetection()      # initDefault() gave the default time step a collision detection
+    ts = pbd.TimeStepControllerHIP() if gpu else pbd.TimeStepController()      # <-- the drop-in: the class name ...
+    ts.init()                                                                  # <--
+    ts.setCollisionDetection(sim.getModel(), cd)                               # <-- (what initDefault did for the old one)
+    sim.setTimeStep(ts)                                                        # <-- ... installed like any custom time step
+    if not gpu:
+        _keep.append(ts)      # pypbd's own TimeStepController is python-owned (pyPBD/TimeStepModule.cpp:30): keep it alive
+
+
 def buildModel(simModel=2, bendingModel=2, gpu=True):
     sim = pbd.Simulation.getCurrent()
     sim.initDefault()
-    ts = pbd.TimeStepControllerHIP() if gpu else pbd.TimeStepController()      # <-- the drop-in: the class name ...
-    sim.setTimeStep(ts)                                                        # <-- ... installed like any custom time step
-    ts.init()                                                                  # <--
+    installTimeStep(gpu)
     createMesh(simModel, bendingModel)
     ts = sim.getTimeStep()
     ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 3)

@@ -36,45 +36,55 @@ namespace
 		return -1;
 	}
 
-	template <typename M> void pushColMajor(std::vector<float> &p, const M &m, int rows, int cols)
+	// The parameter record of a constraint in the layout of include/pbdx.h, handed float by float to a sink: the same walk fills
+	// the engine's parameter arrays (PushSink) and feeds the exact parameter scan (HashSink) -- one definition of "what the engine
+	// was given", so the scan cannot miss a field the upload reads.
+	template <class Sink, typename M> inline void visitColMajor(Sink &p, const M &m, int rows, int cols)
 	{
-		for (int c = 0; c < cols; c++) for (int r = 0; r < rows; r++) p.push_back((float)m(r, c));
+		for (int c = 0; c < cols; c++) for (int r = 0; r < rows; r++) p((float)m(r, c));
 	}
-
-	// parameter record in the layout of include/pbdx.h
-	void pushParams(std::vector<float> &p, int type, Constraint *c)
+	template <class Sink> inline void visitParams(Sink &p, int type, Constraint *c)
 	{
 		switch (type)
 		{
-		case PBDX_DISTANCE: { auto *k = (DistanceConstraint*)c; p.push_back((float)k->m_restLength); p.push_back((float)k->m_stiffness); break; }
-		case PBDX_DISTANCE_XPBD: { auto *k = (DistanceConstraint_XPBD*)c; p.push_back((float)k->m_restLength); p.push_back((float)k->m_stiffness); break; }
-		case PBDX_DIHEDRAL: { auto *k = (DihedralConstraint*)c; p.push_back((float)k->m_restAngle); p.push_back((float)k->m_stiffness); break; }
-		case PBDX_ISOMETRIC_BENDING: { auto *k = (IsometricBendingConstraint*)c; p.push_back((float)k->m_stiffness); pushColMajor(p, k->m_Q, 4, 4); break; }
-		case PBDX_ISOMETRIC_BENDING_XPBD: { auto *k = (IsometricBendingConstraint_XPBD*)c; p.push_back((float)k->m_stiffness); pushColMajor(p, k->m_Q, 4, 4); break; }
-		case PBDX_FEM_TRIANGLE: { auto *k = (FEMTriangleConstraint*)c; p.push_back((float)k->m_area); pushColMajor(p, k->m_invRestMat, 2, 2);
-			p.push_back((float)k->m_xxStiffness); p.push_back((float)k->m_yyStiffness); p.push_back((float)k->m_xyStiffness);
-			p.push_back((float)k->m_xyPoissonRatio); p.push_back((float)k->m_yxPoissonRatio); break; }
-		case PBDX_STRAIN_TRIANGLE: { auto *k = (StrainTriangleConstraint*)c; pushColMajor(p, k->m_invRestMat, 2, 2);
-			p.push_back((float)k->m_xxStiffness); p.push_back((float)k->m_yyStiffness); p.push_back((float)k->m_xyStiffness);
-			p.push_back(k->m_normalizeStretch ? 1.0f : 0.0f); p.push_back(k->m_normalizeShear ? 1.0f : 0.0f); break; }
-		case PBDX_VOLUME: { auto *k = (VolumeConstraint*)c; p.push_back((float)k->m_restVolume); p.push_back((float)k->m_stiffness); break; }
-		case PBDX_VOLUME_XPBD: { auto *k = (VolumeConstraint_XPBD*)c; p.push_back((float)k->m_restVolume); p.push_back((float)k->m_stiffness); break; }
-		case PBDX_FEM_TET: { auto *k = (FEMTetConstraint*)c; p.push_back((float)k->m_volume); pushColMajor(p, k->m_invRestMat, 3, 3);
-			p.push_back((float)k->m_stiffness); p.push_back((float)k->m_poissonRatio); break; }
-		case PBDX_FEM_TET_XPBD: { auto *k = (XPBD_FEMTetConstraint*)c; p.push_back((float)k->m_volume); pushColMajor(p, k->m_invRestMat, 3, 3);
-			p.push_back((float)k->m_stiffness); p.push_back((float)k->m_poissonRatio); break; }
-		case PBDX_STRAIN_TET: { auto *k = (StrainTetConstraint*)c; pushColMajor(p, k->m_invRestMat, 3, 3);
-			p.push_back((float)k->m_stretchStiffness); p.push_back((float)k->m_shearStiffness);
-			p.push_back(k->m_normalizeStretch ? 1.0f : 0.0f); p.push_back(k->m_normalizeShear ? 1.0f : 0.0f); break; }
-		case PBDX_SHAPE_MATCHING: { auto *k = (ShapeMatchingConstraint*)c; p.push_back((float)k->m_stiffness);
-			for (int j = 0; j < 3; j++) p.push_back((float)k->m_restCm[j]);
-			for (int i = 0; i < 4; i++) for (int j = 0; j < 3; j++) p.push_back((float)k->m_x0[i][j]);
-			for (int i = 0; i < 4; i++) p.push_back((float)k->m_w[i]);
-			for (int i = 0; i < 4; i++) p.push_back((float)k->m_numClusters[i]);
+		case PBDX_DISTANCE: { auto *k = (DistanceConstraint*)c; p((float)k->m_restLength); p((float)k->m_stiffness); break; }
+		case PBDX_DISTANCE_XPBD: { auto *k = (DistanceConstraint_XPBD*)c; p((float)k->m_restLength); p((float)k->m_stiffness); break; }
+		case PBDX_DIHEDRAL: { auto *k = (DihedralConstraint*)c; p((float)k->m_restAngle); p((float)k->m_stiffness); break; }
+		case PBDX_ISOMETRIC_BENDING: { auto *k = (IsometricBendingConstraint*)c; p((float)k->m_stiffness); visitColMajor(p, k->m_Q, 4, 4); break; }
+		case PBDX_ISOMETRIC_BENDING_XPBD: { auto *k = (IsometricBendingConstraint_XPBD*)c; p((float)k->m_stiffness); visitColMajor(p, k->m_Q, 4, 4); break; }
+		case PBDX_FEM_TRIANGLE: { auto *k = (FEMTriangleConstraint*)c; p((float)k->m_area); visitColMajor(p, k->m_invRestMat, 2, 2);
+			p((float)k->m_xxStiffness); p((float)k->m_yyStiffness); p((float)k->m_xyStiffness);
+			p((float)k->m_xyPoissonRatio); p((float)k->m_yxPoissonRatio); break; }
+		case PBDX_STRAIN_TRIANGLE: { auto *k = (StrainTriangleConstraint*)c; visitColMajor(p, k->m_invRestMat, 2, 2);
+			p((float)k->m_xxStiffness); p((float)k->m_yyStiffness); p((float)k->m_xyStiffness);
+			p(k->m_normalizeStretch ? 1.0f : 0.0f); p(k->m_normalizeShear ? 1.0f : 0.0f); break; }
+		case PBDX_VOLUME: { auto *k = (VolumeConstraint*)c; p((float)k->m_restVolume); p((float)k->m_stiffness); break; }
+		case PBDX_VOLUME_XPBD: { auto *k = (VolumeConstraint_XPBD*)c; p((float)k->m_restVolume); p((float)k->m_stiffness); break; }
+		case PBDX_FEM_TET: { auto *k = (FEMTetConstraint*)c; p((float)k->m_volume); visitColMajor(p, k->m_invRestMat, 3, 3);
+			p((float)k->m_stiffness); p((float)k->m_poissonRatio); break; }
+		case PBDX_FEM_TET_XPBD: { auto *k = (XPBD_FEMTetConstraint*)c; p((float)k->m_volume); visitColMajor(p, k->m_invRestMat, 3, 3);
+			p((float)k->m_stiffness); p((float)k->m_poissonRatio); break; }
+		case PBDX_STRAIN_TET: { auto *k = (StrainTetConstraint*)c; visitColMajor(p, k->m_invRestMat, 3, 3);
+			p((float)k->m_stretchStiffness); p((float)k->m_shearStiffness);
+			p(k->m_normalizeStretch ? 1.0f : 0.0f); p(k->m_normalizeShear ? 1.0f : 0.0f); break; }
+		case PBDX_SHAPE_MATCHING: { auto *k = (ShapeMatchingConstraint*)c; p((float)k->m_stiffness);
+			for (int j = 0; j < 3; j++) p((float)k->m_restCm[j]);
+			for (int i = 0; i < 4; i++) for (int j = 0; j < 3; j++) p((float)k->m_x0[i][j]);
+			for (int i = 0; i < 4; i++) p((float)k->m_w[i]);
+			for (int i = 0; i < 4; i++) p((float)k->m_numClusters[i]);
 			break; }
 		default: break;
 		}
 	}
+	struct PushSink { std::vector<float> &v; inline void operator()(float f) { v.push_back(f); } };
+	inline void pushParams(std::vector<float> &p, int type, Constraint *c) { PushSink s = { p }; visitParams(s, type, c); }
+	// sequential 64-bit mix over the record's floats (order matters inside a record)
+	struct HashSink
+	{
+		uint64_t h;
+		inline void operator()(float f) { uint32_t u; memcpy(&u, &f, 4); h = (h ^ (uint64_t)u) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+	};
+	const size_t kParamScanBlock = 2048;          // constraints per 64-bit hash of the exact parameter scan
 
 	// FNV-1a over raw bytes
 	inline uint64_t fnv(uint64_t h, const void *p, size_t n)
@@ -139,11 +149,11 @@ namespace
 TimeStepControllerHIP::TimeStepControllerHIP(int device) :
 	TimeStepController(), m_solver(nullptr), m_device(device), m_scheduleValid(false),
 	m_numConstraints(0), m_numParticles(0), m_gpuSteps(0), m_fallbackSteps(0), m_failedSteps(0), m_paramRefreshes(0), m_scheduleBuilds(0), m_uploads(0),
-	m_allowFallback(false), m_deviceAhead(false), m_hostDirty(false), m_imageValid(false), m_paramsDirty(false), m_paramHash(0),
+	m_allowFallback(false), m_deviceAhead(false), m_hostDirty(false), m_imageValid(false), m_paramsDirty(false),
 	m_supportedFor(nullptr), m_supportedConstraints(0), m_supportedBodies(0), m_supportedObjects(0), m_supported(false), m_accelValid(false), m_tetSignature(0)
 {
 	m_accelGravity[0] = m_accelGravity[1] = m_accelGravity[2] = 0;
-	m_fullParameterScan = false; m_partialUploads = 0;
+	m_fullParameterScan = true; m_partialUploads = 0;
 	for (int k = 0; k < 6; k++) m_ms[k] = 0.0;
 	m_deviceMs = 0.0;
 	if (pbdx_solver_create(&m_solver, device) != PBDX_OK)
@@ -552,27 +562,56 @@ void TimeStepControllerHIP::hashHostState(SimulationModel &model, std::vector<ui
 	hashBlocks(jobs, 5);
 }
 
-// hash over the constraints' parameter records (what pushParams would hand to the engine): a strided sample of ~4096 records by
-// default -- a walk over all of a 6 M-constraint model's heap objects costs tens of milliseconds, more than the step -- which
-// sees every bulk edit (SimulationModel::setClothStiffness & co write ALL constraints of a kind); an edit of a single constraint
-// needs refreshParameters() (documented in the header), or setFullParameterScan(true) for hosts that prefer exactness to speed.
-uint64_t TimeStepControllerHIP::hashParameters(SimulationModel &model) const
+// Hashes over the constraints' parameter records (exactly what visitParams hands to the engine), compared before every step with
+// the ones the device image was built from.
+//  * exact (default): EVERY record of EVERY constraint, one 64-bit hash per block of kParamScanBlock constraints, the blocks walked
+//    by up to 32 OpenMP threads (the walk is a pointer chase over the model's heap objects: one or two cache lines per constraint).
+//    A single python-side `constraint.stiffness = ...` (pyPBD/ConstraintsModule.cpp:62-116) is found whatever the size of the model.
+//  * sampled (opt-in, setFullParameterScan(false)): a strided sample of ~4096 records, which sees every bulk edit
+//    (SimulationModel::setClothStiffness & co write ALL constraints of a kind) and can miss a single-constraint edit; the host
+//    then announces such edits with refreshParameters().  For hosts that step multi-million-constraint models one step() at a time
+//    and never edit single constraints: the exact walk costs about as much host time per step as the GPU needs for the step.
+void TimeStepControllerHIP::hashParameters(SimulationModel &model, std::vector<uint64_t> &out) const
 {
 	SimulationModel::ConstraintVector &constraints = model.getConstraints();
 	const size_t nc = constraints.size();
-	uint64_t h = 1469598103934665603ull ^ (uint64_t)nc;
-	if (!nc) return h;
-	const size_t stride = (nc > 4096 && !m_fullParameterScan) ? nc / 4096 : 1;
-	std::vector<float> rec;
-	for (size_t i = 0; i < nc; i += stride)
+	if (!m_fullParameterScan)
 	{
-		rec.clear();
-		pushParams(rec, engineType(constraints[i]), constraints[i]);
-		h = fnv(h, rec.data(), rec.size() * sizeof(float));
+		uint64_t h = 1469598103934665603ull ^ (uint64_t)nc;
+		const size_t stride = nc > 4096 ? nc / 4096 : 1;
+		for (size_t i = 0; i < nc; i += stride) { HashSink s = { h }; visitParams(s, engineType(constraints[i]), constraints[i]); h = s.h; }
+		if (nc) { HashSink s = { h }; visitParams(s, engineType(constraints[nc - 1]), constraints[nc - 1]); h = s.h; }
+		out.assign(1, h);
+		return;
 	}
-	rec.clear();
-	pushParams(rec, engineType(constraints[nc - 1]), constraints[nc - 1]);
-	return fnv(h, rec.data(), rec.size() * sizeof(float));
+	const size_t nb = (nc + kParamScanBlock - 1) / kParamScanBlock;
+	out.resize(nb + 1);
+	out[nb] = (uint64_t)nc;
+	int threads = nc >= 65536 ? omp_get_num_procs() : 1;
+	if (threads > 32) threads = 32;
+	if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) threads = v; }      // developer aid
+	Constraint *const *cs = constraints.data();
+	uint64_t *o = out.data();
+	#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+	for (long long b = 0; b < (long long)nb; b++)
+	{
+		const size_t first = (size_t)b * kParamScanBlock, last = first + kParamScanBlock < nc ? first + kParamScanBlock : nc;
+		HashSink s = { 0x51ed270b7d0e3a5full ^ (uint64_t)b };
+		// objects of one class share their vtable pointer: the type lookup (a virtual call + up to 13 compares) is repeated only
+		// where the class changes (shape matching always: its engine type also depends on the number of bodies)
+		const void *lastVptr = nullptr; int lastType = -1;
+		for (size_t i = first; i < last; i++)
+		{
+			if (i + 12 < last) { const char *nx = (const char *)cs[i + 12]; __builtin_prefetch(nx); __builtin_prefetch(nx + 64); }
+			Constraint *c = cs[i];
+			const void *vptr = *(const void *const *)c;
+			int type = lastType;
+			if (vptr != lastVptr || type == PBDX_SHAPE_MATCHING) { type = engineType(c); lastVptr = vptr; lastType = type; }
+			s((float)type);
+			visitParams(s, type, c);
+		}
+		o[b] = s.h;
+	}
 }
 
 // One pass over every colour group: its constraints are bucketed by type (creation order kept inside a bucket) and each
@@ -642,7 +681,7 @@ bool TimeStepControllerHIP::buildSchedule(SimulationModel &model, bool paramsOnl
 	m_numConstraints = constraints.size();
 	m_scheduleValid = true;
 	m_paramsDirty = false;
-	m_paramHash = hashParameters(model);
+	hashParameters(model, m_paramHash);
 	return true;
 }
 
@@ -693,8 +732,8 @@ bool TimeStepControllerHIP::prepare(SimulationModel &model, bool forceUpload)
 	}
 	else
 	{
-		bool changed;
-		{ Lap lap(&m_ms[2]); changed = m_paramsDirty || hashParameters(model) != m_paramHash; }
+		bool changed = m_paramsDirty;
+		if (!changed) { Lap lap(&m_ms[2]); std::vector<uint64_t> now; hashParameters(model, now); changed = now != m_paramHash; }
 		if (changed && !buildSchedule(model, true)) return false;      // parameter streams only: no replanning, no re-measurement
 	}
 	Lap lap(&m_ms[3]);

@@ -24,9 +24,12 @@
 //                             blocks are uploaded; while the host is stale a written ARRAY replaces the device's as a whole
 //                             (the others are kept) -- to edit single particles, syncToHost first.
 // Masses: ParticleData::setMass between steps (pinning, mouse attach) is found the same way; the inverse masses of the changed
-// blocks are re-derived.  Constraint parameters: bulk edits (setClothStiffness ...) are found by a sampled hash, an edit of a
-// single constraint needs refreshParameters() (or setFullParameterScan(true)): a walk over all heap constraints per step
-// would cost more than the step.
+// blocks are re-derived.  Constraint parameters: before every step EVERY parameter record of EVERY constraint is compared (block
+// hashes, multi-threaded walk) with what the device image was built from, so bulk edits (setClothStiffness ...) and an edit of a
+// single constraint's field (python: `constraint.stiffness = ...`) are both found without any announcement; a change refreshes
+// only the parameter streams.  The walk costs host time proportional to the number of constraints (about 1 ms per million on a
+// many-core host); a host that steps multi-million-constraint models one step() at a time and never edits single constraints can
+// opt in to a sampled check with setFullParameterScan(false) -- or amortise the walk with stepResident(model, n).
 //
 // Scope: models whose constraints are all particle constraints known to the engine.  Rigid bodies are
 // accepted when they are all static (mass 0) colliders of a DistanceFieldCollisionDetection with analytic
@@ -78,9 +81,9 @@ namespace PBD
 		/** Drop the device image (call after editing the topology behind the model's back). */
 		void invalidate() { m_scheduleValid = false; }
 		/** Run-time parameter edits (setClothStiffness, m_stiffness / m_restLength edits, SimulationModel.h
-		 * setConstraintValue<>): every step compares a hash over a sample of the constraints' parameter records with the one
-		 * the device image was built from and, on a change, refreshes ONLY the parameter streams (no replanning).  An edit
-		 * of a single constraint in a large model can fall between the samples: call refreshParameters() then. */
+		 * setConstraintValue<>) are found by the exact parameter scan before every step and refresh ONLY the parameter streams (no
+		 * replanning).  refreshParameters() forces such a refresh; it is needed only after setFullParameterScan(false), when an
+		 * edit of a single constraint in a large model can fall between the samples. */
 		void refreshParameters() { m_paramsDirty = true; }
 		/** Number of steps that ran on the GPU / fell back to the reference's CPU path. */
 		unsigned int numGpuSteps() const { return m_gpuSteps; }
@@ -91,7 +94,8 @@ namespace PBD
 		unsigned int numUploads() const { return m_uploads; }
 		/** uploads of only the blocks the host wrote (host current, full-coverage block hashes) */
 		unsigned int numPartialUploads() const { return m_partialUploads; }
-		/** hash ALL parameter records every step instead of a sample (exact, costs a walk over every constraint object) */
+		/** true (DEFAULT): every parameter record is compared before every step (exact).  false: a strided sample of ~4096 records
+		 * (sees bulk edits; single-constraint edits then need refreshParameters()). */
 		void setFullParameterScan(bool b) { m_fullParameterScan = b; }
 		/** Opt in to running unsupported models / failed steps on the reference's CPU path (default off). */
 		void setAllowReferenceFallback(bool b) { m_allowFallback = b; }
@@ -109,7 +113,7 @@ namespace PBD
 		bool prepare(SimulationModel &model, bool forceUpload);
 		bool runSteps(SimulationModel &model, unsigned int numSteps);
 		bool uploadChanges(SimulationModel &model, std::vector<uint64_t> now[5]);
-		uint64_t hashParameters(SimulationModel &model) const;
+		void hashParameters(SimulationModel &model, std::vector<uint64_t> &out) const;
 		void hashHostState(SimulationModel &model, std::vector<uint64_t> out[5]) const;
 		void refuse(SimulationModel &model, const char *why);
 		void refreshAccelerations(SimulationModel &model);
@@ -132,7 +136,7 @@ namespace PBD
 		bool m_fullParameterScan;
 		// parameters
 		bool m_paramsDirty;
-		uint64_t m_paramHash;
+		std::vector<uint64_t> m_paramHash;   // exact scan: one hash per block of constraints (+ the count); sampled scan: one hash
 		// what `supported` was last evaluated for
 		const void *m_supportedFor; size_t m_supportedConstraints, m_supportedBodies, m_supportedObjects; bool m_supported;
 		bool m_accelValid; Real m_accelGravity[3];

@@ -254,10 +254,22 @@ def test_plugin_full_size_c2_reference_model():
     lib.pbdx_timestep_hip_timing(ts, lap, 1)
     t0 = time.perf_counter()
     ref.step(10)
+    t_round_exact = (time.perf_counter() - t0) / 10
+    lib.pbdx_timestep_hip_timing(ts, lap, 1)
+    print("plug-in round trip at 1000x1000 (default: exact parameter scan of all 5 988 006 records), ms per step: host-array hashes %.3f, uploads %.3f, parameter check %.3f, colliders %.3f, engine step %.3f (device events %.3f), download %.3f" % (
+        lap[0] / 10, lap[1] / 10, lap[2] / 10, lap[3] / 10, lap[4] / 10, lap[6] / 10, lap[5] / 10))
+    # opt-in sampled parameter check (what round 3 did by default)
+    _extra(path).pbdx_timestep_hip_set_full_parameter_scan(ts, 0)
+    ref.step(1)
+    refreshes_after_switch = cnt["param_refreshes"](ts)
+    lib.pbdx_timestep_hip_timing(ts, lap, 1)
+    t0 = time.perf_counter()
+    ref.step(10)
     t_round = (time.perf_counter() - t0) / 10
     lib.pbdx_timestep_hip_timing(ts, lap, 1)
-    print("plug-in round trip at 1000x1000, ms per step: host-array hashes %.3f, uploads %.3f, parameter check %.3f, colliders %.3f, engine step %.3f (device events %.3f), download %.3f" % (
+    print("plug-in round trip at 1000x1000 (opt-in: sampled parameter check), ms per step: host-array hashes %.3f, uploads %.3f, parameter check %.3f, colliders %.3f, engine step %.3f (device events %.3f), download %.3f" % (
         lap[0] / 10, lap[1] / 10, lap[2] / 10, lap[3] / 10, lap[4] / 10, lap[6] / 10, lap[5] / 10))
+    print("round trip per step: exact scan %.3f ms, sampled check %.3f ms" % (1e3 * t_round_exact, 1e3 * t_round))
     assert cnt["step_resident"](ts, model, 5) == 0
     t0 = time.perf_counter()
     assert cnt["step_resident"](ts, model, 50) == 0
@@ -265,89 +277,138 @@ def test_plugin_full_size_c2_reference_model():
     t0 = time.perf_counter()
     assert cnt["sync_to_host"](ts, model) == 0
     t_sync = time.perf_counter() - t0
-    assert cnt["schedule_builds"](ts) == 1 and cnt["param_refreshes"](ts) == 0
+    assert cnt["schedule_builds"](ts) == 1 and cnt["param_refreshes"](ts) == refreshes_after_switch
     print("plug-in at 1000x1000: first step (schedule build + plan + autotune) %.2f s; round trip %.3f ms/step; resident %.3f ms/step; syncToHost %.2f ms" % (
         t_first, 1e3 * t_round, 1e3 * t_res, 1e3 * t_sync))
     ref.reset_all()
-    assert t_res < 1.5e-3 and t_round < 8e-3
+    assert t_res < 1.5e-3 and t_round < 8e-3 and t_round_exact < 30e-3
 
 
 # ---------------------------------------------------------------------------
-# the compiled python side: a reduced pypbd module with TimeStepControllerHIP registered (plugin/pypbd_reduced.cpp)
+# the compiled python side: the reference's OWN pypbd (pyPBD/*.cpp compiled unmodified, plugin/Makefile) with the one
+# added class TimeStepControllerHIP (plugin/TimeStepHIPModule.cpp)
 # ---------------------------------------------------------------------------
-_PYPBD_RUN = r'''
+_PYPBD_RUN = r"""
 import sys, json, importlib.util
 import numpy as np
 spec = importlib.util.spec_from_file_location("ex", %(example)r)
 ex = importlib.util.module_from_spec(spec); spec.loader.exec_module(ex)
 pbd = ex.pbd
-out = {}
-for sim_model, bend in ((2, 2), (4, 3)):
+out = {"classes": sorted(n for n in dir(pbd) if not n.startswith("_"))}
+for cfg in %(configs)r:
     xs = {}
+    key = "".join(str(c) for c in cfg)
     for gpu in %(modes)r:
         # (Simulation.getCurrent() creates AND initialises the singleton, Simulation.cpp:30-38; every leg installs its own time step)
         pbd.TimeManager.getCurrent().setTime(0.0)
-        ex.buildModel(sim_model, bend, gpu)
-        x0 = np.array(pbd.Simulation.getCurrent().getModel().getParticles().getVertices(), copy=True)
+        ex.buildModel(*cfg, gpu=gpu)
+        model = pbd.Simulation.getCurrent().getModel()
+        x0 = np.array(model.getParticles().getVertices(), copy=True)
         for frame in range(2):
             ex.timeStep()
-        x = np.array(pbd.Simulation.getCurrent().getModel().getParticles().getVertices(), copy=True)
+            if %(edit)r and frame == 0:
+                # pyPBD/ConstraintsModule.cpp:62-116: python writes ONE constraint's fields in place -- nothing is announced
+                cs = model.getConstraints()
+                c = cs[len(cs) // 3]
+                for field in ("stiffness", "xxStiffness", "stretchStiffness"):
+                    if hasattr(c, field):
+                        setattr(c, field, 0.25 * getattr(c, field))
+        x = np.array(model.getParticles().getVertices(), copy=True)
         ts = pbd.Simulation.getCurrent().getTimeStep()
         xs[gpu] = x
-        out["%%d%%d_%%s" %% (sim_model, bend, "gpu" if gpu else "cpu")] = dict(
+        out[key + ("_gpu" if gpu else "_cpu")] = dict(
             type=type(ts).__name__, moved=bool(np.abs(x - x0).max() > 0), finite=bool(np.isfinite(x).all()),
             gpu_steps=ts.numGpuSteps() if gpu else None, failed=ts.numFailedSteps() if gpu else None,
-            is_controller=isinstance(ts, pbd.TimeStepController))
+            refreshes=ts.numParameterRefreshes() if gpu else None, builds=ts.numScheduleBuilds() if gpu else None,
+            is_controller=isinstance(ts, pbd.TimeStepController), constraints=len(model.getConstraints()))
     if True in xs and False in xs:
         a, b = xs[True].astype(np.float32), xs[False].astype(np.float32)
-        out["%%d%%d_bitwise" %% (sim_model, bend)] = bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
-        out["%%d%%d_maxabs" %% (sim_model, bend)] = float(np.abs(a - b).max())
+        out[key + "_bitwise"] = bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+        out[key + "_maxabs"] = float(np.abs(a - b).max())
 print("RESULT " + json.dumps(out))
-'''
+"""
 
 
-def _run_pypbd(modes):
+def _run_pypbd(modes, example="cloth_model_pypbd.py", configs=((2, 2), (4, 3)), edit=False):
     import glob
     import json
     import subprocess
     import sys
     if not glob.glob(os.path.join(PLUGIN_DIR, "pypbd*.so")):
-        pytest.skip("reduced pypbd module not built (needs /root/reference at build time)")
-    code = _PYPBD_RUN % {"example": os.path.join(util.ROOT, "examples", "cloth_model_pypbd.py"), "modes": modes}
-    # own process: the module shares the reference's singletons (Simulation::current ...) with oracle/refdrv
+        pytest.skip("pypbd module not built (needs /root/reference at build time)")
+    code = _PYPBD_RUN % {"example": os.path.join(util.ROOT, "examples", example), "modes": modes, "configs": [list(c) for c in configs], "edit": edit}
+    # own process: pypbd carries its own copy of the reference's singletons (Simulation::current ...), like the reference's build
     # (OMP_NUM_THREADS=1: the reference forks / joins one parallel region per colour group; on a 256-thread host that costs more
     # than the 2 500-particle sheet it distributes)
-    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240,
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
                        env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert p.returncode == 0, p.stderr[-3000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     return json.loads(line[7:])
 
 
-def test_compiled_pypbd_registers_the_hip_time_step(have_gpu):
-    """`pypbd.TimeStepControllerHIP` exists in a compiled pypbd module, is a TimeStepController, is accepted by
-    Simulation.setTimeStep, inherits the parameter ids (setValueUInt(NUM_SUB_STEPS, 3) in the example) -- and without a GPU
-    refuses every step instead of computing anything on the host."""
+def test_compiled_pypbd_is_the_references_own_module_plus_one_class(have_gpu):
+    """The module is the reference's pyPBD/*.cpp (every class its ten *Module.cpp files register is there: constraints with
+    their fields, tet models, rigid bodies, joints, collision detection, loaders) + `TimeStepControllerHIP`, which is a
+    TimeStepController, is accepted by Simulation.setTimeStep, inherits the parameter ids (setValueUInt(NUM_SUB_STEPS, 3) in the
+    example) -- and without a GPU refuses every step instead of computing anything on the host."""
     if have_gpu:
-        pytest.skip("GPU present: covered by the gpu test")
+        pytest.skip("GPU present: covered by the gpu tests")
     res = _run_pypbd([True])
+    for name in ("TimeStepControllerHIP", "TimeStepController", "TetModel", "DistanceConstraint_XPBD", "IsometricBendingConstraint_XPBD", "FEMTetConstraint",
+                 "RigidBody", "BallJoint", "CubicSDFCollisionDetection", "DistanceFieldCollisionDetection", "OBJLoader", "TetGenLoader", "VecConstraints", "Timing"):
+        assert name in res["classes"], name
     for key in ("22_gpu", "43_gpu"):
         r = res[key]
         assert r["type"] == "TimeStepControllerHIP" and r["is_controller"]
         assert r["gpu_steps"] == 0 and r["failed"] == 16 and not r["moved"] and r["finite"]
+    res = _run_pypbd([True], example="beam_model_pypbd.py", configs=((2,),))
+    assert res["2_gpu"]["failed"] == 16 and not res["2_gpu"]["moved"]
 
 
 @pytest.mark.gpu
 def test_reference_python_example_through_compiled_pypbd_on_the_gpu():
-    """pyPBD/examples/cloth_model.py's logic, `import pypbd as pbd` unchanged, three lines added to install the GPU time
-    step: 16 steps x 3 substeps for the example's default (FEM triangles + isometric bending) and for the XPBD variant,
-    bit-identical to the same script with the reference's own TimeStepController left in place (same float host)."""
+    """pyPBD/examples/cloth_model.py's logic, `import pypbd as pbd` = the reference's own module, the marked lines added to install
+    the GPU time step: 16 steps x 3 substeps for the example's default (FEM triangles + isometric bending) and for the XPBD variant,
+    bit-identical to the same script with the reference's own TimeStepController (same float host)."""
     res = _run_pypbd([True, False])
     for key in ("22", "43"):
         g, c = res[key + "_gpu"], res[key + "_cpu"]
         assert g["type"] == "TimeStepControllerHIP" and c["type"] == "TimeStepController"
         assert g["gpu_steps"] == 16 and g["failed"] == 0 and g["moved"] and c["moved"]
-        print("compiled pypbd, model %s: bitwise %s, max abs %.3e" % (key, res[key + "_bitwise"], res[key + "_maxabs"]))
+        print("compiled pypbd, cloth model %s: bitwise %s, max abs %.3e" % (key, res[key + "_bitwise"], res[key + "_maxabs"]))
+        assert res[key + "_bitwise"], res[key + "_maxabs"]
+
+
+@pytest.mark.gpu
+def test_reference_python_beam_example_through_compiled_pypbd_on_the_gpu():
+    """pyPBD/examples/beam_model.py's logic (30x5x5 tet beam through TetModel / addSolidConstraints of the reference's own bindings,
+    pyPBD/SimulationModelModule.cpp:206-299): FEM tets, XPBD FEM tets (the example's default), strain tets, shape matching, XPBD
+    distance + volume -- 16 steps x 3 substeps bit-identical to pypbd's own TimeStepController."""
+    res = _run_pypbd([True, False], example="beam_model_pypbd.py", configs=((2,), (3,), (4,), (5,), (6,)))
+    for key in ("2", "3", "4", "5", "6"):
+        g, c = res[key + "_gpu"], res[key + "_cpu"]
+        assert g["type"] == "TimeStepControllerHIP" and c["type"] == "TimeStepController"
+        assert g["gpu_steps"] == 16 and g["failed"] == 0 and g["moved"] and c["moved"]
+        print("compiled pypbd, beam model %s: bitwise %s, max abs %.3e" % (key, res[key + "_bitwise"], res[key + "_maxabs"]))
+        assert res[key + "_bitwise"], res[key + "_maxabs"]
+
+
+@pytest.mark.gpu
+def test_python_edit_of_one_constraint_field_is_seen_without_announcement():
+    """pyPBD/ConstraintsModule.cpp:62-116 makes every constraint's fields python-writable.  ONE constraint of the 50x50 sheet
+    (14 406 constraints) and of the beam gets a quarter of its stiffness between two frames, nothing is announced: the plug-in's
+    exact parameter scan finds it (one parameter refresh, no new schedule) and the run stays bit-identical to the CPU time step."""
+    res = _run_pypbd([True, False], edit=True)
+    for key in ("22", "43"):
+        g = res[key + "_gpu"]
+        print("edit, cloth %s: constraints %d, refreshes %d, builds %d, bitwise %s" % (key, g["constraints"], g["refreshes"], g["builds"], res[key + "_bitwise"]))
+        assert g["constraints"] > 4096 and g["refreshes"] == 1 and g["builds"] == 1 and g["failed"] == 0
+        assert res[key + "_bitwise"], res[key + "_maxabs"]
+    res = _run_pypbd([True, False], example="beam_model_pypbd.py", configs=((2,), (4,)), edit=True)
+    for key in ("2", "4"):
+        g = res[key + "_gpu"]
+        assert g["refreshes"] == 1 and g["builds"] == 1 and g["failed"] == 0
         assert res[key + "_bitwise"], res[key + "_maxabs"]
 
 
@@ -520,27 +581,30 @@ def test_plugin_sees_one_moved_particle_between_resident_steps():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("how", ["refreshParameters", "fullParameterScan"])
-def test_plugin_sees_one_edited_constraint_in_a_large_model(how):
-    """`constraint.stiffness = ...` on ONE of 611 522 constraints (pyPBD/ConstraintsModule.cpp:62-116).  The documented contract:
-    the default sampled parameter hash sees bulk edits only; a single-constraint edit is announced with refreshParameters(), or
-    the host switches the full scan on.  Either way: parameter streams refreshed, no replanning, bitwise vs the CPU path."""
+@pytest.mark.parametrize("how", ["unannounced", "sampled+refreshParameters"])
+@pytest.mark.parametrize("size", ["clothdemo50", "big"])
+def test_plugin_sees_one_edited_constraint(size, how):
+    """`constraint.stiffness = ...` on ONE constraint (pyPBD/ConstraintsModule.cpp:62-116), in the 50x50 ClothDemo sheet (14 406
+    constraints: already more than the 4 096 the sampled check looks at) and in a 611 522-constraint sheet.  Default: NOTHING is
+    announced -- the exact parameter scan (every record of every constraint, every step) finds it.  Opt-in sampled check: the host
+    announces the edit with refreshParameters().  Either way: parameter streams refreshed once, no replanning, bitwise vs the CPU
+    TimeStepController making the same edit."""
     refdrv, path = _plugin("f32")
-    ops = util.cloth_spec(BIG[0], BIG[1], 4, 3)
-    victim = 123457
+    ops = util.cloth_spec(50, 50, 1, 2) if size == "clothdemo50" else util.cloth_spec(BIG[0], BIG[1], 4, 3)
+    victim = 9001 if size == "clothdemo50" else 123457
 
     def run(gpu):
         ref = refdrv.Ref("f32")
         _setup(ref, ops, 1, 5)
-        ref.set_num_threads(8)
+        ref.set_num_threads(8 if size == "big" else 1)
         if gpu:
             assert ref.install_timestep_plugin(path) == 0
         ref.set_params(1, 5, 0)
-        if gpu and how == "fullParameterScan":
-            _extra(path).pbdx_timestep_hip_set_full_parameter_scan(ref.timestep_ptr(), 1)
+        if gpu and how != "unannounced":
+            _extra(path).pbdx_timestep_hip_set_full_parameter_scan(ref.timestep_ptr(), 0)
         ref.step(3)
-        ref.set_constraint_stiffness(victim, 3.0)
-        if gpu and how == "refreshParameters":
+        ref.set_constraint_stiffness(victim, 3.0 if size == "big" else 0.37)
+        if gpu and how != "unannounced":
             _extra(path).pbdx_timestep_hip_refresh_parameters(ref.timestep_ptr())
         ref.step(4)
         out = (ref.positions().copy(), ref.get_array(2).copy())
