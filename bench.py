@@ -664,7 +664,7 @@ def compact_headline(full, detail_path=None):
     """The driver-facing line: every key the bench contract names, summaries instead of tables."""
     c = full["config"]
     cfg = _pick(c, ("workload", "particles", "constraints", "colour_groups", "projections_per_substep", "rccl_ranks", "dist_backend", "oversubscribed",
-                    "per_rank_ms_per_step", "state_ok", "replicas_bit_identical", "shards_distinct", "replica_checksums", "shard_parity", "instances_of_rank0",
+                    "per_rank_ms_per_step", "rank_hip_devices", "rank_pci_bus_ids", "state_ok", "replicas_bit_identical", "shards_distinct", "replica_checksums", "shard_parity", "instances_of_rank0",
                     "device_event_ms_per_substep", "pcie_inclusive_ms_per_step"))
     cfg["workload"] = str(cfg.get("workload", ""))[:200]
     cfg["parallelism"] = "ensemble x%d, no data-path collective" % c.get("rccl_ranks", 1)
@@ -694,7 +694,7 @@ def compact_headline(full, detail_path=None):
     if len(line) >= MAX_LINE:            # never let a long list cost the record: drop the optional parts, longest first
         for k in ("extras",):
             out.pop(k, None)
-        for k in ("replica_checksums", "schedule", "instances_of_rank0"):
+        for k in ("replica_checksums", "schedule", "instances_of_rank0", "rank_pci_bus_ids", "rank_hip_devices"):
             out["config"].pop(k, None)
         line = json.dumps(out, separators=(",", ":"))
     if len(line) >= MAX_LINE:
@@ -766,11 +766,32 @@ def spawn_ranks(n, argv):
                    PBDX_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
+    # rank 0's stdout is drained by a thread while ALL ranks are watched: a rank that dies (no device, HIP error) must end the
+    # job with its exit code -- never leave the others waiting at a rendezvous or a barrier
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc not in (None, 0):
+                failed = (r, rc)
+                break
+        time.sleep(0.05)
+    if failed is not None:
+        for p in procs:               # exactly the processes started above
+            if p.poll() is None:
+                p.kill()
     rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out0 = (chunks[0] if chunks else b"").decode()
     for line in out0.splitlines():      # the JSON lines go to stdout (headline last); library chatter of the rank (gloo / RCCL banners) to stderr
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
+    if failed is not None:
+        raise SystemExit("bench.py: rank %d exited with code %d; the other ranks were stopped (exit codes %r)" % (failed[0], failed[1], rcs))
     if any(rcs):
         raise SystemExit("bench.py: rank exit codes %r" % (rcs,))
 
@@ -804,6 +825,7 @@ def main():
     ap.add_argument("--contacts", action="store_true", help="also time the step with two static colliders (contact detection + velocity solve per step)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than GPUs (ranks share devices; smoke test of the N>1 path, not a measurement)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default=None, help="torch.distributed backend (default: nccl = RCCL when GPUs are visible)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--child-steps", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--dry-line", nargs="?", const=os.path.join(ROOT, "profiles", "r02_bench.json"), default=None,
@@ -819,12 +841,17 @@ def main():
 
     if args.rank_selftest:
         from positionbaseddynamics_amd.ensemble import Ensemble
-        ens = Ensemble(backend=os.environ.get("PBDX_DIST_BACKEND") or "gloo")
+        if os.environ.get("PBDX_SELFTEST_FAIL_RANK") == os.environ.get("RANK", "0"):      # test hook: this rank dies before the rendezvous
+            raise SystemExit(3)
+        # (--dist-backend nccl at one rank = the RCCL path on a one-GPU box: init with device_id, all-reduces, barrier, destroy)
+        ens = Ensemble(backend=args.dist_backend or os.environ.get("PBDX_DIST_BACKEND") or "gloo", force_init=True)
+        sys.stderr.write("[bench rank %d/%d] %r\n" % (ens.rank, ens.world, ens.describe_device()))
         ranks = ens.gather_floats(ens.rank)
         t = ens.max_time(0.5 + ens.rank)
+        rank_sum = ens.sum_count(ens.rank + 1)
         ens.barrier()
         if ens.rank == 0:
-            print(json.dumps({"selftest": "ranks", "n_gpus": None, "rccl_ranks": ens.world, "ranks": ranks, "max_time": t, "spawned_by_bench": os.environ.get("PBDX_SPAWNED") == "1"}), flush=True)
+            print(json.dumps({"selftest": "ranks", "n_gpus": None, "rccl_ranks": ens.world, "dist_backend": ens.backend, "ranks": ranks, "sum": rank_sum, "max_time": t, "spawned_by_bench": os.environ.get("PBDX_SPAWNED") == "1"}), flush=True)
         ens.close()
         return
 
@@ -839,10 +866,27 @@ def main():
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env > ndev and not args.oversubscribe:
         raise SystemExit("bench.py: %d ranks but %d GPU(s) visible; one process per GPU (use --oversubscribe only to smoke-test the N>1 path)" % (world_env, ndev))
-    ens = Ensemble(oversubscribe=args.oversubscribe, num_devices=ndev)
+    local_env = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_env > 1 and local_env >= ndev and not args.oversubscribe:
+        raise SystemExit("bench.py: rank %s has LOCAL_RANK %d but only %d GPU(s) are visible to it (HIP_VISIBLE_DEVICES=%r, ROCR_VISIBLE_DEVICES=%r)" % (
+            os.environ.get("RANK"), local_env, ndev, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES")))
+    # (an explicitly requested backend is initialised even at world size 1: the RCCL path on a one-GPU box)
+    ens = Ensemble(oversubscribe=args.oversubscribe, num_devices=ndev, backend=args.dist_backend, force_init=args.dist_backend is not None)
     rank, world = ens.rank, ens.world
     if world == 1:
         torch.cuda.set_device(0)
+    # which GPU every rank chose (stderr, one line per rank) + a check on rank 0 that no two ranks share a physical device
+    dev = ens.describe_device()
+    sys.stderr.write("[bench rank %d/%d] LOCAL_RANK %d -> HIP device %d of %s visible (%s, pci %s); backend %s; HIP_VISIBLE_DEVICES=%r ROCR_VISIBLE_DEVICES=%r CUDA_VISIBLE_DEVICES=%r\n" % (
+        rank, world, dev["local_rank"], dev["hip_device"], dev["visible_devices"], dev["name"], "%04x" % dev["pci_bus_id"] if dev["pci_bus_id"] is not None else "?",
+        dev["backend"], dev["HIP_VISIBLE_DEVICES"], dev["ROCR_VISIBLE_DEVICES"], dev["CUDA_VISIBLE_DEVICES"]))
+    sys.stderr.flush()
+    rank_devices = ens.gather_ints(dev["hip_device"])
+    rank_pci = ens.gather_ints(dev["pci_bus_id"] if dev["pci_bus_id"] is not None else -1)
+    if world > 1 and not args.oversubscribe:
+        keys = list(zip(rank_devices, rank_pci))
+        if len(set(keys)) != world:
+            raise SystemExit("bench.py: two ranks chose the same GPU (HIP device, pci bus) per rank = %r: one process per GPU" % (keys,))
 
     if args.workload == "c5":
         for sub in (8, 5):
@@ -895,6 +939,7 @@ def main():
                    "projections_per_substep": res["n_constraints"] * args.iters,
                    "parallelism": "ensemble x%d (independent instances per GPU, no cross-GPU constraints, no data-path collective)" % world,
                    "rccl_ranks": world, "dist_backend": ens.backend, "oversubscribed": bool(args.oversubscribe and world > ndev),
+                   "rank_hip_devices": rank_devices, "rank_pci_bus_ids": ["%04x" % b if b >= 0 else None for b in rank_pci],
                    "per_rank_ms_per_step": per_rank_ms, "replica_checksums": ["%016x" % c for c in sums],
                    "state_ok": all_ok, "replicas_bit_identical": replicas_identical, "shards_distinct": shards_distinct, "shard_parity": shard_parity,
                    "instances_of_rank0": list(ens.shard(args.total_instances if args.scaling == "strong" else args.instances * world)) if args.workload == "c4" else None,

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "pbdx_internal.h"
+#include "pbdx_device.h"
 
 namespace pbdx {
 namespace {
@@ -169,7 +170,7 @@ extern "C" int pbdx_colour_constraints(int device, uint32_t num_bodies, uint32_t
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible: the engine has no CPU fallback"); return PBDX_ERR_NO_DEVICE; }
 	if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return PBDX_ERR_INVALID; }
-	HIPCHECK(hipSetDevice(device));
+	ENTER_DEVICE(device);
 	// developer aid: PBDX_COLOUR_VERBOSE=1 prints where the time goes
 	const bool verbose = getenv("PBDX_COLOUR_VERBOSE") != nullptr;
 	const auto t_start = std::chrono::steady_clock::now();

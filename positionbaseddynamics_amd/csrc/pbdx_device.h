@@ -1,0 +1,25 @@
+// pbdx_device.h -- selecting a solver's HIP device for the duration of one entry point.
+#ifndef PBDX_DEVICE_H
+#define PBDX_DEVICE_H
+#include <hip/hip_runtime.h>
+
+namespace {
+// Every entry point runs on ITS solver's device and leaves the calling thread's current HIP device as it found it: a host that
+// keeps a device of its own current (torch's rank device, a second solver on another GPU of the same process) is not disturbed by
+// a call into the engine (tests/test_distributed.py: two solvers on two devices in one process).
+struct DeviceScope
+{
+	int prev = -1; bool switched = false; hipError_t err = hipSuccess;
+	explicit DeviceScope(int device)
+	{
+		err = hipGetDevice(&prev);
+		if (err == hipSuccess && prev != device) { err = hipSetDevice(device); switched = (err == hipSuccess); }
+	}
+	~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+	DeviceScope(const DeviceScope &) = delete;
+	DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define ENTER_DEVICE(device) DeviceScope device_scope_(device); HIPCHECK(device_scope_.err)
+}
+
+#endif

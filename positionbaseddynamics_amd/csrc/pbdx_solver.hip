@@ -33,6 +33,7 @@
 // No MFMA: there is no dense contraction on this path; everything is gather/scatter streaming.
 #include <hip/hip_runtime.h>
 #include "pbdx_internal.h"
+#include "pbdx_device.h"
 #include "pbdx_access.h"
 #include "pbdx_quad.h"
 #include "pbdx_plan.h"
@@ -1152,6 +1153,7 @@ struct DeviceSegment
 
 #define HIPCHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
 	set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return PBDX_ERR_HIP; } } while (0)
+
 
 } // namespace
 
@@ -2291,7 +2293,7 @@ template <class T>
 int set_particles_impl(pbdx_solver *s, uint32_t n, const T *x, const T *v, const T *old_x, const T *last_x, const T *mass, const T *inv_mass)
 {
 	if (!s || !x || !mass || !inv_mass) { set_error("set_particles: x, mass and inv_mass are required"); return PBDX_ERR_INVALID; }
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	if (n != s->n)
 	{
 		HIPCHECK(hipStreamSynchronize(s->stream));
@@ -2354,7 +2356,7 @@ int get_particles_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, T *last
 {
 	if (!s || n != s->n) { set_error("get_particles: particle count mismatch (%u vs %u)", n, s ? s->n : 0); return PBDX_ERR_INVALID; }
 	if (!n) return PBDX_OK;
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	{ int rs = ensure_stage(s, sizeof(T)); if (rs) return rs; }
 	struct { T *dst; const float4 *src; } jobs[4] = { { x, s->d_pos[0] }, { v, s->d_vel }, { old_x, s->d_old }, { last_x, s->d_last } };
 	const size_t b3 = (size_t)3 * n * sizeof(T);
@@ -2377,7 +2379,7 @@ int get_particles_hashed_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, 
 {
 	if (!s || n != s->n) { set_error("get_particles: particle count mismatch (%u vs %u)", n, s ? s->n : 0); return PBDX_ERR_INVALID; }
 	if (!n) return PBDX_OK;
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	{ int rs = ensure_stage(s, sizeof(T)); if (rs) return rs; }
 	const uint32_t nb = pbdx_hash_num_blocks(n);
 	if (s->hash_blocks < nb)
@@ -2417,7 +2419,7 @@ int update_ranges_impl(pbdx_solver *s, int array, const T *base, uint32_t num_ra
 	for (uint32_t r = 0; r < num_ranges; r++)
 		if (ranges[2 * r] > s->n || ranges[2 * r + 1] > s->n - ranges[2 * r]) { set_error("update_particle_ranges: range %u (%u, %u) outside the %u particles", r, ranges[2 * r], ranges[2 * r + 1], s->n); return PBDX_ERR_INVALID; }
 	if (!num_ranges) return PBDX_OK;
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	{ int rs = ensure_stage(s, sizeof(T)); if (rs) return rs; }
 	const uint32_t n = s->n;
 	const bool vec = array <= PBDX_ARRAY_LAST_X;
@@ -2466,7 +2468,8 @@ int pbdx_solver_create(pbdx_solver **out, int device)
 	pbdx_solver *s = new (std::nothrow) pbdx_solver();
 	if (!s) { set_error("out of memory"); return PBDX_ERR_ALLOC; }
 	s->device = device;
-	hipError_t e = hipSetDevice(device);
+	DeviceScope device_scope_(device);
+	hipError_t e = device_scope_.err;
 	if (e == hipSuccess) e = hipGetDeviceProperties(&s->prop, device);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream_side, hipStreamNonBlocking);
@@ -2491,7 +2494,7 @@ int pbdx_solver_create(pbdx_solver **out, int device)
 void pbdx_solver_destroy(pbdx_solver *s)
 {
 	if (!s) return;
-	(void)hipSetDevice(s->device);
+	DeviceScope device_scope_(s->device);
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
 	s->drop_graph();
 	s->free_batches();
@@ -2536,7 +2539,7 @@ int pbdx_solver_set_positions(pbdx_solver *s, uint32_t n, const float *x)
 {
 	if (!s || !x || n != s->n) { set_error("set_positions: particle count mismatch"); return PBDX_ERR_INVALID; }
 	if (!n) return PBDX_OK;
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipMemcpyAsync(s->d_stage, x, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, s->stream));
 	hipLaunchKernelGGL(set_xyz_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_stage, s->d_pos[0], n);
 	HIPCHECK(hipGetLastError());
@@ -2575,7 +2578,7 @@ int pbdx_solver_update_particle_ranges_f64(pbdx_solver *s, int array, const doub
 int pbdx_solver_begin_schedule(pbdx_solver *s)
 {
 	if (!s) return PBDX_ERR_INVALID;
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	s->drop_graph();
 	s->free_batches();
@@ -2596,7 +2599,7 @@ int pbdx_solver_add_batch(pbdx_solver *s, uint32_t group, int type, uint32_t cou
 	const uint32_t nb = ti->num_bodies;
 	for (size_t i = 0; i < (size_t)count * nb; i++)
 		if (indices[i] >= s->n) { set_error("add_batch: particle index %u out of range (%u particles uploaded)", indices[i], s->n); return PBDX_ERR_INVALID; }
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 
 	// host image only: the device arrays of schedule (B) are created on first use (ensure_device_batches);
 	// the fused schedule (A) never needs them
@@ -2636,7 +2639,7 @@ int pbdx_solver_commit_params(pbdx_solver *s)
 {
 	if (!s || s->schedule_open) return PBDX_ERR_INVALID;
 	if (!s->params_dirty) return PBDX_OK;
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	s->params_dirty = false;
 	s->drop_graph();                       // the scalar parameters (TypeView::u) are kernel arguments of the captured launches
@@ -2723,7 +2726,7 @@ int pbdx_solver_set_instancing(pbdx_solver *s, uint32_t particles_per_instance, 
 	const uint32_t k = instances ? instances : 1u;
 	if (k != s->inst_count || (k > 1 && particles_per_instance != s->inst_particles))
 	{
-		HIPCHECK(hipSetDevice(s->device));
+		ENTER_DEVICE(s->device);
 		HIPCHECK(hipStreamSynchronize(s->stream));
 		s->inst_count = k; s->inst_particles = k > 1 ? particles_per_instance : 0;
 		s->drop_graph();
@@ -2797,7 +2800,7 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 	s->drop_graph();
 	if (replan && s->plan_built)
 	{
-		HIPCHECK(hipSetDevice(s->device));
+		ENTER_DEVICE(s->device);
 		HIPCHECK(hipStreamSynchronize(s->stream));
 		s->free_plan();
 	}
@@ -2816,7 +2819,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 {
 	if (!s || !gravity || sub_steps == 0) { set_error("step: bad arguments"); return PBDX_ERR_INVALID; }
 	if (s->schedule_open) { set_error("step: schedule still open"); return PBDX_ERR_INVALID; }
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	const bool fresh_plan = !s->plan_built;
 	int rp = ensure_plan(s);
 	if (!rp && fresh_plan) rp = autotune_schedule(s);
@@ -3029,7 +3032,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
 {
 	if (!s || s->schedule_open) { set_error("project: bad state"); return PBDX_ERR_INVALID; }
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	const bool fresh_plan = !s->plan_built;
 	int r = ensure_plan(s);
 	if (!r && fresh_plan) r = autotune_schedule(s);
@@ -3075,7 +3078,7 @@ int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
 int pbdx_solver_synchronize(pbdx_solver *s)
 {
 	if (!s) return PBDX_ERR_INVALID;
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	return PBDX_OK;
 }
@@ -3085,7 +3088,7 @@ int pbdx_solver_set_colliders(pbdx_solver *s, uint32_t n, const pbdx_collider *c
 	if (!s || (n && !colliders)) { set_error("set_colliders: bad arguments"); return PBDX_ERR_INVALID; }
 	for (uint32_t i = 0; i < n; i++)
 		if (colliders[i].shape < PBDX_SHAPE_BOX || colliders[i].shape > PBDX_SHAPE_HOLLOW_BOX) { set_error("set_colliders: unknown shape %d", colliders[i].shape); return PBDX_ERR_UNSUPPORTED; }
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	if (s->d_colliders) { (void)hipFree(s->d_colliders); s->d_colliders = nullptr; }
 	s->colliders.assign(colliders, colliders + n);
@@ -3107,7 +3110,7 @@ int pbdx_solver_set_collision_ranges(pbdx_solver *s, uint32_t n, const pbdx_coll
 	if (!s || (n && !ranges)) { set_error("set_collision_ranges: bad arguments"); return PBDX_ERR_INVALID; }
 	for (uint32_t i = 0; i < n; i++)
 		if ((uint64_t)ranges[i].first + ranges[i].count > s->n) { set_error("set_collision_ranges: range %u exceeds the %u uploaded particles", i, s->n); return PBDX_ERR_INVALID; }
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	s->ranges.assign(ranges, ranges + n);
 	if (s->d_ranges) { (void)hipFree(s->d_ranges); s->d_ranges = nullptr; }
@@ -3129,7 +3132,7 @@ int pbdx_solver_set_contact_params(pbdx_solver *s, float tolerance, float contac
 int pbdx_solver_set_rest_positions(pbdx_solver *s, uint32_t n, const float *x0)
 {
 	if (!s || !x0 || n != s->n || !n) { set_error("set_rest_positions: particle count mismatch (upload the particles first)"); return PBDX_ERR_INVALID; }
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	{ int rs = ensure_stage(s, sizeof(float)); if (rs) return rs; }
 	if (!s->d_rest) HIPCHECK(hipMalloc(&s->d_rest, (size_t)n * sizeof(float4)));
 	HIPCHECK(hipMemcpyAsync(s->d_stage, x0, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, s->stream));
@@ -3151,7 +3154,7 @@ static int set_tet_colliders_impl(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 {
 	if (!s || (n && !colliders) || n > 256) { set_error("set_tet_colliders: bad arguments (at most 256 colliders)"); return PBDX_ERR_INVALID; }
 	{ const int rv = validate_tet_colliders(n, colliders, s->n); if (rv) return rv; }
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	s->free_tet_colliders();
 	s->drop_graph();
@@ -3271,7 +3274,7 @@ int pbdx_debug_tet_counters(pbdx_solver *s, uint32_t out[8])
 	if (!s || !out) return PBDX_ERR_INVALID;
 	memset(out, 0, 8 * sizeof(uint32_t));
 	if (!s->d_tet_counters) return PBDX_OK;
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	HIPCHECK(hipMemcpy(out, s->d_tet_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
 	return PBDX_OK;
@@ -3288,7 +3291,7 @@ int pbdx_debug_tet_impulses(pbdx_solver *s, uint32_t *last, uint64_t *total)
 int pbdx_debug_tet_hulls(pbdx_solver *s, uint32_t collider, int which, uint32_t capacity, uint32_t *count, float *out)
 {
 	if (!s || !count || collider >= s->tet_dev.size() || which < 0 || which > 2) return PBDX_ERR_INVALID;
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	const pbdx_solver::DevBvh &b = which == 0 ? s->tet_dev[collider].points : which == 1 ? s->tet_dev[collider].tet_bvh : s->tet_dev[collider].tet_bvh0;
 	*count = b.num_nodes;
@@ -3301,7 +3304,7 @@ int pbdx_solver_get_tet_contacts(pbdx_solver *s, uint32_t capacity, uint32_t *co
 	if (!s || !count) return PBDX_ERR_INVALID;
 	*count = 0;
 	if (!s->tet_active() || !s->d_tet_counters) return PBDX_OK;
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	uint32_t c[kTcWords];
 	HIPCHECK(hipMemcpy(c, s->d_tet_counters, sizeof(c), hipMemcpyDeviceToHost));
@@ -3321,7 +3324,7 @@ int pbdx_solver_get_num_contacts(pbdx_solver *s, uint32_t *out)
 	if (!s || !out) return PBDX_ERR_INVALID;
 	*out = 0;
 	if (!s->d_contact_counters) return PBDX_OK;
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	unsigned int c[2] = { 0, 0 };
 	HIPCHECK(hipMemcpy(c, s->d_contact_counters, sizeof(c), hipMemcpyDeviceToHost));
@@ -3335,7 +3338,7 @@ int pbdx_solver_get_lambdas(pbdx_solver *s, uint32_t batch_index, uint32_t count
 	if (!s || !out || batch_index >= s->batches.size()) { set_error("get_lambdas: bad batch"); return PBDX_ERR_INVALID; }
 	const Batch &b = s->batches[batch_index];
 	if (!type_info(b.type)->xpbd || count != b.count) { set_error("get_lambdas: batch has no multipliers or count mismatch"); return PBDX_ERR_INVALID; }
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	if (!s->fused_active())
 	{
@@ -3457,7 +3460,7 @@ int pbdx_solver_get_trace(pbdx_solver *s, uint32_t segment, uint64_t *out, uint3
 	const DeviceSegment &d = s->dsegs[segment];
 	const size_t need = (size_t)d.num_tiles * kTraceStride;
 	if (capacity < need) { set_error("get_trace: need room for %zu stamps", need); return PBDX_ERR_INVALID; }
-	HIPCHECK(hipSetDevice(s->device));
+	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	HIPCHECK(hipMemcpy(out, d.d_trace, need * sizeof(uint64_t), hipMemcpyDeviceToHost));
 	if (stride) *stride = kTraceStride;
@@ -3466,7 +3469,7 @@ int pbdx_solver_get_trace(pbdx_solver *s, uint32_t segment, uint64_t *out, uint3
 
 int pbdx_debug_stream(int device, uint64_t nbytes, int mode)
 {
-	HIPCHECK(hipSetDevice(device));
+	ENTER_DEVICE(device);
 	if (nbytes < 4096) { set_error("debug_stream: nbytes too small"); return PBDX_ERR_INVALID; }
 	float *buf = nullptr, *sink = nullptr;
 	HIPCHECK(hipMalloc(&buf, nbytes));

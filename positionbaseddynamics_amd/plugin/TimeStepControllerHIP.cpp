@@ -78,12 +78,25 @@ namespace
 	}
 	struct PushSink { std::vector<float> &v; inline void operator()(float f) { v.push_back(f); } };
 	inline void pushParams(std::vector<float> &p, int type, Constraint *c) { PushSink s = { p }; visitParams(s, type, c); }
-	// sequential 64-bit mix over the record's floats (order matters inside a record)
+	// Hash of parameter records: the XOR of pbdx_hash_word (include/pbdx.h: a bijective multiplicative mix) over the records' floats
+	// taken two at a time, each pair mixed with (constraint index, position in the record).  The terms are independent of each other
+	// (no serial chain through the multiplier's latency: the walk stays memory-bound), a single changed float always changes the
+	// hash, and equal values in different constraints do not cancel.
 	struct HashSink
 	{
-		uint64_t h;
-		inline void operator()(float f) { uint32_t u; memcpy(&u, &f, 4); h = (h ^ (uint64_t)u) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+		uint64_t h; uint32_t idx, pend; bool half;
+		inline void begin(uint32_t constraint) { idx = constraint << 5; half = false; }      // records hold at most 24 floats = 12 pairs
+		inline void operator()(float f)
+		{
+			uint32_t u; memcpy(&u, &f, 4);
+			if (!half) { pend = u; half = true; }
+			else { h ^= pbdx_hash_word((uint64_t)pend | ((uint64_t)u << 32), idx++); half = false; }
+		}
+		inline void end() { if (half) { h ^= pbdx_hash_word((uint64_t)pend, idx++); half = false; } }
 	};
+#ifndef PBDX_SCAN_PREFETCH
+#define PBDX_SCAN_PREFETCH 12     // objects ahead (scripts/dev/scan_bench.cpp)
+#endif
 	const size_t kParamScanBlock = 2048;          // constraints per 64-bit hash of the exact parameter scan
 
 	// FNV-1a over raw bytes
@@ -579,16 +592,21 @@ void TimeStepControllerHIP::hashParameters(SimulationModel &model, std::vector<u
 	{
 		uint64_t h = 1469598103934665603ull ^ (uint64_t)nc;
 		const size_t stride = nc > 4096 ? nc / 4096 : 1;
-		for (size_t i = 0; i < nc; i += stride) { HashSink s = { h }; visitParams(s, engineType(constraints[i]), constraints[i]); h = s.h; }
-		if (nc) { HashSink s = { h }; visitParams(s, engineType(constraints[nc - 1]), constraints[nc - 1]); h = s.h; }
-		out.assign(1, h);
+		HashSink s = { h, 0u, 0u, false };
+		for (size_t i = 0; i < nc; i += stride) { s.begin((uint32_t)i); visitParams(s, engineType(constraints[i]), constraints[i]); s.end(); }
+		if (nc) { s.begin((uint32_t)nc); visitParams(s, engineType(constraints[nc - 1]), constraints[nc - 1]); s.end(); }
+		out.assign(1, s.h);
 		return;
 	}
 	const size_t nb = (nc + kParamScanBlock - 1) / kParamScanBlock;
 	out.resize(nb + 1);
 	out[nb] = (uint64_t)nc;
-	int threads = nc >= 65536 ? omp_get_num_procs() : 1;
-	if (threads > 32) threads = 32;
+	// one thread per 32 768 constraints, at most 64 (measured on the 256-CPU host of the MI355X box, scripts/dev/scan_bench.cpp: the walk
+	// scales with the threads up to there; a fork / join of 64 threads costs a few tens of microseconds)
+	int threads = (int)(nc / 32768);
+	if (threads > omp_get_num_procs()) threads = omp_get_num_procs();
+	if (threads > 64) threads = 64;
+	if (threads < 1) threads = 1;
 	if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) threads = v; }      // developer aid
 	Constraint *const *cs = constraints.data();
 	uint64_t *o = out.data();
@@ -596,19 +614,21 @@ void TimeStepControllerHIP::hashParameters(SimulationModel &model, std::vector<u
 	for (long long b = 0; b < (long long)nb; b++)
 	{
 		const size_t first = (size_t)b * kParamScanBlock, last = first + kParamScanBlock < nc ? first + kParamScanBlock : nc;
-		HashSink s = { 0x51ed270b7d0e3a5full ^ (uint64_t)b };
+		HashSink s = { 0x51ed270b7d0e3a5full ^ (uint64_t)b, 0u, 0u, false };
 		// objects of one class share their vtable pointer: the type lookup (a virtual call + up to 13 compares) is repeated only
 		// where the class changes (shape matching always: its engine type also depends on the number of bodies)
 		const void *lastVptr = nullptr; int lastType = -1;
 		for (size_t i = first; i < last; i++)
 		{
-			if (i + 12 < last) { const char *nx = (const char *)cs[i + 12]; __builtin_prefetch(nx); __builtin_prefetch(nx + 64); }
+			if (i + PBDX_SCAN_PREFETCH < last) { const char *nx = (const char *)cs[i + PBDX_SCAN_PREFETCH]; __builtin_prefetch(nx); __builtin_prefetch(nx + 64); }
 			Constraint *c = cs[i];
 			const void *vptr = *(const void *const *)c;
 			int type = lastType;
 			if (vptr != lastVptr || type == PBDX_SHAPE_MATCHING) { type = engineType(c); lastVptr = vptr; lastType = type; }
+			s.begin((uint32_t)i);
 			s((float)type);
 			visitParams(s, type, c);
+			s.end();
 		}
 		o[b] = s.h;
 	}

@@ -120,3 +120,92 @@ def test_bench_gpus_n_spawns_its_own_ranks():
     assert all(q.returncode == 0 for q in procs), outs[0][1][-2000:]
     res = json.loads(outs[0][0].strip().splitlines()[-1])
     assert res["rccl_ranks"] == 2 and not res["spawned_by_bench"] and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+
+
+def test_a_dying_rank_ends_the_job_instead_of_hanging_it():
+    """One rank exits before the rendezvous (what a rank without a GPU does): `bench.py --gpus 2` must stop the other rank and
+    fail with that rank's exit code within seconds -- not wait for a rendezvous time-out."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["PBDX_SELFTEST_FAIL_RANK"] = "1"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--rank-selftest"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and "rank 1 exited with code 3" in p.stderr, p.stderr[-2000:]
+    assert time.time() - t0 < 90
+
+
+def test_nccl_rank_without_a_device_fails_before_the_rendezvous():
+    """backend nccl and LOCAL_RANK >= visible devices (here: no GPU at all, or rank 7 on a one-GPU box): a clear error, immediately."""
+    code = ("import os,sys; sys.path.insert(0, %r); os.environ.update(RANK='7', LOCAL_RANK='7', WORLD_SIZE='8', MASTER_ADDR='127.0.0.1', MASTER_PORT='1');"
+            "from positionbaseddynamics_amd.ensemble import Ensemble\n"
+            "try:\n    Ensemble(backend='nccl')\nexcept RuntimeError as e:\n    print('REFUSED', e)\n") % util.ROOT
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 0 and "REFUSED" in p.stdout and "LOCAL_RANK 7" in p.stdout, p.stdout + p.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_rccl_process_group_at_world_size_one_on_the_gpu():
+    """The backend the 8-GPU run uses (torch.distributed "nccl" = RCCL), exercised on the one GPU there is: init_process_group with
+    device_id, the MAX / SUM all-reduces and the one-hot gathers bench.py issues, barrier, destroy_process_group."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--rank-selftest", "--dist-backend", "nccl"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    print(p.stderr.strip().splitlines()[-1][:400])
+    assert res["dist_backend"] == "nccl" and res["rccl_ranks"] == 1 and res["ranks"] == [0.0] and res["sum"] == 1 and res["max_time"] == pytest.approx(0.5)
+
+
+@pytest.mark.gpu
+def test_rccl_ensemble_step_and_checksum_exchange_on_the_gpu():
+    """One rank of the c4 workload over RCCL (world size 1): the whole bench path -- engine steps on the rank's device, barrier,
+    max-over-ranks time, constraint sum, per-rank checksums -- with backend nccl, and the device mapping it reports."""
+    import json
+    env = dict({k: v for k, v in os.environ.items() if k not in ("MASTER_PORT",)}, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "1", "--workload", "c4", "--size", "40", "--instances", "3", "--steps", "5", "--warmup", "2",
+                        "--dist-backend", "nccl", "--no-cpu-baseline", "--no-traffic", "--no-extras"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    mapping = [ln for ln in p.stderr.splitlines() if ln.startswith("[bench rank 0/1]")]
+    assert mapping and "HIP device 0" in mapping[0]
+    print(mapping[0][:300])
+    assert res["config"]["dist_backend"] == "nccl" and res["config"]["rank_hip_devices"] == [0] and res["config"]["state_ok"]
+
+
+@pytest.mark.gpu
+def test_two_solvers_on_two_devices_in_one_process_do_not_disturb_each_other():
+    """Two engines in one process on devices 0 and min(1, n - 1), stepped in turns while the CALLER keeps its own current device:
+    both produce the single-solver result bit for bit, and the calling thread's current HIP device is what it was before every
+    call (csrc/pbdx_device.h: every entry point selects its solver's device and restores the caller's)."""
+    import torch
+    import positionbaseddynamics_amd as pbd
+    n = pbd.device_count()
+    devices = [0, min(1, n - 1)]
+    spec = util.cloth_spec(40, 30, 4, 3)
+
+    def make(dev):
+        model = util.build_mine(spec)
+        ts = pbd.TimeStepController(device=dev)
+        ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+        ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 10)
+        return model, ts
+
+    ref_model, ref_ts = make(0)
+    for _ in range(6):
+        ref_ts.step(ref_model)
+    want = ref_model.getParticles().positions().copy()
+    caller_device = n - 1                      # the caller's own current device (the last one; = 0 on a one-GPU box)
+    torch.cuda.set_device(caller_device)
+    pairs = [make(d) for d in devices]
+    for _ in range(6):
+        for model, ts in pairs:
+            ts.step(model)
+            assert torch.cuda.current_device() == caller_device
+    for (model, ts), d in zip(pairs, devices):
+        got = model.getParticles().positions()
+        assert util.bitwise_equal(got, want), "device %d" % d
+    print("two solvers on devices %r of %d, caller's device %d untouched" % (devices, n, caller_device))
