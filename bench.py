@@ -233,12 +233,22 @@ def run_workload(w, opts, ens, steps, warmup, with_roofline, with_traffic, with_
 
     # warm-up (untimed): uploads the device image, plans, measures the schedule candidates, instantiates the hipGraph
     ts.stepResident(model, max(warmup, 1))
+    # "hipEvents around the device-resident substep loop ..., >= 50 substeps, median": one event after every substep of
+    # the timed call on the engine's stream (the graph replay is unchanged), so the median DEVICE time per substep of exactly the
+    # timed steps is reported beside the host-clock mean that `value` is computed from
+    sol.set_option(S.OPT_SUBSTEP_EVENTS, 1)
     barrier()
     t0 = time.perf_counter()
     ts.stepResident(model, steps)          # synchronises its own stream before returning
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
     stats = sol.stats()
+    sub_ms = sorted(sol.substep_times())
+    sol.set_option(S.OPT_SUBSTEP_EVENTS, 0)
+    substep_device = None
+    if sub_ms:
+        substep_device = {"n": len(sub_ms), "median_ms": sub_ms[len(sub_ms) // 2], "mean_ms": sum(sub_ms) / len(sub_ms), "min_ms": sub_ms[0],
+                          "p90_ms": sub_ms[min(len(sub_ms) - 1, (9 * len(sub_ms)) // 10)], "max_ms": sub_ms[-1]}
     plan = sol.plan_info()
     persist = sol.persistent_info()
     barrier()
@@ -250,7 +260,7 @@ def run_workload(w, opts, ens, steps, warmup, with_roofline, with_traffic, with_
     ok = bool(np.all(np.isfinite(x)) and all(np.array_equal(x[p], x0[p]) for p in pins))
     res = {"desc": desc, "t_local": t_local, "n_particles": n_particles, "n_constraints": n_constraints, "n_groups": n_groups,
            "t_build": t_build, "stats": stats, "plan": plan, "persistent": persist, "state_ok": ok, "checksum": checksum(x),
-           "engine": sol.describe(), "steps_done": max(warmup, 1) + steps}
+           "engine": sol.describe(), "steps_done": max(warmup, 1) + steps, "substep_device": substep_device}
 
     if with_pcie and ens.rank == 0:
         # PCIe-inclusive rate of the TimeStep::step contract (host ParticleData in -> step -> host ParticleData out every
@@ -286,13 +296,13 @@ def run_workload(w, opts, ens, steps, warmup, with_roofline, with_traffic, with_
         sol.set_collision_ranges([])
 
     if with_roofline and ens.rank == 0:
-        res["roofline"] = roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles, stats)
+        res["roofline"] = roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles, stats, substep_device)
         if with_traffic and res["roofline"] is not None and ens.world == 1:
             add_profiled_passes(res["roofline"], w, opts, plan, persist)
     return res
 
 
-def roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles, timed_stats=None):
+def roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles, timed_stats=None, substep_device=None):
     """Dominant kernel of the workload, bytes as SURVEY 8d defines them, duration measured live with HIP events on the
     engine's own stream.  Where ONE launch is the whole substep (persistent schedule with integration and velocity update
     folded in) the duration is taken in the SAME mode as the timed loop: the device-event time of the timed region (graph
@@ -316,6 +326,9 @@ def roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles, timed_stat
         if folded and timed_stats and timed_stats["total_ms"] > 0 and timed_stats["kernel_launches"] == steps:
             dur_s = 1e-3 * timed_stats["total_ms"] / steps
             mode = "timed region: HIP events around the %d graph-replayed launches of the timed loop / %d" % (steps, steps)
+            if substep_device and substep_device["n"] == steps:
+                dur_s = 1e-3 * substep_device["median_ms"]
+                mode = "timed region: MEDIAN of the %d per-substep HIP-event intervals of the timed loop (one launch per substep, graph replay)" % steps
         if folded:      # the launch also integrates and updates the velocities (140 B per particle)
             bytes_per_launch += n_particles * 140
         segs = [sol.segment_info(i) for i in range(plan["num_segments"])]
@@ -327,6 +340,7 @@ def roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles, timed_stat
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "streamed_bytes_per_launch": streamed,
                 "compulsory_bytes_per_launch": compulsory, "avg_launch_us": dur_s * 1e6, "timing_mode": mode,
+                "mean_launch_us_timed_region": (1e3 * timed_stats["total_ms"] / steps) if (timed_stats and steps) else None,
                 "eager_launch_us": eager_s * 1e6,
                 "launches_measured": steps if dur_s != eager_s else pinfo["profiled_launches"], "grid": pinfo["grid"], "block": pinfo["block"], "lds_bytes": pinfo["lds_bytes"], "folded": folded,
                 "segments": [{"segment": i, "colours": [si["colour_begin"], si["colour_end"]], "tiles": si["num_tiles"], "constraints": si["constraints"], "slots": si["slots"],
@@ -406,6 +420,18 @@ def add_profiled_passes(r, w, opts, plan, persist):
             nl = sum(x["launches"] for x in rows)
             r["event_mean_launch_us_all_segments"] = sum(x["avg_us"] * x["launches"] for x in rows) / nl
     dur_us = r["avg_launch_us"] if persist["active"] else r.get("event_mean_launch_us_all_segments") if plan["active"] else None
+    if persist["active"] and dur_us:
+        # VALU issue: SQ_ACTIVE_INST_VALU (quad-cycles in which a SIMD issued a vector-ALU instruction, summed over the SIMDs) against the
+        # SIMD cycles of the launch (GRBM_GUI_ACTIVE: busy cycles summed over the 8 XCDs) -- clock-free
+        va = _pmc_pass("SQ_ACTIVE_INST_VALU", child)
+        ga = _pmc_pass("GRBM_GUI_ACTIVE", child)
+        v = [x for k, xs in (va or {}).items() if kname in k for x in xs]
+        g = [x for k, xs in (ga or {}).items() if kname in k for x in xs]
+        if v and g:
+            simds = 4 * 256
+            r["valu_active_quad_cycles_per_launch"] = sum(v) / len(v)
+            r["gpu_cycles_per_launch"] = sum(g) / len(g) / 8.0
+            r["frac_valu"] = 4.0 * r["valu_active_quad_cycles_per_launch"] / (simds * r["gpu_cycles_per_launch"])
     if r.get("traffic") and dur_us:
         dur_s = dur_us * 1e-6
         r["traffic_GBs"] = r["traffic"] / dur_s / 1e9
@@ -415,6 +441,16 @@ def add_profiled_passes(r, w, opts, plan, persist):
         if r.get("compulsory_bytes_per_launch"):
             r["traffic_over_compulsory"] = r["traffic"] / r["compulsory_bytes_per_launch"]
             r["frac_compulsory"] = r["compulsory_bytes_per_launch"] / dur_s / 1e9 / HBM_PEAK_GBS
+        # SURVEY 8d's algorithmic-byte fraction is saturated (> 1: an LDS-resident tile does not move those bytes), so the
+        # headline `achieved` / `frac` are the PHYSICALLY BOUNDED figures -- bytes the counters saw on the fabric side of the L2 per launch
+        # / the launch's device time / 8 TB/s -- and the contract's number stays beside them as achieved_contract / frac_contract
+        r["achieved_contract"], r["frac_contract"] = r["achieved"], r["frac"]
+        r["achieved"], r["frac"] = r["traffic_GBs"], r["frac_traffic"]
+        r["frac_definition"] = "counter-measured HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated in-pass) / device time per launch / 8 TB/s; frac_contract = SURVEY 8d algorithmic bytes / same time / 8 TB/s"
+    if r.get("frac_valu") is not None:
+        fr = {"hbm traffic": r.get("frac_traffic") or 0.0, "valu issue": r["frac_valu"]}
+        top = max(fr, key=fr.get)
+        r["binding"] = "%s (%.2f of its peak); neither unit is saturated: the colour steps are dependent-latency chains between workgroup barriers" % (top, fr[top]) if fr[top] < 0.8 else "%s (%.2f of its peak)" % (top, fr[top])
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -651,7 +687,7 @@ def _pick(d, keys):
 def compact_roofline(r):
     if not r:
         return None
-    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "traffic_over_compulsory", "algorithmic_bytes_per_launch",
+    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "frac_contract", "achieved_contract", "frac_valu", "binding", "traffic", "frac_traffic", "traffic_over_compulsory", "algorithmic_bytes_per_launch",
                     "compulsory_bytes_per_launch", "avg_launch_us", "eager_launch_us", "rocprofv3_median_kernel_us", "rocprofv3_mean_kernel_us",
                     "rocprofv3_dispatches", "launches_measured"))
     out["kernel"] = str(r.get("kernel", ""))[:110]
@@ -665,7 +701,7 @@ def compact_headline(full, detail_path=None):
     c = full["config"]
     cfg = _pick(c, ("workload", "particles", "constraints", "colour_groups", "projections_per_substep", "rccl_ranks", "dist_backend", "oversubscribed",
                     "per_rank_ms_per_step", "rank_hip_devices", "rank_pci_bus_ids", "state_ok", "replicas_bit_identical", "shards_distinct", "replica_checksums", "shard_parity", "instances_of_rank0",
-                    "device_event_ms_per_substep", "pcie_inclusive_ms_per_step"))
+                    "device_event_ms_per_substep", "device_median_ms_per_substep", "pcie_inclusive_ms_per_step"))
     cfg["workload"] = str(cfg.get("workload", ""))[:200]
     cfg["parallelism"] = "ensemble x%d, no data-path collective" % c.get("rccl_ranks", 1)
     pv = c.get("parity_vs_reference")
@@ -704,7 +740,7 @@ def compact_headline(full, detail_path=None):
 
 def compact_extra(e):
     """One line per extra workload (printed BEFORE the headline)."""
-    out = _pick(e, ("tag", "workload", "particles", "constraints", "colour_groups", "steps", "ms_per_substep", "ms_per_step", "projections_per_s", "state_ok",
+    out = _pick(e, ("tag", "workload", "particles", "constraints", "colour_groups", "steps", "warmup", "ms_per_substep", "device_median_ms_per_substep", "ms_per_step", "projections_per_s", "state_ok",
                     "host_scene_build_s", "bit_identical", "compared_values", "parity_steps", "contacts_deformable_total", "contacts_floor_total", "contacts_max", "sub_steps", "iterations",
                     "reference_ms_per_step", "reference_reproduces_fixture", "error"))
     if "workload" in out:
@@ -945,6 +981,7 @@ def main():
                    "instances_of_rank0": list(ens.shard(args.total_instances if args.scaling == "strong" else args.instances * world)) if args.workload == "c4" else None,
                    "state_checksum": "%016x" % sums[0],
                    "device_event_ms_per_substep": stats["total_ms"] / max(args.steps, 1),
+                   "device_median_ms_per_substep": (res.get("substep_device") or {}).get("median_ms"), "substep_device_times": res.get("substep_device"),
                    "algorithmic_GB_per_substep": stats["algorithmic_bytes"] / max(args.steps, 1) / 1e9,
                    "whole_substep_algorithmic_GBs": stats["algorithmic_bytes"] / max(stats["total_ms"], 1e-9) / 1e6,
                    "host_scene_build_s": res["t_build"], "contacts": res.get("contacts"),
@@ -964,17 +1001,25 @@ def main():
         # the other BASELINE workloads that fit one GPU, witnessed in the same line (shorter runs; same engine, defaults)
         extras = []
         base = {"size": 200, "instances": 64, "bars": False, "solid_method": 2, "iters": args.iters, "scaling": "weak", "total_instances": 512}
-        for tag, ew, want_traffic in (("c3_fem_tets", {**base, "workload": "c3", "solid_method": 2}, True), ("c3_strain_tets", {**base, "workload": "c3", "solid_method": 4}, False),
-                                      ("c3_xpbd_distance_volume", {**base, "workload": "c3", "solid_method": 6}, False), ("c4_block_64x200x200", {**base, "workload": "c4"}, True)):
+        # (tag, workload, PMC traffic passes, warm-up steps).  SURVEY 8d: timing after >= 20 warm-up steps.  The E = 1 bar of configs[2]
+        # collapses under gravity and more of its tets take the inversion-handling branch as the run goes on: `c3_fem_tets_late` times the same
+        # substep after 100 warm-up steps; `c3_x32_fem` is the form that fills the GPU with this workload (32 independent bars, instanced)
+        for tag, ew, want_traffic, wu in (("c3_fem_tets", {**base, "workload": "c3", "solid_method": 2}, True, 20),
+                                          ("c3_fem_tets_late", {**base, "workload": "c3", "solid_method": 2}, False, 100),
+                                          ("c3_strain_tets", {**base, "workload": "c3", "solid_method": 4}, False, 20),
+                                          ("c3_xpbd_distance_volume", {**base, "workload": "c3", "solid_method": 6}, False, 20),
+                                          ("c3_x32_fem", {**base, "workload": "c3", "solid_method": 2, "bars": True, "instances": 32}, False, 20),
+                                          ("c4_block_64x200x200", {**base, "workload": "c4"}, True, 20)):
+            nsteps = max(10, min(args.steps, 30))
             try:
-                r = run_workload(ew, {}, ens, max(10, min(args.steps, 30)), 5, with_roofline=not args.no_roofline, with_traffic=want_traffic and not args.no_traffic)
+                r = run_workload(ew, {}, ens, nsteps, wu, with_roofline=not args.no_roofline, with_traffic=want_traffic and not args.no_traffic)
             except Exception as e:  # an extra must never cost the headline line
                 extras.append({"tag": tag, "workload": ew["workload"], "error": repr(e)})
                 continue
-            nsteps = max(10, min(args.steps, 30))
             ms = 1e3 * r["t_local"] / nsteps
             extras.append({"tag": tag, "workload": r["desc"], "particles": r["n_particles"], "constraints": r["n_constraints"], "colour_groups": r["n_groups"],
-                           "steps": nsteps, "ms_per_substep": ms, "projections_per_s": r["n_constraints"] * ew["iters"] * nsteps / r["t_local"],
+                           "steps": nsteps, "warmup": wu, "ms_per_substep": ms, "device_median_ms_per_substep": (r.get("substep_device") or {}).get("median_ms"),
+                           "projections_per_s": r["n_constraints"] * ew["iters"] * nsteps / r["t_local"],
                            "state_ok": r["state_ok"], "host_scene_build_s": r["t_build"], "plan": r["plan"], "persistent": r["persistent"],
                            "engine": r["engine"], "roofline": r.get("roofline")})
         for sub in (8, 5):

@@ -365,8 +365,11 @@ enum {
 	                                * (smaller tiles, more halo) and one tile's fill / hand-off overlaps another tile's colour sweep on the same CU */
 	PBDX_OPT_TET_CONTACTS_SERIAL = 15,   /* developer cross-check: 1 = detect and solve the contacts between deformable solids in ONE thread, in the reference's own
 	                                      * control flow (default 0: the parallel, order-preserving form of pbdx_tetcontact_dev.h; both give the same bits) */
-	PBDX_OPT_TET_FORCE_IMPULSES = 16     /* developer aid (test of the velocity-impulse application path of particle-tet contacts): 1 = contacts with pMax > 0
+	PBDX_OPT_TET_FORCE_IMPULSES = 16,    /* developer aid (test of the velocity-impulse application path of particle-tet contacts): 1 = contacts with pMax > 0
 	                                      * are given the impulse the reference gives contacts with pMax < 0 -- NOT the reference's result; default 0 */
+	PBDX_OPT_SUBSTEP_EVENTS = 17,        /* measurement (SURVEY 8d "hipEvents around the device-resident substep loop ... median"): 1 = pbdx_solver_step records one
+	                                      * HIP event after every substep on the engine's stream; pbdx_solver_get_substep_times returns the device time of
+	                                      * each substep of the last call.  Default 0 */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
 
@@ -423,6 +426,11 @@ typedef struct pbdx_step_stats {
 	uint64_t algorithmic_bytes; /* SURVEY 8d bytes: sum_type count*bytes_per_projection*iters + particles*140 */
 } pbdx_step_stats;
 int pbdx_solver_get_stats(pbdx_solver *s, pbdx_step_stats *out);
+/* Device time of every substep of the last pbdx_solver_step call, in milliseconds (PBDX_OPT_SUBSTEP_EVENTS; replaces nothing in the
+ * reference -- Utils/Timing.h is the nearest): substep k = from the event after substep k - 1 (the call's start event for k = 0) to the
+ * event after substep k.  *count = substeps measured (0: option off, per-launch profiling on, or the call recovered from a refused /
+ * timed-out persistent launch); at most `capacity` values are written to out_ms (may be NULL). */
+int pbdx_solver_get_substep_times(pbdx_solver *s, float *out_ms, uint32_t capacity, uint32_t *count);
 /* profile_kernels != 0: bracket every projection launch with HIP events (no graph). */
 int pbdx_solver_set_profiling(pbdx_solver *s, int profile_kernels);
 /* Per-constraint-type totals of the last profiled pbdx_solver_step: milliseconds summed over

@@ -670,6 +670,14 @@ class Solver:
         check(lib.pbdx_solver_get_stats(self._h, C.byref(st)), "get_stats")
         return {k: getattr(st, k) for k, _ in StepStats._fields_}
 
+    def substep_times(self):
+        """Device milliseconds of every substep of the last step call (set_option(OPT_SUBSTEP_EVENTS, 1) beforehand)."""
+        n = C.c_uint32(0)
+        check(lib.pbdx_solver_get_substep_times(self._h, None, 0, C.byref(n)), "get_substep_times")
+        buf = (C.c_float * max(n.value, 1))()
+        check(lib.pbdx_solver_get_substep_times(self._h, buf, n.value, C.byref(n)), "get_substep_times")
+        return [float(buf[i]) for i in range(n.value)]
+
     def type_stats(self, ctype):
         ms = C.c_double()
         launches = C.c_uint64()
@@ -781,6 +789,7 @@ class Solver:
     OPT_PERSISTENT_WGS_PER_CU = 14
     OPT_TET_CONTACTS_SERIAL = 15
     OPT_TET_FORCE_IMPULSES = 16
+    OPT_SUBSTEP_EVENTS = 17
     OPT_USE_GRAPH = 1
     OPT_BLOCK_SIZE = 2
     OPT_XCD_REMAP = 3

@@ -105,6 +105,7 @@ SIGNATURES = [
     ("pbdx_solver_get_lambdas", C.c_int, vp, u32, u32, pf),
     ("pbdx_solver_set_option", C.c_int, vp, C.c_int, i64),
     ("pbdx_solver_get_stats", C.c_int, vp, C.POINTER(StepStats)),
+    ("pbdx_solver_get_substep_times", C.c_int, vp, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)),
     ("pbdx_solver_set_profiling", C.c_int, vp, C.c_int),
     ("pbdx_solver_get_type_stats", C.c_int, vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)),
     ("pbdx_solver_describe", C.c_int, vp, C.c_char_p, C.c_size_t),

@@ -956,11 +956,11 @@ __global__ __launch_bounds__(256) void hash_blocks_kernel(const uint32_t *__rest
 	const uint64_t first = (uint64_t)blockIdx.x * bytes_per_block;
 	uint64_t last = first + bytes_per_block;
 	if (last > total_bytes) last = total_bytes;
-	const uint64_t *words = reinterpret_cast<const uint64_t *>(words32);
 	uint64_t h = 0;
 	for (uint64_t o = first + 8ull * threadIdx.x; o < last; o += 8ull * 256)
 	{
-		const uint64_t w = o + 8 <= last ? words[o >> 3] : (uint64_t)words32[o >> 2];      // an odd 32-bit word at the very end of the array
+		// (assembled from two 32-bit loads: the staging slot of array q starts at 3 n q sizeof(T), 4-byte aligned only for odd n)
+		const uint64_t w = o + 8 <= last ? ((uint64_t)words32[o >> 2] | ((uint64_t)words32[(o >> 2) + 1] << 32)) : (uint64_t)words32[o >> 2];      // an odd 32-bit word at the very end of the array
 		h ^= pbdx_hash_word(w, (uint32_t)(o >> 3));
 	}
 	for (int o = 32; o > 0; o >>= 1) h ^= __shfl_xor(h, o, 64);
@@ -1185,6 +1185,7 @@ struct pbdx_solver
 	int fuse_choice = 1;                 // outcome of the auto mode for the current schedule
 	float autotune_ms[3] = { 0.0f, 0.0f, 0.0f }; // measured time of 12 sweeps: per-colour / fused / fused persistent (0 = not measured)
 	bool persist_choice = false;         // outcome of the measurement for the one-launch form
+	bool autotuned_for_tet = false;      // ... taken with / without deformable colliders installed (they select the per-iteration form): re-measured when that changes
 	uint32_t tile_particles = 0;
 	int fuse_block = 0;                  // 0 = auto
 	uint32_t max_segment_colours = 16;
@@ -1299,6 +1300,8 @@ struct pbdx_solver
 	bool graph_valid[2] = { false, false };
 
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	// PBDX_OPT_SUBSTEP_EVENTS: one event after every substep of a pbdx_solver_step call (device time per substep: median / spread)
+	int substep_events = 0; std::vector<hipEvent_t> sub_events; std::vector<float> substep_ms;
 	hipStream_t stream_side = nullptr;                 // forked from / joined to `stream` (also under capture): the short nodes' spheres next to the long chains
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	std::vector<hipEvent_t> prof_events;
@@ -1924,6 +1927,7 @@ int projection_sweeps(pbdx_solver *s, float dt, uint32_t iterations, int src, Pr
 // bit-identical, so the choice can never change a result.
 int autotune_schedule(pbdx_solver *s)
 {
+	s->autotuned_for_tet = s->tet_active();      // the measurement below times the form this decides (per substep / per iteration)
 	s->fuse_choice = 1;
 	s->persist_choice = s->persistent >= 2;      // 2 = always, 3 = self-test (always try, and be refused)
 	s->autotune_ms[0] = s->autotune_ms[1] = s->autotune_ms[2] = 0.0f;
@@ -2195,12 +2199,14 @@ int enqueue_tet_detection(pbdx_solver *s)
 		hipLaunchKernelGGL(tet_impulse_clear_kernel, dim3(64), dim3(256), 0, s->stream, (const TetContact *)s->d_tet_contacts, s->tet_work);
 		const uint64_t nodes = more_nodes ? (uint64_t)s->tet_work.node_cap * 4u : s->tet_work.node_cap;
 		const uint64_t contacts = more_contacts ? (uint64_t)s->tet_work.max_contacts * 4u : s->tet_work.max_contacts;
-		if (nodes > (1ull << 29) || contacts > (1ull << 24) || (s->tet_serial && more_nodes)) return PBDX_OK;      // reported by the step
+		// (an abandoned detection carries no impulse list: the count of the previous step must not drive this step's impulse kernels)
+		if (nodes > (1ull << 29) || contacts > (1ull << 24) || (s->tet_serial && more_nodes)) { s->tet_impulses_last = 0; return PBDX_OK; }      // reported by the step
 		s->tet_grown++;
 		r = alloc_tet_work(s, nodes, (uint32_t)contacts);
 		if (r) return r;
 		HIPCHECK(hipMemsetAsync(s->d_tet_counters, 0, kTcWords * sizeof(uint32_t), s->stream));
 	}
+	s->tet_impulses_last = 0;
 	return PBDX_OK;
 }
 
@@ -2513,6 +2519,7 @@ void pbdx_solver_destroy(pbdx_solver *s)
 	if (s->d_ranges) (void)hipFree(s->d_ranges);
 	if (s->d_contact_counters) (void)hipFree(s->d_contact_counters);
 	for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
+	for (hipEvent_t e : s->sub_events) (void)hipEventDestroy(e);
 	if (s->ev_start) (void)hipEventDestroy(s->ev_start);
 	if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
 	if (s->stream_side) (void)hipStreamDestroy(s->stream_side);
@@ -2792,6 +2799,8 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 		s->tet_serial = value ? 1 : 0; break;
 	case PBDX_OPT_TET_FORCE_IMPULSES:
 		s->tet_force_impulses = value ? 1 : 0; s->tet_work.force_impulses = s->tet_force_impulses; break;
+	case PBDX_OPT_SUBSTEP_EVENTS:
+		s->substep_events = value ? 1 : 0; return PBDX_OK;      // measurement only: the captured graph stays
 	case PBDX_OPT_PERSISTENT_TIMEOUT_MS:
 		if (value < 1 || value > 10000) { set_error("persistent timeout must be 1 .. 10000 ms"); return PBDX_ERR_INVALID; }
 		s->persist_timeout_ms = (uint32_t)value; break;
@@ -2822,7 +2831,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	ENTER_DEVICE(s->device);
 	const bool fresh_plan = !s->plan_built;
 	int rp = ensure_plan(s);
-	if (!rp && fresh_plan) rp = autotune_schedule(s);
+	if (!rp && (fresh_plan || s->autotuned_for_tet != s->tet_active())) rp = autotune_schedule(s);
 	if (!rp) rp = ensure_trace(s);
 	if (!rp && !s->fused_active()) rp = ensure_device_batches(s);
 	if (rp) return rp;
@@ -2884,6 +2893,11 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 		}
 		return PBDX_OK;
 	};
+	// per-substep events (PBDX_OPT_SUBSTEP_EVENTS; not in the per-launch profiling mode, at most 65 536 substeps per call)
+	const bool sub_ev = s->substep_events && !s->profile && substeps_total <= 65536;
+	s->substep_ms.clear();
+	if (sub_ev)
+		while (s->sub_events.size() < substeps_total) { hipEvent_t e = nullptr; HIPCHECK(hipEventCreate(&e)); s->sub_events.push_back(e); }
 	if (s->profile)
 	{
 		HIPCHECK(hipEventRecord(s->ev_start, s->stream));
@@ -2932,6 +2946,7 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 			if (!s->graph_valid[s->phys]) { int r = capture(); if (r) return r; }
 			HIPCHECK(hipGraphLaunch(s->graph_exec[s->phys], s->stream));
 			if (flips) s->swap_state();
+			if (sub_ev) HIPCHECK(hipEventRecord(s->sub_events[k2], s->stream));
 			if ((k2 + 1) % sub_steps == 0) { int r = step_end(); if (!r) r = enqueue_contacts(s); if (r) return r; }
 		}
 		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
@@ -2945,11 +2960,19 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 			int r = enqueue_substep(s, hs, inv_h, max_iterations, vel, gravity, nullptr);
 			if (r) return r;
 			if (s->last_flips) s->swap_state();
+			if (sub_ev) HIPCHECK(hipEventRecord(s->sub_events[k], s->stream));
 			if ((k + 1) % sub_steps == 0) { r = step_end(); if (!r) r = enqueue_contacts(s); if (r) return r; }
 		}
 		HIPCHECK(hipEventRecord(s->ev_stop, s->stream));
 	}
 	HIPCHECK(hipStreamSynchronize(s->stream));
+	if (sub_ev && !s->h_error[0] && !s->h_error[1])
+	{
+		// device time of substep k = from the event after substep k - 1 (the call's start event for k = 0) to the event after substep k
+		s->substep_ms.resize((size_t)substeps_total);
+		for (uint64_t k = 0; k < substeps_total; k++)
+			HIPCHECK(hipEventElapsedTime(&s->substep_ms[(size_t)k], k ? s->sub_events[(size_t)k - 1] : s->ev_start, s->sub_events[(size_t)k]));
+	}
 	if (s->h_error[1])
 	{
 		// A persistent launch refused to start (its workgroups were not all resident within kArriveLimitTicks): the
@@ -3035,7 +3058,7 @@ int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
 	ENTER_DEVICE(s->device);
 	const bool fresh_plan = !s->plan_built;
 	int r = ensure_plan(s);
-	if (!r && fresh_plan) r = autotune_schedule(s);
+	if (!r && (fresh_plan || s->autotuned_for_tet != s->tet_active())) r = autotune_schedule(s);
 	if (!r) r = ensure_trace(s);
 	if (!r && !s->fused_active()) r = ensure_device_batches(s);
 	if (r) return r;
@@ -3382,6 +3405,14 @@ int pbdx_solver_get_stats(pbdx_solver *s, pbdx_step_stats *out)
 {
 	if (!s || !out) return PBDX_ERR_INVALID;
 	*out = s->stats;
+	return PBDX_OK;
+}
+
+int pbdx_solver_get_substep_times(pbdx_solver *s, float *out_ms, uint32_t capacity, uint32_t *count)
+{
+	if (!s || !count) return PBDX_ERR_INVALID;
+	*count = (uint32_t)s->substep_ms.size();
+	if (out_ms) for (uint32_t k = 0; k < capacity && k < *count; k++) out_ms[k] = s->substep_ms[k];
 	return PBDX_OK;
 }
 
