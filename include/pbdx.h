@@ -231,6 +231,20 @@ int pbdx_solver_set_instancing(pbdx_solver *s, uint32_t particles_per_instance, 
  * (the invariant data-race freedom rests on).  Returns PBDX_OK or PBDX_ERR_INVALID. */
 int pbdx_solver_validate_schedule(pbdx_solver *s);
 
+/* ---- One substep in pieces: mixed models ------------------------------------------------------------------
+ * A SimulationModel may hold constraint classes the engine does not know (the reference's PositionBasedGenericConstraints.h:31-218
+ * templates, user subclasses of PBD::Constraint).  The reference runs them through the virtual solvePositionConstraint inside the
+ * same colour groups (TimeStepController.cpp:270-286).  A host that wants the engine for the groups' KNOWN batches drives the substep
+ * itself with the three calls below and runs its own constraints of group g between project_groups(.., g, g + 1) and the next group,
+ * on positions it fetched with pbdx_solver_get_particles and returns with pbdx_solver_update_particle_ranges(PBDX_ARRAY_X):
+ *     integrate;  for iteration: for group: project_groups / host constraints;  update_velocities
+ * -- exactly TimeStepController.cpp:112-160.  Per-colour launches, synchronous (each call returns when the device is done); every
+ * transfer in between is the caller's: correct, and slow by construction (reference-side plug-in: numMixedGroups()). */
+int pbdx_solver_integrate(pbdx_solver *s, float h_sub, const float gravity[3]);      /* TimeStepController.cpp:112-129, TimeIntegration.cpp:7-19 */
+/* the engine's batches of colour groups [group_begin, group_end) for iteration `iteration` of the substep (0: XPBD multipliers := 0) */
+int pbdx_solver_project_groups(pbdx_solver *s, float h_sub, uint32_t iteration, uint32_t group_begin, uint32_t group_end);
+int pbdx_solver_update_velocities(pbdx_solver *s, float h_sub, int velocity_update_method);   /* TimeStepController.cpp:142-160 */
+
 /* Advance `num_steps` full time steps of size h, device-resident (no host
  * transfers).  One step == TimeStepController::step for a particle scene:
  *   a_i = gravity (dynamic particles); hs = h/sub_steps;

@@ -19,6 +19,7 @@
 #include "Simulation/Constraints.h"
 #include "Simulation/DistanceFieldCollisionDetection.h"
 #include "Simulation/RigidBody.h"
+#include "GenericConstraints.h"          // Demos/GenericConstraintsDemos (mixed-model tests)
 #include "PositionBasedDynamics/PositionBasedDynamics.h"
 #include "Utils/IndexedFaceMesh.h"
 #include "Utils/TetGenLoader.h"
@@ -744,6 +745,24 @@ void *refdrv_get_model() { return (void*)model(); }
 // SimulationModel.cpp -> setConstraintValue<>): every constraint of the scene keeps its topology, only m_stiffness changes
 void refdrv_set_cloth_stiffness(double k) { model()->setClothStiffness((Real)k); }
 void refdrv_set_cloth_bending_stiffness(double k) { model()->setClothBendingStiffness((Real)k); }
+// constraint classes outside the engine's scope (mixed models): the reference's generic constraints
+// (Demos/GenericConstraintsDemos/GenericConstraints.cpp; GenericConstraintsModel::addGeneric* without the demo's model class)
+int refdrv_add_generic_distance_constraint(unsigned p1, unsigned p2, double stiffness)
+{
+	GenericDistanceConstraint *c = new GenericDistanceConstraint();
+	if (!c->initConstraint(*model(), p1, p2, (Real)stiffness)) { delete c; return 1; }
+	model()->getConstraints().push_back(c);
+	model()->m_groupsInitialized = false;
+	return 0;
+}
+int refdrv_add_generic_isometric_bending_constraint(unsigned p1, unsigned p2, unsigned p3, unsigned p4, double stiffness)
+{
+	GenericIsometricBendingConstraint *c = new GenericIsometricBendingConstraint();
+	if (!c->initConstraint(*model(), p1, p2, p3, p4, (Real)stiffness)) { delete c; return 1; }
+	model()->getConstraints().push_back(c);
+	model()->m_groupsInitialized = false;
+	return 0;
+}
 // edit of ONE constraint's stiffness behind the model's back (python: constraint.stiffness = ...)
 void refdrv_set_constraint_stiffness(unsigned ci, double k)
 {

@@ -319,6 +319,17 @@ class Ref:
         self.lib.refdrv_set_constraint_stiffness.argtypes = [_u, _d]
         self.lib.refdrv_set_constraint_stiffness(int(c), float(k))
 
+    def add_generic_distance_constraint(self, p1, p2, stiffness):
+        """A constraint class outside the engine's scope (Demos/GenericConstraintsDemos/GenericConstraints.cpp): mixed-model tests."""
+        self.lib.refdrv_add_generic_distance_constraint.argtypes = [_u, _u, _d]
+        self.lib.refdrv_add_generic_distance_constraint.restype = C.c_int
+        assert self.lib.refdrv_add_generic_distance_constraint(int(p1), int(p2), float(stiffness)) == 0
+
+    def add_generic_isometric_bending_constraint(self, p1, p2, p3, p4, stiffness):
+        self.lib.refdrv_add_generic_isometric_bending_constraint.argtypes = [_u, _u, _u, _u, _d]
+        self.lib.refdrv_add_generic_isometric_bending_constraint.restype = C.c_int
+        assert self.lib.refdrv_add_generic_isometric_bending_constraint(int(p1), int(p2), int(p3), int(p4), float(stiffness)) == 0
+
     def model_ptr(self):
         self.lib.refdrv_get_model.restype = C.c_void_p
         return C.c_void_p(self.lib.refdrv_get_model())

@@ -3052,6 +3052,57 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 	return PBDX_OK;
 }
 
+// ---- one substep in pieces (mixed models) ----------------------------------------------------------------------------------
+// A host that interleaves constraints of its own with the engine's colour groups (include/pbdx.h) drives the substep itself:
+// integrate, the engine's batches of a range of groups for ONE iteration, ..., velocity update.  Plain launches of the
+// per-colour kernels on the state buffer, synchronous; the arithmetic is that of every other schedule.
+int pbdx_solver_integrate(pbdx_solver *s, float h_sub, const float gravity[3])
+{
+	if (!s || !gravity || s->schedule_open) { set_error("integrate: bad arguments / schedule still open"); return PBDX_ERR_INVALID; }
+	ENTER_DEVICE(s->device);
+	if (s->n)
+	{
+		const uint32_t bs = 256, nb = (s->n + bs - 1) / bs;
+		hipLaunchKernelGGL(integrate_kernel, dim3(nb), dim3(bs), 0, s->stream, s->d_pos[0], s->d_pos[0], s->d_vel, s->d_old, s->d_last, s->n, h_sub,
+			gravity[0], gravity[1], gravity[2], (const uint32_t *)nullptr);
+		HIPCHECK(hipGetLastError());
+	}
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	return PBDX_OK;
+}
+
+int pbdx_solver_project_groups(pbdx_solver *s, float h_sub, uint32_t iteration, uint32_t group_begin, uint32_t group_end)
+{
+	if (!s || s->schedule_open) { set_error("project_groups: bad state"); return PBDX_ERR_INVALID; }
+	ENTER_DEVICE(s->device);
+	int r = ensure_device_batches(s);
+	if (r) return r;
+	for (uint32_t bi : s->order)        // (group, type) order
+	{
+		const Batch &b = s->batches[bi];
+		if (b.group < group_begin || b.group >= group_end) continue;
+		r = launch_batch(s, b, h_sub, iteration == 0);
+		if (r) return r;
+	}
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	return PBDX_OK;
+}
+
+int pbdx_solver_update_velocities(pbdx_solver *s, float h_sub, int velocity_update_method)
+{
+	if (!s || s->schedule_open || !(h_sub > 0.0f)) { set_error("update_velocities: bad arguments"); return PBDX_ERR_INVALID; }
+	ENTER_DEVICE(s->device);
+	if (s->n)
+	{
+		const uint32_t bs = 256, nb = (s->n + bs - 1) / bs;
+		const float inv_h = (float)(1.0 / (double)h_sub);          // TimeIntegration.cpp:50 evaluates 1.0/h in double
+		hipLaunchKernelGGL(velocity_kernel, dim3(nb), dim3(bs), 0, s->stream, s->d_pos[0], s->d_vel, s->d_old, s->d_last, s->n, inv_h, velocity_update_method != 0, (uint32_t *)nullptr);
+		HIPCHECK(hipGetLastError());
+	}
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	return PBDX_OK;
+}
+
 int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
 {
 	if (!s || s->schedule_open) { set_error("project: bad state"); return PBDX_ERR_INVALID; }

@@ -166,7 +166,7 @@ TimeStepControllerHIP::TimeStepControllerHIP(int device) :
 	m_supportedFor(nullptr), m_supportedConstraints(0), m_supportedBodies(0), m_supportedObjects(0), m_supported(false), m_accelValid(false), m_tetSignature(0)
 {
 	m_accelGravity[0] = m_accelGravity[1] = m_accelGravity[2] = 0;
-	m_fullParameterScan = true; m_partialUploads = 0;
+	m_fullParameterScan = true; m_partialUploads = 0; m_mixed = false; m_mixedGroupsLast = 0;
 	for (int k = 0; k < 6; k++) m_ms[k] = 0.0;
 	m_deviceMs = 0.0;
 	if (pbdx_solver_create(&m_solver, device) != PBDX_OK)
@@ -325,8 +325,15 @@ bool TimeStepControllerHIP::supported(SimulationModel &model)
 			}
 		if (tetObjects > 1 && (tetWithout != 0 || friction)) return false;
 	}
+	// Constraint classes the engine does not know (PositionBasedGenericConstraints.h templates, user subclasses): a MIXED model -- the
+	// known (group, type) buckets run on the GPU, the others through the reference's own virtual solvePositionConstraint on the host
+	// inside the same colour groups (runMixedSteps).  Only for pure particle models: an unknown class may read anything, and what the
+	// plug-in keeps current on the host between the groups is ParticleData's positions (+ masses).
+	size_t unknown = 0;
 	for (Constraint *c : model.getConstraints())
-		if (engineType(c) < 0) return false;                // e.g. GenericConstraints, joints, rods
+		if (engineType(c) < 0) unknown++;                   // e.g. GenericConstraints, joints, rods
+	if (unknown && (!model.getRigidBodies().empty() || nObjects != 0)) return false;
+	m_mixed = unknown != 0;
 	m_supported = true;
 	return true;
 }
@@ -672,6 +679,7 @@ bool TimeStepControllerHIP::buildSchedule(SimulationModel &model, bool paramsOnl
 	SimulationModel::ConstraintVector &constraints = model.getConstraints();
 	SimulationModel::ConstraintGroupVector &groups = model.getConstraintGroups();
 	if (!paramsOnly && pbdx_solver_begin_schedule(m_solver) != PBDX_OK) return false;
+	if (!paramsOnly) { m_hostGroups.clear(); m_hostGroups.resize(groups.size()); }
 	std::vector<unsigned int> idx[PBDX_NUM_CONSTRAINT_TYPES];
 	std::vector<float> par[PBDX_NUM_CONSTRAINT_TYPES];
 	unsigned int batch = 0;
@@ -682,7 +690,13 @@ bool TimeStepControllerHIP::buildSchedule(SimulationModel &model, bool paramsOnl
 		{
 			Constraint *c = constraints[ci];
 			const int type = engineType(c);
-			if (type < 0) return false;
+			if (type < 0)
+			{
+				// mixed model: this constraint stays with the host (runMixedSteps), in its colour group
+				if (!m_mixed) return false;
+				if (!paramsOnly) { if (m_hostGroups.size() < groups.size()) m_hostGroups.resize(groups.size()); m_hostGroups[g].push_back(ci); }
+				continue;
+			}
 			if (!paramsOnly) idx[type].insert(idx[type].end(), c->m_bodies.begin(), c->m_bodies.end());
 			pushParams(par[type], type, c);
 		}
@@ -780,16 +794,84 @@ bool TimeStepControllerHIP::runSteps(SimulationModel &model, unsigned int numSte
 	const Real *gr = sim->getVecValue<Real>(Simulation::GRAVITATION);
 	const float g[3] = { (float)gr[0], (float)gr[1], (float)gr[2] };
 	START_TIMING("position constraints projection");
-	const bool ok = pbdx_solver_step(m_solver, (float)h, m_subSteps, m_maxIterations, m_velocityUpdateMethod, g, numSteps) == PBDX_OK;
+	const bool ok = m_mixed ? runMixedSteps(model, numSteps, g)
+	                        : pbdx_solver_step(m_solver, (float)h, m_subSteps, m_maxIterations, m_velocityUpdateMethod, g, numSteps) == PBDX_OK;
 	STOP_TIMING_AVG;
 	if (!ok) return false;
-	{ pbdx_step_stats st; if (pbdx_solver_get_stats(m_solver, &st) == PBDX_OK) m_deviceMs += st.total_ms; }
+	if (!m_mixed) { pbdx_step_stats st; if (pbdx_solver_get_stats(m_solver, &st) == PBDX_OK) m_deviceMs += st.total_ms; }
 	m_iterations = m_maxIterations;
 	m_iterationsV = m_maxIterationsV;
 	m_deviceAhead = true;
 	m_gpuSteps += numSteps;
 	for (unsigned int i = 0; i < numSteps; i++) tm->setTime(tm->getTime() + h);     // TimeStepController.cpp:239
 	return true;
+}
+
+// Mixed model: TimeStepController.cpp:91-160 driven from the host with the engine's substep in pieces
+// (include/pbdx.h: pbdx_solver_integrate / project_groups / update_velocities).  Colour group by colour group, iteration by iteration:
+// the group's known batches on the GPU, then the group's other constraints through the reference's own updateConstraint /
+// solvePositionConstraint on ParticleData's positions -- fetched from the device before and returned after.  The groups keep the
+// reference's order and a group's constraints touch disjoint particles, so the result is the CPU TimeStepController's, bit for bit
+// (tests/test_plugin.py); the transfers make it slow by construction: numMixedGroups() round trips of the position array per
+// iteration.  Velocities and old positions on the host stay those of the last syncToHost / step().
+bool TimeStepControllerHIP::runMixedSteps(SimulationModel &model, unsigned int numSteps, const float g[3])
+{
+	TimeManager *tm = TimeManager::getCurrent();
+	ParticleData &pd = model.getParticles();
+	const unsigned int n = pd.size();
+	SimulationModel::ConstraintVector &constraints = model.getConstraints();
+	const unsigned int numGroups = (unsigned int)m_hostGroups.size();
+	const Real hOld = tm->getTimeStepSize();
+	const Real h = hOld / (Real)m_subSteps;                   // TimeStepController.cpp:91
+	tm->setTimeStepSize(h);                                     // :92 (solvePositionConstraint of XPBD-style classes reads it)
+	const uint32_t whole[2] = { 0u, n };
+	bool ok = true;
+	m_mixedGroupsLast = 0;
+	for (unsigned int step = 0; step < numSteps && ok; step++)
+		for (unsigned int sub = 0; sub < m_subSteps && ok; sub++)
+		{
+			ok = pbdx_solver_integrate(m_solver, (float)h, g) == PBDX_OK;
+			for (unsigned int it = 0; it < m_maxIterations && ok; it++)
+			{
+				unsigned int g0 = 0;
+				for (unsigned int grp = 0; grp < numGroups && ok; grp++)
+				{
+					if (m_hostGroups[grp].empty()) continue;
+					// the engine's batches of the groups up to and including this one, then this group's host constraints
+					ok = pbdx_solver_project_groups(m_solver, (float)h, it, g0, grp + 1) == PBDX_OK;
+					g0 = grp + 1;
+					if (!ok || !n) continue;
+#ifdef USE_DOUBLE
+					ok = pbdx_solver_get_particles_f64(m_solver, n, &pd.getPosition(0)[0], NULL, NULL, NULL) == PBDX_OK;
+#else
+					ok = pbdx_solver_get_particles(m_solver, n, &pd.getPosition(0)[0], NULL, NULL, NULL) == PBDX_OK;
+#endif
+					if (!ok) break;
+					for (unsigned int ci : m_hostGroups[grp])           // TimeStepController.cpp:279-283
+					{
+						constraints[ci]->updateConstraint(model);
+						constraints[ci]->solvePositionConstraint(model, it);
+					}
+#ifdef USE_DOUBLE
+					ok = pbdx_solver_update_particle_ranges_f64(m_solver, PBDX_ARRAY_X, &pd.getPosition(0)[0], 1, whole) == PBDX_OK;
+#else
+					ok = pbdx_solver_update_particle_ranges(m_solver, PBDX_ARRAY_X, &pd.getPosition(0)[0], 1, whole) == PBDX_OK;
+#endif
+					if (step == 0 && sub == 0 && it == 0) m_mixedGroupsLast++;
+				}
+				if (ok && g0 < numGroups) ok = pbdx_solver_project_groups(m_solver, (float)h, it, g0, numGroups) == PBDX_OK;
+			}
+			if (ok) ok = pbdx_solver_update_velocities(m_solver, (float)h, m_velocityUpdateMethod) == PBDX_OK;
+		}
+	tm->setTimeStepSize(hOld);                                  // :172
+	// the host's position array holds a mid-step state now (the one the last host group left): it must not be mistaken for a host
+	// edit by the next prepare() -- its hashes are recorded as "what the host is known to hold"
+	if (n && !m_blockHash[0].empty())
+	{
+		HashJob job = { &pd.getPosition(0)[0], n, (uint32_t)sizeof(Vector3r), &m_blockHash[0] };
+		hashBlocks(&job, 1);
+	}
+	return ok;
 }
 
 void TimeStepControllerHIP::step(SimulationModel &model)
@@ -887,4 +969,5 @@ extern "C" unsigned int pbdx_timestep_hip_partial_uploads(PBD::TimeStep *ts) { r
 extern "C" void pbdx_timestep_hip_refresh_parameters(PBD::TimeStep *ts) { static_cast<PBD::TimeStepControllerHIP*>(ts)->refreshParameters(); }
 extern "C" void pbdx_timestep_hip_set_full_parameter_scan(PBD::TimeStep *ts, int on) { static_cast<PBD::TimeStepControllerHIP*>(ts)->setFullParameterScan(on != 0); }
 extern "C" void pbdx_timestep_hip_timing(PBD::TimeStep *ts, double out[7], int reset) { static_cast<PBD::TimeStepControllerHIP*>(ts)->timing(out, reset != 0); }
+extern "C" unsigned int pbdx_timestep_hip_mixed_groups(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numMixedGroups(); }
 extern "C" void *pbdx_timestep_hip_solver(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->solver(); }

@@ -31,7 +31,9 @@
 // many-core host); a host that steps multi-million-constraint models one step() at a time and never edits single constraints can
 // opt in to a sampled check with setFullParameterScan(false) -- or amortise the walk with stepResident(model, n).
 //
-// Scope: models whose constraints are all particle constraints known to the engine.  Rigid bodies are
+// Scope: models whose constraints are all particle constraints known to the engine; a pure particle model that ALSO holds constraint
+// classes the engine does not know (PositionBasedGenericConstraints.h, user subclasses) runs as a MIXED model: known buckets on the GPU,
+// the others through the reference's own virtual call on the host inside the same colour groups (numMixedGroups(); exact, slow).  Rigid bodies are
 // accepted when they are all static (mass 0) colliders of a DistanceFieldCollisionDetection with analytic
 // distance fields (box, sphere, torus, cylinder, hollow sphere / box): the particle vs rigid body contacts
 // are then detected and solved on the GPU as well; so are the contacts between tet models that carry such a distance field
@@ -97,6 +99,10 @@ namespace PBD
 		/** true (DEFAULT): every parameter record is compared before every step (exact).  false: a strided sample of ~4096 records
 		 * (sees bulk edits; single-constraint edits then need refreshParameters()). */
 		void setFullParameterScan(bool b) { m_fullParameterScan = b; }
+		/** Mixed models: colour groups of the current schedule that also hold constraints of classes the engine does not know (run on the
+		 * host through the reference's own solvePositionConstraint, one round trip of the positions per such group and iteration); 0 for
+		 * a model the engine runs alone. */
+		unsigned int numMixedGroups() const { unsigned int k = 0; for (const std::vector<unsigned int> &v : m_hostGroups) if (!v.empty()) k++; return m_mixed ? k : 0u; }
 		/** Opt in to running unsupported models / failed steps on the reference's CPU path (default off). */
 		void setAllowReferenceFallback(bool b) { m_allowFallback = b; }
 		/** accumulated host milliseconds of step(): [0] block hashes of the host arrays, [1] full uploads, [2] parameter check, [3] collider refresh, [4] engine step (host wall clock), [5] download, [6] the engine steps' device-event time */
@@ -112,6 +118,7 @@ namespace PBD
 		bool downloadParticles(SimulationModel &model);
 		bool prepare(SimulationModel &model, bool forceUpload);
 		bool runSteps(SimulationModel &model, unsigned int numSteps);
+		bool runMixedSteps(SimulationModel &model, unsigned int numSteps, const float g[3]);
 		bool uploadChanges(SimulationModel &model, std::vector<uint64_t> now[5]);
 		void hashParameters(SimulationModel &model, std::vector<uint64_t> &out) const;
 		void hashHostState(SimulationModel &model, std::vector<uint64_t> out[5]) const;
@@ -142,6 +149,9 @@ namespace PBD
 		bool m_accelValid; Real m_accelGravity[3];
 		uint64_t m_tetSignature;       // which set of deformable colliders the engine holds (0 = none)
 		std::vector<Real> m_invMass;
+		// mixed models: per colour group the constraints that stay with the host
+		bool m_mixed; unsigned int m_mixedGroupsLast;
+		std::vector<std::vector<unsigned int> > m_hostGroups;
 	};
 }
 

@@ -181,8 +181,16 @@ def test_two_solvers_on_two_devices_in_one_process_do_not_disturb_each_other():
     """Two engines in one process on devices 0 and min(1, n - 1), stepped in turns while the CALLER keeps its own current device:
     both produce the single-solver result bit for bit, and the calling thread's current HIP device is what it was before every
     call (csrc/pbdx_device.h: every entry point selects its solver's device and restores the caller's)."""
-    import torch
+    import ctypes
     import positionbaseddynamics_amd as pbd
+    # the HIP runtime the engine itself is linked against (already loaded: resolved by soname), asked from the CALLER's thread
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def current_device():
+        d = ctypes.c_int(-1)
+        assert hip.hipGetDevice(ctypes.byref(d)) == 0
+        return d.value
+
     n = pbd.device_count()
     devices = [0, min(1, n - 1)]
     spec = util.cloth_spec(40, 30, 4, 3)
@@ -199,12 +207,13 @@ def test_two_solvers_on_two_devices_in_one_process_do_not_disturb_each_other():
         ref_ts.step(ref_model)
     want = ref_model.getParticles().positions().copy()
     caller_device = n - 1                      # the caller's own current device (the last one; = 0 on a one-GPU box)
-    torch.cuda.set_device(caller_device)
+    assert hip.hipSetDevice(caller_device) == 0
     pairs = [make(d) for d in devices]
+    assert current_device() == caller_device
     for _ in range(6):
         for model, ts in pairs:
             ts.step(model)
-            assert torch.cuda.current_device() == caller_device
+            assert current_device() == caller_device
     for (model, ts), d in zip(pairs, devices):
         got = model.getParticles().positions()
         assert util.bitwise_equal(got, want), "device %d" % d

@@ -434,6 +434,67 @@ def test_full_size_c2_million_particle_cloth_vs_reference(pbd):
         assert np.array_equal(xg[0], x0[0]) and np.array_equal(xg[999], x0[999]) and np.all(np.isfinite(xg))
 
 
+def test_full_size_c2_hundred_steps_and_f64_envelope(pbd):
+    """configs[1] at full size AND at length: the 1000x1000 sheet after 100 steps x 10 iterations on the
+    bench's schedule -- all 6 000 000 position and velocity words bit-identical to the reference's float build (16 host threads,
+    about a minute) -- and, after the first 10 steps, the stated fp32 tolerance AT THE BASELINE SIZE: the engine's error against
+    the reference's f64 build is the float reference's own error (e_gpu <= e_f32ref, here with equality because the bits agree;
+    the per-particle figure is printed)."""
+    S = pbd.Solver
+    ops = util.cloth_spec(1000, 1000, 4, 3)
+    want = _reference_states(ops, 10, [10, 100])
+    x64 = util.oracle_positions(ops, 10, 1, 10, "f64", threads=16)
+    m, ts = util.mine_run(ops, 10, 1, 10, resident=True, options={S.OPT_PERSISTENT: 2})
+    x10 = m.getParticles().positions().copy()
+    pinfo = ts.solver().persistent_info()
+    assert pinfo["active"] == 1 and pinfo["last_folded"] == 1 and pinfo["refusals"] == 0 and pinfo["timeouts"] == 0
+    assert util.bitwise_equal(x10, want[10][0])
+    e_ref, e_gpu = util.max_err(want[10][0], x64), util.max_err(x10, x64)
+    print("1000x1000, 10 steps: per-particle |f32 reference - f64| = %.3e, |gpu - f64| = %.3e (bounding box diagonal 14)" % (e_ref, e_gpu))
+    assert e_gpu <= e_ref + 1e-7
+    ts.stepResident(m, 90)
+    ts.syncToHost(m)
+    pinfo = ts.solver().persistent_info()
+    assert pinfo["active"] == 1 and pinfo["refusals"] == 0 and pinfo["timeouts"] == 0
+    xg, vg = m.getParticles().positions(), m.getParticles().array(2)
+    assert util.bitwise_equal(xg, want[100][0]), "100 steps: max err %.3e" % util.max_err(xg, want[100][0])
+    assert util.bitwise_equal(vg, want[100][1])
+    print("1000x1000, 100 steps x 10 iterations: 3 000 000 coordinates + 3 000 000 velocity components bit-identical; sheet has dropped to y = %.3f" % float(xg[:, 1].min()))
+
+
+def test_full_size_c3_bar_reaches_the_inversion_branch_bitwise(pbd):
+    """configs[2] at full size and at length: the 100 000-tet FEM bar after 120 steps x 10 iterations.  The bar sags under
+    gravity until the tets at its pinned end are crushed below 20 % of their rest volume and the projection takes the
+    inversion-handling branch (svdWithInversionHandling, MathFunctions.cpp:261-388; Constraints.cpp:1797) -- asserted on the
+    final state by counting those tets -- and every coordinate is still bit-identical to the reference."""
+    ops = util.bar_spec(101, 21, 11, 2)
+    ref = util.get_oracle("f32")
+    util.apply_ref(ref, ops)
+    ref.set_num_threads(16); ref.set_time_step_size(0.005); ref.set_gravity(util.GRAVITY); ref.set_params(1, 10, 0)
+    ref.step(120)
+    xr, vr = ref.positions().astype(np.float32), ref.get_array(2).astype(np.float32)
+    ref.reset_all()
+    m, ts = util.mine_run(ops, 120, 1, 10, resident=True)
+    xg, vg = m.getParticles().positions(), m.getParticles().array(2)
+    # tets whose current volume is below 20 % of the rest volume (the reference's handleInversion test) in the final state
+    tm = m.getTetModels()[0]
+    tets = tm.getParticleMesh().getTets() + tm.getIndexOffset()
+    crushed = None
+    if tets is not None:
+        x0 = m.getParticles().array(1).astype(np.float64)
+        t = np.asarray(tets, dtype=np.int64).reshape(-1, 4)
+
+        def vol(x):
+            a, b, c, d = x[t[:, 0]], x[t[:, 1]], x[t[:, 2]], x[t[:, 3]]
+            return np.einsum("ij,ij->i", d - a, np.cross(c - a, b - a)) / -6.0
+        crushed = int(np.sum(vol(xg.astype(np.float64)) / vol(x0) < 0.2))
+    print("C3 full size, 120 steps: %s tets below 20 %% of their rest volume at the end; plan %s" % (crushed, ts.solver().plan_info()))
+    if crushed is not None:
+        assert crushed > 0, "the run never reached the inversion-handling branch: lengthen it"
+    assert util.bitwise_equal(xg, xr), "max err %.3e" % util.max_err(xg, xr)
+    assert util.bitwise_equal(vg, vr)
+
+
 def test_full_size_c2_odd_pass_count(pbd):
     """5 iterations x 3 segments = 15 passes per substep (odd): the persistent launch at the 1 M size with the other
     parity of the position double buffer, 4 steps, bit-identical to the reference."""

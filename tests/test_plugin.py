@@ -225,6 +225,50 @@ def test_plugin_picks_up_runtime_parameter_edits_without_replanning():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["f32", "f64"])
+def test_plugin_runs_a_mixed_model_group_by_group(variant):
+    """a model with constraint classes the engine does not know -- the 50x50 ClothDemo sheet (XPBD distance + XPBD
+    isometric bending) plus two of the reference's GenericDistanceConstraints (Demos/GenericConstraintsDemos: a stitch between two
+    distant particles and a doubled edge) and one GenericIsometricBendingConstraint -- is NOT refused: the known (group, type) buckets run
+    on the GPU, the generic ones through the reference's own solvePositionConstraint on the host inside the same colour groups.  Float
+    host: bit-identical to the CPU TimeStepController over 8 steps x 2 substeps; double host: inside the usual fp32 envelope."""
+    refdrv, path = _plugin(variant)
+    ops = util.cloth_spec(50, 50, 4, 3)
+
+    def run(gpu):
+        ref = refdrv.Ref(variant)
+        _setup(ref, ops, 2, 5)
+        ref.add_generic_distance_constraint(60, 1890, 0.5)                   # a stitch across the sheet
+        ref.add_generic_distance_constraint(777, 778, 1.0)                   # on top of an existing edge
+        ref.add_generic_isometric_bending_constraint(1200, 1251, 1201, 1250, 0.3)
+        if gpu:
+            assert ref.install_timestep_plugin(path) == 0
+        ref.set_params(2, 5, 0)
+        ref.step(8)
+        out = (ref.positions().copy(), ref.get_array(2).copy())
+        if gpu:
+            lib, cnt = _counters(path)
+            ts = ref.timestep_ptr()
+            lib.pbdx_timestep_hip_mixed_groups.argtypes = [C.c_void_p]; lib.pbdx_timestep_hip_mixed_groups.restype = C.c_uint
+            mixed = lib.pbdx_timestep_hip_mixed_groups(ts)
+            print("mixed model (%s host): %d colour groups hold host constraints; gpu steps %d" % (variant, mixed, cnt["gpu_steps"](ts)))
+            assert cnt["gpu_steps"](ts) == 8 and cnt["failed_steps"](ts) == 0 and cnt["fallback_steps"](ts) == 0
+            assert 1 <= mixed <= 3
+        ref.reset_all()
+        return out
+
+    (xc, vc), (xg, vg) = run(False), run(True)
+    plain = util.oracle_positions(ops, 8, 2, 5, variant)
+    assert util.max_err(xc, plain) > 1e-3, "the generic constraints change nothing: the test would prove nothing"
+    if variant == "f32":
+        assert util.bitwise_equal(xg, xc), "max err %.3e" % util.max_err(xg, xc)
+        assert util.bitwise_equal(vg, vc)
+    else:
+        print("mixed model, double host: max |dx| vs the double CPU path = %.3e" % util.max_err(xg, xc))
+        assert util.max_err(xg, xc) <= 2e-4
+
+
+@pytest.mark.gpu
 def test_plugin_full_size_c2_reference_model():
     """The 1000x1000 REFERENCE model (the reference's own SimulationModel, 5 988 006 heap constraints) stepped through the
     plug-in: bit-identical to the CPU path after 2 steps; plug-in cost per step printed for the round trip
