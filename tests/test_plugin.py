@@ -231,7 +231,7 @@ def test_plugin_runs_a_mixed_model_group_by_group(variant):
     isometric bending) plus two of the reference's GenericDistanceConstraints (Demos/GenericConstraintsDemos: a stitch between two
     distant particles and a doubled edge) and one GenericIsometricBendingConstraint -- is NOT refused: the known (group, type) buckets run
     on the GPU, the generic ones through the reference's own solvePositionConstraint on the host inside the same colour groups.  Float
-    host: bit-identical to the CPU TimeStepController over 8 steps x 2 substeps; double host: inside the usual fp32 envelope."""
+    host: bit-identical to the CPU TimeStepController over 60 steps x 2 substeps; double host: inside the usual fp32 envelope."""
     refdrv, path = _plugin(variant)
     ops = util.cloth_spec(50, 50, 4, 3)
 
@@ -244,7 +244,7 @@ def test_plugin_runs_a_mixed_model_group_by_group(variant):
         if gpu:
             assert ref.install_timestep_plugin(path) == 0
         ref.set_params(2, 5, 0)
-        ref.step(8)
+        ref.step(60)
         out = (ref.positions().copy(), ref.get_array(2).copy())
         if gpu:
             lib, cnt = _counters(path)
@@ -252,20 +252,20 @@ def test_plugin_runs_a_mixed_model_group_by_group(variant):
             lib.pbdx_timestep_hip_mixed_groups.argtypes = [C.c_void_p]; lib.pbdx_timestep_hip_mixed_groups.restype = C.c_uint
             mixed = lib.pbdx_timestep_hip_mixed_groups(ts)
             print("mixed model (%s host): %d colour groups hold host constraints; gpu steps %d" % (variant, mixed, cnt["gpu_steps"](ts)))
-            assert cnt["gpu_steps"](ts) == 8 and cnt["failed_steps"](ts) == 0 and cnt["fallback_steps"](ts) == 0
+            assert cnt["gpu_steps"](ts) == 60 and cnt["failed_steps"](ts) == 0 and cnt["fallback_steps"](ts) == 0
             assert 1 <= mixed <= 3
         ref.reset_all()
         return out
 
     (xc, vc), (xg, vg) = run(False), run(True)
-    plain = util.oracle_positions(ops, 8, 2, 5, variant)
+    plain = util.oracle_positions(ops, 60, 2, 5, variant)
     assert util.max_err(xc, plain) > 1e-3, "the generic constraints change nothing: the test would prove nothing"
     if variant == "f32":
         assert util.bitwise_equal(xg, xc), "max err %.3e" % util.max_err(xg, xc)
         assert util.bitwise_equal(vg, vc)
     else:
         print("mixed model, double host: max |dx| vs the double CPU path = %.3e" % util.max_err(xg, xc))
-        assert util.max_err(xg, xc) <= 2e-4
+        assert util.max_err(xg, xc) <= 2e-3
 
 
 @pytest.mark.gpu
