@@ -742,7 +742,7 @@ def compact_extra(e):
     """One line per extra workload (printed BEFORE the headline)."""
     out = _pick(e, ("tag", "workload", "particles", "constraints", "colour_groups", "steps", "warmup", "ms_per_substep", "device_median_ms_per_substep", "ms_per_step", "projections_per_s", "state_ok",
                     "host_scene_build_s", "bit_identical", "compared_values", "parity_steps", "contacts_deformable_total", "contacts_floor_total", "contacts_max", "sub_steps", "iterations",
-                    "reference_ms_per_step", "reference_reproduces_fixture", "error"))
+                    "reference_ms_per_step", "reference_reproduces_fixture", "same_bits_as_default_build", "error"))
     if "workload" in out:
         out["workload"] = str(out["workload"])[:220]
     if e.get("roofline"):
@@ -1022,6 +1022,22 @@ def main():
                            "projections_per_s": r["n_constraints"] * ew["iters"] * nsteps / r["t_local"],
                            "state_ok": r["state_ok"], "host_scene_build_s": r["t_build"], "plan": r["plan"], "persistent": r["persistent"],
                            "engine": r["engine"], "roofline": r.get("roofline")})
+        # the opt-in contracted build (csrc/Makefile: libpbdx_fma.so, -ffp-contract=fast): same workload, same command, in a child process that
+        # loads that library.  NOT bit-identical to the float reference (tests: inside the fp32 envelope around f64); reported beside the headline,
+        # never as the headline
+        fma_lib = os.path.join(ROOT, "positionbaseddynamics_amd", "_lib", "libpbdx_fma.so")
+        if os.path.exists(fma_lib) and not os.environ.get("PBDX_LIB"):
+            try:
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-traffic", "--no-extras", "--no-roofline", "--steps", str(args.steps),
+                                     "--warmup", str(args.warmup), "--iters", str(args.iters), "--size", str(args.size)], env=dict(os.environ, PBDX_LIB=fma_lib, PBDX_BENCH_DETAIL="/dev/null"),
+                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
+                cd = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+                extras.append({"tag": "c2_fma_contract_build", "workload": "the headline workload on the OPT-IN library built with -ffp-contract=fast (not bit-identical to the float reference; inside the fp32 envelope)",
+                               "steps": cd["steps"], "warmup": cd["warmup"], "ms_per_substep": cd["ms_per_substep"], "device_median_ms_per_substep": cd["config"].get("device_median_ms_per_substep"),
+                               "projections_per_s": cd["value"], "state_ok": cd["config"]["state_ok"],
+                               "same_bits_as_default_build": cd["config"]["replica_checksums"] == out["config"]["replica_checksums"]})
+            except Exception as e:
+                extras.append({"tag": "c2_fma_contract_build", "error": repr(e)})
         for sub in (8, 5):
             try:
                 extras.append(run_c5(ens, sub))

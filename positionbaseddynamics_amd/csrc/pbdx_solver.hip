@@ -305,6 +305,9 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 #ifndef PBDX_STEP_PROBE
 #define PBDX_STEP_PROBE 0
 #endif
+#ifndef PBDX_FETCH_BEFORE_BARRIER
+#define PBDX_FETCH_BEFORE_BARRIER 0
+#endif
 // DICT: a run of dictionary-form steps (FusedStep::dict, pbdx_plan.h): a slot streams its indices, its multiplier and ONE uint16 -- the offset of its
 // parameter record in the tile's table of distinct records, which sits in LDS behind the particles (ltab); the record is read from there when the
 // slot is projected.  Same arithmetic on the same values: bit-identical.
@@ -403,6 +406,13 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 #if PBDX_STEP_PROBE
 			if (probing) { asm volatile("" :: "s"(ch_next.info)); tC = __builtin_readcyclecounter(); }
 #endif
+#if PBDX_FETCH_BEFORE_BARRIER
+			// the record fetch of the chunk D positions ahead goes out BEFORE the colour barrier: it reads read-only streams into the ring slot
+			// that was just consumed, so it does not depend on the barrier -- a wave that reaches the barrier early issues its loads while the
+			// others still project (step probes, profiles/r04e: issuing them cost 0.23 us per sub-iteration when all 16 waves did it at once,
+			// right after the barrier, with the SIMDs otherwise idle)
+			fetch(cur);
+#endif
 			if (chunk_last_of_step(ch.info))
 			{
 				if (chunk_barrier(ch.info)) __syncthreads();
@@ -413,7 +423,11 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 				step_counter++;
 			}
 		}
+#if PBDX_FETCH_BEFORE_BARRIER
+		else fetch(cur);
+#else
 		fetch(cur);
+#endif
 #if PBDX_STEP_PROBE
 		if (probing)
 		{

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Developer aid (library built with -DPBDX_STEP_PROBE=1, PBDX_LIB pointing at it): where the time of ONE colour step of the configs[2] bar goes.
+"""Developer aid (library built with -DPBDX_STEP_PROBE=1, PBDX_LIB pointing at it): where the time of ONE colour step of the configs[2] bar
+(default) or of the 1000x1000 cloth of configs[1] (--cloth 1000) goes.
 Cycle stamps (s_memtime) of the traced tile's thread 0: A sub-iteration entry,
 B projection done and scatter issued, C next chunk descriptor read (LDS round trip; the scatter has landed), D colour barrier passed, E next record fetch issued."""
 import argparse, os, sys
@@ -12,8 +13,9 @@ from tests import util
 ap = argparse.ArgumentParser()
 ap.add_argument("--bar", type=int, default=2)
 ap.add_argument("--persistent", type=int, default=2)
+ap.add_argument("--cloth", type=int, default=0, help="N: the N x N cloth (XPBD distance + XPBD isometric bending) instead of the bar")
 args = ap.parse_args()
-model = util.build_mine(util.bar_spec(101, 21, 11, args.bar))
+model = util.build_mine(util.cloth_spec(args.cloth, args.cloth, 4, 3) if args.cloth else util.bar_spec(101, 21, 11, args.bar))
 ts = pbd.TimeStepController()
 ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
 ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 10)
