@@ -472,6 +472,8 @@ struct FoldArgs
 	float4 *vel, *old, *last;
 	uint32_t state_bytes;          // n * 16 (buffer descriptors)
 	float h, gx, gy, gz, inv_h;
+	float ghx, ghy, ghz;           // g * h, rounded once on the host exactly as the device would (kernel arguments = SGPRs: the products were hoisted out of
+	                               // the pass loop into VGPRs and spilled at the 128-VGPR limit of the 1 024-thread kernel)
 	int second_order;
 };
 __device__ __forceinline__ float4 load_f4_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t index)
@@ -508,7 +510,7 @@ __device__ __forceinline__ void integrate_fill(const FoldArgs &f, const uint4 *s
 			float4 p = x[k], w = v[k];
 			if (w.w != 0.0f)   // mass != 0
 			{
-				w.x = w.x + f.gx * f.h; w.y = w.y + f.gy * f.h; w.z = w.z + f.gz * f.h;
+				w.x = w.x + f.ghx; w.y = w.y + f.ghy; w.z = w.z + f.ghz;
 				p.x = p.x + w.x * f.h; p.y = p.y + w.y * f.h; p.z = p.z + w.z * f.h;
 			}
 			lpos[i] = p;
@@ -2053,6 +2055,7 @@ int enqueue_substep(pbdx_solver *s, float hs, float inv_h, uint32_t iters, int v
 		f.vel = s->d_vel; f.old = s->d_old; f.last = s->d_last;
 		f.state_bytes = s->n * 16u;
 		f.h = hs; f.gx = g[0]; f.gy = g[1]; f.gz = g[2]; f.inv_h = inv_h; f.second_order = vel != 0;
+		f.ghx = g[0] * hs; f.ghy = g[1] * hs; f.ghz = g[2] * hs;      // (host code is compiled without contraction, like the device code)
 		s->last_folded = true;
 		if (pc) { int r = prof_begin(pc, -1, 0); if (r) return r; }
 		int r = launch_persistent(s, 0, hs, iters, &f);
