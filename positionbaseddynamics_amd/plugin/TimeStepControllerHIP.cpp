@@ -110,6 +110,24 @@ namespace
 	// PBDX_HASH_BLOCK elements per 64-bit hash.  The pass is bandwidth-bound (one read of the array) and runs on a handful of
 	// threads when the arrays are large -- the host application is an OpenMP program anyway (TimeStepController.cpp:270-286);
 	// the thread count is stated explicitly because hosts commonly run the solver loops with omp_set_num_threads(1).
+	// Threads of the plug-in's own host passes (block hashes of the particle arrays, the exact parameter scan): up to 64 -- measured on the
+	// 256-CPU host of the MI355X box the parameter walk scales with the threads up to there (scripts/dev/scan_bench.cpp: 6 M constraints
+	// 8.2 / 4.1 / 2.4 ms at 16 / 32 / 64 threads) -- and ONE count for every pass: libgomp keeps one team of threads, and two parallel
+	// regions that ask for different team sizes in turn make it rebuild the team every time (the scan went from 2.4 to 26 ms per step when
+	// it asked for 64 threads next to the hashes' 32).  The count is stated explicitly because hosts commonly run their own solver loops
+	// with omp_set_num_threads(1).
+	inline int pluginThreads()
+	{
+		static int threads = 0;
+		if (!threads)
+		{
+			threads = omp_get_num_procs();
+			if (threads > 64) threads = 64;
+			if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) threads = v; }      // developer aid
+			if (threads < 1) threads = 1;
+		}
+		return threads;
+	}
 	struct HashJob { const void *base; uint32_t n, elemBytes; std::vector<uint64_t> *out; };
 	void hashBlocks(HashJob *jobs, int numJobs)
 	{
@@ -125,9 +143,7 @@ namespace
 			bytes += (size_t)jobs[j].n * jobs[j].elemBytes;
 		}
 		first[numJobs] = total;
-		int threads = bytes >= ((size_t)1 << 20) ? omp_get_num_procs() : 1;
-		if (threads > 32) threads = 32;
-		if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) threads = v; }      // developer aid
+		const int threads = bytes >= ((size_t)1 << 20) ? pluginThreads() : 1;
 		// ONE parallel region over the blocks of all arrays
 		#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
 		for (int q = 0; q < total; q++)
@@ -608,13 +624,7 @@ void TimeStepControllerHIP::hashParameters(SimulationModel &model, std::vector<u
 	const size_t nb = (nc + kParamScanBlock - 1) / kParamScanBlock;
 	out.resize(nb + 1);
 	out[nb] = (uint64_t)nc;
-	// one thread per 32 768 constraints, at most 64 (measured on the 256-CPU host of the MI355X box, scripts/dev/scan_bench.cpp: the walk
-	// scales with the threads up to there; a fork / join of 64 threads costs a few tens of microseconds)
-	int threads = (int)(nc / 32768);
-	if (threads > omp_get_num_procs()) threads = omp_get_num_procs();
-	if (threads > 64) threads = 64;
-	if (threads < 1) threads = 1;
-	if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) threads = v; }      // developer aid
+	const int threads = nc >= 65536 ? pluginThreads() : 1;
 	Constraint *const *cs = constraints.data();
 	uint64_t *o = out.data();
 	#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
