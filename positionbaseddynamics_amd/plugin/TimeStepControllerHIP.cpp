@@ -110,19 +110,18 @@ namespace
 	// PBDX_HASH_BLOCK elements per 64-bit hash.  The pass is bandwidth-bound (one read of the array) and runs on a handful of
 	// threads when the arrays are large -- the host application is an OpenMP program anyway (TimeStepController.cpp:270-286);
 	// the thread count is stated explicitly because hosts commonly run the solver loops with omp_set_num_threads(1).
-	// Threads of the plug-in's own host passes (block hashes of the particle arrays, the exact parameter scan): up to 64 -- measured on the
-	// 256-CPU host of the MI355X box the parameter walk scales with the threads up to there (scripts/dev/scan_bench.cpp: 6 M constraints
-	// 8.2 / 4.1 / 2.4 ms at 16 / 32 / 64 threads) -- and ONE count for every pass: libgomp keeps one team of threads, and two parallel
-	// regions that ask for different team sizes in turn make it rebuild the team every time (the scan went from 2.4 to 26 ms per step when
-	// it asked for 64 threads next to the hashes' 32).  The count is stated explicitly because hosts commonly run their own solver loops
-	// with omp_set_num_threads(1).
+	// Threads of the plug-in's own host passes (block hashes of the particle arrays, the exact parameter scan): 32, ONE count for every
+	// pass, stated explicitly (hosts commonly run their own solver loops with omp_set_num_threads(1)).  Measured on the 256-CPU host of the
+	// MI355X box (profiles/r04b_*, r04_plugin_round_trip.log): the parameter walk alone scales to 64 threads (6 M constraints: 8.2 / 4.1 /
+	// 2.4 ms at 16 / 32 / 64), but libgomp keeps one team per host thread and a team size that differs from the previous region's -- or
+	// from the host application's own (the test host runs with 32) -- costs milliseconds per region (hashes 0.26 -> 8 ms, scan 2.4 -> 26 ms).
 	inline int pluginThreads()
 	{
 		static int threads = 0;
 		if (!threads)
 		{
 			threads = omp_get_num_procs();
-			if (threads > 64) threads = 64;
+			if (threads > 32) threads = 32;
 			if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) threads = v; }      // developer aid
 			if (threads < 1) threads = 1;
 		}
