@@ -297,6 +297,9 @@ def run_workload(w, opts, ens, steps, warmup, with_roofline, with_traffic, with_
 
     if with_roofline and ens.rank == 0:
         res["roofline"] = roofline_record(pbd, sol, ts, model, w, plan, steps, n_particles, stats, substep_device)
+        if res["roofline"] is not None:
+            # until a counter pass replaces them, achieved / frac are SURVEY 8d's algorithmic-byte figures (can exceed 1: LDS-resident tiles)
+            res["roofline"]["frac_kind"] = "contract"
         if with_traffic and res["roofline"] is not None and ens.world == 1:
             add_profiled_passes(res["roofline"], w, opts, plan, persist)
     return res
@@ -446,6 +449,7 @@ def add_profiled_passes(r, w, opts, plan, persist):
         # / the launch's device time / 8 TB/s -- and the contract's number stays beside them as achieved_contract / frac_contract
         r["achieved_contract"], r["frac_contract"] = r["achieved"], r["frac"]
         r["achieved"], r["frac"] = r["traffic_GBs"], r["frac_traffic"]
+        r["frac_kind"] = "traffic"
         r["frac_definition"] = "counter-measured HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated in-pass) / device time per launch / 8 TB/s; frac_contract = SURVEY 8d algorithmic bytes / same time / 8 TB/s"
     if r.get("frac_valu") is not None:
         fr = {"hbm traffic": r.get("frac_traffic") or 0.0, "valu issue": r["frac_valu"]}
@@ -687,7 +691,7 @@ def _pick(d, keys):
 def compact_roofline(r):
     if not r:
         return None
-    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "frac_contract", "achieved_contract", "frac_valu", "binding", "traffic", "frac_traffic", "traffic_over_compulsory", "algorithmic_bytes_per_launch",
+    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "frac_kind", "frac_contract", "achieved_contract", "frac_valu", "binding", "traffic", "frac_traffic", "traffic_over_compulsory", "algorithmic_bytes_per_launch",
                     "compulsory_bytes_per_launch", "avg_launch_us", "eager_launch_us", "rocprofv3_median_kernel_us", "rocprofv3_mean_kernel_us",
                     "rocprofv3_dispatches", "launches_measured"))
     out["kernel"] = str(r.get("kernel", ""))[:110]
