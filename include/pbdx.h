@@ -96,6 +96,11 @@ const char *pbdx_last_error(void);
 int pbdx_version(void);
 /* number of visible HIP devices (0 without a GPU; never fails) */
 int pbdx_device_count(void);
+/* Ensemble sharding: the one thing that shards is a set of independent scene instances -- contiguous blocks, one process (or one
+ * pbdx_solver on its own device: every entry point selects its solver's device and restores the caller's) per GPU, no data-path collective.
+ * [*begin, *end) = the instances of `rank` out of `world`; block sizes differ by at most one.  The python ensemble helper and bench.py use
+ * this definition (positionbaseddynamics_amd/ensemble.py); a C++ host with several solvers in one process uses it the same way. */
+int pbdx_ensemble_shard(uint64_t total, uint32_t world, uint32_t rank, uint64_t *begin, uint64_t *end);
 
 /* ======================================================================== */
 /* pbdx_solver -- the device engine                                         */

@@ -89,6 +89,7 @@ SIGNATURES = [
     ("pbdx_type_num_bodies", u32, C.c_int), ("pbdx_type_param_stride", u32, C.c_int), ("pbdx_type_name", C.c_char_p, C.c_int),
     ("pbdx_type_algorithmic_bytes", u32, C.c_int),
     ("pbdx_last_error", C.c_char_p), ("pbdx_version", C.c_int), ("pbdx_device_count", C.c_int),
+    ("pbdx_ensemble_shard", C.c_int, C.c_uint64, u32, u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)),
     ("pbdx_solver_create", C.c_int, C.POINTER(vp), C.c_int), ("pbdx_solver_destroy", None, vp),
     ("pbdx_solver_set_particles", C.c_int, vp, u32, pf, pf, pf, pf, pf, pf),
     ("pbdx_solver_set_particles_f64", C.c_int, vp, u32, pd_, pd_, pd_, pd_, pd_, pd_),

@@ -50,4 +50,14 @@ uint32_t pbdx_type_param_stride(int type) { const pbdx::TypeInfo *t = pbdx::type
 uint32_t pbdx_type_algorithmic_bytes(int type) { const pbdx::TypeInfo *t = pbdx::type_info(type); return t ? t->algorithmic_bytes : 0; }
 const char *pbdx_type_name(int type) { const pbdx::TypeInfo *t = pbdx::type_info(type); return t ? t->name : ""; }
 
+// contiguous block [begin, end) of `total` independent instances owned by `rank` of `world` (sizes differ by at most one)
+int pbdx_ensemble_shard(uint64_t total, uint32_t world, uint32_t rank, uint64_t *begin, uint64_t *end)
+{
+	if (world == 0 || rank >= world || !begin || !end) { pbdx::set_error("pbdx_ensemble_shard: bad world / rank"); return PBDX_ERR_INVALID; }
+	const uint64_t base = total / world, extra = total % world;
+	*begin = (uint64_t)rank * base + (rank < extra ? rank : extra);
+	*end = *begin + base + (rank < extra ? 1u : 0u);
+	return PBDX_OK;
+}
+
 }

@@ -11,12 +11,15 @@ import numpy as np
 
 
 def shard_range(total, world, rank):
-    """Contiguous block [begin, end) of `total` instances owned by `rank` (sizes differ by at most 1)."""
+    """Contiguous block [begin, end) of `total` instances owned by `rank` (sizes differ by at most 1): include/pbdx.h
+    pbdx_ensemble_shard, the one definition C++ hosts and this helper share."""
+    import ctypes as C
+    from . import _ffi
     if world < 1 or not (0 <= rank < world):
         raise ValueError("bad world/rank")
-    base, extra = divmod(int(total), int(world))
-    begin = rank * base + min(rank, extra)
-    return begin, begin + base + (1 if rank < extra else 0)
+    b, e = C.c_uint64(0), C.c_uint64(0)
+    _ffi.check(_ffi.lib.pbdx_ensemble_shard(int(total), int(world), int(rank), C.byref(b), C.byref(e)), "pbdx_ensemble_shard")
+    return int(b.value), int(e.value)
 
 
 def _free_port():
