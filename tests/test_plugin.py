@@ -422,6 +422,32 @@ def test_compiled_pypbd_is_the_references_own_module_plus_one_class(have_gpu):
     assert res["2_gpu"]["failed"] == 16 and not res["2_gpu"]["moved"]
 
 
+def test_discregrid_shim_fails_loudly_instead_of_inventing_distance_fields():
+    """oracle/shim/Discregrid/All is COMPILE-ONLY: the reference's cubic-SDF entry points exist in the module (unmodified
+    pyPBD/CollisionDetectionModule.cpp:155-186) and raise when called -- no stand-in distance field produces numbers nobody can check."""
+    import glob
+    import subprocess
+    import sys
+    if not glob.glob(os.path.join(PLUGIN_DIR, "pypbd*.so")):
+        pytest.skip("pypbd module not built (needs /root/reference at build time)")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, pypbd as pbd\n"
+            "sim = pbd.Simulation.getCurrent(); sim.initDefault()\n"
+            "cd = sim.getTimeStep().getCollisionDetection()\n"
+            "print('CD', type(cd).__name__)\n"
+            "vd = pbd.VertexData(); mesh = pbd.IndexedFaceMesh()\n"
+            "for p in ((0,0,0),(1,0,0),(0,1,0),(0,0,1)): vd.addVertex(np.array(p, dtype=np.float32))\n"
+            "mesh.initMesh(4, 6, 4)\n"
+            "for f in ((0,2,1),(0,1,3),(0,3,2),(1,2,3)): mesh.addFace(list(f))\n"
+            "mesh.buildNeighbors()\n"
+            "try:\n    pbd.CubicSDFCollisionDetection.generateSDF(vd, mesh, np.array([4,4,4], dtype=np.uint32))\n    print('NO ERROR')\n"
+            "except RuntimeError as e:\n    print('RAISED', e)\n") % PLUGIN_DIR
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "CD CubicSDFCollisionDetection" in p.stdout, p.stdout
+    assert "RAISED" in p.stdout and "Discregrid is not part of this build" in p.stdout, p.stdout
+
+
 @pytest.mark.gpu
 def test_reference_python_example_through_compiled_pypbd_on_the_gpu():
     """pyPBD/examples/cloth_model.py's logic, `import pypbd as pbd` = the reference's own module, the marked lines added to install
