@@ -486,7 +486,8 @@ def cpu_baseline(size, iters, opts, hip_device, parity_steps=3, timed_steps=3):
     else:
         o = refdrv.Ref(variant)
         kind = "reference"
-        thread_settings = sorted(set([1, min(16, ncpu), min(32, ncpu), min(64, ncpu)]))
+        # OMP_NUM_THREADS = 1 and = nproc (the count is stated in `sample`), plus the settings in between where the reference is fastest
+        thread_settings = sorted(set([1, min(16, ncpu), min(32, ncpu), min(64, ncpu), ncpu]))
         flags = {"v4": "-O3 -march=x86-64-v4 -fopenmp, float", "fast": "-O3 -march=x86-64-v3 -fopenmp, float"}[variant]
     t_setup = time.perf_counter()
     apply_ref(o, ops)
@@ -695,6 +696,10 @@ def compact_roofline(r):
                     "compulsory_bytes_per_launch", "avg_launch_us", "eager_launch_us", "rocprofv3_median_kernel_us", "rocprofv3_mean_kernel_us",
                     "rocprofv3_dispatches", "launches_measured"))
     out["kernel"] = str(r.get("kernel", ""))[:110]
+    if r.get("frac_kind") == "traffic":
+        out["note"] = "achieved/frac = PMC HBM-side bytes per launch / median device time (/ 8 TB/s); SURVEY 8d algorithmic-byte figure = achieved_contract/frac_contract (> 1: LDS-resident tiles do not move those bytes)"
+    elif r.get("frac_kind") == "contract":
+        out["note"] = "achieved/frac = SURVEY 8d algorithmic bytes / device time (no counter pass for this line)"
     if r.get("timing_mode"):
         out["timing_mode"] = r["timing_mode"].split(":")[0]
     return out
