@@ -234,3 +234,14 @@ extern "C" int pbdx_colour_constraints(int device, uint32_t num_bodies, uint32_t
 	}
 	return PBDX_OK;
 }
+
+// Stable radix sort of (key, value) pairs of 32-bit words on a stream (hipcub lives in this translation unit only).  temp == nullptr: size query.
+namespace pbdx {
+int sort_pairs_u32(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, void *stream)
+{
+	const hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, *temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 32, (hipStream_t)stream);
+	if (e != hipSuccess) { set_error("radix sort of %u pairs failed: %s", n, hipGetErrorString(e)); return PBDX_ERR_HIP; }
+	return PBDX_OK;
+}
+}
+

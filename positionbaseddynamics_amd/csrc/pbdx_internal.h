@@ -68,6 +68,9 @@ struct TetMesh
 	std::vector<uint32_t> vertex_tet_count; // |verticesTets[v]| (shape-matching cluster counts)
 };
 
+// stable radix sort of 32-bit (key, value) pairs on a HIP stream (pbdx_colour.hip; temp == nullptr: *temp_bytes receives the scratch size)
+int sort_pairs_u32(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, void *stream);
+
 } // namespace pbdx
 
 struct pbdx_model

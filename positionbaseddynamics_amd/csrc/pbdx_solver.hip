@@ -1249,7 +1249,8 @@ struct pbdx_solver
 	uint32_t *d_tet_big = nullptr; uint32_t tet_big_count = 0;   // nodes with long chains (tet_hull_kernel2)
 	uint32_t *d_tet_big_slices = nullptr, *d_tet_big_r2 = nullptr; uint32_t tet_big_slices = 0;
 	TetWork tet_work = {};
-	void *tet_work_alloc[18] = {};
+	void *tet_work_alloc[24] = {};
+	size_t tet_sort_temp_bytes = 0;      // scratch of the (particle, slot) pair sort of the contact velocity impulses (tet_work_alloc[21])
 	pbdx_collision_range *d_ranges = nullptr;     // device copy of `ranges` (read by the tet-contact velocity chains)
 	bool measuring_iter_form = false;    // autotune_schedule: time the one-launch-per-iteration form of the sweeps
 	int tet_force_impulses = 0;          // PBDX_OPT_TET_FORCE_IMPULSES
@@ -2122,6 +2123,13 @@ int alloc_tet_work_impl(pbdx_solver *s, uint64_t nodes, uint32_t contacts)
 	HIPCHECK(hipMalloc(&s->tet_work_alloc[16], (size_t)std::max(1u, s->n)));
 	HIPCHECK(hipMemset(s->tet_work_alloc[16], 0, (size_t)std::max(1u, s->n)));
 	w.imp_mark = (uint8_t *)s->tet_work_alloc[16];
+	// (particle, slot) pairs of the impulse-carrying contacts and the scratch of their sort (pbdx_tetcontact_dev.h: tet_impulse_kernel)
+	for (int q = 17; q <= 20; q++) HIPCHECK(hipMalloc(&s->tet_work_alloc[q], (size_t)5 * contacts * 4));
+	w.imp_keys = (uint32_t *)s->tet_work_alloc[17]; w.imp_slots = (uint32_t *)s->tet_work_alloc[18];
+	w.imp_keys_sorted = (uint32_t *)s->tet_work_alloc[19]; w.imp_slots_sorted = (uint32_t *)s->tet_work_alloc[20];
+	s->tet_sort_temp_bytes = 0;
+	{ int rs = sort_pairs_u32(nullptr, &s->tet_sort_temp_bytes, w.imp_keys, w.imp_keys_sorted, w.imp_slots, w.imp_slots_sorted, 5u * contacts, s->stream); if (rs) return rs; }
+	HIPCHECK(hipMalloc(&s->tet_work_alloc[21], std::max<size_t>(s->tet_sort_temp_bytes, 16)));
 	w.force_impulses = s->tet_force_impulses;
 	return PBDX_OK;
 }
@@ -2263,6 +2271,14 @@ int enqueue_contacts(pbdx_solver *s)
 		a.tolerance = s->contact_tolerance; a.stiffness = s->contact_stiffness; a.iterations = s->max_iterations_v;
 		a.contact_counters = rigid ? s->d_contact_counters : nullptr;
 		const uint32_t blocks = std::min(256u, (5u * s->tet_impulses_last + 255u) / 256u);
+		// a particle's (contact, role) entries side by side and in list order: pairs keyed by particle, stable radix sort
+		hipLaunchKernelGGL(tet_impulse_pairs_kernel, dim3(blocks), dim3(256), 0, s->stream, (const TetContact *)s->d_tet_contacts, s->tet_work);
+		{
+			size_t tb = s->tet_sort_temp_bytes;
+			int rs = sort_pairs_u32(s->tet_work_alloc[21], &tb, s->tet_work.imp_keys, s->tet_work.imp_keys_sorted, s->tet_work.imp_slots, s->tet_work.imp_slots_sorted,
+				5u * s->tet_impulses_last, s->stream);
+			if (rs) return rs;
+		}
 		hipLaunchKernelGGL(tet_impulse_kernel, dim3(blocks), dim3(256), 0, s->stream, a);
 		hipLaunchKernelGGL(tet_impulse_clear_kernel, dim3(blocks), dim3(256), 0, s->stream, (const TetContact *)s->d_tet_contacts, s->tet_work);
 		HIPCHECK(hipGetLastError());

@@ -64,6 +64,9 @@ struct TetWork                    // device scratch of the detection; *_cap are 
 	uint32_t *counters;           // kTcWords
 	uint32_t *imp_list;           // the contacts that carry a velocity impulse (pMax < 0), in list order (max_contacts entries)
 	uint8_t *imp_mark;            // per particle: 1 while it takes part in such a contact as a dynamic particle (all zero between steps)
+	// the (particle, slot) pairs of the impulse-carrying contacts -- slot = 5 * (index in imp_list) + role (0 = the contact particle, 1 .. 4 = the tet's
+	// vertices) -- before and after a stable sort by particle: a particle's entries then sit side by side, in list order (5 * max_contacts entries each)
+	uint32_t *imp_keys, *imp_slots, *imp_keys_sorted, *imp_slots_sorted;
 	int force_impulses;           // developer aid (PBDX_OPT_TET_FORCE_IMPULSES): see tet_contact_velocity_impulse
 };
 
@@ -761,30 +764,39 @@ __global__ __launch_bounds__(1024) void tet_impulse_list_kernel(const TetContact
 	if (threadIdx.x == 0) w.counters[kTcImpulses] = base;
 }
 
+// keys of the sort: the particle of every (impulse contact, role) slot, or ~0 where the particle is static in all its contacts (sorts to the end)
+__global__ __launch_bounds__(256) void tet_impulse_pairs_kernel(const TetContact *contacts, TetWork w)
+{
+	const uint32_t count = w.counters[kTcImpulses];
+	for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < 5u * count; slot += gridDim.x * blockDim.x)
+	{
+		const uint32_t e = slot / 5u, r = slot % 5u;
+		const TetContact &c = contacts[w.imp_list[e]];
+		const uint32_t p = r == 0 ? c.particle : c.vert[r - 1];
+		w.imp_keys[slot] = w.imp_mark[p] ? p : 0xffffffffu;
+		w.imp_slots[slot] = slot;
+	}
+}
+
 struct TetImpulseChain          // Extra of particle_contacts (pbdx_contact.h): the tet-contact impulses of particle `p`, one iteration's worth
 {
 	const TetContact *contacts;
 	const P4 *pos;
 	const uint32_t *list;
-	uint32_t count, p;
+	const uint32_t *keys, *slots;       // sorted by particle (stable: list order inside a particle)
+	uint32_t begin, total, p;           // p's entries start at `begin`
 	bool force;
 	__device__ void after_sweep(V3 &v) const
 	{
-		for (uint32_t e = 0; e < count; e++)
+		// p's contacts in list order; a tet's four vertices are distinct and its contact particle belongs to another solid, so p has ONE role per contact
+		for (uint32_t j = begin; j < total && keys[j] == p; j++)
 		{
+			const uint32_t slot = slots[j], e = slot / 5u, r = slot % 5u;
 			const TetContact &c = contacts[list[e]];
-			const uint32_t ids[5] = { c.particle, c.vert[0], c.vert[1], c.vert[2], c.vert[3] };
-			bool mine = false;
-			for (int r = 0; r < 5; r++) mine = mine || ids[r] == p;
-			if (!mine) continue;
 			const float w0 = pos[c.particle].w;
-			V3 pv;
+			V3 pv, corr;
 			if (!tet_contact_velocity_impulse(c, w0, pv, force)) continue;
-			for (int r = 0; r < 5; r++)            // a tet's four vertices are distinct and its contact particle belongs to another solid
-			{
-				V3 corr;
-				if (ids[r] == p && tet_contact_velocity_share(c, w0, pv, r, corr)) v = v + corr;
-			}
+			if (tet_contact_velocity_share(c, w0, pv, (int)r, corr)) v = v + corr;
 		}
 	}
 };
@@ -801,30 +813,23 @@ struct TetImpulseArgs
 	uint32_t iterations;
 	unsigned int *contact_counters;      // of the rigid-body contacts: [0] contacts, [1] overflow flag (may be null)
 };
+// One lane per marked particle: the lane at the START of the particle's run in the sorted pairs runs its chain.  Linear in the number of
+// (contact, particle) pairs (the first form found a particle's first appearance and its contacts by scanning the whole list per lane).
 __global__ __launch_bounds__(256) void tet_impulse_kernel(TetImpulseArgs a)
 {
-	const uint32_t count = a.w.counters[kTcImpulses];
+	const uint32_t total = 5u * a.w.counters[kTcImpulses];
 	const P4 *pos = reinterpret_cast<const P4 *>(a.pos);
-	for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < 5u * count; slot += gridDim.x * blockDim.x)
+	const uint32_t *keys = a.w.imp_keys_sorted, *slots = a.w.imp_slots_sorted;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
 	{
-		const uint32_t e = slot / 5u, r = slot % 5u;
-		const TetContact &c = a.contacts[a.w.imp_list[e]];
-		const uint32_t p = r == 0 ? c.particle : c.vert[r - 1];
-		if (!a.w.imp_mark[p]) continue;                        // static in this contact and in every other one
-		// this lane runs p's chain iff (e, r) is p's first appearance in the compacted list
-		bool first = true;
-		for (uint32_t e2 = 0; e2 <= e && first; e2++)
-		{
-			const TetContact &c2 = a.contacts[a.w.imp_list[e2]];
-			const uint32_t ids[5] = { c2.particle, c2.vert[0], c2.vert[1], c2.vert[2], c2.vert[3] };
-			for (uint32_t r2 = 0; r2 < (e2 == e ? r : 5u); r2++) if (ids[r2] == p) first = false;
-		}
-		if (!first) continue;
+		const uint32_t p = keys[i];
+		if (p == 0xffffffffu) continue;                        // static in this contact and in every other one
+		if (i && keys[i - 1] == p) continue;                   // not the start of p's run
 		const float4 x = a.pos[p];
 		float4 vv = a.vel[p];
 		if (vv.w == 0.0f) continue;                            // (marks are only set for dynamic particles)
 		V3 v = mk(vv.x, vv.y, vv.z);
-		const TetImpulseChain chain = { a.contacts, pos, a.w.imp_list, count, p, a.w.force_impulses != 0 };
+		const TetImpulseChain chain = { a.contacts, pos, a.w.imp_list, keys, slots, i, total, p, a.w.force_impulses != 0 };
 		// p's contacts with the static rigid bodies, if it belongs to a collision range (pbdx_contact.h)
 		const pbdx_collision_range *rg = nullptr;
 		if (a.num_colliders) for (uint32_t q = 0; q < a.num_ranges; q++) if (p >= a.ranges[q].first && p - a.ranges[q].first < a.ranges[q].count) rg = &a.ranges[q];
