@@ -9,7 +9,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <omp.h>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <chrono>
 
 using namespace PBD;
@@ -108,25 +111,81 @@ namespace
 	}
 	// full-coverage block hashes of a packed host array (include/pbdx.h: pbdx_hash_block): every word of the array is hashed,
 	// PBDX_HASH_BLOCK elements per 64-bit hash.  The pass is bandwidth-bound (one read of the array) and runs on a handful of
-	// threads when the arrays are large -- the host application is an OpenMP program anyway (TimeStepController.cpp:270-286);
-	// the thread count is stated explicitly because hosts commonly run the solver loops with omp_set_num_threads(1).
-	// Threads of the plug-in's own host passes (block hashes of the particle arrays, the exact parameter scan): 32, ONE count for every
-	// pass, stated explicitly (hosts commonly run their own solver loops with omp_set_num_threads(1)).  Measured on the 256-CPU host of the
-	// MI355X box (profiles/r04b_*, r04_plugin_round_trip.log): the parameter walk alone scales to 64 threads (6 M constraints: 8.2 / 4.1 /
-	// 2.4 ms at 16 / 32 / 64), but libgomp keeps one team per host thread and a team size that differs from the previous region's -- or
-	// from the host application's own (the test host runs with 32) -- costs milliseconds per region (hashes 0.26 -> 8 ms, scan 2.4 -> 26 ms).
-	inline int pluginThreads()
+	// threads when the arrays are large (HostPool below).
+	// The plug-in's own host passes (block hashes of the particle arrays, the exact parameter scan) run on a small pool of worker
+	// threads of their OWN, not on the host application's OpenMP runtime: libgomp keeps one team of threads per host thread, and a
+	// parallel region whose team size differs from the previous region's or from the host application's own setting costs milliseconds
+	// (measured on the 256-CPU host of the MI355X box, profiles/HISTORY.md [8]: particle hashes 0.26 -> 8 ms, parameter scan 2.4 ->
+	// 9-26 ms, from one step to the next).  The workers sleep on a condition variable between passes; the thread that calls step()
+	// takes the first share itself.  Up to 64 threads (the parameter walk scales that far: 6 M constraints 7.9 / 4.0 / 2.4 ms at
+	// 8 / 32 / 64; hosts commonly run their own loops with omp_set_num_threads(1), so the count does not follow OpenMP's).
+	class HostPool
 	{
-		static int threads = 0;
-		if (!threads)
+	public:
+		static HostPool &get() { static HostPool pool; return pool; }
+		int threads() const { return m_threads; }
+		// fn(begin, end) over a static partition of [0, n) into `parts` shares (parts <= threads())
+		void run(size_t n, int parts, const std::function<void(size_t, size_t)> &fn)
 		{
-			threads = omp_get_num_procs();
-			if (threads > 32) threads = 32;
-			if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) threads = v; }      // developer aid
-			if (threads < 1) threads = 1;
+			if (parts > m_threads) parts = m_threads;
+			if (parts <= 1 || n < 2) { fn(0, n); return; }
+			start();
+			{
+				std::lock_guard<std::mutex> lk(m_mutex);
+				m_fn = &fn; m_n = n; m_parts = parts; m_pending = parts - 1; m_generation++;
+			}
+			m_wake.notify_all();
+			fn(0, n / (size_t)parts);                                // share 0 on the calling thread
+			std::unique_lock<std::mutex> lk(m_mutex);
+			m_done.wait(lk, [this] { return m_pending == 0; });
+			m_fn = nullptr;
 		}
-		return threads;
-	}
+	private:
+		HostPool() : m_threads(1), m_fn(nullptr), m_n(0), m_parts(0), m_pending(0), m_generation(0), m_stop(false)
+		{
+			unsigned int hw = std::thread::hardware_concurrency();
+			m_threads = hw ? (int)hw : 1;
+			if (m_threads > 64) m_threads = 64;
+			if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) m_threads = v; }      // developer aid
+		}
+		~HostPool()
+		{
+			{ std::lock_guard<std::mutex> lk(m_mutex); m_stop = true; }
+			m_wake.notify_all();
+			for (std::thread &t : m_workers) if (t.joinable()) t.join();
+		}
+		void start()
+		{
+			if (!m_workers.empty() || m_threads <= 1) return;
+			for (int k = 1; k < m_threads; k++) m_workers.emplace_back([this, k] { work(k); });
+		}
+		void work(int k)
+		{
+			uint64_t seen = 0;
+			for (;;)
+			{
+				const std::function<void(size_t, size_t)> *fn; size_t n; int parts;
+				{
+					std::unique_lock<std::mutex> lk(m_mutex);
+					m_wake.wait(lk, [&] { return m_stop || m_generation != seen; });
+					if (m_stop) return;
+					seen = m_generation; fn = m_fn; n = m_n; parts = m_parts;
+				}
+				if (k < parts)
+				{
+					(*fn)(n * (size_t)k / (size_t)parts, n * (size_t)(k + 1) / (size_t)parts);
+					std::lock_guard<std::mutex> lk(m_mutex);
+					if (--m_pending == 0) m_done.notify_one();
+				}
+			}
+		}
+		int m_threads;
+		std::vector<std::thread> m_workers;
+		std::mutex m_mutex;
+		std::condition_variable m_wake, m_done;
+		const std::function<void(size_t, size_t)> *m_fn;
+		size_t m_n; int m_parts, m_pending; uint64_t m_generation; bool m_stop;
+	};
 	struct HashJob { const void *base; uint32_t n, elemBytes; std::vector<uint64_t> *out; };
 	void hashBlocks(HashJob *jobs, int numJobs)
 	{
@@ -142,15 +201,16 @@ namespace
 			bytes += (size_t)jobs[j].n * jobs[j].elemBytes;
 		}
 		first[numJobs] = total;
-		const int threads = bytes >= ((size_t)1 << 20) ? pluginThreads() : 1;
-		// ONE parallel region over the blocks of all arrays
-		#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
-		for (int q = 0; q < total; q++)
+		// ONE pass over the blocks of all arrays
+		HostPool::get().run((size_t)total, bytes >= ((size_t)1 << 20) ? HostPool::get().threads() : 1, [&](size_t q0, size_t q1)
 		{
-			int j = 0;
-			while (q >= first[j + 1]) j++;
-			(*jobs[j].out)[(size_t)(q - first[j])] = pbdx_hash_block(jobs[j].base, jobs[j].n, jobs[j].elemBytes, (uint32_t)(q - first[j]));
-		}
+			for (size_t q = q0; q < q1; q++)
+			{
+				int j = 0;
+				while ((int)q >= first[j + 1]) j++;
+				(*jobs[j].out)[q - (size_t)first[j]] = pbdx_hash_block(jobs[j].base, jobs[j].n, jobs[j].elemBytes, (uint32_t)(q - (size_t)first[j]));
+			}
+		});
 	}
 	// element ranges (first, count pairs; adjacent blocks merged) covered by the blocks whose hash differs
 	void changedRanges(const std::vector<uint64_t> &was, const std::vector<uint64_t> &now, uint32_t n, std::vector<uint32_t> &ranges)
@@ -623,11 +683,11 @@ void TimeStepControllerHIP::hashParameters(SimulationModel &model, std::vector<u
 	const size_t nb = (nc + kParamScanBlock - 1) / kParamScanBlock;
 	out.resize(nb + 1);
 	out[nb] = (uint64_t)nc;
-	const int threads = nc >= 65536 ? pluginThreads() : 1;
 	Constraint *const *cs = constraints.data();
 	uint64_t *o = out.data();
-	#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
-	for (long long b = 0; b < (long long)nb; b++)
+	HostPool::get().run(nb, nc >= 65536 ? HostPool::get().threads() : 1, [&](size_t b0, size_t b1)
+	{
+	for (size_t b = b0; b < b1; b++)
 	{
 		const size_t first = (size_t)b * kParamScanBlock, last = first + kParamScanBlock < nc ? first + kParamScanBlock : nc;
 		HashSink s = { 0x51ed270b7d0e3a5full ^ (uint64_t)b, 0u, 0u, false };
@@ -648,6 +708,7 @@ void TimeStepControllerHIP::hashParameters(SimulationModel &model, std::vector<u
 		}
 		o[b] = s.h;
 	}
+	});
 }
 
 // One pass over every colour group: its constraints are bucketed by type (creation order kept inside a bucket) and each
