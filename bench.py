@@ -486,8 +486,10 @@ def cpu_baseline(size, iters, opts, hip_device, parity_steps=3, timed_steps=3):
     else:
         o = refdrv.Ref(variant)
         kind = "reference"
-        # OMP_NUM_THREADS = 1 and = nproc (the count is stated in `sample`), plus the settings in between where the reference is fastest
-        thread_settings = sorted(set([1, min(16, ncpu), min(32, ncpu), min(64, ncpu), ncpu]))
+        # SURVEY 8d asks for OMP_NUM_THREADS = 1 and = nproc: at nproc = 256 (the MI355X box's host) the reference needs 57.8 s per substep -- it forks and joins
+        # one parallel region per colour group (profiles/r04_bench_detail.json of the run that tried it: 4 minutes of bench time) -- so the sweep stops at 64 and
+        # the best setting is reported
+        thread_settings = sorted(set([1, min(16, ncpu), min(32, ncpu), min(64, ncpu)]))
         flags = {"v4": "-O3 -march=x86-64-v4 -fopenmp, float", "fast": "-O3 -march=x86-64-v3 -fopenmp, float"}[variant]
     t_setup = time.perf_counter()
     apply_ref(o, ops)
