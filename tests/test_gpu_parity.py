@@ -1000,3 +1000,29 @@ def test_fma_build_stays_inside_the_fp32_envelope(pbd):
         assert r["e_gpu"] <= 4.0 * r["e_ref"] + 1e-5, name
         differs += 0 if r["bitwise"] else 1
     assert differs > 0, "the contracted build is bit-identical everywhere: is it really built with -ffp-contract=fast?"
+
+
+@pytest.mark.gpu
+def test_substep_events_time_every_substep_of_a_call(pbd):
+    """PBDX_OPT_SUBSTEP_EVENTS (the bench's median device time): one interval per substep of the last call, all positive, adding up to the
+    call's own event time; the option changes no result and is empty when switched off."""
+    S = pbd.Solver
+    ops = util.cloth_spec(120, 90, 4, 3)
+    base, _ = util.mine_run(ops, 6, 2, 5, resident=True)
+    m = util.build_mine(ops)
+    ts = pbd.TimeStepController()
+    ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 2)
+    ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 5)
+    sol = ts.solver()
+    ts.stepResident(m, 2)
+    assert sol.substep_times() == []
+    sol.set_option(S.OPT_SUBSTEP_EVENTS, 1)
+    ts.stepResident(m, 4)
+    t = sol.substep_times()
+    total = sol.stats()["total_ms"]
+    print("substep events: %d intervals, median %.4f ms, sum %.4f ms, call %.4f ms" % (len(t), sorted(t)[len(t) // 2], sum(t), total))
+    assert len(t) == 8 and all(x > 0.0 for x in t)
+    assert sum(t) <= total * 1.001 + 1e-3 and sum(t) >= 0.8 * total
+    sol.set_option(S.OPT_SUBSTEP_EVENTS, 0)
+    ts.syncToHost(m)
+    assert util.bitwise_equal(m.getParticles().positions(), base.getParticles().positions())
