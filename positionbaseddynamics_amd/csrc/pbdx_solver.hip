@@ -170,10 +170,29 @@ static_assert((PBDX_DEPTH_SMALL == 2 || PBDX_DEPTH_SMALL == 4) && (PBDX_DEPTH_BI
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 struct ChunkS { uint32_t info, idx_boff, par_boff, lam_boff; };
-// chunk descriptors are staged in LDS (uniform address -> broadcast read -> SGPRs)
-__device__ __forceinline__ ChunkS load_chunk(const uint4 *lchunks, uint32_t c)
+// A tile's chunk descriptors are read from the plan through the SCALAR cache (constant address space + uniform index -> s_load straight into
+// SGPRs).  Until round 4 they were staged in LDS by the fill and read back as scalars (uniform address -> broadcast read -> four
+// v_readfirstlane): 8 VALU instructions per sub-iteration of a sweep that is VALU-issue-bound.  Measured (profiles/r04g_*): 1 M cloth 0.654 ->
+// 0.628 ms (-4 %), 100 k-tet bar 0.609 -> 0.595, configs[3] block 1.63 -> 1.58, 300x300 cloth -5 %; bit-identical.  PBDX_SMEM_CHUNKS = 0 builds
+// the LDS form for A/B runs.
+#ifndef PBDX_SMEM_CHUNKS
+#define PBDX_SMEM_CHUNKS 1
+#endif
+struct ChunkSrc { const uint4 *lds; const uint4 *glb; };
+__device__ __forceinline__ uint4 chunk_words(const ChunkSrc &cs, uint32_t c)
 {
-	const uint4 v = lchunks[c];
+#if PBDX_SMEM_CHUNKS && defined(__HIP_DEVICE_COMPILE__)
+	typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+	typedef __attribute__((address_space(4))) const u4 *const_ptr;
+	const u4 v = *((const_ptr)(uintptr_t)cs.glb + c);
+	return make_uint4(v.x, v.y, v.z, v.w);
+#else
+	return cs.lds[c];
+#endif
+}
+__device__ __forceinline__ ChunkS load_chunk(const ChunkSrc &cs, uint32_t c)
+{
+	const uint4 v = chunk_words(cs, c);
 	ChunkS r;
 	r.info = rfl(v.x); r.idx_boff = rfl(v.y); r.par_boff = rfl(v.z); r.lam_boff = rfl(v.w);
 	return r;
@@ -259,8 +278,10 @@ template <int BLOCK, bool COHERENT> struct TileFill
 	template <class Wait> __device__ __forceinline__ void operator()(const Wait &wait) const
 	{
 		static_assert(BLOCK >= (int)kMaxTileChunks, "one chunk descriptor per thread");
+#if !PBDX_SMEM_CHUNKS
 		uint4 chv = make_uint4(0u, 0u, 0u, 0u);       // this thread's chunk descriptor: in flight with the ids
 		if (threadIdx.x < num_chunks) chv = src[threadIdx.x];
+#endif
 		const uint32_t last = n_local - 1u;
 		uint32_t base = first + threadIdx.x;
 #define PBDX_G(k) const uint32_t i##k = base + k * BLOCK; const uint32_t g##k = gid[i##k < last ? i##k : last];
@@ -278,7 +299,9 @@ template <int BLOCK, bool COHERENT> struct TileFill
 #undef PBDX_BATCH
 #undef PBDX_G
 #undef PBDX_D
+#if !PBDX_SMEM_CHUNKS
 		if (threadIdx.x < num_chunks) lchunks[threadIdx.x] = chv;
+#endif
 #if PBDX_DEFER_FILL_WAIT
 		// The positions are still in flight (HBM -> LDS copies).  Only the chunk descriptors have to be visible now: the first run of the sweep
 		// issues its record prefetches (which read the descriptors, not the positions) and THEN waits for the copies (fill_wait below), so that
@@ -313,7 +336,7 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 // slot is projected.  Same arithmetic on the same values: bit-identical.
 struct RecD { uint32_t w[4]; };          // packed indices (2), multiplier, table offset (16-byte units)
 template <int TYPE, bool COMPACT, int BLOCK, bool COHERENT, bool QUAD_STEP = false, bool DICT = false>
-__device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStreams &str, const uint4 *lchunks, uint32_t c0,
+__device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStreams &str, const ChunkSrc &lchunks, uint32_t c0,
 	float4 *lpos, unsigned long long *trace, uint32_t &step_counter, bool &fill_pending, const float4 *ltab = nullptr)
 {
 	static_assert(!(DICT && (QUAD_STEP || is_quad_type(TYPE))), "dictionary form: one lane per slot");
@@ -331,7 +354,7 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 	const uint32_t v_tail = VEC ? (lane_slot >> 6) * (NP * 256u) + (NP / 4u) * 1024u + (lane_slot & 63u) * ((NP % 4u) * 4u) : 0u;
 	const QuadLane ql = quad_lane();
 	// end of the run (first chunk of another type): precomputed on the host
-	const uint32_t run_end = c0 + chunk_run_left(rfl(lchunks[c0].x));
+	const uint32_t run_end = c0 + chunk_run_left(rfl(chunk_words(lchunks, c0).x));
 
 	uint32_t c_ld = c0, c_ex = c0;
 	// the ring lives in named records (not an array): keeps every record in registers
@@ -446,18 +469,18 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 }
 
 #define PBDX_CASE(T) case T: if constexpr ((MASK >> T) & 1u) { \
-		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending) \
-		                        : run_typed<T, false, BLOCK, COHERENT>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending); } \
+		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending) \
+		                        : run_typed<T, false, BLOCK, COHERENT>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending); } \
 	else { c = num_chunks; } break;
 // a run of dictionary-form steps of type T (chunk type kDictChunkType + T)
 #define PBDX_CASE_DICT(T) case kDictChunkType + T: if constexpr (((MASK >> T) & 1u) && dict_type(T)) { \
-		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT, false, true>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending, ltab) \
-		                        : run_typed<T, false, BLOCK, COHERENT, false, true>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending, ltab); } \
+		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT, false, true>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending, ltab) \
+		                        : run_typed<T, false, BLOCK, COHERENT, false, true>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending, ltab); } \
 	else { c = num_chunks; } break;
 // a run of StrainTetConstraint steps in quad form (chunk pseudo-type kQuadStrainChunk)
 #define PBDX_CASE_QUAD_STRAIN case kQuadStrainChunk: if constexpr (((MASK >> PBDX_STRAIN_TET) & 1u) && PBDX_QUAD_STRAIN) { \
-		c = ra.views[PBDX_STRAIN_TET].compact ? run_typed<PBDX_STRAIN_TET, true, BLOCK, COHERENT, true>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending) \
-		                                      : run_typed<PBDX_STRAIN_TET, false, BLOCK, COHERENT, true>(ra, str, lchunks, c, lpos, trace, step_counter, fill_pending); } \
+		c = ra.views[PBDX_STRAIN_TET].compact ? run_typed<PBDX_STRAIN_TET, true, BLOCK, COHERENT, true>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending) \
+		                                      : run_typed<PBDX_STRAIN_TET, false, BLOCK, COHERENT, true>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending); } \
 	else { c = num_chunks; } break;
 
 // LDS: [ chunk descriptors of the tile: kMaxTileChunks x 16 B ][ positions: n_local x float4 ]
@@ -491,8 +514,10 @@ template <int BLOCK>
 __device__ __forceinline__ void integrate_fill(const FoldArgs &f, const uint4 *src, const uint32_t *gid, const float4 *pos_in, uint4 *lchunks, float4 *lpos,
 	uint32_t num_chunks, uint32_t n_local, uint32_t n_owned, unsigned long long *trace)
 {
+#if !PBDX_SMEM_CHUNKS
 	uint4 chv = make_uint4(0u, 0u, 0u, 0u);
 	if (threadIdx.x < num_chunks) chv = src[threadIdx.x];
+#endif
 	const uint32_t last_i = n_local - 1u;
 	for (uint32_t base = threadIdx.x; base < n_local; base += 4u * BLOCK)
 	{
@@ -523,7 +548,9 @@ __device__ __forceinline__ void integrate_fill(const FoldArgs &f, const uint4 *s
 			}
 		}
 	}
+#if !PBDX_SMEM_CHUNKS
 	if (threadIdx.x < num_chunks) lchunks[threadIdx.x] = chv;
+#endif
 	__syncthreads();
 	if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
 }
@@ -631,10 +658,11 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	}
 	bool fill_pending = PBDX_DEFER_FILL_WAIT != 0 && !staged;
 	// chunks are addressed relative to the tile from here on (they sit at lchunks[0 .. num_chunks))
+	const ChunkSrc csrc = { lchunks, reinterpret_cast<const uint4 *>(gchunks) };
 	uint32_t c = 0, step_counter = 0;
 	while (c < num_chunks)
 	{
-		switch (chunk_type(rfl(lchunks[c].x)))
+		switch (chunk_type(rfl(chunk_words(csrc, c).x)))
 		{
 			PBDX_CASE(PBDX_DISTANCE) PBDX_CASE(PBDX_DISTANCE_XPBD) PBDX_CASE(PBDX_DIHEDRAL)
 			PBDX_CASE(PBDX_ISOMETRIC_BENDING) PBDX_CASE(PBDX_ISOMETRIC_BENDING_XPBD)
