@@ -328,6 +328,11 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 #ifndef PBDX_STEP_PROBE
 #define PBDX_STEP_PROBE 0
 #endif
+// the descriptor of the chunk the NEXT record fetch reads is requested at the end of the current fetch, so that the scalar load's latency passes
+// during the projection in between (profiles/r04h_*: 1 M cloth -0.9 %, bar -1.3 %, configs[3] block -2.2 % on top of the scalar-cache descriptors)
+#ifndef PBDX_PIPELINE_FETCH_DESC
+#define PBDX_PIPELINE_FETCH_DESC 1
+#endif
 #ifndef PBDX_FETCH_BEFORE_BARRIER
 #define PBDX_FETCH_BEFORE_BARRIER 0
 #endif
@@ -359,13 +364,22 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 	uint32_t c_ld = c0, c_ex = c0;
 	// the ring lives in named records (not an array): keeps every record in registers
 	RecT r0, r1, r2, r3;
+#if PBDX_PIPELINE_FETCH_DESC
+	// the descriptor of the chunk the NEXT fetch reads is requested at the end of this one (scalar loads, PBDX_SMEM_CHUNKS): its latency
+	// passes during the projection in between instead of in front of the record loads
+	ChunkS ch_fetch = load_chunk(lchunks, c0);
+#endif
 	auto fetch = [&](RecT &dst)
 	{
 		// beyond the run the last chunk is fetched again (harmless): the fetch itself stays unconditional.  (Also for waves none of whose lanes
 		// has a slot in the chunk -- small scenes: 6 of 8 waves on the 100 k-tet bar.  Letting those skip the fetch was measured SLOWER, 0.638 ->
 		// 0.650 ms FEM, 0.745 -> 0.827 XPBD distance + volume, profiles/r03q_*: the compiler can no longer count the loads between a fetch and
 		// its use and waits for ALL outstanding loads, i.e. also for the records requested one step ago, and one step is about one memory latency.)
+#if PBDX_PIPELINE_FETCH_DESC
+		const ChunkS ch = ch_fetch;
+#else
 		const ChunkS ch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
+#endif
 		const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, v_tail, a.views[TYPE] };
 		if constexpr (DICT)
 		{
@@ -378,6 +392,9 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 		else if constexpr (QUAD) load_rec_quad<TYPE, COMPACT>(acc, ql, lane_slot, dst);
 		else load_rec<TYPE, COMPACT>(acc, lane_slot, dst);
 		c_ld++;
+#if PBDX_PIPELINE_FETCH_DESC
+		ch_fetch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
+#endif
 	};
 	fetch(r0); fetch(r1);
 	if constexpr (D == 4) { fetch(r2); fetch(r3); }
