@@ -157,9 +157,19 @@ template <class A> __device__ __forceinline__ void ldp(const A &a, uint32_t h, V
 	p = mk(v.x, v.y, v.z); w = v.w;
 }
 // Constraints.cpp:1198-1204: corrections are added only to dynamic particles
+// (PBDX_LIKELY_DYNAMIC: nearly every particle is dynamic -- the hint keeps the store on the fall-through path instead of in an out-of-line block that
+// costs two taken branches per endpoint)
+#ifndef PBDX_LIKELY_DYNAMIC
+#define PBDX_LIKELY_DYNAMIC 1
+#endif
+#if PBDX_LIKELY_DYNAMIC
+#define PBDX_LIKELY(x) __builtin_expect(!!(x), 1)
+#else
+#define PBDX_LIKELY(x) (x)
+#endif
 template <class A> __device__ __forceinline__ void apply(const A &a, uint32_t h, V3 p, V3 c, float w)
 {
-	if (w != 0.0f)
+	if (PBDX_LIKELY(w != 0.0f))
 		a.st(h, make_float4(p.x + c.x, p.y + c.y, p.z + c.z, w));
 }
 
@@ -224,7 +234,7 @@ template <class A> struct Project<PBDX_DISTANCE, A>
 		V3 p0, p1; float w0, w1;
 		ldp(a, id.x, p0, w0); ldp(a, id.y, p1, w1);
 		V3 c0, c1;
-		if (solve_distance(p0, w0, p1, w1, a.p(0, i), a.p(1, i), c0, c1))
+		if (PBDX_LIKELY(solve_distance(p0, w0, p1, w1, a.p(0, i), a.p(1, i), c0, c1)))
 		{
 			apply(a, id.x, p0, c0, w0); apply(a, id.y, p1, c1, w1);
 		}
@@ -240,7 +250,7 @@ template <class A> struct Project<PBDX_DISTANCE_XPBD, A>
 		ldp(a, id.x, p0, w0); ldp(a, id.y, p1, w1);
 		float lambda = first_iter ? 0.0f : a.lam_load(i);
 		V3 c0, c1;
-		if (solve_distance_xpbd(p0, w0, p1, w1, a.p(0, i), a.p(1, i), dt, lambda, c0, c1))
+		if (PBDX_LIKELY(solve_distance_xpbd(p0, w0, p1, w1, a.p(0, i), a.p(1, i), dt, lambda, c0, c1)))
 		{
 			apply(a, id.x, p0, c0, w0); apply(a, id.y, p1, c1, w1);
 		}
@@ -253,7 +263,7 @@ template <class A> struct Project<PBDX_DIHEDRAL, A>
 	static __device__ __forceinline__ void run(const A &a, uint32_t i, float, int)
 	{
 		PBDX_LOAD4;
-		if (solve_dihedral(p0, w0, p1, w1, p2, w2, p3, w3, a.p(0, i), a.p(1, i), c0, c1, c2, c3))
+		if (PBDX_LIKELY(solve_dihedral(p0, w0, p1, w1, p2, w2, p3, w3, a.p(0, i), a.p(1, i), c0, c1, c2, c3)))
 		{
 			PBDX_APPLY4;
 		}
@@ -267,7 +277,7 @@ template <class A> struct Project<PBDX_ISOMETRIC_BENDING, A>
 		PBDX_LOAD4;
 		QFull q;
 		load_q(a, i, q);
-		if (solve_isometric_bending(p0, w0, p1, w1, p2, w2, p3, w3, q, a.p(0, i), c0, c1, c2, c3))
+		if (PBDX_LIKELY(solve_isometric_bending(p0, w0, p1, w1, p2, w2, p3, w3, q, a.p(0, i), c0, c1, c2, c3)))
 		{
 			PBDX_APPLY4;
 		}
@@ -282,7 +292,7 @@ template <class A> struct Project<PBDX_ISOMETRIC_BENDING_XPBD, A>
 		QFull q;
 		load_q(a, i, q);
 		float lambda = first_iter ? 0.0f : a.lam_load(i);
-		if (solve_isometric_bending_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, q, a.p(0, i), dt, lambda, c0, c1, c2, c3))
+		if (PBDX_LIKELY(solve_isometric_bending_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, q, a.p(0, i), dt, lambda, c0, c1, c2, c3)))
 		{
 			PBDX_APPLY4;
 		}
@@ -297,7 +307,7 @@ template <class A> struct Project<PBDX_FEM_TRIANGLE, A>
 		PBDX_LOAD3;
 		float im[2][2];
 		im[0][0] = a.p(1, i); im[1][0] = a.p(2, i); im[0][1] = a.p(3, i); im[1][1] = a.p(4, i);
-		if (solve_fem_triangle(p0, w0, p1, w1, p2, w2, a.p(0, i), im, a.p(5, i), a.p(6, i), a.p(7, i), a.p(8, i), a.p(9, i), c0, c1, c2))
+		if (PBDX_LIKELY(solve_fem_triangle(p0, w0, p1, w1, p2, w2, a.p(0, i), im, a.p(5, i), a.p(6, i), a.p(7, i), a.p(8, i), a.p(9, i), c0, c1, c2)))
 		{
 			PBDX_APPLY3;
 		}
@@ -311,7 +321,7 @@ template <class A> struct Project<PBDX_STRAIN_TRIANGLE, A>
 		PBDX_LOAD3;
 		float im[2][2];
 		im[0][0] = a.p(0, i); im[1][0] = a.p(1, i); im[0][1] = a.p(2, i); im[1][1] = a.p(3, i);
-		if (solve_strain_triangle(p0, w0, p1, w1, p2, w2, im, a.p(4, i), a.p(5, i), a.p(6, i), a.p(7, i) != 0.0f, a.p(8, i) != 0.0f, c0, c1, c2))
+		if (PBDX_LIKELY(solve_strain_triangle(p0, w0, p1, w1, p2, w2, im, a.p(4, i), a.p(5, i), a.p(6, i), a.p(7, i) != 0.0f, a.p(8, i) != 0.0f, c0, c1, c2)))
 		{
 			PBDX_APPLY3;
 		}
@@ -323,7 +333,7 @@ template <class A> struct Project<PBDX_VOLUME, A>
 	static __device__ __forceinline__ void run(const A &a, uint32_t i, float, int)
 	{
 		PBDX_LOAD4;
-		if (solve_volume(p0, w0, p1, w1, p2, w2, p3, w3, a.p(0, i), a.p(1, i), c0, c1, c2, c3))
+		if (PBDX_LIKELY(solve_volume(p0, w0, p1, w1, p2, w2, p3, w3, a.p(0, i), a.p(1, i), c0, c1, c2, c3)))
 		{
 			PBDX_APPLY4;
 		}
@@ -336,7 +346,7 @@ template <class A> struct Project<PBDX_VOLUME_XPBD, A>
 	{
 		PBDX_LOAD4;
 		float lambda = first_iter ? 0.0f : a.lam_load(i);
-		if (solve_volume_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, a.p(0, i), a.p(1, i), dt, lambda, c0, c1, c2, c3))
+		if (PBDX_LIKELY(solve_volume_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, a.p(0, i), a.p(1, i), dt, lambda, c0, c1, c2, c3)))
 		{
 			PBDX_APPLY4;
 		}
@@ -352,7 +362,7 @@ template <class A> struct Project<PBDX_FEM_TET, A>
 		const float vol = a.p(0, i);
 		const M3 im = load_m3(a, 1, i);
 		const bool hi = fem_tet_handle_inversion(p0, p1, p2, p3, vol);
-		if (solve_fem_tet(p0, w0, p1, w1, p2, w2, p3, w3, vol, im, a.p(10, i), a.p(11, i), hi, c0, c1, c2, c3))
+		if (PBDX_LIKELY(solve_fem_tet(p0, w0, p1, w1, p2, w2, p3, w3, vol, im, a.p(10, i), a.p(11, i), hi, c0, c1, c2, c3)))
 		{
 			PBDX_APPLY4;
 		}
@@ -368,7 +378,7 @@ template <class A> struct Project<PBDX_FEM_TET_XPBD, A>
 		const M3 im = load_m3(a, 1, i);
 		const bool hi = fem_tet_handle_inversion(p0, p1, p2, p3, vol);
 		float lambda = first_iter ? 0.0f : a.lam_load(i);
-		if (solve_fem_tet_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, vol, im, a.p(10, i), a.p(11, i), hi, dt, lambda, c0, c1, c2, c3))
+		if (PBDX_LIKELY(solve_fem_tet_xpbd(p0, w0, p1, w1, p2, w2, p3, w3, vol, im, a.p(10, i), a.p(11, i), hi, dt, lambda, c0, c1, c2, c3)))
 		{
 			PBDX_APPLY4;
 		}
@@ -382,7 +392,7 @@ template <class A> struct Project<PBDX_STRAIN_TET, A>
 	{
 		PBDX_LOAD4;
 		const M3 im = load_m3(a, 0, i);
-		if (solve_strain_tet(p0, w0, p1, w1, p2, w2, p3, w3, im, a.p(9, i), a.p(10, i), a.p(11, i) != 0.0f, a.p(12, i) != 0.0f, c0, c1, c2, c3))
+		if (PBDX_LIKELY(solve_strain_tet(p0, w0, p1, w1, p2, w2, p3, w3, im, a.p(9, i), a.p(10, i), a.p(11, i) != 0.0f, a.p(12, i) != 0.0f, c0, c1, c2, c3)))
 		{
 			PBDX_APPLY4;
 		}
@@ -404,7 +414,7 @@ template <class A> struct Project<PBDX_SHAPE_MATCHING, A>
 			w[k] = a.p(16 + k, i);
 		}
 		const V3 restCm = mk(a.p(1, i), a.p(2, i), a.p(3, i));
-		if (solve_shape_matching4(x0, x, w, restCm, a.p(0, i), corr))
+		if (PBDX_LIKELY(solve_shape_matching4(x0, x, w, restCm, a.p(0, i), corr)))
 		{
 #pragma unroll
 			for (int k = 0; k < 4; k++)
