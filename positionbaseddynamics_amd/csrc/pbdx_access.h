@@ -250,6 +250,9 @@ template <class A> struct Project<PBDX_DISTANCE_XPBD, A>
 		ldp(a, id.x, p0, w0); ldp(a, id.y, p1, w1);
 		float lambda = first_iter ? 0.0f : a.lam_load(i);
 		V3 c0, c1;
+		// (tried in round 4, profiles/HISTORY.md [8]: a wave-uniform fast path -- ballot "no active lane takes one of the two degenerate exits", then
+		// straight-line arithmetic without the twelve v_mov and the exec-mask bookkeeping the per-lane selects cost: -0.9 % on the 1 M cloth, nothing
+		// elsewhere, and one crash of the test process that was not chased down; not kept)
 		if (PBDX_LIKELY(solve_distance_xpbd(p0, w0, p1, w1, a.p(0, i), a.p(1, i), dt, lambda, c0, c1)))
 		{
 			apply(a, id.x, p0, c0, w0); apply(a, id.y, p1, c1, w1);
