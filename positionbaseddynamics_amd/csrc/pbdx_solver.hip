@@ -174,7 +174,7 @@ struct ChunkS { uint32_t info, idx_boff, par_boff, lam_boff; };
 // SGPRs).  Until round 4 they were staged in LDS by the fill and read back as scalars (uniform address -> broadcast read -> four
 // v_readfirstlane): 8 VALU instructions per sub-iteration of a sweep that is VALU-issue-bound.  Measured (profiles/r04g_*): 1 M cloth 0.654 ->
 // 0.628 ms (-4 %), 100 k-tet bar 0.609 -> 0.595, configs[3] block 1.63 -> 1.58, 300x300 cloth -5 %; bit-identical.  PBDX_SMEM_CHUNKS = 0 builds
-// the LDS form for A/B runs.
+// the LDS form for A/B runs.  The kernels invalidate the scalar cache when they start (a plan that is rebuilt may reuse the addresses of the old one).
 #ifndef PBDX_SMEM_CHUNKS
 #define PBDX_SMEM_CHUNKS 1
 #endif
@@ -328,11 +328,6 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 #ifndef PBDX_STEP_PROBE
 #define PBDX_STEP_PROBE 0
 #endif
-// the descriptor of the chunk the NEXT record fetch reads is requested at the end of the current fetch, so that the scalar load's latency passes
-// during the projection in between (profiles/r04h_*: 1 M cloth -0.9 %, bar -1.3 %, configs[3] block -2.2 % on top of the scalar-cache descriptors)
-#ifndef PBDX_PIPELINE_FETCH_DESC
-#define PBDX_PIPELINE_FETCH_DESC 1
-#endif
 #ifndef PBDX_FETCH_BEFORE_BARRIER
 #define PBDX_FETCH_BEFORE_BARRIER 0
 #endif
@@ -364,22 +359,16 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 	uint32_t c_ld = c0, c_ex = c0;
 	// the ring lives in named records (not an array): keeps every record in registers
 	RecT r0, r1, r2, r3;
-#if PBDX_PIPELINE_FETCH_DESC
-	// the descriptor of the chunk the NEXT fetch reads is requested at the end of this one (scalar loads, PBDX_SMEM_CHUNKS): its latency
-	// passes during the projection in between instead of in front of the record loads
-	ChunkS ch_fetch = load_chunk(lchunks, c0);
-#endif
 	auto fetch = [&](RecT &dst)
 	{
 		// beyond the run the last chunk is fetched again (harmless): the fetch itself stays unconditional.  (Also for waves none of whose lanes
 		// has a slot in the chunk -- small scenes: 6 of 8 waves on the 100 k-tet bar.  Letting those skip the fetch was measured SLOWER, 0.638 ->
 		// 0.650 ms FEM, 0.745 -> 0.827 XPBD distance + volume, profiles/r03q_*: the compiler can no longer count the loads between a fetch and
 		// its use and waits for ALL outstanding loads, i.e. also for the records requested one step ago, and one step is about one memory latency.)
-#if PBDX_PIPELINE_FETCH_DESC
-		const ChunkS ch = ch_fetch;
-#else
+		// (requesting the NEXT fetch's descriptor at the end of this one, so that the scalar load's latency passes during the projection, measured
+		// -0.9 ... -2.2 % -- and made the heavy-type kernels fault in 7 of 12 runs of tests/test_examples.py, with or without a scalar-cache
+		// invalidation at kernel start, while this form never did: removed, profiles/HISTORY.md [8])
 		const ChunkS ch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
-#endif
 		const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, v_tail, a.views[TYPE] };
 		if constexpr (DICT)
 		{
@@ -392,9 +381,6 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 		else if constexpr (QUAD) load_rec_quad<TYPE, COMPACT>(acc, ql, lane_slot, dst);
 		else load_rec<TYPE, COMPACT>(acc, lane_slot, dst);
 		c_ld++;
-#if PBDX_PIPELINE_FETCH_DESC
-		ch_fetch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
-#endif
 	};
 	fetch(r0); fetch(r1);
 	if constexpr (D == 4) { fetch(r2); fetch(r3); }
@@ -727,6 +713,10 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(FusedArgs a)
 	extern __shared__ uint4 lds_raw[];
 	uint4 *lchunks = lds_raw;
 	float4 *lpos = reinterpret_cast<float4 *>(lds_raw + kMaxTileChunks);
+#if PBDX_SMEM_CHUNKS
+	// the chunk descriptors are read through the scalar cache: lines of an earlier plan that lived at the same addresses must not be served
+	__builtin_amdgcn_s_dcache_inv();
+#endif
 	const uint32_t tile_index = logical_block(a.seg.num_tiles, a.xcd_remap);
 	unsigned long long *trace = a.trace ? a.trace + (size_t)tile_index * kTraceStride : nullptr;
 	const RunArgs ra = { a.dt, a.first_iter, a.views };
@@ -783,6 +773,9 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 	uint4 *lchunks = lds_raw;
 	float4 *lpos = reinterpret_cast<float4 *>(lds_raw + kMaxTileChunks);
 	uint32_t sgi = 0;
+#if PBDX_SMEM_CHUNKS
+	__builtin_amdgcn_s_dcache_inv();      // (see fused_kernel)
+#endif
 	// Residency handshake, before anything is modified: every workgroup announces itself; the last one to arrive
 	// decides GO, a workgroup that has waited kArriveLimitTicks decides ABORT (one compare-and-swap settles it for
 	// everybody).  After GO all gridDim.x workgroups are running and stay until the end, so no later wait can
