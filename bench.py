@@ -450,6 +450,10 @@ def add_profiled_passes(r, w, opts, plan, persist):
         r["achieved_contract"], r["frac_contract"] = r["achieved"], r["frac"]
         r["achieved"], r["frac"] = r["traffic_GBs"], r["frac_traffic"]
         r["frac_kind"] = "traffic"
+        r["note"] = ("achieved / frac = counter-measured fabric bytes per launch (upper bound of HBM bytes: Infinity-Cache hits are counted) / device time / 8 TB/s, "
+                     "the physically bounded figure. achieved_contract / frac_contract = SURVEY 8d ALGORITHMIC bytes (every endpoint position read and written once per "
+                     "projection, 32-bit indices, no cache credit) / the same time: it exceeds 1 because the kernel keeps positions in LDS and streams 16-bit indices. "
+                     "compulsory_bytes = every distinct constraint record once per sweep + one particle-state pass; traffic_over_compulsory is the redundancy left to remove")
         r["frac_definition"] = "counter-measured HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated in-pass) / device time per launch / 8 TB/s; frac_contract = SURVEY 8d algorithmic bytes / same time / 8 TB/s"
     if r.get("frac_valu") is not None:
         fr = {"hbm traffic": r.get("frac_traffic") or 0.0, "valu issue": r["frac_valu"]}

@@ -73,6 +73,8 @@ int sort_pairs_u32(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint
 
 } // namespace pbdx
 
+namespace pbdx { uint64_t next_model_uid(); }
+
 struct pbdx_model
 {
 	// ParticleData (Simulation/ParticleData.h:91-100), packed xyz
@@ -83,6 +85,7 @@ struct pbdx_model
 	std::vector<pbdx::HostConstraint> constraints;
 	std::vector<std::vector<uint32_t>> groups;
 	bool groups_initialized = false;
+	const uint64_t uid = pbdx::next_model_uid();   // never reused (an address can be)
 	uint64_t topology_version = 0;   // bumped by every add*/cleanup: device image invalidation
 	uint64_t params_version = 0;     // bumped by set_constraint_params / set_mass
 	uint64_t state_version = 0;      // bumped when the host particle state (x, v, a, oldX, lastX) is written through the API

@@ -212,6 +212,8 @@ void store_colmajor(const M3 &A, float *out)
 
 } // namespace
 
+uint64_t pbdx::next_model_uid() { static std::atomic<uint64_t> n(1); return n.fetch_add(1); }
+
 extern "C" {
 
 int pbdx_model_create(pbdx_model **out)

@@ -31,6 +31,9 @@ struct pbdx_timestep
 	bool device_ahead = false;   // device state newer than the host model (resident stepping)
 	uint64_t state_seen = ~0ull; // model->state_version of the host state the device image was built from / synced to
 	uint32_t image_n = 0;        // particles in the device image
+	// what the host acceleration array was last filled for (clear_accelerations): while model, size, masses (params_version), host writes
+	// (state_version), topology and gravity are the same, the pass would store the values that are there -- 0.8 ms per call at 1 M particles
+	struct AccelKey { uint64_t m = 0; uint32_t n = 0; uint64_t state = 0, params = 0, topo = 0; float g[3] = { 0, 0, 0 }; } accel;
 };
 
 namespace {
@@ -159,6 +162,10 @@ int refresh_image(pbdx_timestep *ts, pbdx_model *m, bool force_particles)
 void clear_accelerations(pbdx_timestep *ts, pbdx_model *m)
 {
 	// TimeStep::clearAccelerations  TimeStep.cpp:28-62: static particles keep their (stale) value
+	pbdx_timestep::AccelKey &k = ts->accel;
+	if (k.m == m->uid && k.n == m->size() && k.state == m->state_version && k.params == m->params_version && k.topo == m->topology_version &&
+		memcmp(k.g, ts->gravity, sizeof(k.g)) == 0) return;
+	k.m = m->uid; k.n = m->size(); k.state = m->state_version; k.params = m->params_version; k.topo = m->topology_version; memcpy(k.g, ts->gravity, sizeof(k.g));
 	for (uint32_t i = 0; i < m->size(); i++)
 		if (m->mass[i] != 0.0f) { m->a[3 * i] = ts->gravity[0]; m->a[3 * i + 1] = ts->gravity[1]; m->a[3 * i + 2] = ts->gravity[2]; }
 }
