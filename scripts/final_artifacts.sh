@@ -42,4 +42,13 @@ python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "sm
 timeout 200 python scripts/trace_tiles.py --persistent 2 > $O/trace_cloth_persistent.log 2>&1
 timeout 200 python scripts/trace_tiles.py --bar 2 --persistent 2 > $O/trace_bar_fem_persistent.log 2>&1
 [ -f gpurun_variants/probe/libpbdx.so ] && PBDX_LIB=$PWD/gpurun_variants/probe/libpbdx.so timeout 300 python scripts/probe_steps.py --cloth 1000 > $O/step_probes_cloth.log 2>&1
-cat $O/box.txt; tail -16 $O/pytest_gpu.log; cat $O/persistent_kernel_dispatches.txt; tail -1 $O/bench_stdout.txt | cut -c1-700; tail -3 $O/smoke.log
+# 7. the plug-in's step() round trip at 1000x1000 through the unmodified reference model, and the headline command on other sheet sizes
+timeout 600 python -m pytest tests/test_plugin.py -m gpu -q -s -k full_size_c2 2>&1 | grep -E "round trip|passed|failed" > $O/plugin_round_trip.log
+: > $O/size_sweep.log
+for n in 100 200 300 500 750 1000 1500 2000; do
+	timeout 300 python bench.py --size $n --no-cpu-baseline --no-traffic --no-extras --no-roofline 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); c=d['config']
+print('cloth %4d x %-4d particles %8d constraints %9d: ms/substep %.4f (device median %.4f)  projections/s %.3e  %s' % ($n, $n, c['particles'], c['constraints'], d['ms_per_substep'], c.get('device_median_ms_per_substep') or d.get('device_median_ms_per_substep') or float('nan'), d['value'], 'ok' if c.get('state_ok') else 'STATE NOT OK'))" >> $O/size_sweep.log 2>&1
+done
+cat $O/box.txt; tail -16 $O/pytest_gpu.log 2>/dev/null; cat $O/plugin_round_trip.log $O/size_sweep.log; cat $O/persistent_kernel_dispatches.txt; tail -1 $O/bench_stdout.txt | cut -c1-700; tail -3 $O/smoke.log
