@@ -236,7 +236,7 @@ def run_workload(w, opts, ens, steps, warmup, with_roofline, with_traffic, with_
     # "hipEvents around the device-resident substep loop ..., >= 50 substeps, median": one event after every substep of
     # the timed call on the engine's stream (the graph replay is unchanged), so the median DEVICE time per substep of exactly the
     # timed steps is reported beside the host-clock mean that `value` is computed from
-    sol.set_option(S.OPT_SUBSTEP_EVENTS, 1)
+    sol.set_option(S.OPT_SUBSTEP_EVENTS, max(int(steps), 1))      # (n > 1: the events are created here, outside the timed region)
     barrier()
     t0 = time.perf_counter()
     ts.stepResident(model, steps)          # synchronises its own stream before returning

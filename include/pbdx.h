@@ -388,7 +388,8 @@ enum {
 	                                      * are given the impulse the reference gives contacts with pMax < 0 -- NOT the reference's result; default 0 */
 	PBDX_OPT_SUBSTEP_EVENTS = 17,        /* measurement (SURVEY 8d "hipEvents around the device-resident substep loop ... median"): 1 = pbdx_solver_step records one
 	                                      * HIP event after every substep on the engine's stream; pbdx_solver_get_substep_times returns the device time of
-	                                      * each substep of the last call.  Default 0 */
+	                                      * each substep of the last call.  n > 1: the same, and n events are created right away (the first
+	                                      * measured call then creates none).  Default 0 */
 };
 int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value);
 

@@ -1237,6 +1237,7 @@ struct pbdx_solver
 	int profile = 0;
 	int fuse = 2;                        // 0 per-colour, 1 fused, 2 auto (fused; measured choice when compute-heavy types are present)
 	int fuse_choice = 1;                 // outcome of the auto mode for the current schedule
+	int autotune_rounds = 0; float autotune_spent_ms = 0.0f;      // measured rounds after the warm-up round, and the device time they took
 	float autotune_ms[3] = { 0.0f, 0.0f, 0.0f }; // measured time of 12 sweeps: per-colour / fused / fused persistent (0 = not measured)
 	bool persist_choice = false;         // outcome of the measurement for the one-launch form
 	bool autotuned_for_tet = false;      // ... taken with / without deformable colliders installed (they select the per-iteration form): re-measured when that changes
@@ -2002,11 +2003,22 @@ int autotune_schedule(pbdx_solver *s)
 	const uint32_t sweeps = 12;
 	bool use[3] = { try_percolour, true, try_persistent };
 	s->d_pos[0] = scratch[0]; s->d_pos[1] = scratch[1];
-	// The candidates are measured in turns (round 0 = warm-up, then the minimum over two rounds): the clock of the
+	// The candidates are measured in turns (round 0 = warm-up, then the minimum over the following rounds): the clock of the
 	// first milliseconds after an idle period would otherwise favour whichever candidate runs first.  One measured
 	// run is long (12 sweeps), so that the fixed cost of an eager launch sequence (copies, memsets) does not decide
 	// between one launch and twenty-four.
-	for (int round = 0; round < 3 && !r; round++)
+	// How many rounds: the device comes out of the planning phase (0.04-0.4 s of host work) at a low clock and needs tens of milliseconds of
+	// work to reach the one it holds afterwards -- the substeps of the 1 M cloth take 0.669 ms right after two measured rounds, 0.644 twenty
+	// steps later, 0.622 from about the fiftieth on (profiles/r04l_*) -- and a 2 % decision taken on the ramp is taken on noise.  Rounds are
+	// repeated until the fastest run of a round stops improving on the previous round's (three rounds in a row within 0.2 %), within a budget of
+	// kAutotuneBudgetMs of measured time and kAutotuneMaxRounds rounds.
+	constexpr int kAutotuneMaxRounds = 64;
+	constexpr float kAutotuneBudgetMs = 80.0f;
+	float spent_ms = 0.0f, prev_round_best = 0.0f;
+	int settled = 0, rounds_done = 0;
+	for (int round = 0; round < kAutotuneMaxRounds && !r; round++)
+	{
+		float round_best = 0.0f;
 		for (int cand = 0; cand < 3 && !r; cand++)
 		{
 			if (!use[cand]) continue;
@@ -2023,6 +2035,7 @@ int autotune_schedule(pbdx_solver *s)
 			float t = 0.0f;
 			if (!r) (void)hipEventElapsedTime(&t, s->ev_start, s->ev_stop);
 			if (round > 0) ms[cand] = ms[cand] == 0.0f ? t : std::min(ms[cand], t);
+			if (round > 0 && t > 0.0f) { spent_ms += t; round_best = round_best == 0.0f ? t : std::min(round_best, t); }
 			if (cand == 2 && (s->h_error[0] || s->h_error[1]))
 			{
 				// refused or timed out on the scratch copy: not a candidate (nothing of the real state was touched)
@@ -2034,6 +2047,15 @@ int autotune_schedule(pbdx_solver *s)
 				ms[2] = 0.0f;
 			}
 		}
+		if (round > 0) rounds_done++;
+		if (round >= 2)
+		{
+			settled = (prev_round_best > 0.0f && round_best > 0.998f * prev_round_best) ? settled + 1 : 0;
+			if (settled >= 3 || spent_ms > kAutotuneBudgetMs) break;
+		}
+		if (round > 0) prev_round_best = round_best;
+	}
+	s->autotune_rounds = rounds_done; s->autotune_spent_ms = spent_ms;
 	s->d_pos[0] = keep[0]; s->d_pos[1] = keep[1];
 	(void)hipFree(scratch[0]); (void)hipFree(scratch[1]);
 	s->fuse_choice = 1;
@@ -2871,7 +2893,15 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 	case PBDX_OPT_TET_FORCE_IMPULSES:
 		s->tet_force_impulses = value ? 1 : 0; s->tet_work.force_impulses = s->tet_force_impulses; break;
 	case PBDX_OPT_SUBSTEP_EVENTS:
-		s->substep_events = value ? 1 : 0; return PBDX_OK;      // measurement only: the captured graph stays
+		// measurement only: the captured graph stays.  A value n > 1 also creates n events now, so that the first measured call does not
+		// pay for them (a few µs each: 0.1-0.2 ms of a 20-step call)
+		s->substep_events = value ? 1 : 0;
+		if (value > 1 && value <= 65536)
+		{
+			ENTER_DEVICE(s->device);
+			while (s->sub_events.size() < (size_t)value) { hipEvent_t e = nullptr; HIPCHECK(hipEventCreate(&e)); s->sub_events.push_back(e); }
+		}
+		return PBDX_OK;
 	case PBDX_OPT_PERSISTENT_TIMEOUT_MS:
 		if (value < 1 || value > 10000) { set_error("persistent timeout must be 1 .. 10000 ms"); return PBDX_ERR_INVALID; }
 		s->persist_timeout_ms = (uint32_t)value; break;
@@ -3665,13 +3695,14 @@ int pbdx_solver_describe(pbdx_solver *s, char *buf, size_t n)
 			if (s->persist_refusals && w2 > 0 && (size_t)(w + w2) < n)
 				w2 += snprintf(buf + w + w2, n - w - w2, " persistent_refusals=%u", s->persist_refusals);
 			if ((s->autotune_ms[1] > 0.0f || s->autotune_ms[2] > 0.0f) && w2 > 0 && (size_t)(w + w2) < n)
-				snprintf(buf + w + w2, n - w - w2, " autotune(per-colour %.3f ms, fused %.3f ms, persistent %.3f ms)", s->autotune_ms[0], s->autotune_ms[1], s->autotune_ms[2]);
+				snprintf(buf + w + w2, n - w - w2, " autotune(per-colour %.3f ms, fused %.3f ms, persistent %.3f ms; %d rounds, %.1f ms)", s->autotune_ms[0], s->autotune_ms[1], s->autotune_ms[2],
+					s->autotune_rounds, s->autotune_spent_ms);
 		}
 		else
 		{
 			int w2 = snprintf(buf + w, n - w, " schedule=per-colour%s%s", s->plan_built && !s->plan_ok ? " plan_failed=" : "", s->plan_built && !s->plan_ok ? s->plan_why.c_str() : "");
 			if (s->autotune_ms[1] > 0.0f && w2 > 0 && (size_t)(w + w2) < n)
-				snprintf(buf + w + w2, n - w - w2, " autotune(per-colour %.3f ms, fused %.3f ms)", s->autotune_ms[0], s->autotune_ms[1]);
+				snprintf(buf + w + w2, n - w - w2, " autotune(per-colour %.3f ms, fused %.3f ms; %d rounds, %.1f ms)", s->autotune_ms[0], s->autotune_ms[1], s->autotune_rounds, s->autotune_spent_ms);
 		}
 	}
 	return PBDX_OK;
