@@ -219,6 +219,40 @@ def test_full_state_and_second_order_velocity(pbd):
     assert np.allclose(a[1], [0, -9.81, 0]) and np.all(a[0] == 0)
 
 
+def test_host_accelerations_follow_gravity_masses_and_host_writes(pbd):
+    """TimeStep::clearAccelerations (TimeStep.cpp:28-62) on the host mirror: gravity for every dynamic particle, static ones keep what they
+    had.  The engine skips the pass while nothing it depends on has changed -- so change each of those things between resident calls."""
+    ops = util.cloth_spec(12, 12, 4, 3)
+    m, ts = util.mine_run(ops, 2, 1, 2, resident=True)
+    pd = m.getParticles()
+    a = pd.array(3)
+    assert np.allclose(a[1], [0, -9.81, 0]) and np.all(a[0] == 0)
+    # gravity changes
+    pbd.Simulation.getCurrent().setVecValueFloat(pbd.Simulation.GRAVITATION, [0.5, -3.0, 0.25])
+    ts.stepResident(m, 1); ts.syncToHost(m)
+    a = pd.array(3)
+    assert np.allclose(a[1], [0.5, -3.0, 0.25]) and np.all(a[0] == 0)
+    # the host writes the array: the next step puts gravity back for dynamic particles only
+    junk = np.full_like(a, 7.0)
+    pd.set_array(3, junk)
+    ts.stepResident(m, 1); ts.syncToHost(m)
+    a = pd.array(3)
+    assert np.allclose(a[1], [0.5, -3.0, 0.25]) and np.all(a[0] == 7.0)
+    # a particle becomes static: it keeps its value from now on, also across a change of gravity
+    pd.setMass(5, 0.0)
+    pbd.Simulation.getCurrent().setVecValueFloat(pbd.Simulation.GRAVITATION, [0.0, -1.0, 0.0])
+    ts.stepResident(m, 1); ts.syncToHost(m)
+    a = pd.array(3)
+    assert np.allclose(a[5], [0.5, -3.0, 0.25]) and np.allclose(a[1], [0, -1.0, 0])
+    # another model on the same time step object (possibly at the address of a freed one): filled from scratch
+    del m, pd
+    m2 = util.build_mine(util.cloth_spec(12, 12, 4, 3))
+    ts.stepResident(m2, 1); ts.syncToHost(m2)
+    a2 = m2.getParticles().array(3)
+    assert np.allclose(a2[1], [0, -1.0, 0]) and np.all(a2[0] == 0)
+    pbd.Simulation.getCurrent().setVecValueFloat(pbd.Simulation.GRAVITATION, [0, -9.81, 0])
+
+
 def test_resident_equals_roundtrip_and_options_are_invariant(pbd):
     """Device-resident stepping == upload/download every step; graph vs eager, XCD remap and
     workgroup size must not change a single bit (they only reorder independent work)."""
