@@ -1196,13 +1196,23 @@ void build_persistent_deps(const FusedPlan &plan, PersistentDeps &out)
 	}
 }
 
-bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, uint32_t passes, std::string &why, bool keep_owned)
+bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, uint32_t passes, std::string &why, bool keep_owned, uint32_t workgroups)
 {
+	// keep_owned with `workgroups` < num_tiles (0 = one workgroup per tile): workgroup w walks its tiles w, w + workgroups, ... in ascending order
+	// in even passes and in descending order in odd ones, so the LAST tile of a pass is the FIRST of the next: that tile keeps its owned particles
+	// in LDS across the boundary (stages only its halo; wrote back only its boundary particles), every other tile of the workgroup is staged and
+	// written back in full.  The workgroup's order is part of the model: a tile's fill is enabled only when its predecessor has been written back.
+	const uint32_t grid = (keep_owned && workgroups && workgroups < plan.num_tiles) ? workgroups : plan.num_tiles;
 	const size_t nseg = plan.segs.size();
 	const uint32_t k = plan.num_tiles, n = plan.num_particles;
 	if (!nseg || !k || deps.off.size() != nseg || deps.tile.size() != nseg) { why = "persistent deps: shape"; return false; }
 	for (size_t si = 0; si < nseg; si++)
 		if (deps.off[si].size() != (size_t)k + 1 || deps.off[si][k] != deps.tile[si].size()) { why = "persistent deps: CSR"; return false; }
+	// position of tile t in its workgroup's walk of pass p: tiles of workgroup w = t % grid are w + j grid, j = 0 .. m - 1
+	auto tiles_of = [&](uint32_t w) { return (k - w + grid - 1u) / grid; };
+	auto walk_pos = [&](uint32_t t, uint32_t p) { const uint32_t j = t / grid, m = tiles_of(t % grid); return (p & 1u) ? m - 1u - j : j; };
+	auto first_of_pass = [&](uint32_t t, uint32_t p) { return walk_pos(t, p) == 0u; };
+	auto last_of_pass = [&](uint32_t t, uint32_t p) { return walk_pos(t, p) + 1u == tiles_of(t % grid); };
 	// scheduler strategies: 0 most advanced tile first, 1 least advanced first, 2 pseudo-random, 3.. hold tile (strategy - 3) back
 	const uint32_t held_samples = std::min(k, 6u);
 	for (uint32_t strategy = 0; strategy < 3 + held_samples; strategy++)
@@ -1212,6 +1222,7 @@ bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, ui
 		std::vector<int32_t> ver[2] = { std::vector<int32_t>(n, -1), std::vector<int32_t>(n, -2) };
 		std::vector<uint32_t> done(k, 0);          // passes published
 		std::vector<uint8_t> filled(k, 0);         // FILL of pass done[t] has happened, WRITE-BACK has not
+		std::vector<uint32_t> in_lds(grid, 0xffffffffu);      // the tile whose owned particles a workgroup's LDS holds
 		uint64_t rng = 0x9e3779b97f4a7c15ull + strategy;
 		uint64_t remaining = (uint64_t)k * passes * 2;
 		while (remaining)
@@ -1229,6 +1240,16 @@ bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, ui
 					const uint32_t p = done[t], si = p % (uint32_t)nseg;
 					for (uint32_t d = deps.off[si][t]; d < deps.off[si][t + 1] && enabled; d++)
 						if (done[deps.tile[si][d]] < p) enabled = false;
+				}
+				if (enabled && !filled[t] && grid < k)
+				{
+					// the workgroup's walk: the tile before this one in the pass has been written back
+					const uint32_t p = done[t], pos = walk_pos(t, p);
+					if (pos > 0u)
+					{
+						const uint32_t m = tiles_of(t % grid), jprev = (p & 1u) ? m - pos : pos - 1u;     // the tile at walk position pos - 1
+						if (done[(t % grid) + jprev * grid] < p + 1u) enabled = false;
+					}
 				}
 				if (!enabled) continue;
 				if (t == held) { pick_held = t; continue; }
@@ -1251,7 +1272,16 @@ bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, ui
 				const std::vector<int32_t> &in = ver[p & 1u];
 				// keep_owned (one workgroup per tile): after its first pass a tile stages only what it does not hold already -- its halo and,
 				// for the LDS-DMA granularity, its last (n_owned mod 64) owned particles
-				for (uint32_t i = (keep_owned && p > 0) ? (ft.n_owned & ~63u) : 0u; i < ft.n_local; i++)
+				const bool stays = keep_owned && p > 0 && first_of_pass(t, p);
+				if (stays && in_lds[t % grid] != t)
+				{
+					char buf[200];
+					snprintf(buf, sizeof(buf), "persistent deps: tile %u pass %u expects its owned particles in LDS, the workgroup holds tile %u", t, p, in_lds[t % grid]);
+					why = buf;
+					return false;
+				}
+				in_lds[t % grid] = t;
+				for (uint32_t i = stays ? (ft.n_owned & ~63u) : 0u; i < ft.n_local; i++)
 				{
 					const uint32_t g = seg.gid[ft.gid_off + i];
 					if (in[g] != (int32_t)p - 1)
@@ -1269,7 +1299,7 @@ bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, ui
 			{
 				std::vector<int32_t> &outv = ver[(p + 1) & 1u];
 				// ... and a pass that is not the last one writes back only its boundary particles (FusedTile::wb_begin)
-				for (uint32_t i = (keep_owned && p + 1 < passes) ? ft.wb_begin : 0u; i < ft.n_owned; i++) outv[seg.gid[ft.gid_off + i]] = (int32_t)p;
+				for (uint32_t i = (keep_owned && p + 1 < passes && last_of_pass(t, p)) ? ft.wb_begin : 0u; i < ft.n_owned; i++) outv[seg.gid[ft.gid_off + i]] = (int32_t)p;
 				filled[t] = 0;
 				done[t] = p + 1;
 			}

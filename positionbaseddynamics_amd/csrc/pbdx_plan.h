@@ -291,7 +291,7 @@ void build_persistent_deps(const FusedPlan &plan, PersistentDeps &out);
 // one tile held back for as long as the lists allow, pseudo-random) subject only to the lists.  Every FILL must
 // find, for every particle it reads, the version written by pass p-1 (or the initial state for pass 0).
 // `passes` = iterations x segments to simulate.
-bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, uint32_t passes, std::string &why, bool keep_owned = false);
+bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, uint32_t passes, std::string &why, bool keep_owned = false, uint32_t workgroups = 0);
 
 } // namespace pbdx
 

@@ -328,6 +328,10 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 #ifndef PBDX_STEP_PROBE
 #define PBDX_STEP_PROBE 0
 #endif
+// workgroups with several tiles walk them in alternating order and keep the tile at the turn in LDS (persistent_kernel); 0 = A/B switch
+#ifndef PBDX_WALK_TILES
+#define PBDX_WALK_TILES 1
+#endif
 #ifndef PBDX_FETCH_BEFORE_BARRIER
 #define PBDX_FETCH_BEFORE_BARRIER 0
 #endif
@@ -815,8 +819,16 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 		const RunArgs ra = { a.dt, pass < a.first_iter_passes ? 1 : 0, a.views };
 		const float4 *pos_in = a.pos[(a.start + pass) & 1u];
 		float4 *pos_out = a.pos[(a.start + pass + 1u) & 1u];
-		for (uint32_t tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x)
+		// This workgroup's tiles: blockIdx.x + j gridDim.x, j = 0 .. m - 1, walked forwards in even passes and backwards in odd ones, so that the
+		// LAST tile of a pass is the FIRST of the next.  That tile's owned particles are still in LDS when its next pass starts: it stages only
+		// its halo then, and it wrote back only its boundary particles; the other tiles of the workgroup are staged and written back in full.
+		// One tile per workgroup (m = 1) is the case where every pass is both: the owned particles never leave LDS.  (Asynchronous-execution
+		// model of exactly this walk: check_persistent_deps(..., keep_owned, workgroups), pbdx_plan.cpp.)
+		const uint32_t m = (a.num_tiles - blockIdx.x + gridDim.x - 1u) / gridDim.x;
+		for (uint32_t k = 0; k < m; k++)
 		{
+			const uint32_t tile = blockIdx.x + ((pass & 1u) ? m - 1u - k : k) * gridDim.x;
+			const bool first_of_pass = k == 0u, last_of_pass = k + 1u == m;
 			// the wait for the neighbouring tiles, run by the fill once its particle ids are in flight: one wave polls
 			// the tile's dependencies, one lane each (lists are short: the adjacent tiles)
 			auto wait = [&]()
@@ -839,11 +851,10 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 				__syncthreads();
 			};
 			unsigned long long *trace = (a.trace[sgi] && pass + a.num_segs >= a.passes) ? a.trace[sgi] + (size_t)tile * kTraceStride : nullptr;
-			// one tile per workgroup: its owned particles stay in LDS from pass to pass
 			const uint32_t fold_phase = a.folded ? ((pass == 0 ? 1u : 0u) | (pass + 1u == a.passes ? 2u : 0u)) : 0u;
-			const bool resident = gridDim.x == a.num_tiles;
-			process_tile<MASK, BLOCK, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && resident, wait, &a.fold, fold_phase,
-				resident && pass + 1u != a.passes && !PBDX_FULL_WRITE_BACK);
+			const bool keeps = PBDX_WALK_TILES || m == 1u;      // (PBDX_WALK_TILES = 0: only one-tile workgroups keep their particles, the form before round 4)
+			process_tile<MASK, BLOCK, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && first_of_pass && keeps, wait, &a.fold, fold_phase,
+				last_of_pass && keeps && pass + 1u != a.passes && !PBDX_FULL_WRITE_BACK);
 			if (s_failed)
 			{
 				// a neighbour never arrived: the state of this step is garbage.  Say so, turn every later kernel of the call

@@ -250,6 +250,14 @@ int pbdx_model_plan_check(pbdx_model *m, uint32_t tile_particles, uint32_t lds_p
 			if (!accepted) caught = true;
 		}
 		if (tried && !caught && plan.num_tiles > 1) { set_error("plan check: tiles that write back none of their boundary particles went unnoticed (%u tried)", tried); return PBDX_ERR_INVALID; }
+		// fewer workgroups than tiles (scenes that do not fit the LDS of the whole device at once): a workgroup walks its tiles forwards in even
+		// passes and backwards in odd ones, the tile at the turn keeps its owned particles in LDS -- two and three tiles per workgroup.  (No
+		// check of the check here: the walk itself orders tiles, so a removed list entry can be implied by it and rightly go unnoticed.)
+		for (uint32_t per_wg = 2; per_wg <= 3 && plan.num_tiles >= per_wg; per_wg++)
+		{
+			const uint32_t wgs = (plan.num_tiles + per_wg - 1u) / per_wg;
+			if (!check_persistent_deps(plan, deps, passes, why, true, wgs)) { set_error("plan check (%u tiles per workgroup, walked in alternating order): %s", per_wg, why.c_str()); return PBDX_ERR_INVALID; }
+		}
 	}
 	if (out)
 	{
