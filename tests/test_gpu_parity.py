@@ -777,6 +777,10 @@ def test_persistent_schedule_is_bit_identical_and_recovers_from_a_refused_launch
               ("kitchen sink", util.kitchen_sink_spec(), 4, 2, 4, {}),
               ("fem bar", util.bar_spec(30, 6, 6, 2), 4, 1, 5, {}),
               ("xpbd cloth 120x120, 60-particle tiles (more tiles than CUs)", util.cloth_spec(120, 120, 4, 3), 3, 1, 4, {"opts": {S.OPT_TILE_PARTICLES: 48}}),
+              # three to four tiles per workgroup, walked forwards and backwards in turn (the tile at the turn stays in LDS), with an odd and an even
+              # number of passes per substep
+              ("xpbd cloth 120x120, 16-particle tiles (3-4 tiles per workgroup), 4 iterations", util.cloth_spec(120, 120, 4, 3), 3, 1, 4, {"opts": {S.OPT_TILE_PARTICLES: 16}}),
+              ("xpbd cloth 120x120, 16-particle tiles (3-4 tiles per workgroup), 5 iterations", util.cloth_spec(120, 120, 4, 3), 2, 2, 5, {"opts": {S.OPT_TILE_PARTICLES: 16, S.OPT_MAX_SEGMENT_COLOURS: 9}}),
               # two tiles resident per CU: every tile still has a workgroup of its own, so owned particles stay in LDS and the passes between the
               # first and the last write back only their boundary particles (FusedTile::wb_begin) -- as in the default one-tile-per-CU scenes above
               ("xpbd cloth 120x120, 40-particle tiles, two resident per CU", util.cloth_spec(120, 120, 4, 3), 3, 1, 4, {"opts": {S.OPT_TILE_PARTICLES: 40, S.OPT_PERSISTENT_WGS_PER_CU: 2}})]
