@@ -1202,6 +1202,10 @@ bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, ui
 	// in even passes and in descending order in odd ones, so the LAST tile of a pass is the FIRST of the next: that tile keeps its owned particles
 	// in LDS across the boundary (stages only its halo; wrote back only its boundary particles), every other tile of the workgroup is staged and
 	// written back in full.  The workgroup's order is part of the model: a tile's fill is enabled only when its predecessor has been written back.
+	// (bit 31 of `workgroups`: self-test of this check -- the WRONG rule, boundary-only write-back for the FIRST tile of a pass instead of the last,
+	// which leaves the interior of an evicted tile in no buffer; must be rejected wherever an evicted tile has an interior)
+	const bool wrong_turn = (workgroups & 0x80000000u) != 0;
+	workgroups &= 0x7fffffffu;
 	const uint32_t grid = (keep_owned && workgroups && workgroups < plan.num_tiles) ? workgroups : plan.num_tiles;
 	const size_t nseg = plan.segs.size();
 	const uint32_t k = plan.num_tiles, n = plan.num_particles;
@@ -1299,7 +1303,7 @@ bool check_persistent_deps(const FusedPlan &plan, const PersistentDeps &deps, ui
 			{
 				std::vector<int32_t> &outv = ver[(p + 1) & 1u];
 				// ... and a pass that is not the last one writes back only its boundary particles (FusedTile::wb_begin)
-				for (uint32_t i = (keep_owned && p + 1 < passes && last_of_pass(t, p)) ? ft.wb_begin : 0u; i < ft.n_owned; i++) outv[seg.gid[ft.gid_off + i]] = (int32_t)p;
+				for (uint32_t i = (keep_owned && p + 1 < passes && (wrong_turn ? first_of_pass(t, p) : last_of_pass(t, p))) ? ft.wb_begin : 0u; i < ft.n_owned; i++) outv[seg.gid[ft.gid_off + i]] = (int32_t)p;
 				filled[t] = 0;
 				done[t] = p + 1;
 			}

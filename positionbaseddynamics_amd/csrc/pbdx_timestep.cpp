@@ -257,6 +257,17 @@ int pbdx_model_plan_check(pbdx_model *m, uint32_t tile_particles, uint32_t lds_p
 		{
 			const uint32_t wgs = (plan.num_tiles + per_wg - 1u) / per_wg;
 			if (!check_persistent_deps(plan, deps, passes, why, true, wgs)) { set_error("plan check (%u tiles per workgroup, walked in alternating order): %s", per_wg, why.c_str()); return PBDX_ERR_INVALID; }
+			// the check of this check: with the turn at the wrong end (boundary-only write-back for the FIRST tile of a pass) the interior of
+			// an evicted tile reaches no buffer -- to be caught wherever a tile at either end of a workgroup's walk has an interior
+			bool has_interior = false;
+			for (uint32_t t = 0; t < plan.num_tiles && !has_interior; t++)
+			{
+				// (only the tiles at the two ends of a workgroup's walk are ever first in a pass)
+				const uint32_t m = (plan.num_tiles - (t % wgs) + wgs - 1u) / wgs, j = t / wgs;
+				has_interior = plan.segs[0].tiles[t].wb_begin > 0 && m >= 2u && (j == 0u || j + 1u == m);
+			}
+			if (has_interior && check_persistent_deps(plan, deps, passes, why, true, wgs | 0x80000000u))
+			{ set_error("plan check (%u tiles per workgroup): a walk that keeps the wrong tile went unnoticed", per_wg); return PBDX_ERR_INVALID; }
 		}
 	}
 	if (out)
