@@ -47,6 +47,18 @@ int pbdx_debug_relayout_params(int type, int compact, uint32_t slots, int from_v
 /* ... and the index function itself: float index of (plane, slot) relative to the step's first float. */
 uint64_t pbdx_debug_param_float_index(int vector_params, uint32_t planes, uint32_t plane, uint32_t slot);
 
+/* Developer aid (host only, no GPU): the colour-fused plan the engine builds for `m` on a 256-CU device, with (bank_aware != 0) or without the bank-aware
+ * order of the slots inside every colour step, evaluated under the LDS bank model of csrc/pbdx_plan.h (lds_bank_model) and, if `check`, executed
+ * symbolically against the colour-sequential sweep.  out[0..5] = 16-lane read groups of the endpoint gathers (= their cycles if conflict-free), modelled
+ * read cycles, 8-lane write groups, modelled write cycles, groups and cycles of the dictionary-record reads -- all per sweep; out[6] = slots per sweep,
+ * out[7] = plan build time (microseconds). */
+int pbdx_debug_plan_lds_model(pbdx_model *m, int bank_aware, int check, uint64_t out[8]);
+
+/* Sanitizer-grade debug build (libpbdx built with -DPBDX_BOUNDS=1, scripts/build_variant.sh): every raw address of the fused / persistent sweep is
+ * range-checked before the access (csrc/pbdx_bounds.h).  out[0] = violations since the last reset, out[1..6] = the first one (kind, workgroup, thread,
+ * index, limit, tile), out[7] = 1 if the loaded library is such a build (the product build checks nothing and reports zeros). */
+int pbdx_debug_bounds_report(int device, uint32_t out[8], int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,18 @@ def device_count():
     return lib.pbdx_device_count()
 
 
+def bounds_report(device=0, reset=False):
+    """Record of the range checks of a sanitizer-grade debug build (csrc/pbdx_bounds.h; PBDX_LIB=.../libpbdx_bounds.so).  Returns a dict:
+    `checked` (is the loaded library such a build), `violations` since the last reset, and the first one (kind, workgroup, thread, index,
+    limit, tile).  The product build checks nothing and reports checked = False."""
+    out = (C.c_uint32 * 8)()
+    check(lib.pbdx_debug_bounds_report(int(device), out, 1 if reset else 0), "pbdx_debug_bounds_report")
+    kinds = {1: "gid stream", 2: "particle id", 3: "LDS fill slot", 4: "chunk descriptor", 5: "dictionary table", 6: "LDS gather/scatter slot",
+             7: "tile index", 8: "dependency list", 9: "table source", 10: "chunk range"}
+    return {"checked": bool(out[7]), "violations": int(out[0]), "kind": kinds.get(int(out[1]), int(out[1])), "workgroup": int(out[2]), "thread": int(out[3]),
+            "index": int(out[4]), "limit": int(out[5]), "tile": int(out[6])}
+
+
 def colour_constraints(num_bodies, body_off, bodies, device=0):
     """pbdx_colour_constraints: the reference's greedy colouring (SimulationModel.cpp:1033-1094) on the device, on raw arrays.
     Returns (group_of, num_groups, rounds)."""

@@ -121,6 +121,8 @@ SIGNATURES = [
     ("pbdx_solver_set_contact_params", C.c_int, vp, f32, f32, u32),
     ("pbdx_solver_get_num_contacts", C.c_int, vp, C.POINTER(u32)),
     ("pbdx_debug_stream", C.c_int, C.c_int, C.c_uint64, C.c_int),
+    ("pbdx_debug_bounds_report", C.c_int, C.c_int, C.POINTER(u32), C.c_int),
+    ("pbdx_debug_plan_lds_model", C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_uint64)),
     ("pbdx_debug_relayout_params", C.c_int, C.c_int, C.c_int, u32, C.c_int, pf, C.POINTER(u32)),
     ("pbdx_debug_param_float_index", C.c_uint64, C.c_int, u32, u32, u32),
     ("pbdx_solver_get_particles_hashed", C.c_int, vp, u32, pf, pf, pf, pf, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)),

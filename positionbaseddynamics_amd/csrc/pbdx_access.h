@@ -12,6 +12,10 @@
 #include <hip/hip_runtime.h>
 #include "pbdx_plan.h"
 #include "pbdx_project.h"
+#include "pbdx_bounds.h"
+#ifndef PBDX_ST96
+#define PBDX_ST96 0
+#endif
 
 namespace pbdx {
 
@@ -65,6 +69,9 @@ template <int TYPE, bool COMPACT> struct GlobalAccess
 struct TileStreams
 {
 	__amdgpu_buffer_rsrc_t idx, par, lam;
+#if PBDX_BOUNDS
+	uint32_t dbg_n_local, dbg_tab_f4, dbg_tile;      // LDS slots of the tile's particles, size of its dictionary table, tile index (range checks of the debug build)
+#endif
 };
 
 // COHERENT (persistent schedule): the multiplier stream is re-read by the same workgroup one iteration later
@@ -101,8 +108,23 @@ template <int TYPE, bool COMPACT, bool COHERENT = false, bool VEC = false> struc
 		const uint2 v = idx_raw2(i);
 		return make_uint4(v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16);
 	}
+#if PBDX_BOUNDS
+	__device__ __forceinline__ float4 ld(uint32_t h) const { return pos[PBDX_BCLAMP(kBndLdsSlot, h, str.dbg_n_local, str.dbg_tile)]; }
+	__device__ __forceinline__ void st(uint32_t h, float4 v) const { if (PBDX_BOK(kBndLdsSlot, h, str.dbg_n_local, str.dbg_tile)) pos[h] = v; }
+#else
 	__device__ __forceinline__ float4 ld(uint32_t h) const { return pos[h]; }
+#if PBDX_ST96
+	// (A/B build: the inverse mass of a slot never changes -- a 12-byte store moves one dword less from the SIMD to the LDS, MI355X_MICROARCH.md LDS table)
+	__device__ __forceinline__ void st(uint32_t h, float4 v) const
+	{
+		typedef float f3 __attribute__((ext_vector_type(3)));      // (16-byte aligned, 12 bytes stored: ds_write_b96)
+		f3 w; w.x = v.x; w.y = v.y; w.z = v.z;
+		*reinterpret_cast<f3 *>(pos + h) = w;
+	}
+#else
 	__device__ __forceinline__ void st(uint32_t h, float4 v) const { pos[h] = v; }
+#endif
+#endif
 	__device__ __forceinline__ float p(int k, uint32_t) const
 	{
 		if (is_scalar_param(TYPE, COMPACT, k)) return view.u[k];

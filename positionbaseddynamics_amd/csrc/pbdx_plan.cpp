@@ -36,9 +36,142 @@ struct Graph
 	}
 };
 
+// ---- bank-aware slot order of one step (pbdx_plan.h, LDS bank model) ---------------------------------------
+// `cnt` independent constraints with `nb` endpoints each (h[c * nb + j] = tile-local slot of endpoint j) and optionally a table-record key per
+// constraint (tkey: records with different keys that fall into the same class tcls conflict; 0xffffffff = none).  Returns in `order` a permutation of
+// 0 .. cnt-1: lane l of the step's l / 64-th wave-pass projects constraint order[l].  Greedy: lanes are filled in turn, every lane takes the first of the
+// next kWindow unassigned constraints (original order) whose endpoints collide with nothing its read group (16 lanes, banks = slot mod 16) and its write
+// group (8 lanes, slot mod 8) already hold, or the one with the fewest collisions.  Never affects results (a colour's constraints are independent).
+// Bank-aware NUMBERING of a run of LDS slots: `ids` (ascending particle ids) are to occupy slots start, start + 1, ...; they are permuted so that as
+// many slots as possible satisfy slot mod 16 == id mod 16.  The bank class of a particle then follows its id across the regions of a tile (interior,
+// boundary, halo), so that on a mesh with regular ids (grids: neighbours at constant id offsets) the endpoints of every constraint of one shape sit at
+// constant CLASS offsets everywhere in the tile -- which is what lets BankOrder below form conflict-free groups.  Ids of a run that is contiguous stay in
+// ascending order (a rotation by less than 16 at most): the fill's HBM reads remain as coalesced as before.  Any numbering is valid; never affects results.
+inline void class_order(uint32_t *ids, uint32_t count, uint32_t start, std::vector<uint32_t> &tmp)
+{
+	if (count < 2) return;
+	uint32_t n[16] = {}, head[16], off[17];
+	for (uint32_t i = 0; i < count; i++) n[ids[i] & 15u]++;
+	off[0] = 0;
+	for (uint32_t q = 0; q < 16; q++) { off[q + 1] = off[q] + n[q]; head[q] = off[q]; }
+	tmp.resize(count);
+	{
+		uint32_t fill[16];
+		for (uint32_t q = 0; q < 16; q++) fill[q] = off[q];
+		for (uint32_t i = 0; i < count; i++) tmp[fill[ids[i] & 15u]++] = ids[i];      // (stable: ascending inside a class)
+	}
+	for (uint32_t sl = 0; sl < count; sl++)
+	{
+		uint32_t q = (start + sl) & 15u;
+		if (head[q] == off[q + 1])
+		{
+			// the wanted class has run out: the class with most particles left gives one up
+			uint32_t best = 0, left = 0;
+			for (uint32_t k = 0; k < 16; k++) if (off[k + 1] - head[k] > left) { left = off[k + 1] - head[k]; best = k; }
+			q = best;
+		}
+		ids[sl] = tmp[head[q]++];
+	}
+}
+
+struct BankOrder
+{
+	// Unassigned constraints by SHAPE (the bank classes of the other endpoints relative to the first: constraints of one shape whose first endpoints
+	// fall into different classes collide in no endpoint) and by the class of the first endpoint; original order inside a queue.
+	struct Shape { uint32_t sig, count, left; std::vector<uint32_t> q[16]; uint32_t head[16]; };
+	std::vector<Shape> shapes;
+	std::vector<uint32_t> sig_of, rank;
+	void run(uint32_t cnt, uint32_t nb, const uint32_t *h, const uint32_t *tkey, const uint32_t *tcls, std::vector<uint32_t> &order)
+	{
+		order.resize(cnt);
+		// shapes, most frequent first
+		sig_of.resize(cnt);
+		for (uint32_t i = 0; i < cnt; i++)
+		{
+			uint32_t sg = 0;
+			for (uint32_t j = 1; j < nb; j++) sg = sg * 16u + ((h[(size_t)i * nb + j] - h[(size_t)i * nb]) & 15u);
+			sig_of[i] = sg;
+		}
+		rank.assign(sig_of.begin(), sig_of.end());
+		std::sort(rank.begin(), rank.end());
+		size_t used = 0;
+		for (size_t i = 0; i < rank.size();)
+		{
+			size_t e = i;
+			while (e < rank.size() && rank[e] == rank[i]) e++;
+			if (used == shapes.size()) shapes.emplace_back();
+			Shape &sh = shapes[used++];
+			sh.sig = rank[i]; sh.count = sh.left = (uint32_t)(e - i);
+			for (uint32_t q = 0; q < 16; q++) { sh.q[q].clear(); sh.head[q] = 0; }
+			i = e;
+		}
+		std::sort(shapes.begin(), shapes.begin() + used, [](const Shape &x, const Shape &y) { return x.count != y.count ? x.count > y.count : x.sig < y.sig; });
+		// (signature -> shape: binary search over a sorted copy would do; the shape count is small, a linear map by signature is built instead)
+		rank.assign(65536u >> (nb == 2 ? 12 : nb == 3 ? 8 : 4), 0xffffffffu);
+		for (size_t k = 0; k < used; k++) rank[shapes[k].sig] = (uint32_t)k;
+		for (uint32_t i = 0; i < cnt; i++) shapes[rank[sig_of[i]]].q[h[(size_t)i * nb] & 15u].push_back(i);
+		uint16_t rmask[4][4]; uint8_t wmask[8][4];
+		uint32_t tk[4][16];                // per read group and class: the record key that holds it (0xffffffff = free)
+		auto cost_of = [&](uint32_t c, uint32_t rg, uint32_t wg)
+		{
+			uint32_t cost = 0;
+			for (uint32_t j = 0; j < nb; j++)
+			{
+				const uint32_t hh = h[(size_t)c * nb + j];
+				cost += (rmask[rg][j] >> (hh & 15u)) & 1u;
+				cost += (wmask[wg][j] >> (hh & 7u)) & 1u;
+			}
+			if (tkey && tkey[c] != 0xffffffffu) { const uint32_t o = tk[rg][tcls[c] & 15u]; cost += (o != 0xffffffffu && o != tkey[c]) ? 1u : 0u; }
+			return cost;
+		};
+		size_t cur = 0;                    // first shape with constraints left
+		for (uint32_t l = 0; l < cnt; l++)
+		{
+			const uint32_t lane = l & 63u;
+			if (lane == 0u) { memset(rmask, 0, sizeof(rmask)); memset(wmask, 0, sizeof(wmask)); memset(tk, 0xff, sizeof(tk)); }
+			const uint32_t rg = lds_read_group(lane), wg = lds_write_group(lane);
+			while (cur < used && !shapes[cur].left) cur++;
+			// candidates: shape by shape from the current one; inside a shape the class lane mod 16 first (lanes of a group then differ by construction)
+			size_t bs = 0; uint32_t bq = 0, bk = 0, best_cost = 0xffffffffu, evaluated = 0;
+			for (size_t si = cur; si < used && best_cost && evaluated < kBudget; si++)
+			{
+				Shape &sh = shapes[si];
+				if (!sh.left) continue;
+				for (uint32_t dq = 0; dq < 16 && best_cost; dq++)
+				{
+					const uint32_t q = (lane + dq) & 15u;
+					const uint32_t avail = (uint32_t)sh.q[q].size() - sh.head[q];
+					const uint32_t look = std::min<uint32_t>(avail, dq == 0 ? 2u : 1u);
+					for (uint32_t k = 0; k < look; k++)
+					{
+						const uint32_t cst = cost_of(sh.q[q][sh.head[q] + k], rg, wg);
+						evaluated++;
+						if (cst < best_cost) { best_cost = cst; bs = si; bq = q; bk = k; if (!cst) break; }
+					}
+				}
+			}
+			Shape &sh = shapes[bs];
+			std::vector<uint32_t> &qq = sh.q[bq];
+			const uint32_t c = qq[sh.head[bq] + bk];
+			for (uint32_t k = bk; k > 0; k--) qq[sh.head[bq] + k] = qq[sh.head[bq] + k - 1];      // (keeps the queue in original order)
+			sh.head[bq]++; sh.left--;
+			order[l] = c;
+			for (uint32_t j = 0; j < nb; j++)
+			{
+				const uint32_t hh = h[(size_t)c * nb + j];
+				rmask[rg][j] |= (uint16_t)(1u << (hh & 15u));
+				wmask[wg][j] |= (uint8_t)(1u << (hh & 7u));
+			}
+			if (tkey && tkey[c] != 0xffffffffu && tk[rg][tcls[c] & 15u] == 0xffffffffu) tk[rg][tcls[c] & 15u] = tkey[c];
+		}
+	}
+	static constexpr uint32_t kBudget = 96;
+};
+
 struct Scratch
 {
 	std::vector<uint32_t> stamp_p, stamp_c, local_of;
+	BankOrder bank; std::vector<uint32_t> bank_h, bank_key, bank_cls, bank_order;      // bank-aware slot order of the step being emitted
 	uint32_t serial = 0;
 	std::vector<std::vector<uint32_t>> bucket;
 	std::vector<uint32_t> halo;
@@ -287,6 +420,7 @@ bool build_tile_dictionary(const FusedStep *steps, size_t nsteps, const TypeView
 }
 // floats a dictionary-form step occupies in the parameter stream: one uint16 per slot, whole 256-byte units
 inline uint32_t dict_step_floats(uint32_t count) { return round_up((count + 1u) / 2u, 64u); }
+
 
 // developer aid (PBDX_PLAN_VERBOSE): how much of the dictionary-eligible work took the form
 void print_dictionary_coverage(const FusedPlan &plan)
@@ -598,6 +732,13 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 			uint32_t *first = perm.data() + tile_begin[t], *last = perm.data() + tile_begin[t + 1];
 			uint32_t *mid = std::stable_partition(first, last, [&](uint32_t p) { return boundary[p] == 0; });      // both parts stay sorted by id
 			const uint32_t n_owned = (uint32_t)(last - first);
+			if (opt.bank_aware && getenv("PBDX_PLAN_CLASS_ORDER"))
+			{
+				// (developer experiment: numbered so that a slot's bank class follows the particle id, class_order)
+				std::vector<uint32_t> tmp;
+				class_order(first, (uint32_t)(mid - first), 0u, tmp);
+				class_order(mid, (uint32_t)(last - mid), (uint32_t)(mid - first), tmp);
+			}
 			// the persistent fill re-reads the owned particles from index (n_owned & ~63) on (LDS-DMA granularity): they count as boundary
 			wb_begin[t] = std::min((uint32_t)(mid - first), n_owned & ~63u);
 		}
@@ -620,6 +761,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 			o.n_owned = tile_begin[t + 1] - tile_begin[t];
 			closure(g, s, owned, o.n_owned, c0, c1, [](uint32_t) {});
 			std::sort(s.halo.begin(), s.halo.end());
+			if (opt.bank_aware && getenv("PBDX_PLAN_CLASS_ORDER")) class_order(s.halo.data(), (uint32_t)s.halo.size(), o.n_owned, s.bank_order);
 			const uint32_t n_local = o.n_owned + (uint32_t)s.halo.size();
 			uint32_t w = worst.load();
 			while (n_local > w && !worst.compare_exchange_weak(w, n_local)) {}
@@ -692,9 +834,37 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 					else
 						o.params.resize(o.params.size() + (size_t)groups64 * np_stream * 64, 0.0f);
 					uint32_t rec[PBDX_MAX_PARAMS];
+					// bank-aware order of the step's slots (pbdx_plan.h lds_bank_model): which lane projects which constraint
+					const bool reorder = opt.bank_aware && st.count > 1u && !is_quad_type(pb.type) && pb.type != 11 /* strain tets: steps may run in quad form */;
+					if (reorder)
+					{
+						const uint32_t nb = ti->num_bodies;
+						s.bank_h.resize((size_t)st.count * nb);
+						for (size_t q = a; q < e; q++)
+						{
+							const uint32_t i = bk[q] - g.batch_base[b];
+							for (uint32_t j = 0; j < nb; j++) s.bank_h[(q - a) * nb + j] = s.local_of[pb.idx[(size_t)i * nb + j]];
+						}
+						const uint32_t *tkey = nullptr, *tcls = nullptr;
+						if (candidate)
+						{
+							// the record of every slot first: lanes of a read group that fetch DIFFERENT records from the same bank class conflict
+							s.bank_key.resize(st.count); s.bank_cls.resize(st.count);
+							const uint32_t ef4 = dict_entry_f4(np_stream);
+							for (size_t q = a; q < e; q++)
+							{
+								const float *src = pb.params + (size_t)(bk[q] - g.batch_base[b]) * ti->param_stride;
+								for (uint32_t p = 0; p < ti->param_stride; p++) if (plane_of[p] >= 0) memcpy(&rec[plane_of[p]], &src[p], 4);
+								const uint32_t en = o.tables[pb.type]->find_or_add(rec);
+								s.bank_key[q - a] = en; s.bank_cls[q - a] = en * ef4;
+							}
+							tkey = s.bank_key.data(); tcls = s.bank_cls.data();
+						}
+						s.bank.run(st.count, nb, s.bank_h.data(), tkey, tcls, s.bank_order);
+					}
 					for (size_t q = a; q < e; q++)
 					{
-						const uint32_t cid = bk[q];
+						const uint32_t cid = reorder ? bk[a + s.bank_order[q - a]] : bk[q];
 						const uint32_t i = cid - g.batch_base[b];
 						const uint32_t slot = (uint32_t)(q - a);
 						for (uint32_t j = 0; j < ti->num_bodies; j++)
@@ -1155,6 +1325,81 @@ bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const st
 	return true;
 }
 
+
+// LDS bank model of a plan (pbdx_plan.h): cycles the endpoint gathers / scatters and the dictionary reads of ONE sweep take on the LDS array
+void lds_bank_model(const FusedPlan &plan, uint32_t block, LdsBankModel &out)
+{
+	out = LdsBankModel();
+	uint64_t lb_read[PBDX_NUM_CONSTRAINT_TYPES] = {}, lb_write[PBDX_NUM_CONSTRAINT_TYPES] = {}, cyc_read[PBDX_NUM_CONSTRAINT_TYPES] = {}, cyc_write[PBDX_NUM_CONSTRAINT_TYPES] = {},
+		grp_read[PBDX_NUM_CONSTRAINT_TYPES] = {}, grp_write[PBDX_NUM_CONSTRAINT_TYPES] = {};
+	const bool verbose = getenv("PBDX_PLAN_VERBOSE") != nullptr;
+	(void)block;      // (a chunk is a multiple of 64 slots: the wave a slot runs in, slot / 64, and its lane, slot % 64, do not depend on the workgroup size)
+	for (const FusedSegment &seg : plan.segs)
+		for (const FusedTile &t : seg.tiles)
+			for (uint32_t si = t.step_begin; si < t.step_end; si++)
+			{
+				const FusedStep &st = seg.steps[si];
+				const TypeInfo *ti = type_info((int)st.type);
+				if (is_quad_type((int)st.type) || st.type == 11u) continue;
+				const uint32_t nb = ti->num_bodies, iw = nb == 2 ? 2u : 4u;
+				const uint32_t np = (uint32_t)num_planes((int)st.type, plan.views[st.type].compact != 0), ef4 = dict_entry_f4(np);
+				const uint16_t *ent = st.dict ? reinterpret_cast<const uint16_t *>(&seg.params[st.par_off]) : nullptr;
+				if (verbose)
+				{
+					// what ANY order of this step's slots can reach with the tile's slot numbering as it is: a group cycle serves one slot per bank class
+					for (uint32_t j = 0; j < nb; j++)
+					{
+						uint32_t h16[16] = {}, h8[8] = {};
+						for (uint32_t q = 0; q < st.count; q++) { const uint32_t h = seg.idx[st.idx_off + (size_t)q * iw + j]; h16[h & 15u]++; h8[h & 7u]++; }
+						lb_read[st.type] += std::max((st.count + 15u) / 16u, *std::max_element(h16, h16 + 16));
+						lb_write[st.type] += std::max((st.count + 7u) / 8u, *std::max_element(h8, h8 + 8));
+					}
+				}
+				const uint64_t r0 = out.read_cycles, w0c = out.write_cycles, rg0 = out.read_groups, wg0 = out.write_groups;
+				for (uint32_t w0 = 0; w0 < st.count; w0 += 64u)
+				{
+					const uint32_t lanes = std::min(64u, st.count - w0);
+					for (uint32_t j = 0; j < nb; j++)
+					{
+						uint8_t rc[4][16] = {}, wc[8][8] = {};
+						bool rn[4] = {}, wn[8] = {};
+						for (uint32_t l = 0; l < lanes; l++)
+						{
+							const uint32_t h = seg.idx[st.idx_off + (size_t)(w0 + l) * iw + j];
+							rc[lds_read_group(l)][h & 15u]++; rn[lds_read_group(l)] = true;
+							wc[lds_write_group(l)][h & 7u]++; wn[lds_write_group(l)] = true;
+						}
+						for (uint32_t gq = 0; gq < 4; gq++) if (rn[gq]) { out.read_groups++; out.read_cycles += *std::max_element(rc[gq], rc[gq] + 16); }
+						for (uint32_t gq = 0; gq < 8; gq++) if (wn[gq]) { out.write_groups++; out.write_cycles += *std::max_element(wc[gq], wc[gq] + 8); }
+					}
+					if (ent)
+					{
+						// distinct records per bank class and read group (equal addresses are one broadcast access); the ef4 reads of a record are this pattern shifted
+						for (uint32_t gq = 0; gq < 4; gq++)
+						{
+							uint32_t seen[16][8]; uint32_t ns[16] = {}; bool any = false;
+							for (uint32_t l = 0; l < lanes; l++)
+							{
+								if (lds_read_group(l) != gq) continue;
+								any = true;
+								const uint32_t off = t.n_local + ent[w0 + l], cls = off & 15u;
+								bool dup = false;
+								for (uint32_t k = 0; k < ns[cls] && k < 8u; k++) if (seen[cls][k] == off) dup = true;
+								if (!dup) { if (ns[cls] < 8u) seen[cls][ns[cls]] = off; ns[cls]++; }
+							}
+							if (any) { out.table_groups += ef4; out.table_cycles += (uint64_t)ef4 * *std::max_element(ns, ns + 16); }
+						}
+					}
+				}
+				cyc_read[st.type] += out.read_cycles - r0; cyc_write[st.type] += out.write_cycles - w0c; grp_read[st.type] += out.read_groups - rg0; grp_write[st.type] += out.write_groups - wg0;
+			}
+	if (verbose)
+		for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++)
+			if (grp_read[t])
+				fprintf(stderr, "[lds model] type %2d: reads %llu groups, best order %llu, this order %llu; writes %llu groups, best order %llu, this order %llu\n", t,
+					(unsigned long long)grp_read[t], (unsigned long long)lb_read[t], (unsigned long long)cyc_read[t],
+					(unsigned long long)grp_write[t], (unsigned long long)lb_write[t], (unsigned long long)cyc_write[t]);
+}
 
 void build_persistent_deps(const FusedPlan &plan, PersistentDeps &out)
 {

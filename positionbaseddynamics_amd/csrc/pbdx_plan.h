@@ -227,6 +227,7 @@ struct PlanOptions
 	bool vector_params = false;         // form of the parameter streams (the caller predicts the workgroup size: vector_params_for_block)
 	bool dict_params = false;           // wide, repetitive records go into per-tile dictionaries (FusedStep::dict); the caller reserves kDictTableF4 of max_local
 	bool dict_keep_streams = false;     // (set by build_instanced_plan for its prototype: pbdx_plan.cpp dictionary_pass)
+	bool bank_aware = true;             // order the slots of every step so that the lanes of an LDS access group hit different banks (lds_bank_model)
 	uint32_t sizing_local = 0;          // LDS capacity the default tile SIZE is derived from (0: max_local); the caller that reserved LDS for the tables passes
 	                                    // the unreduced capacity, so that the reservation does not change the tile count where the tiles fit anyway
 };
@@ -272,6 +273,28 @@ bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const st
 // produce, for every particle, the hash the colour-sequential sweep produces.  Also checks that
 // every particle is owned exactly once and that every local index is in range.
 bool check_fused_plan(uint32_t n, const std::vector<PlanBatch> &batches, const FusedPlan &plan, std::string &why);
+
+// ---- LDS bank model of the colour sweep ---------------------------------------------------------------------
+// The projections gather and scatter their endpoints as 16-byte LDS accesses at tile-local slot h (byte address 16 h).  gfx950 services a wave's
+// ds_read_b128 in four groups of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,28-31}, {32-35,44-47,52-59}, {36-43,48-51,60-63} -- over 64 banks of 4
+// bytes, and a ds_write_b128 in eight groups of 8 consecutive lanes over 32 banks (MI355X_MICROARCH.md, LDS table): a group takes one LDS cycle if
+// its lanes' slots are pairwise distinct mod 16 (reads) / mod 8 (writes), and one more cycle for every further distinct address on the busiest bank.
+// Counters of the 1 M cloth (profiles/r04_sq_counters_persistent_c2.log): SQ_LDS_BANK_CONFLICT = 52 % of SQ_LDS_IDX_ACTIVE.  Within a colour step
+// the constraints are independent, so their ORDER inside the step (which lane of which wave projects which one) is free: results do not depend on it.
+// lds_bank_model() evaluates a plan under this model; PlanOptions::bank_aware makes the planner order every step's slots to reduce the modelled cycles.
+struct LdsBankModel
+{
+	uint64_t read_groups = 0, read_cycles = 0;      // non-empty 16-lane groups of the endpoint gathers (= conflict-free cycles) and modelled cycles
+	uint64_t write_groups = 0, write_cycles = 0;    // the same for the scatter (8-lane groups)
+	uint64_t table_groups = 0, table_cycles = 0;    // reads of the dictionary records (broadcast for equal records)
+};
+void lds_bank_model(const FusedPlan &plan, uint32_t block, LdsBankModel &out);
+// the read / write groups of a wave (lane -> group), shared by the model and the planner
+constexpr uint32_t lds_read_group(uint32_t lane)      // lane in 0..63
+{
+	return (lane >> 5) * 2u + ((((lane & 31u) < 4u) || ((lane & 31u) >= 12u && (lane & 31u) < 16u) || ((lane & 31u) >= 20u && (lane & 31u) < 28u)) ? 0u : 1u);
+}
+constexpr uint32_t lds_write_group(uint32_t lane) { return lane >> 3; }
 
 // ---- persistent schedule (all passes of a substep in one launch, tiles synchronised pairwise) -------------
 // Per segment a CSR list: the tiles whose pass p-1 must be complete before tile t may start pass p when that

@@ -109,6 +109,7 @@ project_fn kProjectKernels[PBDX_NUM_CONSTRAINT_TYPES][2] = {
 // ------------------------------------------------------------------------------------------------
 // (A) colour-fused tile kernel
 // ------------------------------------------------------------------------------------------------
+struct BndLim { uint32_t gid_left, n_particles, lds_f4, tile; };      // what a tile's raw accesses are checked against (PBDX_BOUNDS builds)
 // the plan image of one segment (read-only except the multiplier stream, which is private per tile)
 struct SegArgs
 {
@@ -120,6 +121,9 @@ struct SegArgs
 	const uint32_t *gid;
 	uint32_t idx_bytes, params_bytes, lambda_bytes;   // stream sizes (buffer descriptors)
 	uint32_t num_tiles;
+#if PBDX_BOUNDS
+	uint32_t gid_count, chunk_count, n_particles, lds_f4;      // sizes of the raw-pointer streams, particle count, LDS capacity behind the chunk header (16-byte units)
+#endif
 };
 struct FusedArgs
 {
@@ -178,9 +182,18 @@ struct ChunkS { uint32_t info, idx_boff, par_boff, lam_boff; };
 #ifndef PBDX_SMEM_CHUNKS
 #define PBDX_SMEM_CHUNKS 1
 #endif
-struct ChunkSrc { const uint4 *lds; const uint4 *glb; };
+struct ChunkSrc
+{
+	const uint4 *lds; const uint4 *glb;
+#if PBDX_BOUNDS
+	uint32_t n;              // the tile's number of chunk descriptors
+#endif
+};
 __device__ __forceinline__ uint4 chunk_words(const ChunkSrc &cs, uint32_t c)
 {
+#if PBDX_BOUNDS
+	c = PBDX_BCLAMP(kBndChunk, c, cs.n, 0u);
+#endif
 #if PBDX_SMEM_CHUNKS && defined(__HIP_DEVICE_COMPILE__)
 	typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 	typedef __attribute__((address_space(4))) const u4 *const_ptr;
@@ -269,6 +282,7 @@ template <int BLOCK, bool COHERENT> struct TileFill
 	uint32_t num_chunks, n_local;
 	uint32_t first;              // local particles [0, first) are already in LDS (multiple of 64; 0 = stage everything)
 	unsigned long long *trace;
+	BndLim lim;                  // (PBDX_BOUNDS builds; zeros and unused otherwise)
 
 	// Eight particles per thread and batch.  The positions go from HBM straight into LDS (lds_dma16), so a
 	// batch holds eight ids in registers and nothing else.  All eight ids are consumed by one empty asm statement:
@@ -284,8 +298,13 @@ template <int BLOCK, bool COHERENT> struct TileFill
 #endif
 		const uint32_t last = n_local - 1u;
 		uint32_t base = first + threadIdx.x;
+#if PBDX_BOUNDS
+#define PBDX_G(k) const uint32_t i##k = base + k * BLOCK; const uint32_t g##k = gid[PBDX_BCLAMP(kBndGid, (i##k < last ? i##k : last), lim.gid_left, lim.tile)];
+#define PBDX_D(k) if (i##k < n_local && PBDX_BOK(kBndParticle, g##k, lim.n_particles, lim.tile) && PBDX_BOK(kBndLdsFill, i##k, lim.lds_f4, lim.tile)) lds_dma16<COHERENT>(pos_in, g##k, lpos + (i##k & ~63u));
+#else
 #define PBDX_G(k) const uint32_t i##k = base + k * BLOCK; const uint32_t g##k = gid[i##k < last ? i##k : last];
 #define PBDX_D(k) if (i##k < n_local) lds_dma16<COHERENT>(pos_in, g##k, lpos + (i##k & ~63u));
+#endif
 #define PBDX_BATCH(BETWEEN) { \
 			PBDX_G(0) PBDX_G(1) PBDX_G(2) PBDX_G(3) PBDX_G(4) PBDX_G(5) PBDX_G(6) PBDX_G(7) \
 			BETWEEN; \
@@ -335,6 +354,11 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 #ifndef PBDX_FETCH_BEFORE_BARRIER
 #define PBDX_FETCH_BEFORE_BARRIER 0
 #endif
+// developer switch (A/B and fault-hunting builds only; see profiles/HISTORY.md [8], [9]): the descriptor of the chunk the NEXT record fetch reads is
+// requested at the end of the current fetch
+#ifndef PBDX_PIPELINE_FETCH_DESC
+#define PBDX_PIPELINE_FETCH_DESC 0
+#endif
 // DICT: a run of dictionary-form steps (FusedStep::dict, pbdx_plan.h): a slot streams its indices, its multiplier and ONE uint16 -- the offset of its
 // parameter record in the tile's table of distinct records, which sits in LDS behind the particles (ltab); the record is read from there when the
 // slot is projected.  Same arithmetic on the same values: bit-identical.
@@ -363,6 +387,9 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 	uint32_t c_ld = c0, c_ex = c0;
 	// the ring lives in named records (not an array): keeps every record in registers
 	RecT r0, r1, r2, r3;
+#if PBDX_PIPELINE_FETCH_DESC
+	ChunkS ch_fetch = load_chunk(lchunks, c0);
+#endif
 	auto fetch = [&](RecT &dst)
 	{
 		// beyond the run the last chunk is fetched again (harmless): the fetch itself stays unconditional.  (Also for waves none of whose lanes
@@ -372,7 +399,11 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 		// (requesting the NEXT fetch's descriptor at the end of this one, so that the scalar load's latency passes during the projection, measured
 		// -0.9 ... -2.2 % -- and made the heavy-type kernels fault in 7 of 12 runs of tests/test_examples.py, with or without a scalar-cache
 		// invalidation at kernel start, while this form never did: removed, profiles/HISTORY.md [8])
+#if PBDX_PIPELINE_FETCH_DESC
+		const ChunkS ch = ch_fetch;
+#else
 		const ChunkS ch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
+#endif
 		const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, v_tail, a.views[TYPE] };
 		if constexpr (DICT)
 		{
@@ -385,6 +416,9 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 		else if constexpr (QUAD) load_rec_quad<TYPE, COMPACT>(acc, ql, lane_slot, dst);
 		else load_rec<TYPE, COMPACT>(acc, lane_slot, dst);
 		c_ld++;
+#if PBDX_PIPELINE_FETCH_DESC
+		ch_fetch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
+#endif
 	};
 	fetch(r0); fetch(r1);
 	if constexpr (D == 4) { fetch(r2); fetch(r3); }
@@ -414,7 +448,11 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 					// the slot's record: indices and multiplier as streamed, the parameter planes from the tile's table
 					Rec<TYPE, COMPACT> full;
 					full.w[0] = cur.w[0]; full.w[1] = cur.w[1]; full.w[2] = cur.w[2];
+#if PBDX_BOUNDS
+					const float4 *e = ltab + (PBDX_BOK(kBndTable, cur.w[3] + dict_entry_f4(NP) - 1u, str.dbg_tab_f4, str.dbg_tile) ? cur.w[3] : 0u);
+#else
 					const float4 *e = ltab + cur.w[3];
+#endif
 #pragma unroll
 					for (uint32_t q4 = 0; q4 < dict_entry_f4(NP); q4++)
 					{
@@ -472,6 +510,11 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 		else { sub(r0); sub(r1); }
 		if (c_ex >= run_end) break;
 	}
+#if PBDX_PIPELINE_FETCH_DESC == 2
+	// fault-hunting build: the descriptor requested by the run's last fetch is never used; here it is consumed (the compiler then waits for the scalar
+	// load before the registers can be given to anything else)
+	asm volatile("" :: "s"(ch_fetch.info), "s"(ch_fetch.idx_boff), "s"(ch_fetch.par_boff), "s"(ch_fetch.lam_boff));
+#endif
 	return run_end;
 }
 
@@ -519,7 +562,7 @@ __device__ __forceinline__ float4 load_f4_sc1(__amdgpu_buffer_rsrc_t rs, uint32_
 // earlier launches: plain loads.
 template <int BLOCK>
 __device__ __forceinline__ void integrate_fill(const FoldArgs &f, const uint4 *src, const uint32_t *gid, const float4 *pos_in, uint4 *lchunks, float4 *lpos,
-	uint32_t num_chunks, uint32_t n_local, uint32_t n_owned, unsigned long long *trace)
+	uint32_t num_chunks, uint32_t n_local, uint32_t n_owned, unsigned long long *trace, const BndLim &lim)
 {
 #if !PBDX_SMEM_CHUNKS
 	uint4 chv = make_uint4(0u, 0u, 0u, 0u);
@@ -531,7 +574,12 @@ __device__ __forceinline__ void integrate_fill(const FoldArgs &f, const uint4 *s
 		uint32_t g[4];
 		float4 x[4], v[4];
 #pragma unroll
-		for (uint32_t k = 0; k < 4; k++) { const uint32_t i = base + k * BLOCK; g[k] = gid[i < last_i ? i : last_i]; }
+		for (uint32_t k = 0; k < 4; k++)
+		{
+			const uint32_t i = base + k * BLOCK;
+			g[k] = gid[PBDX_BCLAMP(kBndGid, (i < last_i ? i : last_i), lim.gid_left, lim.tile)];
+			g[k] = PBDX_BCLAMP(kBndParticle, g[k], lim.n_particles, lim.tile);
+		}
 #pragma unroll
 		for (uint32_t k = 0; k < 4; k++) { x[k] = pos_in[g[k]]; v[k] = f.vel[g[k]]; }
 #pragma unroll
@@ -545,7 +593,7 @@ __device__ __forceinline__ void integrate_fill(const FoldArgs &f, const uint4 *s
 				w.x = w.x + f.ghx; w.y = w.y + f.ghy; w.z = w.z + f.ghz;
 				p.x = p.x + w.x * f.h; p.y = p.y + w.y * f.h; p.z = p.z + w.z * f.h;
 			}
-			lpos[i] = p;
+			if (PBDX_BOK(kBndLdsFill, i, lim.lds_f4, lim.tile)) lpos[i] = p;
 			if (i < n_owned)
 			{
 				f.last[g[k]] = f.old[g[k]];
@@ -565,7 +613,7 @@ __device__ __forceinline__ void integrate_fill(const FoldArgs &f, const uint4 *s
 // last pass of a substep: final positions + TimeIntegration::velocityUpdateFirstOrder / SecondOrder (TimeIntegration.cpp:42-51,
 // 69-79) for the owned particles.  old / last / vel were written by this workgroup in pass 0 of the same launch: sc1 loads.
 template <int BLOCK>
-__device__ __forceinline__ void velocity_write_back(const FoldArgs &f, const uint32_t *gid, float4 *pos_out, const float4 *lpos, uint32_t n_owned)
+__device__ __forceinline__ void velocity_write_back(const FoldArgs &f, const uint32_t *gid, float4 *pos_out, const float4 *lpos, uint32_t n_owned, const BndLim &lim)
 {
 	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(f.vel, 0, f.state_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(f.old, 0, f.state_bytes, 0x00020000);
@@ -579,7 +627,12 @@ __device__ __forceinline__ void velocity_write_back(const FoldArgs &f, const uin
 		uint32_t g[kBatch];
 		float4 v[kBatch], o[kBatch], l[kBatch];
 #pragma unroll
-		for (uint32_t k = 0; k < kBatch; k++) { const uint32_t i = base + k * BLOCK; g[k] = gid[i < last_i ? i : last_i]; }
+		for (uint32_t k = 0; k < kBatch; k++)
+		{
+			const uint32_t i = base + k * BLOCK;
+			g[k] = gid[PBDX_BCLAMP(kBndGid, (i < last_i ? i : last_i), lim.gid_left, lim.tile)];
+			g[k] = PBDX_BCLAMP(kBndParticle, g[k], lim.n_particles, lim.tile);
+		}
 #pragma unroll
 		for (uint32_t k = 0; k < kBatch; k++)
 		{
@@ -622,15 +675,31 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	// boundary_only (persistent schedule, one workgroup per tile, not the last pass of the launch): the owned particles stay in LDS for the next
 	// pass, so only the ones another tile stages -- [wb_begin, n_owned): the planner orders the interior first -- have to reach memory
 	// fold_phase (persistent schedule only): bit 0 = this pass integrates while it stages, bit 1 = it updates the velocities
+#if PBDX_BOUNDS
+	tile_index = PBDX_BCLAMP(kBndTile, tile_index, sg.num_tiles, 0u);
+#endif
 	const FusedTile t = sg.tiles[tile_index];
 	if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
 	const uint32_t *gid = sg.gid + t.gid_off;
 	const uint32_t num_chunks = t.chunk_end - t.chunk_begin;
+#if PBDX_BOUNDS
+	// the tile descriptor itself: its slices of the gid and chunk streams, its LDS footprint
+	(void)PBDX_BOK(kBndGid, t.gid_off + t.n_local - 1u, sg.gid_count, tile_index);
+	(void)PBDX_BOK(kBndChunkRange, t.chunk_end, sg.chunk_count + 1u, tile_index);
+	(void)PBDX_BOK(kBndChunkRange, num_chunks, kMaxTileChunks + 1u, tile_index);
+	(void)PBDX_BOK(kBndLdsFill, t.n_local + t.tab_f4 - 1u, sg.lds_f4, tile_index);
+	const BndLim lim = { sg.gid_count - t.gid_off, sg.n_particles, sg.lds_f4, tile_index };
+#else
+	const BndLim lim = { 0u, 0u, 0u, 0u };
+#endif
 	// stream descriptors, from kernel arguments only (wave-uniform by construction)
 	TileStreams str;
 	str.idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(sg.idx), 0, sg.idx_bytes, 0x00020000);
 	str.par = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sg.params), 0, sg.params_bytes, 0x00020000);
 	str.lam = __builtin_amdgcn_make_buffer_rsrc(sg.lambda, 0, sg.lambda_bytes, 0x00020000);
+#if PBDX_BOUNDS
+	str.dbg_n_local = t.n_local; str.dbg_tab_f4 = t.tab_f4; str.dbg_tile = tile_index;
+#endif
 	const FusedChunk *gchunks = sg.chunks + t.chunk_begin;
 	// the tile's table of distinct parameter records (dictionary-form steps): requested now, written into LDS behind the particles once the fill is through
 	constexpr uint32_t kTabPerThread = kDictTableF4 / (uint32_t)BLOCK;
@@ -641,17 +710,21 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	{
 		const float4 *gtab = reinterpret_cast<const float4 *>(sg.params) + t.tab_off;
 		const uint32_t lastf4 = t.tab_f4 - 1u, i0 = threadIdx.x;
+#if PBDX_BOUNDS
+		(void)PBDX_BOK(kBndTableSrc, t.tab_off + lastf4, sg.params_bytes / 16u, tile_index);
+		(void)PBDX_BOK(kBndTable, lastf4, kDictTableF4, tile_index);
+#endif
 		tabv0 = gtab[i0 < lastf4 ? i0 : lastf4];
 		if constexpr (kTabPerThread > 1) tabv1 = gtab[i0 + BLOCK < lastf4 ? i0 + BLOCK : lastf4];
 		if constexpr (kTabPerThread > 2) { tabv2 = gtab[i0 + 2 * BLOCK < lastf4 ? i0 + 2 * BLOCK : lastf4]; tabv3 = gtab[i0 + 3 * BLOCK < lastf4 ? i0 + 3 * BLOCK : lastf4]; }
 	}
 	const TileFill<BLOCK, COHERENT> fill = { reinterpret_cast<const uint4 *>(gchunks), gid, pos_in, lchunks, lpos, num_chunks, t.n_local,
-		keep_owned ? (t.n_owned & ~63u) : 0u, trace };
+		keep_owned ? (t.n_owned & ~63u) : 0u, trace, lim };
 	bool staged = false;
 	if constexpr (COHERENT)
 		if (fold_phase & 1u)
 		{
-			integrate_fill<BLOCK>(*fold, reinterpret_cast<const uint4 *>(gchunks), gid, pos_in, lchunks, lpos, num_chunks, t.n_local, t.n_owned, trace);
+			integrate_fill<BLOCK>(*fold, reinterpret_cast<const uint4 *>(gchunks), gid, pos_in, lchunks, lpos, num_chunks, t.n_local, t.n_owned, trace, lim);
 			staged = true;
 		}
 	if (!staged) fill(wait);
@@ -665,7 +738,11 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	}
 	bool fill_pending = PBDX_DEFER_FILL_WAIT != 0 && !staged;
 	// chunks are addressed relative to the tile from here on (they sit at lchunks[0 .. num_chunks))
+#if PBDX_BOUNDS
+	const ChunkSrc csrc = { lchunks, reinterpret_cast<const uint4 *>(gchunks), num_chunks };
+#else
 	const ChunkSrc csrc = { lchunks, reinterpret_cast<const uint4 *>(gchunks) };
+#endif
 	uint32_t c = 0, step_counter = 0;
 	while (c < num_chunks)
 	{
@@ -687,7 +764,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	if constexpr (COHERENT)
 		if (fold_phase & 2u)
 		{
-			velocity_write_back<BLOCK>(*fold, gid, pos_out, lpos, t.n_owned);
+			velocity_write_back<BLOCK>(*fold, gid, pos_out, lpos, t.n_owned, lim);
 			written = true;
 		}
 	// write-back of the owned particles, ids batched like the fill
@@ -699,9 +776,13 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 		{
 			uint32_t g[kWbBatch];
 #pragma unroll
-			for (uint32_t k = 0; k < kWbBatch; k++) { const uint32_t i = base + k * BLOCK; g[k] = gid[i < last ? i : last]; }
+			for (uint32_t k = 0; k < kWbBatch; k++) { const uint32_t i = base + k * BLOCK; g[k] = gid[PBDX_BCLAMP(kBndGid, (i < last ? i : last), lim.gid_left, lim.tile)]; }
 #pragma unroll
-			for (uint32_t k = 0; k < kWbBatch; k++) { const uint32_t i = base + k * BLOCK; store_pos<COHERENT>(pos_out, g[k], lpos[i < last ? i : last]); }
+			for (uint32_t k = 0; k < kWbBatch; k++)
+			{
+				const uint32_t i = base + k * BLOCK;
+				if (PBDX_BOK(kBndParticle, g[k], lim.n_particles, lim.tile)) store_pos<COHERENT>(pos_out, g[k], lpos[i < last ? i : last]);
+			}
 		}
 	}
 	if (trace && threadIdx.x == 0)
@@ -766,6 +847,9 @@ struct PersistArgs
 	FoldArgs fold;
 	int start;                                    // position buffer pass 0 reads
 	float dt;
+#if PBDX_BOUNDS
+	uint32_t dep_count[kMaxPersistSegs];          // entries of dep_tile
+#endif
 	TypeView views[PBDX_NUM_CONSTRAINT_TYPES];
 };
 
@@ -827,7 +911,7 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 		const uint32_t m = (a.num_tiles - blockIdx.x + gridDim.x - 1u) / gridDim.x;
 		for (uint32_t k = 0; k < m; k++)
 		{
-			const uint32_t tile = blockIdx.x + ((pass & 1u) ? m - 1u - k : k) * gridDim.x;
+			const uint32_t tile = PBDX_BCLAMP(kBndTile, blockIdx.x + ((pass & 1u) ? m - 1u - k : k) * gridDim.x, a.num_tiles, pass);
 			const bool first_of_pass = k == 0u, last_of_pass = k + 1u == m;
 			// the wait for the neighbouring tiles, run by the fill once its particle ids are in flight: one wave polls
 			// the tile's dependencies, one lane each (lists are short: the adjacent tiles)
@@ -840,6 +924,9 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 					const unsigned long long t0 = wall_clock64();
 					for (uint32_t d = d0 + threadIdx.x; d < d1; d += 64)
 					{
+#if PBDX_BOUNDS
+						if (!PBDX_BOK(kBndDep, d, a.dep_count[sgi], tile) || !PBDX_BOK(kBndDep, a.dep_tile[sgi][d], a.num_tiles, tile)) continue;
+#endif
 						const uint32_t *flag = a.epoch + a.dep_tile[sgi][d];
 						while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pass)
 						{
@@ -1206,6 +1293,7 @@ struct DeviceSegment
 	uint32_t num_tiles = 0;
 	uint32_t lds_bytes = 0;
 	uint32_t idx_bytes = 0, params_bytes = 0, lambda_bytes = 0;
+	uint32_t gid_count = 0, chunk_count = 0, n_particles = 0, dep_count = 0;      // sizes the debug build (PBDX_BOUNDS) checks raw indices against
 	uint32_t type_mask = 0;
 	uint64_t algorithmic_bytes = 0;  // SURVEY 8d bytes of the DISTINCT constraints of the segment
 	uint64_t constraints = 0;
@@ -1514,6 +1602,7 @@ int prepare_persistent(pbdx_solver *s)
 	{
 		std::vector<uint32_t> lst = deps.tile[si];
 		if (lst.empty()) lst.push_back(0);
+		s->dsegs[si].dep_count = (uint32_t)deps.tile[si].size();
 		int r = upload(&s->dsegs[si].d_dep_off, deps.off[si]);
 		if (!r) r = upload(&s->dsegs[si].d_dep_tile, lst);
 		if (r) return r;
@@ -1584,6 +1673,8 @@ int ensure_plan(pbdx_solver *s)
 		// bandwidth-bound (1 M cloth -15 %, configs[3] block -17 %), still 4-8 % on 200x200 ... 360x360 cloths, nothing at 100x100 (profiles/r03z_*)
 		opt.dict_params = !getenv("PBDX_NO_DICT") && opt.max_local > 2u * kDictTableF4;
 		if (opt.dict_params) { opt.sizing_local = opt.max_local; opt.max_local -= kDictTableF4; }
+		// bank-aware order of the slots inside a colour step (pbdx_plan.h lds_bank_model; PBDX_NO_BANK_ORDER: developer A/B switch)
+		opt.bank_aware = !getenv("PBDX_NO_BANK_ORDER");
 	}
 	bool planned = false;
 	if (s->inst_count > 1 && (uint64_t)s->inst_particles * s->inst_count == s->n)
@@ -1701,6 +1792,7 @@ int ensure_plan(pbdx_solver *s)
 		d.idx_bytes = (uint32_t)(seg.idx.size() * sizeof(uint16_t));
 		d.params_bytes = (uint32_t)(seg.params.size() * sizeof(float));
 		d.lambda_bytes = (uint32_t)((size_t)seg.lam_count * sizeof(float));
+		d.gid_count = (uint32_t)seg.gid.size(); d.chunk_count = (uint32_t)chunks.size(); d.n_particles = s->n;
 		d.num_tiles = (uint32_t)seg.tiles.size();
 		d.lds_bytes = (std::max(seg.max_local, 1u) + seg.max_tab_f4) * 16u + kMaxTileChunks * 16u;       // (+ the largest dictionary table of a tile)
 		d.type_mask = seg.type_mask;
@@ -1792,6 +1884,9 @@ SegArgs seg_args(const DeviceSegment &d)
 	g.tiles = d.d_tiles; g.chunks = d.d_chunks; g.idx = d.d_idx; g.params = d.d_params; g.lambda = d.d_lambda; g.gid = d.d_gid;
 	g.idx_bytes = d.idx_bytes; g.params_bytes = d.params_bytes; g.lambda_bytes = d.lambda_bytes;
 	g.num_tiles = d.num_tiles;
+#if PBDX_BOUNDS
+	g.gid_count = d.gid_count; g.chunk_count = d.chunk_count; g.n_particles = d.n_particles; g.lds_f4 = d.lds_bytes / 16u - kMaxTileChunks;
+#endif
 	return g;
 }
 
@@ -1807,6 +1902,9 @@ int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations, co
 		a.dep_off[si] = s->dsegs[si].d_dep_off;
 		a.dep_tile[si] = s->dsegs[si].d_dep_tile;
 		a.trace[si] = s->trace ? s->dsegs[si].d_trace : nullptr;
+#if PBDX_BOUNDS
+		a.dep_count[si] = s->dsegs[si].dep_count;
+#endif
 	}
 	a.epoch = s->d_epoch;
 	a.ctl = s->d_ctl;
@@ -3683,6 +3781,28 @@ int pbdx_debug_stream(int device, uint64_t nbytes, int mode)
 	HIPCHECK(hipGetLastError());
 	HIPCHECK(hipDeviceSynchronize());
 	(void)hipFree(buf); (void)hipFree(sink);
+	return PBDX_OK;
+}
+
+// Record of the range checks of a PBDX_BOUNDS build on `device` (after a device synchronisation): out[0] violations since the last reset, out[1..6] the
+// first one (kind, workgroup, thread, index, limit, tile / aux), out[7] = 1 if this library IS such a build (0: the product build, which checks nothing).
+int pbdx_debug_bounds_report(int device, uint32_t out[8], int reset)
+{
+	if (!out) return PBDX_ERR_INVALID;
+	memset(out, 0, 8 * sizeof(uint32_t));
+#if PBDX_BOUNDS
+	ENTER_DEVICE(device);
+	HIPCHECK(hipDeviceSynchronize());
+	HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bounds_rec), 8 * sizeof(uint32_t)));
+	out[7] = 1u;
+	if (reset)
+	{
+		const uint32_t zero[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+		HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bounds_rec), zero, sizeof(zero)));
+	}
+#else
+	(void)device; (void)reset;
+#endif
 	return PBDX_OK;
 }
 

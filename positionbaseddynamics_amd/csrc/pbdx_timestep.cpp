@@ -289,6 +289,55 @@ int pbdx_model_plan_check(pbdx_model *m, uint32_t tile_particles, uint32_t lds_p
 	return PBDX_OK;
 }
 
+// Developer aid (host only): the plan the engine would build for this model on a 256-CU device with the one-launch schedule, planned with and without
+// the bank-aware slot order, both evaluated under the LDS bank model (pbdx_plan.h) and the bank-aware one executed symbolically (check_fused_plan).
+// out[0..5] = read groups, read cycles, write groups, write cycles, table groups, table cycles of the plan AS BUILT (bank_aware as given);
+// out[6] = slots per sweep, out[7] = plan build time in microseconds.
+int pbdx_debug_plan_lds_model(pbdx_model *m, int bank_aware, int check, uint64_t out[8])
+{
+	if (!m || !out) return PBDX_ERR_INVALID;
+	struct Held { std::vector<uint32_t> idx; std::vector<float> par; };
+	std::vector<std::unique_ptr<Held>> held;
+	std::vector<PlanBatch> pbs;
+	uint32_t colour = 0, last_group = 0xffffffffu, mask = 0;
+	int r = for_each_batch(m, [&](uint32_t g, int type, uint32_t count, const std::vector<uint32_t> &idx, const std::vector<float> &par) {
+		if (last_group != 0xffffffffu && g != last_group) colour++;
+		last_group = g;
+		mask |= 1u << type;
+		held.emplace_back(new Held{ idx, par });
+		pbs.push_back({ type, colour, count, held.back()->idx.data(), held.back()->par.data() });
+		return (int)PBDX_OK;
+	});
+	if (r) return r;
+	// (the rules of ensure_plan, pbdx_solver.hip, for a 256-CU device with 160 KiB of LDS per CU and one workgroup per CU)
+	PlanOptions opt;
+	opt.num_cus = 256;
+	opt.max_local = 10240u - 256u;
+	const bool big = (uint64_t)m->size() > 256ull * 1024ull;
+	if (big) { opt.launch_cost_ns = 1500.0; opt.owned_stay_in_lds = true; }
+	const uint32_t light = (1u << PBDX_DISTANCE) | (1u << PBDX_DISTANCE_XPBD) | (1u << PBDX_ISOMETRIC_BENDING) | (1u << PBDX_ISOMETRIC_BENDING_XPBD) |
+		(1u << PBDX_VOLUME) | (1u << PBDX_VOLUME_XPBD) | (1u << PBDX_DIHEDRAL);
+	opt.vector_params = (mask & ~light) != 0 || (uint64_t)m->size() <= 256ull * 512ull;
+	opt.dict_params = !getenv("PBDX_NO_DICT");
+	if (opt.dict_params) { opt.sizing_local = opt.max_local; opt.max_local -= kDictTableF4; }
+	opt.bank_aware = bank_aware != 0;
+	FusedPlan plan;
+	std::string why;
+	if (m->inst_count > 1)
+	{
+		if (!build_instanced_plan(m->inst_particles, m->inst_count, m->x.data(), pbs, opt, plan, why)) { set_error("instanced plan: %s", why.c_str()); return PBDX_ERR_INVALID; }
+	}
+	else if (!build_fused_plan(m->size(), m->x.data(), pbs, opt, plan, why)) { set_error("plan: %s", why.c_str()); return PBDX_ERR_INVALID; }
+	if (check && !check_fused_plan(m->size(), pbs, plan, why)) { set_error("plan check: %s", why.c_str()); return PBDX_ERR_INVALID; }
+	LdsBankModel lm;
+	lds_bank_model(plan, 1024, lm);
+	out[0] = lm.read_groups; out[1] = lm.read_cycles; out[2] = lm.write_groups; out[3] = lm.write_cycles; out[4] = lm.table_groups; out[5] = lm.table_cycles;
+	out[6] = 0;
+	for (const FusedSegment &seg : plan.segs) out[6] += seg.slots;
+	out[7] = (uint64_t)(plan.build_seconds * 1e6);
+	return PBDX_OK;
+}
+
 int pbdx_timestep_create(pbdx_timestep **out, int device)
 {
 	if (!out) { set_error("pbdx_timestep_create: null out"); return PBDX_ERR_INVALID; }

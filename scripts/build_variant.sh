@@ -6,4 +6,4 @@
 set -eu
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
-make -C "$root/positionbaseddynamics_amd/csrc" OUT="$root/gpurun_variants/$name" EXTRA="$*" "$root/gpurun_variants/$name/libpbdx.so"
+make -j8 -C "$root/positionbaseddynamics_amd/csrc" OUT="$root/gpurun_variants/$name" EXTRA="$*" "$root/gpurun_variants/$name/libpbdx.so"

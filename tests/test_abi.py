@@ -154,3 +154,14 @@ def test_pypbd_style_surface():
     view = pd.getVertices()
     view[1, 1] = 42.0                      # zero-copy: writes land in the model
     assert pd.getPosition(1)[1] == 42.0
+
+
+def test_bounds_report_of_the_product_build_says_unchecked():
+    """The product library compiles none of the range checks of the sanitizer-grade debug build (csrc/pbdx_bounds.h: the macros fold to the plain
+    access) and says so; needs no GPU."""
+    import os
+    import positionbaseddynamics_amd as pbd
+    if "bounds" in os.path.basename(os.environ.get("PBDX_LIB", "")):
+        pytest.skip("the library under test IS the debug build")
+    rep = pbd.bounds_report(0)
+    assert rep["checked"] is False and rep["violations"] == 0

@@ -973,23 +973,28 @@ def test_more_contacts_per_particle_than_the_engine_keeps_is_an_error(pbd):
 
 
 @pytest.mark.gpu
-def test_quad_lane_build_is_bit_identical(pbd):
-    """The opt-in build with the FEM tet projections spread over the four lanes of a quad (pbdx_quad.h: columns of F / strain / stress per lane, DPP
-    quad_perm exchanges, reductions replayed in the reference's order; `north_star`: "DPP reductions for per-constraint 3x3 math"): the FEM known-answer
-    tests, the inversion branch, every scene against the float reference, the fused-vs-per-colour cross-check and the full-size 100 k-tet bar, all
-    bit for bit, in a process that loads _lib/libpbdx_quad.so instead of the product library."""
+def test_bounds_checked_build_finds_no_out_of_range_access(pbd):
+    """SURVEY 5 (sanitizers): the hot path under a sanitizer-grade debug build.  _lib/libpbdx_bounds.so is the product's sources compiled with
+    -DPBDX_BOUNDS=1 (csrc/pbdx_bounds.h): every address of the fused / persistent sweep that no buffer descriptor checks in hardware -- particle ids from
+    the gid streams, the positions they select, LDS slots of the fill, the gather / scatter and the dictionary tables, chunk / tile descriptor indices,
+    the dependency lists -- is compared with the size of what it addresses, violations are recorded and the access suppressed.  A second process runs the
+    known-answer tests, every scene, the three schedules' cross-checks, the examples (the all-types kernels) and the full-size cloth under it; every
+    test there must stay bit-identical AND leave the record empty (tests/conftest.py: _bounds_record_stays_empty)."""
     import subprocess
     import sys
-    lib = os.path.join(util.ROOT, "positionbaseddynamics_amd", "_lib", "libpbdx_quad.so")
+    lib = os.path.join(util.ROOT, "positionbaseddynamics_amd", "_lib", "libpbdx_bounds.so")
     if not os.path.exists(lib):
-        pytest.skip("libpbdx_quad.so not built")
-    sel = "known_answer_projection or fem_tet_inversion_branch or scene_parity_vs_float_reference or fused_tiles_equal_per_colour_schedule or full_size_c3"
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(util.ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k", sel],
-                       env=dict(os.environ, PBDX_LIB=lib), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-    tail = p.stdout[-1500:]
+        pytest.skip("libpbdx_bounds.so not built")
+    sel = ("known_answer_projection or fem_tet_inversion_branch or scene_parity_vs_float_reference or fused_tiles_equal_per_colour_schedule or "
+           "persistent_schedule_is_bit_identical or full_size_c2_million_particle_cloth_vs_reference or full_size_c2_odd_pass_count or "
+           "c4_ensemble_block or example_runs_and_matches_reference or dictionary_form")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(util.ROOT, "tests", "test_gpu_parity.py"), os.path.join(util.ROOT, "tests", "test_examples.py"),
+                        "-m", "gpu", "-q", "-x", "-k", sel],
+                       env=dict(os.environ, PBDX_LIB=lib), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    tail = p.stdout[-2000:]
     assert p.returncode == 0, tail
     assert " passed" in tail and "failed" not in tail, tail
-    print("quad-lane build: " + tail.strip().splitlines()[-1])
+    print("bounds-checked build: " + tail.strip().splitlines()[-1])
 
 
 _FMA_ENVELOPE = r"""
