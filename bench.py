@@ -115,21 +115,25 @@ def _rocprof_child(extra_args, child_args, prefix, timeout_s=300, child_steps=No
 
 
 def _pmc_pass(counter, child_args):
-    """One `rocprofv3 --pmc <counter>` pass over a short child run.  Returns {kernel_name: [values per dispatch]} or None."""
+    """One `rocprofv3 --pmc <counter ...>` pass over a short child run (`counter`: one name, or several that fit one pass: 8 SQ slots, GRBM on its
+    own).  One name: returns {kernel_name: [values per dispatch]}; several: {counter: {kernel_name: [...]}}; None if the pass failed."""
     import csv
     import glob
     import shutil
-    outdir = _rocprof_child(["--pmc", counter, "--kernel-trace"], child_args, "pbdx_pmc_")
+    names = counter.split()
+    outdir = _rocprof_child(["--pmc"] + names + ["--kernel-trace"], child_args, "pbdx_pmc_")
     if outdir is None:
         return None
-    vals = {}
+    vals = {n: {} for n in names}
     for f in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if row.get("Counter_Name") == counter:
-                    vals.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+                if row.get("Counter_Name") in vals:
+                    vals[row["Counter_Name"]].setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
     shutil.rmtree(outdir, ignore_errors=True)
-    return vals or None
+    if len(names) == 1:
+        return vals[names[0]] or None
+    return vals if any(vals.values()) else None
 
 
 def rocprof_kernel_durations(child_args, kernel_substring):
@@ -233,16 +237,19 @@ def run_workload(w, opts, ens, steps, warmup, with_roofline, with_traffic, with_
 
     # warm-up (untimed): uploads the device image, plans, measures the schedule candidates, instantiates the hipGraph
     ts.stepResident(model, max(warmup, 1))
-    # "hipEvents around the device-resident substep loop ..., >= 50 substeps, median": one event after every substep of
-    # the timed call on the engine's stream (the graph replay is unchanged), so the median DEVICE time per substep of exactly the
-    # timed steps is reported beside the host-clock mean that `value` is computed from
-    sol.set_option(S.OPT_SUBSTEP_EVENTS, max(int(steps), 1))      # (n > 1: the events are created here, outside the timed region)
+    # the timed region: EXACTLY `steps` steps, nothing else on the stream (the per-substep event records used to sit inside it)
     barrier()
     t0 = time.perf_counter()
     ts.stepResident(model, steps)          # synchronises its own stream before returning
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
     stats = sol.stats()
+    # "hipEvents around the device-resident substep loop ..., >= 50 substeps, median": an UNTIMED replay of the same `steps` steps right
+    # after the timed region with one event after every substep on the engine's stream (the graph replay is unchanged): the median DEVICE time per
+    # substep, reported beside the host-clock mean of the timed region that `value` is computed from
+    sol.set_option(S.OPT_SUBSTEP_EVENTS, max(int(steps), 1))      # (n > 1: the events are created here)
+    ts.stepResident(model, steps)
+    torch.cuda.synchronize()
     sub_ms = sorted(sol.substep_times())
     sol.set_option(S.OPT_SUBSTEP_EVENTS, 0)
     substep_device = None
@@ -260,7 +267,7 @@ def run_workload(w, opts, ens, steps, warmup, with_roofline, with_traffic, with_
     ok = bool(np.all(np.isfinite(x)) and all(np.array_equal(x[p], x0[p]) for p in pins))
     res = {"desc": desc, "t_local": t_local, "n_particles": n_particles, "n_constraints": n_constraints, "n_groups": n_groups,
            "t_build": t_build, "stats": stats, "plan": plan, "persistent": persist, "state_ok": ok, "checksum": checksum(x),
-           "engine": sol.describe(), "steps_done": max(warmup, 1) + steps, "substep_device": substep_device}
+           "engine": sol.describe(), "steps_done": max(warmup, 1) + 2 * steps, "substep_device": substep_device}
 
     if with_pcie and ens.rank == 0:
         # PCIe-inclusive rate of the TimeStep::step contract (host ParticleData in -> step -> host ParticleData out every
@@ -426,44 +433,99 @@ def add_profiled_passes(r, w, opts, plan, persist):
     if persist["active"] and dur_us:
         # VALU issue: SQ_ACTIVE_INST_VALU (quad-cycles in which a SIMD issued a vector-ALU instruction, summed over the SIMDs) against the
         # SIMD cycles of the launch (GRBM_GUI_ACTIVE: busy cycles summed over the 8 XCDs) -- clock-free
-        va = _pmc_pass("SQ_ACTIVE_INST_VALU", child)
-        ga = _pmc_pass("GRBM_GUI_ACTIVE", child)
-        v = [x for k, xs in (va or {}).items() if kname in k for x in xs]
-        g = [x for k, xs in (ga or {}).items() if kname in k for x in xs]
-        if v and g:
+        # (until round 4 this was SQ_ACTIVE_INST_VALU x 4 cycles -- but a SIMD issues a wave64 fp32 instruction every ~2 cycles when it
+        # has four waves to choose from; the interval is MEASURED here, in this run, at the kernel's own occupancy: pbdx_debug_valu_issue)
+        pm = _pmc_pass("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE", child) or {}
+
+        def mean_of(name):
+            xs = [x for k, v in (pm.get(name) or {}).items() if kname in k for x in v]
+            return sum(xs) / len(xs) if xs else None
+        iv, va, g = mean_of("SQ_INSTS_VALU"), mean_of("SQ_ACTIVE_INST_VALU"), mean_of("GRBM_GUI_ACTIVE")
+        if iv and g:
+            import positionbaseddynamics_amd as pbd
             simds = 4 * 256
-            r["valu_active_quad_cycles_per_launch"] = sum(v) / len(v)
-            r["gpu_cycles_per_launch"] = sum(g) / len(g) / 8.0
-            r["frac_valu"] = 4.0 * r["valu_active_quad_cycles_per_launch"] / (simds * r["gpu_cycles_per_launch"])
+            r["valu_instructions_per_launch"] = iv
+            r["valu_active_quad_cycles_per_launch"] = va
+            r["gpu_cycles_per_launch"] = g / 8.0
+            cpi = pbd.valu_issue_interval(0, int(persist.get("block") or 1024))
+            r["valu_cycles_per_instruction_measured"] = cpi
+            r["frac_valu"] = iv * cpi / (simds * r["gpu_cycles_per_launch"])
+            r["frac_valu_definition"] = ("SQ_INSTS_VALU x the measured issue interval of a SIMD at this kernel's occupancy (pbdx_debug_valu_issue: v_mul_f32 / v_add_f32, "
+                                         "%d threads per workgroup, one workgroup per CU) / (1 024 SIMDs x GRBM_GUI_ACTIVE / 8)" % int(persist.get("block") or 1024))
+            la, lc, li = mean_of("SQ_LDS_IDX_ACTIVE"), mean_of("SQ_LDS_BANK_CONFLICT"), mean_of("SQ_INSTS_LDS")
+            if la:
+                r["lds_active_cycles_per_launch"] = la
+                r["lds_bank_conflict_cycles_per_launch"] = lc
+                r["lds_instructions_per_launch"] = li
+                r["frac_lds"] = la / (256 * r["gpu_cycles_per_launch"])      # LDS-array cycles of a CU / the launch's cycles
     if r.get("traffic") and dur_us:
         dur_s = dur_us * 1e-6
         r["traffic_GBs"] = r["traffic"] / dur_s / 1e9
         r["frac_traffic"] = r["traffic_GBs"] / HBM_PEAK_GBS
-        r["frac_traffic_of_copy_ceiling"] = r["traffic_GBs"] / HBM_COPY_GBS
+        try:
+            import positionbaseddynamics_amd as pbd
+            r["copy_ceiling_gbs"] = pbd.copy_bandwidth(0)      # the practical roof, measured in this run (float4 copy, 1 GiB per direction)
+        except Exception:
+            r["copy_ceiling_gbs"] = None
+        r["copy_ceiling_gbs_guide"] = HBM_COPY_GBS
+        r["frac_traffic_of_copy_ceiling"] = r["traffic_GBs"] / (r["copy_ceiling_gbs"] or HBM_COPY_GBS)
         r["traffic_over_algorithmic"] = r["traffic"] / r.get("algorithmic_bytes_per_launch_mean", r["algorithmic_bytes_per_launch"])
         if r.get("compulsory_bytes_per_launch"):
             r["traffic_over_compulsory"] = r["traffic"] / r["compulsory_bytes_per_launch"]
             r["frac_compulsory"] = r["compulsory_bytes_per_launch"] / dur_s / 1e9 / HBM_PEAK_GBS
-        # SURVEY 8d's algorithmic-byte fraction is saturated (> 1: an LDS-resident tile does not move those bytes), so the
-        # headline `achieved` / `frac` are the PHYSICALLY BOUNDED figures -- bytes the counters saw on the fabric side of the L2 per launch
-        # / the launch's device time / 8 TB/s -- and the contract's number stays beside them as achieved_contract / frac_contract
+        # achieved / frac stay what the contract defines on EVERY line (SURVEY 8d algorithmic bytes / device time / 8 TB/s; ADVICE r4: they used to switch
+        # meaning with the counter pass); the physically bounded figures are keys of their own: achieved_traffic / frac_traffic (counter-measured fabric
+        # bytes), frac_traffic_of_copy_ceiling (against the copy bandwidth measured in this run), frac_valu, frac_lds
         r["achieved_contract"], r["frac_contract"] = r["achieved"], r["frac"]
-        r["achieved"], r["frac"] = r["traffic_GBs"], r["frac_traffic"]
-        r["frac_kind"] = "traffic"
-        r["note"] = ("achieved / frac = counter-measured fabric bytes per launch (upper bound of HBM bytes: Infinity-Cache hits are counted) / device time / 8 TB/s, "
-                     "the physically bounded figure. achieved_contract / frac_contract = SURVEY 8d ALGORITHMIC bytes (every endpoint position read and written once per "
-                     "projection, 32-bit indices, no cache credit) / the same time: it exceeds 1 because the kernel keeps positions in LDS and streams 16-bit indices. "
-                     "compulsory_bytes = every distinct constraint record once per sweep + one particle-state pass; traffic_over_compulsory is the redundancy left to remove")
-        r["frac_definition"] = "counter-measured HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated in-pass) / device time per launch / 8 TB/s; frac_contract = SURVEY 8d algorithmic bytes / same time / 8 TB/s"
+        r["achieved_traffic"] = r["traffic_GBs"]
+        r["note"] = ("achieved / frac = SURVEY 8d ALGORITHMIC bytes (every endpoint position read and written once per projection, 32-bit indices, no cache credit) / "
+                     "device time / 8 TB/s: it exceeds 1 because the kernel keeps positions in LDS and streams 16-bit indices (the work is proven bit-identical). "
+                     "achieved_traffic / frac_traffic = counter-measured fabric bytes per launch (upper bound of HBM bytes: Infinity-Cache hits are counted) / the same "
+                     "time / 8 TB/s -- the physically bounded figure; frac_valu / frac_lds = share of the launch's cycles a SIMD needs to issue its vector-ALU instructions "
+                     "at the measured rate / the CU's LDS array is busy. compulsory_bytes = every distinct constraint record once per sweep + one particle-state pass")
+        r["frac_definition"] = "SURVEY 8d algorithmic bytes per launch / device time per launch / 8 TB/s; frac_traffic = counter-measured HBM-side bytes (FETCH_SIZE + WRITE_SIZE, calibrated in-pass) / same time / 8 TB/s"
     if r.get("frac_valu") is not None:
-        fr = {"hbm traffic": r.get("frac_traffic") or 0.0, "valu issue": r["frac_valu"]}
+        fr = {"hbm traffic": r.get("frac_traffic") or 0.0, "valu issue": r["frac_valu"], "lds array": r.get("frac_lds") or 0.0}
         top = max(fr, key=fr.get)
-        r["binding"] = "%s (%.2f of its peak); neither unit is saturated: the colour steps are dependent-latency chains between workgroup barriers" % (top, fr[top]) if fr[top] < 0.8 else "%s (%.2f of its peak)" % (top, fr[top])
+        r["binding"] = ("none of the three units is saturated (%s): what is left of the launch is synchronisation -- workgroup barriers between dependent colour steps, "
+                        "record-fetch issue, tile hand-offs at the pass boundaries" % ", ".join("%s %.2f" % kv for kv in sorted(fr.items(), key=lambda kv: -kv[1]))
+                        ) if fr[top] < 0.8 else "%s (%.2f of its peak)" % (top, fr[top])
 
 
 # ---------------------------------------------------------------------------------------------------
 # CPU side: the reference itself on this box's host cores (timing) and as the checker of the timed engine (parity)
 # ---------------------------------------------------------------------------------------------------
+_NPROC_LEG = r"""
+import json, sys, time
+sys.path.insert(0, %(root)r)
+from oracle import refdrv
+from oracle.scene_ref import apply_ref
+from positionbaseddynamics_amd import scenes
+o = refdrv.Ref(%(variant)r)
+apply_ref(o, scenes.cloth_spec(%(size)d, %(size)d, 4, 3))
+o.set_time_step_size(0.005)
+o.set_params(1, %(iters)d, 0)
+o.set_num_threads(64)
+o.step(1)
+o.set_num_threads(%(ncpu)d)
+t = o.time_steps(1)
+print(json.dumps({"threads": %(ncpu)d, "ms_per_substep": 1e3 * t, "projections_per_s": o.num_constraints() * %(iters)d / t, "timed_steps": 1}))
+"""
+
+
+def cpu_nproc_leg(size, iters, ncpu, variant, limit_s=150):
+    """One step of the reference at OMP_NUM_THREADS = nproc in a child process (see cpu_baseline); a dict, with `timed_out_after_s` if it did not finish."""
+    import subprocess
+    try:
+        cp = subprocess.run([sys.executable, "-c", _NPROC_LEG % {"root": os.path.dirname(os.path.abspath(__file__)), "variant": variant, "size": size, "iters": iters, "ncpu": ncpu}],
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit_s)
+        if cp.returncode == 0 and cp.stdout.strip():
+            return json.loads(cp.stdout.strip().splitlines()[-1])
+        return {"threads": ncpu, "error": (cp.stderr or "")[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"threads": ncpu, "timed_out_after_s": limit_s}
+
+
 def cpu_baseline(size, iters, opts, hip_device, parity_steps=3, timed_steps=3):
     """(1) TIMING.  The reference's own TimeStepController::step (oracle/_ref, release-like build: -O3 -fopenmp and the
     widest -march level this host executes, oracle/refdrv.py:best_timing_variant) on the SAME scene as the GPU workload
@@ -520,6 +582,11 @@ def cpu_baseline(size, iters, opts, hip_device, parity_steps=3, timed_steps=3):
                      "reference build '%s' (%s); OMP threads tried %s, best = %d (host reports %d logical CPUs); scene build + colouring + warm-up %.1fs" % (
                          size, size, nc, iters, timed_steps, variant, flags, sorted(results), best, ncpu, t_setup)}
     o.reset_all()
+    # BASELINE.md 2 / SURVEY 8d also ask for OMP_NUM_THREADS = nproc.  On the MI355X box's 256-CPU host that leg takes about a minute per substep (one
+    # fork / join per colour group and iteration), so it is ONE step in a child process with a time limit; reported as a field, never `value`
+    rec["nproc_threads"] = None
+    if variant is not None and ncpu > max(thread_settings) and not opts.get("no_cpu_nproc"):
+        rec["nproc_threads"] = cpu_nproc_leg(size, iters, ncpu, variant)
 
     parity = None
     if refdrv.available("f32") and parity_steps > 0:
@@ -698,14 +765,14 @@ def _pick(d, keys):
 def compact_roofline(r):
     if not r:
         return None
-    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "frac_kind", "frac_contract", "achieved_contract", "frac_valu", "binding", "traffic", "frac_traffic", "traffic_over_compulsory", "algorithmic_bytes_per_launch",
+    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "frac_kind", "achieved_traffic", "frac_traffic", "copy_ceiling_gbs", "frac_traffic_of_copy_ceiling", "frac_valu", "valu_cycles_per_instruction_measured",
+                    "valu_instructions_per_launch", "gpu_cycles_per_launch", "frac_lds", "lds_active_cycles_per_launch", "lds_bank_conflict_cycles_per_launch", "binding", "traffic", "traffic_over_compulsory", "algorithmic_bytes_per_launch",
                     "compulsory_bytes_per_launch", "avg_launch_us", "eager_launch_us", "rocprofv3_median_kernel_us", "rocprofv3_mean_kernel_us",
                     "rocprofv3_dispatches", "launches_measured"))
     out["kernel"] = str(r.get("kernel", ""))[:110]
-    if r.get("frac_kind") == "traffic":
-        out["note"] = "achieved/frac = PMC HBM-side bytes per launch / median device time (/ 8 TB/s); SURVEY 8d algorithmic-byte figure = achieved_contract/frac_contract (> 1: LDS-resident tiles do not move those bytes)"
-    elif r.get("frac_kind") == "contract":
-        out["note"] = "achieved/frac = SURVEY 8d algorithmic bytes / device time (no counter pass for this line)"
+    out["note"] = ("achieved/frac = SURVEY 8d algorithmic bytes / median device time (/ 8 TB/s; > 1: LDS-resident tiles do not move those bytes)" +
+                   ("; achieved_traffic/frac_traffic = PMC HBM-side bytes per launch / the same time; frac_valu = SQ_INSTS_VALU x measured issue interval; frac_lds = LDS-array cycles, all / the launch's cycles"
+                    if r.get("frac_traffic") is not None else " (no counter pass for this line)"))
     if r.get("timing_mode"):
         out["timing_mode"] = r["timing_mode"].split(":")[0]
     return out
@@ -735,7 +802,7 @@ def compact_headline(full, detail_path=None):
         out["roofline"] = compact_roofline(full["roofline"])
     cb = full.get("cpu_baseline")
     if cb:
-        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ms_per_substep", "single_thread", "variant", "host_logical_cpus"))
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ms_per_substep", "single_thread", "variant", "host_logical_cpus", "nproc_threads"))
         out["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
     ex = full.get("extra_workloads") or []
     if ex:

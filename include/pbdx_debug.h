@@ -47,6 +47,12 @@ int pbdx_debug_relayout_params(int type, int compact, uint32_t slots, int from_v
 /* ... and the index function itself: float index of (plane, slot) relative to the step's first float. */
 uint64_t pbdx_debug_param_float_index(int vector_params, uint32_t planes, uint32_t plane, uint32_t slot);
 
+/* The practical HBM roof ("use the measured copy bandwidth as the practical roof and report both"): device-to-device float4 copy of `nbytes`,
+ * best of `reps` launches, read + written bytes per second in GB/s. */
+int pbdx_debug_copy_bandwidth(int device, uint64_t nbytes, int reps, double *gbs);
+/* The vector-ALU issue interval the SQ_INSTS_VALU counter is to be priced with: shader cycles per wave64 v_mul_f32 / v_add_f32 and SIMD, measured with
+ * `threads` (256, 512, 1024) threads per workgroup and one workgroup per CU, i.e. at the occupancy of the sweep kernels. */
+int pbdx_debug_valu_issue(int device, int threads, double *cycles_per_instruction);
 /* Developer aid (host only, no GPU): the colour-fused plan the engine builds for `m` on a 256-CU device, with (bank_aware != 0) or without the bank-aware
  * order of the slots inside every colour step, evaluated under the LDS bank model of csrc/pbdx_plan.h (lds_bank_model) and, if `check`, executed
  * symbolically against the colour-sequential sweep.  out[0..5] = 16-lane read groups of the endpoint gathers (= their cycles if conflict-free), modelled

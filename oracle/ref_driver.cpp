@@ -755,6 +755,37 @@ int refdrv_add_generic_distance_constraint(unsigned p1, unsigned p2, double stif
 	model()->m_groupsInitialized = false;
 	return 0;
 }
+// A USER SUBCLASS that overrides the per-substep hook (Constraint::initConstraintBeforeProjection, called for every constraint at the start of every
+// positionConstraintProjection: TimeStepController.cpp:264-268): its rest length follows the state the hook sees -- the integrated velocity and the
+// distance travelled since oldX of its first particle -- so a host that calls the hook at another point of the substep, or not at all, or on stale
+// velocities / old positions, gets different positions (tests/test_plugin.py: mixed models).
+static unsigned g_hooked_calls = 0;
+namespace {
+class HookedDistanceConstraint : public GenericDistanceConstraint
+{
+public:
+	Real m_base = 0;
+	bool initConstraintBeforeProjection(SimulationModel &m) override
+	{
+		ParticleData &pd = m.getParticles();
+		const Vector3r d = pd.getPosition(m_bodies[0]) - pd.getOldPosition(m_bodies[0]);
+		m_restLength = m_base * ((Real)1.0 + (Real)0.05 * pd.getVelocity(m_bodies[0]).norm() + d.norm());
+		g_hooked_calls++;
+		return true;
+	}
+};
+}
+int refdrv_add_hooked_distance_constraint(unsigned p1, unsigned p2, double stiffness)
+{
+	HookedDistanceConstraint *c = new HookedDistanceConstraint();
+	if (!c->initConstraint(*model(), p1, p2, (Real)stiffness)) { delete c; return 1; }
+	c->m_base = c->m_restLength;
+	model()->getConstraints().push_back(c);
+	model()->m_groupsInitialized = false;
+	return 0;
+}
+unsigned refdrv_hooked_calls() { return g_hooked_calls; }
+void refdrv_reset_hooked_calls() { g_hooked_calls = 0; }
 int refdrv_add_generic_isometric_bending_constraint(unsigned p1, unsigned p2, unsigned p3, unsigned p4, double stiffness)
 {
 	GenericIsometricBendingConstraint *c = new GenericIsometricBendingConstraint();

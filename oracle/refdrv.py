@@ -319,6 +319,19 @@ class Ref:
         self.lib.refdrv_set_constraint_stiffness.argtypes = [_u, _d]
         self.lib.refdrv_set_constraint_stiffness(int(c), float(k))
 
+    def add_hooked_distance_constraint(self, p1, p2, stiffness):
+        """A user subclass of the reference's GenericDistanceConstraint that overrides initConstraintBeforeProjection (oracle/ref_driver.cpp)."""
+        self.lib.refdrv_add_hooked_distance_constraint.argtypes = [_u, _u, _d]
+        self.lib.refdrv_add_hooked_distance_constraint.restype = C.c_int
+        assert self.lib.refdrv_add_hooked_distance_constraint(int(p1), int(p2), float(stiffness)) == 0
+
+    def hooked_calls(self, reset=False):
+        self.lib.refdrv_hooked_calls.restype = C.c_uint
+        n = int(self.lib.refdrv_hooked_calls())
+        if reset:
+            self.lib.refdrv_reset_hooked_calls()
+        return n
+
     def add_generic_distance_constraint(self, p1, p2, stiffness):
         """A constraint class outside the engine's scope (Demos/GenericConstraintsDemos/GenericConstraints.cpp): mixed-model tests."""
         self.lib.refdrv_add_generic_distance_constraint.argtypes = [_u, _u, _d]

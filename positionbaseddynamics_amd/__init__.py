@@ -46,6 +46,20 @@ def bounds_report(device=0, reset=False):
             "index": int(out[4]), "limit": int(out[5]), "tile": int(out[6])}
 
 
+def copy_bandwidth(device=0, nbytes=1 << 30, reps=3):
+    """Measured device-to-device float4 copy bandwidth (GB/s, read + written): the practical HBM roof."""
+    out = C.c_double(0.0)
+    check(lib.pbdx_debug_copy_bandwidth(int(device), int(nbytes), int(reps), C.byref(out)), "pbdx_debug_copy_bandwidth")
+    return float(out.value)
+
+
+def valu_issue_interval(device=0, threads=1024):
+    """Measured shader cycles per wave64 v_mul_f32 / v_add_f32 and SIMD with `threads` threads per workgroup, one workgroup per CU."""
+    out = C.c_double(0.0)
+    check(lib.pbdx_debug_valu_issue(int(device), int(threads), C.byref(out)), "pbdx_debug_valu_issue")
+    return float(out.value)
+
+
 def colour_constraints(num_bodies, body_off, bodies, device=0):
     """pbdx_colour_constraints: the reference's greedy colouring (SimulationModel.cpp:1033-1094) on the device, on raw arrays.
     Returns (group_of, num_groups, rounds)."""

@@ -901,6 +901,20 @@ bool TimeStepControllerHIP::runMixedSteps(SimulationModel &model, unsigned int n
 		for (unsigned int sub = 0; sub < m_subSteps && ok; sub++)
 		{
 			ok = pbdx_solver_integrate(m_solver, (float)h, g) == PBDX_OK;
+			// TimeStepController.cpp:264-268: every constraint's initConstraintBeforeProjection runs once per substep, after the integration and
+			// before the first iteration.  For the classes the engine knows the hook only clears the XPBD multiplier (the engine does that itself);
+			// the host-side classes of a mixed model -- user subclasses that may override it -- get the call, and they get it on the state the
+			// reference's hook would see: the INTEGRATED positions and velocities and the shuffled old / last positions.
+			if (ok && n)
+			{
+#ifdef USE_DOUBLE
+				ok = pbdx_solver_get_particles_f64(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0]) == PBDX_OK;
+#else
+				ok = pbdx_solver_get_particles(m_solver, n, &pd.getPosition(0)[0], &pd.getVelocity(0)[0], &pd.getOldPosition(0)[0], &pd.getLastPosition(0)[0]) == PBDX_OK;
+#endif
+				for (unsigned int grp = 0; grp < numGroups && ok; grp++)
+					for (unsigned int ci : m_hostGroups[grp]) constraints[ci]->initConstraintBeforeProjection(model);
+			}
 			for (unsigned int it = 0; it < m_maxIterations && ok; it++)
 			{
 				unsigned int g0 = 0;
@@ -936,10 +950,12 @@ bool TimeStepControllerHIP::runMixedSteps(SimulationModel &model, unsigned int n
 	tm->setTimeStepSize(hOld);                                  // :172
 	// the host's position array holds a mid-step state now (the one the last host group left): it must not be mistaken for a host
 	// edit by the next prepare() -- its hashes are recorded as "what the host is known to hold"
+	// (the same for velocities and old / last positions, which the host constraints' per-substep hook is shown)
 	if (n && !m_blockHash[0].empty())
 	{
-		HashJob job = { &pd.getPosition(0)[0], n, (uint32_t)sizeof(Vector3r), &m_blockHash[0] };
-		hashBlocks(&job, 1);
+		HashJob jobs[4] = { { &pd.getPosition(0)[0], n, (uint32_t)sizeof(Vector3r), &m_blockHash[0] }, { &pd.getVelocity(0)[0], n, (uint32_t)sizeof(Vector3r), &m_blockHash[1] },
+			{ &pd.getOldPosition(0)[0], n, (uint32_t)sizeof(Vector3r), &m_blockHash[2] }, { &pd.getLastPosition(0)[0], n, (uint32_t)sizeof(Vector3r), &m_blockHash[3] } };
+		hashBlocks(jobs, 4);
 	}
 	return ok;
 }

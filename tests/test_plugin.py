@@ -269,6 +269,42 @@ def test_plugin_runs_a_mixed_model_group_by_group(variant):
 
 
 @pytest.mark.gpu
+def test_plugin_mixed_model_calls_the_per_substep_hook_of_user_subclasses():
+    """the reference calls every constraint's initConstraintBeforeProjection once per substep, after the integration
+    (TimeStepController.cpp:264-268).  A user subclass that overrides it (oracle/ref_driver.cpp: HookedDistanceConstraint, whose rest length follows
+    the INTEGRATED velocity and x - oldX of a particle) lives on the host side of a mixed model: the plug-in must call the hook there, as often as the
+    CPU controller does, and on the same state -- bit-identical positions and velocities after 40 steps x 2 substeps are the proof."""
+    refdrv, path = _plugin("f32")
+    ops = util.cloth_spec(50, 50, 4, 3)
+
+    def run(gpu):
+        ref = refdrv.Ref("f32")
+        _setup(ref, ops, 2, 5)
+        ref.add_hooked_distance_constraint(60, 1890, 0.5)
+        ref.add_hooked_distance_constraint(1300, 1301, 1.0)
+        if gpu:
+            assert ref.install_timestep_plugin(path) == 0
+        ref.set_params(2, 5, 0)
+        ref.hooked_calls(reset=True)
+        ref.step(40)
+        calls = ref.hooked_calls(reset=True)
+        out = (ref.positions().copy(), ref.get_array(2).copy(), calls)
+        if gpu:
+            lib, cnt = _counters(path)
+            ts = ref.timestep_ptr()
+            assert cnt["gpu_steps"](ts) == 40 and cnt["failed_steps"](ts) == 0 and cnt["fallback_steps"](ts) == 0
+        ref.reset_all()
+        return out
+
+    (xc, vc, nc), (xg, vg, ng) = run(False), run(True)
+    assert nc == 2 * 40 * 2 and ng == nc, "hook calls: CPU controller %d, plug-in %d" % (nc, ng)
+    plain = util.oracle_positions(ops, 40, 2, 5, "f32")
+    assert util.max_err(xc, plain) > 1e-3, "the hooked constraints change nothing: the test would prove nothing"
+    assert util.bitwise_equal(xg, xc), "max err %.3e" % util.max_err(xg, xc)
+    assert util.bitwise_equal(vg, vc)
+
+
+@pytest.mark.gpu
 def test_plugin_full_size_c2_reference_model():
     """The 1000x1000 REFERENCE model (the reference's own SimulationModel, 5 988 006 heap constraints) stepped through the
     plug-in: bit-identical to the CPU path after 2 steps; plug-in cost per step printed for the round trip
