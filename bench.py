@@ -627,6 +627,44 @@ def cpu_baseline(size, iters, opts, hip_device, parity_steps=3, timed_steps=3):
     return rec, parity
 
 
+def extra_parity(ew, ens, hip_device, steps=2):
+    """Parity leg of an extra workload (`state_ok` only says finite + pins): the scene stepped `steps` steps from rest by the reference's
+    contraction-free float build (oracle/_ref f32, up to 32 threads) and by a fresh engine with default options; positions and velocities bit for bit."""
+    try:
+        from oracle import refdrv
+        from oracle.scene_ref import apply_ref
+        import positionbaseddynamics_amd as pbd
+        from positionbaseddynamics_amd import scenes
+        if not refdrv.available("f32"):
+            return None
+        ops, _, _ = workload_spec(ew, ens)
+        ncpu = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        ref = refdrv.Ref("f32")
+        apply_ref(ref, ops)
+        ref.set_time_step_size(0.005)
+        ref.set_gravity(scenes.GRAVITY)
+        ref.set_params(1, ew["iters"], 0)
+        ref.set_num_threads(min(32, ncpu))
+        ref.step(steps)
+        xr, vr = ref.positions().astype(np.float32), ref.get_array(2).astype(np.float32)
+        ref.reset_all()
+        t_ref = time.perf_counter() - t0
+        model = scenes.build_model(ops)
+        pbd.TimeManager.getCurrent().setTimeStepSize(0.005)
+        ts = pbd.TimeStepController(device=hip_device)
+        ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+        ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, ew["iters"])
+        ts.stepResident(model, steps)
+        ts.syncToHost(model)
+        xg, vg = model.getParticles().positions(), model.getParticles().array(2)
+        return {"bit_identical": bool(np.array_equal(xg.view(np.uint32), xr.view(np.uint32)) and np.array_equal(vg.view(np.uint32), vr.view(np.uint32))),
+                "steps": steps, "from": "rest", "compared_values": int(xg.size + vg.size), "reference_seconds": t_ref,
+                "max_abs": float(np.max(np.abs(xg.astype(np.float64) - xr.astype(np.float64))))}
+    except Exception as e:  # pragma: no cover
+        return {"error": repr(e)}
+
+
 def run_c5(ens, sub_steps, with_reference=True):
     """BASELINE configs[4] in the shape that can be pinned (positionbaseddynamics_amd/scenes.py: armadillo_collision_scene): three armadillo_4k FEM
     solids + static floor, floor contacts and deformable-deformable contacts, maxIterations 1, maxIterationsV 5, h = 0.01.  Timed: 260 steps
@@ -806,7 +844,8 @@ def compact_headline(full, detail_path=None):
         out["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
     ex = full.get("extra_workloads") or []
     if ex:
-        out["extras"] = [{"w": e.get("tag", "?"), "ms": _r(e.get("ms_per_step", e.get("ms_per_substep")), 4), "ok": bool(e.get("state_ok", False) and e.get("bit_identical", True))} for e in ex]
+        out["extras"] = [{"w": e.get("tag", "?"), "ms": _r(e.get("ms_per_step", e.get("ms_per_substep")), 4), "ok": bool(e.get("state_ok", False) and e.get("bit_identical", True)),
+                          "bit_identical": e.get("bit_identical")} for e in ex]      # (ok = finite + pins AND, where a reference leg ran, bit-identical; bit_identical null = no leg)
     out = _r(out)
     line = json.dumps(out, separators=(",", ":"))
     if len(line) >= MAX_LINE:            # never let a long list cost the record: drop the optional parts, longest first
@@ -1099,7 +1138,10 @@ def main():
                 extras.append({"tag": tag, "workload": ew["workload"], "error": repr(e)})
                 continue
             ms = 1e3 * r["t_local"] / nsteps
+            # every extra line carries a reference leg of its own (the late-state bar shares the bar's: its state after 120 steps is pinned in the GPU suite)
+            par = None if (args.no_cpu_baseline or tag == "c3_fem_tets_late") else extra_parity(ew, ens, ens.hip_device)
             extras.append({"tag": tag, "workload": r["desc"], "particles": r["n_particles"], "constraints": r["n_constraints"], "colour_groups": r["n_groups"],
+                           "parity_vs_reference": par, "bit_identical": (par or {}).get("bit_identical"),
                            "steps": nsteps, "warmup": wu, "ms_per_substep": ms, "device_median_ms_per_substep": (r.get("substep_device") or {}).get("median_ms"),
                            "projections_per_s": r["n_constraints"] * ew["iters"] * nsteps / r["t_local"],
                            "state_ok": r["state_ok"], "host_scene_build_s": r["t_build"], "plan": r["plan"], "persistent": r["persistent"],

@@ -109,7 +109,7 @@ project_fn kProjectKernels[PBDX_NUM_CONSTRAINT_TYPES][2] = {
 // ------------------------------------------------------------------------------------------------
 // (A) colour-fused tile kernel
 // ------------------------------------------------------------------------------------------------
-struct BndLim { uint32_t gid_left, n_particles, lds_f4, tile; };      // what a tile's raw accesses are checked against (PBDX_BOUNDS builds)
+struct BndLim { uint32_t gid_left, n_particles, lds_f4, tile, ids_cap; };      // what a tile's raw accesses are checked against (PBDX_BOUNDS builds)
 // the plan image of one segment (read-only except the multiplier stream, which is private per tile)
 struct SegArgs
 {
@@ -123,6 +123,9 @@ struct SegArgs
 	uint32_t num_tiles;
 #if PBDX_BOUNDS
 	uint32_t gid_count, chunk_count, n_particles, lds_f4;      // sizes of the raw-pointer streams, particle count, LDS capacity behind the chunk header (16-byte units)
+	__device__ __forceinline__ uint32_t gid_count_dbg() const { return gid_count; }
+#else
+	__device__ __forceinline__ uint32_t gid_count_dbg() const { return 0u; }
 #endif
 };
 struct FusedArgs
@@ -168,12 +171,13 @@ constexpr uint32_t kTraceStride = 80;
 #ifndef PBDX_DEPTH_BIG
 #define PBDX_DEPTH_BIG 2       // ring depth for the wide records (bending 11-17, FEM 10-13, shape matching 24 floats)
 #endif
-template <int TYPE> struct Depth { static constexpr int value = kParamCount[TYPE] <= 2 ? PBDX_DEPTH_SMALL : PBDX_DEPTH_BIG; };
+constexpr int ring_depth(int type) { return kParamCount[type] <= 2 ? PBDX_DEPTH_SMALL : PBDX_DEPTH_BIG; }      // (also used by the host when it expands a plan into chunks)
+template <int TYPE> struct Depth { static constexpr int value = ring_depth(TYPE); };
 static_assert((PBDX_DEPTH_SMALL == 2 || PBDX_DEPTH_SMALL == 4) && (PBDX_DEPTH_BIG == 2 || PBDX_DEPTH_BIG == 4), "ring depth must be 2 or 4");
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-struct ChunkS { uint32_t info, idx_boff, par_boff, lam_boff; };
+struct ChunkS { uint32_t info, idx_boff, par_boff, lam_boff, f_idx_boff, f_par_boff, f_lam_boff; };
 // A tile's chunk descriptors are read from the plan through the SCALAR cache (constant address space + uniform index -> s_load straight into
 // SGPRs).  Until round 4 they were staged in LDS by the fill and read back as scalars (uniform address -> broadcast read -> four
 // v_readfirstlane): 8 VALU instructions per sub-iteration of a sweep that is VALU-issue-bound.  Measured (profiles/r04g_*): 1 M cloth 0.654 ->
@@ -182,9 +186,10 @@ struct ChunkS { uint32_t info, idx_boff, par_boff, lam_boff; };
 #ifndef PBDX_SMEM_CHUNKS
 #define PBDX_SMEM_CHUNKS 1
 #endif
+static_assert(PBDX_SMEM_CHUNKS, "the chunk descriptors are read with scalar loads (the LDS-staged form went with the 32-byte descriptors of round 5)");
 struct ChunkSrc
 {
-	const uint4 *lds; const uint4 *glb;
+	const uint4 *lds; const uint4 *glb;      // (glb: the tile's 32-byte descriptors in the plan)
 #if PBDX_BOUNDS
 	uint32_t n;              // the tile's number of chunk descriptors
 #endif
@@ -197,7 +202,7 @@ __device__ __forceinline__ uint4 chunk_words(const ChunkSrc &cs, uint32_t c)
 #if PBDX_SMEM_CHUNKS && defined(__HIP_DEVICE_COMPILE__)
 	typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 	typedef __attribute__((address_space(4))) const u4 *const_ptr;
-	const u4 v = *((const_ptr)(uintptr_t)cs.glb + c);
+	const u4 v = *((const_ptr)(uintptr_t)cs.glb + 2u * c);      // (the first half of the 32-byte descriptor)
 	return make_uint4(v.x, v.y, v.z, v.w);
 #else
 	return cs.lds[c];
@@ -205,9 +210,19 @@ __device__ __forceinline__ uint4 chunk_words(const ChunkSrc &cs, uint32_t c)
 }
 __device__ __forceinline__ ChunkS load_chunk(const ChunkSrc &cs, uint32_t c)
 {
-	const uint4 v = chunk_words(cs, c);
+#if PBDX_BOUNDS
+	c = PBDX_BCLAMP(kBndChunk, c, cs.n, 0u);
+#endif
 	ChunkS r;
-	r.info = rfl(v.x); r.idx_boff = rfl(v.y); r.par_boff = rfl(v.z); r.lam_boff = rfl(v.w);
+#if defined(__HIP_DEVICE_COMPILE__)
+	typedef unsigned int u8 __attribute__((ext_vector_type(8)));
+	typedef __attribute__((address_space(4))) const u8 *const_ptr8;
+	const u8 v = *((const_ptr8)(uintptr_t)cs.glb + c);           // one s_load_dwordx8
+	r.info = rfl(v[0]); r.idx_boff = rfl(v[1]); r.par_boff = rfl(v[2]); r.lam_boff = rfl(v[3]);
+	r.f_idx_boff = rfl(v[4]); r.f_par_boff = rfl(v[5]); r.f_lam_boff = rfl(v[6]);
+#else
+	r = ChunkS();
+#endif
 	return r;
 }
 __device__ __forceinline__ uint32_t chunk_type(uint32_t info) { return info & 0x3fu; }
@@ -230,13 +245,17 @@ __device__ __forceinline__ void lds_dma16(const float4 *base, uint32_t index, fl
 {
 	const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4 *)lds_wave_base);
 	const uint32_t boff = index * 16u;        // scalar base + 32-bit lane offset: one address register per copy
+	// (the base as a SCALAR pair whatever the compiler knows about its uniformity: kernel-argument pointers fold to themselves, a pointer derived from a
+	// tile descriptor is read from the first lane)
+	const unsigned long long bv = (unsigned long long)(uintptr_t)base;
+	const unsigned long long sbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(bv >> 32)) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)bv);
 	uint32_t saved;      // M0 is a reserved register: preserved around the copy
 	if constexpr (COHERENT)
 		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
-			: "=&s"(saved) : "v"(boff), "s"(base), "s"(m0v) : "memory");
+			: "=&s"(saved) : "v"(boff), "s"(sbase), "s"(m0v) : "memory");
 	else
 		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-			: "=&s"(saved) : "v"(boff), "s"(base), "s"(m0v) : "memory");
+			: "=&s"(saved) : "v"(boff), "s"(sbase), "s"(m0v) : "memory");
 }
 // write-back store of one position
 template <bool COHERENT>
@@ -246,7 +265,11 @@ __device__ __forceinline__ void store_pos(float4 *base, uint32_t index, float4 v
 	{
 		typedef float f4 __attribute__((ext_vector_type(4)));
 		f4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-		asm volatile("global_store_dwordx4 %0, %1, %2 sc1" :: "v"(index * 16u), "v"(w), "s"(base) : "memory");
+		// (the base as an explicitly scalar pair: a uniform pointer the compiler happens to keep in vector registers would otherwise be printed into the
+		// scalar operand as it is -- "invalid operand for instruction")
+		const unsigned long long bv = (unsigned long long)(uintptr_t)base;
+		const unsigned long long sbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(bv >> 32)) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)bv);
+		asm volatile("global_store_dwordx4 %0, %1, %2 sc1" :: "v"(index * 16u), "v"(w), "s"(sbase) : "memory");
 	}
 	else
 		base[index] = v;
@@ -283,6 +306,7 @@ template <int BLOCK, bool COHERENT> struct TileFill
 	uint32_t first;              // local particles [0, first) are already in LDS (multiple of 64; 0 = stage everything)
 	unsigned long long *trace;
 	BndLim lim;                  // (PBDX_BOUNDS builds; zeros and unused otherwise)
+	const uint32_t *lids;        // LDS copy of gid[first .. n_local) (persistent schedule, requested during the previous pass: LdsIds) or null
 
 	// Eight particles per thread and batch.  The positions go from HBM straight into LDS (lds_dma16), so a
 	// batch holds eight ids in registers and nothing else.  All eight ids are consumed by one empty asm statement:
@@ -299,10 +323,11 @@ template <int BLOCK, bool COHERENT> struct TileFill
 		const uint32_t last = n_local - 1u;
 		uint32_t base = first + threadIdx.x;
 #if PBDX_BOUNDS
-#define PBDX_G(k) const uint32_t i##k = base + k * BLOCK; const uint32_t g##k = gid[PBDX_BCLAMP(kBndGid, (i##k < last ? i##k : last), lim.gid_left, lim.tile)];
+#define PBDX_G(k) const uint32_t i##k = base + k * BLOCK; const uint32_t g##k = lids ? lids[PBDX_BCLAMP(kBndLdsIds, (i##k < last ? i##k : last) - first, lim.ids_cap, lim.tile)] \
+	: gid[PBDX_BCLAMP(kBndGid, (i##k < last ? i##k : last), lim.gid_left, lim.tile)];
 #define PBDX_D(k) if (i##k < n_local && PBDX_BOK(kBndParticle, g##k, lim.n_particles, lim.tile) && PBDX_BOK(kBndLdsFill, i##k, lim.lds_f4, lim.tile)) lds_dma16<COHERENT>(pos_in, g##k, lpos + (i##k & ~63u));
 #else
-#define PBDX_G(k) const uint32_t i##k = base + k * BLOCK; const uint32_t g##k = gid[i##k < last ? i##k : last];
+#define PBDX_G(k) const uint32_t i##k = base + k * BLOCK; const uint32_t g##k = lids ? lids[(i##k < last ? i##k : last) - first] : gid[i##k < last ? i##k : last];
 #define PBDX_D(k) if (i##k < n_local) lds_dma16<COHERENT>(pos_in, g##k, lpos + (i##k & ~63u));
 #endif
 #define PBDX_BATCH(BETWEEN) { \
@@ -354,11 +379,6 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 #ifndef PBDX_FETCH_BEFORE_BARRIER
 #define PBDX_FETCH_BEFORE_BARRIER 0
 #endif
-// developer switch (A/B and fault-hunting builds only; see profiles/HISTORY.md [8], [9]): the descriptor of the chunk the NEXT record fetch reads is
-// requested at the end of the current fetch
-#ifndef PBDX_PIPELINE_FETCH_DESC
-#define PBDX_PIPELINE_FETCH_DESC 0
-#endif
 // DICT: a run of dictionary-form steps (FusedStep::dict, pbdx_plan.h): a slot streams its indices, its multiplier and ONE uint16 -- the offset of its
 // parameter record in the tile's table of distinct records, which sits in LDS behind the particles (ltab); the record is read from there when the
 // slot is projected.  Same arithmetic on the same values: bit-identical.
@@ -387,41 +407,38 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 	uint32_t c_ld = c0, c_ex = c0;
 	// the ring lives in named records (not an array): keeps every record in registers
 	RecT r0, r1, r2, r3;
-#if PBDX_PIPELINE_FETCH_DESC
-	ChunkS ch_fetch = load_chunk(lchunks, c0);
-#endif
-	auto fetch = [&](RecT &dst)
+	// (idx_b, par_b, lam_b: byte offsets of the chunk to fetch in the three streams -- from that chunk's own descriptor while the ring is primed, from
+	// the descriptor of the chunk being projected afterwards: FusedChunk::f_*)
+	auto fetch = [&](RecT &dst, uint32_t idx_b, uint32_t par_b, uint32_t lam_b)
 	{
 		// beyond the run the last chunk is fetched again (harmless): the fetch itself stays unconditional.  (Also for waves none of whose lanes
 		// has a slot in the chunk -- small scenes: 6 of 8 waves on the 100 k-tet bar.  Letting those skip the fetch was measured SLOWER, 0.638 ->
 		// 0.650 ms FEM, 0.745 -> 0.827 XPBD distance + volume, profiles/r03q_*: the compiler can no longer count the loads between a fetch and
 		// its use and waits for ALL outstanding loads, i.e. also for the records requested one step ago, and one step is about one memory latency.)
-		// (requesting the NEXT fetch's descriptor at the end of this one, so that the scalar load's latency passes during the projection, measured
-		// -0.9 ... -2.2 % -- and made the heavy-type kernels fault in 7 of 12 runs of tests/test_examples.py, with or without a scalar-cache
-		// invalidation at kernel start, while this form never did: removed, profiles/HISTORY.md [8])
-#if PBDX_PIPELINE_FETCH_DESC
-		const ChunkS ch = ch_fetch;
-#else
-		const ChunkS ch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
-#endif
-		const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, v_tail, a.views[TYPE] };
+		// (round 4 requested the NEXT fetch's descriptor at the end of this one -- a scalar load whose result was live across the projection: -0.9 ... -2.2 %,
+		// and intermittent memory faults in the heavy-type kernels, profiles/HISTORY.md [8], [9]; since round 5 the offsets arrive with the descriptor
+		// of the chunk being projected, which is read a whole sub-iteration ahead anyway)
+		const Acc acc = { lpos, str, idx_b, par_b, lam_b, v_par, v_tail, a.views[TYPE] };
 		if constexpr (DICT)
 		{
 			if constexpr (kTwoBodies[TYPE]) { dst.w[0] = acc.idx_raw1(lane_slot); dst.w[1] = 0u; }
 			else { const uint2 v = acc.idx_raw2(lane_slot); dst.w[0] = v.x; dst.w[1] = v.y; }
 			dst.w[2] = 0u;
 			if constexpr (kHasLambda[TYPE]) dst.w[2] = __builtin_bit_cast(uint32_t, acc.lam_load(lane_slot));
-			dst.w[3] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(str.par, (int)(lane_slot * 2u), (int)ch.par_boff, 0);
+			dst.w[3] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(str.par, (int)(lane_slot * 2u), (int)par_b, 0);
 		}
 		else if constexpr (QUAD) load_rec_quad<TYPE, COMPACT>(acc, ql, lane_slot, dst);
 		else load_rec<TYPE, COMPACT>(acc, lane_slot, dst);
 		c_ld++;
-#if PBDX_PIPELINE_FETCH_DESC
-		ch_fetch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
-#endif
 	};
-	fetch(r0); fetch(r1);
-	if constexpr (D == 4) { fetch(r2); fetch(r3); }
+	// the ring is primed from the first D chunks' own descriptors (once per run)
+	auto prime = [&](RecT &dst)
+	{
+		const ChunkS ch = load_chunk(lchunks, c_ld < run_end ? c_ld : run_end - 1);
+		fetch(dst, ch.idx_boff, ch.par_boff, ch.lam_boff);
+	};
+	prime(r0); prime(r1);
+	if constexpr (D == 4) { prime(r2); prime(r3); }
 	fill_wait(fill_pending, trace);      // (first run of a pass: the positions land while the ring's first records are on their way)
 	// Every sub-iteration issues exactly one record fetch, whether or not a projection still happens in it
 	// (single loop exit at the bottom): the number of memory operations between a fetch and its use is then
@@ -437,9 +454,10 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 		unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
 		if (probing) tA = __builtin_readcyclecounter();
 #endif
+		// (beyond the run `ch` is the run's last descriptor again and the record fetched with it is never used)
+		const ChunkS ch = ch_next;
 		if (c_ex < run_end)
 		{
-			const ChunkS ch = ch_next;
 			const Acc acc = { lpos, str, ch.idx_boff, ch.par_boff, ch.lam_boff, v_par, v_tail, a.views[TYPE] };
 			if (lane_slot < chunk_valid(ch.info))
 			{
@@ -479,7 +497,7 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 			// that was just consumed, so it does not depend on the barrier -- a wave that reaches the barrier early issues its loads while the
 			// others still project (step probes, profiles/r04e: issuing them cost 0.23 us per sub-iteration when all 16 waves did it at once,
 			// right after the barrier, with the SIMDs otherwise idle)
-			fetch(cur);
+			fetch(cur, ch.f_idx_boff, ch.f_par_boff, ch.f_lam_boff);
 #endif
 			if (chunk_last_of_step(ch.info))
 			{
@@ -491,10 +509,11 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 				step_counter++;
 			}
 		}
+		// the record of the chunk D positions ahead, into the ring slot just consumed; its stream offsets came with this chunk's descriptor
 #if PBDX_FETCH_BEFORE_BARRIER
-		else fetch(cur);
+		else fetch(cur, ch.f_idx_boff, ch.f_par_boff, ch.f_lam_boff);
 #else
-		fetch(cur);
+		fetch(cur, ch.f_idx_boff, ch.f_par_boff, ch.f_lam_boff);
 #endif
 #if PBDX_STEP_PROBE
 		if (probing)
@@ -510,11 +529,6 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 		else { sub(r0); sub(r1); }
 		if (c_ex >= run_end) break;
 	}
-#if PBDX_PIPELINE_FETCH_DESC == 2
-	// fault-hunting build: the descriptor requested by the run's last fetch is never used; here it is consumed (the compiler then waits for the scalar
-	// load before the registers can be given to anything else)
-	asm volatile("" :: "s"(ch_fetch.info), "s"(ch_fetch.idx_boff), "s"(ch_fetch.par_boff), "s"(ch_fetch.lam_boff));
-#endif
 	return run_end;
 }
 
@@ -664,14 +678,28 @@ __device__ __forceinline__ void velocity_write_back(const FoldArgs &f, const uin
 	}
 }
 
+// Particle ids kept in LDS by the persistent schedule (round 5).  A pass boundary used to pay two dependent memory round trips in front (particle ids ->
+// positions: the halo fill) and one behind (ids -> stores: the boundary write-back).  The ids are static, and a tile leaves a quarter of the LDS unused:
+//  * halo: right after the fill of pass p every wave requests the id list of the tile's NEXT pass (gid[first .. n_local) of the next segment) with HBM -> LDS
+//    copies; they land during the sweep, are complete at the pass's publish (vmcnt(0) + barrier) and the next fill reads its ids with ds_read;
+//  * boundary: gid[wb_begin .. n_owned) -- the same in every segment -- is copied once, in pass 0, and every boundary write-back reads it from LDS.
+// Only for workgroups with ONE tile (the walk of several tiles changes tile between passes) and where the LDS has the room; the host decides (PersistArgs::ids).
+struct LdsIds
+{
+	uint32_t *halo, *bnd;        // LDS; null = not in use
+	uint32_t halo_cap, bnd_cap;  // entries
+};
+
 // One tile of one segment: LDS fill, colour sweep, write-back of the owned particles.
 // `keep_owned`: the tile's owned particles are still in LDS from its previous pass (persistent schedule, same
 // workgroup, same owned set in every segment): only the halo is staged.  `wait`: see TileFill.
 template <uint32_t MASK, int BLOCK, bool COHERENT, class Wait>
 __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &ra, const float4 *pos_in, float4 *pos_out, uint32_t tile_index,
 	unsigned long long *trace, uint4 *lchunks, float4 *lpos, bool keep_owned, const Wait &wait, const FoldArgs *fold = nullptr, uint32_t fold_phase = 0,
-	bool boundary_only = false)
+	bool boundary_only = false, const LdsIds *ids = nullptr, const SegArgs *sg_next = nullptr, bool halo_ids_ready = false)
 {
+	// ids (persistent schedule, one tile per workgroup): see LdsIds.  sg_next: the segment of this tile's next pass (its halo ids are requested after the
+	// fill) or null; halo_ids_ready: the halo ids of THIS pass were requested during the previous one.
 	// boundary_only (persistent schedule, one workgroup per tile, not the last pass of the launch): the owned particles stay in LDS for the next
 	// pass, so only the ones another tile stages -- [wb_begin, n_owned): the planner orders the interior first -- have to reach memory
 	// fold_phase (persistent schedule only): bit 0 = this pass integrates while it stages, bit 1 = it updates the velocities
@@ -688,10 +716,13 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	(void)PBDX_BOK(kBndChunkRange, t.chunk_end, sg.chunk_count + 1u, tile_index);
 	(void)PBDX_BOK(kBndChunkRange, num_chunks, kMaxTileChunks + 1u, tile_index);
 	(void)PBDX_BOK(kBndLdsFill, t.n_local + t.tab_f4 - 1u, sg.lds_f4, tile_index);
-	const BndLim lim = { sg.gid_count - t.gid_off, sg.n_particles, sg.lds_f4, tile_index };
+	const BndLim lim = { sg.gid_count - t.gid_off, sg.n_particles, sg.lds_f4, tile_index, ids ? ids->halo_cap : 0u };
 #else
-	const BndLim lim = { 0u, 0u, 0u, 0u };
+	const BndLim lim = { 0u, 0u, 0u, 0u, 0u };
 #endif
+	// the next pass's tile descriptor: requested here so that its latency passes during the fill
+	FusedTile tn = t;
+	if (ids && sg_next) tn = sg_next->tiles[tile_index];
 	// stream descriptors, from kernel arguments only (wave-uniform by construction)
 	TileStreams str;
 	str.idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(sg.idx), 0, sg.idx_bytes, 0x00020000);
@@ -719,7 +750,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 		if constexpr (kTabPerThread > 2) { tabv2 = gtab[i0 + 2 * BLOCK < lastf4 ? i0 + 2 * BLOCK : lastf4]; tabv3 = gtab[i0 + 3 * BLOCK < lastf4 ? i0 + 3 * BLOCK : lastf4]; }
 	}
 	const TileFill<BLOCK, COHERENT> fill = { reinterpret_cast<const uint4 *>(gchunks), gid, pos_in, lchunks, lpos, num_chunks, t.n_local,
-		keep_owned ? (t.n_owned & ~63u) : 0u, trace, lim };
+		keep_owned ? (t.n_owned & ~63u) : 0u, trace, lim, (ids && keep_owned && halo_ids_ready) ? ids->halo : nullptr };
 	bool staged = false;
 	if constexpr (COHERENT)
 		if (fold_phase & 1u)
@@ -728,6 +759,29 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			staged = true;
 		}
 	if (!staged) fill(wait);
+	if (ids)
+	{
+		// (the fill ended with vmcnt(0) + barrier: every id it read from ids->halo has been consumed)
+		constexpr uint32_t kPerPass = 4u * (uint32_t)BLOCK;      // ids one workgroup-wide round of 16-byte copies moves
+		if (sg_next)
+		{
+			const uint32_t nfirst = tn.n_owned & ~63u, count = tn.n_local - nfirst;      // gid[nfirst .. n_local) of the next pass; 16-byte aligned: gid_off and nfirst are multiples of 4
+			const float4 *src = reinterpret_cast<const float4 *>(sg_next->gid + tn.gid_off + nfirst);
+			for (uint32_t j = threadIdx.x; 4u * j < count; j += BLOCK)
+				if (PBDX_BOK(kBndLdsIds, 4u * j + 3u, ids->halo_cap, tile_index) && PBDX_BOK(kBndGid, tn.gid_off + nfirst + 4u * j + 3u, sg_next->gid_count_dbg(), tile_index))
+					lds_dma16<false>(src, j, reinterpret_cast<float4 *>(ids->halo) + (j & ~63u));
+			(void)kPerPass;
+		}
+		if (fold_phase & 1u)
+		{
+			// pass 0 of a launch: the boundary ids, once (read by the write-backs after the wait below)
+			const uint32_t b0 = t.wb_begin & ~3u, count = t.n_owned - b0;
+			const float4 *src = reinterpret_cast<const float4 *>(gid + b0);
+			for (uint32_t j = threadIdx.x; 4u * j < count; j += BLOCK)
+				if (PBDX_BOK(kBndLdsIds, 4u * j + 3u, ids->bnd_cap, tile_index))
+					lds_dma16<false>(src, j, reinterpret_cast<float4 *>(ids->bnd) + (j & ~63u));
+		}
+	}
 	if (t.tab_f4)
 	{
 		const uint32_t i0 = threadIdx.x;
@@ -767,6 +821,18 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			velocity_write_back<BLOCK>(*fold, gid, pos_out, lpos, t.n_owned, lim);
 			written = true;
 		}
+	// write-back of the boundary particles with their ids from LDS (LdsIds): no memory round trip in front of the stores
+	if (!written && ids && boundary_only)
+	{
+		if (fold_phase & 1u) { lds_dma_wait(); __syncthreads(); }      // (pass 0: the copy of the boundary ids was requested above)
+		const uint32_t b0 = t.wb_begin & ~3u;
+		for (uint32_t i = t.wb_begin + threadIdx.x; i < t.n_owned; i += BLOCK)
+		{
+			const uint32_t g = ids->bnd[PBDX_BCLAMP(kBndLdsIds, i - b0, ids->bnd_cap, tile_index)];
+			if (PBDX_BOK(kBndParticle, g, lim.n_particles, lim.tile)) store_pos<COHERENT>(pos_out, g, lpos[i]);
+		}
+		written = true;
+	}
 	// write-back of the owned particles, ids batched like the fill
 	if (!written)
 	{
@@ -847,6 +913,9 @@ struct PersistArgs
 	FoldArgs fold;
 	int start;                                    // position buffer pass 0 reads
 	float dt;
+	// particle ids resident in LDS (LdsIds; one tile per workgroup only): offsets of the two regions from the start of the dynamic LDS in 16-byte units
+	// and their capacities in ids; ids_halo_cap == 0: not in use
+	uint32_t ids_halo_off16, ids_bnd_off16, ids_halo_cap, ids_bnd_cap;
 #if PBDX_BOUNDS
 	uint32_t dep_count[kMaxPersistSegs];          // entries of dep_tile
 #endif
@@ -940,8 +1009,13 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 			unsigned long long *trace = (a.trace[sgi] && pass + a.num_segs >= a.passes) ? a.trace[sgi] + (size_t)tile * kTraceStride : nullptr;
 			const uint32_t fold_phase = a.folded ? ((pass == 0 ? 1u : 0u) | (pass + 1u == a.passes ? 2u : 0u)) : 0u;
 			const bool keeps = PBDX_WALK_TILES || m == 1u;      // (PBDX_WALK_TILES = 0: only one-tile workgroups keep their particles, the form before round 4)
+			// particle ids in LDS (LdsIds): one tile per workgroup, folded launch (pass 0 stages everything and copies the boundary ids)
+			const bool use_ids = a.ids_halo_cap != 0u && m == 1u && a.folded;
+			const LdsIds ids = { reinterpret_cast<uint32_t *>(lds_raw + a.ids_halo_off16), reinterpret_cast<uint32_t *>(lds_raw + a.ids_bnd_off16), a.ids_halo_cap, a.ids_bnd_cap };
+			const uint32_t sgi_next = sgi + 1u == a.num_segs ? 0u : sgi + 1u;
 			process_tile<MASK, BLOCK, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && first_of_pass && keeps, wait, &a.fold, fold_phase,
-				last_of_pass && keeps && pass + 1u != a.passes && !PBDX_FULL_WRITE_BACK);
+				last_of_pass && keeps && pass + 1u != a.passes && !PBDX_FULL_WRITE_BACK, use_ids ? &ids : nullptr,
+				(use_ids && pass + 1u != a.passes) ? &a.seg[sgi_next] : nullptr, use_ids && pass != 0u);
 			if (s_failed)
 			{
 				// a neighbour never arrived: the state of this step is garbage.  Say so, turn every later kernel of the call
@@ -1395,6 +1469,7 @@ struct pbdx_solver
 	persist_fn persist_kernel = nullptr;
 	int persist_block = 0;
 	uint32_t persist_lds = 0, persist_grid = 0;
+	uint32_t ids_halo_off16 = 0, ids_bnd_off16 = 0, ids_halo_cap = 0, ids_bnd_cap = 0;      // particle ids resident in LDS (LdsIds)
 	uint32_t *d_epoch = nullptr;
 	uint32_t *h_error = nullptr, *d_error = nullptr;   // page-locked host words the persistent kernel raises: [0] timeout, [1] launch refused, [2] at substep
 	uint32_t *d_ctl = nullptr;           // kCtl* device words
@@ -1643,6 +1718,28 @@ int prepare_persistent(pbdx_solver *s)
 	HIPCHECK(hipMalloc(&s->d_epoch, ((size_t)k + 2) * sizeof(uint32_t)));      // + arrivals, decision
 	s->persist_block = s->dsegs[0].block;
 	s->persist_lds = lds;
+	// particle ids resident in LDS (LdsIds): room for the largest halo id list and the largest boundary id list behind the largest tile image
+	s->ids_halo_cap = s->ids_bnd_cap = 0;
+	if (!getenv("PBDX_NO_LDS_IDS"))
+	{
+		uint32_t hmax = 0, bmax = 0;
+		for (const FusedSegment &seg : s->plan.segs)
+			for (const FusedTile &t : seg.tiles)
+			{
+				hmax = std::max(hmax, t.n_local - (t.n_owned & ~63u));
+				bmax = std::max(bmax, t.n_owned - (t.wb_begin & ~3u));
+			}
+		const uint32_t hcap = (hmax + 255u) & ~255u, bcap = (bmax + 255u) & ~255u;      // (whole 1 KiB wave copies)
+		const size_t cap = s->prop.maxSharedMemoryPerMultiProcessor ? s->prop.maxSharedMemoryPerMultiProcessor : s->prop.sharedMemPerBlock;
+		const uint32_t base16 = (lds + 15u) / 16u;
+		if ((size_t)base16 * 16u + (size_t)(hcap + bcap) * 4u + 64u <= cap / s->persist_wgs_per_cu)
+		{
+			s->ids_halo_off16 = base16; s->ids_bnd_off16 = base16 + hcap / 4u;
+			s->ids_halo_cap = hcap; s->ids_bnd_cap = bcap;
+			s->persist_lds = (base16 + (hcap + bcap) / 4u) * 16u;
+			lds = s->persist_lds;
+		}
+	}
 	s->persist_kernel = pick_persistent_kernel(mask, s->persist_block);
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(s->persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	// every workgroup must be resident: at most as many as the occupancy query admits (one per tile otherwise)
@@ -1779,7 +1876,7 @@ int ensure_plan(pbdx_solver *s)
 					const uint32_t first = k * cap;
 					const uint32_t valid = std::min<uint32_t>(cap, st.count - first);
 					const bool last = (k + 1 == nchunks);
-					FusedChunk c;
+					FusedChunk c = {};
 					c.info = (st.dict ? kDictChunkType + st.type : quad_step ? kQuadStrainChunk : st.type) | ((last && st.barrier) ? 0x40u : 0u) | (last ? 0x80u : 0u) | (valid << 8);
 					c.idx_boff = st.idx_off * 2u + first * slot_idx_bytes;
 					c.par_boff = st.dict ? st.par_off * 4u + first * 2u : (st.par_off + (first / 64u) * nplanes * 64u) * 4u;       // (dictionary form: one uint16 per slot)
@@ -1796,6 +1893,15 @@ int ensure_plan(pbdx_solver *s)
 				const bool same = (ci + 1 < t.chunk_end) && ((chunks[ci + 1].info & 0x3fu) == (chunks[ci].info & 0x3fu));
 				left = same ? left + 1 : 1;
 				chunks[ci].info |= std::min(left, 8191u) << 19;
+			}
+			// ... and where the chunk fetched while chunk ci is projected sits in the streams: `ring depth` positions ahead, the run's last chunk beyond its end
+			for (uint32_t ci = t.chunk_begin; ci < t.chunk_end; ci++)
+			{
+				const uint32_t ctype = chunks[ci].info & 0x3fu, run_left = chunks[ci].info >> 19;
+				const int real_type = ctype >= kDictChunkType ? (int)(ctype - kDictChunkType) : ctype == kQuadStrainChunk ? (int)PBDX_STRAIN_TET : (int)ctype;
+				const uint32_t depth = (uint32_t)ring_depth(real_type);
+				const FusedChunk &f = chunks[ci + std::min(depth, run_left - 1u)];
+				chunks[ci].f_idx_boff = f.idx_boff; chunks[ci].f_par_boff = f.par_boff; chunks[ci].f_lam_boff = f.lam_boff; chunks[ci].pad = 0u;
 			}
 		}
 		if (too_many)
@@ -1952,6 +2058,11 @@ int launch_persistent(pbdx_solver *s, int src, float dt, uint32_t iterations, co
 	a.start = src;
 	a.dt = dt;
 	if (fold) { a.folded = 1; a.fold = *fold; }
+	// (one tile per workgroup: decided again in the kernel from its own grid)
+	if (s->ids_halo_cap && s->persist_grid == s->plan.num_tiles)
+	{
+		a.ids_halo_off16 = s->ids_halo_off16; a.ids_bnd_off16 = s->ids_bnd_off16; a.ids_halo_cap = s->ids_halo_cap; a.ids_bnd_cap = s->ids_bnd_cap;
+	}
 	memcpy(a.views, s->plan.views, sizeof(a.views));
 	HIPCHECK(hipMemsetAsync(s->d_epoch, 0, ((size_t)s->plan.num_tiles + 2) * sizeof(uint32_t), s->stream));
 	hipLaunchKernelGGL(s->persist_kernel, dim3(s->persist_grid), dim3(s->persist_block), s->persist_lds, s->stream, a);

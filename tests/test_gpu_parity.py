@@ -561,11 +561,16 @@ def test_c4_ensemble_block_of_instances_vs_reference(pbd):
     constraints) against the reference on the same model, 2 steps x 10 iterations, bit-identical."""
     import time
     ops = util.cloth_spec(200, 200, 4, 3, instances=64, instance_offset=(0.0, 0.0, 12.0), instanced=True)
-    want = _reference_states(ops, 10, [2], threads=32)           # the reference builds the 64 sheets one after the other
+    want = _reference_states(ops, 10, [2, 10], threads=32)       # the reference builds the 64 sheets one after the other
     t0 = time.perf_counter()
     m = util.build_mine(ops)
     m.initConstraintGroups()
     t_build = time.perf_counter() - t0
+    # ... and at 10 steps (VERDICT r4: the walk -- two tiles per workgroup, alternating order -- was pinned at 2 steps only), on the schedule the bench times
+    m10, ts10 = util.mine_run(ops, 10, 1, 10, resident=True, options={pbd.Solver.OPT_PERSISTENT: 2})
+    p10 = ts10.solver().persistent_info()
+    assert p10["active"] == 1 and p10["refusals"] == 0 and p10["timeouts"] == 0 and ts10.solver().plan_info()["num_tiles"] > p10["grid"], "more tiles than workgroups: the walk"
+    assert util.bitwise_equal(m10.getParticles().positions(), want[10][0]) and util.bitwise_equal(m10.getParticles().array(2), want[10][1])
     m, ts = util.mine_run(ops, 2, 1, 10, resident=True)
     d = ts.solver().describe()
     print("C4 block: host build + colouring %.3f s; %s" % (t_build, d))
@@ -579,6 +584,36 @@ def test_c4_ensemble_block_of_instances_vs_reference(pbd):
     m2, ts2 = util.mine_run(expand_instances(ops), 2, 1, 10, resident=True)
     assert "replicated" not in ts2.solver().describe()
     assert util.bitwise_equal(m2.getParticles().positions(), want[2][0])
+
+
+def test_walk_of_a_1500x1500_sheet_vs_reference(pbd):
+    """What bench.py's size sweep reports above 1 M particles: a 1500x1500 sheet (2 250 000 particles, 13.5 M constraints) needs
+    2-3 tiles per workgroup, which the persistent schedule walks in alternating order with the tile at the turn kept in LDS.  2 steps x 10 iterations
+    against the reference's float build (16 threads), every position and velocity bit for bit, on the forced and asserted one-launch schedule."""
+    S = pbd.Solver
+    ops = util.cloth_spec(1500, 1500, 4, 3)
+    want = _reference_states(ops, 10, [2], threads=32)
+    m, ts = util.mine_run(ops, 2, 1, 10, resident=True, options={S.OPT_PERSISTENT: 2})
+    info, pinfo = ts.solver().plan_info(), ts.solver().persistent_info()
+    print("1500x1500 sheet: %s | %s" % (info, pinfo))
+    assert pinfo["active"] == 1 and pinfo["refusals"] == 0 and pinfo["timeouts"] == 0 and pinfo["last_folded"] == 1
+    assert info["num_tiles"] >= 2 * pinfo["grid"], "at least two tiles per workgroup: the walk is what is tested"
+    assert util.bitwise_equal(m.getParticles().positions(), want[2][0]), "max err %.3e" % util.max_err(m.getParticles().positions(), want[2][0])
+    assert util.bitwise_equal(m.getParticles().array(2), want[2][1])
+
+
+def test_32_instanced_100k_tet_bars_vs_reference(pbd):
+    """bench.py's extra line `c3_x32_fem` (the form in which configs[2] fills the GPU): 32 instanced 101x21x11 FEM bars, 3.2 M tets, 2 steps x 10
+    iterations against the reference on the same 32-bar model, bit for bit; the plan is one instance's, replicated."""
+    from positionbaseddynamics_amd import scenes
+    ops = scenes.bar_spec(101, 21, 11, 2, instances=32, instanced=True)
+    want = _reference_states(ops, 10, [2], threads=32)
+    m, ts = util.mine_run(ops, 2, 1, 10, resident=True)
+    d = ts.solver().describe()
+    print("32 bars: %s" % d)
+    assert m.numInstances() == 32 and m.getParticles().size() == 32 * 23331 and "one instance planned, replicated" in d
+    assert util.bitwise_equal(m.getParticles().positions(), want[2][0]), "max err %.3e" % util.max_err(m.getParticles().positions(), want[2][0])
+    assert util.bitwise_equal(m.getParticles().array(2), want[2][1])
 
 
 # ---------------------------------------------------------------------------
