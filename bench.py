@@ -953,6 +953,51 @@ def spawn_ranks(n, argv):
         raise SystemExit("bench.py: rank exit codes %r" % (rcs,))
 
 
+def single_process_ensemble(args):
+    """BASELINE configs[3] over N devices of ONE process through the C ABI (include/pbdx.h pbdx_ensemble_*): --instances 200x200 sheets per device in one
+    instanced model, split into contiguous blocks, one engine + stream + host thread per device, no torch.distributed.  Same contract line as the
+    one-process-per-GPU form (weak scaling: value = all devices' projections / wall time of the K timed steps)."""
+    import positionbaseddynamics_amd as pbd
+    from positionbaseddynamics_amd import scenes
+    ndev = pbd.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if max(devices) >= ndev:
+        raise SystemExit("bench.py --single-process: device list %r but %d GPU(s) visible" % (devices, ndev))
+    size = args.size or 200
+    total = args.instances * len(devices)
+    ops = scenes.cloth_spec(size, size, 4, 3, instances=total, instance_offset=(0.0, 0.0, 12.0), instanced=True)
+    t0 = time.perf_counter()
+    model = scenes.build_model(ops)
+    model.initConstraintGroups()
+    t_build = time.perf_counter() - t0
+    pbd.TimeManager.getCurrent().setTimeStepSize(0.005)
+    e = pbd.DeviceEnsemble(devices)
+    e.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+    e.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, args.iters)
+    e.setModel(model)
+    e.step(max(args.warmup, 1))
+    t0 = time.perf_counter()
+    e.step(args.steps)                     # returns when every device's stream has drained
+    t = time.perf_counter() - t0
+    e.gather()
+    x = model.getParticles().positions()
+    ok = bool(np.all(np.isfinite(x)))
+    nc = model.numConstraints()
+    blocks = [e.shard(i) for i in range(e.numShards())]
+    out = {"metric": "constraint-projections/s", "value": nc * args.iters * args.steps / t, "unit": "projections/s", "n_gpus": len(set(devices)), "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * t / args.steps, "ms_per_substep": 1e3 * t / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[3] in ONE process (pbdx_ensemble_*): %d x (%dx%d) cloth instances, %d per engine, XPBD distance + XPBD isometric bending, %d iterations x 1 substep" % (
+                          total, size, size, args.instances, args.iters),
+                      "parallelism": "single process, %d engines on devices %r, contiguous blocks of instances, no collective" % (len(devices), devices),
+                      "particles": model.getParticles().size(), "constraints": nc, "projections_per_substep": nc * args.iters, "state_ok": ok,
+                      "blocks": blocks, "per_block_ms_per_step": [b["last_step_ms"] / args.steps for b in blocks], "host_scene_build_s": t_build,
+                      "engines": [e.shardSolver(i).describe()[-150:] for i in range(e.numShards()) if blocks[i]["end"] > blocks[i]["begin"]]}}
+    print(json.dumps(_r(out), separators=(",", ":")), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -988,11 +1033,16 @@ def main():
     ap.add_argument("--dry-line", nargs="?", const=os.path.join(ROOT, "profiles", "r02_bench.json"), default=None,
                     help="no GPU: print the compact lines for a stored FULL record (default profiles/r02_bench.json)")
     ap.add_argument("--check-shards", action="store_true", help="c4: every rank also steps ITS instances with the reference (oracle/_ref f32) and compares bits (small sizes only)")
+    ap.add_argument("--single-process", action="store_true", help="c4 with --gpus N in ONE process: the C ABI's pbdx_ensemble_* (one engine per device, all devices stepping at once, no torch.distributed); "
+                    "a second way to measure ensemble scaling")
+    ap.add_argument("--devices", type=str, default=None, help="--single-process: comma-separated HIP device list (default 0..N-1; a device may repeat: smoke test on one GPU)")
     ap.add_argument("--rank-selftest", action="store_true", help="launcher self-test: the ranks rendezvous, exchange their rank numbers and exit (no GPU work, no metric)")
     args = ap.parse_args()
 
     if args.dry_line:
         return dry_line(args.dry_line)
+    if args.single_process:
+        return single_process_ensemble(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
         return spawn_ranks(args.gpus, sys.argv[1:])
 

@@ -647,6 +647,37 @@ int pbdx_timestep_project(pbdx_timestep *ts, pbdx_model *m, uint32_t iterations)
 /* the engine underneath (owned by the timestep; created on demand, NULL without a HIP device) */
 pbdx_solver *pbdx_timestep_solver(pbdx_timestep *ts);
 
+/* ======================================================================== */
+/* pbdx_ensemble -- independent instances over several devices, one process  */
+/* ======================================================================== */
+/* a single scene does not shard (one connected colour-sequential Gauss-Seidel problem; the reference itself is one process on one model,
+ * Simulation/TimeStepController.cpp:75-241); a model of K congruent independent instances (pbdx_model_add_instances) does -- contiguous blocks of
+ * instances (pbdx_ensemble_shard), one per device, no exchange on the data path.  One engine (time step, solver, stream, device image) per entry of
+ * `devices`; a device may be listed more than once (its blocks then share it).  A step runs every device's block concurrently (one host thread per device
+ * for the duration of the call; every entry point selects its device and restores the caller's).  A single process needs no collective: what RCCL
+ * reduces between the ranks of `bench.py --gpus N` is available on the host here. */
+typedef struct pbdx_ensemble pbdx_ensemble;
+int pbdx_ensemble_create(pbdx_ensemble **out, const int *devices, uint32_t n);
+void pbdx_ensemble_destroy(pbdx_ensemble *e);
+uint32_t pbdx_ensemble_num_shards(const pbdx_ensemble *e);
+/* parameters of every engine (ids, names and defaults of pbdx_timestep_set_param / TimeStepController.cpp:47-72) */
+int pbdx_ensemble_set_param(pbdx_ensemble *e, int id, int64_t value);
+int pbdx_ensemble_set_gravity(pbdx_ensemble *e, const float g[3]);
+int pbdx_ensemble_set_time_step_size(pbdx_ensemble *e, float h);
+/* Splits `m` into one block of instances per device (fewer instances than devices: the surplus devices stay idle; a model without instances is one
+ * block).  The blocks are COPIES: after editing `m` call this again.  Every record of a block is bit for bit the whole model's. */
+int pbdx_ensemble_set_model(pbdx_ensemble *e, const pbdx_model *m);
+/* `num_steps` steps of every block, device-resident, all devices at once; returns when all are done. */
+int pbdx_ensemble_step(pbdx_ensemble *e, uint32_t num_steps);
+/* The blocks' particle state (x, v, oldX, lastX) into the arrays of the model given to pbdx_ensemble_set_model. */
+int pbdx_ensemble_gather(pbdx_ensemble *e, pbdx_model *m);
+/* Block `shard`: its device, its instances [*begin, *end) and the host wall time of its last step call; the engine and the block model behind it
+ * (plan / schedule / timing queries: pbdx_timestep_solver + pbdx_solver_get_*); wall time of the last pbdx_ensemble_step over all devices. */
+int pbdx_ensemble_get_shard(const pbdx_ensemble *e, uint32_t shard, int *device, uint64_t *begin, uint64_t *end, double *last_step_ms);
+pbdx_timestep *pbdx_ensemble_timestep(pbdx_ensemble *e, uint32_t shard);
+pbdx_model *pbdx_ensemble_shard_model(pbdx_ensemble *e, uint32_t shard);
+double pbdx_ensemble_last_step_ms(const pbdx_ensemble *e);
+
 #ifdef __cplusplus
 }
 #endif

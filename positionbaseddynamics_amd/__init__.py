@@ -613,6 +613,62 @@ class TimeStepController:
         return Solver(handle=h, owner=self)
 
 
+class DeviceEnsemble:
+    """pbdx_ensemble_*: independent instances of one model over several HIP devices of THIS process -- contiguous blocks of instances, one
+    engine per entry of `devices` (a device may be listed twice), all devices stepping at once, no exchange on the data path.  The multi-process form
+    (one rank per GPU, RCCL for the bookkeeping) is positionbaseddynamics_amd.ensemble / bench.py --gpus N."""
+
+    def __init__(self, devices):
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        check(lib.pbdx_ensemble_create(C.byref(h), devs, len(devices)), "pbdx_ensemble_create")
+        self._h = h
+        self._model = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib.pbdx_ensemble_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def setValueUInt(self, pid, v):
+        check(lib.pbdx_ensemble_set_param(self._h, pid, int(v)), "pbdx_ensemble_set_param")
+
+    def setModel(self, model):
+        tm = TimeManager.getCurrent()
+        check(lib.pbdx_ensemble_set_time_step_size(self._h, float(tm._h)), "pbdx_ensemble_set_time_step_size")
+        g = Simulation.getCurrent()._gravity if Simulation.hasCurrent() else np.array([0, -9.81, 0], dtype=np.float32)
+        check(lib.pbdx_ensemble_set_gravity(self._h, _f(_vec(g, 3))), "pbdx_ensemble_set_gravity")
+        check(lib.pbdx_ensemble_set_model(self._h, model._h), "pbdx_ensemble_set_model")
+        self._model = model
+
+    def step(self, numSteps=1):
+        check(lib.pbdx_ensemble_step(self._h, int(numSteps)), "pbdx_ensemble_step")
+
+    def gather(self):
+        check(lib.pbdx_ensemble_gather(self._h, self._model._h), "pbdx_ensemble_gather")
+
+    def numShards(self):
+        return int(lib.pbdx_ensemble_num_shards(self._h))
+
+    def shard(self, i):
+        dev, b, e, ms = C.c_int(0), C.c_uint64(0), C.c_uint64(0), C.c_double(0.0)
+        check(lib.pbdx_ensemble_get_shard(self._h, int(i), C.byref(dev), C.byref(b), C.byref(e), C.byref(ms)), "pbdx_ensemble_get_shard")
+        return {"device": int(dev.value), "begin": int(b.value), "end": int(e.value), "last_step_ms": float(ms.value)}
+
+    def shardSolver(self, i):
+        ts = lib.pbdx_ensemble_timestep(self._h, int(i))
+        h = lib.pbdx_timestep_solver(ts) if ts else None
+        if not h:
+            raise PbdxError(2, "DeviceEnsemble.shardSolver")
+        return Solver(handle=h, owner=self)
+
+    def lastStepMs(self):
+        return float(lib.pbdx_ensemble_last_step_ms(self._h))
+
+
 class Solver:
     """The raw device engine (pbdx_solver_*): what a reference-side TimeStep plug-in binds to."""
 

@@ -195,6 +195,11 @@ SIGNATURES = [
     ("pbdx_timestep_step_resident", C.c_int, vp, vp, u32), ("pbdx_timestep_sync_to_host", C.c_int, vp, vp),
     ("pbdx_timestep_sync_from_host", C.c_int, vp, vp), ("pbdx_model_mark_state_dirty", C.c_int, vp),
     ("pbdx_timestep_invalidate", C.c_int, vp), ("pbdx_timestep_project", C.c_int, vp, vp, u32), ("pbdx_timestep_solver", vp, vp),
+    ("pbdx_ensemble_create", C.c_int, C.POINTER(vp), C.POINTER(C.c_int), u32), ("pbdx_ensemble_destroy", None, vp), ("pbdx_ensemble_num_shards", u32, vp),
+    ("pbdx_ensemble_set_param", C.c_int, vp, C.c_int, i64), ("pbdx_ensemble_set_gravity", C.c_int, vp, pf), ("pbdx_ensemble_set_time_step_size", C.c_int, vp, f32),
+    ("pbdx_ensemble_set_model", C.c_int, vp, vp), ("pbdx_ensemble_step", C.c_int, vp, u32), ("pbdx_ensemble_gather", C.c_int, vp, vp),
+    ("pbdx_ensemble_get_shard", C.c_int, vp, u32, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)),
+    ("pbdx_ensemble_timestep", vp, vp, u32), ("pbdx_ensemble_shard_model", vp, vp, u32), ("pbdx_ensemble_last_step_ms", C.c_double, vp),
 ]
 
 for _s in SIGNATURES:

@@ -248,7 +248,7 @@ __device__ __forceinline__ void lds_dma16(const float4 *base, uint32_t index, fl
 	// (the base as a SCALAR pair whatever the compiler knows about its uniformity: kernel-argument pointers fold to themselves, a pointer derived from a
 	// tile descriptor is read from the first lane)
 	const unsigned long long bv = (unsigned long long)(uintptr_t)base;
-	const unsigned long long sbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(bv >> 32)) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)bv);
+	const unsigned long long sbase = ((unsigned long long)rfl((uint32_t)(bv >> 32)) << 32) | (unsigned long long)rfl((uint32_t)bv);      // (rfl returns uint32_t: the builtin's int would sign-extend the low half)
 	uint32_t saved;      // M0 is a reserved register: preserved around the copy
 	if constexpr (COHERENT)
 		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
@@ -268,7 +268,7 @@ __device__ __forceinline__ void store_pos(float4 *base, uint32_t index, float4 v
 		// (the base as an explicitly scalar pair: a uniform pointer the compiler happens to keep in vector registers would otherwise be printed into the
 		// scalar operand as it is -- "invalid operand for instruction")
 		const unsigned long long bv = (unsigned long long)(uintptr_t)base;
-		const unsigned long long sbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(bv >> 32)) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)bv);
+		const unsigned long long sbase = ((unsigned long long)rfl((uint32_t)(bv >> 32)) << 32) | (unsigned long long)rfl((uint32_t)bv);      // (rfl returns uint32_t: the builtin's int would sign-extend the low half)
 		asm volatile("global_store_dwordx4 %0, %1, %2 sc1" :: "v"(index * 16u), "v"(w), "s"(sbase) : "memory");
 	}
 	else
@@ -686,8 +686,8 @@ __device__ __forceinline__ void velocity_write_back(const FoldArgs &f, const uin
 // Only for workgroups with ONE tile (the walk of several tiles changes tile between passes) and where the LDS has the room; the host decides (PersistArgs::ids).
 struct LdsIds
 {
-	uint32_t *halo, *bnd;        // LDS; null = not in use
-	uint32_t halo_cap, bnd_cap;  // entries
+	uint32_t *halo = nullptr, *bnd = nullptr;      // LDS; halo == null: not in use
+	uint32_t halo_cap = 0, bnd_cap = 0;            // entries
 };
 
 // One tile of one segment: LDS fill, colour sweep, write-back of the owned particles.
@@ -696,10 +696,12 @@ struct LdsIds
 template <uint32_t MASK, int BLOCK, bool COHERENT, class Wait>
 __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &ra, const float4 *pos_in, float4 *pos_out, uint32_t tile_index,
 	unsigned long long *trace, uint4 *lchunks, float4 *lpos, bool keep_owned, const Wait &wait, const FoldArgs *fold = nullptr, uint32_t fold_phase = 0,
-	bool boundary_only = false, const LdsIds *ids = nullptr, const SegArgs *sg_next = nullptr, bool halo_ids_ready = false)
+	bool boundary_only = false, const LdsIds ids = LdsIds(), const SegArgs &sg_next = SegArgs(), bool have_next = false, bool halo_ids_ready = false)
 {
-	// ids (persistent schedule, one tile per workgroup): see LdsIds.  sg_next: the segment of this tile's next pass (its halo ids are requested after the
-	// fill) or null; halo_ids_ready: the halo ids of THIS pass were requested during the previous one.
+	// ids (persistent schedule, one tile per workgroup; ids.halo == null: not in use): see LdsIds.  sg_next / have_next: the segment of this tile's next
+	// pass (its halo ids are requested after the fill); halo_ids_ready: the halo ids of THIS pass were requested during the previous one.  (Everything by
+	// value or by reference to a kernel argument: a conditional POINTER to one makes the compiler copy the whole argument block into scratch.)
+	const bool use_ids = ids.halo != nullptr;
 	// boundary_only (persistent schedule, one workgroup per tile, not the last pass of the launch): the owned particles stay in LDS for the next
 	// pass, so only the ones another tile stages -- [wb_begin, n_owned): the planner orders the interior first -- have to reach memory
 	// fold_phase (persistent schedule only): bit 0 = this pass integrates while it stages, bit 1 = it updates the velocities
@@ -716,13 +718,13 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 	(void)PBDX_BOK(kBndChunkRange, t.chunk_end, sg.chunk_count + 1u, tile_index);
 	(void)PBDX_BOK(kBndChunkRange, num_chunks, kMaxTileChunks + 1u, tile_index);
 	(void)PBDX_BOK(kBndLdsFill, t.n_local + t.tab_f4 - 1u, sg.lds_f4, tile_index);
-	const BndLim lim = { sg.gid_count - t.gid_off, sg.n_particles, sg.lds_f4, tile_index, ids ? ids->halo_cap : 0u };
+	const BndLim lim = { sg.gid_count - t.gid_off, sg.n_particles, sg.lds_f4, tile_index, ids.halo_cap };
 #else
 	const BndLim lim = { 0u, 0u, 0u, 0u, 0u };
 #endif
 	// the next pass's tile descriptor: requested here so that its latency passes during the fill
 	FusedTile tn = t;
-	if (ids && sg_next) tn = sg_next->tiles[tile_index];
+	if (use_ids && have_next) tn = sg_next.tiles[tile_index];
 	// stream descriptors, from kernel arguments only (wave-uniform by construction)
 	TileStreams str;
 	str.idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(sg.idx), 0, sg.idx_bytes, 0x00020000);
@@ -750,7 +752,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 		if constexpr (kTabPerThread > 2) { tabv2 = gtab[i0 + 2 * BLOCK < lastf4 ? i0 + 2 * BLOCK : lastf4]; tabv3 = gtab[i0 + 3 * BLOCK < lastf4 ? i0 + 3 * BLOCK : lastf4]; }
 	}
 	const TileFill<BLOCK, COHERENT> fill = { reinterpret_cast<const uint4 *>(gchunks), gid, pos_in, lchunks, lpos, num_chunks, t.n_local,
-		keep_owned ? (t.n_owned & ~63u) : 0u, trace, lim, (ids && keep_owned && halo_ids_ready) ? ids->halo : nullptr };
+		keep_owned ? (t.n_owned & ~63u) : 0u, trace, lim, (use_ids && keep_owned && halo_ids_ready) ? ids.halo : nullptr };
 	bool staged = false;
 	if constexpr (COHERENT)
 		if (fold_phase & 1u)
@@ -759,18 +761,16 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			staged = true;
 		}
 	if (!staged) fill(wait);
-	if (ids)
+	if (use_ids)
 	{
-		// (the fill ended with vmcnt(0) + barrier: every id it read from ids->halo has been consumed)
-		constexpr uint32_t kPerPass = 4u * (uint32_t)BLOCK;      // ids one workgroup-wide round of 16-byte copies moves
-		if (sg_next)
+		// (the fill ended with vmcnt(0) + barrier: every id it read from ids.halo has been consumed)
+		if (have_next)
 		{
 			const uint32_t nfirst = tn.n_owned & ~63u, count = tn.n_local - nfirst;      // gid[nfirst .. n_local) of the next pass; 16-byte aligned: gid_off and nfirst are multiples of 4
-			const float4 *src = reinterpret_cast<const float4 *>(sg_next->gid + tn.gid_off + nfirst);
+			const float4 *src = reinterpret_cast<const float4 *>(sg_next.gid + tn.gid_off + nfirst);
 			for (uint32_t j = threadIdx.x; 4u * j < count; j += BLOCK)
-				if (PBDX_BOK(kBndLdsIds, 4u * j + 3u, ids->halo_cap, tile_index) && PBDX_BOK(kBndGid, tn.gid_off + nfirst + 4u * j + 3u, sg_next->gid_count_dbg(), tile_index))
-					lds_dma16<false>(src, j, reinterpret_cast<float4 *>(ids->halo) + (j & ~63u));
-			(void)kPerPass;
+				if (PBDX_BOK(kBndLdsIds, 4u * j + 3u, ids.halo_cap, tile_index) && PBDX_BOK(kBndGid, tn.gid_off + nfirst + 4u * j + 3u, sg_next.gid_count_dbg(), tile_index))
+					lds_dma16<false>(src, j, reinterpret_cast<float4 *>(ids.halo) + (j & ~63u));
 		}
 		if (fold_phase & 1u)
 		{
@@ -778,8 +778,8 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			const uint32_t b0 = t.wb_begin & ~3u, count = t.n_owned - b0;
 			const float4 *src = reinterpret_cast<const float4 *>(gid + b0);
 			for (uint32_t j = threadIdx.x; 4u * j < count; j += BLOCK)
-				if (PBDX_BOK(kBndLdsIds, 4u * j + 3u, ids->bnd_cap, tile_index))
-					lds_dma16<false>(src, j, reinterpret_cast<float4 *>(ids->bnd) + (j & ~63u));
+				if (PBDX_BOK(kBndLdsIds, 4u * j + 3u, ids.bnd_cap, tile_index))
+					lds_dma16<false>(src, j, reinterpret_cast<float4 *>(ids.bnd) + (j & ~63u));
 		}
 	}
 	if (t.tab_f4)
@@ -822,13 +822,13 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			written = true;
 		}
 	// write-back of the boundary particles with their ids from LDS (LdsIds): no memory round trip in front of the stores
-	if (!written && ids && boundary_only)
+	if (!written && use_ids && boundary_only)
 	{
 		if (fold_phase & 1u) { lds_dma_wait(); __syncthreads(); }      // (pass 0: the copy of the boundary ids was requested above)
 		const uint32_t b0 = t.wb_begin & ~3u;
 		for (uint32_t i = t.wb_begin + threadIdx.x; i < t.n_owned; i += BLOCK)
 		{
-			const uint32_t g = ids->bnd[PBDX_BCLAMP(kBndLdsIds, i - b0, ids->bnd_cap, tile_index)];
+			const uint32_t g = ids.bnd[PBDX_BCLAMP(kBndLdsIds, i - b0, ids.bnd_cap, tile_index)];
 			if (PBDX_BOK(kBndParticle, g, lim.n_particles, lim.tile)) store_pos<COHERENT>(pos_out, g, lpos[i]);
 		}
 		written = true;
@@ -1011,11 +1011,11 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 			const bool keeps = PBDX_WALK_TILES || m == 1u;      // (PBDX_WALK_TILES = 0: only one-tile workgroups keep their particles, the form before round 4)
 			// particle ids in LDS (LdsIds): one tile per workgroup, folded launch (pass 0 stages everything and copies the boundary ids)
 			const bool use_ids = a.ids_halo_cap != 0u && m == 1u && a.folded;
-			const LdsIds ids = { reinterpret_cast<uint32_t *>(lds_raw + a.ids_halo_off16), reinterpret_cast<uint32_t *>(lds_raw + a.ids_bnd_off16), a.ids_halo_cap, a.ids_bnd_cap };
+			LdsIds ids;
+			if (use_ids) { ids.halo = reinterpret_cast<uint32_t *>(lds_raw + a.ids_halo_off16); ids.bnd = reinterpret_cast<uint32_t *>(lds_raw + a.ids_bnd_off16); ids.halo_cap = a.ids_halo_cap; ids.bnd_cap = a.ids_bnd_cap; }
 			const uint32_t sgi_next = sgi + 1u == a.num_segs ? 0u : sgi + 1u;
 			process_tile<MASK, BLOCK, true>(sg, ra, pos_in, pos_out, tile, trace, lchunks, lpos, pass != 0 && first_of_pass && keeps, wait, &a.fold, fold_phase,
-				last_of_pass && keeps && pass + 1u != a.passes && !PBDX_FULL_WRITE_BACK, use_ids ? &ids : nullptr,
-				(use_ids && pass + 1u != a.passes) ? &a.seg[sgi_next] : nullptr, use_ids && pass != 0u);
+				last_of_pass && keeps && pass + 1u != a.passes && !PBDX_FULL_WRITE_BACK, ids, a.seg[sgi_next], use_ids && pass + 1u != a.passes, use_ids && pass != 0u);
 			if (s_failed)
 			{
 				// a neighbour never arrived: the state of this step is garbage.  Say so, turn every later kernel of the call
@@ -1040,7 +1040,12 @@ typedef void (*persist_fn)(PersistArgs);
 constexpr uint32_t kMaskClothXpbd = (1u << PBDX_DISTANCE_XPBD) | (1u << PBDX_ISOMETRIC_BENDING_XPBD);
 constexpr uint32_t kMaskLight = (1u << PBDX_DISTANCE) | (1u << PBDX_DISTANCE_XPBD) | (1u << PBDX_ISOMETRIC_BENDING) |
 	(1u << PBDX_ISOMETRIC_BENDING_XPBD) | (1u << PBDX_VOLUME) | (1u << PBDX_VOLUME_XPBD) | (1u << PBDX_DIHEDRAL);
-constexpr uint32_t kMaskAll = (1u << PBDX_NUM_CONSTRAINT_TYPES) - 1u;
+// (fault-hunting builds, profiles/HISTORY.md [9]: PBDX_HUNT_NO_SM takes shape matching -- the one type whose code keeps a private array in scratch memory -- out of
+// the all-types kernels)
+#ifndef PBDX_HUNT_NO_SM
+#define PBDX_HUNT_NO_SM 0
+#endif
+constexpr uint32_t kMaskAll = ((1u << PBDX_NUM_CONSTRAINT_TYPES) - 1u) & ~(PBDX_HUNT_NO_SM ? (1u << PBDX_SHAPE_MATCHING) : 0u);
 // the solid workloads get kernels of their own: the everything-kernel carries the register demand of its heaviest type (shape matching, strain
 // tets: 256 VGPRs and spills) into every run
 constexpr uint32_t kMaskFemTet = kMaskLight | (1u << PBDX_FEM_TET) | (1u << PBDX_FEM_TET_XPBD);
@@ -1753,6 +1758,18 @@ int prepare_persistent(pbdx_solver *s)
 	// `wgs_per_cu` workgroups per CU at most (default one: leaves the margin the occupancy API lacks; the handshake of the
 	// launch is what actually guards residency)
 	s->persist_grid = std::min<uint32_t>(k, (uint32_t)std::max(1, s->prop.multiProcessorCount) * s->persist_wgs_per_cu);
+	// Fewer workgroups than tiles: the walk (persistent_kernel).  The asynchronous-execution model of the lists is run for THIS grid before the schedule is
+	// used (the plan check covers synthetic grids of two and three tiles per workgroup only; here the real one, uneven tile counts per workgroup
+	// included).  A fraction of a second on the host for the 512-tile block, once per plan; a failure keeps the schedule off (one launch per segment) and says why.
+	if (s->persist_grid < k && !getenv("PBDX_NO_WALK_CHECK"))
+	{
+		std::string why;
+		if (!check_persistent_deps(s->plan, deps, 2u * (uint32_t)nseg + 1u, why, true, s->persist_grid))
+		{
+			s->plan_why = "persistent schedule off: the asynchronous-execution check of the walk failed for " + std::to_string(s->persist_grid) + " workgroups: " + why;
+			return PBDX_OK;
+		}
+	}
 	s->persist_ok = true;
 	return PBDX_OK;
 }

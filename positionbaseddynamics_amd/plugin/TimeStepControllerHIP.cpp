@@ -9,6 +9,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
+#include <pthread.h>
+#include <new>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -129,6 +132,9 @@ namespace
 		{
 			if (parts > m_threads) parts = m_threads;
 			if (parts <= 1 || n < 2) { fn(0, n); return; }
+			// one pass at a time: the pool is shared by every controller of the process, and two controllers may be stepped from two host threads
+			// (the single m_fn / m_pending state raced)
+			std::lock_guard<std::mutex> pass(m_pass);
 			start();
 			{
 				std::lock_guard<std::mutex> lk(m_mutex);
@@ -143,10 +149,16 @@ namespace
 	private:
 		HostPool() : m_threads(1), m_fn(nullptr), m_n(0), m_parts(0), m_pending(0), m_generation(0), m_stop(false)
 		{
-			unsigned int hw = std::thread::hardware_concurrency();
+			// the CPUs this process may run on (affinity mask: cgroup / taskset limits), not the machine's
+			unsigned int hw = 0;
+			cpu_set_t set;
+			if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = (unsigned int)CPU_COUNT(&set);
+			if (!hw) hw = std::thread::hardware_concurrency();
 			m_threads = hw ? (int)hw : 1;
 			if (m_threads > 64) m_threads = 64;
 			if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) m_threads = v; }      // developer aid
+			// after fork() the child has the pool object but none of its threads: forget them (they are started again on first use)
+			pthread_atfork(nullptr, nullptr, [] { HostPool &p = get(); new (&p.m_workers) std::vector<std::thread>(); p.m_pending = 0; p.m_fn = nullptr; });
 		}
 		~HostPool()
 		{
@@ -181,7 +193,7 @@ namespace
 		}
 		int m_threads;
 		std::vector<std::thread> m_workers;
-		std::mutex m_mutex;
+		std::mutex m_mutex, m_pass;
 		std::condition_variable m_wake, m_done;
 		const std::function<void(size_t, size_t)> *m_fn;
 		size_t m_n; int m_parts, m_pending; uint64_t m_generation; bool m_stop;
