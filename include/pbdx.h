@@ -262,6 +262,11 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
  * at sweep 0, XPBD dt = h_sub.  Used by known-answer tests. */
 int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations);
 int pbdx_solver_synchronize(pbdx_solver *s);
+/* Checkpoint of the device-resident particle state (x, v, oldX, lastX) and its restoration: stream-ordered device-to-device copies, no host
+ * synchronisation.  The reference-side plug-in steps speculatively while its exact parameter scan still runs on the host; an edit found by the scan
+ * undoes the step with restore_state (plugin/TimeStepControllerHIP.cpp).  The checkpoint is dropped when the particle set changes. */
+int pbdx_solver_save_state(pbdx_solver *s);
+int pbdx_solver_restore_state(pbdx_solver *s);
 
 /* ---- contacts with static rigid bodies ------------------------------------------
  * Particle vs static rigid body contacts with analytic distance fields, i.e. the part of

@@ -103,6 +103,7 @@ SIGNATURES = [
     ("pbdx_solver_end_schedule", C.c_int, vp), ("pbdx_solver_validate_schedule", C.c_int, vp),
     ("pbdx_solver_step", C.c_int, vp, f32, u32, u32, C.c_int, pf, u32),
     ("pbdx_solver_project", C.c_int, vp, f32, u32), ("pbdx_solver_synchronize", C.c_int, vp),
+    ("pbdx_solver_save_state", C.c_int, vp), ("pbdx_solver_restore_state", C.c_int, vp),
     ("pbdx_solver_integrate", C.c_int, vp, f32, pf), ("pbdx_solver_project_groups", C.c_int, vp, f32, u32, u32, u32),
     ("pbdx_solver_update_velocities", C.c_int, vp, f32, C.c_int),
     ("pbdx_solver_get_lambdas", C.c_int, vp, u32, u32, pf),

@@ -14,7 +14,7 @@
 #include "pbdx_project.h"
 #include "pbdx_bounds.h"
 #ifndef PBDX_ST96
-#define PBDX_ST96 0
+#define PBDX_ST96 1
 #endif
 
 namespace pbdx {

@@ -171,6 +171,13 @@ constexpr uint32_t kTraceStride = 80;
 #ifndef PBDX_DEPTH_BIG
 #define PBDX_DEPTH_BIG 2       // ring depth for the wide records (bending 11-17, FEM 10-13, shape matching 24 floats)
 #endif
+// packed records (run_typed PACKED): chunk type of a packed step of a compact one-plane type = kPackedChunkType + type; dictionary-form steps are packed
+// when PBDX_PACK_DICT (A/B switch of the build)
+#ifndef PBDX_PACK_DICT
+#define PBDX_PACK_DICT 1
+#endif
+constexpr uint32_t kPackedChunkType = 32;
+constexpr bool packed_plain_type(int type) { return type == PBDX_DISTANCE || type == PBDX_DISTANCE_XPBD || type == PBDX_VOLUME || type == PBDX_VOLUME_XPBD; }
 constexpr int ring_depth(int type) { return kParamCount[type] <= 2 ? PBDX_DEPTH_SMALL : PBDX_DEPTH_BIG; }      // (also used by the host when it expands a plan into chunks)
 template <int TYPE> struct Depth { static constexpr int value = ring_depth(TYPE); };
 static_assert((PBDX_DEPTH_SMALL == 2 || PBDX_DEPTH_SMALL == 4) && (PBDX_DEPTH_BIG == 2 || PBDX_DEPTH_BIG == 4), "ring depth must be 2 or 4");
@@ -383,11 +390,16 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 // parameter record in the tile's table of distinct records, which sits in LDS behind the particles (ltab); the record is read from there when the
 // slot is projected.  Same arithmetic on the same values: bit-identical.
 struct RecD { uint32_t w[4]; };          // packed indices (2), multiplier, table offset (16-byte units)
-template <int TYPE, bool COMPACT, int BLOCK, bool COHERENT, bool QUAD_STEP = false, bool DICT = false>
+// PACKED (round 5): the slot's indices and its ONE streamed dword -- the single parameter plane of a compact two-parameter type (rest length, rest volume)
+// or the table offset of a dictionary-form slot -- sit side by side in the index stream as one 8- or 12-byte record (kPackedChunkType, build_idx_image):
+// a record fetch is two vector-memory instructions (record, multiplier) instead of three.  Issuing them is what a sub-iteration pays right after the
+// colour barrier, when all sixteen waves do it at once (step probes, profiles/HISTORY.md [8]).
+template <int TYPE, bool COMPACT, int BLOCK, bool COHERENT, bool QUAD_STEP = false, bool DICT = false, bool PACKED = false>
 __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStreams &str, const ChunkSrc &lchunks, uint32_t c0,
 	float4 *lpos, unsigned long long *trace, uint32_t &step_counter, bool &fill_pending, const float4 *ltab = nullptr)
 {
 	static_assert(!(DICT && (QUAD_STEP || is_quad_type(TYPE))), "dictionary form: one lane per slot");
+	static_assert(!PACKED || (!QUAD_STEP && !is_quad_type(TYPE) && (DICT || num_planes(TYPE, COMPACT) == 1)), "packed records: one lane per slot, one streamed dword");
 	constexpr int D = Depth<TYPE>::value;
 	constexpr bool VEC = vector_params_for_block(BLOCK);
 	typedef TileAccess<TYPE, COMPACT, COHERENT, VEC> Acc;
@@ -419,7 +431,24 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 		// and intermittent memory faults in the heavy-type kernels, profiles/HISTORY.md [8], [9]; since round 5 the offsets arrive with the descriptor
 		// of the chunk being projected, which is read a whole sub-iteration ahead anyway)
 		const Acc acc = { lpos, str, idx_b, par_b, lam_b, v_par, v_tail, a.views[TYPE] };
-		if constexpr (DICT)
+		if constexpr (PACKED)
+		{
+			typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+			typedef unsigned int v3u __attribute__((ext_vector_type(3)));
+			if constexpr (kTwoBodies[TYPE])
+			{
+				const v2u r = __builtin_amdgcn_raw_buffer_load_b64(str.idx, (int)(lane_slot * 8u), (int)idx_b, 0);
+				dst.w[0] = r.x; dst.w[1] = 0u; dst.w[3] = r.y;
+			}
+			else
+			{
+				const v3u r = __builtin_amdgcn_raw_buffer_load_b96(str.idx, (int)(lane_slot * 12u), (int)idx_b, 0);
+				dst.w[0] = r.x; dst.w[1] = r.y; dst.w[3] = r.z;
+			}
+			dst.w[2] = 0u;
+			if constexpr (kHasLambda[TYPE]) dst.w[2] = __builtin_bit_cast(uint32_t, acc.lam_load(lane_slot));
+		}
+		else if constexpr (DICT)
 		{
 			if constexpr (kTwoBodies[TYPE]) { dst.w[0] = acc.idx_raw1(lane_slot); dst.w[1] = 0u; }
 			else { const uint2 v = acc.idx_raw2(lane_slot); dst.w[0] = v.x; dst.w[1] = v.y; }
@@ -536,10 +565,14 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending) \
 		                        : run_typed<T, false, BLOCK, COHERENT>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending); } \
 	else { c = num_chunks; } break;
-// a run of dictionary-form steps of type T (chunk type kDictChunkType + T)
+// a run of dictionary-form steps of type T (chunk type kDictChunkType + T); their records are packed (PBDX_PACK_DICT)
 #define PBDX_CASE_DICT(T) case kDictChunkType + T: if constexpr (((MASK >> T) & 1u) && dict_type(T)) { \
-		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT, false, true>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending, ltab) \
-		                        : run_typed<T, false, BLOCK, COHERENT, false, true>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending, ltab); } \
+		c = ra.views[T].compact ? run_typed<T, true, BLOCK, COHERENT, false, true, PBDX_PACK_DICT != 0>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending, ltab) \
+		                        : run_typed<T, false, BLOCK, COHERENT, false, true, PBDX_PACK_DICT != 0>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending, ltab); } \
+	else { c = num_chunks; } break;
+// a run of packed steps of a compact one-plane type T (chunk type kPackedChunkType + T)
+#define PBDX_CASE_PACKED(T) case kPackedChunkType + T: if constexpr (((MASK >> T) & 1u) && packed_plain_type(T)) { \
+		c = run_typed<T, true, BLOCK, COHERENT, false, false, true>(ra, str, csrc, c, lpos, trace, step_counter, fill_pending); } \
 	else { c = num_chunks; } break;
 // a run of StrainTetConstraint steps in quad form (chunk pseudo-type kQuadStrainChunk)
 #define PBDX_CASE_QUAD_STRAIN case kQuadStrainChunk: if constexpr (((MASK >> PBDX_STRAIN_TET) & 1u) && PBDX_QUAD_STRAIN) { \
@@ -810,6 +843,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			PBDX_CASE(PBDX_SHAPE_MATCHING)
 			PBDX_CASE_QUAD_STRAIN
 			PBDX_CASE_DICT(PBDX_ISOMETRIC_BENDING) PBDX_CASE_DICT(PBDX_ISOMETRIC_BENDING_XPBD) PBDX_CASE_DICT(PBDX_FEM_TET) PBDX_CASE_DICT(PBDX_FEM_TET_XPBD)
+			PBDX_CASE_PACKED(PBDX_DISTANCE) PBDX_CASE_PACKED(PBDX_DISTANCE_XPBD) PBDX_CASE_PACKED(PBDX_VOLUME) PBDX_CASE_PACKED(PBDX_VOLUME_XPBD)
 		default: c = num_chunks; break;
 		}
 	}
@@ -1466,6 +1500,8 @@ struct pbdx_solver
 	uint32_t persist_timeouts = 0;       // calls in which a tile gave up waiting for a neighbour (state restored, call repeated with schedule (A))
 	uint32_t persist_timeout_ms = 250;   // PBDX_OPT_PERSISTENT_TIMEOUT_MS
 	uint32_t persist_wgs_per_cu = 1;     // PBDX_OPT_PERSISTENT_WGS_PER_CU: tiles resident per CU in the one-launch schedule
+	float4 *d_ckpt[4] = { nullptr, nullptr, nullptr, nullptr };   // pbdx_solver_save_state / restore_state: the caller's checkpoint of pos / vel / old / last
+	uint32_t ckpt_n = 0;                                          // particles in the checkpoint (0 = none)
 	float4 *d_snap[4] = { nullptr, nullptr, nullptr, nullptr };   // pos / vel / old / last as they were when the current call started (persistent schedule only)
 	bool last_folded = false;            // the substeps enqueued last ran integrate / velocity update inside the persistent launch
 	bool last_flips = false;             // ... and ended in the other position buffer (odd number of passes): swap_state() after each
@@ -1475,6 +1511,7 @@ struct pbdx_solver
 	int persist_block = 0;
 	uint32_t persist_lds = 0, persist_grid = 0;
 	uint32_t ids_halo_off16 = 0, ids_bnd_off16 = 0, ids_halo_cap = 0, ids_bnd_cap = 0;      // particle ids resident in LDS (LdsIds)
+	bool pack_plain = getenv("PBDX_NO_PACK") == nullptr;     // packed records for compact one-plane types (build_idx_image; the switch is a developer A/B aid)
 	uint32_t *d_epoch = nullptr;
 	uint32_t *h_error = nullptr, *d_error = nullptr;   // page-locked host words the persistent kernel raises: [0] timeout, [1] launch refused, [2] at substep
 	uint32_t *d_ctl = nullptr;           // kCtl* device words
@@ -1632,6 +1669,8 @@ struct pbdx_solver
 		if (d_stage) { (void)hipFree(d_stage); d_stage = nullptr; }
 		if (d_hash) { (void)hipFree(d_hash); d_hash = nullptr; hash_blocks = 0; }
 		for (float4 *&p : d_snap) if (p) { (void)hipFree(p); p = nullptr; }
+		for (float4 *&p : d_ckpt) if (p) { (void)hipFree(p); p = nullptr; }
+		ckpt_n = 0;
 		if (d_rest) { (void)hipFree(d_rest); d_rest = nullptr; }
 		rest_set = false;
 		n = 0;
@@ -1774,6 +1813,43 @@ int prepare_persistent(pbdx_solver *s)
 	return PBDX_OK;
 }
 
+// Device image of a segment's index stream (run_typed PACKED).  The plan (pbdx_plan.cpp) keeps indices and parameters in separate streams; the image
+// interleaves them where a slot streams exactly one dword besides its indices: steps of a compact one-plane type (packed_plain_type) and dictionary-form
+// steps (the table offset, widened to a dword) become arrays of 8-byte (two bodies) or 12-byte (four bodies) records in slot order; every other step's
+// indices are copied as they are.  steps[si] = byte offset of step si in the image, bytes per slot there, packed or not.
+struct StepImage { uint32_t boff, rec_bytes; bool packed; };
+void build_idx_image(const FusedSegment &seg, const TypeView *views, int block, bool pack_plain, std::vector<uint8_t> &img, std::vector<StepImage> &steps)
+{
+	img.clear();
+	steps.assign(seg.steps.size(), StepImage{ 0u, 0u, false });
+	for (size_t si = 0; si < seg.steps.size(); si++)
+	{
+		const FusedStep &st = seg.steps[si];
+		const TypeInfo *ti = type_info((int)st.type);
+		const bool compact = views[st.type].compact != 0;
+		const uint32_t iw = ti->num_bodies == 2 ? 2u : 4u, ib = iw * 2u;
+		const uint32_t np = (uint32_t)num_planes((int)st.type, compact);
+		const bool quad = quad_strain_step((int)st.type, st.count, (uint32_t)block) || is_quad_type((int)st.type);
+		const bool packed = !quad && ((st.dict && PBDX_PACK_DICT) || (!st.dict && pack_plain && packed_plain_type((int)st.type) && compact && np == 1u));
+		const uint32_t rb = packed ? ib + 4u : ib;
+		const size_t off = img.size();
+		img.resize(off + (((size_t)st.count * rb + 15u) & ~(size_t)15u), 0);
+		steps[si] = { (uint32_t)off, rb, packed };
+		const uint16_t *src = &seg.idx[st.idx_off];
+		if (!packed) { memcpy(&img[off], src, (size_t)st.count * ib); continue; }
+		const uint16_t *entry = st.dict ? reinterpret_cast<const uint16_t *>(&seg.params[st.par_off]) : nullptr;
+		for (uint32_t q = 0; q < st.count; q++)
+		{
+			uint8_t *rec = &img[off + (size_t)q * rb];
+			memcpy(rec, src + (size_t)q * iw, ib);
+			uint32_t word;
+			if (entry) word = entry[q];
+			else memcpy(&word, &seg.params[st.par_off + param_float_index(seg.vector_params, 1u, 0u, q)], 4);
+			memcpy(rec + ib, &word, 4);
+		}
+	}
+}
+
 int ensure_plan(pbdx_solver *s)
 {
 	if (!s->fuse || s->plan_built) return PBDX_OK;
@@ -1871,6 +1947,10 @@ int ensure_plan(pbdx_solver *s)
 		DeviceSegment &d = s->dsegs.back();
 		const int block = blocks[segi];
 		d.block = block;
+		// the index stream as the kernels read it: packed records where a slot streams one dword besides its indices (build_idx_image)
+		std::vector<uint8_t> idx_img;
+		std::vector<StepImage> step_img;
+		build_idx_image(seg, s->plan.views, block, s->pack_plain, idx_img, step_img);
 		// expand every tile's steps into workgroup-wide chunks (FusedChunk) for this workgroup size
 		std::vector<FusedTile> tiles = seg.tiles;
 		std::vector<FusedChunk> chunks;
@@ -1894,8 +1974,10 @@ int ensure_plan(pbdx_solver *s)
 					const uint32_t valid = std::min<uint32_t>(cap, st.count - first);
 					const bool last = (k + 1 == nchunks);
 					FusedChunk c = {};
-					c.info = (st.dict ? kDictChunkType + st.type : quad_step ? kQuadStrainChunk : st.type) | ((last && st.barrier) ? 0x40u : 0u) | (last ? 0x80u : 0u) | (valid << 8);
-					c.idx_boff = st.idx_off * 2u + first * slot_idx_bytes;
+					const StepImage &im = step_img[si];
+					c.info = (st.dict ? kDictChunkType + st.type : quad_step ? kQuadStrainChunk : im.packed ? kPackedChunkType + st.type : st.type) | ((last && st.barrier) ? 0x40u : 0u) | (last ? 0x80u : 0u) | (valid << 8);
+					c.idx_boff = im.boff + first * im.rec_bytes;
+					(void)slot_idx_bytes;
 					c.par_boff = st.dict ? st.par_off * 4u + first * 2u : (st.par_off + (first / 64u) * nplanes * 64u) * 4u;       // (dictionary form: one uint16 per slot)
 					c.lam_boff = (st.lam_off + first) * 4u;
 					chunks.push_back(c);
@@ -1915,7 +1997,7 @@ int ensure_plan(pbdx_solver *s)
 			for (uint32_t ci = t.chunk_begin; ci < t.chunk_end; ci++)
 			{
 				const uint32_t ctype = chunks[ci].info & 0x3fu, run_left = chunks[ci].info >> 19;
-				const int real_type = ctype >= kDictChunkType ? (int)(ctype - kDictChunkType) : ctype == kQuadStrainChunk ? (int)PBDX_STRAIN_TET : (int)ctype;
+				const int real_type = ctype >= kPackedChunkType ? (int)(ctype - kPackedChunkType) : ctype >= kDictChunkType ? (int)(ctype - kDictChunkType) : ctype == kQuadStrainChunk ? (int)PBDX_STRAIN_TET : (int)ctype;
 				const uint32_t depth = (uint32_t)ring_depth(real_type);
 				const FusedChunk &f = chunks[ci + std::min(depth, run_left - 1u)];
 				chunks[ci].f_idx_boff = f.idx_boff; chunks[ci].f_par_boff = f.par_boff; chunks[ci].f_lam_boff = f.lam_boff; chunks[ci].pad = 0u;
@@ -1930,7 +2012,7 @@ int ensure_plan(pbdx_solver *s)
 		}
 		int r = upload(&d.d_tiles, tiles);
 		if (!r) r = upload(&d.d_chunks, chunks);
-		if (!r) r = upload(&d.d_idx, seg.idx);
+		if (!r) r = upload(reinterpret_cast<uint8_t **>(&d.d_idx), idx_img);
 		if (!r) r = upload(&d.d_params, seg.params);
 		if (!r) r = upload(&d.d_gid, seg.gid);
 		if (!r && seg.lam_count)
@@ -1945,7 +2027,7 @@ int ensure_plan(pbdx_solver *s)
 			s->plan_built = true;
 			return r;
 		}
-		d.idx_bytes = (uint32_t)(seg.idx.size() * sizeof(uint16_t));
+		d.idx_bytes = (uint32_t)idx_img.size();
 		d.params_bytes = (uint32_t)(seg.params.size() * sizeof(float));
 		d.lambda_bytes = (uint32_t)((size_t)seg.lam_count * sizeof(float));
 		d.gid_count = (uint32_t)seg.gid.size(); d.chunk_count = (uint32_t)chunks.size(); d.n_particles = s->n;
@@ -3085,6 +3167,14 @@ int pbdx_solver_commit_params(pbdx_solver *s)
 		}
 		if (!seg.params.empty())
 			HIPCHECK(hipMemcpy(s->dsegs[si].d_params, seg.params.data(), seg.params.size() * sizeof(float), hipMemcpyHostToDevice));
+		// the packed records of the index image carry a copy of the one-plane types' parameter: rebuilt (same layout, same offsets)
+		{
+			std::vector<uint8_t> idx_img;
+			std::vector<StepImage> step_img;
+			build_idx_image(seg, s->plan.views, s->dsegs[si].block, s->pack_plain, idx_img, step_img);
+			if (idx_img.size() != s->dsegs[si].idx_bytes) { s->free_plan(); return PBDX_OK; }      // (cannot happen: the layout depends on counts and views only)
+			if (!idx_img.empty()) HIPCHECK(hipMemcpy(s->dsegs[si].d_idx, idx_img.data(), idx_img.size(), hipMemcpyHostToDevice));
+		}
 	}
 	return PBDX_OK;
 }
@@ -3517,6 +3607,35 @@ int pbdx_solver_project(pbdx_solver *s, float h_sub, uint32_t iterations)
 		if (r) return r;
 		HIPCHECK(hipStreamSynchronize(s->stream));
 	}
+	return PBDX_OK;
+}
+
+// A caller's checkpoint of the particle state on the device (pos, vel, old, last: four stream-ordered device-to-device copies, no host
+// synchronisation) and its restoration.  The reference-side plug-in steps SPECULATIVELY while its exact parameter scan runs on the host's worker
+// threads; if the scan finds an edit the step is undone with this and repeated on the refreshed parameter streams.
+int pbdx_solver_save_state(pbdx_solver *s)
+{
+	if (!s) return PBDX_ERR_INVALID;
+	ENTER_DEVICE(s->device);
+	s->ckpt_n = 0;
+	if (!s->n) return PBDX_OK;
+	float4 *src[4] = { s->d_pos[0], s->d_vel, s->d_old, s->d_last };
+	for (int k = 0; k < 4; k++)
+	{
+		if (!s->d_ckpt[k]) HIPCHECK(hipMalloc(&s->d_ckpt[k], (size_t)s->n * sizeof(float4)));
+		HIPCHECK(hipMemcpyAsync(s->d_ckpt[k], src[k], (size_t)s->n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+	}
+	s->ckpt_n = s->n;
+	return PBDX_OK;
+}
+int pbdx_solver_restore_state(pbdx_solver *s)
+{
+	if (!s) return PBDX_ERR_INVALID;
+	ENTER_DEVICE(s->device);
+	if (!s->ckpt_n || s->ckpt_n != s->n) { set_error("restore_state: no checkpoint of the current particle set (pbdx_solver_save_state)"); return PBDX_ERR_INVALID; }
+	float4 *dst[4] = { s->d_pos[0], s->d_vel, s->d_old, s->d_last };
+	for (int k = 0; k < 4; k++)
+		HIPCHECK(hipMemcpyAsync(dst[k], s->d_ckpt[k], (size_t)s->n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
 	return PBDX_OK;
 }
 

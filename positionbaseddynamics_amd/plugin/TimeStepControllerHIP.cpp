@@ -254,6 +254,8 @@ TimeStepControllerHIP::TimeStepControllerHIP(int device) :
 {
 	m_accelGravity[0] = m_accelGravity[1] = m_accelGravity[2] = 0;
 	m_fullParameterScan = true; m_partialUploads = 0; m_mixed = false; m_mixedGroupsLast = 0;
+	m_speculate = getenv("PBDX_PLUGIN_NO_SPECULATION") == NULL; m_speculativeSteps = 0; m_repeatedSteps = 0;
+	m_rawH = 0.0f; m_rawG[0] = m_rawG[1] = m_rawG[2] = 0.0f;
 	for (int k = 0; k < 6; k++) m_ms[k] = 0.0;
 	m_deviceMs = 0.0;
 	if (pbdx_solver_create(&m_solver, device) != PBDX_OK)
@@ -808,8 +810,9 @@ bool TimeStepControllerHIP::buildSchedule(SimulationModel &model, bool paramsOnl
 //  * device ahead (stepResident without syncToHost): the host arrays are STALE as a whole, so a change is read at array
 //    granularity -- an array the host wrote replaces the device's, the others are first pulled from the device (a partial
 //    host write must not roll the rest back).  Element edits of a stale array make no sense: syncToHost() first.
-bool TimeStepControllerHIP::prepare(SimulationModel &model, bool forceUpload)
+bool TimeStepControllerHIP::prepare(SimulationModel &model, bool forceUpload, bool *scanDeferred)
 {
+	if (scanDeferred) *scanDeferred = false;
 	bool upload = forceUpload || m_hostDirty || !m_imageValid || model.getParticles().size() != m_numParticles || m_blockHash[4].empty();
 	if (!upload)
 	{
@@ -849,7 +852,9 @@ bool TimeStepControllerHIP::prepare(SimulationModel &model, bool forceUpload)
 	else
 	{
 		bool changed = m_paramsDirty;
-		if (!changed) { Lap lap(&m_ms[2]); std::vector<uint64_t> now; hashParameters(model, now); changed = now != m_paramHash; }
+		// (step(): the exact scan is left to the caller, who runs it WHILE the device steps -- see step())
+		if (!changed && scanDeferred && m_fullParameterScan) *scanDeferred = true;
+		else if (!changed) { Lap lap(&m_ms[2]); std::vector<uint64_t> now; hashParameters(model, now); changed = now != m_paramHash; }
 		if (changed && !buildSchedule(model, true)) return false;      // parameter streams only: no replanning, no re-measurement
 	}
 	Lap lap(&m_ms[3]);
@@ -868,24 +873,40 @@ void TimeStepControllerHIP::refreshAccelerations(SimulationModel &model)
 	m_accelValid = true;
 }
 
-bool TimeStepControllerHIP::runSteps(SimulationModel &model, unsigned int numSteps)
+// the engine call alone (time step size and gravity read HERE, on the calling thread, by the callers below: m_rawH / m_rawG)
+bool TimeStepControllerHIP::stepRaw(unsigned int numSteps)
+{
+	if (pbdx_solver_step(m_solver, m_rawH, m_subSteps, m_maxIterations, m_velocityUpdateMethod, m_rawG, numSteps) != PBDX_OK) return false;
+	pbdx_step_stats st;
+	if (pbdx_solver_get_stats(m_solver, &st) == PBDX_OK) m_deviceMs += st.total_ms;
+	return true;
+}
+// bookkeeping of `numSteps` completed steps (the reference's singletons: calling thread only)
+void TimeStepControllerHIP::finishSteps(unsigned int numSteps)
 {
 	TimeManager *tm = TimeManager::getCurrent();
 	const Real h = tm->getTimeStepSize();
-	Simulation *sim = Simulation::getCurrent();
-	const Real *gr = sim->getVecValue<Real>(Simulation::GRAVITATION);
-	const float g[3] = { (float)gr[0], (float)gr[1], (float)gr[2] };
-	START_TIMING("position constraints projection");
-	const bool ok = m_mixed ? runMixedSteps(model, numSteps, g)
-	                        : pbdx_solver_step(m_solver, (float)h, m_subSteps, m_maxIterations, m_velocityUpdateMethod, g, numSteps) == PBDX_OK;
-	STOP_TIMING_AVG;
-	if (!ok) return false;
-	if (!m_mixed) { pbdx_step_stats st; if (pbdx_solver_get_stats(m_solver, &st) == PBDX_OK) m_deviceMs += st.total_ms; }
 	m_iterations = m_maxIterations;
 	m_iterationsV = m_maxIterationsV;
 	m_deviceAhead = true;
 	m_gpuSteps += numSteps;
 	for (unsigned int i = 0; i < numSteps; i++) tm->setTime(tm->getTime() + h);     // TimeStepController.cpp:239
+}
+void TimeStepControllerHIP::readGlobals()
+{
+	m_rawH = (float)TimeManager::getCurrent()->getTimeStepSize();
+	const Real *gr = Simulation::getCurrent()->getVecValue<Real>(Simulation::GRAVITATION);
+	m_rawG[0] = (float)gr[0]; m_rawG[1] = (float)gr[1]; m_rawG[2] = (float)gr[2];
+}
+
+bool TimeStepControllerHIP::runSteps(SimulationModel &model, unsigned int numSteps)
+{
+	readGlobals();
+	START_TIMING("position constraints projection");
+	const bool ok = m_mixed ? runMixedSteps(model, numSteps, m_rawG) : stepRaw(numSteps);
+	STOP_TIMING_AVG;
+	if (!ok) return false;
+	finishSteps(numSteps);
 	return true;
 }
 
@@ -984,27 +1005,78 @@ void TimeStepControllerHIP::step(SimulationModel &model)
 	// every word of the host arrays (block hashes) and uploads what differs from what the device delivered last time -- after
 	// the plug-in's own download that is nothing, unless the host wrote in between.  (If the device is ahead -- a stepResident
 	// without syncToHost -- prepare() merges at array granularity instead.)
-	bool ok = prepare(model, /*forceUpload=*/false);
-	if (ok)
+	// The exact parameter scan (every record of every constraint: 3-4 ms at 6 M constraints) does not depend on the device, and the device step does
+	// not depend on it UNLESS it finds an edit -- which is rare.  So the step and the download run speculatively on a helper thread while this thread
+	// (and the worker pool) scan; an edit undoes the step on the device, refreshes the parameter streams and repeats it.  Only for plain particle
+	// models (no colliders, no mixed groups): their steps have no host-visible side effects besides ParticleData.
+	bool deferred = false;
+	const bool canSpeculate = m_speculate && !m_mixed && m_collisionDetection == NULL;
+	bool ok = prepare(model, /*forceUpload=*/false, canSpeculate ? &deferred : NULL);
+	if (ok && deferred)
 	{
-		refreshAccelerations(model);                        // host-visible side effect of TimeStepController.cpp:84
-		Lap lap(&m_ms[4]);
-		ok = runSteps(model, 1);
+		refreshAccelerations(model);
+		readGlobals();
+		ok = pbdx_solver_save_state(m_solver) == PBDX_OK;
+		bool stepped = false, downloaded = false;
+		std::string err;
+		std::vector<uint64_t> now;
+		if (ok)
+		{
+			const auto t0 = std::chrono::steady_clock::now();
+			std::thread helper([&] {
+				// (raw engine call + download: nothing here touches the reference's singletons)
+				const auto a = std::chrono::steady_clock::now();
+				stepped = stepRaw(1);
+				const auto b = std::chrono::steady_clock::now();
+				if (stepped) downloaded = downloadParticles(model);
+				if (!stepped || !downloaded) err = pbdx_last_error();
+				m_ms[4] += std::chrono::duration<double, std::milli>(b - a).count();
+				m_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b).count();
+			});
+			hashParameters(model, now);
+			m_ms[2] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+			helper.join();
+			ok = stepped && downloaded;
+			if (!ok) m_helperError = err;      // (the engine's message is thread-local: carried over by hand)
+		}
+		if (ok)
+		{
+			m_speculativeSteps++;
+			if (now != m_paramHash)
+			{
+				// a parameter was edited since the streams were built: the step just taken used the old value
+				m_repeatedSteps++;
+				ok = pbdx_solver_restore_state(m_solver) == PBDX_OK && buildSchedule(model, true);
+				if (ok) { Lap lap(&m_ms[4]); ok = stepRaw(1); }
+				if (ok) { Lap lap(&m_ms[5]); ok = downloadParticles(model); }
+			}
+		}
+		if (ok) finishSteps(1);
 	}
-	if (ok)
+	else
 	{
-		// TimeStepController.cpp:216-223: the reference rebuilds the contact lists every step; the device keeps
-		// its contacts to itself, so the host lists are emptied (counts: pbdx_solver_get_num_contacts)
-		if (m_collisionDetection != NULL) model.resetContacts();
-		Lap lap(&m_ms[5]);
-		ok = downloadParticles(model);
+		if (ok)
+		{
+			refreshAccelerations(model);                        // host-visible side effect of TimeStepController.cpp:84
+			Lap lap(&m_ms[4]);
+			ok = runSteps(model, 1);
+		}
+		if (ok)
+		{
+			// TimeStepController.cpp:216-223: the reference rebuilds the contact lists every step; the device keeps
+			// its contacts to itself, so the host lists are emptied (counts: pbdx_solver_get_num_contacts)
+			if (m_collisionDetection != NULL) model.resetContacts();
+			Lap lap(&m_ms[5]);
+			ok = downloadParticles(model);
+		}
 	}
 	if (!ok)
 	{
 		STOP_TIMING_AVG;
 		m_scheduleValid = false;
 		m_imageValid = false;
-		refuse(model, pbdx_last_error());
+		refuse(model, m_helperError.empty() ? pbdx_last_error() : m_helperError.c_str());
+		m_helperError.clear();
 		return;
 	}
 	STOP_TIMING_AVG;
@@ -1069,3 +1141,6 @@ extern "C" void pbdx_timestep_hip_set_full_parameter_scan(PBD::TimeStep *ts, int
 extern "C" void pbdx_timestep_hip_timing(PBD::TimeStep *ts, double out[7], int reset) { static_cast<PBD::TimeStepControllerHIP*>(ts)->timing(out, reset != 0); }
 extern "C" unsigned int pbdx_timestep_hip_mixed_groups(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numMixedGroups(); }
 extern "C" void *pbdx_timestep_hip_solver(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->solver(); }
+extern "C" unsigned int pbdx_timestep_hip_speculative_steps(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numSpeculativeSteps(); }
+extern "C" unsigned int pbdx_timestep_hip_repeated_steps(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numRepeatedSteps(); }
+extern "C" void pbdx_timestep_hip_set_speculative_step(PBD::TimeStep *ts, int on) { static_cast<PBD::TimeStepControllerHIP*>(ts)->setSpeculativeStep(on != 0); }

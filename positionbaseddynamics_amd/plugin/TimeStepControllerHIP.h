@@ -51,6 +51,7 @@
 #include "../../include/pbdx.h"
 #include <stdint.h>
 #include <vector>
+#include <string>
 
 namespace PBD
 {
@@ -92,6 +93,12 @@ namespace PBD
 		unsigned int numFallbackSteps() const { return m_fallbackSteps; }
 		unsigned int numFailedSteps() const { return m_failedSteps; }
 		unsigned int numParameterRefreshes() const { return m_paramRefreshes; }
+		/** step() runs the device step and the download SPECULATIVELY while the exact parameter scan still walks the constraints on the host's worker
+		 * threads (the scan costs several times the step at millions of constraints); an edit found by the scan undoes the step on the device
+		 * (pbdx_solver_restore_state), refreshes the parameter streams and repeats it.  Counters: steps taken that way / steps that had to be repeated. */
+		unsigned int numSpeculativeSteps() const { return m_speculativeSteps; }
+		unsigned int numRepeatedSteps() const { return m_repeatedSteps; }
+		void setSpeculativeStep(bool b) { m_speculate = b; }
 		unsigned int numScheduleBuilds() const { return m_scheduleBuilds; }
 		unsigned int numUploads() const { return m_uploads; }
 		/** uploads of only the blocks the host wrote (host current, full-coverage block hashes) */
@@ -116,7 +123,12 @@ namespace PBD
 		bool uploadColliders(SimulationModel &model);
 		bool uploadTetColliders(SimulationModel &model, float tolerance);
 		bool downloadParticles(SimulationModel &model);
-		bool prepare(SimulationModel &model, bool forceUpload);
+		bool prepare(SimulationModel &model, bool forceUpload, bool *scanDeferred = NULL);
+		bool stepRaw(unsigned int numSteps);
+		void finishSteps(unsigned int numSteps);
+		void readGlobals();
+		float m_rawH, m_rawG[3];
+		std::string m_helperError;
 		bool runSteps(SimulationModel &model, unsigned int numSteps);
 		bool runMixedSteps(SimulationModel &model, unsigned int numSteps, const float g[3]);
 		bool uploadChanges(SimulationModel &model, std::vector<uint64_t> now[5]);
@@ -141,6 +153,8 @@ namespace PBD
 		double m_deviceMs;             // device-event time of the engine's steps (pbdx_step_stats.total_ms), to tell GPU time from host-side waiting
 		double m_ms[6];                // host milliseconds spent in: hashing the host arrays, full uploads, the parameter check, the collider refresh, the engine's step, the download
 		bool m_fullParameterScan;
+		bool m_speculate;
+		unsigned int m_speculativeSteps, m_repeatedSteps;
 		// parameters
 		bool m_paramsDirty;
 		std::vector<uint64_t> m_paramHash;   // exact scan: one hash per block of constraints (+ the count); sampled scan: one hash

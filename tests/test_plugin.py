@@ -589,6 +589,9 @@ def _extra(path):
     lib.pbdx_timestep_hip_partial_uploads.argtypes = [C.c_void_p]; lib.pbdx_timestep_hip_partial_uploads.restype = C.c_uint
     lib.pbdx_timestep_hip_refresh_parameters.argtypes = [C.c_void_p]; lib.pbdx_timestep_hip_refresh_parameters.restype = None
     lib.pbdx_timestep_hip_set_full_parameter_scan.argtypes = [C.c_void_p, C.c_int]; lib.pbdx_timestep_hip_set_full_parameter_scan.restype = None
+    lib.pbdx_timestep_hip_speculative_steps.argtypes = [C.c_void_p]; lib.pbdx_timestep_hip_speculative_steps.restype = C.c_uint
+    lib.pbdx_timestep_hip_repeated_steps.argtypes = [C.c_void_p]; lib.pbdx_timestep_hip_repeated_steps.restype = C.c_uint
+    lib.pbdx_timestep_hip_set_speculative_step.argtypes = [C.c_void_p, C.c_int]; lib.pbdx_timestep_hip_set_speculative_step.restype = None
     return lib
 
 
@@ -731,6 +734,16 @@ def test_plugin_sees_one_edited_constraint(size, how):
             ts = ref.timestep_ptr()
             assert cnt["gpu_steps"](ts) == 7 and cnt["failed_steps"](ts) == 0
             assert cnt["schedule_builds"](ts) == 1 and cnt["param_refreshes"](ts) == 1
+            ex = _extra(path)
+            ex.pbdx_timestep_hip_speculative_steps.restype = C.c_uint; ex.pbdx_timestep_hip_repeated_steps.restype = C.c_uint
+            spec, rep = ex.pbdx_timestep_hip_speculative_steps(ts), ex.pbdx_timestep_hip_repeated_steps(ts)
+            print("speculative steps %d, repeated %d (%s, %s)" % (spec, rep, size, how))
+            if how == "unannounced":
+                # the exact scan runs WHILE the device steps: every step but the first (which builds the schedule) is speculative, and exactly the one
+                # step that followed the edit had to be undone on the device and repeated
+                assert spec == 6 and rep == 1
+            else:
+                assert rep == 0
         ref.reset_all()
         return out
 
