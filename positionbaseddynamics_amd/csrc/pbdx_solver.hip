@@ -238,6 +238,12 @@ __device__ __forceinline__ bool chunk_last_of_step(uint32_t info) { return (info
 __device__ __forceinline__ uint32_t chunk_valid(uint32_t info) { return (info >> 8) & 0x7ffu; }
 __device__ __forceinline__ uint32_t chunk_run_left(uint32_t info) { return info >> 19; }
 
+// HAZARD (root cause of the intermittent "Memory access fault" of rounds 3-5, profiles/HISTORY.md [9]): on gfx9-family hardware a vector-memory instruction
+// that reads an SGPR written by a VALU instruction needs FIVE wait states in between.  The compiler inserts them for its own instructions
+// (GCNHazardRecognizer) but cannot see inside an inline-assembly string: in kernels that spill SGPRs to vector-register lanes the base pointer of the
+// hand-written copies / stores below is restored with v_readlane_b32 (a VALU write of an SGPR) immediately in front of the statement, the memory
+// instruction then reads the OLD register contents -- a garbage address -- and whether it does depends on what else the SIMD issues in between (one wave
+// per SIMD in the 256-thread kernels: nothing).  Every hand-written memory instruction with a scalar operand therefore starts with `s_nop 4`.
 // HBM -> LDS copy of 16 bytes per lane without a register in between (global_load_lds_dwordx4: lane l of the wave
 // lands at lds_wave_base + 16 l).  Issued as inline assembly on purpose: with the builtin the compiler drains
 // vmcnt to 0 in front of every such copy (it cannot order them against the other outstanding loads), which
@@ -258,10 +264,10 @@ __device__ __forceinline__ void lds_dma16(const float4 *base, uint32_t index, fl
 	const unsigned long long sbase = ((unsigned long long)rfl((uint32_t)(bv >> 32)) << 32) | (unsigned long long)rfl((uint32_t)bv);      // (rfl returns uint32_t: the builtin's int would sign-extend the low half)
 	uint32_t saved;      // M0 is a reserved register: preserved around the copy
 	if constexpr (COHERENT)
-		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+		asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
 			: "=&s"(saved) : "v"(boff), "s"(sbase), "s"(m0v) : "memory");
 	else
-		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+		asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
 			: "=&s"(saved) : "v"(boff), "s"(sbase), "s"(m0v) : "memory");
 }
 // write-back store of one position
@@ -276,7 +282,7 @@ __device__ __forceinline__ void store_pos(float4 *base, uint32_t index, float4 v
 		// scalar operand as it is -- "invalid operand for instruction")
 		const unsigned long long bv = (unsigned long long)(uintptr_t)base;
 		const unsigned long long sbase = ((unsigned long long)rfl((uint32_t)(bv >> 32)) << 32) | (unsigned long long)rfl((uint32_t)bv);      // (rfl returns uint32_t: the builtin's int would sign-extend the low half)
-		asm volatile("global_store_dwordx4 %0, %1, %2 sc1" :: "v"(index * 16u), "v"(w), "s"(sbase) : "memory");
+		asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1" :: "v"(index * 16u), "v"(w), "s"(sbase) : "memory");
 	}
 	else
 		base[index] = v;
