@@ -1013,19 +1013,18 @@ def test_bounds_checked_build_finds_no_out_of_range_access(pbd):
     -DPBDX_BOUNDS=1 (csrc/pbdx_bounds.h): every address of the fused / persistent sweep that no buffer descriptor checks in hardware -- particle ids from
     the gid streams, the positions they select, LDS slots of the fill, the gather / scatter and the dictionary tables, chunk / tile descriptor indices,
     the dependency lists -- is compared with the size of what it addresses, violations are recorded and the access suppressed.  A second process runs the
-    BASELINE workloads at full size (1 M cloth on all schedules, odd pass counts, the 1500x1500 walk, the configs[3] block, the 100 k-tet bars), the
-    dictionary form and its switch under it; every test there must stay bit-identical AND leave the record empty
-    (tests/conftest.py: _bounds_record_stays_empty)."""
+    known-answer tests, every scene, the three schedules' cross-checks, the examples and kitchen-sink scenes (the all-types kernels), the dictionary form
+    and the BASELINE workloads at full size (1 M cloth on all schedules, the 1500x1500 walk, the configs[3] block, the 100 k-tet bars) under it; every
+    test there must stay bit-identical AND leave the record empty (tests/conftest.py: _bounds_record_stays_empty).  (Until the hazard of
+    profiles/HISTORY.md [9] was found -- tests/test_asm_hazards.py -- this build died intermittently on the persistent schedule.)"""
     import subprocess
     import sys
     lib = os.path.join(util.ROOT, "positionbaseddynamics_amd", "_lib", "libpbdx_bounds.so")
     if not os.path.exists(lib):
         pytest.skip("libpbdx_bounds.so not built")
-    # (the BASELINE workloads' kernels: cloth, light types, FEM / strain solids.  The all-types kernels -- MASK = 8191: the examples, the kitchen-sink scenes --
-    # are left out: the range-checked build of persistent_kernel<8191, 256> dies intermittently with an address error at a store whose base and offsets the
-    # debugger shows in range, while recording no violation; open, profiles/HISTORY.md [9])
-    sel = ("full_size_c2_million_particle_cloth_vs_reference or full_size_c2_odd_pass_count or c4_ensemble_block or dictionary_form or "
-           "full_size_c3_100k or walk_of_a_1500")
+    sel = ("known_answer_projection or fem_tet_inversion_branch or scene_parity_vs_float_reference or fused_tiles_equal_per_colour_schedule or "
+           "persistent_schedule_is_bit_identical or full_size_c2_million_particle_cloth_vs_reference or full_size_c2_odd_pass_count or "
+           "c4_ensemble_block or example_runs_and_matches_reference or dictionary_form or full_size_c3_100k or walk_of_a_1500")
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(util.ROOT, "tests", "test_gpu_parity.py"), os.path.join(util.ROOT, "tests", "test_examples.py"),
                         "-m", "gpu", "-q", "-x", "-k", sel],
                        env=dict(os.environ, PBDX_LIB=lib), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
