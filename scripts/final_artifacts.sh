@@ -3,7 +3,7 @@
 # copied from gpurun_out/<tag>final/ into profiles/<tag>_* afterwards.  Counters and traces are separate rocprofv3 passes.
 set -u
 ulimit -c 0
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=$PWD/gpurun_out/${TAG}final; mkdir -p $O; export TMPDIR=/tmp; REPO=$PWD
 ( rocminfo | grep -E "Marketing|Compute Unit|gfx" | head -8; echo "nproc $(nproc)"; grep -m1 "model name" /proc/cpuinfo ) > $O/box.txt 2>&1
 # 1. the driver's command, as is (stdout = compact lines, headline last; full record = bench_detail.json)
@@ -34,6 +34,11 @@ rm -rf $O/pmc
 timeout 300 python bench.py --gpus 2 --oversubscribe --workload c4 --scaling strong --total-instances 6 --size 40 --steps 5 --warmup 2 --check-shards > $O/bench_gpus2_check_shards.txt 2>> $O/bench_gpus8.err; echo "gpus2 check-shards rc=$?" >> $O/box.txt
 ( MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 600 python bench.py --gpus 1 --dist-backend nccl --no-cpu-baseline --no-traffic --no-extras --steps 20 --warmup 5 > $O/bench_rccl_world1.txt 2> $O/bench_rccl_world1.err ); echo "rccl world 1 rc=$?" >> $O/box.txt
 grep "bench rank" $O/bench_rccl_world1.err >> $O/bench_rccl_world1.txt
+# 4b. the same ensemble in ONE process through the C ABI (pbdx_ensemble_*): two engines sharing this GPU (smoke test of the path)
+timeout 300 python bench.py --gpus 2 --single-process --devices 0,0 --workload c4 --instances 16 --steps 10 --warmup 3 > $O/bench_single_process_two_engines_one_gpu.txt 2>> $O/bench_gpus8.err; echo "single-process ensemble rc=$?" >> $O/box.txt
+# 4c. two 512-thread workgroups per CU on today's kernel (round 4: 0.684 against 0.624 ms)
+bash scripts/ab.sh --reps 1 --arm "one workgroup of 1024 per CU" -- "" > $O/two_wgs_per_cu.log 2>&1
+bash scripts/ab.sh --reps 1 --arm "two workgroups of 512 per CU" -- "--wgs-per-cu 2 --fuse-block 512" >> $O/two_wgs_per_cu.log 2>&1
 # 5. tests (with durations) and smoke
 # (SKIP_TESTS=1 when the suite has just been run on this commit in its own call)
 [ -z "${SKIP_TESTS:-}" ] && { timeout -k 5 2400 python -m pytest tests -m gpu -q -s --durations=12 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/box.txt; }
