@@ -769,7 +769,11 @@ public:
 	{
 		ParticleData &pd = m.getParticles();
 		const Vector3r d = pd.getPosition(m_bodies[0]) - pd.getOldPosition(m_bodies[0]);
-		m_restLength = m_base * ((Real)1.0 + (Real)0.05 * pd.getVelocity(m_bodies[0]).norm() + d.norm());
+		// (bounded: the rest length stays within [1, 1.15] x its initial value, the scene stays stable)
+		Real sv = pd.getVelocity(m_bodies[0]).norm(), sd = d.norm();
+		if (sv > (Real)1.0) sv = (Real)1.0;
+		if (sd > (Real)0.1) sd = (Real)0.1;
+		m_restLength = m_base * ((Real)1.0 + (Real)0.05 * sv + sd);
 		g_hooked_calls++;
 		return true;
 	}

@@ -12,6 +12,7 @@
 #include <sched.h>
 #include <pthread.h>
 #include <new>
+#include <algorithm>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -155,7 +156,9 @@ namespace
 			if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = (unsigned int)CPU_COUNT(&set);
 			if (!hw) hw = std::thread::hardware_concurrency();
 			m_threads = hw ? (int)hw : 1;
-			if (m_threads > 64) m_threads = 64;
+			// up to 64 threads, on hosts with more than 128 CPUs half of them up to 128: since round 5 the exact parameter scan runs while the device steps and is
+			// what a round trip waits for (6 M constraints on the 256-CPU host: 2.9 ms at 64 threads)
+			if (m_threads > 64) m_threads = m_threads >= 128 ? std::min(128, m_threads / 2) : 64;
 			if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) m_threads = v; }      // developer aid
 			// after fork() the child has the pool object but none of its threads: forget them (they are started again on first use)
 			pthread_atfork(nullptr, nullptr, [] { HostPool &p = get(); new (&p.m_workers) std::vector<std::thread>(); p.m_pending = 0; p.m_fn = nullptr; });
@@ -879,6 +882,7 @@ bool TimeStepControllerHIP::stepRaw(unsigned int numSteps)
 	if (pbdx_solver_step(m_solver, m_rawH, m_subSteps, m_maxIterations, m_velocityUpdateMethod, m_rawG, numSteps) != PBDX_OK) return false;
 	pbdx_step_stats st;
 	if (pbdx_solver_get_stats(m_solver, &st) == PBDX_OK) m_deviceMs += st.total_ms;
+	m_deviceAhead = true;          // (until a download says otherwise: set HERE, before the download that may follow on the same thread)
 	return true;
 }
 // bookkeeping of `numSteps` completed steps (the reference's singletons: calling thread only)
@@ -888,7 +892,6 @@ void TimeStepControllerHIP::finishSteps(unsigned int numSteps)
 	const Real h = tm->getTimeStepSize();
 	m_iterations = m_maxIterations;
 	m_iterationsV = m_maxIterationsV;
-	m_deviceAhead = true;
 	m_gpuSteps += numSteps;
 	for (unsigned int i = 0; i < numSteps; i++) tm->setTime(tm->getTime() + h);     // TimeStepController.cpp:239
 }
@@ -906,6 +909,7 @@ bool TimeStepControllerHIP::runSteps(SimulationModel &model, unsigned int numSte
 	const bool ok = m_mixed ? runMixedSteps(model, numSteps, m_rawG) : stepRaw(numSteps);
 	STOP_TIMING_AVG;
 	if (!ok) return false;
+	m_deviceAhead = true;
 	finishSteps(numSteps);
 	return true;
 }
