@@ -844,7 +844,7 @@ def compact_headline(full, detail_path=None):
         out["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
     ex = full.get("extra_workloads") or []
     if ex:
-        out["extras"] = [{"w": e.get("tag", "?"), "ms": _r(e.get("ms_per_step", e.get("ms_per_substep")), 4), "ok": bool(e.get("state_ok", False) and e.get("bit_identical", True)),
+        out["extras"] = [{"w": e.get("tag", "?"), "ms": _r(e.get("ms_per_step", e.get("ms_per_substep")), 4), "ok": bool(e.get("state_ok", False) and e.get("bit_identical") is not False),
                           "bit_identical": e.get("bit_identical")} for e in ex]      # (ok = finite + pins AND, where a reference leg ran, bit-identical; bit_identical null = no leg)
     out = _r(out)
     line = json.dumps(out, separators=(",", ":"))

@@ -156,9 +156,8 @@ namespace
 			if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = (unsigned int)CPU_COUNT(&set);
 			if (!hw) hw = std::thread::hardware_concurrency();
 			m_threads = hw ? (int)hw : 1;
-			// up to 64 threads, on hosts with more than 128 CPUs half of them up to 128: since round 5 the exact parameter scan runs while the device steps and is
-			// what a round trip waits for (6 M constraints on the 256-CPU host: 2.9 ms at 64 threads)
-			if (m_threads > 64) m_threads = m_threads >= 128 ? std::min(128, m_threads / 2) : 64;
+			// (128 threads on the 256-CPU host were tried in round 5: the scan does not get faster and the particle hashes get three times slower, profiles/HISTORY.md [9])
+			if (m_threads > 64) m_threads = 64;
 			if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) m_threads = v; }      // developer aid
 			// after fork() the child has the pool object but none of its threads: forget them (they are started again on first use)
 			pthread_atfork(nullptr, nullptr, [] { HostPool &p = get(); new (&p.m_workers) std::vector<std::thread>(); p.m_pending = 0; p.m_fn = nullptr; });
