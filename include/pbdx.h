@@ -370,9 +370,11 @@ enum {
 	PBDX_OPT_MAX_SEGMENT_COLOURS = 7, /* upper bound on colours fused into one launch (default 16) */
 	PBDX_OPT_LDS_PARTICLES = 8,    /* LDS capacity of a tile in particles (default 10240 = 160 KiB / 16 B) */
 	PBDX_OPT_TRACE = 9,            /* developer aid: fused kernels stamp wall_clock64() per tile and colour step */
-	PBDX_OPT_PIN_HOST = 11,        /* page-lock (hipHostRegister) the caller's particle arrays passed to set/get_particles so that
-	                                * transfers DMA at full PCIe rate; the arrays must stay allocated until the option is cleared or the
-	                                * solver destroyed (default 0) */
+	PBDX_OPT_PIN_HOST = 11,        /* particle transfers (set/get_particles, update_particle_ranges) go through a page-locked mirror the ENGINE owns
+	                                * (56 B per particle of page-locked host memory; 112 B for a double host) and run at the PCIe rate: the device
+	                                * copies to / from the mirror, host threads copy between the mirror and the caller's arrays, array by array,
+	                                * overlapped.  The caller's memory is never registered with the GPU (until round 5 it was: hipHostRegister of
+	                                * heap arrays; HISTORY [9] has why that went).  Default 0 */
 	PBDX_OPT_PAIRS = 10,           /* removed (round 2): projected two chunks of a colour step jointly with packed fp32 arithmetic, measured 10-30 % slower; accepted, ignored */
 	PBDX_OPT_PERSISTENT = 12,      /* fused schedule only: all sweeps of a substep as ONE launch; a tile starts its next pass as soon as its
 	                                * neighbouring tiles have published theirs (no kernel boundary, no chip-wide wait for the slowest tile).

@@ -40,6 +40,8 @@
 #include "pbdx_contact.h"
 #include "pbdx_tetcontact_dev.h"
 #include <chrono>
+#include <thread>
+#include <vector>
 #include <algorithm>
 #include <type_traits>
 #include <string.h>
@@ -1470,6 +1472,32 @@ struct DeviceSegment
 
 } // namespace
 
+// Host transfers at the PCIe rate (PBDX_OPT_PIN_HOST) go through a page-locked MIRROR the engine owns (HostMirror below), not through
+// hipHostRegister of the caller's arrays as they did until round 5.  Registering maps the caller's heap pages into the GPU's address space at
+// their HOST addresses, the runtime finds a registration by address, and the whole arrangement depends on what the host's allocator does with
+// the neighbouring heap afterwards; a full GPU test run of round 5 died with "Memory access fault by GPU" at a host heap address in the middle
+// of a plug-in test, one run in four (profiles/HISTORY.md [9]).  With the mirror the GPU is never given an address of memory the engine does
+// not own: the device copies to / from the mirror, host threads copy between the mirror and the caller's arrays, array by array, so that the
+// copy of one array runs while the next one is on the bus.
+static void host_copy(void *dst, const void *src, size_t bytes)
+{
+	const size_t kSlice = (size_t)1 << 20;
+	unsigned threads = (unsigned)std::min<size_t>(bytes / kSlice, 16);
+	const unsigned hw = std::thread::hardware_concurrency();
+	if (hw && threads > hw) threads = hw;
+	if (threads < 2) { memcpy(dst, src, bytes); return; }
+	std::vector<std::thread> team;
+	team.reserve(threads - 1);
+	const size_t per = ((bytes + threads - 1) / threads + 63) & ~(size_t)63;
+	for (unsigned t = 1; t < threads; t++)
+	{
+		const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, per * (t + 1));
+		if (hi > lo) team.emplace_back([=]() { memcpy(static_cast<char *>(dst) + lo, static_cast<const char *>(src) + lo, hi - lo); });
+	}
+	memcpy(dst, src, std::min(bytes, per));
+	for (std::thread &t : team) t.join();
+}
+
 struct pbdx_solver
 {
 	int device = 0;
@@ -1505,9 +1533,10 @@ struct pbdx_solver
 	uint32_t max_segment_colours = 16;
 	uint32_t lds_particles = 10240;
 	int trace = 0;
-	int pin_host = 0;                    // hipHostRegister the caller's particle arrays (opt-in: they must outlive the solver or be unpinned)
-	struct Pin { const void *p; size_t bytes; };
-	std::vector<Pin> pins;
+	int pin_host = 0;                    // PBDX_OPT_PIN_HOST: particle transfers through the page-locked mirror below
+	char *h_mirror = nullptr;            // page-locked host image of d_stage (same layout) + the block hashes behind it
+	size_t mirror_bytes = 0;
+	hipEvent_t mirror_ev[4] = { nullptr, nullptr, nullptr, nullptr };
 	int persistent = 1;                  // PBDX_OPT_PERSISTENT: the sweeps of a substep as one launch (A'): 0 never, 1 where measured faster, 2 always, 3 self-test
 	bool persist_ok = false;             // the plan is eligible (and no launch has been refused or has timed out)
 	uint32_t persist_refusals = 0;
@@ -1698,31 +1727,28 @@ struct pbdx_solver
 	// contacts between deformable solids are solved BETWEEN the iterations (TimeStepController.cpp:288-291): the one-launch schedule then runs one
 	// launch per ITERATION (all segments of a sweep; tile-to-tile hand-offs instead of kernel boundaries), the contact solve in between
 	bool persistent_iter_active() const { return persistent && persist_ok && persist_choice && fused_active() && tet_active(); }
-	void unpin_all()
+	void free_mirror()
 	{
-		for (const Pin &pn : pins) (void)hipHostUnregister(const_cast<void *>(pn.p));
-		pins.clear();
+		if (h_mirror) { (void)hipHostFree(h_mirror); h_mirror = nullptr; }
+		mirror_bytes = 0;
+		for (hipEvent_t &e : mirror_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
 	}
-	// Page-lock a caller buffer so that hipMemcpyAsync DMAs straight from / into it.  Failure is not an
-	// error (the copy then goes through the driver's staging path).
-	void pin(const void *p, size_t bytes)
+	// the mirror for `bytes` of staging (+ hashes), or nullptr: option off, or no page-locked memory to be had (the copy then takes the
+	// driver's path for pageable memory, as with the option off)
+	char *mirror(size_t bytes)
 	{
-		if (!pin_host || !p || !bytes) return;
-		for (size_t i = 0; i < pins.size(); i++)
+		if (!pin_host) return nullptr;
+		if (bytes > mirror_bytes)
 		{
-			if (pins[i].p == p && pins[i].bytes == bytes) return;
-			const char *a = static_cast<const char *>(pins[i].p), *b = static_cast<const char *>(p);
-			if (a < b + bytes && b < a + pins[i].bytes)     // stale overlapping registration
-			{
-				(void)hipHostUnregister(const_cast<void *>(pins[i].p));
-				pins.erase(pins.begin() + i);
-				i--;
-			}
+			(void)hipStreamSynchronize(stream);
+			if (h_mirror) { (void)hipHostFree(h_mirror); h_mirror = nullptr; }
+			mirror_bytes = 0;
+			if (hipHostMalloc(reinterpret_cast<void **>(&h_mirror), bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h_mirror = nullptr; return nullptr; }
+			mirror_bytes = bytes;
 		}
-		if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess)
-			pins.push_back({ p, bytes });
-		else
-			(void)hipGetLastError();
+		for (hipEvent_t &e : mirror_ev)
+			if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; return nullptr; }
+		return h_mirror;
 	}
 };
 
@@ -2790,13 +2816,23 @@ int set_particles_impl(pbdx_solver *s, uint32_t n, const T *x, const T *v, const
 	T *st_x = reinterpret_cast<T *>(s->d_stage), *st_v = st_x + (size_t)3 * n, *st_o = st_v + (size_t)3 * n, *st_l = st_o + (size_t)3 * n;
 	T *st_m = st_l + (size_t)3 * n, *st_w = st_m + n;
 	const size_t b3 = (size_t)3 * n * sizeof(T), b1 = (size_t)n * sizeof(T);
-	s->pin(x, b3); s->pin(v, b3); s->pin(old_x, b3); s->pin(last_x, b3); s->pin(mass, b1); s->pin(inv_mass, b1);
-	HIPCHECK(hipMemcpyAsync(st_x, x, b3, hipMemcpyHostToDevice, s->stream));
-	if (v) HIPCHECK(hipMemcpyAsync(st_v, v, b3, hipMemcpyHostToDevice, s->stream));
-	if (old_x) HIPCHECK(hipMemcpyAsync(st_o, old_x, b3, hipMemcpyHostToDevice, s->stream));
-	if (last_x) HIPCHECK(hipMemcpyAsync(st_l, last_x, b3, hipMemcpyHostToDevice, s->stream));
-	HIPCHECK(hipMemcpyAsync(st_m, mass, b1, hipMemcpyHostToDevice, s->stream));
-	HIPCHECK(hipMemcpyAsync(st_w, inv_mass, b1, hipMemcpyHostToDevice, s->stream));
+	{
+		// (with the mirror: the host copy of an array runs while the previous array is on the bus)
+		char *mir = s->mirror((size_t)14 * n * sizeof(T));
+		struct { T *dst; const T *src; size_t bytes; } jobs[6] = { { st_x, x, b3 }, { st_v, v, b3 }, { st_o, old_x, b3 }, { st_l, last_x, b3 }, { st_m, mass, b1 }, { st_w, inv_mass, b1 } };
+		for (auto &j : jobs)
+		{
+			if (!j.src) continue;
+			const void *from = j.src;
+			if (mir)
+			{
+				char *slot = mir + (reinterpret_cast<char *>(j.dst) - reinterpret_cast<char *>(s->d_stage));
+				host_copy(slot, j.src, j.bytes);
+				from = slot;
+			}
+			HIPCHECK(hipMemcpyAsync(j.dst, from, j.bytes, hipMemcpyHostToDevice, s->stream));
+		}
+	}
 	const dim3 grid((n + 255) / 256), block(256);
 	hipLaunchKernelGGL(pack_kernel<T>, grid, block, 0, s->stream, (const T *)st_x, (const T *)st_w, s->d_pos[0], n);
 	if (!s->rest_set)
@@ -2825,15 +2861,29 @@ int get_particles_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, T *last
 	{ int rs = ensure_stage(s, sizeof(T)); if (rs) return rs; }
 	struct { T *dst; const float4 *src; } jobs[4] = { { x, s->d_pos[0] }, { v, s->d_vel }, { old_x, s->d_old }, { last_x, s->d_last } };
 	const size_t b3 = (size_t)3 * n * sizeof(T);
+	char *mir = s->mirror((size_t)14 * n * sizeof(T));
 	int k = 0;
 	for (auto &j : jobs)
 	{
-		T *st = reinterpret_cast<T *>(s->d_stage) + (size_t)3 * n * k++;
+		const int q = k++;
+		T *st = reinterpret_cast<T *>(s->d_stage) + (size_t)3 * n * q;
 		if (!j.dst) continue;
-		s->pin(j.dst, b3);
 		hipLaunchKernelGGL(unpack_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s->stream, j.src, st, n);
 		HIPCHECK(hipGetLastError());
-		HIPCHECK(hipMemcpyAsync(j.dst, st, b3, hipMemcpyDeviceToHost, s->stream));
+		HIPCHECK(hipMemcpyAsync(mir ? static_cast<void *>(mir + b3 * q) : static_cast<void *>(j.dst), st, b3, hipMemcpyDeviceToHost, s->stream));
+		if (mir) HIPCHECK(hipEventRecord(s->mirror_ev[q], s->stream));
+	}
+	if (mir)
+	{
+		// array q leaves the mirror while array q + 1 is still on the bus
+		k = 0;
+		for (auto &j : jobs)
+		{
+			const int q = k++;
+			if (!j.dst) continue;
+			HIPCHECK(hipEventSynchronize(s->mirror_ev[q]));
+			host_copy(j.dst, mir + b3 * q, b3);
+		}
 	}
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	return PBDX_OK;
@@ -2857,20 +2907,34 @@ int get_particles_hashed_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, 
 	struct { T *dst; const float4 *src; uint64_t *h; } jobs[4] = { { x, s->d_pos[0], hx }, { v, s->d_vel, hv }, { old_x, s->d_old, ho }, { last_x, s->d_last, hl } };
 	const size_t b3 = (size_t)3 * n * sizeof(T);
 	const uint32_t elem_words = 3 * (uint32_t)(sizeof(T) / 4);
+	const size_t hb = (size_t)nb * sizeof(uint64_t), stage_bytes = (size_t)14 * n * sizeof(T);
+	char *mir = s->mirror(stage_bytes + 4 * hb);
 	int k = 0;
 	for (auto &j : jobs)
 	{
 		const int q = k++;
 		T *st = reinterpret_cast<T *>(s->d_stage) + (size_t)3 * n * q;
 		if (!j.dst && !j.h) continue;
-		if (j.dst) s->pin(j.dst, b3);
 		hipLaunchKernelGGL(unpack_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s->stream, j.src, st, n);
 		if (j.h)
 			hipLaunchKernelGGL(hash_blocks_kernel, dim3(nb), dim3(256), 0, s->stream, reinterpret_cast<const uint32_t *>(st), (uint64_t)n * elem_words * 4u,
 				PBDX_HASH_BLOCK * elem_words * 4u, s->d_hash + (size_t)q * nb);
 		HIPCHECK(hipGetLastError());
-		if (j.dst) HIPCHECK(hipMemcpyAsync(j.dst, st, b3, hipMemcpyDeviceToHost, s->stream));
-		if (j.h) HIPCHECK(hipMemcpyAsync(j.h, s->d_hash + (size_t)q * nb, (size_t)nb * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+		if (j.dst) HIPCHECK(hipMemcpyAsync(mir ? static_cast<void *>(mir + b3 * q) : static_cast<void *>(j.dst), st, b3, hipMemcpyDeviceToHost, s->stream));
+		if (j.h) HIPCHECK(hipMemcpyAsync(mir ? static_cast<void *>(mir + stage_bytes + hb * q) : static_cast<void *>(j.h), s->d_hash + (size_t)q * nb, hb, hipMemcpyDeviceToHost, s->stream));
+		if (mir) HIPCHECK(hipEventRecord(s->mirror_ev[q], s->stream));
+	}
+	if (mir)
+	{
+		k = 0;
+		for (auto &j : jobs)
+		{
+			const int q = k++;
+			if (!j.dst && !j.h) continue;
+			HIPCHECK(hipEventSynchronize(s->mirror_ev[q]));
+			if (j.dst) host_copy(j.dst, mir + b3 * q, b3);
+			if (j.h) memcpy(j.h, mir + stage_bytes + hb * q, hb);
+		}
 	}
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	return PBDX_OK;
@@ -2891,14 +2955,21 @@ int update_ranges_impl(pbdx_solver *s, int array, const T *base, uint32_t num_ra
 	// the staging slot of the array (layout of set_particles_impl)
 	T *st = reinterpret_cast<T *>(s->d_stage) + (vec ? (size_t)3 * n * array : (size_t)12 * n + (size_t)n * (array - PBDX_ARRAY_MASS));
 	const size_t per = vec ? 3 : 1;
-	s->pin(base, per * n * sizeof(T));
+	char *mir = s->mirror((size_t)14 * n * sizeof(T));
 	float4 *dst = array == PBDX_ARRAY_X ? s->d_pos[0] : array == PBDX_ARRAY_V ? s->d_vel : array == PBDX_ARRAY_OLD_X ? s->d_old : array == PBDX_ARRAY_LAST_X ? s->d_last :
 		array == PBDX_ARRAY_MASS ? s->d_vel : s->d_pos[0];
 	for (uint32_t r = 0; r < num_ranges; r++)
 	{
 		const uint32_t first = ranges[2 * r], count = ranges[2 * r + 1];
 		if (!count) continue;
-		HIPCHECK(hipMemcpyAsync(st + per * first, base + per * first, per * count * sizeof(T), hipMemcpyHostToDevice, s->stream));
+		const void *from = base + per * first;
+		if (mir)
+		{
+			char *slot = mir + (reinterpret_cast<char *>(st + per * first) - reinterpret_cast<char *>(s->d_stage));
+			host_copy(slot, from, per * count * sizeof(T));
+			from = slot;
+		}
+		HIPCHECK(hipMemcpyAsync(st + per * first, from, per * count * sizeof(T), hipMemcpyHostToDevice, s->stream));
 		if (vec) hipLaunchKernelGGL(update_xyz_kernel<T>, dim3((count + 255) / 256), dim3(256), 0, s->stream, (const T *)st, dst, first, count);
 		else hipLaunchKernelGGL(update_w_kernel<T>, dim3((count + 255) / 256), dim3(256), 0, s->stream, (const T *)st, dst, first, count);
 	}
@@ -2973,7 +3044,7 @@ void pbdx_solver_destroy(pbdx_solver *s)
 	s->free_tet_colliders();
 	if (s->d_tet_contacts) (void)hipFree(s->d_tet_contacts);
 	if (s->d_tet_counters) (void)hipFree(s->d_tet_counters);
-	s->unpin_all();
+	s->free_mirror();
 	if (s->d_colliders) (void)hipFree(s->d_colliders);
 	if (s->d_ranges) (void)hipFree(s->d_ranges);
 	if (s->d_contact_counters) (void)hipFree(s->d_contact_counters);
@@ -3255,7 +3326,7 @@ int pbdx_solver_set_option(pbdx_solver *s, int option, int64_t value)
 		s->lds_particles = (uint32_t)value; replan = true; break;
 	case PBDX_OPT_TRACE: s->trace = value != 0; break;
 	case PBDX_OPT_PAIRS: break;        // removed (the packed two-slots-per-lane projection measured 10-30 % slower): accepted and ignored
-	case PBDX_OPT_PIN_HOST: s->pin_host = value != 0; if (!s->pin_host) s->unpin_all(); break;
+	case PBDX_OPT_PIN_HOST: s->pin_host = value != 0; if (!s->pin_host) { (void)hipStreamSynchronize(s->stream); s->free_mirror(); } break;
 	case PBDX_OPT_PERSISTENT:
 		if (value < 0 || value > 4) { set_error("persistent must be 0 .. 4"); return PBDX_ERR_INVALID; }
 		s->persistent = (int)value; replan = true; break;

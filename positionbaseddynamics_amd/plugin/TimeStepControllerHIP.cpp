@@ -265,8 +265,9 @@ TimeStepControllerHIP::TimeStepControllerHIP(int device) :
 		LOG_ERR << "TimeStepControllerHIP: " << pbdx_last_error() << " -- every step() will fail (no CPU path)";
 		m_solver = nullptr;
 	}
-	// ParticleData's arrays are handed to the engine in place: page-lock them (hipHostRegister) so that the per-step round trip
-	// of step() runs at the PCIe rate (setPinHostArrays(false) switches that off)
+	// ParticleData's arrays are handed to the engine in place; PBDX_OPT_PIN_HOST moves them through a page-locked mirror the engine owns, so that
+	// the per-step round trip of step() runs at the PCIe rate without the reference's heap being registered with the GPU
+	// (setPinHostArrays(false) switches that off)
 	if (m_solver) pbdx_solver_set_option(m_solver, PBDX_OPT_PIN_HOST, 1);
 }
 

@@ -76,7 +76,7 @@ namespace PBD
 		 * host writes are found by full-coverage block hashes (every word of x, v, oldX, lastX, masses is looked at before every
 		 * step) -- only to override the device-ahead merge rule below. */
 		void markHostDirty() { m_hostDirty = true; m_accelValid = false; }
-		/** page-lock ParticleData's arrays for the transfers of step() (default on) */
+		/** transfers of step() through the engine's page-locked mirror (PBDX_OPT_PIN_HOST; default on) */
 		void setPinHostArrays(bool b) { if (m_solver) pbdx_solver_set_option(m_solver, PBDX_OPT_PIN_HOST, b ? 1 : 0); }
 		/** the device holds a newer state than ParticleData */
 		bool deviceAhead() const { return m_deviceAhead; }

@@ -551,18 +551,20 @@ def _np_block_hashes(a):
 
 
 @pytest.mark.gpu
-def test_device_block_hashes_equal_the_host_definition():
+@pytest.mark.parametrize("n,mirror", [(5 * 1024 + 137, 0), (5 * 1024 + 137, 1), (700 * 1024 + 13, 1)])
+def test_device_block_hashes_equal_the_host_definition(n, mirror):
     """pbdx_solver_get_particles_hashed: the hashes the device returns are the host definition applied to the delivered bytes
     (float and double hosts; a particle count that is not a multiple of the block size), and pbdx_solver_update_particle_ranges
-    replaces exactly the given ranges."""
+    replaces exactly the given ranges.  mirror = 1: the same through the engine's page-locked mirror (PBDX_OPT_PIN_HOST; the large
+    case is copied by several host threads per array)."""
     import positionbaseddynamics_amd as pbd
     from positionbaseddynamics_amd import _ffi
-    n = 5 * 1024 + 137
     rng = np.random.default_rng(7)
     x = rng.standard_normal((n, 3)).astype(np.float32)
     v = rng.standard_normal((n, 3)).astype(np.float32)
     mass = np.ones(n, dtype=np.float32)
     sol = pbd.Solver()
+    sol.set_option(pbd.Solver.OPT_PIN_HOST, mirror)
     sol.set_particles(x, mass, v=v)
     pu64 = C.POINTER(C.c_uint64)
     nb = (n + 1023) // 1024
@@ -575,13 +577,30 @@ def test_device_block_hashes_equal_the_host_definition():
             assert np.array_equal(h, _np_block_hashes(o))
     # partial upload: two ranges of x, one of v; everything else stays
     x2 = x.copy(); x2[10:20] += 1.0; x2[4000:4100] -= 2.0; x2[3000] = 99.0          # 3000 is NOT in a range: must not arrive
-    ranges = np.array([10, 10, 4000, 100], dtype=np.uint32)
-    _ffi.check(_ffi.lib.pbdx_solver_update_particle_ranges(sol._h, 0, x2.ctypes.data_as(_ffi.pf), 2, ranges.ctypes.data_as(_ffi.pu)), "update_ranges")
-    want = x.copy(); want[10:20] = x2[10:20]; want[4000:4100] = x2[4000:4100]
+    rl = [10, 10, 4000, 100]
+    if n > 600000:
+        x2[100000:550000] *= np.float32(3.0); rl += [100000, 450000]                 # (a range several host threads copy)
+    ranges = np.array(rl, dtype=np.uint32)
+    _ffi.check(_ffi.lib.pbdx_solver_update_particle_ranges(sol._h, 0, x2.ctypes.data_as(_ffi.pf), len(rl) // 2, ranges.ctypes.data_as(_ffi.pu)), "update_ranges")
+    want = x.copy()
+    for q in range(0, len(rl), 2):
+        want[rl[q]:rl[q] + rl[q + 1]] = x2[rl[q]:rl[q] + rl[q + 1]]
     got = sol.get_particles()
     assert np.array_equal(got[0], want) and np.array_equal(got[1], v)
     bad = np.array([n - 5, 10], dtype=np.uint32)
     assert _ffi.lib.pbdx_solver_update_particle_ranges(sol._h, 0, x2.ctypes.data_as(_ffi.pf), 1, bad.ctypes.data_as(_ffi.pu)) != 0
+    # a double host: the whole image again, every array given, and back (values are floats: the conversion is exact both ways)
+    pd_ = C.POINTER(C.c_double)
+    arrs = [rng.standard_normal((n, 3)).astype(np.float32).astype(np.float64) for _ in range(4)]
+    m64 = np.full(n, 2.0); w64 = np.full(n, 0.5)
+    _ffi.check(_ffi.lib.pbdx_solver_set_particles_f64(sol._h, n, *[a.ctypes.data_as(pd_) for a in arrs], m64.ctypes.data_as(pd_), w64.ctypes.data_as(pd_)), "set_particles_f64")
+    back = [np.zeros((n, 3)) for _ in range(4)]
+    _ffi.check(_ffi.lib.pbdx_solver_get_particles_f64(sol._h, n, *[b.ctypes.data_as(pd_) for b in back]), "get_particles_f64")
+    for a, b in zip(arrs, back):
+        assert np.array_equal(a, b)
+    sol.set_option(pbd.Solver.OPT_PIN_HOST, 0)            # (the mirror goes; transfers keep working)
+    got = sol.get_particles()
+    assert np.array_equal(got[0], arrs[0].astype(np.float32)) and np.array_equal(got[3], arrs[3].astype(np.float32))
 
 
 def _extra(path):
