@@ -190,8 +190,8 @@ extern "C" int pbdx_colour_constraints(int device, uint32_t num_bodies, uint32_t
 	HIPCHECK(buf.alloc(&d_succ, npairs)); HIPCHECK(buf.alloc(&d_pending, nc)); HIPCHECK(buf.alloc(&d_colour, nc));
 	HIPCHECK(buf.alloc(&d_front_a, nc)); HIPCHECK(buf.alloc(&d_front_b, nc)); HIPCHECK(buf.alloc(&d_status, (size_t)kStWords));
 	HIPCHECK(buf.alloc(&d_used, (size_t)num_bodies * kWords));
-	HIPCHECK(hipMemcpy(d_off, body_off, ((size_t)nc + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
-	HIPCHECK(hipMemcpy(d_bodies, bodies, (size_t)nidx * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIPCHECK(pbdx::copy_to_device(d_off, body_off, ((size_t)nc + 1) * sizeof(uint32_t)));
+	HIPCHECK(pbdx::copy_to_device(d_bodies, bodies, (size_t)nidx * sizeof(uint32_t)));
 	HIPCHECK(hipMemset(d_status, 0, kStWords * sizeof(uint32_t)));
 	HIPCHECK(hipMemset(d_used, 0, (size_t)num_bodies * kWords * sizeof(uint64_t)));
 	lap("allocated, uploaded");
@@ -225,7 +225,7 @@ extern "C" int pbdx_colour_constraints(int device, uint32_t num_bodies, uint32_t
 		set_error("pbdx_colour_constraints: %s (colour on the host instead)", what[std::min<uint32_t>(status[kStError], 4u)]);
 		return status[kStError] == kErrBodyRange ? PBDX_ERR_INVALID : PBDX_ERR_UNSUPPORTED;
 	}
-	HIPCHECK(hipMemcpy(group_of, d_colour, (size_t)nc * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	HIPCHECK(pbdx::copy_from_device(group_of, d_colour, (size_t)nc * sizeof(uint32_t)));
 	if (num_groups)
 	{
 		uint32_t g = 0;

@@ -22,4 +22,11 @@ struct DeviceScope
 #define ENTER_DEVICE(device) DeviceScope device_scope_(device); HIPCHECK(device_scope_.err)
 }
 
+// pbdx_hostio.hip: synchronous copies between host memory the library does not own and the CURRENT device, through the library's page-locked
+// bounce buffer -- instead of hipMemcpy on the caller's pointer, which has the runtime map the caller's heap pages into the GPU's address space
+namespace pbdx {
+hipError_t copy_to_device(void *dst, const void *src, size_t bytes);
+hipError_t copy_from_device(void *dst, const void *src, size_t bytes);
+}
+
 #endif

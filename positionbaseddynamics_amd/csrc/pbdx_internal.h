@@ -75,6 +75,11 @@ int sort_pairs_u32(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint
 
 namespace pbdx { uint64_t next_model_uid(); }
 
+// pbdx_hostio.hip (the copies to / from the device are declared in pbdx_device.h)
+namespace pbdx {
+void host_copy(void *dst, const void *src, size_t bytes);             // memcpy, by several threads when large
+}
+
 struct pbdx_model
 {
 	// ParticleData (Simulation/ParticleData.h:91-100), packed xyz

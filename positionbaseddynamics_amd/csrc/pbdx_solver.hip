@@ -1479,24 +1479,7 @@ struct DeviceSegment
 // of a plug-in test, one run in four (profiles/HISTORY.md [9]).  With the mirror the GPU is never given an address of memory the engine does
 // not own: the device copies to / from the mirror, host threads copy between the mirror and the caller's arrays, array by array, so that the
 // copy of one array runs while the next one is on the bus.
-static void host_copy(void *dst, const void *src, size_t bytes)
-{
-	const size_t kSlice = (size_t)1 << 20;
-	unsigned threads = (unsigned)std::min<size_t>(bytes / kSlice, 16);
-	const unsigned hw = std::thread::hardware_concurrency();
-	if (hw && threads > hw) threads = hw;
-	if (threads < 2) { memcpy(dst, src, bytes); return; }
-	std::vector<std::thread> team;
-	team.reserve(threads - 1);
-	const size_t per = ((bytes + threads - 1) / threads + 63) & ~(size_t)63;
-	for (unsigned t = 1; t < threads; t++)
-	{
-		const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, per * (t + 1));
-		if (hi > lo) team.emplace_back([=]() { memcpy(static_cast<char *>(dst) + lo, static_cast<const char *>(src) + lo, hi - lo); });
-	}
-	memcpy(dst, src, std::min(bytes, per));
-	for (std::thread &t : team) t.join();
-}
+using pbdx::host_copy;
 
 struct pbdx_solver
 {
@@ -1759,7 +1742,7 @@ template <class T> int upload(T **dst, const std::vector<T> &src)
 	*dst = nullptr;
 	if (src.empty()) return PBDX_OK;
 	HIPCHECK(hipMalloc(dst, src.size() * sizeof(T)));
-	HIPCHECK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+	HIPCHECK(pbdx::copy_to_device(*dst, src.data(), src.size() * sizeof(T)));
 	return PBDX_OK;
 }
 
@@ -2099,7 +2082,7 @@ int ensure_device_batches(pbdx_solver *s)
 		for (uint32_t i = 0; i < count; i++)
 			for (uint32_t k = 0; k < nb; k++) idx[(size_t)i * iw + k] = b.h_idx[(size_t)i * nb + k];
 		HIPCHECK(hipMalloc(&b.d_idx, idx.size() * sizeof(uint32_t)));
-		HIPCHECK(hipMemcpy(b.d_idx, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		HIPCHECK(pbdx::copy_to_device(b.d_idx, idx.data(), idx.size() * sizeof(uint32_t)));
 		// parameters: planar streams of the layout chosen for this batch (compact / full)
 		const bool compact = b.view.compact != 0;
 		if (num_planes(b.type, compact) && !b.d_params)
@@ -2112,7 +2095,7 @@ int ensure_device_batches(pbdx_solver *s)
 				for (uint32_t i = 0; i < count; i++) dst[i] = b.h_params[(size_t)i * np + k];
 			}
 			HIPCHECK(hipMalloc(&b.d_params, planar.size() * sizeof(float)));
-			HIPCHECK(hipMemcpy(b.d_params, planar.data(), planar.size() * sizeof(float), hipMemcpyHostToDevice));
+			HIPCHECK(pbdx::copy_to_device(b.d_params, planar.data(), planar.size() * sizeof(float)));
 		}
 		if (ti->xpbd && !b.d_lambda)
 		{
@@ -2823,14 +2806,10 @@ int set_particles_impl(pbdx_solver *s, uint32_t n, const T *x, const T *v, const
 		for (auto &j : jobs)
 		{
 			if (!j.src) continue;
-			const void *from = j.src;
-			if (mir)
-			{
-				char *slot = mir + (reinterpret_cast<char *>(j.dst) - reinterpret_cast<char *>(s->d_stage));
-				host_copy(slot, j.src, j.bytes);
-				from = slot;
-			}
-			HIPCHECK(hipMemcpyAsync(j.dst, from, j.bytes, hipMemcpyHostToDevice, s->stream));
+			if (!mir) { HIPCHECK(pbdx::copy_to_device(j.dst, j.src, j.bytes)); continue; }       // (the library's bounce buffer)
+			char *slot = mir + (reinterpret_cast<char *>(j.dst) - reinterpret_cast<char *>(s->d_stage));
+			host_copy(slot, j.src, j.bytes);
+			HIPCHECK(hipMemcpyAsync(j.dst, slot, j.bytes, hipMemcpyHostToDevice, s->stream));
 		}
 	}
 	const dim3 grid((n + 255) / 256), block(256);
@@ -2870,8 +2849,9 @@ int get_particles_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, T *last
 		if (!j.dst) continue;
 		hipLaunchKernelGGL(unpack_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s->stream, j.src, st, n);
 		HIPCHECK(hipGetLastError());
-		HIPCHECK(hipMemcpyAsync(mir ? static_cast<void *>(mir + b3 * q) : static_cast<void *>(j.dst), st, b3, hipMemcpyDeviceToHost, s->stream));
-		if (mir) HIPCHECK(hipEventRecord(s->mirror_ev[q], s->stream));
+		if (!mir) { HIPCHECK(pbdx::copy_from_device(j.dst, st, b3)); continue; }       // (waits for the kernel; the library's bounce buffer)
+		HIPCHECK(hipMemcpyAsync(mir + b3 * q, st, b3, hipMemcpyDeviceToHost, s->stream));
+		HIPCHECK(hipEventRecord(s->mirror_ev[q], s->stream));
 	}
 	if (mir)
 	{
@@ -2920,9 +2900,15 @@ int get_particles_hashed_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, 
 			hipLaunchKernelGGL(hash_blocks_kernel, dim3(nb), dim3(256), 0, s->stream, reinterpret_cast<const uint32_t *>(st), (uint64_t)n * elem_words * 4u,
 				PBDX_HASH_BLOCK * elem_words * 4u, s->d_hash + (size_t)q * nb);
 		HIPCHECK(hipGetLastError());
-		if (j.dst) HIPCHECK(hipMemcpyAsync(mir ? static_cast<void *>(mir + b3 * q) : static_cast<void *>(j.dst), st, b3, hipMemcpyDeviceToHost, s->stream));
-		if (j.h) HIPCHECK(hipMemcpyAsync(mir ? static_cast<void *>(mir + stage_bytes + hb * q) : static_cast<void *>(j.h), s->d_hash + (size_t)q * nb, hb, hipMemcpyDeviceToHost, s->stream));
-		if (mir) HIPCHECK(hipEventRecord(s->mirror_ev[q], s->stream));
+		if (!mir)
+		{
+			if (j.dst) HIPCHECK(pbdx::copy_from_device(j.dst, st, b3));
+			if (j.h) HIPCHECK(pbdx::copy_from_device(j.h, s->d_hash + (size_t)q * nb, hb));
+			continue;
+		}
+		if (j.dst) HIPCHECK(hipMemcpyAsync(mir + b3 * q, st, b3, hipMemcpyDeviceToHost, s->stream));
+		if (j.h) HIPCHECK(hipMemcpyAsync(mir + stage_bytes + hb * q, s->d_hash + (size_t)q * nb, hb, hipMemcpyDeviceToHost, s->stream));
+		HIPCHECK(hipEventRecord(s->mirror_ev[q], s->stream));
 	}
 	if (mir)
 	{
@@ -2962,14 +2948,13 @@ int update_ranges_impl(pbdx_solver *s, int array, const T *base, uint32_t num_ra
 	{
 		const uint32_t first = ranges[2 * r], count = ranges[2 * r + 1];
 		if (!count) continue;
-		const void *from = base + per * first;
 		if (mir)
 		{
 			char *slot = mir + (reinterpret_cast<char *>(st + per * first) - reinterpret_cast<char *>(s->d_stage));
-			host_copy(slot, from, per * count * sizeof(T));
-			from = slot;
+			host_copy(slot, base + per * first, per * count * sizeof(T));
+			HIPCHECK(hipMemcpyAsync(st + per * first, slot, per * count * sizeof(T), hipMemcpyHostToDevice, s->stream));
 		}
-		HIPCHECK(hipMemcpyAsync(st + per * first, from, per * count * sizeof(T), hipMemcpyHostToDevice, s->stream));
+		else HIPCHECK(pbdx::copy_to_device(st + per * first, base + per * first, per * count * sizeof(T)));
 		if (vec) hipLaunchKernelGGL(update_xyz_kernel<T>, dim3((count + 255) / 256), dim3(256), 0, s->stream, (const T *)st, dst, first, count);
 		else hipLaunchKernelGGL(update_w_kernel<T>, dim3((count + 255) / 256), dim3(256), 0, s->stream, (const T *)st, dst, first, count);
 	}
@@ -3077,7 +3062,7 @@ int pbdx_solver_set_positions(pbdx_solver *s, uint32_t n, const float *x)
 	if (!s || !x || n != s->n) { set_error("set_positions: particle count mismatch"); return PBDX_ERR_INVALID; }
 	if (!n) return PBDX_OK;
 	ENTER_DEVICE(s->device);
-	HIPCHECK(hipMemcpyAsync(s->d_stage, x, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+	HIPCHECK(pbdx::copy_to_device(s->d_stage, x, (size_t)3 * n * sizeof(float)));
 	hipLaunchKernelGGL(set_xyz_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_stage, s->d_pos[0], n);
 	HIPCHECK(hipGetLastError());
 	HIPCHECK(hipStreamSynchronize(s->stream));
@@ -3251,14 +3236,14 @@ int pbdx_solver_commit_params(pbdx_solver *s)
 			}
 		}
 		if (!seg.params.empty())
-			HIPCHECK(hipMemcpy(s->dsegs[si].d_params, seg.params.data(), seg.params.size() * sizeof(float), hipMemcpyHostToDevice));
+			HIPCHECK(pbdx::copy_to_device(s->dsegs[si].d_params, seg.params.data(), seg.params.size() * sizeof(float)));
 		// the packed records of the index image carry a copy of the one-plane types' parameter: rebuilt (same layout, same offsets)
 		{
 			std::vector<uint8_t> idx_img;
 			std::vector<StepImage> step_img;
 			build_idx_image(seg, s->plan.views, s->dsegs[si].block, s->pack_plain, idx_img, step_img);
 			if (idx_img.size() != s->dsegs[si].idx_bytes) { s->free_plan(); return PBDX_OK; }      // (cannot happen: the layout depends on counts and views only)
-			if (!idx_img.empty()) HIPCHECK(hipMemcpy(s->dsegs[si].d_idx, idx_img.data(), idx_img.size(), hipMemcpyHostToDevice));
+			if (!idx_img.empty()) HIPCHECK(pbdx::copy_to_device(s->dsegs[si].d_idx, idx_img.data(), idx_img.size()));
 		}
 	}
 	return PBDX_OK;
@@ -3744,7 +3729,7 @@ int pbdx_solver_set_colliders(pbdx_solver *s, uint32_t n, const pbdx_collider *c
 	if (n)
 	{
 		HIPCHECK(hipMalloc(&s->d_colliders, (size_t)n * sizeof(pbdx_collider)));
-		HIPCHECK(hipMemcpy(s->d_colliders, colliders, (size_t)n * sizeof(pbdx_collider), hipMemcpyHostToDevice));
+		HIPCHECK(pbdx::copy_to_device(s->d_colliders, colliders, (size_t)n * sizeof(pbdx_collider)));
 	}
 	if (!s->d_contact_counters)
 	{
@@ -3766,7 +3751,7 @@ int pbdx_solver_set_collision_ranges(pbdx_solver *s, uint32_t n, const pbdx_coll
 	if (n)
 	{
 		HIPCHECK(hipMalloc(&s->d_ranges, (size_t)n * sizeof(pbdx_collision_range)));
-		HIPCHECK(hipMemcpy(s->d_ranges, ranges, (size_t)n * sizeof(pbdx_collision_range), hipMemcpyHostToDevice));
+		HIPCHECK(pbdx::copy_to_device(s->d_ranges, ranges, (size_t)n * sizeof(pbdx_collision_range)));
 	}
 	return PBDX_OK;
 }
@@ -3784,7 +3769,7 @@ int pbdx_solver_set_rest_positions(pbdx_solver *s, uint32_t n, const float *x0)
 	ENTER_DEVICE(s->device);
 	{ int rs = ensure_stage(s, sizeof(float)); if (rs) return rs; }
 	if (!s->d_rest) HIPCHECK(hipMalloc(&s->d_rest, (size_t)n * sizeof(float4)));
-	HIPCHECK(hipMemcpyAsync(s->d_stage, x0, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+	HIPCHECK(pbdx::copy_to_device(s->d_stage, x0, (size_t)3 * n * sizeof(float)));
 	hipLaunchKernelGGL(pack_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s->stream, (const float *)s->d_stage, (const float *)nullptr, s->d_rest, n);
 	HIPCHECK(hipGetLastError());
 	HIPCHECK(hipStreamSynchronize(s->stream));
@@ -3811,7 +3796,7 @@ static int set_tet_colliders_impl(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 	auto up = [](auto **dst, const auto *src, size_t count) -> hipError_t
 	{
 		hipError_t e = hipMalloc(dst, count * sizeof(**dst));
-		if (e == hipSuccess) e = hipMemcpy(*dst, src, count * sizeof(**dst), hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = pbdx::copy_to_device(*dst, src, count * sizeof(**dst));
 		return e;
 	};
 	s->tet_dev.resize(n);
@@ -3836,7 +3821,7 @@ static int set_tet_colliders_impl(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 			HIPCHECK(up(&dst[q]->lst, src[q]->entities, src[q]->num_entities));
 			HIPCHECK(up(&dst[q]->nodes, src[q]->nodes, (size_t)4 * src[q]->num_nodes));
 			HIPCHECK(hipMalloc(&dst[q]->hulls, (size_t)src[q]->num_nodes * sizeof(P4)));
-			if (q == 2) HIPCHECK(hipMemcpy(dst[q]->hulls, src[q]->hulls, (size_t)src[q]->num_nodes * sizeof(P4), hipMemcpyHostToDevice));
+			if (q == 2) HIPCHECK(pbdx::copy_to_device(dst[q]->hulls, src[q]->hulls, (size_t)src[q]->num_nodes * sizeof(P4)));
 			else HIPCHECK(hipMemset(dst[q]->hulls, 0, (size_t)src[q]->num_nodes * sizeof(P4)));
 			dst[q]->num_nodes = src[q]->num_nodes;
 			*view[q] = BvhView{ dst[q]->lst, dst[q]->nodes, dst[q]->hulls, dst[q]->num_nodes, nullptr, nullptr, nullptr, 0, 0 };
@@ -3886,7 +3871,7 @@ static int set_tet_colliders_impl(pbdx_solver *s, uint32_t n, const pbdx_tet_col
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(tet_hull_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTcBigNodeLds);
 	}
 	HIPCHECK(hipMalloc(&s->d_tet_views, (size_t)n * sizeof(TetColliderView)));
-	HIPCHECK(hipMemcpy(s->d_tet_views, s->tet_views.data(), (size_t)n * sizeof(TetColliderView), hipMemcpyHostToDevice));
+	HIPCHECK(pbdx::copy_to_device(s->d_tet_views, s->tet_views.data(), (size_t)n * sizeof(TetColliderView)));
 	HIPCHECK(hipMalloc(&s->d_tet_aabb, (size_t)6 * n * sizeof(float)));
 	if (!s->d_tet_counters) HIPCHECK(hipMalloc(&s->d_tet_counters, kTcWords * sizeof(uint32_t)));
 	HIPCHECK(hipMemset(s->d_tet_counters, 0, kTcWords * sizeof(uint32_t)));      // no contacts before the first detection
@@ -3944,7 +3929,7 @@ int pbdx_debug_tet_hulls(pbdx_solver *s, uint32_t collider, int which, uint32_t 
 	HIPCHECK(hipStreamSynchronize(s->stream));
 	const pbdx_solver::DevBvh &b = which == 0 ? s->tet_dev[collider].points : which == 1 ? s->tet_dev[collider].tet_bvh : s->tet_dev[collider].tet_bvh0;
 	*count = b.num_nodes;
-	if (out && capacity) HIPCHECK(hipMemcpy(out, b.hulls, (size_t)std::min(capacity, b.num_nodes) * sizeof(P4), hipMemcpyDeviceToHost));
+	if (out && capacity) HIPCHECK(pbdx::copy_from_device(out, b.hulls, (size_t)std::min(capacity, b.num_nodes) * sizeof(P4)));
 	return PBDX_OK;
 }
 
@@ -3962,7 +3947,7 @@ int pbdx_solver_get_tet_contacts(pbdx_solver *s, uint32_t capacity, uint32_t *co
 	if (m && out)
 	{
 		std::vector<TetContact> tmp(m);
-		HIPCHECK(hipMemcpy(tmp.data(), s->d_tet_contacts, (size_t)m * sizeof(TetContact), hipMemcpyDeviceToHost));
+		HIPCHECK(pbdx::copy_from_device(tmp.data(), s->d_tet_contacts, (size_t)m * sizeof(TetContact)));
 		for (uint32_t i = 0; i < m; i++) contact_to_floats(tmp[i], out + (size_t)i * PBDX_TET_CONTACT_FLOATS);
 	}
 	return PBDX_OK;
@@ -3992,7 +3977,7 @@ int pbdx_solver_get_lambdas(pbdx_solver *s, uint32_t batch_index, uint32_t count
 	if (!s->fused_active())
 	{
 		if (!b.d_lambda) { memset(out, 0, (size_t)count * sizeof(float)); return PBDX_OK; }     // schedule never ran
-		HIPCHECK(hipMemcpy(out, b.d_lambda, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+		HIPCHECK(pbdx::copy_from_device(out, b.d_lambda, (size_t)count * sizeof(float)));
 		return PBDX_OK;
 	}
 	// fused schedule: the multiplier of a constraint lives in the lambda stream of every tile that
@@ -4016,7 +4001,7 @@ int pbdx_solver_get_lambdas(pbdx_solver *s, uint32_t batch_index, uint32_t count
 				if (cid < cid0 || cid >= cid0 + count || have[cid - cid0]) continue;
 				if (!fetched)
 				{
-					HIPCHECK(hipMemcpy(lam.data(), s->dsegs[si].d_lambda, (size_t)seg.lam_count * sizeof(float), hipMemcpyDeviceToHost));
+					HIPCHECK(pbdx::copy_from_device(lam.data(), s->dsegs[si].d_lambda, (size_t)seg.lam_count * sizeof(float)));
 					fetched = true;
 				}
 				out[cid - cid0] = lam[st.lam_off + q];
@@ -4119,7 +4104,7 @@ int pbdx_solver_get_trace(pbdx_solver *s, uint32_t segment, uint64_t *out, uint3
 	if (capacity < need) { set_error("get_trace: need room for %zu stamps", need); return PBDX_ERR_INVALID; }
 	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
-	HIPCHECK(hipMemcpy(out, d.d_trace, need * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	HIPCHECK(pbdx::copy_from_device(out, d.d_trace, need * sizeof(uint64_t)));
 	if (stride) *stride = kTraceStride;
 	return PBDX_OK;
 }
@@ -4201,7 +4186,7 @@ int pbdx_debug_valu_issue(int device, int threads, double *cycles_per_instructio
 		HIPCHECK(hipDeviceSynchronize());
 	}
 	std::vector<unsigned long long> cyc((size_t)cus * waves);
-	HIPCHECK(hipMemcpy(cyc.data(), d_cyc, cyc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIPCHECK(pbdx::copy_from_device(cyc.data(), d_cyc, cyc.size() * sizeof(unsigned long long)));
 	(void)hipFree(sink); (void)hipFree(d_cyc);
 	std::sort(cyc.begin(), cyc.end());
 	const double per_wave = (double)cyc[cyc.size() / 2] / ((double)iters * 64.0);      // cycles per instruction of ONE wave

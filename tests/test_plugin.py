@@ -551,12 +551,13 @@ def _np_block_hashes(a):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,mirror", [(5 * 1024 + 137, 0), (5 * 1024 + 137, 1), (700 * 1024 + 13, 1)])
+@pytest.mark.parametrize("n,mirror", [(5 * 1024 + 137, 0), (5 * 1024 + 137, 1), (700 * 1024 + 13, 1), (1500 * 1024 + 7, 0)])
 def test_device_block_hashes_equal_the_host_definition(n, mirror):
     """pbdx_solver_get_particles_hashed: the hashes the device returns are the host definition applied to the delivered bytes
     (float and double hosts; a particle count that is not a multiple of the block size), and pbdx_solver_update_particle_ranges
     replaces exactly the given ranges.  mirror = 1: the same through the engine's page-locked mirror (PBDX_OPT_PIN_HOST; the large
-    case is copied by several host threads per array)."""
+    case is copied by several host threads per array); mirror = 0 goes through the library's bounce buffer (pbdx_hostio.hip: 8 MiB
+    halves -- the 1.5 M case takes three per array)."""
     import positionbaseddynamics_amd as pbd
     from positionbaseddynamics_amd import _ffi
     rng = np.random.default_rng(7)
