@@ -165,3 +165,33 @@ def test_bounds_report_of_the_product_build_says_unchecked():
         pytest.skip("the library under test IS the debug build")
     rep = pbd.bounds_report(0)
     assert rep["checked"] is False and rep["violations"] == 0
+
+
+def test_no_caller_memory_is_handed_to_the_gpu():
+    """Host memory the library does not own never reaches the device by ADDRESS: the built libraries do not import hipHostRegister, and
+    in the sources every copy with a host side either goes through csrc/pbdx_hostio.hip (the library's page-locked bounce buffer), through
+    an engine's page-locked mirror, or is one of the 32-byte counter reads (profiles/HISTORY.md [9]: a GPU memory fault at a host heap
+    address).  Needs no GPU."""
+    import glob
+    import subprocess
+    libs = glob.glob(os.path.join(util.ROOT, "positionbaseddynamics_amd", "_lib", "libpbdx*.so"))
+    assert libs
+    for lib in libs:
+        syms = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+        assert "hipHostRegister" not in syms and "hipHostUnregister" not in syms, lib
+    csrc = os.path.join(util.ROOT, "positionbaseddynamics_amd", "csrc")
+    own = re.compile(r"hipMemcpy(Async)?\((mir\b|mir \+|j\.dst, slot|st \+ per \* first, slot|c, s->d_(tet|contact)_counters|status, d_status|out, s->d_tet_counters, 8 \*)")
+    bad = []
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.h"))):
+        if os.path.basename(path) == "pbdx_hostio.hip":
+            continue
+        for ln, line in enumerate(open(path), 1):
+            if re.search(r"hipMemcpy(Async)?\(", line) and "DeviceToDevice" not in line and not own.search(line):
+                bad.append("%s:%d: %s" % (os.path.basename(path), ln, line.strip()))
+            if "hipHostRegister(" in line:
+                bad.append("%s:%d: %s" % (os.path.basename(path), ln, line.strip()))
+    assert not bad, "\n".join(bad)
+    plug = os.path.join(util.ROOT, "positionbaseddynamics_amd", "plugin")
+    for path in glob.glob(os.path.join(plug, "*.cpp")) + glob.glob(os.path.join(plug, "*.h")):
+        text = open(path).read()
+        assert "hipMemcpy" not in text and "hipHostRegister(" not in text, path
