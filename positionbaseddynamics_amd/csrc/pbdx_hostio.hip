@@ -10,30 +10,100 @@
 #include <hip/hip_runtime.h>
 #include "pbdx_internal.h"
 #include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
 #include <string.h>
+#include <unistd.h>
 
 namespace pbdx {
 
+// memcpy by a team of worker threads that is started on first use and stays (a thread start per 8 MiB half costs more than the half's copy).
+// One job at a time; the calling thread works too.  All job state is guarded by one mutex, and a job's fields change only when the previous
+// job is complete, so a worker that wakes late finds nothing to take.  After fork() the child has no workers: it copies on its own thread.
+namespace {
+class CopyTeam
+{
+public:
+	explicit CopyTeam(unsigned workers) : pid_(getpid())
+	{
+		for (unsigned t = 0; t < workers; t++) std::thread([this]() { work(); }).detach();
+	}
+	void run(char *dst, const char *src, size_t bytes, size_t per)
+	{
+		std::lock_guard<std::mutex> one_job(jobs_);
+		std::unique_lock<std::mutex> lock(m_);
+		dst_ = dst; src_ = src; bytes_ = bytes; per_ = per; parts_ = (unsigned)((bytes + per - 1) / per); next_ = 0; done_ = 0;
+		wake_.notify_all();
+		while (next_ < parts_) take(lock);
+		finished_.wait(lock, [this]() { return done_ == parts_; });
+		parts_ = 0; next_ = 0;
+	}
+	pid_t pid() const { return pid_; }
+private:
+	void take(std::unique_lock<std::mutex> &lock)
+	{
+		const size_t lo = per_ * next_++, hi = std::min(bytes_, lo + per_);
+		char *d = dst_; const char *s = src_;
+		lock.unlock();
+		memcpy(d + lo, s + lo, hi - lo);
+		lock.lock();
+		if (++done_ == parts_) finished_.notify_all();
+	}
+	void work()
+	{
+		std::unique_lock<std::mutex> lock(m_);
+		for (;;)
+		{
+			wake_.wait(lock, [this]() { return next_ < parts_; });
+			take(lock);
+		}
+	}
+	std::mutex jobs_, m_;
+	std::condition_variable wake_, finished_;
+	char *dst_ = nullptr; const char *src_ = nullptr;
+	size_t bytes_ = 0, per_ = 0;
+	unsigned parts_ = 0, next_ = 0, done_ = 0;
+	const pid_t pid_;
+};
+} // namespace
+
+#ifndef PBDX_COPY_TEAM
+#define PBDX_COPY_TEAM 1        // 0: threads started per call (A/B builds: scripts/build_variant.sh spawn -DPBDX_COPY_TEAM=0)
+#endif
+
 void host_copy(void *dst, const void *src, size_t bytes)
 {
-	const size_t kSlice = (size_t)1 << 20;
-	unsigned threads = (unsigned)std::min<size_t>(bytes / kSlice, 16);
-	const unsigned hw = std::thread::hardware_concurrency();
-	if (hw && threads > hw) threads = hw;
-	if (threads < 2) { memcpy(dst, src, bytes); return; }
-	std::vector<std::thread> team;
-	team.reserve(threads - 1);
-	const size_t per = ((bytes + threads - 1) / threads + 63) & ~(size_t)63;
-	for (unsigned t = 1; t < threads; t++)
+#if !PBDX_COPY_TEAM
 	{
-		const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, per * (t + 1));
-		if (hi > lo) team.emplace_back([=]() { memcpy(static_cast<char *>(dst) + lo, static_cast<const char *>(src) + lo, hi - lo); });
+		const size_t kSlice = (size_t)1 << 20;
+		unsigned threads = (unsigned)std::min<size_t>(bytes / kSlice, 16);
+		const unsigned hw = std::thread::hardware_concurrency();
+		if (hw && threads > hw) threads = hw;
+		if (threads < 2) { memcpy(dst, src, bytes); return; }
+		std::vector<std::thread> team;
+		team.reserve(threads - 1);
+		const size_t per = ((bytes + threads - 1) / threads + 63) & ~(size_t)63;
+		for (unsigned t = 1; t < threads; t++)
+		{
+			const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, per * (t + 1));
+			if (hi > lo) team.emplace_back([=]() { memcpy(static_cast<char *>(dst) + lo, static_cast<const char *>(src) + lo, hi - lo); });
+		}
+		memcpy(dst, src, std::min(bytes, per));
+		for (std::thread &t : team) t.join();
+		return;
 	}
-	memcpy(dst, src, std::min(bytes, per));
-	for (std::thread &t : team) t.join();
+#endif
+	const size_t kPart = (size_t)256 << 10;
+	if (bytes < 4 * kPart) { memcpy(dst, src, bytes); return; }
+	static CopyTeam *team = []()
+	{
+		const unsigned hw = std::thread::hardware_concurrency();
+		return new CopyTeam(std::max(1u, std::min(hw ? hw / 2 : 4u, 16u)) - 0u);         // never destroyed: the workers sleep until the process ends
+	}();
+	if (team->pid() != getpid()) { memcpy(dst, src, bytes); return; }                  // (forked child)
+	team->run(static_cast<char *>(dst), static_cast<const char *>(src), bytes, kPart);
 }
 
 namespace {

@@ -372,6 +372,13 @@ def test_plugin_full_size_c2_reference_model():
     assert cnt["schedule_builds"](ts) == 1 and cnt["param_refreshes"](ts) == refreshes_after_switch
     print("plug-in at 1000x1000: first step (schedule build + plan + autotune) %.2f s; round trip %.3f ms/step; resident %.3f ms/step; syncToHost %.2f ms" % (
         t_first, 1e3 * t_round, 1e3 * t_res, 1e3 * t_sync))
+    try:      # (diagnostic only: a refused or timed-out one-launch schedule would explain a slow resident figure)
+        import positionbaseddynamics_amd as pbd
+        lib.pbdx_timestep_hip_solver.argtypes = [C.c_void_p]; lib.pbdx_timestep_hip_solver.restype = C.c_void_p
+        pi = pbd.Solver(handle=lib.pbdx_timestep_hip_solver(ts)).persistent_info()
+        print("  engine of the plug-in: one-launch schedule active %s, refusals %s, time-outs %s" % (pi.get("active"), pi.get("refusals"), pi.get("timeouts")))
+    except Exception as e:
+        print("  (no schedule information: %r)" % (e,))
     ref.reset_all()
     assert t_res < 1.5e-3 and t_round < 8e-3 and t_round_exact < 30e-3
 
