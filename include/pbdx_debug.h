@@ -50,6 +50,9 @@ uint64_t pbdx_debug_param_float_index(int vector_params, uint32_t planes, uint32
 /* The practical HBM roof ("use the measured copy bandwidth as the practical roof and report both"): device-to-device float4 copy of `nbytes`,
  * best of `reps` launches, read + written bytes per second in GB/s. */
 int pbdx_debug_copy_bandwidth(int device, uint64_t nbytes, int reps, double *gbs);
+/* The library's host-side copy (csrc/pbdx_hostio.hip: memcpy by a resident team of threads above 1 MiB; the copy between caller memory and
+ * the library's page-locked buffers).  Needs no GPU: tests/test_hostio.py, scripts/dev/hostio_bench.py. */
+void pbdx_debug_host_copy(void *dst, const void *src, uint64_t bytes);
 /* The vector-ALU issue interval the SQ_INSTS_VALU counter is to be priced with: shader cycles per wave64 v_mul_f32 / v_add_f32 and SIMD, measured with
  * `threads` (256, 512, 1024) threads per workgroup and one workgroup per CU, i.e. at the occupancy of the sweep kernels. */
 int pbdx_debug_valu_issue(int device, int threads, double *cycles_per_instruction);

@@ -124,6 +124,7 @@ SIGNATURES = [
     ("pbdx_debug_stream", C.c_int, C.c_int, C.c_uint64, C.c_int),
     ("pbdx_debug_bounds_report", C.c_int, C.c_int, C.POINTER(u32), C.c_int),
     ("pbdx_debug_copy_bandwidth", C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double)),
+    ("pbdx_debug_host_copy", None, C.c_void_p, C.c_void_p, C.c_uint64),
     ("pbdx_debug_valu_issue", C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)),
     ("pbdx_debug_plan_lds_model", C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_uint64)),
     ("pbdx_debug_relayout_params", C.c_int, C.c_int, C.c_int, u32, C.c_int, pf, C.POINTER(u32)),

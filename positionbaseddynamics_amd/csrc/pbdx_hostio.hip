@@ -16,8 +16,11 @@
 #include <vector>
 #include <string.h>
 #include <unistd.h>
+#include <dlfcn.h>
 
 namespace pbdx {
+
+void host_copy(void *dst, const void *src, size_t bytes);
 
 // memcpy by a team of worker threads that is started on first use and stays (a thread start per 8 MiB half costs more than the half's copy).
 // One job at a time; the calling thread works too.  All job state is guarded by one mutex, and a job's fields change only when the previous
@@ -28,6 +31,10 @@ class CopyTeam
 public:
 	explicit CopyTeam(unsigned workers) : pid_(getpid())
 	{
+		// the workers run code of this library until the process ends: a host that dlclose()s the library (or a plug-in linked to it) must not
+		// take their code away -- pin the library in memory
+		Dl_info info;
+		if (dladdr(reinterpret_cast<const void *>(&pbdx::host_copy), &info) && info.dli_fname) (void)dlopen(info.dli_fname, RTLD_NOW | RTLD_NOLOAD | RTLD_NODELETE);
 		for (unsigned t = 0; t < workers; t++) std::thread([this]() { work(); }).detach();
 	}
 	void run(char *dst, const char *src, size_t bytes, size_t per)
@@ -195,3 +202,8 @@ hipError_t copy_from_device(void *dst, const void *src, size_t bytes)
 }
 
 } // namespace pbdx
+
+extern "C" void pbdx_debug_host_copy(void *dst, const void *src, uint64_t bytes)
+{
+	if (dst && src && bytes) pbdx::host_copy(dst, src, (size_t)bytes);
+}

@@ -12,15 +12,14 @@ import positionbaseddynamics_amd as pbd
 from positionbaseddynamics_amd import _ffi
 
 lib = _ffi.lib
-f = getattr(C.CDLL(_ffi.LIB_PATH if hasattr(_ffi, "LIB_PATH") else lib._name), "_ZN4pbdx9host_copyEPvPKvm")
-f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]; f.restype = None
+f = lib.pbdx_debug_host_copy
 rng = np.random.default_rng(1)
 for n in (8 << 20, 12 << 20, 64 << 20):
     a = rng.integers(0, 255, n, dtype=np.uint8); b = np.zeros(n, dtype=np.uint8)
-    f(b.ctypes.data, a.ctypes.data, n)
+    f(C.c_void_p(b.ctypes.data), C.c_void_p(a.ctypes.data), n)
     t0 = time.perf_counter()
     for _ in range(20):
-        f(b.ctypes.data, a.ctypes.data, n)
+        f(C.c_void_p(b.ctypes.data), C.c_void_p(a.ctypes.data), n)
     dt = (time.perf_counter() - t0) / 20
     t0 = time.perf_counter()
     for _ in range(20):
