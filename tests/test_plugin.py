@@ -380,7 +380,7 @@ def test_plugin_full_size_c2_reference_model():
     except Exception as e:
         print("  (no schedule information: %r)" % (e,))
     ref.reset_all()
-    assert t_res < 1.5e-3 and t_round < 8e-3 and t_round_exact < 30e-3
+    assert t_res < 2.2e-3 and t_round < 8e-3 and t_round_exact < 30e-3      # (resident: well below a round trip; 0.66 measured, 1.2 once on a throttled host)
 
 
 # ---------------------------------------------------------------------------
