@@ -5,7 +5,8 @@ v_readfirstlane_b32) and a vector-memory instruction that reads that SGPR as its
 it cannot see inside inline assembly, where the engine's HBM -> LDS copies (global_load_lds_dwordx4) and write-through stores
 (global_store_dwordx4 ... sc1) live.  This script extracts the gfx950 code objects from a library, disassembles them and reports every
 vector-memory instruction with a scalar base whose base register was written by a VALU instruction fewer than five wait states earlier
-(straight-line scan backwards; `s_nop N` counts N + 1).
+(straight-line scan backwards; `s_nop N` counts N + 1).  Two one-wait-state hazards of the same family are looked for as well (scan_other):
+a store of more than 64 bits whose data registers the next instruction overwrites, and an HBM -> LDS copy directly behind a write of M0.
 
     python scripts/check_asm_hazards.py positionbaseddynamics_amd/_lib/libpbdx.so [more libraries]      exit status 1 if anything is found"""
 import os
@@ -79,19 +80,56 @@ def scan(instructions, need=5):
     return found
 
 
+WIDE_STORE = re.compile(r"^(global_store|flat_store|scratch_store|buffer_store)_dwordx[34]\s+(.*)$")
+VREG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
+LDS_DMA = re.compile(r"^(global_load_lds_\w+|buffer_load_\w+\s.*\blds\b)")
+
+
+def _vregs(operand):
+    m = VREG.search(operand)
+    if not m:
+        return None
+    return (int(m.group(1)), int(m.group(2))) if m.group(1) is not None else (int(m.group(3)), int(m.group(3)))
+
+
+def scan_other(instructions):
+    """Two more hazards of the same family that the compiler cannot see through inline assembly (one wait state each):
+    (a) a vector-memory store of more than 64 bits followed directly by a VALU write of its data registers;
+    (b) an SALU write of M0 followed directly by an HBM -> LDS copy (which takes its LDS base from M0).
+    -> [(index, what, instruction, previous / next instruction)]"""
+    found = []
+    for i, t in enumerate(instructions):
+        m = WIDE_STORE.match(t)
+        if m and i + 1 < len(instructions):
+            ops = [o.strip() for o in m.group(2).split(",")]
+            data = _vregs(ops[0] if m.group(1) == "buffer_store" else (ops[1] if len(ops) > 1 else ""))
+            nxt = instructions[i + 1]
+            if data and nxt.startswith("v_") and not nxt.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_nop")):
+                dst = _vregs(nxt.split(None, 1)[1].split(",")[0]) if " " in nxt else None
+                if dst and dst[0] <= data[1] and data[0] <= dst[1]:
+                    found.append((i, "store data overwritten in the next cycle", t, nxt))
+        if LDS_DMA.match(t) and i > 0 and re.match(r"^s_\w+\s+m0\b", instructions[i - 1]):
+            found.append((i, "M0 written by the instruction before", t, instructions[i - 1]))
+    return found
+
+
 def main(argv):
     bad = 0
     for lib in argv:
         kernels = disassemble(lib)
         total = sum(len(v) for v in kernels.values())
-        sites = 0
+        sites = other = 0
         for name, ins in sorted(kernels.items()):
             for i, ws, t, u in scan(ins):
                 sites += 1
                 if sites <= 8:
                     print("%s: %s: `%s` only %d wait state(s) after `%s`" % (os.path.basename(lib), name[:70], t, ws, u))
-        print("%s: %d kernels, %d instructions, %d hazard site(s)" % (os.path.basename(lib), len(kernels), total, sites))
-        bad += sites
+            for i, what, t, u in scan_other(ins):
+                other += 1
+                if other <= 8:
+                    print("%s: %s: `%s`: %s (`%s`)" % (os.path.basename(lib), name[:70], t, what, u))
+        print("%s: %d kernels, %d instructions, %d hazard site(s), %d of the one-wait-state kinds" % (os.path.basename(lib), len(kernels), total, sites, other))
+        bad += sites + other
     return 1 if bad else 0
 
 

@@ -34,6 +34,20 @@ def test_the_checker_finds_the_site_rocgdb_stopped_at():
     assert tool.scan(["s_load_dwordx2 s[4:5], s[0:1], 0x0", "s_waitcnt lgkmcnt(0)", "global_load_dword v1, v0, s[4:5]"]) == []
 
 
+def test_the_checker_knows_the_one_wait_state_hazards_of_hand_written_memory_instructions():
+    """A store of more than 64 bits must not be followed directly by a VALU write of its data registers, nor an HBM -> LDS copy directly by the
+    write of M0 it takes its LDS base from: the compiler keeps its own instructions apart, it cannot do so across inline assembly."""
+    tool = _tool()
+    assert len(tool.scan_other(["global_store_dwordx4 v5, v[26:29], s[12:13] sc1", "v_mov_b32_e32 v27, v1"])) == 1
+    assert len(tool.scan_other(["global_store_dwordx3 v[4:5], v[26:28], off", "v_add_f32_e32 v28, v1, v2"])) == 1
+    assert len(tool.scan_other(["buffer_store_dwordx4 v[26:29], v4, s[0:3], 0 offen", "v_mul_f32_e32 v26, v1, v2"])) == 1
+    assert tool.scan_other(["global_store_dwordx4 v5, v[26:29], s[12:13] sc1", "v_mov_b32_e32 v30, v1"]) == []
+    assert tool.scan_other(["global_store_dwordx4 v5, v[26:29], s[12:13] sc1", "s_nop 0", "v_mov_b32_e32 v27, v1"]) == []
+    assert tool.scan_other(["global_store_dwordx2 v5, v[26:27], s[12:13]", "v_mov_b32_e32 v27, v1"]) == []       # (64 bits: no hazard)
+    assert len(tool.scan_other(["s_mov_b32 m0, s7", "global_load_lds_dwordx4 v3, s[4:5] sc1"])) == 1
+    assert tool.scan_other(["s_mov_b32 m0, s7", "s_nop 0", "global_load_lds_dwordx4 v3, s[4:5] sc1"]) == []
+
+
 @pytest.mark.parametrize("lib", ["libpbdx.so", "libpbdx_bounds.so", "libpbdx_fma.so"])
 def test_no_hand_written_memory_instruction_reads_a_freshly_valu_written_scalar(lib):
     path = os.path.join(ROOT, "positionbaseddynamics_amd", "_lib", lib)
@@ -44,6 +58,8 @@ def test_no_hand_written_memory_instruction_reads_a_freshly_valu_written_scalar(
     assert any("persistent_kernel" in k for k in kernels) and any("fused_kernel" in k for k in kernels)
     sites = [(k, s) for k, ins in kernels.items() for s in tool.scan(ins)]
     assert not sites, "%d hazard site(s), first: %r" % (len(sites), sites[0])
+    other = [(k, s) for k, ins in kernels.items() for s in tool.scan_other(ins)]
+    assert not other, "%d one-wait-state hazard site(s), first: %r" % (len(other), other[0])
     # every hand-written copy / store is there and guarded
     n_dma = sum(1 for ins in kernels.values() for t in ins if t.startswith("global_load_lds_dwordx4"))
     assert n_dma > 100
