@@ -394,6 +394,13 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 #ifndef PBDX_FETCH_BEFORE_BARRIER
 #define PBDX_FETCH_BEFORE_BARRIER 0
 #endif
+// timing-only upper bounds (results wrong by construction): the colour barrier / the steady-state record fetch removed
+#ifndef PBDX_UB_NO_BARRIER
+#define PBDX_UB_NO_BARRIER 0
+#endif
+#ifndef PBDX_UB_NO_FETCH
+#define PBDX_UB_NO_FETCH 0
+#endif
 // DICT: a run of dictionary-form steps (FusedStep::dict, pbdx_plan.h): a slot streams its indices, its multiplier and ONE uint16 -- the offset of its
 // parameter record in the tile's table of distinct records, which sits in LDS behind the particles (ltab); the record is read from there when the
 // slot is projected.  Same arithmetic on the same values: bit-identical.
@@ -538,7 +545,9 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 #endif
 			if (chunk_last_of_step(ch.info))
 			{
+#if !PBDX_UB_NO_BARRIER
 				if (chunk_barrier(ch.info)) __syncthreads();
+#endif
 #if PBDX_STEP_PROBE
 				if (probing) tD = __builtin_readcyclecounter();
 #endif
@@ -549,6 +558,8 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 		// the record of the chunk D positions ahead, into the ring slot just consumed; its stream offsets came with this chunk's descriptor
 #if PBDX_FETCH_BEFORE_BARRIER
 		else fetch(cur, ch.f_idx_boff, ch.f_par_boff, ch.f_lam_boff);
+#elif PBDX_UB_NO_FETCH
+		c_ld++;
 #else
 		fetch(cur, ch.f_idx_boff, ch.f_par_boff, ch.f_lam_boff);
 #endif

@@ -256,7 +256,7 @@ TimeStepControllerHIP::TimeStepControllerHIP(int device) :
 {
 	m_accelGravity[0] = m_accelGravity[1] = m_accelGravity[2] = 0;
 	m_fullParameterScan = true; m_partialUploads = 0; m_mixed = false; m_mixedGroupsLast = 0;
-	m_speculate = getenv("PBDX_PLUGIN_NO_SPECULATION") == NULL; m_speculativeSteps = 0; m_repeatedSteps = 0;
+	m_speculate = getenv("PBDX_PLUGIN_NO_SPECULATION") == NULL; m_speculativeSteps = 0; m_repeatedSteps = 0; m_failRepeatForTest = false;
 	m_rawH = 0.0f; m_rawG[0] = m_rawG[1] = m_rawG[2] = 0.0f;
 	for (int k = 0; k < 6; k++) m_ms[k] = 0.0;
 	m_deviceMs = 0.0;
@@ -1050,9 +1050,24 @@ void TimeStepControllerHIP::step(SimulationModel &model)
 			{
 				// a parameter was edited since the streams were built: the step just taken used the old value
 				m_repeatedSteps++;
-				ok = pbdx_solver_restore_state(m_solver) == PBDX_OK && buildSchedule(model, true);
+				// From here until the repeated step is back on the host, ParticleData holds the result of a step taken with STALE parameters.  If anything
+				// below fails, refuse() must not see it: a fallback would step the CPU controller a second time from it, and without a fallback a step
+				// reported as "not executed" would leave an advanced host state that the next prepare() uploads.  So: once the checkpoint is back on the
+				// device, the DEVICE is the side that holds the pre-step state (m_deviceAhead, host hashes dropped), and a failure re-downloads it.
+				const bool restored = pbdx_solver_restore_state(m_solver) == PBDX_OK;
+				if (restored) { m_deviceAhead = true; for (int k = 0; k < 4; k++) m_blockHash[k].clear(); }
+				ok = restored && buildSchedule(model, true) && !m_failRepeatForTest;
 				if (ok) { Lap lap(&m_ms[4]); ok = stepRaw(1); }
 				if (ok) { Lap lap(&m_ms[5]); ok = downloadParticles(model); }
+				if (!ok)
+				{
+					m_helperError = pbdx_last_error();
+					if (m_failRepeatForTest) m_helperError = "repeat of the speculative step failed (test hook)";
+					// host back to the pre-step state (the device still holds it if the restore succeeded and the repeated step did not run; after a failed
+					// repeat it is restored once more).  If even that fails the image is declared invalid and the host arrays are marked unknown.
+					const bool back = restored && pbdx_solver_restore_state(m_solver) == PBDX_OK && downloadParticles(model);
+					if (!back) { m_hostDirty = true; m_deviceAhead = false; }
+				}
 			}
 		}
 		if (ok) finishSteps(1);
@@ -1147,4 +1162,5 @@ extern "C" unsigned int pbdx_timestep_hip_mixed_groups(PBD::TimeStep *ts) { retu
 extern "C" void *pbdx_timestep_hip_solver(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->solver(); }
 extern "C" unsigned int pbdx_timestep_hip_speculative_steps(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numSpeculativeSteps(); }
 extern "C" unsigned int pbdx_timestep_hip_repeated_steps(PBD::TimeStep *ts) { return static_cast<PBD::TimeStepControllerHIP*>(ts)->numRepeatedSteps(); }
+extern "C" void pbdx_timestep_hip_set_fail_repeat_for_test(PBD::TimeStep *ts, int on) { static_cast<PBD::TimeStepControllerHIP*>(ts)->setFailRepeatForTest(on != 0); }
 extern "C" void pbdx_timestep_hip_set_speculative_step(PBD::TimeStep *ts, int on) { static_cast<PBD::TimeStepControllerHIP*>(ts)->setSpeculativeStep(on != 0); }

@@ -99,6 +99,9 @@ namespace PBD
 		unsigned int numSpeculativeSteps() const { return m_speculativeSteps; }
 		unsigned int numRepeatedSteps() const { return m_repeatedSteps; }
 		void setSpeculativeStep(bool b) { m_speculate = b; }
+		/** Test hook: the repeat of a speculative step (after the scan found an edit) is made to fail once the checkpoint is back on the device, so
+		 * that the tests can check what the host holds then (the pre-step state, not the stale speculative result). */
+		void setFailRepeatForTest(bool b) { m_failRepeatForTest = b; }
 		unsigned int numScheduleBuilds() const { return m_scheduleBuilds; }
 		unsigned int numUploads() const { return m_uploads; }
 		/** uploads of only the blocks the host wrote (host current, full-coverage block hashes) */
@@ -154,6 +157,7 @@ namespace PBD
 		double m_ms[6];                // host milliseconds spent in: hashing the host arrays, full uploads, the parameter check, the collider refresh, the engine's step, the download
 		bool m_fullParameterScan;
 		bool m_speculate;
+		bool m_failRepeatForTest;
 		unsigned int m_speculativeSteps, m_repeatedSteps;
 		// parameters
 		bool m_paramsDirty;

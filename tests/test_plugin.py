@@ -619,6 +619,7 @@ def _extra(path):
     lib.pbdx_timestep_hip_speculative_steps.argtypes = [C.c_void_p]; lib.pbdx_timestep_hip_speculative_steps.restype = C.c_uint
     lib.pbdx_timestep_hip_repeated_steps.argtypes = [C.c_void_p]; lib.pbdx_timestep_hip_repeated_steps.restype = C.c_uint
     lib.pbdx_timestep_hip_set_speculative_step.argtypes = [C.c_void_p, C.c_int]; lib.pbdx_timestep_hip_set_speculative_step.restype = None
+    lib.pbdx_timestep_hip_allow_reference_fallback.argtypes = [C.c_void_p, C.c_int]; lib.pbdx_timestep_hip_allow_reference_fallback.restype = None
     return lib
 
 
@@ -778,3 +779,54 @@ def test_plugin_sees_one_edited_constraint(size, how):
     assert not np.array_equal(xc, util.oracle_positions(ops, 7, 1, 5, "f32")), "the edit changes nothing: the test would prove nothing"
     assert util.bitwise_equal(xg, xc), "max err %.3e" % util.max_err(xg, xc)
     assert util.bitwise_equal(vg, vc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fallback", [False, True])
+def test_plugin_failed_repeat_of_a_speculative_step_leaves_the_pre_step_state(fallback):
+    """the speculative step() downloads its result before the parameter scan has finished.  If the scan then finds an edit and the REPEAT
+    fails, the host must not keep the stale result: without a fallback the step is reported as not executed and ParticleData holds the pre-step
+    state (the next step continues from it, bitwise like a CPU run that made the same edit); with the reference fallback opted in the CPU
+    controller steps ONCE from that pre-step state (no double step)."""
+    refdrv, path = _plugin("f32")
+    ops = util.cloth_spec(50, 50, 1, 2)
+    victim = 9001
+    ex = _extra(path)
+    ex.pbdx_timestep_hip_set_fail_repeat_for_test.argtypes = [C.c_void_p, C.c_int]; ex.pbdx_timestep_hip_set_fail_repeat_for_test.restype = None
+    lib, cnt = _counters(path)
+
+    def run(gpu):
+        ref = refdrv.Ref("f32")
+        _setup(ref, ops, 1, 5)
+        ref.set_num_threads(1)
+        if gpu:
+            assert ref.install_timestep_plugin(path) == 0
+        ref.set_params(1, 5, 0)
+        ref.step(3)
+        before = [ref.get_array(k).copy() for k in (0, 2, 4, 5)]
+        ref.set_constraint_stiffness(victim, 0.37)
+        if gpu:
+            ts = ref.timestep_ptr()
+            ex.pbdx_timestep_hip_allow_reference_fallback(ts, 1 if fallback else 0)
+            ex.pbdx_timestep_hip_set_fail_repeat_for_test(ts, 1)
+            ref.step(1)                      # speculative step, edit found, repeat made to fail
+            ex.pbdx_timestep_hip_set_fail_repeat_for_test(ts, 0)
+            after = [ref.get_array(k).copy() for k in (0, 2, 4, 5)]
+            if fallback:
+                assert cnt["fallback_steps"](ts) == 1 and cnt["failed_steps"](ts) == 0
+            else:
+                assert cnt["failed_steps"](ts) == 1
+                for k in range(4):
+                    assert util.bitwise_equal(after[k], before[k]), "array %d: the host holds a state other than the pre-step one" % k
+                ref.step(1)                  # the step the host asked for, now executed
+            ref.step(2)
+            assert cnt["failed_steps"](ts) == (0 if fallback else 1)
+        else:
+            ref.step(3)
+        out = [ref.get_array(k).copy() for k in (0, 2, 4, 5)]
+        ref.reset_all()
+        return out
+
+    a, b = run(False), run(True)
+    for k in range(4):
+        assert util.bitwise_equal(a[k], b[k]), "array %d" % k
