@@ -111,11 +111,41 @@ project_fn kProjectKernels[PBDX_NUM_CONSTRAINT_TYPES][2] = {
 // ------------------------------------------------------------------------------------------------
 // (A) colour-fused tile kernel
 // ------------------------------------------------------------------------------------------------
+// A tile descriptor as the kernels read it: padded to 64 bytes and read with ONE scalar load (constant address space + uniform index -> s_load_dwordx16
+// straight into SGPRs).  As a plain global load it came back in vector registers -- a dependent vector-memory round trip followed by eleven
+// v_readfirstlane at the start of every pass, behind the scalar loads of the segment's arguments (pass probes, profiles/HISTORY.md [10]).
+struct alignas(64) TileDev { FusedTile t; uint32_t pad[5]; };
+static_assert(sizeof(TileDev) == 64 && sizeof(FusedTile) == 44, "one s_load_dwordx16 per tile descriptor");
+__device__ __forceinline__ uint32_t rfl(uint32_t v);
+// one dword of a read-only array at a wave-uniform index, as a scalar load
+__device__ __forceinline__ uint32_t sload_u32(const uint32_t *p, uint32_t index)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	typedef __attribute__((address_space(4))) const uint32_t *const_ptr;
+	return rfl(*((const_ptr)(uintptr_t)p + index));
+#else
+	return p[index];
+#endif
+}
+__device__ __forceinline__ FusedTile load_tile(const TileDev *tiles, uint32_t index)
+{
+	FusedTile t;
+#if defined(__HIP_DEVICE_COMPILE__)
+	typedef unsigned int u16v __attribute__((ext_vector_type(16)));
+	typedef __attribute__((address_space(4))) const u16v *const_ptr16;
+	const u16v v = *((const_ptr16)(uintptr_t)tiles + index);
+	t.step_begin = rfl(v[0]); t.step_end = rfl(v[1]); t.n_local = rfl(v[2]); t.n_owned = rfl(v[3]); t.gid_off = rfl(v[4]); t.slots = rfl(v[5]);
+	t.chunk_begin = rfl(v[6]); t.chunk_end = rfl(v[7]); t.tab_off = rfl(v[8]); t.tab_f4 = rfl(v[9]); t.wb_begin = rfl(v[10]);
+#else
+	t = tiles[index].t;
+#endif
+	return t;
+}
 struct BndLim { uint32_t gid_left, n_particles, lds_f4, tile, ids_cap; };      // what a tile's raw accesses are checked against (PBDX_BOUNDS builds)
 // the plan image of one segment (read-only except the multiplier stream, which is private per tile)
 struct SegArgs
 {
-	const FusedTile *tiles;
+	const TileDev *tiles;
 	const FusedChunk *chunks;
 	const uint16_t *idx;
 	const float *params;
@@ -328,7 +358,9 @@ template <int BLOCK, bool COHERENT> struct TileFill
 	// the compiler waits for them once and places no wait (stricter than necessary, see lds_dma16) between the copies.
 	// `wait` runs after the first batch of ids is in flight and before any position is read: the persistent
 	// schedule waits for the neighbouring tiles there (the ids do not depend on them).
-	template <class Wait> __device__ __forceinline__ void operator()(const Wait &wait) const
+	// `extra` runs once the copies have been issued and before they are waited for: work that only has to be complete at the fill's closing barrier (the
+	// dictionary table into LDS, the request of the next pass's halo ids) overlaps with the copies' latency instead of taking a phase and a barrier of its own
+	template <class Wait, class Extra> __device__ __forceinline__ void operator()(const Wait &wait, const Extra &extra) const
 	{
 		static_assert(BLOCK >= (int)kMaxTileChunks, "one chunk descriptor per thread");
 #if !PBDX_SMEM_CHUNKS
@@ -361,6 +393,7 @@ template <int BLOCK, bool COHERENT> struct TileFill
 #if !PBDX_SMEM_CHUNKS
 		if (threadIdx.x < num_chunks) lchunks[threadIdx.x] = chv;
 #endif
+		extra();
 #if PBDX_DEFER_FILL_WAIT
 		// The positions are still in flight (HBM -> LDS copies).  Only the chunk descriptors have to be visible now: the first run of the sweep
 		// issues its record prefetches (which read the descriptors, not the positions) and THEN waits for the copies (fill_wait below), so that
@@ -395,11 +428,23 @@ __device__ __forceinline__ void fill_wait(bool &pending, unsigned long long *tra
 #define PBDX_FETCH_BEFORE_BARRIER 0
 #endif
 // timing-only upper bounds (results wrong by construction): the colour barrier / the steady-state record fetch removed
+// developer build (-DPBDX_PASS_PROBE=1, scripts/probe_pass.py): wall-clock stamps of the traced tile's first thread along a pass boundary, trace[40 ..]
+#ifndef PBDX_PASS_PROBE
+#define PBDX_PASS_PROBE 0
+#endif
+#if PBDX_PASS_PROBE
+#define PBDX_PSTAMP(k) do { if (trace && threadIdx.x == 0) trace[40 + (k)] = wall_clock64(); } while (0)
+#else
+#define PBDX_PSTAMP(k) do { } while (0)
+#endif
 #ifndef PBDX_UB_NO_BARRIER
 #define PBDX_UB_NO_BARRIER 0
 #endif
 #ifndef PBDX_UB_NO_FETCH
 #define PBDX_UB_NO_FETCH 0
+#endif
+#ifndef PBDX_UB_NO_TABLE
+#define PBDX_UB_NO_TABLE 0
 #endif
 // DICT: a run of dictionary-form steps (FusedStep::dict, pbdx_plan.h): a slot streams its indices, its multiplier and ONE uint16 -- the offset of its
 // parameter record in the tile's table of distinct records, which sits in LDS behind the particles (ltab); the record is read from there when the
@@ -513,7 +558,7 @@ __device__ __forceinline__ uint32_t run_typed(const RunArgs &a, const TileStream
 #if PBDX_BOUNDS
 					const float4 *e = ltab + (PBDX_BOK(kBndTable, cur.w[3] + dict_entry_f4(NP) - 1u, str.dbg_tab_f4, str.dbg_tile) ? cur.w[3] : 0u);
 #else
-					const float4 *e = ltab + cur.w[3];
+					const float4 *e = ltab + (PBDX_UB_NO_TABLE ? (cur.w[3] & 0u) : cur.w[3]);      // (knock-out: every lane reads the table's first record -- one broadcast)
 #endif
 #pragma unroll
 					for (uint32_t q4 = 0; q4 < dict_entry_f4(NP); q4++)
@@ -760,8 +805,12 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 #if PBDX_BOUNDS
 	tile_index = PBDX_BCLAMP(kBndTile, tile_index, sg.num_tiles, 0u);
 #endif
-	const FusedTile t = sg.tiles[tile_index];
+	const FusedTile t = load_tile(sg.tiles, tile_index);
 	if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
+#if PBDX_PASS_PROBE
+	asm volatile("" :: "s"(rfl(t.n_local)));      // the descriptor has arrived
+	PBDX_PSTAMP(0);
+#endif
 	const uint32_t *gid = sg.gid + t.gid_off;
 	const uint32_t num_chunks = t.chunk_end - t.chunk_begin;
 #if PBDX_BOUNDS
@@ -776,7 +825,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 #endif
 	// the next pass's tile descriptor: requested here so that its latency passes during the fill
 	FusedTile tn = t;
-	if (use_ids && have_next) tn = sg_next.tiles[tile_index];
+	if (use_ids && have_next) tn = load_tile(sg_next.tiles, tile_index);
 	// stream descriptors, from kernel arguments only (wave-uniform by construction)
 	TileStreams str;
 	str.idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(sg.idx), 0, sg.idx_bytes, 0x00020000);
@@ -812,18 +861,36 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			integrate_fill<BLOCK>(*fold, reinterpret_cast<const uint4 *>(gchunks), gid, pos_in, lchunks, lpos, num_chunks, t.n_local, t.n_owned, trace, lim);
 			staged = true;
 		}
-	if (!staged) fill(wait);
+	// the next pass's halo ids and the dictionary table: inside the fill (TileFill `extra`) where the fill's first batch covers the whole halo -- every id of
+	// THIS pass has then been read from ids.halo before the barrier of `wait`, so the list of the next pass may be requested into the same region right behind
+	// the position copies -- and otherwise (pass 0, which integrates while it stages; halos of more than eight ids per thread) behind it as before
+	const bool single_batch = fill.first + 8u * (uint32_t)BLOCK >= t.n_local;
+	const bool ids_in_fill = !staged && single_batch && !PBDX_DEFER_FILL_WAIT;
+	auto request_next_ids = [&]()
+	{
+		const uint32_t nfirst = tn.n_owned & ~63u, count = tn.n_local - nfirst;      // gid[nfirst .. n_local) of the next pass; 16-byte aligned: gid_off and nfirst are multiples of 4
+		const float4 *src = reinterpret_cast<const float4 *>(sg_next.gid + tn.gid_off + nfirst);
+		for (uint32_t j = threadIdx.x; 4u * j < count; j += BLOCK)
+			if (PBDX_BOK(kBndLdsIds, 4u * j + 3u, ids.halo_cap, tile_index) && PBDX_BOK(kBndGid, tn.gid_off + nfirst + 4u * j + 3u, sg_next.gid_count_dbg(), tile_index))
+				lds_dma16<false>(src, j, reinterpret_cast<float4 *>(ids.halo) + (j & ~63u));
+	};
+	auto store_table = [&]()
+	{
+		const uint32_t i0 = threadIdx.x;
+		if (i0 < t.tab_f4) ltab[i0] = tabv0;
+		if constexpr (kTabPerThread > 1) { if (i0 + BLOCK < t.tab_f4) ltab[i0 + BLOCK] = tabv1; }
+		if constexpr (kTabPerThread > 2) { if (i0 + 2 * BLOCK < t.tab_f4) ltab[i0 + 2 * BLOCK] = tabv2; if (i0 + 3 * BLOCK < t.tab_f4) ltab[i0 + 3 * BLOCK] = tabv3; }
+	};
+	const bool table_in_fill = !staged && !PBDX_DEFER_FILL_WAIT;
+	if (!staged)
+		fill(wait, [&]() {
+			if (use_ids && have_next && ids_in_fill) request_next_ids();
+			if (t.tab_f4 && table_in_fill) store_table();
+		});
 	if (use_ids)
 	{
 		// (the fill ended with vmcnt(0) + barrier: every id it read from ids.halo has been consumed)
-		if (have_next)
-		{
-			const uint32_t nfirst = tn.n_owned & ~63u, count = tn.n_local - nfirst;      // gid[nfirst .. n_local) of the next pass; 16-byte aligned: gid_off and nfirst are multiples of 4
-			const float4 *src = reinterpret_cast<const float4 *>(sg_next.gid + tn.gid_off + nfirst);
-			for (uint32_t j = threadIdx.x; 4u * j < count; j += BLOCK)
-				if (PBDX_BOK(kBndLdsIds, 4u * j + 3u, ids.halo_cap, tile_index) && PBDX_BOK(kBndGid, tn.gid_off + nfirst + 4u * j + 3u, sg_next.gid_count_dbg(), tile_index))
-					lds_dma16<false>(src, j, reinterpret_cast<float4 *>(ids.halo) + (j & ~63u));
-		}
+		if (have_next && !ids_in_fill) request_next_ids();
 		if (fold_phase & 1u)
 		{
 			// pass 0 of a launch: the boundary ids, once (read by the write-backs after the wait below)
@@ -834,14 +901,12 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 					lds_dma16<false>(src, j, reinterpret_cast<float4 *>(ids.bnd) + (j & ~63u));
 		}
 	}
-	if (t.tab_f4)
+	if (t.tab_f4 && !table_in_fill)
 	{
-		const uint32_t i0 = threadIdx.x;
-		if (i0 < t.tab_f4) ltab[i0] = tabv0;
-		if constexpr (kTabPerThread > 1) { if (i0 + BLOCK < t.tab_f4) ltab[i0 + BLOCK] = tabv1; }
-		if constexpr (kTabPerThread > 2) { if (i0 + 2 * BLOCK < t.tab_f4) ltab[i0 + 2 * BLOCK] = tabv2; if (i0 + 3 * BLOCK < t.tab_f4) ltab[i0 + 3 * BLOCK] = tabv3; }
+		store_table();
 		__syncthreads();
 	}
+	PBDX_PSTAMP(3);      // table staged
 	bool fill_pending = PBDX_DEFER_FILL_WAIT != 0 && !staged;
 	// chunks are addressed relative to the tile from here on (they sit at lchunks[0 .. num_chunks))
 #if PBDX_BOUNDS
@@ -867,6 +932,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 		}
 	}
 	fill_wait(fill_pending, trace);          // (a tile without work in this segment, or whose first chunk has an unknown type)
+	PBDX_PSTAMP(4);      // sweep done
 	bool written = false;
 	if constexpr (COHERENT)
 		if (fold_phase & 2u)
@@ -904,6 +970,7 @@ __device__ __forceinline__ void process_tile(const SegArgs &sg, const RunArgs &r
 			}
 		}
 	}
+	PBDX_PSTAMP(5);      // write-back stores issued
 	if (trace && threadIdx.x == 0)
 	{
 		__builtin_amdgcn_s_waitcnt(0);
@@ -1021,7 +1088,11 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 	if (!s_go) return;
 	for (uint32_t pass = 0; pass < a.passes; pass++)
 	{
-		const SegArgs &sg = a.seg[sgi];
+		// BY VALUE: one wide scalar load of the segment's arguments per pass.  As a reference into the kernel-argument segment every field was fetched where it
+		// was first used, each behind a wait of its own -- five dependent scalar-cache round trips between the publish of a pass and the poll of the next
+		// (pass probes: 0.56 + 0.76 us per pass; profiles/HISTORY.md [10]).  The values live in SGPRs (spilled to lanes of a vector register under pressure:
+		// a v_readlane, not a memory access).
+		const SegArgs sg = a.seg[sgi];
 		const RunArgs ra = { a.dt, pass < a.first_iter_passes ? 1 : 0, a.views };
 		const float4 *pos_in = a.pos[(a.start + pass) & 1u];
 		float4 *pos_out = a.pos[(a.start + pass + 1u) & 1u];
@@ -1037,12 +1108,15 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 			const bool first_of_pass = k == 0u, last_of_pass = k + 1u == m;
 			// the wait for the neighbouring tiles, run by the fill once its particle ids are in flight: one wave polls
 			// the tile's dependencies, one lane each (lists are short: the adjacent tiles)
+			unsigned long long *trace = (a.trace[sgi] && pass + a.num_segs >= a.passes) ? a.trace[sgi] + (size_t)tile * kTraceStride : nullptr;
+			// the bounds of the tile's dependency list: scalar loads, requested here with the pass's other scalars (not behind the fill's first ids)
+			const uint32_t d0 = sload_u32(a.dep_off[sgi], tile), d1 = sload_u32(a.dep_off[sgi], tile + 1u);
 			auto wait = [&]()
 			{
 				if (!pass) return;
+				PBDX_PSTAMP(1);      // the fill's first ids are in flight: the wait for the neighbours starts
 				if (threadIdx.x < 64)
 				{
-					const uint32_t d0 = a.dep_off[sgi][tile], d1 = a.dep_off[sgi][tile + 1];
 					const unsigned long long t0 = wall_clock64();
 					for (uint32_t d = d0 + threadIdx.x; d < d1; d += 64)
 					{
@@ -1057,9 +1131,9 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 						}
 					}
 				}
+				PBDX_PSTAMP(2);      // this wave's dependencies have published
 				__syncthreads();
 			};
-			unsigned long long *trace = (a.trace[sgi] && pass + a.num_segs >= a.passes) ? a.trace[sgi] + (size_t)tile * kTraceStride : nullptr;
 			const uint32_t fold_phase = a.folded ? ((pass == 0 ? 1u : 0u) | (pass + 1u == a.passes ? 2u : 0u)) : 0u;
 			const bool keeps = PBDX_WALK_TILES || m == 1u;      // (PBDX_WALK_TILES = 0: only one-tile workgroups keep their particles, the form before round 4)
 			// particle ids in LDS (LdsIds): one tile per workgroup, folded launch (pass 0 stages everything and copies the boundary ids)
@@ -1079,8 +1153,10 @@ __global__ __launch_bounds__(BLOCK) void persistent_kernel(PersistArgs a)
 			}
 			// publish: this thread's stores have left the CU, then everybody's, then the counter
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			PBDX_PSTAMP(6);      // this thread's stores have left the CU
 			__syncthreads();
 			if (threadIdx.x == 0 && !(a.mute_tile0 && tile == 0u)) __hip_atomic_store(a.epoch + tile, pass + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			PBDX_PSTAMP(7);      // published
 		}
 		sgi = sgi + 1u == a.num_segs ? 0u : sgi + 1u;
 	}
@@ -1455,7 +1531,7 @@ struct Batch
 
 struct DeviceSegment
 {
-	FusedTile *d_tiles = nullptr;
+	TileDev *d_tiles = nullptr;
 	FusedChunk *d_chunks = nullptr;
 	uint16_t *d_idx = nullptr;
 	float *d_params = nullptr;
@@ -2044,7 +2120,9 @@ int ensure_plan(pbdx_solver *s)
 			s->plan_why = "a tile needs more chunk descriptors than fit the LDS header: use smaller segments or larger workgroups";
 			return PBDX_OK;
 		}
-		int r = upload(&d.d_tiles, tiles);
+		std::vector<TileDev> tiles_dev(tiles.size());
+		for (size_t ti = 0; ti < tiles.size(); ti++) { memset(&tiles_dev[ti], 0, sizeof(TileDev)); tiles_dev[ti].t = tiles[ti]; }
+		int r = upload(&d.d_tiles, tiles_dev);
 		if (!r) r = upload(&d.d_chunks, chunks);
 		if (!r) r = upload(reinterpret_cast<uint8_t **>(&d.d_idx), idx_img);
 		if (!r) r = upload(&d.d_params, seg.params);
