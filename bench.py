@@ -469,6 +469,12 @@ def add_profiled_passes(r, w, opts, plan, persist):
             r["copy_ceiling_gbs"] = None
         r["copy_ceiling_gbs_guide"] = HBM_COPY_GBS
         r["frac_traffic_of_copy_ceiling"] = r["traffic_GBs"] / (r["copy_ceiling_gbs"] or HBM_COPY_GBS)
+        # the distance to the machine as ONE number: counter traffic / time against the guide's measured copy bandwidth, and the time the
+        # compulsory bytes would take at the copy bandwidth measured in THIS run -- what a launch that did nothing but move its bytes would need
+        r["frac_of_achievable"] = r["traffic_GBs"] / HBM_COPY_GBS
+        if r.get("compulsory_bytes_per_launch"):
+            r["floor_ms"] = 1e3 * r["compulsory_bytes_per_launch"] / ((r["copy_ceiling_gbs"] or HBM_COPY_GBS) * 1e9)
+            r["time_over_floor"] = (dur_s * 1e3) / r["floor_ms"]
         r["traffic_over_algorithmic"] = r["traffic"] / r.get("algorithmic_bytes_per_launch_mean", r["algorithmic_bytes_per_launch"])
         if r.get("compulsory_bytes_per_launch"):
             r["traffic_over_compulsory"] = r["traffic"] / r["compulsory_bytes_per_launch"]
@@ -555,7 +561,7 @@ def cpu_baseline(size, iters, opts, hip_device, parity_steps=3, timed_steps=3):
         # SURVEY 8d asks for OMP_NUM_THREADS = 1 and = nproc: at nproc = 256 (the MI355X box's host) the reference needs 57.8 s per substep -- it forks and joins
         # one parallel region per colour group (profiles/r04_bench_detail.json of the run that tried it: 4 minutes of bench time) -- so the sweep stops at 64 and
         # the best setting is reported
-        thread_settings = sorted(set([1, min(16, ncpu), min(32, ncpu), min(64, ncpu)]))
+        thread_settings = sorted(set([1, min(16, ncpu), min(64, ncpu)]))
         flags = {"v4": "-O3 -march=x86-64-v4 -fopenmp, float", "fast": "-O3 -march=x86-64-v3 -fopenmp, float"}[variant]
     t_setup = time.perf_counter()
     apply_ref(o, ops)
@@ -585,7 +591,8 @@ def cpu_baseline(size, iters, opts, hip_device, parity_steps=3, timed_steps=3):
     # BASELINE.md 2 / SURVEY 8d also ask for OMP_NUM_THREADS = nproc.  On the MI355X box's 256-CPU host that leg takes about a minute per substep (one
     # fork / join per colour group and iteration), so it is ONE step in a child process with a time limit; reported as a field, never `value`
     rec["nproc_threads"] = None
-    if variant is not None and ncpu > max(thread_settings) and not opts.get("no_cpu_nproc"):
+    # (opt-in since round 6, --cpu-nproc: informative once -- 60 s of every driver run for one step -- and on record in profiles/r05_bench_detail.json)
+    if variant is not None and ncpu > max(thread_settings) and opts.get("cpu_nproc"):
         rec["nproc_threads"] = cpu_nproc_leg(size, iters, ncpu, variant)
 
     parity = None
@@ -803,7 +810,7 @@ def _pick(d, keys):
 def compact_roofline(r):
     if not r:
         return None
-    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "frac_kind", "achieved_traffic", "frac_traffic", "copy_ceiling_gbs", "frac_traffic_of_copy_ceiling", "frac_valu", "valu_cycles_per_instruction_measured",
+    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "frac_kind", "achieved_traffic", "frac_traffic", "copy_ceiling_gbs", "frac_traffic_of_copy_ceiling", "frac_of_achievable", "floor_ms", "time_over_floor", "frac_valu", "valu_cycles_per_instruction_measured",
                     "valu_instructions_per_launch", "gpu_cycles_per_launch", "frac_lds", "lds_active_cycles_per_launch", "lds_bank_conflict_cycles_per_launch", "binding", "traffic", "traffic_over_compulsory", "algorithmic_bytes_per_launch",
                     "compulsory_bytes_per_launch", "avg_launch_us", "eager_launch_us", "rocprofv3_median_kernel_us", "rocprofv3_mean_kernel_us",
                     "rocprofv3_dispatches", "launches_measured"))
@@ -1012,6 +1019,7 @@ def main():
     ap.add_argument("--solid-method", type=int, default=2, help="c3: addSolidConstraints method (2 FEM tet, 4 strain tet, 6 XPBD distance+volume)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-nproc", action="store_true", help="cpu_baseline: also ONE reference step at OMP_NUM_THREADS = nproc in a child process (a minute on a 256-CPU host; off by default)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra_workloads (configs[2] variants, configs[3] block)")
     ap.add_argument("--xcd-remap", type=int, default=None)
@@ -1110,7 +1118,7 @@ def main():
     w = {"workload": args.workload, "size": args.size, "instances": args.instances, "bars": args.bars, "solid_method": args.solid_method,
          "iters": args.iters, "scaling": args.scaling, "total_instances": args.total_instances}
     opts = {"xcd_remap": args.xcd_remap, "block": args.block, "fuse": args.fuse, "tile": args.tile, "fuse_block": args.fuse_block,
-            "max_seg": args.max_seg, "lds_particles": args.lds_particles, "persistent": args.persistent, "no_graph": args.no_graph, "wgs_per_cu": args.wgs_per_cu}
+            "max_seg": args.max_seg, "lds_particles": args.lds_particles, "persistent": args.persistent, "no_graph": args.no_graph, "wgs_per_cu": args.wgs_per_cu, "cpu_nproc": args.cpu_nproc}
 
     res = run_workload(w, opts, ens, args.steps, args.warmup, with_roofline=not args.no_roofline, with_traffic=not args.no_traffic and not args.pmc_child,
                        with_pcie=not args.pmc_child, with_contacts=args.contacts)
@@ -1188,8 +1196,9 @@ def main():
                 extras.append({"tag": tag, "workload": ew["workload"], "error": repr(e)})
                 continue
             ms = 1e3 * r["t_local"] / nsteps
-            # every extra line carries a reference leg of its own (the late-state bar shares the bar's: its state after 120 steps is pinned in the GPU suite)
-            par = None if (args.no_cpu_baseline or tag == "c3_fem_tets_late") else extra_parity(ew, ens, ens.hip_device)
+            # every extra line carries a reference leg of its own; the late-state bar's runs INTO the late state (warm-up + 2 steps from rest: crushed
+            # tets in the inversion branch on both sides; 102 steps of the reference at up to 32 threads take a few seconds)
+            par = None if args.no_cpu_baseline else extra_parity(ew, ens, ens.hip_device, steps=(wu + 2) if tag == "c3_fem_tets_late" else 2)
             extras.append({"tag": tag, "workload": r["desc"], "particles": r["n_particles"], "constraints": r["n_constraints"], "colour_groups": r["n_groups"],
                            "parity_vs_reference": par, "bit_identical": (par or {}).get("bit_identical"),
                            "steps": nsteps, "warmup": wu, "ms_per_substep": ms, "device_median_ms_per_substep": (r.get("substep_device") or {}).get("median_ms"),

@@ -660,8 +660,8 @@ pbdx_solver *pbdx_timestep_solver(pbdx_timestep *ts);
 /* a single scene does not shard (one connected colour-sequential Gauss-Seidel problem; the reference itself is one process on one model,
  * Simulation/TimeStepController.cpp:75-241); a model of K congruent independent instances (pbdx_model_add_instances) does -- contiguous blocks of
  * instances (pbdx_ensemble_shard), one per device, no exchange on the data path.  One engine (time step, solver, stream, device image) per entry of
- * `devices`; a device may be listed more than once (its blocks then share it).  A step runs every device's block concurrently (one host thread per device
- * for the duration of the call; every entry point selects its device and restores the caller's).  A single process needs no collective: what RCCL
+ * `devices`; a device may be listed more than once (its blocks then share it).  A step runs every device's block concurrently (one RESIDENT host thread
+ * per device, created with the ensemble and woken per call; every entry point selects its device and restores the caller's).  A single process needs no collective: what RCCL
  * reduces between the ranks of `bench.py --gpus N` is available on the host here. */
 typedef struct pbdx_ensemble pbdx_ensemble;
 int pbdx_ensemble_create(pbdx_ensemble **out, const int *devices, uint32_t n);
@@ -672,7 +672,8 @@ int pbdx_ensemble_set_param(pbdx_ensemble *e, int id, int64_t value);
 int pbdx_ensemble_set_gravity(pbdx_ensemble *e, const float g[3]);
 int pbdx_ensemble_set_time_step_size(pbdx_ensemble *e, float h);
 /* Splits `m` into one block of instances per device (fewer instances than devices: the surplus devices stay idle; a model without instances is one
- * block).  The blocks are COPIES: after editing `m` call this again.  Every record of a block is bit for bit the whole model's. */
+ * block).  The blocks are COPIES: `m` is not referenced after the call (it may be destroyed); after editing `m` call this again -- pbdx_ensemble_gather
+ * refuses a model that was edited since.  Every record of a block is bit for bit the whole model's.  A failure leaves the ensemble without a model. */
 int pbdx_ensemble_set_model(pbdx_ensemble *e, const pbdx_model *m);
 /* `num_steps` steps of every block, device-resident, all devices at once; returns when all are done. */
 int pbdx_ensemble_step(pbdx_ensemble *e, uint32_t num_steps);
@@ -684,6 +685,27 @@ int pbdx_ensemble_get_shard(const pbdx_ensemble *e, uint32_t shard, int *device,
 pbdx_timestep *pbdx_ensemble_timestep(pbdx_ensemble *e, uint32_t shard);
 pbdx_model *pbdx_ensemble_shard_model(pbdx_ensemble *e, uint32_t shard);
 double pbdx_ensemble_last_step_ms(const pbdx_ensemble *e);
+
+/* ======================================================================== */
+/* pbdx_comm -- the collective of a multi-process host: RCCL, loaded at run time */
+/* ======================================================================== */
+/* with one PROCESS per GPU (the form `bench.py --gpus N` runs under torch.distributed) the ranks exchange control data only -- a barrier,
+ * the maximum of their times, the sum of their projection counts, their checksums.  A C / C++ host has no torch: these entry points give it the same
+ * operations on the same library.  librccl.so is opened with dlopen by the first call (libpbdx.so does not link it; PBDX_RCCL_LIB names another file);
+ * rank 0 calls pbdx_comm_unique_id and hands the PBDX_COMM_ID_BYTES bytes to the other ranks by the host's own channel (a file, MPI, a socket); every rank
+ * calls pbdx_comm_create with its HIP device.  Values cross by value: host arrays in, host arrays out.  No reference counterpart. */
+#define PBDX_COMM_ID_BYTES 128
+typedef struct pbdx_comm pbdx_comm;
+int pbdx_comm_available(void);                                   /* 1: librccl.so and the symbols used here were found */
+int pbdx_comm_unique_id(void *id, size_t bytes);                 /* bytes >= PBDX_COMM_ID_BYTES */
+int pbdx_comm_create(pbdx_comm **out, const void *id, size_t bytes, int world, int rank, int device);
+void pbdx_comm_destroy(pbdx_comm *c);
+int pbdx_comm_world(const pbdx_comm *c);
+int pbdx_comm_rank(const pbdx_comm *c);
+int pbdx_comm_all_reduce_sum_u64(pbdx_comm *c, uint64_t *values, uint32_t n);      /* in place */
+int pbdx_comm_all_reduce_max_f64(pbdx_comm *c, double *values, uint32_t n);        /* in place */
+int pbdx_comm_all_gather_u64(pbdx_comm *c, const uint64_t *mine, uint32_t n, uint64_t *all);   /* all: world x n, rank-major */
+int pbdx_comm_barrier(pbdx_comm *c);
 
 #ifdef __cplusplus
 }

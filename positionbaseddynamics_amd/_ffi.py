@@ -202,6 +202,12 @@ SIGNATURES = [
     ("pbdx_ensemble_set_model", C.c_int, vp, vp), ("pbdx_ensemble_step", C.c_int, vp, u32), ("pbdx_ensemble_gather", C.c_int, vp, vp),
     ("pbdx_ensemble_get_shard", C.c_int, vp, u32, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)),
     ("pbdx_ensemble_timestep", vp, vp, u32), ("pbdx_ensemble_shard_model", vp, vp, u32), ("pbdx_ensemble_last_step_ms", C.c_double, vp),
+    # the collective of a multi-process host (RCCL loaded at run time, csrc/pbdx_comm.cpp)
+    ("pbdx_comm_available", C.c_int), ("pbdx_comm_unique_id", C.c_int, vp, C.c_size_t),
+    ("pbdx_comm_create", C.c_int, C.POINTER(vp), vp, C.c_size_t, C.c_int, C.c_int, C.c_int), ("pbdx_comm_destroy", None, vp),
+    ("pbdx_comm_world", C.c_int, vp), ("pbdx_comm_rank", C.c_int, vp),
+    ("pbdx_comm_all_reduce_sum_u64", C.c_int, vp, C.POINTER(C.c_uint64), u32), ("pbdx_comm_all_reduce_max_f64", C.c_int, vp, C.POINTER(C.c_double), u32),
+    ("pbdx_comm_all_gather_u64", C.c_int, vp, C.POINTER(C.c_uint64), u32, C.POINTER(C.c_uint64)), ("pbdx_comm_barrier", C.c_int, vp),
 ]
 
 for _s in SIGNATURES:

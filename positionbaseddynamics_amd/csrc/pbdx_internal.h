@@ -73,7 +73,8 @@ int sort_pairs_u32(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint
 
 } // namespace pbdx
 
-namespace pbdx { uint64_t next_model_uid(); }
+struct pbdx_model;
+namespace pbdx { uint64_t next_model_uid(); const pbdx_model *find_model(uint64_t uid); /* null: destroyed */ }
 
 // pbdx_hostio.hip (the copies to / from the device are declared in pbdx_device.h)
 namespace pbdx {

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 
@@ -213,6 +214,18 @@ void store_colmajor(const M3 &A, float *out)
 } // namespace
 
 uint64_t pbdx::next_model_uid() { static std::atomic<uint64_t> n(1); return n.fetch_add(1); }
+// the models alive in this process by their never-reused uid: holders of a model's IDENTITY (pbdx_ensemble: its blocks are copies) ask whether it still
+// exists instead of keeping its address
+namespace {
+std::mutex g_models_mu;
+std::unordered_map<uint64_t, const pbdx_model *> &live_models() { static std::unordered_map<uint64_t, const pbdx_model *> m; return m; }
+}
+const pbdx_model *pbdx::find_model(uint64_t uid)
+{
+	std::lock_guard<std::mutex> lk(g_models_mu);
+	auto it = live_models().find(uid);
+	return it == live_models().end() ? nullptr : it->second;
+}
 
 extern "C" {
 
@@ -221,10 +234,16 @@ int pbdx_model_create(pbdx_model **out)
 	if (!out) { set_error("pbdx_model_create: null out"); return PBDX_ERR_INVALID; }
 	*out = new (std::nothrow) pbdx_model();
 	if (!*out) { set_error("out of memory"); return PBDX_ERR_ALLOC; }
+	{ std::lock_guard<std::mutex> lk(g_models_mu); live_models()[(*out)->uid] = *out; }
 	return PBDX_OK;
 }
 
-void pbdx_model_destroy(pbdx_model *m) { delete m; }
+void pbdx_model_destroy(pbdx_model *m)
+{
+	if (!m) return;
+	{ std::lock_guard<std::mutex> lk(g_models_mu); live_models().erase(m->uid); }
+	delete m;
+}
 
 int pbdx_model_cleanup(pbdx_model *m)
 {

@@ -287,3 +287,112 @@ def test_single_process_ensemble_steps_like_one_engine_and_like_the_reference():
         e.step(1)
     e.setModel(m)
     e.step(1)
+
+
+def test_single_process_ensemble_does_not_keep_the_models_address():
+    """the ensemble's blocks are copies, so the model given to pbdx_ensemble_set_model may be destroyed afterwards -- the ensemble identifies it
+    by its never-reused uid, not by address; and a failed set_model leaves the ensemble WITHOUT a model (the next step says so instead of returning OK
+    having done nothing).  No GPU: the step itself then reports the missing device, not a stale-model error and not a crash."""
+    import ctypes as C
+    import positionbaseddynamics_amd as pbd
+    from positionbaseddynamics_amd import _ffi
+    lib = _ffi.lib
+    e = pbd.DeviceEnsemble([0, 0])
+    m = util.build_mine(util.cloth_spec(10, 10, 4, 3, instances=4, instance_offset=(0.0, 0.0, 12.0), instanced=True))
+    e.setModel(m)
+    assert [(e.shard(i)["begin"], e.shard(i)["end"]) for i in range(2)] == [(0, 2), (2, 4)]
+    # an edit while the model is alive is refused by step() and gather() alike
+    m.getParticles().setPosition(3, [0.0, 2.0, 0.0])
+    assert lib.pbdx_ensemble_step(e._h, 1) == 1 and b"edited" in lib.pbdx_last_error()
+    assert lib.pbdx_ensemble_gather(e._h, m._h) == 1 and b"edited" in lib.pbdx_last_error()
+    e.setModel(m)
+    # the model goes away: the blocks stay, nothing dereferences the old address
+    h_old = m._h
+    lib.pbdx_model_destroy(m._h); m._h = None
+    rc = lib.pbdx_ensemble_step(e._h, 1)
+    assert rc in (0, 2), lib.pbdx_last_error()            # 2 = PBDX_ERR_NO_DEVICE here; never "edited", never a fault
+    assert b"edited" not in lib.pbdx_last_error()
+    # an address that now belongs to ANOTHER model is not mistaken for the old one
+    m2 = util.build_mine(util.cloth_spec(10, 10, 4, 3, instances=4, instance_offset=(0.0, 0.0, 12.0), instanced=True))
+    assert lib.pbdx_ensemble_gather(e._h, m2._h) == 1 and b"not the model" in lib.pbdx_last_error()
+    # a model that is refused before anything is dropped (empty) leaves the previous blocks in place ...
+    empty = pbd.SimulationModel()
+    assert lib.pbdx_ensemble_set_model(e._h, empty._h) == 1
+    assert lib.pbdx_ensemble_step(e._h, 1) in (0, 2)
+    # ... and an ensemble that never got a model says so
+    e3 = pbd.DeviceEnsemble([0])
+    assert lib.pbdx_ensemble_step(e3._h, 1) == 1 and b"no model" in lib.pbdx_last_error()
+    e.setModel(m2)
+    assert e.shard(1)["end"] == 4
+
+
+def test_comm_loads_rccl_at_run_time_or_says_why():
+    """pbdx_comm_*: RCCL is opened with dlopen by the first call (libpbdx.so itself does not link it).  Without a GPU no communicator can be made; the
+    entry points must say so cleanly."""
+    import ctypes as C
+    import subprocess
+    from positionbaseddynamics_amd import _ffi
+    lib = _ffi.lib
+    needed = subprocess.run(["readelf", "-d", _ffi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed, "libpbdx.so must not link RCCL: it is loaded on demand"
+    avail = lib.pbdx_comm_available()
+    assert avail in (0, 1)
+    ident = (C.c_char * 128)()
+    assert lib.pbdx_comm_unique_id(ident, 64) == 1            # too small a buffer
+    h = C.c_void_p()
+    assert lib.pbdx_comm_create(C.byref(h), ident, 128, 2, 2, 0) == 1      # rank outside the world
+    import positionbaseddynamics_amd as pbd
+    if pbd.device_count() < 1:
+        rc = lib.pbdx_comm_create(C.byref(h), ident, 128, 1, 0, 0)
+        assert rc in (2, 4) and not h.value, lib.pbdx_last_error()      # no device / no RCCL
+    assert lib.pbdx_comm_barrier(None) == 1
+    lib.pbdx_comm_destroy(None)
+
+
+@pytest.mark.gpu
+def test_comm_world_of_one_rank_on_the_gpu():
+    """The C-side collective at world size 1 on the MI355X (one GPU per box: what can be run here): unique id, communicator on device 0, sum / max
+    all-reduce, all-gather, barrier, destroy -- RCCL reached without torch."""
+    import ctypes as C
+    from positionbaseddynamics_amd import _ffi
+    lib = _ffi.lib
+    assert lib.pbdx_comm_available() == 1, lib.pbdx_last_error()
+    ident = (C.c_char * 128)()
+    assert lib.pbdx_comm_unique_id(ident, 128) == 0, lib.pbdx_last_error()
+    h = C.c_void_p()
+    assert lib.pbdx_comm_create(C.byref(h), ident, 128, 1, 0, 0) == 0, lib.pbdx_last_error()
+    assert lib.pbdx_comm_world(h) == 1 and lib.pbdx_comm_rank(h) == 0
+    v = (C.c_uint64 * 3)(5, 1 << 40, 7)
+    assert lib.pbdx_comm_all_reduce_sum_u64(h, v, 3) == 0, lib.pbdx_last_error()
+    assert list(v) == [5, 1 << 40, 7]
+    d = (C.c_double * 2)(0.575, -3.0)
+    assert lib.pbdx_comm_all_reduce_max_f64(h, d, 2) == 0, lib.pbdx_last_error()
+    assert list(d) == [0.575, -3.0]
+    mine, allv = (C.c_uint64 * 2)(0xdeadbeefcafe, 42), (C.c_uint64 * 2)()
+    assert lib.pbdx_comm_all_gather_u64(h, mine, 2, allv) == 0, lib.pbdx_last_error()
+    assert list(allv) == [0xdeadbeefcafe, 42]
+    for _ in range(3):
+        assert lib.pbdx_comm_barrier(h) == 0, lib.pbdx_last_error()
+    lib.pbdx_comm_destroy(h)
+
+
+@pytest.mark.gpu
+def test_single_process_ensemble_with_one_device_listed_eight_times():
+    """The 8-GPU shape of the single-process ensemble on the one GPU of the box: eight engines, seven resident worker threads, sixteen 40x40 sheets (two
+    per engine), stepped in several calls (the workers are woken per call, not created), gathered: bit-identical to one engine on the whole model."""
+    import positionbaseddynamics_amd as pbd
+    spec = util.cloth_spec(40, 40, 4, 3, instances=16, instance_offset=(0.0, 0.0, 12.0), instanced=True)
+    m = util.build_mine(spec)
+    pbd.TimeManager.setCurrent(pbd.TimeManager())
+    e = pbd.DeviceEnsemble([0] * 8)
+    e.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
+    e.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 10)
+    e.setModel(m)
+    assert [(e.shard(i)["begin"], e.shard(i)["end"]) for i in range(8)] == [(2 * i, 2 * i + 2) for i in range(8)]
+    for n in (1, 2, 1, 2):
+        e.step(n)
+    e.gather()
+    xe, ve = m.getParticles().positions().copy(), m.getParticles().array(2).copy()
+    print("ensemble of 8 engines on one GPU: last step call %.3f ms" % e.lastStepMs())
+    m1, ts1 = util.mine_run(spec, 6, 1, 10, resident=True)
+    assert util.bitwise_equal(xe, m1.getParticles().positions()) and util.bitwise_equal(ve, m1.getParticles().array(2))
