@@ -168,9 +168,49 @@ struct BankOrder
 	static constexpr uint32_t kBudget = 96;
 };
 
+// The constraints a closure has already collected: an open-addressing set stamped with the closure's serial number (no reset between closures).  Until
+// round 6 this was a stamp word per constraint of the whole schedule and per thread -- 24 MB per thread at 6 M constraints, first touched (page faults)
+// at the start of every build, for closures that hold some ten thousand constraints.
+struct CidSet
+{
+	std::vector<uint32_t> key, ser;
+	uint32_t mask = 0, used = 0, serial_of_used = 0;
+	void init(uint32_t cap_log2) { key.assign((size_t)1 << cap_log2, 0u); ser.assign((size_t)1 << cap_log2, 0u); mask = (1u << cap_log2) - 1u; used = 0; serial_of_used = 0; }
+	void clear_all() { std::fill(ser.begin(), ser.end(), 0u); used = 0; }
+	// true if `cid` was not in the set of closure `serial` yet (and is now)
+	inline bool insert(uint32_t cid, uint32_t serial)
+	{
+		if (serial_of_used != serial) { serial_of_used = serial; used = 0; }
+		uint32_t h = (cid * 2654435761u) & mask;
+		while (ser[h] == serial)
+		{
+			if (key[h] == cid) return false;
+			h = (h + 1u) & mask;
+		}
+		key[h] = cid; ser[h] = serial;
+		if (++used * 2u > mask) grow(serial);
+		return true;
+	}
+	void grow(uint32_t serial)
+	{
+		std::vector<uint32_t> ok, os;
+		ok.swap(key); os.swap(ser);
+		const uint32_t nm = mask * 2u + 1u;
+		key.assign((size_t)nm + 1u, 0u); ser.assign((size_t)nm + 1u, 0u); mask = nm;
+		for (size_t i = 0; i < ok.size(); i++)
+			if (os[i] == serial)
+			{
+				uint32_t h = (ok[i] * 2654435761u) & mask;
+				while (ser[h] == serial) h = (h + 1u) & mask;
+				key[h] = ok[i]; ser[h] = serial;
+			}
+	}
+};
+
 struct Scratch
 {
-	std::vector<uint32_t> stamp_p, stamp_c, local_of;
+	std::vector<uint32_t> stamp_p, local_of;
+	CidSet cset;
 	BankOrder bank; std::vector<uint32_t> bank_h, bank_key, bank_cls, bank_order;      // bank-aware slot order of the step being emitted
 	uint32_t serial = 0;
 	std::vector<std::vector<uint32_t>> bucket;
@@ -179,7 +219,7 @@ struct Scratch
 	void init(const Graph &g)
 	{
 		stamp_p.assign(g.n, 0);
-		stamp_c.assign(g.nc, 0);
+		cset.init(17);
 		local_of.assign(g.n, 0);
 		serial = 0;
 	}
@@ -194,7 +234,7 @@ void closure(const Graph &g, Scratch &s, const uint32_t *owned, uint32_t n_owned
 	if (++s.serial == 0)
 	{
 		std::fill(s.stamp_p.begin(), s.stamp_p.end(), 0u);
-		std::fill(s.stamp_c.begin(), s.stamp_c.end(), 0u);
+		s.cset.clear_all();
 		s.serial = 1;
 	}
 	const uint32_t serial = s.serial;
@@ -210,11 +250,7 @@ void closure(const Graph &g, Scratch &s, const uint32_t *owned, uint32_t n_owned
 			const uint32_t col = g.colour(cid);
 			if (col >= c_limit) break;
 			if (col < c_lo) continue;
-			if (s.stamp_c[cid] != serial)
-			{
-				s.stamp_c[cid] = serial;
-				s.bucket[col - c_lo].push_back(cid);
-			}
+			if (s.cset.insert(cid, serial)) s.bucket[col - c_lo].push_back(cid);
 		}
 	};
 	for (uint32_t i = 0; i < n_owned; i++) add(owned[i], c1);
@@ -553,6 +589,8 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	plan = FusedPlan();
 	if (n == 0 || batches.empty()) { why = "empty schedule"; return false; }
 	if (batches.size() >= 65535) { why = "too many batches"; return false; }
+	const bool verbose_build = getenv("PBDX_PLAN_VERBOSE") != nullptr;
+	auto lap_build = [&](const char *what) { if (verbose_build) fprintf(stderr, "[plan] %-24s %7.3f s since start\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
 
 	Graph g;
 	g.n = n;
@@ -599,6 +637,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	}
 	g.adj_off.pop_back();     // adj_off[p] .. adj_off[p+1]
 
+	lap_build("graph");
 	// ---- parameter views: uniform over the whole schedule -> scalar ------------------------------
 	for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++)
 	{
@@ -607,6 +646,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 		compute_type_view(t, spans, plan.views[t]);
 	}
 
+	lap_build("parameter views");
 	// ---- tiles ---------------------------------------------------------------------------------
 	// (tile count: default_tile_count above)
 	uint32_t T = opt.tile_particles, k;
@@ -639,9 +679,13 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	plan.num_constraints = g.nc;
 	plan.batch_base = g.batch_base;
 
+	lap_build("tiles (bisection)");
 	uint32_t threads = opt.threads ? opt.threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	// (every thread's stamps are a pass over n + nc words: 32 MB per thread at 1 M particles / 6 M constraints -- initialised by the threads themselves;
+	// done one after the other on the calling thread this was the largest serial piece of the whole build: 1.05 of 4.8 s on 8 cores)
 	std::vector<Scratch> scratch(threads);
-	for (Scratch &s : scratch) s.init(g);
+	parallel_for(threads, threads, [&](uint32_t i, uint32_t) { scratch[i].init(g); });
+	lap_build("scratch");
 
 	// ---- segment boundaries: dynamic programme over a sample of tiles ---------------------------
 	// (developer aid: PBDX_PLAN_SLOT_SCALE / PBDX_PLAN_FIXED_NS / PBDX_PLAN_LAUNCH_NS rescale the time model to explore other
@@ -706,6 +750,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 			const double cst = best[c1 - len] + seg_bytes[e] * scale + launch_ns;
 			if (cst < best[c1]) { best[c1] = cst; prev[c1] = c1 - len; }
 		}
+	lap_build("segment boundaries (DP)");
 	std::vector<std::pair<uint32_t, uint32_t>> todo;
 	for (uint32_t c = ncol; c > 0; c = prev[c]) todo.push_back({ prev[c], c });
 	std::reverse(todo.begin(), todo.end());
@@ -744,9 +789,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 		}
 	}
 
-	const bool verbose_build = getenv("PBDX_PLAN_VERBOSE") != nullptr;
-	auto lap_build = [&](const char *what) { if (verbose_build) fprintf(stderr, "[plan] %-24s %7.3f s since start\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
-	lap_build("segments, boundary split");
+	lap_build("boundary split");
 	// ---- full build ----------------------------------------------------------------------------
 	uint64_t slots_total = 0;
 	for (size_t si = 0; si < todo.size(); si++)
@@ -911,40 +954,52 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 		for (size_t b = 0; b < batches.size(); b++)
 			if (batches[b].colour >= c0 && batches[b].colour < c1) { seg.constraints += batches[b].count; seg.type_mask |= 1u << batches[b].type; }
 		seg.tiles.resize(k);
+		// where every tile's part of the segment's streams goes (a prefix sum on the calling thread), then the copies by all threads: the streams of a
+		// segment of the 1 M cloth are 140 MB, and appending them tile after tile to growing vectors was half a second per segment
+		struct Base { uint64_t idx, par, gid, cid, step; uint32_t lam; };
+		std::vector<Base> base(k + 1);
+		base[0] = Base{ 0, 0, 0, 0, 0, 0 };
 		for (uint32_t t = 0; t < k; t++)
 		{
-			TileOut &o = outs[t];
+			const TileOut &o = outs[t];
+			base[t + 1] = Base{ base[t].idx + o.idx.size(), base[t].par + o.params.size(), base[t].gid + round_up((uint32_t)o.gid.size(), 4), base[t].cid + o.slot_cid.size(),
+				base[t].step + o.steps.size(), base[t].lam + o.lam_count };
+			// streams are addressed with 32-bit BYTE offsets (buffer descriptors)
+			if (base[t + 1].idx * 2 >= 0xfffffff0ull || base[t + 1].par * 4 >= 0xfffffff0ull || (uint64_t)base[t + 1].lam * 4 >= 0xfffffff0ull || base[t + 1].gid >= 0xfffffff0ull)
+			{ why = "a segment stream exceeds 4 GiB"; return false; }
+		}
+		seg.idx.resize(base[k].idx); seg.params.resize(base[k].par); seg.gid.assign(base[k].gid, 0u); seg.slot_cid.resize(base[k].cid); seg.steps.resize(base[k].step);
+		seg.lam_count = base[k].lam;
+		parallel_for(k, threads, [&](uint32_t t, uint32_t) {
+			const TileOut &o = outs[t];
 			FusedTile &ft = seg.tiles[t];
 			memset(&ft, 0, sizeof(ft));
-			ft.step_begin = (uint32_t)seg.steps.size();
+			ft.step_begin = (uint32_t)base[t].step;
+			ft.step_end = (uint32_t)base[t + 1].step;
 			ft.n_local = (uint32_t)o.gid.size();
 			ft.n_owned = o.n_owned;
 			ft.wb_begin = wb_begin[t];
-
-			ft.gid_off = (uint32_t)seg.gid.size();
+			ft.gid_off = (uint32_t)base[t].gid;
 			ft.slots = o.slots;
-			const uint32_t idx_base = (uint32_t)seg.idx.size(), par_base = (uint32_t)seg.params.size();
+			const uint32_t idx_base = (uint32_t)base[t].idx, par_base = (uint32_t)base[t].par, lam_base = base[t].lam, cid_base = (uint32_t)base[t].cid;
 			ft.tab_off = o.tab_f4 ? (par_base + o.tab_off) / 4u : 0u;      // (every block of the stream is a whole number of 256-byte units)
 			ft.tab_f4 = o.tab_f4;
-			seg.max_tab_f4 = std::max(seg.max_tab_f4, o.tab_f4);
-			const uint32_t lam_base = seg.lam_count, cid_base = (uint32_t)seg.slot_cid.size();
-			// streams are addressed with 32-bit BYTE offsets (buffer descriptors)
-			if (((uint64_t)idx_base + o.idx.size()) * 2 >= 0xfffffff0ull || ((uint64_t)par_base + o.params.size()) * 4 >= 0xfffffff0ull ||
-				((uint64_t)lam_base + o.lam_count) * 4 >= 0xfffffff0ull)
-			{ why = "a segment stream exceeds 4 GiB"; return false; }
-			for (FusedStep st : o.steps)
+			for (size_t q = 0; q < o.steps.size(); q++)
 			{
+				FusedStep st = o.steps[q];
 				st.idx_off += idx_base; st.par_off += par_base; st.lam_off += lam_base; st.cid_off += cid_base;
-				seg.steps.push_back(st);
+				seg.steps[base[t].step + q] = st;
 			}
-			ft.step_end = (uint32_t)seg.steps.size();
-			seg.idx.insert(seg.idx.end(), o.idx.begin(), o.idx.end());
-			seg.params.insert(seg.params.end(), o.params.begin(), o.params.end());
-			seg.gid.insert(seg.gid.end(), o.gid.begin(), o.gid.end());
-			seg.gid.resize(round_up((uint32_t)seg.gid.size(), 4), 0);
-			seg.slot_cid.insert(seg.slot_cid.end(), o.slot_cid.begin(), o.slot_cid.end());
-			seg.lam_count += o.lam_count;
-			seg.max_local = std::max(seg.max_local, ft.n_local);
+			if (!o.idx.empty()) memcpy(&seg.idx[base[t].idx], o.idx.data(), o.idx.size() * sizeof(uint16_t));
+			if (!o.params.empty()) memcpy(&seg.params[base[t].par], o.params.data(), o.params.size() * sizeof(float));
+			if (!o.gid.empty()) memcpy(&seg.gid[base[t].gid], o.gid.data(), o.gid.size() * sizeof(uint32_t));
+			if (!o.slot_cid.empty()) memcpy(&seg.slot_cid[base[t].cid], o.slot_cid.data(), o.slot_cid.size() * sizeof(uint32_t));
+		});
+		for (uint32_t t = 0; t < k; t++)
+		{
+			const TileOut &o = outs[t];
+			seg.max_tab_f4 = std::max(seg.max_tab_f4, o.tab_f4);
+			seg.max_local = std::max(seg.max_local, (uint32_t)o.gid.size());
 			seg.slots += o.slots;
 			seg.stream_bytes += o.stream_bytes;
 		}

@@ -40,6 +40,9 @@
 #include "pbdx_contact.h"
 #include "pbdx_tetcontact_dev.h"
 #include <chrono>
+#include <mutex>
+#include <array>
+#include <unordered_map>
 #include <thread>
 #include <vector>
 #include <algorithm>
@@ -1653,6 +1656,7 @@ struct pbdx_solver
 	void *tet_work_alloc[24] = {};
 	size_t tet_sort_temp_bytes = 0;      // scratch of the (particle, slot) pair sort of the contact velocity impulses (tet_work_alloc[21])
 	pbdx_collision_range *d_ranges = nullptr;     // device copy of `ranges` (read by the tet-contact velocity chains)
+	uint32_t autotune_cache_hits = 0;     // schedule decisions taken from the process-wide cache (autotune_schedule)
 	bool measuring_iter_form = false;    // autotune_schedule: time the one-launch-per-iteration form of the sweeps
 	int tet_force_impulses = 0;          // PBDX_OPT_TET_FORCE_IMPULSES
 	uint32_t tet_impulses_last = 0; uint64_t tet_impulses_total = 0;     // contacts with a non-zero velocity impulse: last detection / since the colliders were set
@@ -1966,6 +1970,9 @@ int ensure_plan(pbdx_solver *s)
 	s->plan_built = true;
 	s->plan_ok = false;
 	if (s->order.empty() || s->n == 0 || s->h_x.size() != (size_t)3 * s->n) { s->plan_why = "no schedule / particles"; return PBDX_OK; }
+	const auto t_plan0 = std::chrono::steady_clock::now();
+	const bool plan_verbose = getenv("PBDX_PLAN_VERBOSE") != nullptr;
+	auto lap_plan = [&](const char *what) { if (plan_verbose) fprintf(stderr, "[engine] %-36s %7.3f s since ensure_plan\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_plan0).count()); };
 	std::vector<PlanBatch> pbs;
 	uint32_t colour = 0;
 	for (size_t oi = 0; oi < s->order.size(); oi++)
@@ -2019,6 +2026,7 @@ int ensure_plan(pbdx_solver *s)
 	}
 	if (!planned && !build_fused_plan(s->n, s->h_x.data(), pbs, opt, s->plan, s->plan_why))
 		return PBDX_OK;
+	lap_plan("plan built");
 	// workgroup size per segment: enough threads to cover the largest colour step of a tile once, at most 1024
 	std::vector<int> blocks;
 	uint32_t all_mask = 0;
@@ -2122,6 +2130,7 @@ int ensure_plan(pbdx_solver *s)
 		}
 		std::vector<TileDev> tiles_dev(tiles.size());
 		for (size_t ti = 0; ti < tiles.size(); ti++) { memset(&tiles_dev[ti], 0, sizeof(TileDev)); tiles_dev[ti].t = tiles[ti]; }
+		lap_plan("segment image (records, chunks)");
 		int r = upload(&d.d_tiles, tiles_dev);
 		if (!r) r = upload(&d.d_chunks, chunks);
 		if (!r) r = upload(reinterpret_cast<uint8_t **>(&d.d_idx), idx_img);
@@ -2154,7 +2163,10 @@ int ensure_plan(pbdx_solver *s)
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(d.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_bytes);
 	}
 	s->plan_ok = true;
-	return prepare_persistent(s);
+	lap_plan("segments uploaded");
+	const int rp_ = prepare_persistent(s);
+	lap_plan("persistent schedule prepared");
+	return rp_;
 }
 
 // Device arrays of the per-colour schedule (B), created the first time that schedule actually runs.
@@ -2457,6 +2469,30 @@ int autotune_schedule(pbdx_solver *s)
 	const bool try_percolour = s->fuse == 2 && (mask & ~kMaskLight) != 0;
 	const bool try_persistent = s->persistent == 1 && s->persist_ok;
 	if (!try_percolour && !try_persistent) return PBDX_OK;
+	// The decision depends on the shape of the plan, not on its contents: a plan of the same shape on the same device (a topology edit that leaves the
+	// sizes alone, the engines of an ensemble with congruent blocks, a second solver on the same scene) takes the decision measured before instead of
+	// 60-80 ms of measurement (PBDX_NO_AUTOTUNE_CACHE: always measure).  The cache is process-wide.
+	uint64_t sig = 0xcbf29ce484222325ull;
+	{
+		auto mixin = [&](uint64_t v) { sig ^= v + 0x9e3779b97f4a7c15ull + (sig << 6) + (sig >> 2); sig *= 0x100000001b3ull; };
+		mixin((uint64_t)s->device); mixin(s->n); mixin(s->plan.num_constraints); mixin(s->plan.num_tiles); mixin(s->dsegs.size()); mixin(mask);
+		mixin(s->persist_ok ? s->persist_grid : 0u); mixin((uint64_t)s->persist_block); mixin(s->tet_active() ? 1u : 0u); mixin((uint64_t)s->fuse); mixin((uint64_t)s->persistent);
+		for (const DeviceSegment &d : s->dsegs) { mixin(d.constraints); mixin(d.idx_bytes); mixin(d.params_bytes); mixin(d.lds_bytes); mixin((uint64_t)d.block); }
+	}
+	static std::mutex cache_mu;
+	static std::unordered_map<uint64_t, std::array<float, 5>> cache;      // signature -> ms[3], fuse_choice, persist_choice
+	if (!getenv("PBDX_NO_AUTOTUNE_CACHE"))
+	{
+		std::lock_guard<std::mutex> lk(cache_mu);
+		auto it = cache.find(sig);
+		if (it != cache.end())
+		{
+			for (int i = 0; i < 3; i++) s->autotune_ms[i] = it->second[i];
+			s->fuse_choice = (int)it->second[3]; s->persist_choice = it->second[4] != 0.0f;
+			s->autotune_rounds = 0; s->autotune_spent_ms = 0.0f; s->autotune_cache_hits++;
+			return PBDX_OK;
+		}
+	}
 	int r = try_percolour ? ensure_device_batches(s) : PBDX_OK;
 	if (r) return r;
 	float4 *scratch[2] = { nullptr, nullptr }, *keep[2] = { s->d_pos[0], s->d_pos[1] };
@@ -2535,6 +2571,10 @@ int autotune_schedule(pbdx_solver *s)
 	const float fused_best = s->persist_choice ? ms[2] : ms[1];
 	if (ms[0] > 0.0f && ms[0] < fused_best) { s->fuse_choice = 0; s->persist_choice = false; }
 	if (s->persistent >= 2 && s->fuse_choice) s->persist_choice = true;
+	{
+		std::lock_guard<std::mutex> lk(cache_mu);
+		cache[sig] = { ms[0], ms[1], ms[2], (float)s->fuse_choice, s->persist_choice ? 1.0f : 0.0f };
+	}
 	return PBDX_OK;
 }
 
