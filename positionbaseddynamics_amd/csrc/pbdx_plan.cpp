@@ -680,7 +680,7 @@ bool build_fused_plan(uint32_t n, const float *x, const std::vector<PlanBatch> &
 	plan.batch_base = g.batch_base;
 
 	lap_build("tiles (bisection)");
-	uint32_t threads = opt.threads ? opt.threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	uint32_t threads = opt.threads ? opt.threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));      // (32: the tile builds of the 1 M cloth scale to about there on the 256-CPU host)
 	// (every thread's stamps are a pass over n + nc words: 32 MB per thread at 1 M particles / 6 M constraints -- initialised by the threads themselves;
 	// done one after the other on the calling thread this was the largest serial piece of the whole build: 1.05 of 4.8 s on 8 cores)
 	std::vector<Scratch> scratch(threads);
@@ -1251,7 +1251,7 @@ bool build_instanced_plan(uint32_t n_proto, uint32_t K, const float *x, const st
 	plan.tile_of.resize((size_t)n_proto * K);
 	for (uint32_t k = 0; k < K; k++)
 		for (uint32_t p = 0; p < n_proto; p++) plan.tile_of[(size_t)k * n_proto + p] = pp.tile_of[p] + k * kt;
-	const uint32_t threads = opt.threads ? opt.threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	const uint32_t threads = opt.threads ? opt.threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));      // (32: the tile builds of the 1 M cloth scale to about there on the 256-CPU host)
 	plan.segs.resize(pp.segs.size());
 	for (size_t si = 0; si < pp.segs.size(); si++)
 	{

@@ -17,6 +17,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <atomic>
 #include <chrono>
 
 using namespace PBD;
@@ -421,9 +422,19 @@ bool TimeStepControllerHIP::supported(SimulationModel &model)
 	// known (group, type) buckets run on the GPU, the others through the reference's own virtual solvePositionConstraint on the host
 	// inside the same colour groups (runMixedSteps).  Only for pure particle models: an unknown class may read anything, and what the
 	// plug-in keeps current on the host between the groups is ParticleData's positions (+ masses).
-	size_t unknown = 0;
-	for (Constraint *c : model.getConstraints())
-		if (engineType(c) < 0) unknown++;                   // e.g. GenericConstraints, joints, rods
+	// (a walk over every heap object of the model: by the worker pool -- at 6 M constraints a single thread needs 0.2-0.3 s for it, and the first step made
+	// three such walks one after the other: this one, the bodies for the colouring and the schedule, profiles/HISTORY.md [10])
+	std::atomic<size_t> unknownCount(0);
+	{
+		SimulationModel::ConstraintVector &cs = model.getConstraints();
+		HostPool &pool = HostPool::get();
+		pool.run(cs.size(), cs.size() > 65536 ? pool.threads() : 1, [&](size_t b, size_t e) {
+			size_t u = 0;
+			for (size_t i = b; i < e; i++) if (engineType(cs[i]) < 0) u++;                   // e.g. GenericConstraints, joints, rods
+			if (u) unknownCount += u;
+		});
+	}
+	const size_t unknown = unknownCount.load();
 	if (unknown && (!model.getRigidBodies().empty() || nObjects != 0)) return false;
 	m_mixed = unknown != 0;
 	m_supported = true;
@@ -744,11 +755,22 @@ static void initConstraintGroupsFast(SimulationModel &model)
 	const size_t numBodies = (size_t)model.getParticles().size() + model.getRigidBodies().size();
 	if (nc == 0 || nc >= 0xffffffffull || numBodies >= 0xffffffffull) { model.initConstraintGroups(); return; }
 	std::vector<uint32_t> off(nc + 1, 0), bodies, groupOf(nc, 0);
-	bodies.reserve(nc * 4);
-	for (size_t i = 0; i < nc; i++)
 	{
-		for (unsigned int b : constraints[i]->m_bodies) bodies.push_back((uint32_t)b);
-		off[i + 1] = (uint32_t)bodies.size();
+		// body counts (parallel), offsets (one pass over integers), bodies (parallel)
+		HostPool &pool = HostPool::get();
+		const int parts = nc > 65536 ? pool.threads() : 1;
+		pool.run(nc, parts, [&](size_t b, size_t e) { for (size_t i = b; i < e; i++) off[i + 1] = (uint32_t)constraints[i]->m_bodies.size(); });
+		uint64_t total = 0;
+		for (size_t i = 0; i < nc; i++) { total += off[i + 1]; off[i + 1] = (uint32_t)total; }
+		if (total >= 0xffffffffull) { model.initConstraintGroups(); return; }
+		bodies.resize((size_t)total);
+		pool.run(nc, parts, [&](size_t b, size_t e) {
+			for (size_t i = b; i < e; i++)
+			{
+				uint32_t *dst = bodies.data() + off[i];
+				for (unsigned int bd : constraints[i]->m_bodies) *dst++ = (uint32_t)bd;
+			}
+		});
 	}
 	uint32_t numGroups = 0;
 	if (pbdx_colour_constraints_host((uint32_t)numBodies, (uint32_t)nc, off.data(), bodies.data(), groupOf.data(), &numGroups) != PBDX_OK)
@@ -756,6 +778,11 @@ static void initConstraintGroupsFast(SimulationModel &model)
 	SimulationModel::ConstraintGroupVector &groups = model.getConstraintGroups();
 	groups.clear();
 	groups.resize(numGroups);
+	{
+		std::vector<size_t> count(numGroups, 0);
+		for (size_t i = 0; i < nc; i++) count[groupOf[i]]++;
+		for (uint32_t g = 0; g < numGroups; g++) groups[g].reserve(count[g]);
+	}
 	for (size_t i = 0; i < nc; i++) groups[groupOf[i]].push_back((unsigned int)i);
 	model.m_groupsInitialized = true;
 }
@@ -770,22 +797,47 @@ bool TimeStepControllerHIP::buildSchedule(SimulationModel &model, bool paramsOnl
 	std::vector<unsigned int> idx[PBDX_NUM_CONSTRAINT_TYPES];
 	std::vector<float> par[PBDX_NUM_CONSTRAINT_TYPES];
 	unsigned int batch = 0;
+	// A colour group is packed by the worker pool: every share walks its contiguous part of the group into buckets of its own (type by type, in the
+	// group's order), the buckets are concatenated share by share -- the order inside a (group, type) batch is the group's, as with one thread.
+	struct Share { std::vector<unsigned int> idx[PBDX_NUM_CONSTRAINT_TYPES]; std::vector<float> par[PBDX_NUM_CONSTRAINT_TYPES]; std::vector<unsigned int> host; bool unknown = false; };
+	HostPool &pool = HostPool::get();
+	std::vector<Share> shares((size_t)std::max(1, pool.threads()));
 	for (unsigned int g = 0; g < groups.size(); g++)
 	{
 		for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++) { idx[t].clear(); par[t].clear(); }
-		for (unsigned int ci : groups[g])
-		{
-			Constraint *c = constraints[ci];
-			const int type = engineType(c);
-			if (type < 0)
+		const std::vector<unsigned int> &grp = groups[g];
+		const size_t gn = grp.size();
+		const int parts = gn > 16384 ? std::min<int>(pool.threads(), (int)shares.size()) : 1;
+		for (int k = 0; k < parts; k++) { Share &sh = shares[(size_t)k]; for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++) { sh.idx[t].clear(); sh.par[t].clear(); } sh.host.clear(); sh.unknown = false; }
+		pool.run(gn, parts, [&](size_t b, size_t e) {
+			// (the pool's static partition: share k covers [gn k / parts, gn (k + 1) / parts))
+			size_t k = gn ? (b * (size_t)parts + (size_t)parts - 1) / gn : 0;
+			while (k > 0 && gn * k / (size_t)parts > b) k--;
+			while (k + 1 < (size_t)parts && gn * (k + 1) / (size_t)parts <= b) k++;
+			Share &sh = shares[parts > 1 ? k : 0];
+			for (size_t q = b; q < e; q++)
 			{
-				// mixed model: this constraint stays with the host (runMixedSteps), in its colour group
-				if (!m_mixed) return false;
-				if (!paramsOnly) { if (m_hostGroups.size() < groups.size()) m_hostGroups.resize(groups.size()); m_hostGroups[g].push_back(ci); }
-				continue;
+				const unsigned int ci = grp[q];
+				Constraint *c = constraints[ci];
+				const int type = engineType(c);
+				if (type < 0) { sh.unknown = true; sh.host.push_back(ci); continue; }      // mixed model: this constraint stays with the host (runMixedSteps), in its colour group
+				if (!paramsOnly) sh.idx[type].insert(sh.idx[type].end(), c->m_bodies.begin(), c->m_bodies.end());
+				pushParams(sh.par[type], type, c);
 			}
-			if (!paramsOnly) idx[type].insert(idx[type].end(), c->m_bodies.begin(), c->m_bodies.end());
-			pushParams(par[type], type, c);
+		});
+		for (int k = 0; k < parts; k++)
+		{
+			Share &sh = shares[(size_t)k];
+			if (sh.unknown)
+			{
+				if (!m_mixed) return false;
+				if (!paramsOnly) { if (m_hostGroups.size() < groups.size()) m_hostGroups.resize(groups.size()); m_hostGroups[g].insert(m_hostGroups[g].end(), sh.host.begin(), sh.host.end()); }
+			}
+			for (int t = 0; t < PBDX_NUM_CONSTRAINT_TYPES; t++)
+			{
+				if (!sh.idx[t].empty()) idx[t].insert(idx[t].end(), sh.idx[t].begin(), sh.idx[t].end());
+				if (!sh.par[t].empty()) par[t].insert(par[t].end(), sh.par[t].begin(), sh.par[t].end());
+			}
 		}
 		for (int type = 0; type < PBDX_NUM_CONSTRAINT_TYPES; type++)
 		{
