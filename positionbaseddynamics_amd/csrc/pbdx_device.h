@@ -27,6 +27,9 @@ struct DeviceScope
 namespace pbdx {
 hipError_t copy_to_device(void *dst, const void *src, size_t bytes);
 hipError_t copy_from_device(void *dst, const void *src, size_t bytes);
+// asynchronous copies whose host side lies inside page-locked memory THE LIBRARY owns (pinned_alloc: checked, hipErrorInvalidValue otherwise)
+hipError_t copy_pinned_to_device_async(void *dst, const void *src, size_t bytes, hipStream_t stream);
+hipError_t copy_device_to_pinned_async(void *dst, const void *src, size_t bytes, hipStream_t stream);
 }
 
 #endif

@@ -64,8 +64,8 @@ pbdx_model *slice_model(const pbdx_model *m, uint64_t b, uint64_t e, std::string
 	if (pbdx_model_create(&s) != PBDX_OK) { why = pbdx_last_error(); return nullptr; }
 	const uint32_t np = m->inst_count > 1 ? m->inst_particles : m->size();
 	const size_t p0 = (size_t)b * np, p1 = (size_t)e * np;
-	auto cut1 = [&](const std::vector<float> &a, std::vector<float> &d) { d.assign(a.begin() + p0, a.begin() + p1); };
-	auto cut3 = [&](const std::vector<float> &a, std::vector<float> &d) { d.assign(a.begin() + 3 * p0, a.begin() + 3 * p1); };
+	auto cut1 = [&](const ParticleArray &a, ParticleArray &d) { d.assign(a.begin() + p0, a.begin() + p1); };
+	auto cut3 = [&](const ParticleArray &a, ParticleArray &d) { d.assign(a.begin() + 3 * p0, a.begin() + 3 * p1); };
 	cut1(m->mass, s->mass); cut1(m->inv_mass, s->inv_mass);
 	cut3(m->x0, s->x0); cut3(m->x, s->x); cut3(m->v, s->v); cut3(m->a, s->a); cut3(m->old_x, s->old_x); cut3(m->last_x, s->last_x);
 	s->tri_models = m->tri_models;

@@ -207,3 +207,78 @@ extern "C" void pbdx_debug_host_copy(void *dst, const void *src, uint64_t bytes)
 {
 	if (dst && src && bytes) pbdx::host_copy(dst, src, (size_t)bytes);
 }
+
+// ---- page-locked memory THE LIBRARY owns (pbdx_model's particle arrays) ----------------------------------------------------------------------
+// The host mirror of the reference's ParticleData (pbdx_model: mass, inverse mass, x0, x, v, a, oldX, lastX) is the library's own memory, so it may be
+// page-locked and handed to the copy engine as it is -- which is what the reference's python binding does with its own arrays (zero-copy getVertices,
+// pyPBD/ParticleDataModule.cpp:54-58).  A step of the host-in / host-out contract then moves its 56 + 48 MB at the bus rate and no host thread touches
+// them (round 5: 3.6-3.8 ms per step through a mirror and a team of copying threads, 4.8-5.1 through the bounce buffer).  Allocations are registered by
+// address range; the direct copies below REFUSE any address that is not inside one -- a caller's pointer still cannot reach the GPU by address.
+namespace pbdx {
+namespace {
+std::mutex g_pinned_mu;
+std::vector<std::pair<uintptr_t, size_t>> &pinned_ranges() { static std::vector<std::pair<uintptr_t, size_t>> r; return r; }
+bool g_have_device_known = false, g_have_device = false;
+bool have_device()
+{
+	if (!g_have_device_known)
+	{
+		int n = 0;
+		g_have_device = hipGetDeviceCount(&n) == hipSuccess && n > 0;
+		if (!g_have_device) (void)hipGetLastError();
+		g_have_device_known = true;
+	}
+	return g_have_device;
+}
+}
+void *pinned_alloc(size_t bytes)
+{
+	if (!bytes) return nullptr;
+	void *p = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(g_pinned_mu);
+		if (!getenv("PBDX_NO_PINNED_MODEL") && have_device() && hipHostMalloc(&p, bytes, hipHostMallocPortable) == hipSuccess && p)
+		{
+			pinned_ranges().push_back({ (uintptr_t)p, bytes });
+			return p;
+		}
+	}
+	(void)hipGetLastError();
+	return malloc(bytes);
+}
+void pinned_free(void *p)
+{
+	if (!p) return;
+	{
+		std::lock_guard<std::mutex> lk(g_pinned_mu);
+		auto &r = pinned_ranges();
+		for (size_t i = 0; i < r.size(); i++)
+			if (r[i].first == (uintptr_t)p)
+			{
+				r[i] = r.back(); r.pop_back();
+				(void)hipHostFree(p);
+				return;
+			}
+	}
+	free(p);
+}
+bool is_library_pinned(const void *p, size_t bytes)
+{
+	if (!p) return false;
+	std::lock_guard<std::mutex> lk(g_pinned_mu);
+	for (const auto &r : pinned_ranges())
+		if ((uintptr_t)p >= r.first && (uintptr_t)p + bytes <= r.first + r.second) return true;
+	return false;
+}
+// asynchronous copies on `stream` with a host side inside the library's own page-locked memory (checked); hipErrorInvalidValue otherwise
+hipError_t copy_pinned_to_device_async(void *dst, const void *src, size_t bytes, hipStream_t stream)
+{
+	if (!is_library_pinned(src, bytes)) return hipErrorInvalidValue;
+	return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+}
+hipError_t copy_device_to_pinned_async(void *dst, const void *src, size_t bytes, hipStream_t stream)
+{
+	if (!is_library_pinned(dst, bytes)) return hipErrorInvalidValue;
+	return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+}
+} // namespace pbdx

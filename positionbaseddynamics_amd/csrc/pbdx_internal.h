@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string>
 #include <vector>
+#include <new>
 
 namespace pbdx {
 
@@ -79,13 +80,30 @@ namespace pbdx { uint64_t next_model_uid(); const pbdx_model *find_model(uint64_
 // pbdx_hostio.hip (the copies to / from the device are declared in pbdx_device.h)
 namespace pbdx {
 void host_copy(void *dst, const void *src, size_t bytes);             // memcpy, by several threads when large
+// page-locked memory the library owns (malloc without a HIP device), registered by address range: the only host memory whose ADDRESS reaches the GPU
+void *pinned_alloc(size_t bytes);
+void pinned_free(void *p);
+bool is_library_pinned(const void *p, size_t bytes);
+template <class T> struct PinnedAllocator
+{
+	typedef T value_type;
+	PinnedAllocator() {}
+	template <class U> PinnedAllocator(const PinnedAllocator<U> &) {}
+	T *allocate(size_t n) { T *p = static_cast<T *>(pinned_alloc(n * sizeof(T))); if (!p && n) throw std::bad_alloc(); return p; }
+	void deallocate(T *p, size_t) { pinned_free(p); }
+	template <class U> bool operator==(const PinnedAllocator<U> &) const { return true; }
+	template <class U> bool operator!=(const PinnedAllocator<U> &) const { return false; }
+};
+// a particle array of the host mirror (pbdx_model): std::vector<float> in page-locked memory of the library
+typedef std::vector<float, PinnedAllocator<float>> ParticleArray;
 }
 
 struct pbdx_model
 {
 	// ParticleData (Simulation/ParticleData.h:91-100), packed xyz
-	std::vector<float> mass, inv_mass;
-	std::vector<float> x0, x, v, a, old_x, last_x;
+	// (page-locked memory of the library where a HIP device exists: a step's transfers go straight from / into these arrays, pbdx_hostio.hip)
+	pbdx::ParticleArray mass, inv_mass;
+	pbdx::ParticleArray x0, x, v, a, old_x, last_x;
 	std::vector<pbdx::TriMesh> tri_models;
 	std::vector<pbdx::TetMesh> tet_models;
 	std::vector<pbdx::HostConstraint> constraints;

@@ -35,17 +35,17 @@ template <class T> inline void grow_for(std::vector<T> &v, size_t extra)
 	if (need > v.capacity()) v.reserve(need > 2 * v.capacity() ? need : 2 * v.capacity());
 }
 
-inline V3 ld(const std::vector<float> &a, uint32_t i) { return mk(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
-inline void st(std::vector<float> &a, uint32_t i, V3 v) { a[3 * i] = v.x; a[3 * i + 1] = v.y; a[3 * i + 2] = v.z; }
+template <class A> inline V3 ld(const A &a, uint32_t i) { return mk(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+template <class A> inline void st(A &a, uint32_t i, V3 v) { a[3 * i] = v.x; a[3 * i + 1] = v.y; a[3 * i + 2] = v.z; }
 
 uint32_t add_vertex(pbdx_model *m, V3 p)
 {
 	// ParticleData::addVertex  ParticleData.h:128-138
-	for (std::vector<float> *arr : { &m->x0, &m->x, &m->old_x, &m->last_x })
+	for (ParticleArray *arr : { &m->x0, &m->x, &m->old_x, &m->last_x })
 	{
 		arr->push_back(p.x); arr->push_back(p.y); arr->push_back(p.z);
 	}
-	for (std::vector<float> *arr : { &m->v, &m->a })
+	for (ParticleArray *arr : { &m->v, &m->a })
 	{
 		arr->push_back(0.0f); arr->push_back(0.0f); arr->push_back(0.0f);
 	}
@@ -486,7 +486,7 @@ int pbdx_model_add_instances(pbdx_model *m, uint32_t count, const float *offsets
 	if ((uint64_t)np * (count + 1) > 0xffffffffull || (uint64_t)m->constraints.size() * (count + 1) > 0xffffffffull)
 	{ set_error("add_instances: more than 2^32 particles or constraints"); return PBDX_ERR_INVALID; }
 	const uint32_t K = count + 1;
-	std::vector<float> x0((size_t)3 * np * K);
+	ParticleArray x0((size_t)3 * np * K);
 	memcpy(x0.data(), m->x0.data(), (size_t)3 * np * sizeof(float));
 	for (uint32_t k = 1; k < K; k++)
 	{
@@ -512,13 +512,13 @@ int pbdx_model_add_instances(pbdx_model *m, uint32_t count, const float *offsets
 			}
 	}
 	// commit: particle state of the copies = their rest state; masses as the prototype's
-	std::vector<float> mass((size_t)np * K), inv((size_t)np * K);
+	ParticleArray mass((size_t)np * K), inv((size_t)np * K);
 	for (uint32_t k = 0; k < K; k++)
 	{
 		memcpy(mass.data() + (size_t)np * k, m->mass.data(), (size_t)np * sizeof(float));
 		memcpy(inv.data() + (size_t)np * k, m->inv_mass.data(), (size_t)np * sizeof(float));
 	}
-	auto extend = [&](std::vector<float> &a, bool zero)
+	auto extend = [&](ParticleArray &a, bool zero)
 	{
 		a.resize((size_t)3 * np * K, 0.0f);
 		if (!zero) memcpy(a.data() + (size_t)3 * np, x0.data() + (size_t)3 * np, (size_t)3 * np * (K - 1) * sizeof(float));
@@ -583,7 +583,7 @@ int pbdx_model_set_mass(pbdx_model *m, uint32_t i, float mass)
 	return PBDX_OK;
 }
 
-static std::vector<float> *model_array(pbdx_model *m, int which)
+static ParticleArray *model_array(pbdx_model *m, int which)
 {
 	switch (which)
 	{
@@ -596,7 +596,7 @@ static std::vector<float> *model_array(pbdx_model *m, int which)
 int pbdx_model_get_array(const pbdx_model *m, int which, float *out)
 {
 	if (!m || !out) return PBDX_ERR_INVALID;
-	const std::vector<float> *a = model_array(const_cast<pbdx_model*>(m), which);
+	const ParticleArray *a = model_array(const_cast<pbdx_model*>(m), which);
 	if (!a) { set_error("get_array: bad selector %d", which); return PBDX_ERR_INVALID; }
 	memcpy(out, a->data(), a->size() * sizeof(float));
 	return PBDX_OK;
@@ -611,7 +611,7 @@ int pbdx_model_set_array(pbdx_model *m, int which, const float *in)
 		m->params_version++;
 		return PBDX_OK;
 	}
-	std::vector<float> *a = model_array(m, which);
+	ParticleArray *a = model_array(m, which);
 	if (!a || which == 7) { set_error("set_array: bad selector %d", which); return PBDX_ERR_INVALID; }
 	memcpy(a->data(), in, a->size() * sizeof(float));
 	m->state_version++;

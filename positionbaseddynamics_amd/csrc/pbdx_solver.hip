@@ -2935,6 +2935,8 @@ int set_particles_impl(pbdx_solver *s, uint32_t n, const T *x, const T *v, const
 		for (auto &j : jobs)
 		{
 			if (!j.src) continue;
+			// the library's own page-locked memory (pbdx_model's arrays): straight onto the bus, no host-side copy at all
+			if (pbdx::is_library_pinned(j.src, j.bytes)) { HIPCHECK(pbdx::copy_pinned_to_device_async(j.dst, j.src, j.bytes, s->stream)); continue; }
 			if (!mir) { HIPCHECK(pbdx::copy_to_device(j.dst, j.src, j.bytes)); continue; }       // (the library's bounce buffer)
 			char *slot = mir + (reinterpret_cast<char *>(j.dst) - reinterpret_cast<char *>(s->d_stage));
 			host_copy(slot, j.src, j.bytes);
@@ -2970,6 +2972,7 @@ int get_particles_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, T *last
 	struct { T *dst; const float4 *src; } jobs[4] = { { x, s->d_pos[0] }, { v, s->d_vel }, { old_x, s->d_old }, { last_x, s->d_last } };
 	const size_t b3 = (size_t)3 * n * sizeof(T);
 	char *mir = s->mirror((size_t)14 * n * sizeof(T));
+	bool direct[4] = { false, false, false, false };
 	int k = 0;
 	for (auto &j : jobs)
 	{
@@ -2978,6 +2981,7 @@ int get_particles_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, T *last
 		if (!j.dst) continue;
 		hipLaunchKernelGGL(unpack_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s->stream, j.src, st, n);
 		HIPCHECK(hipGetLastError());
+		if (pbdx::is_library_pinned(j.dst, b3)) { HIPCHECK(pbdx::copy_device_to_pinned_async(j.dst, st, b3, s->stream)); direct[q] = true; continue; }      // (the library's own page-locked memory)
 		if (!mir) { HIPCHECK(pbdx::copy_from_device(j.dst, st, b3)); continue; }       // (waits for the kernel; the library's bounce buffer)
 		HIPCHECK(hipMemcpyAsync(mir + b3 * q, st, b3, hipMemcpyDeviceToHost, s->stream));
 		HIPCHECK(hipEventRecord(s->mirror_ev[q], s->stream));
@@ -2989,7 +2993,7 @@ int get_particles_impl(pbdx_solver *s, uint32_t n, T *x, T *v, T *old_x, T *last
 		for (auto &j : jobs)
 		{
 			const int q = k++;
-			if (!j.dst) continue;
+			if (!j.dst || direct[q]) continue;
 			HIPCHECK(hipEventSynchronize(s->mirror_ev[q]));
 			host_copy(j.dst, mir + b3 * q, b3);
 		}
