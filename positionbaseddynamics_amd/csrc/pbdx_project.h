@@ -396,6 +396,60 @@ PBDX_HD bool solve_strain_triangle(V3 p0, float w0, V3 p1, float w1, V3 p2, floa
 // ---------------------------------------------------------------------------
 // 3x3 Jacobi eigen decomposition + SVD with inversion handling
 // MathFunctions.cpp:11-75, 261-388 (only reached by crushed / inverted tets)
+// The two double expressions of a Jacobi rotation, narrowed to float (see jacobi_rotate).  On the device the correctly rounded double square root and
+// division are what a crushed tet's colour step WAITS for: ten sequential rotations, each a chain of two sqrt and two divisions of ~15 and ~11 dependent
+// double instructions (the 100 k-tet bar's late state: 2.07 ms per substep against 0.58, profiles/HISTORY.md [9], [10]).  Only the FLOAT the expression
+// is narrowed to matters, so the device takes a short way -- v_rsq_f64 / v_rcp_f64 and two Newton steps, good to a few units of the 52nd bit -- and
+// PROVES that the narrowing cannot tell: if the value shrunk and the value grown by 2^-44 round to the same float, every double in between does
+// (rounding is monotonic), in particular the one the reference computes with its three correctly rounded operations; otherwise (one case in a million,
+// and for non-finite inputs) the expression is evaluated as written.  Bit-identical by construction; the host always evaluates as written.
+#ifndef PBDX_FAST_NARROW
+#define PBDX_FAST_NARROW 1
+#endif
+#ifndef PBDX_UNIFORM_JACOBI
+#define PBDX_UNIFORM_JACOBI 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && PBDX_FAST_NARROW
+__device__ __forceinline__ double pbdx_rsqrt_refined(double x)
+{
+	double r = __builtin_amdgcn_rsq(x);
+	const double h = 0.5 * x;
+#pragma unroll
+	for (int k = 0; k < 2; k++) { const double e = __builtin_fma(-(h * r), r, 0.5); r = __builtin_fma(r, e, r); }
+	return r;
+}
+__device__ __forceinline__ bool pbdx_narrow_is_certain(double v, float &out)
+{
+	const float lo = (float)(v * (1.0 - 0x1p-44)), hi = (float)(v * (1.0 + 0x1p-44));
+	out = lo;
+	return lo == hi;      // (false for NaN)
+}
+// (float)(1.0 / (fabs((double)d) + sqrt((double)x)))
+__device__ __forceinline__ float narrowed_recip_abs_plus_sqrt(float d, float x)
+{
+	const double X = (double)x;
+	const double sq = X * pbdx_rsqrt_refined(X);
+	const double den = fabs((double)d) + sq;
+	double r = __builtin_amdgcn_rcp(den);
+#pragma unroll
+	for (int k = 0; k < 2; k++) { const double e = __builtin_fma(-den, r, 1.0); r = __builtin_fma(r, e, r); }
+	float out;
+	if (__builtin_expect(pbdx_narrow_is_certain(r, out), 1)) return out;
+	return (float)(1.0 / (fabs((double)d) + sqrt(X)));
+}
+// (float)(1.0 / sqrt((double)y))
+__device__ __forceinline__ float narrowed_rsqrt(float y)
+{
+	const double Y = (double)y;
+	float out;
+	if (__builtin_expect(pbdx_narrow_is_certain(pbdx_rsqrt_refined(Y), out), 1)) return out;
+	return (float)(1.0 / sqrt(Y));
+}
+#else
+PBDX_HD float narrowed_recip_abs_plus_sqrt(float d, float x) { return (float)(1.0 / (fabs((double)d) + sqrt((double)x))); }
+PBDX_HD float narrowed_rsqrt(float y) { return (float)(1.0 / sqrt((double)y)); }
+#endif
+
 PBDX_HD void jacobi_rotate(M3 &A, M3 &R, int p, int q)
 {
 	if (A.m[p][q] == 0.0f)
@@ -403,9 +457,9 @@ PBDX_HD void jacobi_rotate(M3 &A, M3 &R, int p, int q)
 	const float d = (A.m[p][p] - A.m[q][q]) / (2.0f * A.m[p][q]);
 	// ::fabs / ::sqrt are the double functions in MathFunctions.cpp (:18,:20): the sum and the quotient
 	// are double expressions narrowed to Real on assignment
-	float t = (float)(1.0 / (fabs((double)d) + sqrt((double)(d * d + 1.0f))));
+	float t = narrowed_recip_abs_plus_sqrt(d, d * d + 1.0f);
 	if (d < 0.0f) t = -t;
-	const float c = (float)(1.0 / sqrt((double)(t * t + 1.0f)));
+	const float c = narrowed_rsqrt(t * t + 1.0f);
 	const float s = t * c;
 	A.m[p][p] += t * A.m[p][q];
 	A.m[q][q] -= t * A.m[p][q];
@@ -429,8 +483,67 @@ PBDX_HD void jacobi_rotate(M3 &A, M3 &R, int p, int q)
 	}
 }
 
+// Device form of eigen_decomposition: ONE rotation body for all three pivots.  The lanes of a wave choose their pivots independently, so with the three
+// statically dispatched bodies below a wave in which the pivots differ executes up to three rotations per iteration, one after the other -- and a
+// rotation is a long dependent chain (a float division, two narrowed double expressions).  Here the pivot only SELECTS which of the six entries of the
+// symmetric matrix and which two columns of the vectors take part (v_cndmask); the arithmetic is jacobi_rotate's, operation for operation
+// (MathFunctions.cpp:11-43: the symmetric twin of every entry is written with the same value there, so six entries carry the matrix).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void eigen_decomposition_uniform(const M3 &A, M3 &vecs, float vals[3])
+{
+	const float epsilon = 1e-15f;
+	float d0 = A.m[0][0], d1 = A.m[1][1], d2 = A.m[2][2], o01 = A.m[0][1], o02 = A.m[0][2], o12 = A.m[1][2];
+	// (the reference reads D(0,1), D(0,2), D(1,2) for the pivot search and A(k,p) / A(k,q) with k the remaining index in the rotation: for a matrix whose
+	// twins are equal -- A^T A as mul() builds it is not bitwise symmetric in general, so the LOWER entries the rotation reads are carried as well)
+	float l10 = A.m[1][0], l20 = A.m[2][0], l21 = A.m[2][1];
+	float r00 = 1.0f, r01 = 0.0f, r02 = 0.0f, r10 = 0.0f, r11 = 1.0f, r12 = 0.0f, r20 = 0.0f, r21 = 0.0f, r22 = 1.0f;
+	for (int iter = 0; iter < 10; iter++)
+	{
+		int pv = 0;                                   // 0: (p, q) = (0, 1), k = 2;  1: (0, 2), k = 1;  2: (1, 2), k = 0
+		float mx = fabsf(o01);
+		float a = fabsf(o02);
+		if (a > mx) { pv = 1; mx = a; }
+		a = fabsf(o12);
+		if (a > mx) { pv = 2; mx = a; }
+		if (mx < epsilon) break;
+		const float Apq = pv == 0 ? o01 : pv == 1 ? o02 : o12;
+		if (Apq == 0.0f) continue;                    // (jacobi_rotate returns; the iteration still counts)
+		const float App = pv == 2 ? d1 : d0, Aqq = pv == 0 ? d1 : d2;
+		// A(k, p), A(k, q): row k of the full matrix
+		const float Akp = pv == 0 ? l20 : pv == 1 ? l10 : o01;
+		const float Akq = pv == 0 ? l21 : pv == 1 ? o12 : o02;
+		const float d = (App - Aqq) / (2.0f * Apq);
+		float t = narrowed_recip_abs_plus_sqrt(d, d * d + 1.0f);
+		if (d < 0.0f) t = -t;
+		const float c = narrowed_rsqrt(t * t + 1.0f);
+		const float s = t * c;
+		const float nApp = App + t * Apq, nAqq = Aqq - t * Apq;
+		const float nAkp = c * Akp + s * Akq;
+		const float nAkq = -s * Akp + c * Akq;
+		// write back: A(p,p), A(q,q), A(p,q) = A(q,p) = 0, A(k,p) = A(p,k), A(k,q) = A(q,k)
+		if (pv == 0) { d0 = nApp; d1 = nAqq; o01 = 0.0f; l10 = 0.0f; l20 = nAkp; o02 = nAkp; l21 = nAkq; o12 = nAkq; }
+		else if (pv == 1) { d0 = nApp; d2 = nAqq; o02 = 0.0f; l20 = 0.0f; l10 = nAkp; o01 = nAkp; o12 = nAkq; l21 = nAkq; }
+		else { d1 = nApp; d2 = nAqq; o12 = 0.0f; l21 = 0.0f; o01 = nAkp; l10 = nAkp; o02 = nAkq; l20 = nAkq; }
+		// columns p and q of the vectors
+		const float p0 = pv == 2 ? r01 : r00, p1 = pv == 2 ? r11 : r10, p2 = pv == 2 ? r21 : r20;
+		const float q0 = pv == 0 ? r01 : r02, q1 = pv == 0 ? r11 : r12, q2 = pv == 0 ? r21 : r22;
+		const float np0 = c * p0 + s * q0, nq0 = -s * p0 + c * q0;
+		const float np1 = c * p1 + s * q1, nq1 = -s * p1 + c * q1;
+		const float np2 = c * p2 + s * q2, nq2 = -s * p2 + c * q2;
+		if (pv == 2) { r01 = np0; r11 = np1; r21 = np2; } else { r00 = np0; r10 = np1; r20 = np2; }
+		if (pv == 0) { r01 = nq0; r11 = nq1; r21 = nq2; } else { r02 = nq0; r12 = nq1; r22 = nq2; }
+	}
+	vecs.m[0][0] = r00; vecs.m[0][1] = r01; vecs.m[0][2] = r02; vecs.m[1][0] = r10; vecs.m[1][1] = r11; vecs.m[1][2] = r12; vecs.m[2][0] = r20; vecs.m[2][1] = r21; vecs.m[2][2] = r22;
+	vals[0] = d0; vals[1] = d1; vals[2] = d2;
+}
+#endif
+
 PBDX_HD void eigen_decomposition(const M3 &A, M3 &vecs, float vals[3])
 {
+#if defined(__HIP_DEVICE_COMPILE__) && PBDX_UNIFORM_JACOBI
+	eigen_decomposition_uniform(A, vecs, vals);
+	return;
+#endif
 	const float epsilon = 1e-15f;
 	M3 D = A;
 	for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) vecs.m[i][j] = (i == j) ? 1.0f : 0.0f;
