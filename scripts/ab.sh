@@ -40,7 +40,9 @@ import json, sys
 try:
     d = json.loads(sys.stdin.read()); c = d['config']
     segs = json.load(open('/tmp/ab_detail.json'))['config']['plan']['num_segments']
-    print('%-28s [%s] rep $rep: ms/substep %.4f  device median %.4f  passes/sweep %s  %s' % ('$label', '$w', d['ms_per_substep'], c.get('device_median_ms_per_substep') or 0, segs, 'ok' if c['state_ok'] else 'STATE BAD'))
+    sch = c.get('schedule') or {}
+    print('%-28s [%s] rep $rep: ms/substep %.4f  device median %.4f  passes/sweep %s  %s  %s' % ('$label', '$w', d['ms_per_substep'], c.get('device_median_ms_per_substep') or 0, segs,
+        'one launch' if sch.get('persistent') else 'launch per segment' if sch.get('fused') else 'launch per colour', 'ok' if c['state_ok'] else 'STATE BAD'))
 except Exception as e:
     print('%-28s [%s] rep $rep: FAILED %r' % ('$label', '$w', e))"
     done
