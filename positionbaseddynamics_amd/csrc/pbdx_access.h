@@ -13,19 +13,6 @@
 #include "pbdx_plan.h"
 #include "pbdx_project.h"
 #include "pbdx_bounds.h"
-// timing-only knock-outs of one phase of a colour step each (results wrong by construction; profiles/HISTORY.md [10])
-#ifndef PBDX_UB_NO_COMPUTE
-#define PBDX_UB_NO_COMPUTE 0
-#endif
-#ifndef PBDX_UB_NO_SCATTER
-#define PBDX_UB_NO_SCATTER 0
-#endif
-#ifndef PBDX_UB_NO_LDS
-#define PBDX_UB_NO_LDS 0
-#endif
-#ifndef PBDX_UB_NO_LAMBDA
-#define PBDX_UB_NO_LAMBDA 0
-#endif
 #ifndef PBDX_ST96
 #define PBDX_ST96 1
 #endif
@@ -126,9 +113,7 @@ template <int TYPE, bool COMPACT, bool COHERENT = false, bool VEC = false> struc
 	__device__ __forceinline__ void st(uint32_t h, float4 v) const { if (PBDX_BOK(kBndLdsSlot, h, str.dbg_n_local, str.dbg_tile)) pos[h] = v; }
 #else
 	__device__ __forceinline__ float4 ld(uint32_t h) const { return pos[h]; }
-#if PBDX_UB_NO_SCATTER
-	__device__ __forceinline__ void st(uint32_t h, float4 v) const { asm volatile("" :: "v"(h), "v"(v.x), "v"(v.y), "v"(v.z)); }      // timing-only knock-out: the value is computed, not stored
-#elif PBDX_ST96
+#if PBDX_ST96
 	// (A/B build: the inverse mass of a slot never changes -- a 12-byte store moves one dword less from the SIMD to the LDS, MI355X_MICROARCH.md LDS table)
 	__device__ __forceinline__ void st(uint32_t h, float4 v) const
 	{
@@ -184,14 +169,8 @@ template <int TYPE, bool COMPACT, bool COHERENT = false, bool VEC = false> struc
 	// raw dword of the chunk's parameter block at a per-lane byte offset (quad-lane records, pbdx_quad.h: every lane fetches its own planes)
 	__device__ __forceinline__ uint32_t par_raw(uint32_t voff) const { return __builtin_amdgcn_raw_buffer_load_b32(str.par, (int)voff, (int)par_soff, 0); }
 	__device__ __forceinline__ bool sym() const { return COMPACT; }
-#if PBDX_UB_NO_LAMBDA
-	// timing-only knock-out: no multiplier traffic (the value is computed and kept alive, neither loaded nor stored)
-	__device__ __forceinline__ float lam_load(uint32_t i) const { return 0.0f; }
-	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { asm volatile("" :: "v"(v)); }
-#else
 	__device__ __forceinline__ float lam_load(uint32_t i) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(str.lam, (int)(i * 4u), (int)lam_soff, COHERENT ? 16 : 0)); }
 	__device__ __forceinline__ void lam_store(uint32_t i, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), str.lam, (int)(i * 4u), (int)lam_soff, 0); }
-#endif
 };
 
 template <class A> __device__ __forceinline__ void ldp(const A &a, uint32_t h, V3 &p, float &w)
@@ -534,17 +513,6 @@ template <int TYPE, bool COMPACT, class A> __device__ __forceinline__ void load_
 template <int TYPE, bool COMPACT, class A> __device__ __forceinline__ void exec_rec(const A &a, const Rec<TYPE, COMPACT> &r, uint32_t i, float dt, int first_iter)
 {
 	const RecAccess<TYPE, COMPACT, A> ra = { a, r, first_iter };
-#if PBDX_UB_NO_COMPUTE
-	// timing-only knock-out (results wrong by construction): the slot's endpoints are gathered and stored back unchanged, the multiplier is stored back
-#if PBDX_UB_NO_LDS
-	asm volatile("" :: "v"(r.w[0]), "v"(r.w[1]));
-#else
-	if constexpr (kTwoBodies[TYPE]) { const uint2 h = ra.idx2(i); const float4 p0 = a.ld(h.x), p1 = a.ld(h.y); a.st(h.x, p0); a.st(h.y, p1); }
-	else { const uint4 h = ra.idx4(i); const float4 p0 = a.ld(h.x), p1 = a.ld(h.y), p2 = a.ld(h.z), p3 = a.ld(h.w); a.st(h.x, p0); a.st(h.y, p1); a.st(h.z, p2); a.st(h.w, p3); }
-#endif
-	if constexpr (kHasLambda[TYPE]) a.lam_store(i, r.lambda() + r.plane(0));
-	return;
-#endif
 	Project<TYPE, RecAccess<TYPE, COMPACT, A>>::run(ra, i, dt, first_iter);
 }
 

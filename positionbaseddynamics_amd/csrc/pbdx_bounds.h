@@ -16,7 +16,8 @@
 #endif
 enum { kBndGid = 1, kBndParticle = 2, kBndLdsFill = 3, kBndChunk = 4, kBndTable = 5, kBndLdsSlot = 6, kBndTile = 7, kBndDep = 8, kBndTableSrc = 9, kBndChunkRange = 10, kBndLdsIds = 11 };
 #if PBDX_BOUNDS
-__device__ uint32_t g_bounds_rec[8];      // [0] violations, first one: [1] kind, [2] workgroup, [3] thread, [4] index, [5] limit, [6] tile / aux
+static __device__ uint32_t g_bounds_rec[8];      // (one per translation unit; the checks all live in pbdx_sweep.hip, which also reads it out: sweep_bounds_report)
+                                                 // [0] violations, first one: [1] kind, [2] workgroup, [3] thread, [4] index, [5] limit, [6] tile / aux
 __device__ __forceinline__ bool bounds_ok(uint32_t kind, uint32_t index, uint32_t limit, uint32_t aux = 0u)
 {
 	if (index < limit) return true;

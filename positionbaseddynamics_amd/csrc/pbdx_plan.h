@@ -194,7 +194,7 @@ struct FusedChunk
 	// ... and of the chunk whose record the sweep FETCHES while it projects this one: the chunk `ring depth` positions ahead in the run (the run's last
 	// chunk beyond its end).  With them in the descriptor the sweep reads ONE descriptor per sub-iteration, a whole sub-iteration before it is used,
 	// and the record fetch waits for no scalar load (round 5; until then the fetch read a descriptor of its own and waited for it right after the
-	// colour barrier).  The ring depth per type is the kernels' (pbdx_solver.hip Depth<TYPE>); the engine fills these when it expands the steps.
+	// colour barrier).  The ring depth per type is the kernels' (pbdx_sweep.h Depth<TYPE>); the engine fills these when it expands the steps.
 	uint32_t f_idx_boff, f_par_boff, f_lam_boff, pad;
 };
 static_assert(sizeof(FusedChunk) == 32, "one s_load_dwordx8 per chunk descriptor");

@@ -2,7 +2,7 @@
 
 gfx9-family hardware needs five wait states between a VALU write of an SGPR (v_readlane_b32 restoring a spilled scalar, v_readfirstlane_b32) and a
 vector-memory instruction that reads it as scalar base; the compiler cannot see inside the inline assembly of the engine's HBM -> LDS copies and
-write-through stores (csrc/pbdx_solver.hip: lds_dma16, store_pos), which therefore start with `s_nop 4`.  scripts/check_asm_hazards.py disassembles the
+write-through stores (csrc/pbdx_sweep.hip: lds_dma16, store_pos), which therefore start with `s_nop 4`.  scripts/check_asm_hazards.py disassembles the
 gfx950 code objects of every library the suite loads and must find no such site; it must find the site in the listing rocgdb stopped at
 (profiles/r05e_*: the range-checked build before the fix)."""
 import importlib.util
