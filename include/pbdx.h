@@ -308,6 +308,34 @@ int pbdx_solver_set_contact_params(pbdx_solver *s, float tolerance, float contac
  * pbdx_solver_step itself returns PBDX_ERR_UNSUPPORTED for such a call (the reference has no per-particle limit). */
 int pbdx_solver_get_num_contacts(pbdx_solver *s, uint32_t *out);
 
+/* ---- dynamic rigid bodies as impulse sinks (the remainder) ------------------------------------------------
+ * A rigid body of finite mass keeps its state and its time integration on the host (rigid-body dynamics are outside this path:
+ * TimeStepController.cpp:94-104,137-152 stay the host's).  What the engine takes over is the body's part in
+ * ParticleRigidBodyContactConstraint::solveVelocityConstraint (Constraints.cpp:2148-2189): the contact impulses change the body's
+ * velocity and angular velocity, which the next contact of the same body reads.  The contacts of particles that touch a dynamic
+ * body (all their contacts, also the ones with static bodies) are therefore collected into one list in the REFERENCE'S ORDER and
+ * solved sequentially on the device; every other particle keeps its independent chain.  The reference's order
+ * (DistanceFieldCollisionDetection.cpp:34-47,102-177,197-213): collision-object pairs (i, k) lexicographically, and inside a pair the
+ * depth-first, left-to-right walk of object i's point hierarchy, i.e. ascending position in its entity list (kdTree.inl:84-105).
+ * The host hands over that position per particle (`rank`) and the object indices of the ranges and colliders.
+ * Before every step: pbdx_solver_set_colliders with the bodies' poses and velocities at the END of the step's substeps (the host has
+ * integrated them), pbdx_solver_set_collider_dynamics; after the step: pbdx_solver_get_body_velocities = the bodies' velocities after
+ * the contact solve (the host writes them into its bodies, Constraints.cpp:2180-2187).
+ * Not combined with contacts between deformable solids (pbdx_solver_set_tet_colliders): PBDX_ERR_UNSUPPORTED. */
+typedef struct pbdx_collider_dynamics {
+	float inv_mass;                /* RigidBody::getInvMass(); 0: static */
+	float inertia_inv_w[9];        /* RigidBody::getInertiaTensorInverseW(), row-major */
+	uint32_t object_index;         /* position of the body's collision object in CollisionDetection::getCollisionObjects() */
+	uint32_t pad;
+} pbdx_collider_dynamics;
+/* n = number of colliders (same order as pbdx_solver_set_colliders), or 0: every body static again */
+int pbdx_solver_set_collider_dynamics(pbdx_solver *s, uint32_t n, const pbdx_collider_dynamics *dyn);
+/* range_object_index[r]: position of collision range r's object in the collision-object list; rank[i] for every particle i of the
+ * engine (n_particles entries): its position in its collision object's point hierarchy (ignored for particles outside the ranges) */
+int pbdx_solver_set_contact_order(pbdx_solver *s, uint32_t n_ranges, const uint32_t *range_object_index, uint32_t n_particles, const uint32_t *rank);
+/* v, omega: 3 floats per collider */
+int pbdx_solver_get_body_velocities(pbdx_solver *s, uint32_t n, float *v, float *omega);
+
 /* ---- contacts between deformable solids (second half) -----------------------------------------------------
  * Tet models that carry an analytic distance field in their rest frame (DistanceFieldCollisionDetection::addCollisionBox / ...
  * on a TetModelCollisionObjectType body + initTetBVH, DistanceFieldCollisionDetection.cpp:496-509,730-742) colliding with the

@@ -491,6 +491,54 @@ int refdrv_add_static_collider(int shape, const double *pos, const double *quat,
 	return (int)idx;
 }
 
+// A rigid body of FINITE mass (density * volume of `bbox`) with an analytic distance field: the impulse sink of particle contacts
+// (ParticleRigidBodyContactConstraint with a dynamic body, Constraints.cpp:2148-2189).  testMesh = 0: the body's own vertices are not tested against other
+// objects.  Returns the rigid body index.
+int refdrv_add_dynamic_collider(int shape, const double *pos, const double *quat, const double *bbox, const double *p,
+	double density, double restitution, double friction, int testMesh)
+{
+	SimulationModel *m = model();
+	VertexData vd; Utilities::IndexedFaceMesh mesh;
+	cubeMesh(vd, mesh);
+	RigidBody *rb = new RigidBody();
+	rb->initBody(static_cast<Real>(density), v3(pos), Quaternionr((Real)quat[0], (Real)quat[1], (Real)quat[2], (Real)quat[3]), vd, mesh, v3(bbox));
+	rb->setRestitutionCoeff((Real)restitution);
+	rb->setFrictionCoeff((Real)friction);
+	SimulationModel::RigidBodyVector &rbs = m->getRigidBodies();
+	rbs.push_back(rb);
+	const unsigned int idx = (unsigned int)rbs.size() - 1;
+	const std::vector<Vector3r> &verts = rb->getGeometry().getVertexDataLocal().getVertices();
+	const unsigned int nv = (unsigned int)verts.size();
+	const unsigned int T = CollisionDetection::CollisionObject::RigidBodyCollisionObjectType;
+	switch (shape)
+	{
+	case 0: cd().addCollisionBox(idx, T, verts.data(), nv, Vector3r((Real)p[0], (Real)p[1], (Real)p[2]), testMesh != 0, false); break;
+	case 1: cd().addCollisionSphere(idx, T, verts.data(), nv, (Real)p[0], testMesh != 0, false); break;
+	case 2: cd().addCollisionTorus(idx, T, verts.data(), nv, Vector2r((Real)p[0], (Real)p[1]), testMesh != 0, false); break;
+	case 3: cd().addCollisionCylinder(idx, T, verts.data(), nv, Vector2r((Real)p[0], (Real)p[1]), testMesh != 0, false); break;
+	default: return -1;
+	}
+	return (int)idx;
+}
+// state of a rigid body: position (3), rotation quaternion w x y z (4), velocity (3), angular velocity (3), mass (1)
+int refdrv_get_rigid_body_state(unsigned index, double *out)
+{
+	SimulationModel *m = model();
+	if (index >= m->getRigidBodies().size()) return -1;
+	RigidBody *rb = m->getRigidBodies()[index];
+	for (int k = 0; k < 3; k++) { out[k] = (double)rb->getPosition()[k]; out[7 + k] = (double)rb->getVelocity()[k]; out[10 + k] = (double)rb->getAngularVelocity()[k]; }
+	out[3] = (double)rb->getRotation().w(); out[4] = (double)rb->getRotation().x(); out[5] = (double)rb->getRotation().y(); out[6] = (double)rb->getRotation().z();
+	out[13] = (double)rb->getMass();
+	return 0;
+}
+void refdrv_set_rigid_body_velocity(unsigned index, const double *v, const double *omega)
+{
+	SimulationModel *m = model();
+	if (index >= m->getRigidBodies().size()) return;
+	RigidBody *rb = m->getRigidBodies()[index];
+	rb->getVelocity() = v3(v); rb->getAngularVelocity() = v3(omega);
+}
+
 // Register every triangle / tet model as a collision object without geometry (its particles are tested
 // against the colliders) and attach the collision detection to the time step
 // (ClothCollisionDemo.cpp:163-180).

@@ -279,6 +279,24 @@ class Ref:
         return self.lib.refdrv_add_static_collider(self.SHAPES[shape], _dp(a[0]), _dp(a[1]), _dp(a[2]), _dp(a[3]),
                                                    float(restitution), float(friction), int(bool(invert)))
 
+    def add_dynamic_collider(self, shape, pos, quat, bbox, params, density=100.0, restitution=0.6, friction=0.2, test_mesh=False):
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (pos, quat, bbox, list(params) + [0.0] * (4 - len(params)))]
+        self.lib.refdrv_add_dynamic_collider.argtypes = [_i, _pd, _pd, _pd, _pd, _d, _d, _d, _i]
+        return self.lib.refdrv_add_dynamic_collider(self.SHAPES[shape], _dp(a[0]), _dp(a[1]), _dp(a[2]), _dp(a[3]), float(density),
+                                                    float(restitution), float(friction), int(bool(test_mesh)))
+
+    def rigid_body_state(self, index):
+        """position (3), rotation w x y z (4), velocity (3), angular velocity (3), mass."""
+        out = np.zeros(14, dtype=np.float64)
+        self.lib.refdrv_get_rigid_body_state.argtypes = [_u, _pd]
+        assert self.lib.refdrv_get_rigid_body_state(int(index), _dp(out)) == 0
+        return out
+
+    def set_rigid_body_velocity(self, index, v, omega=(0, 0, 0)):
+        a = [np.ascontiguousarray(q, dtype=np.float64) for q in (v, omega)]
+        self.lib.refdrv_set_rigid_body_velocity.argtypes = [_u, _pd, _pd]
+        self.lib.refdrv_set_rigid_body_velocity(int(index), _dp(a[0]), _dp(a[1]))
+
     def enable_collisions(self, tolerance=0.05, restitution=0.6, friction=0.1):
         self.lib.refdrv_enable_collisions(float(tolerance), float(restitution), float(friction))
 

@@ -793,6 +793,28 @@ class Solver:
             k.body_index = int(c.get("body_index", i))
         check(lib.pbdx_solver_set_colliders(self._h, len(colliders), arr), "set_colliders")
 
+    def set_collider_dynamics(self, dynamics):
+        """dynamics: per collider (inv_mass, inertia_inv_w 3x3, object_index), or [] (every body static): pbdx_solver_set_collider_dynamics."""
+        arr = (_ffi.ColliderDynamics * max(len(dynamics), 1))()
+        for i, (inv_mass, ji, obj) in enumerate(dynamics):
+            arr[i].inv_mass = float(inv_mass)
+            vals = np.asarray(ji, dtype=np.float32).reshape(-1)
+            for j in range(9):
+                arr[i].inertia_inv_w[j] = vals[j]
+            arr[i].object_index = int(obj)
+        check(lib.pbdx_solver_set_collider_dynamics(self._h, len(dynamics), arr), "set_collider_dynamics")
+
+    def set_contact_order(self, range_object_index, rank):
+        ro = np.ascontiguousarray(range_object_index, dtype=np.uint32)
+        rk = np.ascontiguousarray(rank, dtype=np.uint32)
+        check(lib.pbdx_solver_set_contact_order(self._h, len(ro), _u(ro), len(rk), _u(rk)), "set_contact_order")
+
+    def get_body_velocities(self, n):
+        v = np.zeros((n, 3), dtype=np.float32)
+        w = np.zeros((n, 3), dtype=np.float32)
+        check(lib.pbdx_solver_get_body_velocities(self._h, n, _f(v), _f(w)), "get_body_velocities")
+        return v, w
+
     def set_collision_ranges(self, ranges):
         """ranges: list of (first, count, restitution, friction)."""
         arr = (_ffi.CollisionRange * max(len(ranges), 1))()

@@ -38,6 +38,10 @@ class Collider(C.Structure):
                 ("body_v", C.c_float * 3), ("body_omega", C.c_float * 3), ("body_index", C.c_uint32)]
 
 
+class ColliderDynamics(C.Structure):
+    _fields_ = [("inv_mass", C.c_float), ("inertia_inv_w", C.c_float * 9), ("object_index", C.c_uint32), ("pad", C.c_uint32)]
+
+
 class CollisionRange(C.Structure):
     _fields_ = [("first", C.c_uint32), ("count", C.c_uint32), ("restitution", C.c_float), ("friction", C.c_float)]
 
@@ -121,6 +125,9 @@ SIGNATURES = [
     ("pbdx_solver_set_collision_ranges", C.c_int, vp, u32, C.POINTER(CollisionRange)),
     ("pbdx_solver_set_contact_params", C.c_int, vp, f32, f32, u32),
     ("pbdx_solver_get_num_contacts", C.c_int, vp, C.POINTER(u32)),
+    ("pbdx_solver_set_collider_dynamics", C.c_int, vp, u32, C.POINTER(ColliderDynamics)),
+    ("pbdx_solver_set_contact_order", C.c_int, vp, u32, C.POINTER(u32), u32, C.POINTER(u32)),
+    ("pbdx_solver_get_body_velocities", C.c_int, vp, u32, pf, pf),
     ("pbdx_debug_stream", C.c_int, C.c_int, C.c_uint64, C.c_int),
     ("pbdx_debug_bounds_report", C.c_int, C.c_int, C.POINTER(u32), C.c_int),
     ("pbdx_debug_copy_bandwidth", C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double)),

@@ -10,9 +10,12 @@
 //   PositionBasedRigidBodyDynamics::init_ParticleRigidBodyContactConstraint   PositionBasedRigidBodyDynamics.cpp:2385-2452
 //   PositionBasedRigidBodyDynamics::velocitySolve_ParticleRigidBodyContactConstraint  :2455-2539
 //   ParticleRigidBodyContactConstraint::solveVelocityConstraint       Constraints.cpp:2148-2189
-// Only static bodies (inverse mass 0) are handled: a contact then changes nothing but its own
-// particle's velocity, so the reference's sequential sweep over the contact list decomposes into
-// independent per-particle chains (contacts of one particle keep their order = collider order).
+// With static bodies (inverse mass 0) a contact changes nothing but its own particle's velocity, so the reference's
+// sequential sweep over the contact list decomposes into independent per-particle chains (contacts of one particle keep
+// their order = collider order): particle_contacts().  A contact with a DYNAMIC body also changes the body's velocity and
+// angular velocity, which the next contact of that body reads: those contacts (and every other contact of their particles)
+// are collected into ONE list in the reference's order and solved sequentially (dyn_contact_* below, dyn_contact_solve_kernel
+// in pbdx_solver.hip); the body's own time integration stays with the host (rigid-body dynamics are outside the path).
 #ifndef PBDX_CONTACT_H
 #define PBDX_CONTACT_H
 
@@ -224,16 +227,11 @@ PBDX_HD bool contact_velocity_solve(float invMass0, V3 v0, float stiffness, Cont
 
 #define PBDX_MAX_CONTACTS_PER_PARTICLE 8
 
-// All contacts of ONE particle: detection against the colliders in order, contact initialisation with
-// the pre-solve velocity, `iterations` velocity sweeps.  Returns the number of contacts (or -1 on overflow).
-// `extra.after_sweep(v)`: what else changes this particle's velocity at the end of every iteration of velocityConstraintProjection
-// (TimeStepController.cpp:342-355: after the particle-rigid-body contacts come the particle-tet contacts, whose impulses are constants).
-struct NoExtraImpulses { PBDX_HD void after_sweep(V3 &) const {} };
-template <class Extra>
-PBDX_HD int particle_contacts(V3 x, V3 &v, float invMass, float mass, const pbdx_collider *colliders, uint32_t num_colliders,
-	float tolerance, float stiffness, float model_restitution, float model_friction, uint32_t iterations, const Extra &extra)
+// Detection of ONE particle against the colliders in order (collisionDetectionRBSolid's leaf test, DistanceFieldCollisionDetection.cpp:334-356).
+// Returns the number of contacts (or -1 on overflow).
+struct RawContact { uint32_t collider; V3 cp_w, n_w; };
+PBDX_HD int detect_particle_contacts(V3 x, const pbdx_collider *colliders, uint32_t num_colliders, float tolerance, RawContact *out)
 {
-	ContactInfo ci[PBDX_MAX_CONTACTS_PER_PARTICLE];
 	int nc = 0;
 	for (uint32_t k = 0; k < num_colliders; k++)
 	{
@@ -245,12 +243,118 @@ PBDX_HD int particle_contacts(V3 x, V3 &v, float invMass, float mass, const pbdx
 			continue;
 		if (nc >= PBDX_MAX_CONTACTS_PER_PARTICLE)
 			return -1;
-		const V3 cp_w = mul_Rt(c.R, cp) + mk(c.v2[0], c.v2[1], c.v2[2]);
-		const V3 n_w = mul_Rt(c.R, n);
-		contact_init(invMass, v, com, mk(c.body_v[0], c.body_v[1], c.body_v[2]), mk(c.body_omega[0], c.body_omega[1], c.body_omega[2]),
-			x, cp_w, n_w, model_restitution * c.restitution, ci[nc]);
-		ci[nc].friction = model_friction + c.friction;
+		out[nc].collider = k;
+		out[nc].cp_w = mul_Rt(c.R, cp) + mk(c.v2[0], c.v2[1], c.v2[2]);
+		out[nc].n_w = mul_Rt(c.R, n);
 		nc++;
+	}
+	return nc;
+}
+
+// ---- contacts with dynamic bodies ---------------------------------------------------------------------------------------
+// PositionBasedRigidBodyDynamics::computeMatrixK (one connector)   PositionBasedRigidBodyDynamics.cpp:11-45
+PBDX_HD void compute_matrix_k(V3 connector, float invMass, V3 x, const float *Ji /* inertiaInverseW, row-major */, float K[3][3])
+{
+	if (invMass != 0.0f)
+	{
+		const V3 v = connector - x;
+		const float a = v.x, b = v.y, c = v.z;
+		const float j11 = Ji[0], j12 = Ji[1], j13 = Ji[2], j22 = Ji[4], j23 = Ji[5], j33 = Ji[8];
+		K[0][0] = c * c * j22 - b * c * (j23 + j23) + b * b * j33 + invMass;
+		K[0][1] = -(c * c * j12) + a * c * j23 + b * c * j13 - a * b * j33;
+		K[0][2] = b * c * j12 - a * c * j22 - b * b * j13 + a * b * j23;
+		K[1][0] = K[0][1];
+		K[1][1] = c * c * j11 - a * c * (j13 + j13) + a * a * j33 + invMass;
+		K[1][2] = -(b * c * j11) + a * c * j12 + a * b * j13 - a * a * j23;
+		K[2][0] = K[0][2];
+		K[2][1] = K[1][2];
+		K[2][2] = b * b * j11 - a * b * (j12 + j12) + a * a * j22 + invMass;
+	}
+	else
+		for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) K[i][j] = 0.0f;
+}
+// init_ParticleRigidBodyContactConstraint for any body (:2385-2452): the constants of a contact.  For invMass1 == 0 the same values as contact_init.
+struct DynContactInfo { V3 cp0, cp1, normal, tangent; float nKn_inv, pMax, goal; };
+PBDX_HD void dyn_contact_init(float invMass0, V3 v0, float invMass1, V3 x1, V3 v1, const float *Ji, V3 omega1, V3 cp0, V3 cp1, V3 normal, float restitution, DynContactInfo &ci)
+{
+	const V3 r1 = cp1 - x1;
+	const V3 u1 = v1 + cross(omega1, r1);
+	const V3 u_rel = v0 - u1;
+	const float u_rel_n = dot(normal, u_rel);
+	ci.cp0 = cp0; ci.cp1 = cp1; ci.normal = normal;
+	V3 t = u_rel - u_rel_n * normal;
+	const float tl2 = sqn(t);
+	if ((double)tl2 > 1.0e-6)
+		t = t * (1.0f / sqrtf(tl2));
+	ci.tangent = t;
+	float K[3][3];
+	compute_matrix_k(cp1, invMass1, x1, Ji, K);
+	if (invMass0 != 0.0f) { K[0][0] += invMass0; K[1][1] += invMass0; K[2][2] += invMass0; }
+	const V3 Kn = mk(K[0][0] * normal.x + (K[0][1] * normal.y + K[0][2] * normal.z), K[1][0] * normal.x + (K[1][1] * normal.y + K[1][2] * normal.z),
+		K[2][0] * normal.x + (K[2][1] * normal.y + K[2][2] * normal.z));
+	ci.nKn_inv = 1.0f / dot(normal, Kn);
+	const V3 Kt = mk(K[0][0] * t.x + (K[0][1] * t.y + K[0][2] * t.z), K[1][0] * t.x + (K[1][1] * t.y + K[1][2] * t.z),
+		K[2][0] * t.x + (K[2][1] * t.y + K[2][2] * t.z));
+	ci.pMax = 1.0f / dot(t, Kt) * dot(u_rel, t);
+	ci.goal = 0.0f;
+	if (u_rel_n < 0.0f)
+		ci.goal = -restitution * u_rel_n;
+}
+// velocitySolve_ParticleRigidBodyContactConstraint (:2455-2539) + ParticleRigidBodyContactConstraint::solveVelocityConstraint (Constraints.cpp:2148-2189):
+// the impulse of one contact against the CURRENT velocities; v0 (if mass0 != 0) and the body's v1 / omega1 (if invMass1 != 0) are updated in place
+PBDX_HD void dyn_contact_velocity_solve(float invMass0, float mass0, V3 &v0, float invMass1, V3 x1, V3 &v1, const float *Ji, V3 &omega1, float stiffness, float friction,
+	float &sum_impulses, const DynContactInfo &ci)
+{
+	if (invMass0 == 0.0f && invMass1 == 0.0f)
+		return;
+	const float d = dot(ci.normal, ci.cp0 - ci.cp1);
+	const V3 r1 = ci.cp1 - x1;
+	const V3 u1 = v1 + cross(omega1, r1);
+	const V3 u_rel = v0 - u1;
+	const float u_rel_n = dot(u_rel, ci.normal);
+	const float delta_u_reln = ci.goal - u_rel_n;
+	float correctionMagnitude = ci.nKn_inv * delta_u_reln;
+	if (correctionMagnitude < -sum_impulses)
+		correctionMagnitude = -sum_impulses;
+	if (d < 0.0f)
+		correctionMagnitude -= stiffness * ci.nKn_inv * d;
+	V3 p = correctionMagnitude * ci.normal;
+	sum_impulses += correctionMagnitude;
+	const float pn = dot(p, ci.normal);
+	if (friction * pn > ci.pMax)
+		p = p - ci.pMax * ci.tangent;
+	else if (friction * pn < -ci.pMax)
+		p = p + ci.pMax * ci.tangent;
+	else
+		p = p - (friction * pn) * ci.tangent;
+	if (invMass0 != 0.0f && mass0 != 0.0f)
+		v0 = v0 + invMass0 * p;
+	if (invMass1 != 0.0f)
+	{
+		v1 = v1 + (-invMass1) * p;                    // corr_v1 = -invMass1 * p
+		omega1 = omega1 + mul_R(Ji, cross(r1, -p));   // corr_omega1 = inertiaInverseW1 * (r1 x -p)
+	}
+}
+
+// All contacts of ONE particle: detection against the colliders in order, contact initialisation with
+// the pre-solve velocity, `iterations` velocity sweeps.  Returns the number of contacts (or -1 on overflow).
+// `extra.after_sweep(v)`: what else changes this particle's velocity at the end of every iteration of velocityConstraintProjection
+// (TimeStepController.cpp:342-355: after the particle-rigid-body contacts come the particle-tet contacts, whose impulses are constants).
+struct NoExtraImpulses { PBDX_HD void after_sweep(V3 &) const {} };
+template <class Extra>
+PBDX_HD int particle_contacts(V3 x, V3 &v, float invMass, float mass, const pbdx_collider *colliders, uint32_t num_colliders,
+	float tolerance, float stiffness, float model_restitution, float model_friction, uint32_t iterations, const Extra &extra)
+{
+	ContactInfo ci[PBDX_MAX_CONTACTS_PER_PARTICLE];
+	RawContact raw[PBDX_MAX_CONTACTS_PER_PARTICLE];
+	const int nc = detect_particle_contacts(x, colliders, num_colliders, tolerance, raw);
+	if (nc < 0) return -1;
+	for (int q = 0; q < nc; q++)
+	{
+		const pbdx_collider &c = colliders[raw[q].collider];
+		contact_init(invMass, v, mk(c.com[0], c.com[1], c.com[2]), mk(c.body_v[0], c.body_v[1], c.body_v[2]), mk(c.body_omega[0], c.body_omega[1], c.body_omega[2]),
+			x, raw[q].cp_w, raw[q].n_w, model_restitution * c.restitution, ci[q]);
+		ci[q].friction = model_friction + c.friction;
 	}
 	for (uint32_t it = 0; it < iterations; it++)
 	{

@@ -2,6 +2,15 @@
 #ifndef PBDX_DEVICE_H
 #define PBDX_DEVICE_H
 #include <hip/hip_runtime.h>
+#include <mutex>
+
+// One host thread at a time inside the library per DEVICE (process-wide, re-entrant).  Two engines that share a device and are driven from two host threads
+// -- an ensemble with a device listed more than once, the plug-in's helper thread next to a second controller -- otherwise meet inside the runtime: while one
+// thread captures a substep into a hipGraph, another thread's device-wide synchronisation or null-stream copy is "not permitted when stream is capturing"
+// and poisons the capture (soak of round 6: 8 of 12 runs of the GPU suite lost `test_single_process_ensemble_with_one_device_listed_eight_times` that way,
+// profiles/HISTORY.md [10]).  Engines on different devices do not share a mutex and run concurrently as before; on one device the work of two engines
+// was serialised by the hardware anyway (the persistent launch needs every CU).
+namespace pbdx { std::recursive_mutex &device_mutex(int device); }
 
 namespace {
 // Every entry point runs on ITS solver's device and leaves the calling thread's current HIP device as it found it: a host that
@@ -10,12 +19,14 @@ namespace {
 struct DeviceScope
 {
 	int prev = -1; bool switched = false; hipError_t err = hipSuccess;
-	explicit DeviceScope(int device)
+	std::recursive_mutex &mutex;
+	explicit DeviceScope(int device) : mutex(pbdx::device_mutex(device))
 	{
+		mutex.lock();
 		err = hipGetDevice(&prev);
 		if (err == hipSuccess && prev != device) { err = hipSetDevice(device); switched = (err == hipSuccess); }
 	}
-	~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+	~DeviceScope() { if (switched) (void)hipSetDevice(prev); mutex.unlock(); }
 	DeviceScope(const DeviceScope &) = delete;
 	DeviceScope &operator=(const DeviceScope &) = delete;
 };

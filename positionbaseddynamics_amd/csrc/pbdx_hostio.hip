@@ -143,6 +143,12 @@ hipError_t prepare(Bounce &b)
 
 } // namespace
 
+std::recursive_mutex &device_mutex(int device)
+{
+	static std::recursive_mutex m[kMaxDevices + 1];
+	return m[device >= 0 && device < kMaxDevices ? device : kMaxDevices];
+}
+
 // dst (device) := src (host), complete on return.  Current device.
 hipError_t copy_to_device(void *dst, const void *src, size_t bytes)
 {
@@ -155,15 +161,17 @@ hipError_t copy_to_device(void *dst, const void *src, size_t bytes)
 	std::lock_guard<std::mutex> lock(b.mutex);
 	if ((e = prepare(b)) != hipSuccess) return e;
 	if ((e = hipDeviceSynchronize()) != hipSuccess) return e;          // (what hipMemcpy on the null stream waits for)
+	// (an error in the middle: copies already enqueued still read / write the halves -- they are waited for before the mutex lets the next caller at them)
+	auto fail = [&](hipError_t err) { (void)hipStreamSynchronize(b.stream); return err; };
 	bool busy[2] = { false, false };
 	int i = 0;
 	for (size_t off = 0; off < bytes; off += kHalf, i ^= 1)
 	{
 		const size_t n = std::min(kHalf, bytes - off);
-		if (busy[i] && (e = hipEventSynchronize(b.ev[i])) != hipSuccess) return e;
+		if (busy[i] && (e = hipEventSynchronize(b.ev[i])) != hipSuccess) return fail(e);
 		host_copy(b.buf + kHalf * i, static_cast<const char *>(src) + off, n);
-		if ((e = hipMemcpyAsync(static_cast<char *>(dst) + off, b.buf + kHalf * i, n, hipMemcpyHostToDevice, b.stream)) != hipSuccess) return e;
-		if ((e = hipEventRecord(b.ev[i], b.stream)) != hipSuccess) return e;
+		if ((e = hipMemcpyAsync(static_cast<char *>(dst) + off, b.buf + kHalf * i, n, hipMemcpyHostToDevice, b.stream)) != hipSuccess) return fail(e);
+		if ((e = hipEventRecord(b.ev[i], b.stream)) != hipSuccess) return fail(e);
 		busy[i] = true;
 	}
 	return hipStreamSynchronize(b.stream);
@@ -181,6 +189,7 @@ hipError_t copy_from_device(void *dst, const void *src, size_t bytes)
 	std::lock_guard<std::mutex> lock(b.mutex);
 	if ((e = prepare(b)) != hipSuccess) return e;
 	if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+	auto fail = [&](hipError_t err) { (void)hipStreamSynchronize(b.stream); return err; };
 	// chunk k is on the bus while chunk k - 1 leaves the buffer
 	const size_t chunks = (bytes + kHalf - 1) / kHalf;
 	for (size_t k = 0; k <= chunks; k++)
@@ -188,13 +197,13 @@ hipError_t copy_from_device(void *dst, const void *src, size_t bytes)
 		if (k < chunks)
 		{
 			const size_t off = k * kHalf, n = std::min(kHalf, bytes - off);
-			if ((e = hipMemcpyAsync(b.buf + kHalf * (k & 1), static_cast<const char *>(src) + off, n, hipMemcpyDeviceToHost, b.stream)) != hipSuccess) return e;
-			if ((e = hipEventRecord(b.ev[k & 1], b.stream)) != hipSuccess) return e;
+			if ((e = hipMemcpyAsync(b.buf + kHalf * (k & 1), static_cast<const char *>(src) + off, n, hipMemcpyDeviceToHost, b.stream)) != hipSuccess) return fail(e);
+			if ((e = hipEventRecord(b.ev[k & 1], b.stream)) != hipSuccess) return fail(e);
 		}
 		if (k > 0)
 		{
 			const size_t off = (k - 1) * kHalf, n = std::min(kHalf, bytes - off);
-			if ((e = hipEventSynchronize(b.ev[(k - 1) & 1])) != hipSuccess) return e;
+			if ((e = hipEventSynchronize(b.ev[(k - 1) & 1])) != hipSuccess) return fail(e);
 			host_copy(static_cast<char *>(dst) + off, b.buf + kHalf * ((k - 1) & 1), n);
 		}
 	}

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void set_xyz_kernel(const float *__restrict__ 
 }
 
 // ---- contacts with static colliders: one particle per lane (pbdx_contact.h) -----------------------------
+struct DynContact { uint32_t particle, collider, range, pad; float cp_w[3], n_w[3]; };      // an entry of the sequential list (dynamic bodies)
 struct ContactArgs
 {
 	const float4 *pos;
@@ -197,6 +198,15 @@ struct ContactArgs
 	unsigned int *counters;         // [0] contacts, [1] overflow flag
 	const uint32_t *ctl;            // see integrate_kernel
 	const uint8_t *imp_mark;        // or null: particles whose velocity chain also holds particle-tet contact impulses (run by tet_impulse_kernel)
+	// dynamic bodies (include/pbdx.h: dynamic rigid bodies as impulse sinks) or dyn == null: a particle that touches one hands ALL its contacts to the
+	// sequential list instead of solving them here
+	const pbdx_collider_dynamics *dyn;
+	const uint32_t *rank;           // per particle: position in its collision object's point hierarchy
+	uint32_t pair_base;             // (position of the range among the ranges ordered by object index) * num_colliders
+	const uint8_t *collider_pos;    // per collider: its position among the colliders ordered by object index
+	uint32_t range_index;
+	DynContact *list; uint32_t *list_keys, *list_vals; uint32_t list_cap;
+	unsigned int *list_counters;    // [0] entries, [1] overflow
 };
 __global__ __launch_bounds__(256) void contact_kernel(ContactArgs a)
 {
@@ -208,6 +218,33 @@ __global__ __launch_bounds__(256) void contact_kernel(ContactArgs a)
 	const float4 p = a.pos[i];
 	float4 vv = a.vel[i];
 	V3 v = mk(vv.x, vv.y, vv.z);
+	if (a.dyn)
+	{
+		RawContact raw[PBDX_MAX_CONTACTS_PER_PARTICLE];
+		const int n = detect_particle_contacts(mk(p.x, p.y, p.z), a.colliders, a.num_colliders, a.tolerance, raw);
+		if (n < 0) { atomicExch(&a.counters[1], 1u); return; }
+		bool dynamic = false;
+		for (int q = 0; q < n; q++) if (a.dyn[raw[q].collider].inv_mass != 0.0f) dynamic = true;
+		if (dynamic)
+		{
+			// the reference's place of every contact: pair (range object, collider object) lexicographically, then the particle's place in the
+			// range's point hierarchy (DistanceFieldCollisionDetection.cpp:34-47, kdTree.inl:84-105)
+			atomicAdd(&a.counters[0], (unsigned int)n);
+			const uint32_t at = atomicAdd(&a.list_counters[0], (unsigned int)n);
+			if (at + (uint32_t)n > a.list_cap) { atomicExch(&a.list_counters[1], 1u); return; }
+			for (int q = 0; q < n; q++)
+			{
+				DynContact c;
+				c.particle = i; c.collider = raw[q].collider; c.range = a.range_index; c.pad = 0u;
+				c.cp_w[0] = raw[q].cp_w.x; c.cp_w[1] = raw[q].cp_w.y; c.cp_w[2] = raw[q].cp_w.z;
+				c.n_w[0] = raw[q].n_w.x; c.n_w[1] = raw[q].n_w.y; c.n_w[2] = raw[q].n_w.z;
+				a.list[at + q] = c;
+				a.list_keys[at + q] = ((a.pair_base + a.collider_pos[raw[q].collider]) << 24) | (a.rank[i] & 0xffffffu);
+				a.list_vals[at + q] = at + q;
+			}
+			return;
+		}
+	}
 	const int nc = particle_contacts(mk(p.x, p.y, p.z), v, p.w, vv.w, a.colliders, a.num_colliders, a.tolerance, a.stiffness,
 		a.restitution, a.friction, a.iterations);
 	if (nc < 0) { atomicExch(&a.counters[1], 1u); return; }
@@ -216,6 +253,86 @@ __global__ __launch_bounds__(256) void contact_kernel(ContactArgs a)
 		atomicAdd(&a.counters[0], (unsigned int)nc);
 		a.vel[i] = make_float4(v.x, v.y, v.z, vv.w);
 	}
+}
+
+// The sequential part of the contact velocity solve with dynamic bodies (include/pbdx.h): the list in the reference's order (sorted keys), its contacts
+// initialised in parallel from the pre-solve velocities (ParticleRigidBodyContactConstraint::initConstraint, Constraints.cpp:2115-2146), then ONE lane walks
+// the list `iterations` times (TimeStepController.cpp:342-350) with the bodies' velocities in registers / LDS; the loads of contact j + 1 are issued before
+// contact j is solved (the chain is through the body, not through memory).
+struct DynSolveArgs
+{
+	const float4 *pos; float4 *vel;
+	const pbdx_collider *colliders; const pbdx_collider_dynamics *dyn; uint32_t num_colliders;
+	const pbdx_collision_range *ranges;
+	const DynContact *list; const uint32_t *order;      // order[j] = list entry at place j of the reference's order
+	DynContactInfo *info; float *sum_impulses;
+	const unsigned int *list_counters;
+	float *body;                    // per collider: v (3), omega (3), pad (2): in = the colliders' velocities, out = after the solve
+	float stiffness; uint32_t iterations;
+	const uint32_t *ctl;
+};
+constexpr uint32_t kMaxDynColliders = 32;
+__global__ __launch_bounds__(256) void dyn_contact_solve_kernel(DynSolveArgs a)
+{
+	if (a.ctl && a.ctl[kCtlAbort]) return;
+	__shared__ float s_body[kMaxDynColliders][8];
+	const uint32_t count = a.list_counters[1] ? 0u : a.list_counters[0];
+	for (uint32_t k = threadIdx.x; k < a.num_colliders; k += blockDim.x)
+	{
+		const pbdx_collider &c = a.colliders[k];
+		s_body[k][0] = c.body_v[0]; s_body[k][1] = c.body_v[1]; s_body[k][2] = c.body_v[2];
+		s_body[k][3] = c.body_omega[0]; s_body[k][4] = c.body_omega[1]; s_body[k][5] = c.body_omega[2];
+	}
+	for (uint32_t j = threadIdx.x; j < count; j += blockDim.x)
+	{
+		const DynContact c = a.list[a.order[j]];
+		const pbdx_collider &col = a.colliders[c.collider];
+		const pbdx_collider_dynamics &d = a.dyn[c.collider];
+		const float4 x = a.pos[c.particle], vv = a.vel[c.particle];
+		DynContactInfo ci;
+		dyn_contact_init(x.w, mk(vv.x, vv.y, vv.z), d.inv_mass, mk(col.com[0], col.com[1], col.com[2]), mk(col.body_v[0], col.body_v[1], col.body_v[2]), d.inertia_inv_w,
+			mk(col.body_omega[0], col.body_omega[1], col.body_omega[2]), mk(x.x, x.y, x.z), mk(c.cp_w[0], c.cp_w[1], c.cp_w[2]), mk(c.n_w[0], c.n_w[1], c.n_w[2]),
+			a.ranges[c.range].restitution * col.restitution, ci);
+		a.info[j] = ci;
+		a.sum_impulses[j] = 0.0f;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && count)
+	{
+		for (uint32_t it = 0; it < a.iterations; it++)
+		{
+			DynContact c = a.list[a.order[0]];
+			float4 vv = a.vel[c.particle], x = a.pos[c.particle];
+			DynContactInfo ci = a.info[0];
+			float sum = a.sum_impulses[0];
+			for (uint32_t j = 0; j < count; j++)
+			{
+				// what contact j + 1 needs from memory, requested now (its particle's velocity only if it is another particle: otherwise the value computed below)
+				const uint32_t jn = j + 1u < count ? j + 1u : j;
+				const DynContact cn = a.list[a.order[jn]];
+				const bool same = cn.particle == c.particle;
+				float4 vn = make_float4(0.f, 0.f, 0.f, 0.f), xn = x;
+				if (!same) { vn = a.vel[cn.particle]; xn = a.pos[cn.particle]; }
+				const DynContactInfo cin = a.info[jn];
+				const float sumn = a.sum_impulses[jn];
+				const pbdx_collider &col = a.colliders[c.collider];
+				const pbdx_collider_dynamics &d = a.dyn[c.collider];
+				float *b = s_body[c.collider];
+				V3 v0 = mk(vv.x, vv.y, vv.z), v1 = mk(b[0], b[1], b[2]), w1 = mk(b[3], b[4], b[5]);
+				dyn_contact_velocity_solve(x.w, vv.w, v0, d.inv_mass, mk(col.com[0], col.com[1], col.com[2]), v1, d.inertia_inv_w, w1, a.stiffness,
+					a.ranges[c.range].friction + col.friction, sum, ci);
+				b[0] = v1.x; b[1] = v1.y; b[2] = v1.z; b[3] = w1.x; b[4] = w1.y; b[5] = w1.z;
+				vv = make_float4(v0.x, v0.y, v0.z, vv.w);
+				a.vel[c.particle] = vv;
+				a.sum_impulses[j] = sum;
+				if (!same) vv = vn;
+				x = xn; c = cn; ci = cin; sum = sumn;
+			}
+		}
+	}
+	__syncthreads();
+	for (uint32_t k = threadIdx.x; k < a.num_colliders; k += blockDim.x)
+		for (int q = 0; q < 6; q++) a.body[k * 8u + q] = s_body[k][q];
 }
 
 // ---- contacts between deformable solids (pbdx_tetcontact.h, pbdx_tetcontact_dev.h) -------------------------------------------
@@ -406,6 +523,25 @@ struct pbdx_solver
 	float contact_tolerance = 0.01f, contact_stiffness = 100.0f;
 	uint32_t max_iterations_v = 5;
 	uint64_t contact_version = 0;
+	// ... with dynamic bodies (include/pbdx.h): the sequential list and what orders it
+	std::vector<pbdx_collider_dynamics> dynamics;      // per collider, or empty: every body static
+	std::vector<uint32_t> range_object;                // per range: its object index
+	pbdx_collider_dynamics *d_dynamics = nullptr;
+	uint32_t *d_rank = nullptr; uint32_t rank_count = 0;
+	uint8_t *d_collider_pos = nullptr;
+	DynContact *d_dyn_list = nullptr; uint32_t *d_dyn_keys = nullptr, *d_dyn_keys_sorted = nullptr, *d_dyn_vals = nullptr, *d_dyn_vals_sorted = nullptr;
+	DynContactInfo *d_dyn_info = nullptr; float *d_dyn_sum = nullptr, *d_dyn_body = nullptr;
+	unsigned int *d_dyn_counters = nullptr;
+	void *d_dyn_sort_temp = nullptr; size_t dyn_sort_temp_bytes = 0;
+	uint32_t dyn_cap = 0;
+	bool any_dynamic() const { for (const pbdx_collider_dynamics &d : dynamics) if (d.inv_mass != 0.0f) return true; return false; }
+	void free_dynamic_work()
+	{
+		void *ptrs[] = { d_dyn_list, d_dyn_keys, d_dyn_keys_sorted, d_dyn_vals, d_dyn_vals_sorted, d_dyn_info, d_dyn_sum, d_dyn_sort_temp };
+		for (void *q : ptrs) if (q) (void)hipFree(q);
+		d_dyn_list = nullptr; d_dyn_keys = d_dyn_keys_sorted = d_dyn_vals = d_dyn_vals_sorted = nullptr; d_dyn_info = nullptr; d_dyn_sum = nullptr; d_dyn_sort_temp = nullptr;
+		dyn_cap = 0; dyn_sort_temp_bytes = 0;
+	}
 
 	// contacts between deformable solids (pbdx_tetcontact.h)
 	struct DevBvh { uint32_t *lst = nullptr; int32_t *nodes = nullptr; P4 *hulls = nullptr; uint32_t num_nodes = 0; uint32_t *flat = nullptr; P4 *gathered = nullptr; float *soa = nullptr; };
@@ -1565,6 +1701,37 @@ int enqueue_tet_detection(pbdx_solver *s)
 	return PBDX_OK;
 }
 
+// scratch and order tables of the contact solve with dynamic bodies (include/pbdx.h); range_pos[r] = place of range r among the ranges by object index
+int prepare_dynamic_contacts(pbdx_solver *s, std::vector<uint32_t> &range_pos)
+{
+	const uint32_t nc = (uint32_t)s->colliders.size(), nr = (uint32_t)s->ranges.size();
+	if (s->tet_active()) { set_error("dynamic rigid bodies are not combined with contacts between deformable solids"); return PBDX_ERR_UNSUPPORTED; }
+	if (nc > kMaxDynColliders || (uint64_t)nc * nr > 255u) { set_error("dynamic rigid bodies: at most %u colliders and 255 (range, collider) pairs", kMaxDynColliders); return PBDX_ERR_UNSUPPORTED; }
+	if (s->range_object.size() != nr || s->rank_count != s->n || !s->d_rank) { set_error("dynamic rigid bodies: pbdx_solver_set_contact_order has not been called for these ranges / particles"); return PBDX_ERR_INVALID; }
+	for (uint32_t r = 0; r < nr; r++) { range_pos[r] = 0; for (uint32_t q = 0; q < nr; q++) if (s->range_object[q] < s->range_object[r] || (s->range_object[q] == s->range_object[r] && q < r)) range_pos[r]++; }
+	uint64_t in_ranges = 0;
+	for (const pbdx_collision_range &r : s->ranges) in_ranges += r.count;
+	const uint32_t cap = (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1024u, in_ranges * std::min<uint32_t>(nc, PBDX_MAX_CONTACTS_PER_PARTICLE)));
+	if (cap != s->dyn_cap)
+	{
+		s->free_dynamic_work();
+		HIPCHECK(hipMalloc(&s->d_dyn_list, (size_t)cap * sizeof(DynContact)));
+		HIPCHECK(hipMalloc(&s->d_dyn_keys, (size_t)cap * 4)); HIPCHECK(hipMalloc(&s->d_dyn_keys_sorted, (size_t)cap * 4));
+		HIPCHECK(hipMalloc(&s->d_dyn_vals, (size_t)cap * 4)); HIPCHECK(hipMalloc(&s->d_dyn_vals_sorted, (size_t)cap * 4));
+		HIPCHECK(hipMalloc(&s->d_dyn_info, (size_t)cap * sizeof(DynContactInfo))); HIPCHECK(hipMalloc(&s->d_dyn_sum, (size_t)cap * 4));
+		s->dyn_sort_temp_bytes = 0;
+		{ int rs = sort_pairs_u32(nullptr, &s->dyn_sort_temp_bytes, s->d_dyn_keys, s->d_dyn_keys_sorted, s->d_dyn_vals, s->d_dyn_vals_sorted, cap, s->stream); if (rs) return rs; }
+		HIPCHECK(hipMalloc(&s->d_dyn_sort_temp, std::max<size_t>(s->dyn_sort_temp_bytes, 16)));
+		s->dyn_cap = cap;
+	}
+	if (!s->d_dyn_counters) HIPCHECK(hipMalloc(&s->d_dyn_counters, 2 * sizeof(unsigned int)));
+	if (!s->d_dyn_body) HIPCHECK(hipMalloc(&s->d_dyn_body, (size_t)kMaxDynColliders * 8 * sizeof(float)));
+	HIPCHECK(hipMemsetAsync(s->d_dyn_counters, 0, 2 * sizeof(unsigned int), s->stream));
+	HIPCHECK(hipMemsetAsync(s->d_dyn_keys, 0xff, (size_t)cap * 4, s->stream));
+	HIPCHECK(hipMemsetAsync(s->d_dyn_vals, 0, (size_t)cap * 4, s->stream));
+	return PBDX_OK;
+}
+
 int enqueue_contacts(pbdx_solver *s)
 {
 	{
@@ -1572,6 +1739,13 @@ int enqueue_contacts(pbdx_solver *s)
 		if (rt) return rt;
 	}
 	const bool rigid = !s->colliders.empty() && !s->ranges.empty() && s->n;
+	const bool dynamic = rigid && s->dynamics.size() == s->colliders.size() && s->any_dynamic();
+	std::vector<uint32_t> range_pos(s->ranges.size(), 0u);
+	if (dynamic)
+	{
+		int rd = prepare_dynamic_contacts(s, range_pos);
+		if (rd) return rd;
+	}
 	if (rigid)
 	{
 		HIPCHECK(hipMemsetAsync(s->d_contact_counters, 0, sizeof(unsigned int), s->stream));      // [0] contacts of this step; [1] (overflow) is reset per call
@@ -1579,6 +1753,13 @@ int enqueue_contacts(pbdx_solver *s)
 		{
 			if (!r.count) continue;
 			ContactArgs a;
+			a.dyn = nullptr; a.rank = nullptr; a.pair_base = 0u; a.collider_pos = nullptr; a.range_index = (uint32_t)(&r - s->ranges.data());
+			a.list = nullptr; a.list_keys = a.list_vals = nullptr; a.list_cap = 0u; a.list_counters = nullptr;
+			if (dynamic)
+			{
+				a.dyn = s->d_dynamics; a.rank = s->d_rank; a.pair_base = range_pos[a.range_index] * (uint32_t)s->colliders.size(); a.collider_pos = s->d_collider_pos;
+				a.list = s->d_dyn_list; a.list_keys = s->d_dyn_keys; a.list_vals = s->d_dyn_vals; a.list_cap = s->dyn_cap; a.list_counters = s->d_dyn_counters;
+			}
 			a.pos = s->d_pos[0]; a.vel = s->d_vel; a.colliders = s->d_colliders; a.num_colliders = (uint32_t)s->colliders.size();
 			a.first = r.first; a.count = r.count;
 			a.tolerance = s->contact_tolerance; a.stiffness = s->contact_stiffness; a.restitution = r.restitution; a.friction = r.friction;
@@ -1587,6 +1768,19 @@ int enqueue_contacts(pbdx_solver *s)
 			a.ctl = ctl_of(s, nullptr);
 			a.imp_mark = s->tet_active() ? s->tet_work.imp_mark : nullptr;
 			hipLaunchKernelGGL(contact_kernel, dim3((r.count + 255) / 256), dim3(256), 0, s->stream, a);
+			HIPCHECK(hipGetLastError());
+		}
+		if (dynamic)
+		{
+			// the list in the reference's order (unused places carry the largest key), then the sequential solve
+			size_t tb = s->dyn_sort_temp_bytes;
+			int rs = sort_pairs_u32(s->d_dyn_sort_temp, &tb, s->d_dyn_keys, s->d_dyn_keys_sorted, s->d_dyn_vals, s->d_dyn_vals_sorted, s->dyn_cap, s->stream);
+			if (rs) return rs;
+			DynSolveArgs d;
+			d.pos = s->d_pos[0]; d.vel = s->d_vel; d.colliders = s->d_colliders; d.dyn = s->d_dynamics; d.num_colliders = (uint32_t)s->colliders.size();
+			d.ranges = s->d_ranges; d.list = s->d_dyn_list; d.order = s->d_dyn_vals_sorted; d.info = s->d_dyn_info; d.sum_impulses = s->d_dyn_sum;
+			d.list_counters = s->d_dyn_counters; d.body = s->d_dyn_body; d.stiffness = s->contact_stiffness; d.iterations = s->max_iterations_v; d.ctl = ctl_of(s, nullptr);
+			hipLaunchKernelGGL(dyn_contact_solve_kernel, dim3(1), dim3(256), 0, s->stream, d);
 			HIPCHECK(hipGetLastError());
 		}
 	}
@@ -1931,6 +2125,12 @@ void pbdx_solver_destroy(pbdx_solver *s)
 	s->free_mirror();
 	if (s->d_colliders) (void)hipFree(s->d_colliders);
 	if (s->d_ranges) (void)hipFree(s->d_ranges);
+	s->free_dynamic_work();
+	if (s->d_dynamics) (void)hipFree(s->d_dynamics);
+	if (s->d_rank) (void)hipFree(s->d_rank);
+	if (s->d_collider_pos) (void)hipFree(s->d_collider_pos);
+	if (s->d_dyn_body) (void)hipFree(s->d_dyn_body);
+	if (s->d_dyn_counters) (void)hipFree(s->d_dyn_counters);
 	if (s->d_contact_counters) (void)hipFree(s->d_contact_counters);
 	for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
 	for (hipEvent_t e : s->sub_events) (void)hipEventDestroy(e);
@@ -2468,6 +2668,12 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 			return PBDX_ERR_UNSUPPORTED;
 		}
 	}
+	if (s->d_dyn_counters && s->any_dynamic())
+	{
+		unsigned int c[2] = { 0, 0 };
+		HIPCHECK(hipMemcpy(c, s->d_dyn_counters, sizeof(c), hipMemcpyDeviceToHost));
+		if (c[1]) { set_error("contacts with dynamic rigid bodies: more than %u contacts in the sequential list; their response was skipped", s->dyn_cap); return PBDX_ERR_UNSUPPORTED; }
+	}
 	if (s->d_contact_counters && !s->colliders.empty())
 	{
 		// the reference has no per-particle contact limit: exceeding the engine's is an error, not a silent divergence
@@ -2623,11 +2829,12 @@ int pbdx_solver_set_colliders(pbdx_solver *s, uint32_t n, const pbdx_collider *c
 		if (colliders[i].shape < PBDX_SHAPE_BOX || colliders[i].shape > PBDX_SHAPE_HOLLOW_BOX) { set_error("set_colliders: unknown shape %d", colliders[i].shape); return PBDX_ERR_UNSUPPORTED; }
 	ENTER_DEVICE(s->device);
 	HIPCHECK(hipStreamSynchronize(s->stream));
-	if (s->d_colliders) { (void)hipFree(s->d_colliders); s->d_colliders = nullptr; }
+	// (the same number of colliders again -- a host that moves its bodies every step -- keeps the allocation)
+	if (s->d_colliders && n != s->colliders.size()) { (void)hipFree(s->d_colliders); s->d_colliders = nullptr; }
 	s->colliders.assign(colliders, colliders + n);
 	if (n)
 	{
-		HIPCHECK(hipMalloc(&s->d_colliders, (size_t)n * sizeof(pbdx_collider)));
+		if (!s->d_colliders) HIPCHECK(hipMalloc(&s->d_colliders, (size_t)n * sizeof(pbdx_collider)));
 		HIPCHECK(pbdx::copy_to_device(s->d_colliders, colliders, (size_t)n * sizeof(pbdx_collider)));
 	}
 	if (!s->d_contact_counters)
@@ -2863,6 +3070,60 @@ int pbdx_solver_get_num_contacts(pbdx_solver *s, uint32_t *out)
 	HIPCHECK(hipMemcpy(c, s->d_contact_counters, sizeof(c), hipMemcpyDeviceToHost));
 	*out = c[0];
 	if (c[1]) { set_error("a particle had more than %d simultaneous contacts", PBDX_MAX_CONTACTS_PER_PARTICLE); return PBDX_ERR_INVALID; }
+	return PBDX_OK;
+}
+
+int pbdx_solver_set_collider_dynamics(pbdx_solver *s, uint32_t n, const pbdx_collider_dynamics *dyn)
+{
+	if (!s || (n && !dyn)) { set_error("set_collider_dynamics: null argument"); return PBDX_ERR_INVALID; }
+	if (n && n != s->colliders.size()) { set_error("set_collider_dynamics: %u records for %zu colliders", n, s->colliders.size()); return PBDX_ERR_INVALID; }
+	ENTER_DEVICE(s->device);
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	s->dynamics.assign(dyn, dyn + n);
+	if (s->d_dynamics) { (void)hipFree(s->d_dynamics); s->d_dynamics = nullptr; }
+	if (s->d_collider_pos) { (void)hipFree(s->d_collider_pos); s->d_collider_pos = nullptr; }
+	if (!n) return PBDX_OK;
+	// a collider's place among the colliders ordered by the object index of their bodies
+	std::vector<uint8_t> pos(n, 0);
+	for (uint32_t k = 0; k < n; k++) for (uint32_t q = 0; q < n; q++) if (dyn[q].object_index < dyn[k].object_index || (dyn[q].object_index == dyn[k].object_index && q < k)) pos[k]++;
+	HIPCHECK(hipMalloc(&s->d_dynamics, (size_t)n * sizeof(pbdx_collider_dynamics)));
+	HIPCHECK(pbdx::copy_to_device(s->d_dynamics, dyn, (size_t)n * sizeof(pbdx_collider_dynamics)));
+	HIPCHECK(hipMalloc(&s->d_collider_pos, std::max<size_t>(n, 16)));
+	HIPCHECK(pbdx::copy_to_device(s->d_collider_pos, pos.data(), n));
+	return PBDX_OK;
+}
+
+int pbdx_solver_set_contact_order(pbdx_solver *s, uint32_t n_ranges, const uint32_t *range_object_index, uint32_t n_particles, const uint32_t *rank)
+{
+	if (!s || (n_ranges && !range_object_index) || (n_particles && !rank)) { set_error("set_contact_order: null argument"); return PBDX_ERR_INVALID; }
+	if (n_ranges != s->ranges.size() || n_particles != s->n) { set_error("set_contact_order: %u ranges / %u particles, the engine holds %zu / %u", n_ranges, n_particles, s->ranges.size(), s->n); return PBDX_ERR_INVALID; }
+	ENTER_DEVICE(s->device);
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	s->range_object.assign(range_object_index, range_object_index + n_ranges);
+	if (s->d_rank) { (void)hipFree(s->d_rank); s->d_rank = nullptr; }
+	s->rank_count = 0;
+	if (!n_particles) return PBDX_OK;
+	HIPCHECK(hipMalloc(&s->d_rank, (size_t)n_particles * 4));
+	HIPCHECK(pbdx::copy_to_device(s->d_rank, rank, (size_t)n_particles * 4));
+	s->rank_count = n_particles;
+	return PBDX_OK;
+}
+
+int pbdx_solver_get_body_velocities(pbdx_solver *s, uint32_t n, float *v, float *omega)
+{
+	if (!s || !v || !omega) { set_error("get_body_velocities: null argument"); return PBDX_ERR_INVALID; }
+	if (n != s->colliders.size()) { set_error("get_body_velocities: %u bodies asked for, %zu colliders", n, s->colliders.size()); return PBDX_ERR_INVALID; }
+	ENTER_DEVICE(s->device);
+	HIPCHECK(hipStreamSynchronize(s->stream));
+	std::vector<float> b((size_t)kMaxDynColliders * 8, 0.0f);
+	const bool solved = s->d_dyn_body && s->dynamics.size() == s->colliders.size() && s->any_dynamic();
+	if (solved) HIPCHECK(pbdx::copy_from_device(b.data(), s->d_dyn_body, b.size() * sizeof(float)));
+	for (uint32_t k = 0; k < n; k++)
+		for (int q = 0; q < 3; q++)
+		{
+			v[3 * k + q] = solved ? b[8 * k + q] : s->colliders[k].body_v[q];
+			omega[3 * k + q] = solved ? b[8 * k + 3 + q] : s->colliders[k].body_omega[q];
+		}
 	return PBDX_OK;
 }
 

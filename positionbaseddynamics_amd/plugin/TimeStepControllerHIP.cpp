@@ -4,6 +4,7 @@
 #include "Simulation/Constraints.h"
 #include "Simulation/DistanceFieldCollisionDetection.h"
 #include "Simulation/RigidBody.h"
+#include "PositionBasedDynamics/TimeIntegration.h"
 #include "Utils/Logger.h"
 #include "Utils/Timing.h"
 #include <stdio.h>
@@ -11,6 +12,7 @@
 #include <string.h>
 #include <sched.h>
 #include <pthread.h>
+#include <unistd.h>
 #include <new>
 #include <algorithm>
 #include <condition_variable>
@@ -134,6 +136,11 @@ namespace
 		{
 			if (parts > m_threads) parts = m_threads;
 			if (parts <= 1 || n < 2) { fn(0, n); return; }
+			// A forked child has this object but none of its threads, and its mutexes and condition variables in whatever state another thread held them
+			// when the fork happened: it never touches them and runs its passes on the calling thread (no pthread_atfork handler, which would
+			// outlive a dlclose of the plug-in).  The same for a job that calls run() itself (m_pass is not recursive).
+			if (getpid() != m_pid || t_inPass) { fn(0, n); return; }
+			struct InPass { InPass() { t_inPass = true; } ~InPass() { t_inPass = false; } } inPass;
 			// one pass at a time: the pool is shared by every controller of the process, and two controllers may be stepped from two host threads
 			// (the single m_fn / m_pending state raced)
 			std::lock_guard<std::mutex> pass(m_pass);
@@ -160,8 +167,7 @@ namespace
 			// (128 threads on the 256-CPU host were tried in round 5: the scan does not get faster and the particle hashes get three times slower, profiles/HISTORY.md [9])
 			if (m_threads > 64) m_threads = 64;
 			if (const char *e = getenv("PBDX_PLUGIN_HASH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) m_threads = v; }      // developer aid
-			// after fork() the child has the pool object but none of its threads: forget them (they are started again on first use)
-			pthread_atfork(nullptr, nullptr, [] { HostPool &p = get(); new (&p.m_workers) std::vector<std::thread>(); p.m_pending = 0; p.m_fn = nullptr; });
+			m_pid = getpid();
 		}
 		~HostPool()
 		{
@@ -188,19 +194,24 @@ namespace
 				}
 				if (k < parts)
 				{
+					t_inPass = true;
 					(*fn)(n * (size_t)k / (size_t)parts, n * (size_t)(k + 1) / (size_t)parts);
+					t_inPass = false;
 					std::lock_guard<std::mutex> lk(m_mutex);
 					if (--m_pending == 0) m_done.notify_one();
 				}
 			}
 		}
 		int m_threads;
+		pid_t m_pid;
+		static thread_local bool t_inPass;
 		std::vector<std::thread> m_workers;
 		std::mutex m_mutex, m_pass;
 		std::condition_variable m_wake, m_done;
 		const std::function<void(size_t, size_t)> *m_fn;
 		size_t m_n; int m_parts, m_pending; uint64_t m_generation; bool m_stop;
 	};
+	thread_local bool HostPool::t_inPass = false;
 	struct HashJob { const void *base; uint32_t n, elemBytes; std::vector<uint64_t> *out; };
 	void hashBlocks(HashJob *jobs, int numJobs)
 	{
@@ -256,7 +267,7 @@ TimeStepControllerHIP::TimeStepControllerHIP(int device) :
 	m_supportedFor(nullptr), m_supportedConstraints(0), m_supportedBodies(0), m_supportedObjects(0), m_supported(false), m_accelValid(false), m_tetSignature(0)
 {
 	m_accelGravity[0] = m_accelGravity[1] = m_accelGravity[2] = 0;
-	m_fullParameterScan = true; m_partialUploads = 0; m_mixed = false; m_mixedGroupsLast = 0;
+	m_fullParameterScan = true; m_partialUploads = 0; m_mixed = false; m_mixedGroupsLast = 0; m_dynamicBodies = false;
 	m_speculate = getenv("PBDX_PLUGIN_NO_SPECULATION") == NULL; m_speculativeSteps = 0; m_repeatedSteps = 0; m_failRepeatForTest = false;
 	m_rawH = 0.0f; m_rawG[0] = m_rawG[1] = m_rawG[2] = 0.0f;
 	for (int k = 0; k < 6; k++) m_ms[k] = 0.0;
@@ -379,11 +390,32 @@ bool TimeStepControllerHIP::supported(SimulationModel &model)
 	m_supportedBodies = model.getRigidBodies().size(); m_supportedObjects = nObjects;
 	m_supported = false;
 	if (model.getOrientations().size() != 0) return false;
-	// rigid bodies: only static ones (mass 0), as colliders of a distance-field collision detection
+	// rigid bodies: as colliders of a distance-field collision detection.  Static ones (mass 0) always; bodies of finite mass as impulse sinks of the
+	// particle contacts (include/pbdx.h) -- their own dynamics stay on the host (integrateBodies) -- as long as no contact BETWEEN rigid bodies can
+	// arise (RigidBodyContactConstraint is outside the path: a dynamic body next to another rigid collision object is only taken when neither tests its
+	// mesh against the other, DistanceFieldCollisionDetection.cpp:112-124) and no tet model collides with tet models at the same time
+	m_dynamicBodies = false;
 	for (RigidBody *rb : model.getRigidBodies())
-		if (rb->getMass() != 0.0) return false;
+		if (rb->getMass() != 0.0) m_dynamicBodies = true;
 	if (!model.getRigidBodies().empty() && m_collisionDetection == NULL) return false;
 	if (m_collisionDetection != NULL && dynamic_cast<DistanceFieldCollisionDetection*>(m_collisionDetection) == NULL) return false;
+	if (m_dynamicBodies)
+	{
+		typedef DistanceFieldCollisionDetection D;
+		unsigned int rigidObjects = 0, rigidTesting = 0, tetObjects = 0;
+		for (CollisionDetection::CollisionObject *co : m_collisionDetection->getCollisionObjects())
+		{
+			if (co->m_bodyType == CollisionDetection::CollisionObject::RigidBodyCollisionObjectType)
+			{
+				rigidObjects++;
+				if (((D::DistanceFieldCollisionObject*)co)->m_testMesh) rigidTesting++;
+			}
+			else if (co->m_bodyType == CollisionDetection::CollisionObject::TetModelCollisionObjectType) tetObjects++;
+		}
+		if (rigidObjects > 1 && rigidTesting != 0) return false;
+		if (tetObjects > 1) return false;
+		if (rigidObjects > 32) return false;
+	}
 	if (m_collisionDetection != NULL)
 	{
 		typedef DistanceFieldCollisionDetection D;
@@ -448,11 +480,15 @@ bool TimeStepControllerHIP::uploadColliders(SimulationModel &model)
 {
 	std::vector<pbdx_collider> cols;
 	std::vector<pbdx_collision_range> ranges;
+	std::vector<pbdx_collider_dynamics> dyns;
+	std::vector<uint32_t> rangeObject, rank;
+	m_colliderBody.clear();
 	float tolerance = 0.01f;
 	if (m_collisionDetection != NULL)
 	{
 		typedef DistanceFieldCollisionDetection D;
 		tolerance = (float)m_collisionDetection->getTolerance();
+		uint32_t objectIndex = 0;
 		for (CollisionDetection::CollisionObject *co : m_collisionDetection->getCollisionObjects())
 		{
 			const int t = co->getTypeId();
@@ -478,6 +514,14 @@ bool TimeStepControllerHIP::uploadColliders(SimulationModel &model)
 				c.friction = (float)rb->getFrictionCoeff();
 				c.body_index = co->m_bodyIndex;
 				cols.push_back(c);
+				pbdx_collider_dynamics d;
+				memset(&d, 0, sizeof(d));
+				d.inv_mass = (float)rb->getInvMass();
+				const Matrix3r &Ji = rb->getInertiaTensorInverseW();
+				for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) d.inertia_inv_w[3 * r + k] = (float)Ji(r, k);
+				d.object_index = objectIndex;
+				dyns.push_back(d);
+				m_colliderBody.push_back(co->m_bodyIndex);
 			}
 			else if (((D::DistanceFieldCollisionObject*)co)->m_testMesh)
 			{
@@ -495,11 +539,27 @@ bool TimeStepControllerHIP::uploadColliders(SimulationModel &model)
 					r.restitution = (float)tm->getRestitutionCoeff(); r.friction = (float)tm->getFrictionCoeff();
 				}
 				ranges.push_back(r);
+				rangeObject.push_back(objectIndex);
+				if (m_dynamicBodies)
+				{
+					// a particle's place in the reference's contact order: its position in the entity list of the object's point hierarchy, which the
+					// reference walks depth first, left to right (collisionDetectionRBSolid, kdTree.inl:84-105)
+					if (rank.empty()) rank.assign(model.getParticles().size(), 0u);
+					const PointCloudBSH &bvh = ((D::DistanceFieldCollisionObject*)co)->m_bvh;
+					for (unsigned int q = 0; q < r.count; q++) rank[r.first + bvh.entity(q)] = q;
+				}
 			}
+			objectIndex++;
 		}
 	}
 	if (pbdx_solver_set_colliders(m_solver, (uint32_t)cols.size(), cols.data()) != PBDX_OK) return false;
 	if (pbdx_solver_set_collision_ranges(m_solver, (uint32_t)ranges.size(), ranges.data()) != PBDX_OK) return false;
+	if (pbdx_solver_set_collider_dynamics(m_solver, m_dynamicBodies ? (uint32_t)dyns.size() : 0u, dyns.data()) != PBDX_OK) return false;
+	if (m_dynamicBodies && !ranges.empty())
+	{
+		if (rank.size() != model.getParticles().size()) rank.assign(model.getParticles().size(), 0u);
+		if (pbdx_solver_set_contact_order(m_solver, (uint32_t)rangeObject.size(), rangeObject.data(), (uint32_t)rank.size(), rank.data()) != PBDX_OK) return false;
+	}
 	if (!uploadTetColliders(model, tolerance)) return false;
 	return pbdx_solver_set_contact_params(m_solver, tolerance, (float)model.getContactStiffnessParticleRigidBody(), m_maxIterationsV) == PBDX_OK;
 }
@@ -954,11 +1014,75 @@ void TimeStepControllerHIP::readGlobals()
 	m_rawG[0] = (float)gr[0]; m_rawG[1] = (float)gr[1]; m_rawG[2] = (float)gr[2];
 }
 
+// The rigid bodies' part of TimeStepController::step for ONE step (TimeStepController.cpp:84, 94-104, 137-152, 178-186): nothing the particles do during
+// the substeps reaches a body (no joint or constraint on a body is taken, supported()), so all substeps of the bodies run before the engine's step; what
+// couples the two is the contact velocity solve at the end of the step, which the engine runs with the bodies' end-of-step state (uploadColliders).
+void TimeStepControllerHIP::integrateBodies(SimulationModel &model)
+{
+	SimulationModel::RigidBodyVector &rb = model.getRigidBodies();
+	const Vector3r grav(Simulation::getCurrent()->getVecValue<Real>(Simulation::GRAVITATION));
+	for (size_t i = 0; i < rb.size(); i++) if (rb[i]->getMass() != 0.0) rb[i]->getAcceleration() = grav;      // TimeStep.cpp:36-45
+	TimeManager *tm = TimeManager::getCurrent();
+	const Real h = tm->getTimeStepSize() / (Real)m_subSteps;
+	for (unsigned int step = 0; step < m_subSteps; step++)
+		for (size_t i = 0; i < rb.size(); i++)
+		{
+			rb[i]->getLastPosition() = rb[i]->getOldPosition();
+			rb[i]->getOldPosition() = rb[i]->getPosition();
+			TimeIntegration::semiImplicitEuler(h, rb[i]->getMass(), rb[i]->getPosition(), rb[i]->getVelocity(), rb[i]->getAcceleration());
+			rb[i]->getLastRotation() = rb[i]->getOldRotation();
+			rb[i]->getOldRotation() = rb[i]->getRotation();
+			TimeIntegration::semiImplicitEulerRotation(h, rb[i]->getMass(), rb[i]->getInertiaTensorW(), rb[i]->getInertiaTensorInverseW(), rb[i]->getRotation(), rb[i]->getAngularVelocity(), rb[i]->getTorque());
+			rb[i]->rotationUpdated();
+			if (m_velocityUpdateMethod == 0)
+			{
+				TimeIntegration::velocityUpdateFirstOrder(h, rb[i]->getMass(), rb[i]->getPosition(), rb[i]->getOldPosition(), rb[i]->getVelocity());
+				TimeIntegration::angularVelocityUpdateFirstOrder(h, rb[i]->getMass(), rb[i]->getRotation(), rb[i]->getOldRotation(), rb[i]->getAngularVelocity());
+			}
+			else
+			{
+				TimeIntegration::velocityUpdateSecondOrder(h, rb[i]->getMass(), rb[i]->getPosition(), rb[i]->getOldPosition(), rb[i]->getLastPosition(), rb[i]->getVelocity());
+				TimeIntegration::angularVelocityUpdateSecondOrder(h, rb[i]->getMass(), rb[i]->getRotation(), rb[i]->getOldRotation(), rb[i]->getLastRotation(), rb[i]->getAngularVelocity());
+			}
+		}
+	for (size_t i = 0; i < rb.size(); i++)
+		if (rb[i]->getMass() != 0.0)
+			rb[i]->getGeometry().updateMeshTransformation(rb[i]->getPosition(), rb[i]->getRotationMatrix());
+}
+
+// the bodies' velocities after the engine's contact solve (Constraints.cpp:2180-2187: what the contacts added to them)
+bool TimeStepControllerHIP::applyBodyVelocities(SimulationModel &model)
+{
+	const uint32_t n = (uint32_t)m_colliderBody.size();
+	if (!n) return true;
+	std::vector<float> v(3 * (size_t)n), w(3 * (size_t)n);
+	if (pbdx_solver_get_body_velocities(m_solver, n, v.data(), w.data()) != PBDX_OK) return false;
+	SimulationModel::RigidBodyVector &rb = model.getRigidBodies();
+	for (uint32_t k = 0; k < n; k++)
+	{
+		RigidBody *b = rb[m_colliderBody[k]];
+		if (b->getMass() == 0.0) continue;
+		b->getVelocity() = Vector3r((Real)v[3 * k], (Real)v[3 * k + 1], (Real)v[3 * k + 2]);
+		b->getAngularVelocity() = Vector3r((Real)w[3 * k], (Real)w[3 * k + 1], (Real)w[3 * k + 2]);
+	}
+	return true;
+}
+
 bool TimeStepControllerHIP::runSteps(SimulationModel &model, unsigned int numSteps)
 {
 	readGlobals();
 	START_TIMING("position constraints projection");
-	const bool ok = m_mixed ? runMixedSteps(model, numSteps, m_rawG) : stepRaw(numSteps);
+	bool ok = true;
+	if (m_dynamicBodies && !m_mixed)
+	{
+		// step by step: the bodies' substeps on the host, their end-of-step state to the engine, the engine's step, the contact impulses back
+		for (unsigned int i = 0; ok && i < numSteps; i++)
+		{
+			integrateBodies(model);
+			ok = uploadColliders(model) && stepRaw(1) && applyBodyVelocities(model);
+		}
+	}
+	else ok = m_mixed ? runMixedSteps(model, numSteps, m_rawG) : stepRaw(numSteps);
 	STOP_TIMING_AVG;
 	if (!ok) return false;
 	m_deviceAhead = true;

@@ -124,6 +124,10 @@ namespace PBD
 		bool buildSchedule(SimulationModel &model, bool paramsOnly);
 		bool uploadParticles(SimulationModel &model);
 		bool uploadColliders(SimulationModel &model);
+		// dynamic rigid bodies (finite mass) as impulse sinks of the particle contacts: their time integration stays here, on the host
+		// (TimeStepController.cpp:94-104,137-152,178-186), the contact velocity solve runs on the device in the reference's contact order
+		void integrateBodies(SimulationModel &model);
+		bool applyBodyVelocities(SimulationModel &model);
 		bool uploadTetColliders(SimulationModel &model, float tolerance);
 		bool downloadParticles(SimulationModel &model);
 		bool prepare(SimulationModel &model, bool forceUpload, bool *scanDeferred = NULL);
@@ -169,6 +173,8 @@ namespace PBD
 		std::vector<Real> m_invMass;
 		// mixed models: per colour group the constraints that stay with the host
 		bool m_mixed; unsigned int m_mixedGroupsLast;
+		bool m_dynamicBodies;              // some rigid body has a finite mass
+		std::vector<unsigned int> m_colliderBody;      // collider -> rigid body index (uploadColliders)
 		std::vector<std::vector<unsigned int> > m_hostGroups;
 	};
 }

@@ -180,7 +180,7 @@ def test_no_caller_memory_is_handed_to_the_gpu():
         syms = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
         assert "hipHostRegister" not in syms and "hipHostUnregister" not in syms, lib
     csrc = os.path.join(util.ROOT, "positionbaseddynamics_amd", "csrc")
-    own = re.compile(r"hipMemcpy(Async)?\((mir\b|mir \+|j\.dst, slot|st \+ per \* first, slot|c, s->d_(tet|contact)_counters|status, d_status|out, s->d_tet_counters, 8 \*|c->d_buf, c->h_mir,|c->h_mir \+)")
+    own = re.compile(r"hipMemcpy(Async)?\((mir\b|mir \+|j\.dst, slot|st \+ per \* first, slot|c, s->d_(tet|contact|dyn)_counters|status, d_status|out, s->d_tet_counters, 8 \*|c->d_buf, c->h_mir,|c->h_mir \+)")
     bad = []
     for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.h"))):
         if os.path.basename(path) == "pbdx_hostio.hip":

@@ -146,6 +146,50 @@ def test_plugin_with_static_colliders_and_contacts():
 
 
 @pytest.mark.gpu
+def test_plugin_with_a_dynamic_rigid_body_as_impulse_sink():
+    """SURVEY 8f rank 2, the remainder: a rigid body of FINITE mass in the particle contacts.  A 16 kg sphere dropped onto a cloth held at its
+    four corners: ParticleRigidBodyContactConstraint::solveVelocityConstraint (Constraints.cpp:2148-2189) changes the sphere's velocity and
+    angular velocity with every contact, and the next contact of the sphere reads them -- the device solves the list sequentially in the
+    reference's contact order (pair order, then the cloth's point hierarchy left to right), the sphere's own time integration stays on the host
+    (plug-in: integrateBodies).  Particles, sphere position, rotation and velocities equal the CPU TimeStepController's bit for bit."""
+    refdrv, path = _plugin("f32")
+    n = 30
+    ops = util.cloth_spec(n, n, 4, 3, T=(-5, 4, -5), pin=True) + [("mass", (n - 1) * n, 0.0), ("mass", n * n - 1, 0.0)]
+
+    def scene(ref):
+        _setup(ref, ops, 2, 5)
+        b = ref.add_dynamic_collider("sphere", (0.3, 5.5, -0.2), (1, 0, 0, 0), (2, 2, 2), (1.0,), density=2.0, restitution=0.6, friction=0.3)
+        ref.enable_collisions(0.05, 0.6, 0.1)
+        return b
+
+    ref = refdrv.Ref("f32")
+    b = scene(ref)
+    ref.set_params(2, 5, 0)
+    seen = 0
+    for _ in range(8):
+        ref.step(40)
+        seen += len(ref.contacts())
+    assert seen > 0
+    x_cpu, v_cpu, body_cpu = ref.positions().copy(), ref.get_array(2).copy(), ref.rigid_body_state(b).copy()
+    assert abs(body_cpu[10:13]).max() > 1e-3 and abs(body_cpu[7]) > 1e-3          # the cloth threw the sphere back, sideways and spinning
+    b = scene(ref)
+    assert ref.install_timestep_plugin(path) == 0
+    ref.lib.refdrv_attach_collision_detection()
+    ref.set_params(2, 5, 0)
+    for _ in range(8):
+        ref.step(40)
+    lib, cnt = _counters(path)
+    ts = C.c_void_p(ref.lib.refdrv_get_timestep())
+    assert cnt["gpu_steps"](ts) == 320 and cnt["failed_steps"](ts) == 0 and cnt["fallback_steps"](ts) == 0
+    x_gpu, v_gpu, body_gpu = ref.positions().copy(), ref.get_array(2).copy(), ref.rigid_body_state(b).copy()
+    ref.reset_all()
+    print("sphere after 320 steps: CPU", body_cpu[:3], body_cpu[7:13], "GPU", body_gpu[:3], body_gpu[7:13])
+    assert np.array_equal(body_gpu, body_cpu), "sphere state differs by %.3e" % abs(body_gpu - body_cpu).max()
+    assert util.bitwise_equal(x_gpu, x_cpu), "max err %.3e" % util.max_err(x_gpu, x_cpu)
+    assert util.bitwise_equal(v_gpu, v_cpu)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["f32", "f64"])
 def test_plugin_resident_mode_and_dirty_tracking(variant):
     """SURVEY 8f rank 1 on the reference side: TimeStepControllerHIP::stepResident keeps the state in HBM (one upload, no
