@@ -18,8 +18,15 @@ T=tests/test_tetcontact.py::test_plugin_tet_contacts_medium_scene_timing_and_par
 tfail=0; done_reps=0
 while [ $done_reps -lt $M ]; do
   reps=$(( M - done_reps )); [ $reps -gt 50 ] && reps=50
-  args=""; for k in $(seq 1 $reps); do args="$args $T"; done
-  timeout 1200 python -m pytest $args --keep-duplicates -m gpu -q -p no:cacheprovider > $out/tet_$done_reps.log 2>&1
+  # (pytest runs a node id once however often it is named: the repetitions are separate pytest.main calls inside ONE process)
+  timeout 1800 python -c "
+import sys, pytest
+for k in range($reps):
+    rc = pytest.main(['$T', '-m', 'gpu', '-q', '-p', 'no:cacheprovider'])
+    if rc != 0:
+        print('repetition', k, 'failed with', rc); sys.exit(1)
+print('$reps repetitions passed')
+" > $out/tet_$done_reps.log 2>&1
   rc=$?
   grep -q "Memory access fault" $out/tet_$done_reps.log && faults=$((faults+1))
   if [ $rc -ne 0 ]; then tfail=$((tfail+1)); echo "tet block at $done_reps: rc=$rc $(tail -1 $out/tet_$done_reps.log)"; else echo "tet block at $done_reps ($reps repetitions): $(tail -1 $out/tet_$done_reps.log)"; rm -f $out/tet_$done_reps.log; fi
