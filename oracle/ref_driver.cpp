@@ -531,6 +531,13 @@ int refdrv_get_rigid_body_state(unsigned index, double *out)
 	out[13] = (double)rb->getMass();
 	return 0;
 }
+// mass 0 = static (RigidBody::setMass also clears the inverse mass); with refdrv_add_dynamic_collider(..., testMesh = 0): a static collider whose own mesh is
+// not tested against other rigid bodies
+void refdrv_set_rigid_body_mass(unsigned index, double mass)
+{
+	SimulationModel *m = model();
+	if (index < m->getRigidBodies().size()) m->getRigidBodies()[index]->setMass((Real)mass);
+}
 void refdrv_set_rigid_body_velocity(unsigned index, const double *v, const double *omega)
 {
 	SimulationModel *m = model();

@@ -292,6 +292,10 @@ class Ref:
         assert self.lib.refdrv_get_rigid_body_state(int(index), _dp(out)) == 0
         return out
 
+    def set_rigid_body_mass(self, index, mass):
+        self.lib.refdrv_set_rigid_body_mass.argtypes = [_u, _d]
+        self.lib.refdrv_set_rigid_body_mass(int(index), float(mass))
+
     def set_rigid_body_velocity(self, index, v, omega=(0, 0, 0)):
         a = [np.ascontiguousarray(q, dtype=np.float64) for q in (v, omega)]
         self.lib.refdrv_set_rigid_body_velocity.argtypes = [_u, _pd, _pd]

@@ -2458,6 +2458,9 @@ int pbdx_solver_step(pbdx_solver *s, float h, uint32_t sub_steps, uint32_t max_i
 {
 	if (!s || !gravity || sub_steps == 0) { set_error("step: bad arguments"); return PBDX_ERR_INVALID; }
 	if (s->schedule_open) { set_error("step: schedule still open"); return PBDX_ERR_INVALID; }
+	// bodies of finite mass move between steps and the host integrates them: one step per call (include/pbdx.h, dynamic rigid bodies as impulse sinks)
+	if (num_steps > 1 && !s->ranges.empty() && s->dynamics.size() == s->colliders.size() && s->any_dynamic())
+	{ set_error("step: %u steps in one call with dynamic rigid bodies among the colliders (their poses are the host's to update between steps)", num_steps); return PBDX_ERR_UNSUPPORTED; }
 	ENTER_DEVICE(s->device);
 	const bool fresh_plan = !s->plan_built;
 	int rp = ensure_plan(s);

@@ -146,32 +146,41 @@ def test_plugin_with_static_colliders_and_contacts():
 
 
 @pytest.mark.gpu
-def test_plugin_with_a_dynamic_rigid_body_as_impulse_sink():
+@pytest.mark.parametrize("floor", [False, True])
+def test_plugin_with_a_dynamic_rigid_body_as_impulse_sink(floor):
     """SURVEY 8f rank 2, the remainder: a rigid body of FINITE mass in the particle contacts.  A 16 kg sphere dropped onto a cloth held at its
     four corners: ParticleRigidBodyContactConstraint::solveVelocityConstraint (Constraints.cpp:2148-2189) changes the sphere's velocity and
     angular velocity with every contact, and the next contact of the sphere reads them -- the device solves the list sequentially in the
     reference's contact order (pair order, then the cloth's point hierarchy left to right), the sphere's own time integration stays on the host
-    (plug-in: integrateBodies).  Particles, sphere position, rotation and velocities equal the CPU TimeStepController's bit for bit."""
+    (plug-in: integrateBodies).  Particles, sphere position, rotation and velocities equal the CPU TimeStepController's bit for bit.
+    floor: the cloth is free and lands on a STATIC box (whose mesh is not tested against the sphere: no contact between rigid bodies), the sphere
+    lands on the cloth -- particles squeezed between the two have a contact with each, both in the sequential list, in the reference's order."""
     refdrv, path = _plugin("f32")
     n = 30
-    ops = util.cloth_spec(n, n, 4, 3, T=(-5, 4, -5), pin=True) + [("mass", (n - 1) * n, 0.0), ("mass", n * n - 1, 0.0)]
+    ops = util.cloth_spec(n, n, 4, 3, T=(-5, 4, -5), pin=not floor) + ([] if floor else [("mass", (n - 1) * n, 0.0), ("mass", n * n - 1, 0.0)])
 
     def scene(ref):
         _setup(ref, ops, 2, 5)
-        b = ref.add_dynamic_collider("sphere", (0.3, 5.5, -0.2), (1, 0, 0, 0), (2, 2, 2), (1.0,), density=2.0, restitution=0.6, friction=0.3)
+        if floor:
+            f = ref.add_dynamic_collider("box", (0, 2.0, 0), (1, 0, 0, 0), (100, 1, 100), (100, 1, 100), density=1.0, restitution=0.6, friction=0.2)
+            ref.set_rigid_body_mass(f, 0.0)
+        b = ref.add_dynamic_collider("sphere", (0.3, 6.5 if floor else 5.5, -0.2), (1, 0, 0, 0), (2, 2, 2), (1.0,), density=2.0, restitution=0.6, friction=0.3)
         ref.enable_collisions(0.05, 0.6, 0.1)
         return b
 
     ref = refdrv.Ref("f32")
     b = scene(ref)
     ref.set_params(2, 5, 0)
-    seen = 0
+    seen = two = 0
     for _ in range(8):
         ref.step(40)
-        seen += len(ref.contacts())
-    assert seen > 0
+        c = ref.contacts()
+        seen += len(c)
+        if len(c):
+            two += int((np.unique(c[:, 0].astype(np.int64), return_counts=True)[1] > 1).sum())
+    assert seen > 0 and (two > 0 or not floor)            # (floor: some particle touched the floor and the sphere in the same step)
     x_cpu, v_cpu, body_cpu = ref.positions().copy(), ref.get_array(2).copy(), ref.rigid_body_state(b).copy()
-    assert abs(body_cpu[10:13]).max() > 1e-3 and abs(body_cpu[7]) > 1e-3          # the cloth threw the sphere back, sideways and spinning
+    assert abs(body_cpu[10:13]).max() > 1e-3 and abs(body_cpu[7]) > 1e-3          # the contacts pushed the sphere sideways and set it spinning
     b = scene(ref)
     assert ref.install_timestep_plugin(path) == 0
     ref.lib.refdrv_attach_collision_detection()
