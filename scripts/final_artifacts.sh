@@ -27,6 +27,12 @@ rm -rf $O/stats
 # 3. SQ / TCC counters of the timed kernel at this commit
 KERNEL=persistent_kernel OUT=$O/pmc timeout 900 bash scripts/pmc_sq.sh --persistent 2 > $O/sq_counters_persistent_c2.log 2>&1
 rm -rf $O/pmc
+# 3b. the same counters for the other two single-GPU lines: configs[2] (100 k-tet bar; in the ab.sh runs of round 6 the engine picked one launch per segment
+#     for it, hence both kernel names) and the configs[3] block (no counter pass existed for either)
+KERNEL=_kernel OUT=$O/pmc3 timeout 900 bash scripts/pmc_sq.sh --workload c3 > $O/sq_counters_c3_bar.log 2>&1
+rm -rf $O/pmc3
+KERNEL=persistent_kernel OUT=$O/pmc4 timeout 900 bash scripts/pmc_sq.sh --workload c4 --persistent 2 > $O/sq_counters_c4_block.log 2>&1
+rm -rf $O/pmc4
 # 4. the N>1 launcher shapes the driver uses on an 8-GPU node, on this one-GPU box (ranks share the device: a smoke test of the path, not a
 #    measurement), and ONE rank over RCCL (the backend of the real run)
 ( time timeout 600 python bench.py --gpus 8 --oversubscribe --steps 10 --warmup 3 > $O/bench_gpus8_c2_oversubscribed.txt 2> $O/bench_gpus8.err ) 2>> $O/box.txt; echo "gpus8 c2 rc=$?" >> $O/box.txt

@@ -146,30 +146,41 @@ def test_plugin_with_static_colliders_and_contacts():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("floor", [False, True])
-def test_plugin_with_a_dynamic_rigid_body_as_impulse_sink(floor):
-    """SURVEY 8f rank 2, the remainder: a rigid body of FINITE mass in the particle contacts.  A 16 kg sphere dropped onto a cloth held at its
+@pytest.mark.parametrize("what", ["sphere", "floor", "two bodies"])
+def test_plugin_with_a_dynamic_rigid_body_as_impulse_sink(what):
+    """SURVEY 8f rank 2, the remainder: rigid bodies of FINITE mass in the particle contacts.  A 16 kg sphere dropped onto a cloth held at its
     four corners: ParticleRigidBodyContactConstraint::solveVelocityConstraint (Constraints.cpp:2148-2189) changes the sphere's velocity and
     angular velocity with every contact, and the next contact of the sphere reads them -- the device solves the list sequentially in the
-    reference's contact order (pair order, then the cloth's point hierarchy left to right), the sphere's own time integration stays on the host
-    (plug-in: integrateBodies).  Particles, sphere position, rotation and velocities equal the CPU TimeStepController's bit for bit.
+    reference's contact order (pair order, then the cloth's point hierarchy left to right), the bodies' own time integration stays on the host
+    (plug-in: integrateBodies).  Particles, body positions, rotations and velocities equal the CPU TimeStepController's bit for bit.
     floor: the cloth is free and lands on a STATIC box (whose mesh is not tested against the sphere: no contact between rigid bodies), the sphere
-    lands on the cloth -- particles squeezed between the two have a contact with each, both in the sequential list, in the reference's order."""
+    lands on the cloth -- particles squeezed between the two have a contact with each, both in the sequential list, in the reference's order.
+    two bodies: a tumbling 9 kg box (rotated, spinning: the full world inertia tensor in computeMatrixK and in the angular impulse) and a sphere,
+    neither testing its mesh, on the held cloth."""
     refdrv, path = _plugin("f32")
     n = 30
+    floor = what == "floor"
     ops = util.cloth_spec(n, n, 4, 3, T=(-5, 4, -5), pin=not floor) + ([] if floor else [("mass", (n - 1) * n, 0.0), ("mass", n * n - 1, 0.0)])
 
     def scene(ref):
         _setup(ref, ops, 2, 5)
+        bodies = []
         if floor:
             f = ref.add_dynamic_collider("box", (0, 2.0, 0), (1, 0, 0, 0), (100, 1, 100), (100, 1, 100), density=1.0, restitution=0.6, friction=0.2)
             ref.set_rigid_body_mass(f, 0.0)
-        b = ref.add_dynamic_collider("sphere", (0.3, 6.5 if floor else 5.5, -0.2), (1, 0, 0, 0), (2, 2, 2), (1.0,), density=2.0, restitution=0.6, friction=0.3)
+        if what == "two bodies":
+            q = np.array([0.9, 0.2, 0.3, 0.1])
+            b = ref.add_dynamic_collider("box", (1.0, 5.5, 0.5), tuple(q / np.linalg.norm(q)), (2, 1, 3), (2, 1, 3), density=1.5, restitution=0.5, friction=0.4)
+            ref.set_rigid_body_velocity(b, (0.5, 0, -0.3), (1.0, 2.0, -1.5))
+            bodies.append(b)
+            bodies.append(ref.add_dynamic_collider("sphere", (-2.0, 6.0, -1.5), (1, 0, 0, 0), (1.6, 1.6, 1.6), (0.8,), density=3.0, restitution=0.6, friction=0.3))
+        else:
+            bodies.append(ref.add_dynamic_collider("sphere", (0.3, 6.5 if floor else 5.5, -0.2), (1, 0, 0, 0), (2, 2, 2), (1.0,), density=2.0, restitution=0.6, friction=0.3))
         ref.enable_collisions(0.05, 0.6, 0.1)
-        return b
+        return bodies
 
     ref = refdrv.Ref("f32")
-    b = scene(ref)
+    bodies = scene(ref)
     ref.set_params(2, 5, 0)
     seen = two = 0
     for _ in range(8):
@@ -179,9 +190,9 @@ def test_plugin_with_a_dynamic_rigid_body_as_impulse_sink(floor):
         if len(c):
             two += int((np.unique(c[:, 0].astype(np.int64), return_counts=True)[1] > 1).sum())
     assert seen > 0 and (two > 0 or not floor)            # (floor: some particle touched the floor and the sphere in the same step)
-    x_cpu, v_cpu, body_cpu = ref.positions().copy(), ref.get_array(2).copy(), ref.rigid_body_state(b).copy()
-    assert abs(body_cpu[10:13]).max() > 1e-3 and abs(body_cpu[7]) > 1e-3          # the contacts pushed the sphere sideways and set it spinning
-    b = scene(ref)
+    x_cpu, v_cpu, body_cpu = ref.positions().copy(), ref.get_array(2).copy(), np.array([ref.rigid_body_state(b) for b in bodies])
+    assert abs(body_cpu[:, 10:13]).max() > 1e-3 and abs(body_cpu[:, 7]).max() > 1e-3          # the contacts pushed the bodies sideways and set them spinning
+    bodies = scene(ref)
     assert ref.install_timestep_plugin(path) == 0
     ref.lib.refdrv_attach_collision_detection()
     ref.set_params(2, 5, 0)
@@ -190,10 +201,10 @@ def test_plugin_with_a_dynamic_rigid_body_as_impulse_sink(floor):
     lib, cnt = _counters(path)
     ts = C.c_void_p(ref.lib.refdrv_get_timestep())
     assert cnt["gpu_steps"](ts) == 320 and cnt["failed_steps"](ts) == 0 and cnt["fallback_steps"](ts) == 0
-    x_gpu, v_gpu, body_gpu = ref.positions().copy(), ref.get_array(2).copy(), ref.rigid_body_state(b).copy()
+    x_gpu, v_gpu, body_gpu = ref.positions().copy(), ref.get_array(2).copy(), np.array([ref.rigid_body_state(b) for b in bodies])
     ref.reset_all()
-    print("sphere after 320 steps: CPU", body_cpu[:3], body_cpu[7:13], "GPU", body_gpu[:3], body_gpu[7:13])
-    assert np.array_equal(body_gpu, body_cpu), "sphere state differs by %.3e" % abs(body_gpu - body_cpu).max()
+    print("bodies after 320 steps (position, rotation, velocity, angular velocity, mass): CPU", body_cpu, "GPU", body_gpu)
+    assert np.array_equal(body_gpu, body_cpu), "body state differs by %.3e" % abs(body_gpu - body_cpu).max()
     assert util.bitwise_equal(x_gpu, x_cpu), "max err %.3e" % util.max_err(x_gpu, x_cpu)
     assert util.bitwise_equal(v_gpu, v_cpu)
 
