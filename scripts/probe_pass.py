@@ -11,9 +11,10 @@ from tests import util
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=1000)
-ap.add_argument("--workload", default="cloth")
+ap.add_argument("--instances", type=int, default=1, help="an ensemble block of that many sheets (configs[3]: --size 200 --instances 64)")
 args = ap.parse_args()
-model = util.build_mine(util.cloth_spec(args.size, args.size, 4, 3))
+model = util.build_mine(util.cloth_spec(args.size, args.size, 4, 3) if args.instances == 1 else
+                        util.cloth_spec(args.size, args.size, 4, 3, instances=args.instances, instance_offset=(0.0, 0.0, 12.0), instanced=True))
 ts = pbd.TimeStepController()
 ts.setValueUInt(pbd.TimeStepController.NUM_SUB_STEPS, 1)
 ts.setValueUInt(pbd.TimeStepController.MAX_ITERATIONS, 10)
