@@ -63,3 +63,21 @@ def test_no_hand_written_memory_instruction_reads_a_freshly_valu_written_scalar(
     # every hand-written copy / store is there and guarded
     n_dma = sum(1 for ins in kernels.values() for t in ins if t.startswith("global_load_lds_dwordx4"))
     assert n_dma > 100
+
+
+@pytest.mark.parametrize("lib", ["libpbdx.so", "libpbdx_fma.so"])
+def test_position_scatter_is_a_twelve_byte_lds_store(lib):
+    """ADVICE r5: TileAccess::st stores a projected endpoint as a 3-vector through a 16-byte-aligned pointer and relies on the backend emitting
+    ds_write_b96 -- widened to ds_write_b128 it would overwrite the inverse mass kept in .w with an undefined lane.  Checked on the built code
+    objects: every sweep kernel scatters with ds_write_b96, and the 16-byte LDS stores it has left are the handful of the fill (integrated
+    positions with their inverse mass, the dictionary table), far fewer than its scatters."""
+    path = os.path.join(ROOT, "positionbaseddynamics_amd", "_lib", lib)
+    if not os.path.exists(path) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("library or llvm-objdump not present")
+    kernels = _tool().disassemble(path)
+    sweeps = {k: ins for k, ins in kernels.items() if "persistent_kernel" in k or "fused_kernel" in k}
+    assert len(sweeps) >= 20
+    for k, ins in sweeps.items():
+        b96 = sum(1 for t in ins if t.startswith("ds_write_b96"))
+        b128 = sum(1 for t in ins if t.startswith("ds_write_b128"))
+        assert b96 >= 8 and b128 <= 16 and b128 * 3 <= b96, (k, b96, b128)

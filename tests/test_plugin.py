@@ -146,7 +146,7 @@ def test_plugin_with_static_colliders_and_contacts():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("what", ["sphere", "floor", "two bodies"])
+@pytest.mark.parametrize("what", ["sphere", "floor", "two bodies", "sphere on 200x200"])
 def test_plugin_with_a_dynamic_rigid_body_as_impulse_sink(what):
     """SURVEY 8f rank 2, the remainder: rigid bodies of FINITE mass in the particle contacts.  A 16 kg sphere dropped onto a cloth held at its
     four corners: ParticleRigidBodyContactConstraint::solveVelocityConstraint (Constraints.cpp:2148-2189) changes the sphere's velocity and
@@ -155,11 +155,13 @@ def test_plugin_with_a_dynamic_rigid_body_as_impulse_sink(what):
     (plug-in: integrateBodies).  Particles, body positions, rotations and velocities equal the CPU TimeStepController's bit for bit.
     floor: the cloth is free and lands on a STATIC box (whose mesh is not tested against the sphere: no contact between rigid bodies), the sphere
     lands on the cloth -- particles squeezed between the two have a contact with each, both in the sequential list, in the reference's order.
+    sphere on 200x200: the first scene on a 40 000-particle sheet.
     two bodies: a tumbling 9 kg box (rotated, spinning: the full world inertia tensor in computeMatrixK and in the angular impulse) and a sphere,
     neither testing its mesh, on the held cloth."""
     refdrv, path = _plugin("f32")
-    n = 30
-    floor = what == "floor"
+    n = 200 if what.endswith("200x200") else 30          # (200x200: several hundred contacts per step in the sequential list)
+    floor, big = what == "floor", what.endswith("200x200")
+    calls = [1] * 20 + [20] * 5 if big else [40] * 8          # (steps per call; contacts are counted after every call)
     ops = util.cloth_spec(n, n, 4, 3, T=(-5, 4, -5), pin=not floor) + ([] if floor else [("mass", (n - 1) * n, 0.0), ("mass", n * n - 1, 0.0)])
 
     def scene(ref):
@@ -175,7 +177,9 @@ def test_plugin_with_a_dynamic_rigid_body_as_impulse_sink(what):
             bodies.append(b)
             bodies.append(ref.add_dynamic_collider("sphere", (-2.0, 6.0, -1.5), (1, 0, 0, 0), (1.6, 1.6, 1.6), (0.8,), density=3.0, restitution=0.6, friction=0.3))
         else:
-            bodies.append(ref.add_dynamic_collider("sphere", (0.3, 6.5 if floor else 5.5, -0.2), (1, 0, 0, 0), (2, 2, 2), (1.0,), density=2.0, restitution=0.6, friction=0.3))
+            bodies.append(ref.add_dynamic_collider("sphere", (0.3, 6.5 if floor else 5.2 if big else 5.5, -0.2), (1, 0, 0, 0), (2, 2, 2), (1.0,), density=2.0, restitution=0.6, friction=0.3))
+            if big:
+                ref.set_rigid_body_velocity(bodies[-1], (0.4, -12.0, 0.2), (0.5, 0, 1.0))      # (thrown at the sheet: a large soft sheet falls almost as fast as the sphere)
         ref.enable_collisions(0.05, 0.6, 0.1)
         return bodies
 
@@ -183,8 +187,8 @@ def test_plugin_with_a_dynamic_rigid_body_as_impulse_sink(what):
     bodies = scene(ref)
     ref.set_params(2, 5, 0)
     seen = two = 0
-    for _ in range(8):
-        ref.step(40)
+    for k in calls:
+        ref.step(k)
         c = ref.contacts()
         seen += len(c)
         if len(c):
@@ -196,14 +200,14 @@ def test_plugin_with_a_dynamic_rigid_body_as_impulse_sink(what):
     assert ref.install_timestep_plugin(path) == 0
     ref.lib.refdrv_attach_collision_detection()
     ref.set_params(2, 5, 0)
-    for _ in range(8):
-        ref.step(40)
+    for k in calls:
+        ref.step(k)
     lib, cnt = _counters(path)
     ts = C.c_void_p(ref.lib.refdrv_get_timestep())
-    assert cnt["gpu_steps"](ts) == 320 and cnt["failed_steps"](ts) == 0 and cnt["fallback_steps"](ts) == 0
+    assert cnt["gpu_steps"](ts) == sum(calls) and cnt["failed_steps"](ts) == 0 and cnt["fallback_steps"](ts) == 0
     x_gpu, v_gpu, body_gpu = ref.positions().copy(), ref.get_array(2).copy(), np.array([ref.rigid_body_state(b) for b in bodies])
     ref.reset_all()
-    print("bodies after 320 steps (position, rotation, velocity, angular velocity, mass): CPU", body_cpu, "GPU", body_gpu)
+    print("contacts seen at the call boundaries of the CPU run:", seen, "; bodies after %d steps" % sum(calls), " (position, rotation, velocity, angular velocity, mass): CPU", body_cpu, "GPU", body_gpu)
     assert np.array_equal(body_gpu, body_cpu), "body state differs by %.3e" % abs(body_gpu - body_cpu).max()
     assert util.bitwise_equal(x_gpu, x_cpu), "max err %.3e" % util.max_err(x_gpu, x_cpu)
     assert util.bitwise_equal(v_gpu, v_cpu)
