@@ -1711,6 +1711,7 @@ int prepare_dynamic_contacts(pbdx_solver *s, std::vector<uint32_t> &range_pos)
 	for (uint32_t r = 0; r < nr; r++) { range_pos[r] = 0; for (uint32_t q = 0; q < nr; q++) if (s->range_object[q] < s->range_object[r] || (s->range_object[q] == s->range_object[r] && q < r)) range_pos[r]++; }
 	uint64_t in_ranges = 0;
 	for (const pbdx_collision_range &r : s->ranges) in_ranges += r.count;
+	for (const pbdx_collision_range &r : s->ranges) if (r.count > (1u << 24)) { set_error("dynamic rigid bodies: a collision range of more than 2^24 particles (the contact order's key holds 24 bits of a particle's place)"); return PBDX_ERR_UNSUPPORTED; }
 	const uint32_t cap = (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1024u, in_ranges * std::min<uint32_t>(nc, PBDX_MAX_CONTACTS_PER_PARTICLE)));
 	if (cap != s->dyn_cap)
 	{

@@ -558,7 +558,12 @@ bool TimeStepControllerHIP::uploadColliders(SimulationModel &model)
 	if (m_dynamicBodies && !ranges.empty())
 	{
 		if (rank.size() != model.getParticles().size()) rank.assign(model.getParticles().size(), 0u);
-		if (pbdx_solver_set_contact_order(m_solver, (uint32_t)rangeObject.size(), rangeObject.data(), (uint32_t)rank.size(), rank.data()) != PBDX_OK) return false;
+		// (the hierarchies' entity lists are fixed when the objects are registered: uploaded again only if something about them changed)
+		if (rank != m_contactRank || rangeObject != m_contactRangeObject)
+		{
+			if (pbdx_solver_set_contact_order(m_solver, (uint32_t)rangeObject.size(), rangeObject.data(), (uint32_t)rank.size(), rank.data()) != PBDX_OK) return false;
+			m_contactRank = rank; m_contactRangeObject = rangeObject;
+		}
 	}
 	if (!uploadTetColliders(model, tolerance)) return false;
 	return pbdx_solver_set_contact_params(m_solver, tolerance, (float)model.getContactStiffnessParticleRigidBody(), m_maxIterationsV) == PBDX_OK;
@@ -646,7 +651,7 @@ bool TimeStepControllerHIP::uploadParticles(SimulationModel &model)
 {
 	ParticleData &pd = model.getParticles();
 	const unsigned int n = pd.size();
-	if (n != m_numParticles) { m_scheduleValid = false; }      // the engine drops its schedule with the old particle image
+	if (n != m_numParticles) { m_scheduleValid = false; m_contactRank.clear(); m_contactRangeObject.clear(); }      // the engine drops its schedule (and the contact order) with the old particle image
 	m_numParticles = n;
 	m_uploads++;
 	m_accelValid = false;

@@ -175,6 +175,7 @@ namespace PBD
 		bool m_mixed; unsigned int m_mixedGroupsLast;
 		bool m_dynamicBodies;              // some rigid body has a finite mass
 		std::vector<unsigned int> m_colliderBody;      // collider -> rigid body index (uploadColliders)
+		std::vector<uint32_t> m_contactRank, m_contactRangeObject;      // what pbdx_solver_set_contact_order was last called with
 		std::vector<std::vector<unsigned int> > m_hostGroups;
 	};
 }
