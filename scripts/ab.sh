@@ -7,7 +7,7 @@
 #   --arm    one configuration to compare: a label and environment assignments, e.g.
 #              --arm "in-tree"                                   the library in positionbaseddynamics_amd/_lib
 #              --arm "fma:PBDX_LIB=$PWD/positionbaseddynamics_amd/_lib/libpbdx_fma.so"
-#              --arm "early:PBDX_LIB=$PWD/gpurun_variants/early/libpbdx.so"      (scripts/build_variant.sh early -DPBDX_FETCH_BEFORE_BARRIER=1)
+#              --arm "depth4:PBDX_LIB=$PWD/gpurun_variants/depth4/libpbdx.so"    (scripts/build_variant.sh depth4 -DPBDX_DEPTH_BIG=4)
 #              --arm "no dictionary:PBDX_NO_DICT=1"
 #   after -- one quoted string of bench.py options per workload ("" = the headline configs[1] sheet)
 #   --suite  run the GPU parity tests first (gpurun_out/ab_pytest.log)
