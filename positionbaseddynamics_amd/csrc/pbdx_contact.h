@@ -341,14 +341,12 @@ PBDX_HD void dyn_contact_velocity_solve(float invMass0, float mass0, V3 &v0, flo
 // `extra.after_sweep(v)`: what else changes this particle's velocity at the end of every iteration of velocityConstraintProjection
 // (TimeStepController.cpp:342-355: after the particle-rigid-body contacts come the particle-tet contacts, whose impulses are constants).
 struct NoExtraImpulses { PBDX_HD void after_sweep(V3 &) const {} };
+// initialisation with the pre-solve velocity and `iterations` velocity sweeps over the contacts of ONE particle that touch static bodies only (raw: in collider order)
 template <class Extra>
-PBDX_HD int particle_contacts(V3 x, V3 &v, float invMass, float mass, const pbdx_collider *colliders, uint32_t num_colliders,
-	float tolerance, float stiffness, float model_restitution, float model_friction, uint32_t iterations, const Extra &extra)
+PBDX_HD void solve_particle_contacts(V3 x, V3 &v, float invMass, float mass, const pbdx_collider *colliders, const RawContact *raw, int nc,
+	float stiffness, float model_restitution, float model_friction, uint32_t iterations, const Extra &extra)
 {
 	ContactInfo ci[PBDX_MAX_CONTACTS_PER_PARTICLE];
-	RawContact raw[PBDX_MAX_CONTACTS_PER_PARTICLE];
-	const int nc = detect_particle_contacts(x, colliders, num_colliders, tolerance, raw);
-	if (nc < 0) return -1;
 	for (int q = 0; q < nc; q++)
 	{
 		const pbdx_collider &c = colliders[raw[q].collider];
@@ -367,6 +365,15 @@ PBDX_HD int particle_contacts(V3 x, V3 &v, float invMass, float mass, const pbdx
 		}
 		extra.after_sweep(v);
 	}
+}
+template <class Extra>
+PBDX_HD int particle_contacts(V3 x, V3 &v, float invMass, float mass, const pbdx_collider *colliders, uint32_t num_colliders,
+	float tolerance, float stiffness, float model_restitution, float model_friction, uint32_t iterations, const Extra &extra)
+{
+	RawContact raw[PBDX_MAX_CONTACTS_PER_PARTICLE];
+	const int nc = detect_particle_contacts(x, colliders, num_colliders, tolerance, raw);
+	if (nc < 0) return -1;
+	solve_particle_contacts(x, v, invMass, mass, colliders, raw, nc, stiffness, model_restitution, model_friction, iterations, extra);
 	return nc;
 }
 PBDX_HD int particle_contacts(V3 x, V3 &v, float invMass, float mass, const pbdx_collider *colliders, uint32_t num_colliders,

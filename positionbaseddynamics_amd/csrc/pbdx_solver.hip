@@ -244,6 +244,14 @@ __global__ __launch_bounds__(256) void contact_kernel(ContactArgs a)
 			}
 			return;
 		}
+		// static bodies only: the independent chain, on the contacts just found
+		if (n > 0)
+		{
+			solve_particle_contacts(mk(p.x, p.y, p.z), v, p.w, vv.w, a.colliders, raw, n, a.stiffness, a.restitution, a.friction, a.iterations, NoExtraImpulses());
+			atomicAdd(&a.counters[0], (unsigned int)n);
+			a.vel[i] = make_float4(v.x, v.y, v.z, vv.w);
+		}
+		return;
 	}
 	const int nc = particle_contacts(mk(p.x, p.y, p.z), v, p.w, vv.w, a.colliders, a.num_colliders, a.tolerance, a.stiffness,
 		a.restitution, a.friction, a.iterations);
