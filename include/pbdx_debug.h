@@ -30,6 +30,8 @@ int pbdx_debug_tet_contacts(uint32_t n_particles, const float *pos4, const float
 /* Developer aid: the velocity part of ONE particle-tet contact on the host (the engine's arithmetic; friction 0).  in (26 floats): invMass0, v0[3],
  * invMass[4], v[4][3], bary[3], normal[3]; out (20 floats): tangent[3], pMax, impulse applied (1 / 0), corr_v0[3], corr_v[4][3]. */
 int pbdx_debug_tet_velocity_kat(const float *in, float *out);
+/* The contact of a particle with a rigid body of any mass on the host (csrc/pbdx_contact.h dyn_contact_*): in 38 floats, out 20 floats, see csrc/pbdx_tetcontact.cpp. */
+int pbdx_debug_dyn_contact_kat(const float *in, float *out);
 /* Developer aid: how many contacts of the last detection carried a non-zero velocity impulse (pMax < 0), and the total since the colliders were set. */
 int pbdx_debug_tet_impulses(pbdx_solver *s, uint32_t *last, uint64_t *total);
 

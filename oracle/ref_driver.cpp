@@ -21,6 +21,7 @@
 #include "Simulation/RigidBody.h"
 #include "GenericConstraints.h"          // Demos/GenericConstraintsDemos (mixed-model tests)
 #include "PositionBasedDynamics/PositionBasedDynamics.h"
+#include "PositionBasedDynamics/PositionBasedRigidBodyDynamics.h"
 #include "Utils/IndexedFaceMesh.h"
 #include "Utils/TetGenLoader.h"
 #include "Utils/Logger.h"
@@ -531,6 +532,35 @@ int refdrv_get_rigid_body_state(unsigned index, double *out)
 	out[13] = (double)rb->getMass();
 	return 0;
 }
+// The reference's own functions for ONE contact of a particle with a rigid body (any mass): init_ParticleRigidBodyContactConstraint, then `sweeps` times
+// velocitySolve_ParticleRigidBodyContactConstraint applied as ParticleRigidBodyContactConstraint::solveVelocityConstraint applies it (Constraints.cpp:2148-2189).
+// in / out: the layout of pbdx_debug_dyn_contact_kat (csrc/pbdx_tetcontact.cpp), as doubles.
+void refdrv_dyn_contact_kat(const double *in, double *out)
+{
+	const Real w0 = (Real)in[0], m0 = (Real)in[1], w1 = (Real)in[5];
+	Vector3r v0 = v3(in + 2), x1 = v3(in + 6), v1 = v3(in + 9), om = v3(in + 21);
+	Matrix3r Ji;
+	for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ji(r, c) = (Real)in[12 + 3 * r + c];
+	const Vector3r cp0 = v3(in + 24), cp1 = v3(in + 27), n = v3(in + 30);
+	const Vector3r x0 = cp0;
+	Eigen::Matrix<Real, 3, 5, Eigen::DontAlign> info;
+	PositionBasedRigidBodyDynamics::init_ParticleRigidBodyContactConstraint(w0, x0, v0, w1, x1, v1, Ji, Quaternionr(1, 0, 0, 0), om, cp0, cp1, n, (Real)in[33], info);
+	for (int k = 0; k < 3; k++) out[k] = (double)info(k, 3);
+	out[3] = (double)info(0, 4); out[4] = (double)info(1, 4); out[5] = (double)info(2, 4);
+	Real sum = 0.0;
+	for (int it = 0; it < (int)in[36]; it++)
+	{
+		Vector3r c0, c1, cw;
+		if (PositionBasedRigidBodyDynamics::velocitySolve_ParticleRigidBodyContactConstraint(w0, x0, v0, w1, x1, v1, Ji, om, (Real)in[34], (Real)in[35], sum, info, c0, c1, cw))
+		{
+			if (m0 != 0.0) v0 += c0;
+			if (w1 != 0.0) { v1 += c1; om += cw; }
+		}
+	}
+	for (int k = 0; k < 3; k++) { out[6 + k] = (double)v0[k]; out[9 + k] = (double)v1[k]; out[12 + k] = (double)om[k]; }
+	out[15] = (double)sum; out[16] = out[17] = out[18] = out[19] = 0.0;
+}
+
 // mass 0 = static (RigidBody::setMass also clears the inverse mass); with refdrv_add_dynamic_collider(..., testMesh = 0): a static collider whose own mesh is
 // not tested against other rigid bodies
 void refdrv_set_rigid_body_mass(unsigned index, double mass)

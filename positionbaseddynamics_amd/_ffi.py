@@ -150,6 +150,7 @@ SIGNATURES = [
     ("pbdx_debug_tet_solve_host", C.c_int, u32, pf, u32, pf, C.POINTER(u32)),
     ("pbdx_debug_tet_contacts", C.c_int, u32, pf, pf, pf, u32, C.POINTER(TetCollider), f32, u32, C.POINTER(u32), pf),
     ("pbdx_debug_tet_velocity_kat", C.c_int, pf, pf),
+    ("pbdx_debug_dyn_contact_kat", C.c_int, pf, pf),
     ("pbdx_debug_tet_impulses", C.c_int, vp, C.POINTER(u32), C.POINTER(C.c_uint64)),
     ("pbdx_model_plan_check", C.c_int, vp, u32, u32, u32, C.POINTER(PlanInfo)),
     ("pbdx_model_create", C.c_int, C.POINTER(vp)), ("pbdx_model_destroy", None, vp),

@@ -213,3 +213,28 @@ extern "C" int pbdx_debug_tet_solve_host(uint32_t n_particles, float *pos4, uint
 	}
 	return PBDX_OK;
 }
+
+// Known-answer form of the contact of a particle with a rigid body of ANY mass on the HOST (pbdx_contact.h: compute_matrix_k, dyn_contact_init,
+// dyn_contact_velocity_solve = init_ParticleRigidBodyContactConstraint + velocitySolve_ParticleRigidBodyContactConstraint +
+// ParticleRigidBodyContactConstraint::solveVelocityConstraint, PositionBasedRigidBodyDynamics.cpp:11-45,2385-2539, Constraints.cpp:2148-2189).
+// in (38 floats): invMass0, mass0, v0[3], invMass1, x1[3], v1[3], inertiaInverseW1[9] row-major, omega1[3], cp0[3], cp1[3], normal[3], restitution, stiffness,
+// friction, sweeps.  out (20 floats): tangent[3], 1 / (n^T K n), pMax, goal velocity, then after `sweeps` velocity solves: v0[3], v1[3], omega1[3], sum of impulses, 0
+extern "C" int pbdx_debug_dyn_contact_kat(const float *in, float *out)
+{
+	if (!in || !out) return PBDX_ERR_INVALID;
+	const float w0 = in[0], m0 = in[1], w1 = in[5];
+	V3 v0 = mk(in[2], in[3], in[4]);
+	const V3 x1 = mk(in[6], in[7], in[8]);
+	V3 v1 = mk(in[9], in[10], in[11]);
+	const float *Ji = in + 12;
+	V3 om = mk(in[21], in[22], in[23]);
+	const V3 cp0 = mk(in[24], in[25], in[26]), cp1 = mk(in[27], in[28], in[29]), n = mk(in[30], in[31], in[32]);
+	DynContactInfo ci;
+	dyn_contact_init(w0, v0, w1, x1, v1, Ji, om, cp0, cp1, n, in[33], ci);
+	out[0] = ci.tangent.x; out[1] = ci.tangent.y; out[2] = ci.tangent.z; out[3] = ci.nKn_inv; out[4] = ci.pMax; out[5] = ci.goal;
+	float sum = 0.0f;
+	for (int k = 0; k < (int)in[36]; k++) dyn_contact_velocity_solve(w0, m0, v0, w1, x1, v1, Ji, om, in[34], in[35], sum, ci);
+	out[6] = v0.x; out[7] = v0.y; out[8] = v0.z; out[9] = v1.x; out[10] = v1.y; out[11] = v1.z; out[12] = om.x; out[13] = om.y; out[14] = om.z; out[15] = sum;
+	out[16] = out[17] = out[18] = out[19] = 0.0f;
+	return PBDX_OK;
+}
